@@ -1,0 +1,150 @@
+"""Deterministic synthetic weights and object crops (no dataset, no checkpoint, no torch RNG).
+
+Every value is a pure function of (seed, tensor name, element index) through splitmix64, so the
+golden-vector generator (tests/golden/gen_golden.py, run where /root/reference exists), the
+parity tests and bench.py (run on the GPU box, where it does not) rebuild identical tensors.
+
+Shapes follow SURVEY.md 8(d): crops are box-frame point scatters (static_model.py:529-572
+hands forward() box-centred, box-aligned xyz), dynamic items carry the 0.1*(j-2) time channel
+(dynamic_model.py:432-437) and a 101-box window with 0.1*(j-50) in channel 7 (:441-447).
+"""
+import zlib
+
+import numpy as np
+
+from . import arch
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+SEED = 10922081            # the reference's own fixSeed value (static_eval.py:303)
+
+
+def _splitmix(z):
+    with np.errstate(over="ignore"):
+        z = (z + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _stream(seed, name, n, lane=0):
+    """n uint64 words for (seed, name, lane)."""
+    key = (np.uint64(seed) << np.uint64(32)) ^ np.uint64(zlib.crc32(name.encode())) \
+        ^ (np.uint64(lane) << np.uint64(56))
+    base = _splitmix(np.array([key], dtype=np.uint64))[0]
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + base
+    return _splitmix(idx)
+
+
+def uniform(seed, name, shape, lo=0.0, hi=1.0, lane=0):
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = (_stream(seed, name, n, lane) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    return (lo + (hi - lo) * u).reshape(shape)
+
+
+def normal(seed, name, shape, mean=0.0, std=1.0):
+    u1 = uniform(seed, name, shape, lane=1)
+    u2 = uniform(seed, name, shape, lane=2)
+    z = np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+    return mean + std * z
+
+
+# --------------------------------------------------------------------------- weights
+def state_dict(model, seed=SEED):
+    """Random-init state_dict (numpy) with the reference key set of
+    'static_one' | 'static_two' | 'dynamic'. Conv/Linear: He-uniform; BN running stats are
+    randomised so that folding is exercised (SURVEY.md 8(c) golden-vector recipe)."""
+    sd = {}
+    for key, shape in arch.model_param_specs(model):
+        leaf = key.rsplit(".", 1)[1]
+        mod = key.rsplit(".", 2)[-2]
+        is_bn = "bn" in mod
+        if leaf == "num_batches_tracked":
+            sd[key] = np.array(1000, dtype=np.int64)
+        elif is_bn and leaf == "weight":
+            sd[key] = uniform(seed, key, shape, 0.5, 1.5).astype(np.float32)
+        elif is_bn and leaf == "bias":
+            sd[key] = normal(seed, key, shape, 0.0, 0.2).astype(np.float32)
+        elif leaf == "running_mean":
+            sd[key] = normal(seed, key, shape, 0.0, 0.5).astype(np.float32)
+        elif leaf == "running_var":
+            sd[key] = uniform(seed, key, shape, 0.5, 2.0).astype(np.float32)
+        elif leaf == "weight":
+            fan_in = shape[1]
+            a = np.sqrt(6.0 / fan_in)
+            sd[key] = uniform(seed, key, shape, -a, a).astype(np.float32)
+        else:  # conv / linear bias
+            sd[key] = uniform(seed, key, shape, -0.1, 0.1).astype(np.float32)
+    return sd
+
+
+def recentre_seg_bias(sd, margin_mean):
+    """Shift ins_seg.dconv5.bias[1] so the mean of (logit1 - logit0) is zero and roughly half
+    the points are segmented as object (with raw random init every point lands in one class)."""
+    sd = dict(sd)
+    b = sd["ins_seg.dconv5.bias"].copy()
+    b[1] -= np.float32(margin_mean)
+    sd["ins_seg.dconv5.bias"] = b
+    return sd
+
+
+# --------------------------------------------------------------------------- inputs
+def static_crops(batch, n_pts, seed=SEED, first=0):
+    """pts (batch, n_pts, 3) fp32 point-major, init_box (batch, 7), bbox_gt (batch, 7).
+    Items are keyed on their global index `first + i`, so a shard of a larger job generates
+    exactly the rows the whole job would."""
+    pts = np.empty((batch, n_pts, 3), np.float32)
+    init = np.empty((batch, 7), np.float32)
+    gt = np.empty((batch, 7), np.float32)
+    for i in range(batch):
+        g = first + i
+        pts[i] = _crop_xyz(seed, f"s{g}", n_pts)
+        init[i], gt[i] = _boxes(seed, f"s{g}", g)
+    return pts, init, gt
+
+
+def dynamic_items(batch, n_per_frame=1024, seed=SEED, first=0, n_box=101):
+    """pts (batch, 5*n_per_frame, 4), box (batch, n_box, 8), init_box (batch, 8), bbox_gt (batch, 7)."""
+    n = arch.NUM_FRAME * n_per_frame
+    pts = np.empty((batch, n, 4), np.float32)
+    box = np.empty((batch, n_box, 8), np.float32)
+    init = np.empty((batch, 8), np.float32)
+    gt = np.empty((batch, 7), np.float32)
+    half = n_box // 2
+    for i in range(batch):
+        g = first + i
+        for f in range(arch.NUM_FRAME):
+            sl = slice(f * n_per_frame, (f + 1) * n_per_frame)
+            pts[i, sl, :3] = _crop_xyz(seed, f"d{g}f{f}", n_per_frame)
+            pts[i, sl, 3] = np.float32(0.1 * (f - 2))
+        ib, gtb = _boxes(seed, f"d{g}", g)
+        step = normal(seed, f"d{g}walk", (n_box, 3), 0.0, 0.05)
+        ctr = np.cumsum(step, axis=0)
+        ctr -= ctr[half]
+        yaw = np.cumsum(normal(seed, f"d{g}yaw", (n_box,), 0.0, 0.01))
+        yaw -= yaw[half]
+        box[i, :, 0:3] = ctr
+        box[i, :, 3:6] = ib[3:6]
+        box[i, :, 6] = yaw
+        box[i, :, 7] = 0.1 * (np.arange(n_box) - half)
+        init[i, :7] = ib                        # (x,y,z,l,w,h,yaw,t): yaw at [-2] (dynamic_eval.py:239)
+        init[i, 7] = 0.0                        # t of the centre box = 0.1*(50-50)
+        gt[i] = gtb
+    return pts, box, init, gt
+
+
+def _crop_xyz(seed, tag, n):
+    u = uniform(seed, tag + "sel", (n,))
+    obj = uniform(seed, tag + "obj", (n, 3), -1.0, 1.0) * np.array([2.4, 0.9, 0.75])
+    clut = uniform(seed, tag + "clu", (n, 3), -1.0, 1.0) * np.array([7.2, 2.7, 2.25])
+    return np.where((u < 0.4)[:, None], obj, clut).astype(np.float32)
+
+
+def _boxes(seed, tag, g):
+    c = normal(seed, tag + "c", (3,), 0.0, 0.3)
+    size = np.array(arch.MEAN_SIZE[g % 3]) + normal(seed, tag + "s", (3,), 0.0, 0.1)
+    yaw = uniform(seed, tag + "y", (1,), -np.pi, np.pi)
+    init = np.concatenate([c, size, yaw]).astype(np.float32)
+    gt = init + np.concatenate([normal(seed, tag + "g", (6,), 0.0, 0.1),
+                                normal(seed, tag + "gy", (1,), 0.0, 0.2)]).astype(np.float32)
+    return init, gt.astype(np.float32)

@@ -1,0 +1,48 @@
+"""Shared helpers for the parity tests: rebuild the deterministic inputs/weights the golden
+vectors were generated on (3dal_pytorch_amd/synth.py) and load the fixtures."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pkg = importlib.import_module("3dal_pytorch_amd")
+synth = importlib.import_module("3dal_pytorch_amd.synth")
+arch = importlib.import_module("3dal_pytorch_amd.arch")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def static_case(kind, batch, n_pts, g):
+    """-> (numpy state_dict re-centred as the fixture was, pts (B,3,N) view of point-major
+    storage, init_box, bbox_gt) as CPU torch tensors."""
+    pts_np, init_np, gt_np = synth.static_crops(batch, n_pts)
+    s = pts_np.astype(np.float64).sum() + init_np.astype(np.float64).sum()
+    assert abs(s - float(g["in_sum"])) < 1e-9, "synthetic input generator drifted from the fixtures"
+    sd = synth.recentre_seg_bias(synth.state_dict(kind), float(g["margin_mean"]))
+    pts = torch.from_numpy(pts_np).transpose(2, 1)
+    return sd, pts, torch.from_numpy(init_np), torch.from_numpy(gt_np)
+
+
+def dynamic_case(batch, g):
+    pts_np, box_np, init8_np, gt_np = synth.dynamic_items(batch)
+    s = pts_np.astype(np.float64).sum() + box_np.astype(np.float64).sum()
+    assert abs(s - float(g["in_sum"])) < 1e-9, "synthetic input generator drifted from the fixtures"
+    sd = synth.recentre_seg_bias(synth.state_dict("dynamic"), float(g["margin_mean"]))
+    return (sd, torch.from_numpy(pts_np).transpose(2, 1), torch.from_numpy(box_np).transpose(2, 1),
+            torch.from_numpy(init8_np), torch.from_numpy(gt_np))
+
+
+def rel_err(a, b):
+    """max |a-b| / max|b| : the '<= 1e-4 relative' measure of BASELINE.json's north_star."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))

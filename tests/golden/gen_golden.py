@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (jacky121298/3DAL_PyTorch).
+
+Run only where /root/reference exists (the build container):
+    python tests/golden/gen_golden.py
+
+The reference's tools/static_model.py, tools/dynamic_model.py, tools/static_eval.py and
+tools/dynamic_eval.py are imported (never copied) through the shim of SURVEY.md 8(c) — stubs
+for the un-vendored det3d / fpointnet_train imports, `np.float`, and a no-op Tensor.cuda()
+because forward() hard-codes .cuda() — and run on CPU on the deterministic inputs and weights
+of 3dal_pytorch_amd/synth.py. Only inputs' checksums and the reference's OUTPUTS are stored;
+the inputs are rebuilt from synth.py wherever the fixtures are used.
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+synth = importlib.import_module("3dal_pytorch_amd.synth")
+
+REF = os.environ.get("DAL3_REFERENCE", "/root/reference")
+
+
+def import_reference():
+    np.float = float
+    for name in ["det3d", "det3d.core", "det3d.core.bbox", "det3d.core.bbox.box_np_ops",
+                 "fpointnet_train", "fpointnet_train.provider_fpointnet"]:
+        mod = types.ModuleType(name)
+        mod.__path__ = []
+        sys.modules[name] = mod
+    sys.modules["det3d.core.bbox"].box_np_ops = sys.modules["det3d.core.bbox.box_np_ops"]
+    sys.modules["fpointnet_train"].provider_fpointnet = sys.modules["fpointnet_train.provider_fpointnet"]
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, os.path.join(REF, "tools"))
+    import static_model, dynamic_model, static_eval, dynamic_eval, utils  # noqa: E401
+    return static_model, dynamic_model, static_eval, dynamic_eval, utils
+
+
+def load(model, sd_np):
+    sd = {k: torch.as_tensor(v) for k, v in sd_np.items()}
+    missing = model.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model.eval()
+
+
+def centred_sd(kind, model, pts, weight_seed):
+    """Raw synth weights -> measure mean(logit1-logit0) with the reference -> re-centre."""
+    sd = synth.state_dict(kind, weight_seed)
+    load(model, sd)
+    with torch.no_grad():
+        lg = model.ins_seg(pts)
+    mm = float((lg[:, :, 1] - lg[:, :, 0]).mean())
+    sd = synth.recentre_seg_bias(sd, mm)
+    load(model, sd)
+    return sd, mm
+
+
+def tonp(d):
+    out = {}
+    for k, v in d.items():
+        out[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    return out
+
+
+def capture_global(model):
+    store = {}
+
+    def hook(_m, _i, o):
+        store["g"] = torch.relu(o).max(2)[0].detach().clone()
+    h = model.ins_seg.bn5.register_forward_hook(hook)
+    return store, h
+
+
+def main():
+    sm, dm, se, de, ut = import_reference()
+    torch.set_grad_enabled(False)
+    torch.manual_seed(0)
+    out_dir = HERE
+
+    # ------------------------------------------------------------------ static, one box est
+    for tag, B, N, rng_seed in (("static_one_b4_n1024", 4, 1024, 7), ("static_one_b1_n512", 1, 512, 11)):
+        pts_np, init_np, gt_np = synth.static_crops(B, N)
+        pts = torch.from_numpy(pts_np).transpose(2, 1)          # logical (B,3,N), physical (B,N,3)
+        init, gt = torch.from_numpy(init_np), torch.from_numpy(gt_np)
+        model = sm.StaticModelOneBoxEst(3, 3)
+        sd, mm = centred_sd("static_one", model, pts, synth.SEED)
+        store, h = capture_global(model)
+        np.random.seed(rng_seed)
+        out = model(pts, init, gt)
+        h.remove()
+        # replay the gather alone to record indices / object points (same seed => same draw)
+        np.random.seed(rng_seed)
+        obj, idx = sm.gather_object_pts(pts[:, :3, :], out["mask"], sm.NUM_OBJECT_POINT)
+        box_pred = model.box_est(obj.float())
+        # refined boxes through the reference's own eval loop
+        np.random.seed(rng_seed)
+        batch = (None, init[:, None, :].double(), gt.double(), torch.from_numpy(pts_np).double(),
+                 None, None, None, None, None, None, None)
+        boxes7 = se.test_one_epoch(model, [batch], None)
+        o = tonp(out)
+        margin = o["logits"][:, :, 1] - o["logits"][:, :, 0]
+        np.savez_compressed(
+            os.path.join(out_dir, tag + ".npz"), rng_seed=rng_seed, margin_mean=mm,
+            in_sum=np.float64(pts_np.astype(np.float64).sum() + init_np.astype(np.float64).sum()),
+            global_feat=store["g"].numpy(), indices=idx.numpy().astype(np.int32),
+            object_pts=obj.numpy(), box_pred=box_pred.numpy(), boxes7=boxes7,
+            min_abs_margin=np.abs(margin).min(), **o)
+        print(tag, "counts", o["mask"].sum(1), "min|margin|", np.abs(margin).min(),
+              "logit scale", np.abs(o["logits"]).mean())
+
+    # ------------------------------------------------------------------ static, two box est
+    tag, B, N, rng_seed = "static_two_b4_n1024", 4, 1024, 13
+    pts_np, init_np, gt_np = synth.static_crops(B, N)
+    pts = torch.from_numpy(pts_np).transpose(2, 1)
+    init, gt = torch.from_numpy(init_np), torch.from_numpy(gt_np)
+    model = sm.StaticModelTwoBoxEst(3, 3)
+    sd, mm = centred_sd("static_two", model, pts, synth.SEED)
+    np.random.seed(rng_seed)
+    out = model(pts, init, gt)
+    np.random.seed(rng_seed)
+    obj, idx = sm.gather_object_pts(pts[:, :3, :], out["mask"], sm.NUM_OBJECT_POINT)
+    np.random.seed(rng_seed)
+    batch = (None, init[:, None, :].double(), gt.double(), torch.from_numpy(pts_np).double(),
+             None, None, None, None, None, None, None)
+    boxes7 = se.test_one_epoch(model, [batch], None)
+    o = tonp(out)
+    np.savez_compressed(
+        os.path.join(out_dir, tag + ".npz"), rng_seed=rng_seed, margin_mean=mm,
+        in_sum=np.float64(pts_np.astype(np.float64).sum() + init_np.astype(np.float64).sum()),
+        indices=idx.numpy().astype(np.int32), boxes7=boxes7, **o)
+    print(tag, "counts", o["mask"].sum(1), "labels", o["heading_class_label_two"])
+
+    # ------------------------------------------------------------------ dynamic
+    tag, B, rng_seed = "dynamic_b2", 2, 17
+    pts_np, box_np, init8_np, gt_np = synth.dynamic_items(B)
+    pts = torch.from_numpy(pts_np).transpose(2, 1)              # (B,4,5120)
+    box = torch.from_numpy(box_np).transpose(2, 1)              # (B,8,101)
+    model = dm.DynamicModel(3, 4)
+    sd, mm = centred_sd("dynamic", model, pts, synth.SEED)
+    np.random.seed(rng_seed)
+    out = model(pts, box, torch.from_numpy(gt_np))
+    np.random.seed(rng_seed)
+    obj, idx = dm.gather_object_pts(pts[:, :4, :], out["mask"], dm.NUM_FRAME * dm.NUM_OBJECT_POINT)
+    point_e = model.point_emb(obj.float())
+    box_e = model.box_emb(box)
+    np.random.seed(rng_seed)
+    batch = (None, torch.from_numpy(init8_np).double(), torch.from_numpy(box_np).double(),
+             torch.from_numpy(gt_np).double(), torch.from_numpy(pts_np).double(),
+             None, None, None, None, None, None, None)
+    boxes7 = de.test_one_epoch(model, [batch])
+    o = tonp(out)
+    np.savez_compressed(
+        os.path.join(out_dir, tag + ".npz"), rng_seed=rng_seed, margin_mean=mm,
+        in_sum=np.float64(pts_np.astype(np.float64).sum() + box_np.astype(np.float64).sum()),
+        indices=idx.numpy().astype(np.int32), point_e=point_e.numpy(), box_e=box_e.numpy(),
+        boxes7=boxes7, **o)
+    print(tag, "counts", o["mask"].sum(1))
+
+    # ------------------------------------------------------------------ gather: RNG call order
+    N, M = 1024, 512
+    counts = [0, 1, 300, 511, 512, 700, N]
+    mask = np.zeros((len(counts), N), bool)
+    for i, c in enumerate(counts):
+        order = np.argsort(synth.uniform(3, f"gmask{i}", (N,)))
+        mask[i, order[:c]] = True
+    gp = torch.from_numpy(synth.static_crops(len(counts), N, seed=5)[0]).transpose(2, 1)
+    np.random.seed(12345)
+    obj, idx = sm.gather_object_pts(gp, torch.from_numpy(mask), M)
+    after = np.random.randint(0, 1 << 30)                      # pins how much of the stream was consumed
+    np.savez_compressed(os.path.join(out_dir, "gather_rng.npz"), counts=np.array(counts), mask=mask,
+                        indices=idx.numpy().astype(np.int32), object_pts=obj.numpy(), next_draw=after)
+
+    # ------------------------------------------------------------------ class/angle/size tables
+    angles = np.array([0.0, np.pi / 12, np.pi / 12 - 1e-9, np.pi / 12 + 1e-9, 1.0, np.pi, 2 * np.pi - 1e-6,
+                       -0.3, -np.pi, 5.5, 7.0, -7.0])
+    a2c = np.array([ut.angle2class(a, 12) for a in angles])
+    cls = np.arange(12)
+    res = np.linspace(-0.26, 0.26, 12)
+    c2a = np.array([[ut.class2angle(c, r, 12) for r in res] for c in cls])
+    sizes = np.array([[4.5, 1.9, 1.6], [9.0, 2.5, 3.0], [2.2, 0.9, 1.5], [6.5, 2.2, 2.3], [0.5, 0.5, 0.5]])
+    s2c = [ut.size2class(s) for s in sizes]
+    np.savez_compressed(os.path.join(out_dir, "class_tables.npz"), angles=angles, a2c=a2c, res=res, c2a=c2a,
+                        sizes=sizes, s2c_cls=np.array([c for c, _ in s2c]),
+                        s2c_res=np.array([r for _, r in s2c]),
+                        c2s=np.array([ut.class2size(c, np.array([0.1, -0.2, 0.3])) for c in range(3)]))
+
+    # ------------------------------------------------------------------ state_dict key pin
+    keys = {}
+    for kind, ctor in (("static_one", lambda: sm.StaticModelOneBoxEst(3, 3)),
+                       ("static_two", lambda: sm.StaticModelTwoBoxEst(3, 3)),
+                       ("dynamic", lambda: dm.DynamicModel(3, 4))):
+        m = ctor()
+        keys[kind + "_keys"] = np.array(list(m.state_dict().keys()))
+        keys[kind + "_shapes"] = np.array([str(tuple(v.shape)) for v in m.state_dict().values()])
+    np.savez_compressed(os.path.join(out_dir, "state_dict_keys.npz"), **keys)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
