@@ -1,0 +1,178 @@
+"""Host-side pieces shared by static_model.py and dynamic_model.py: the parameter containers
+(same attribute names as the reference so state_dicts load with strict=True), the packed-weight
+cache, the NumPy-stream sampler, and train-mode composites.
+
+Eval-mode math lives in lib3dal_hip.so; torch is used here for parameters, device buffers and
+the stream (plumbing). The train-mode `forward_train` methods run stock torch ops because
+training needs batch-statistics BN, live dropout and autograd (SURVEY.md 8(a) note T); they are
+never used when `self.training` is False.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _hip, arch
+
+
+def _conv_bn_stack(mod, specs, conv_cls):
+    for name, bn, ci, co in specs:
+        setattr(mod, name, conv_cls(ci, co))
+    for name, bn, ci, co in specs:
+        if bn:
+            setattr(mod, bn, nn.BatchNorm1d(co))
+
+
+def _conv1d(ci, co):
+    return nn.Conv1d(ci, co, 1)
+
+
+class PointNetInstanceSeg(nn.Module):
+    """Parameters of tools/static_model.py:241-269 / tools/dynamic_model.py:157-185."""
+
+    def __init__(self, n_classes=3, n_channel=3):
+        super().__init__()
+        self.n_channel = n_channel
+        layers = arch.ins_seg_layers(n_channel)
+        _conv_bn_stack(self, layers[:5], _conv1d)
+        for name, bn, ci, co in layers[5:9]:
+            setattr(self, name, _conv1d(ci, co))
+        self.dropout = nn.Dropout(p=0.5)
+        self.dconv5 = _conv1d(128, 2)
+        for name, bn, ci, co in layers[5:9]:
+            setattr(self, bn, nn.BatchNorm1d(co))
+
+    def pairs(self):
+        return [(getattr(self, n), getattr(self, b) if b else None)
+                for n, b, _, _ in arch.ins_seg_layers(self.n_channel)]
+
+    def forward(self, pts):   # train-mode composite (stock torch ops, autograd)
+        n = pts.size(2)
+        o1 = F.relu(self.bn1(self.conv1(pts)))
+        o2 = F.relu(self.bn2(self.conv2(o1)))
+        o3 = F.relu(self.bn3(self.conv3(o2)))
+        o4 = F.relu(self.bn4(self.conv4(o3)))
+        o5 = F.relu(self.bn5(self.conv5(o4)))
+        g = torch.max(o5, 2, keepdim=True)[0]
+        x = torch.cat([o2, g.expand(-1, -1, n)], 1)
+        x = F.relu(self.dbn1(self.dconv1(x)))
+        x = F.relu(self.dbn2(self.dconv2(x)))
+        x = F.relu(self.dbn3(self.dconv3(x)))
+        x = F.relu(self.dbn4(self.dconv4(x)))
+        x = self.dconv5(self.dropout(x))
+        return x.transpose(2, 1).contiguous()
+
+
+class _PointHead(nn.Module):
+    """conv1..4 + bn1..4 + fc* + fcbn* with the reference's registration order."""
+    TABLE = None
+    HEAD_KIND = None
+
+    def __init__(self, n_classes=3):
+        super().__init__()
+        _conv_bn_stack(self, self.TABLE["convs"], _conv1d)
+        _conv_bn_stack(self, self.TABLE["fcs"], nn.Linear)
+
+    def pairs(self):
+        return [(getattr(self, n), getattr(self, b) if b else None)
+                for n, b, _, _ in self.TABLE["convs"] + self.TABLE["fcs"]]
+
+    def forward(self, x):     # train-mode composite
+        for name, bn, _, _ in self.TABLE["convs"]:
+            x = F.relu(getattr(self, bn)(getattr(self, name)(x)))
+        if self.TABLE["convs"]:
+            x = torch.max(x, 2)[0]
+        for name, bn, _, _ in self.TABLE["fcs"]:
+            x = getattr(self, name)(x)
+            if bn:
+                x = F.relu(getattr(self, bn)(x))
+        return x
+
+
+class StaticPointNetEstimation(_PointHead):
+    """tools/static_model.py:298-318."""
+    TABLE = arch.STATIC_BOX_EST
+    HEAD_KIND = _hip.HEAD_STATIC_BOX_EST
+
+
+class PointEmbedding(_PointHead):
+    """tools/dynamic_model.py:214-232."""
+    TABLE = arch.POINT_EMB
+    HEAD_KIND = _hip.HEAD_POINT_EMB
+
+
+class BoxEmbedding(_PointHead):
+    """tools/dynamic_model.py:251-269."""
+    TABLE = arch.BOX_EMB
+    HEAD_KIND = _hip.HEAD_BOX_EMB
+
+
+class DynamicPointNetEstimation(_PointHead):
+    """tools/dynamic_model.py:288-298."""
+    TABLE = arch.DYNAMIC_BOX_EST
+    HEAD_KIND = _hip.HEAD_DYNAMIC_BOX_EST
+
+
+class PackedCache:
+    """Folded + fragment-ordered device weights are a derived cache of the nn.Parameters: rebuilt
+    when any tensor's version counter, storage or device changes (load_state_dict, .cuda(),
+    optimizer steps)."""
+
+    def __init__(self):
+        self._stamp = {}
+        self._blob = {}
+
+    @staticmethod
+    def _stamp_of(module):
+        s = 0
+        for t in list(module.parameters()) + list(module.buffers()):
+            s = (s * 1000003 + t._version * 31 + t.data_ptr()) & 0xFFFFFFFFFFFF
+        return s
+
+    def get(self, key, module, head_kind):
+        stamp = self._stamp_of(module)
+        if self._stamp.get(key) != stamp:
+            dev = next(module.parameters()).device
+            self._blob[key] = _hip.pack(head_kind, module.pairs(), dev)
+            self._stamp[key] = stamp
+        return self._blob[key]
+
+
+def numpy_choice(counts, m):
+    """The reference's per-sample draws (gather_object_pts, static_model.py:36-47) on the global
+    legacy NumPy stream, in order; rows with count 0 consume nothing. Returns (B,m) int32 positions
+    into each sample's ordered list of segmented points."""
+    out = np.zeros((len(counts), m), np.int32)
+    for i, k in enumerate(counts):
+        k = int(k)
+        if k == 0:
+            continue
+        if k >= m:
+            choice = np.random.choice(k, m, replace=False)
+        else:
+            choice = np.concatenate((np.arange(k), np.random.choice(k, m - k, replace=True)))
+        np.random.shuffle(choice)
+        out[i] = choice
+    return out
+
+
+class Workspace:
+    """One growing device buffer per module, handed to the library as the caller-owned workspace."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+def as_f32(t, what):
+    _hip.require_gpu(t, what)
+    return t if t.dtype == torch.float32 else t.float()
+
+
+def rows_contiguous(t):
+    """(B,K) fp32 with contiguous rows (the library takes these as plain (B,K) arrays)."""
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,153 @@
+"""ctypes binding of lib3dal_hip.so (include/dal3.h). No torch math here: tensors are only a way
+to own device memory (data_ptr) and to find the current HIP stream.
+
+The library is REQUIRED: every eval-mode forward of the model classes goes through it, and
+loading raises if it has not been built (python -c "import __graft_entry__ as g; g.build()" or
+`make -C 3dal_pytorch_amd/csrc`). There is no CPU / eager fallback.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib3dal_hip.so")
+
+OK, EINVAL, EWORKSPACE, EHIP = 0, -1, -2, -3
+F32 = 0
+HEAD_INS_SEG, HEAD_STATIC_BOX_EST, HEAD_POINT_EMB, HEAD_BOX_EMB, HEAD_DYNAMIC_BOX_EST = range(5)
+SAMPLER_DEVICE, SAMPLER_CHOICE = 0, 1
+PHASE_SEG, PHASE_BOX, PHASE_ALL = 1, 2, 3
+
+vp = C.c_void_p
+
+
+class Layer(C.Structure):
+    _fields_ = [("weight", vp), ("bias", vp), ("bn_weight", vp), ("bn_bias", vp), ("bn_mean", vp),
+                ("bn_var", vp), ("c_in", C.c_int32), ("c_out", C.c_int32)]
+
+
+class BCN(C.Structure):
+    _fields_ = [("data", vp), ("stride_b", C.c_int64), ("stride_c", C.c_int64), ("stride_n", C.c_int64)]
+
+
+class StaticArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("two_stage", C.c_int32), ("sampler", C.c_int32),
+                ("seed", C.c_uint64), ("item_offset", C.c_int64), ("pts", BCN),
+                ("init_box", vp), ("bbox_gt", vp), ("choice", vp),
+                ("w_ins_seg", vp), ("w_box_est_one", vp), ("w_box_est_two", vp),
+                ("logits", vp), ("mask", vp),
+                ("box_pred_one", vp), ("heading_residuals_one", vp), ("size_residuals_one", vp),
+                ("center_one", vp), ("box_one", vp),
+                ("box_pred_two", vp), ("heading_residuals_two", vp), ("size_residuals_two", vp),
+                ("center_two", vp), ("heading_class_label_two", vp), ("heading_residuals_label_two", vp),
+                ("boxes7", vp), ("counts", vp), ("obj_idx", vp),
+                ("workspace", vp), ("workspace_bytes", C.c_size_t)]
+
+
+class DynamicArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n_box", C.c_int32), ("sampler", C.c_int32),
+                ("seed", C.c_uint64), ("item_offset", C.c_int64), ("pts", BCN), ("box", BCN),
+                ("init_box8", vp), ("choice", vp),
+                ("w_ins_seg", vp), ("w_point_emb", vp), ("w_box_emb", vp), ("w_box_est", vp),
+                ("logits", vp), ("mask", vp), ("embedding", vp), ("box_pred", vp),
+                ("heading_residuals", vp), ("size_residuals", vp), ("boxes7", vp),
+                ("counts", vp), ("obj_idx", vp),
+                ("workspace", vp), ("workspace_bytes", C.c_size_t)]
+
+
+# every symbol include/dal3.h declares: (restype, argtypes)
+_i, _i64, _u64, _sz = C.c_int, C.c_int64, C.c_uint64, C.c_size_t
+SIGNATURES = {
+    "dal3_version": (_i, []),
+    "dal3_last_error": (C.c_char_p, []),
+    "dal3_pack_weights": (_i, [_i, C.POINTER(Layer), _i, _i, vp, C.POINTER(_sz), vp]),
+    "dal3_ins_seg_workspace_bytes": (_sz, [_i]),
+    "dal3_ins_seg_forward": (_i, [vp, _i, BCN, _i, _i, vp, vp, vp, vp, _sz, vp]),
+    "dal3_gather_workspace_bytes": (_sz, [_i, _i]),
+    "dal3_segment_counts": (_i, [vp, _i, _i, vp, vp]),
+    "dal3_mask_compact_sample": (_i, [vp, BCN, _i, _i, _i, _i, _i, vp, _u64, _i64, vp, vp, vp, vp, _sz, vp]),
+    "dal3_point_head_workspace_bytes": (_sz, [_i]),
+    "dal3_point_head_forward": (_i, [_i, vp, BCN, _i, _i, vp, _i64, vp, _sz, vp]),
+    "dal3_dynamic_box_est_forward": (_i, [vp, vp, _i, vp, vp, _sz, vp]),
+    "dal3_decode_boxes": (_i, [vp, _i, vp, _i64, _i, vp, _i64, vp, _i64, vp, vp, vp, vp, vp]),
+    "dal3_recenter_rotz": (_i, [vp, _i, _i, vp, vp, vp, vp, vp, vp, vp]),
+    "dal3_maxpool_n": (_i, [vp, _i64, _i64, vp, vp]),
+    "dal3_shared_mlp_layer": (_i, [C.POINTER(Layer), _i, BCN, _i, _i, vp, vp, _sz, vp]),
+    "dal3_shared_mlp_layer_workspace_bytes": (_sz, [_i, _i]),
+    "dal3_static_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dal3_static_forward": (_i, [C.POINTER(StaticArgs), _i, vp]),
+    "dal3_dynamic_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dal3_dynamic_forward": (_i, [C.POINTER(DynamicArgs), _i, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (loudly) if it was never built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP library first "
+                "(`make -C 3dal_pytorch_amd/csrc` or __graft_entry__.build()). "
+                "There is no CPU/eager fallback for the eval-mode forward.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise RuntimeError(f"lib3dal_hip error {rc}: {lib().dal3_last_error().decode()}")
+
+
+def stream():
+    return vp(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return vp(t.data_ptr()) if t is not None else vp(None)
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} lives on {t.device}: the eval-mode forward runs only on an MI355X through "
+            "lib3dal_hip.so (no CPU fallback). Move the model and its inputs to the GPU.")
+
+
+def bcn(t):
+    """logical (B,C,N) fp32 tensor with arbitrary element strides -> dal3_bcn (no copy)."""
+    assert t.dim() == 3 and t.dtype == torch.float32
+    sb, sc, sn = t.stride()
+    return BCN(ptr(t), sb, sc, sn)
+
+
+def layer_struct(conv, bn):
+    """nn.Conv1d(k=1)/nn.Linear (+ optional nn.BatchNorm1d) -> dal3_layer of raw device pointers."""
+    w = conv.weight
+    c_out, c_in = w.shape[0], w.shape[1]
+    if not w.is_contiguous() or w.dtype != torch.float32:
+        raise RuntimeError("weights must be contiguous fp32")
+    L = Layer(ptr(w), ptr(conv.bias), None, None, None, None, c_in, c_out)
+    if bn is not None:
+        L.bn_weight, L.bn_bias = ptr(bn.weight), ptr(bn.bias)
+        L.bn_mean, L.bn_var = ptr(bn.running_mean), ptr(bn.running_var)
+    return L
+
+
+def pack(head_kind, pairs, device):
+    """pairs: [(conv_or_linear, bn_or_None), ...] in forward order -> packed uint8 device tensor."""
+    arr = (Layer * len(pairs))(*[layer_struct(c, b) for c, b in pairs])
+    need = _sz(0)
+    check(lib().dal3_pack_weights(head_kind, arr, len(pairs), F32, None, C.byref(need), None))
+    buf = torch.empty(need.value, dtype=torch.uint8, device=device)
+    assert buf.data_ptr() % 256 == 0
+    check(lib().dal3_pack_weights(head_kind, arr, len(pairs), F32, ptr(buf), C.byref(need), stream()))
+    return buf

@@ -1,0 +1,575 @@
+// dal3_api.hip — the C ABI of include/dal3.h: packed-weight layout, argument checks, sequencing of
+// the kernels on the caller's stream. Host code only; no allocation, no synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "dal3_kernels.h"
+
+// ---------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(DAL3_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define TRY(expr)               \
+    do {                        \
+        int r_ = (expr);        \
+        if (r_ != 0) return r_; \
+    } while (0)
+
+extern "C" int dal3_version(void) { return DAL3_VERSION; }
+extern "C" const char* dal3_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------- layout
+static inline size_t al(size_t floats) { return (floats + 63) & ~(size_t)63; }   // 256-byte sections
+
+struct Cursor {
+    const float* base;
+    size_t off;
+    const float* take(size_t floats) {
+        const float* p = base ? base + off : nullptr;
+        off += al(floats);
+        return p;
+    }
+    const f32x4* take4(size_t floats) { return reinterpret_cast<const f32x4*>(take(floats)); }
+};
+
+static InsSegW ins_seg_walk(Cursor& c) {
+    InsSegW w;
+    w.w1 = c.take(2 * 2 * 64);        w.b1 = c.take(64);
+    w.w2 = c.take4(2 * 2 * 1024);     w.b2 = c.take(64);
+    w.w3 = c.take4(2 * 2 * 1024);     w.b3 = c.take(64);
+    w.w4 = c.take4(4 * 2 * 1024);     w.b4 = c.take(128);
+    w.w5 = c.take4(32 * 4 * 1024);    w.b5 = c.take(1024);
+    w.dw1a = c.take4(16 * 2 * 1024);  w.dw1g = c.take(512 * 1024);   w.db1 = c.take(512);
+    w.dw2 = c.take4(16 * 8 * 1024);   w.db2 = c.take(256);
+    w.dw3 = c.take4(4 * 8 * 1024);    w.db3 = c.take(128);
+    w.dw4 = c.take4(4 * 4 * 1024);    w.db4 = c.take(128);
+    w.dw5 = c.take(2 * 128);          w.db5 = c.take(32);
+    return w;
+}
+
+size_t ins_seg_packed_floats(int) {
+    Cursor c{nullptr, 0};
+    ins_seg_walk(c);
+    return c.off;
+}
+InsSegW ins_seg_view(const float* base, int) {
+    Cursor c{base, 0};
+    return ins_seg_walk(c);
+}
+
+void point_head_dims(int head_kind, int* c_in, int* ks, int c[4], int* n_fc, int fc_in[3], int fc_out[3]) {
+    switch (head_kind) {
+        case DAL3_HEAD_STATIC_BOX_EST:
+            *c_in = 3; *ks = 2; c[0] = 128; c[1] = 128; c[2] = 256; c[3] = 512; *n_fc = 3;
+            fc_in[0] = 512; fc_out[0] = 512; fc_in[1] = 512; fc_out[1] = 256; fc_in[2] = 256; fc_out[2] = 39;
+            break;
+        case DAL3_HEAD_POINT_EMB:
+            *c_in = 4; *ks = 2; c[0] = 64; c[1] = 128; c[2] = 256; c[3] = 512; *n_fc = 2;
+            fc_in[0] = 512; fc_out[0] = 512; fc_in[1] = 512; fc_out[1] = 256; fc_in[2] = 0; fc_out[2] = 0;
+            break;
+        default:  // DAL3_HEAD_BOX_EMB
+            *c_in = 8; *ks = 4; c[0] = 64; c[1] = 64; c[2] = 128; c[3] = 512; *n_fc = 2;
+            fc_in[0] = 512; fc_out[0] = 128; fc_in[1] = 128; fc_out[1] = 128; fc_in[2] = 0; fc_out[2] = 0;
+            break;
+    }
+}
+
+static PointHeadW point_head_walk(Cursor& cur, int head_kind) {
+    int c_in, ks, c[4], n_fc, fi[3], fo[3];
+    point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
+    PointHeadW w;
+    w.w1 = cur.take((size_t)(c[0] / 32) * ks * 64);                   w.b1 = cur.take(c[0]);
+    w.w2 = cur.take4((size_t)(c[1] / 32) * (c[0] / 32) * 1024);       w.b2 = cur.take(c[1]);
+    w.w3 = cur.take4((size_t)(c[2] / 32) * (c[1] / 32) * 1024);       w.b3 = cur.take(c[2]);
+    w.w4 = cur.take4((size_t)(c[3] / 32) * (c[2] / 32) * 1024);       w.b4 = cur.take(c[3]);
+    w.fc.n = n_fc;
+    for (int i = 0; i < 3; ++i) {
+        w.fc.c_in[i] = fi[i];
+        w.fc.c_out[i] = fo[i];
+        w.fc.relu[i] = !(head_kind == DAL3_HEAD_STATIC_BOX_EST && i == 2);
+        w.fc.w[i] = i < n_fc ? cur.take((size_t)fi[i] * fo[i]) : nullptr;
+        w.fc.b[i] = i < n_fc ? cur.take((fo[i] + 31) / 32 * 32) : nullptr;
+    }
+    return w;
+}
+size_t point_head_packed_floats(int head_kind) {
+    Cursor c{nullptr, 0};
+    point_head_walk(c, head_kind);
+    return c.off;
+}
+PointHeadW point_head_view(const float* base, int head_kind) {
+    Cursor c{base, 0};
+    return point_head_walk(c, head_kind);
+}
+
+static const int kDynFcIn[3] = {384, 128, 128}, kDynFcOut[3] = {128, 128, 39};
+static FcW fc_head_walk(Cursor& cur) {
+    FcW f;
+    f.n = 3;
+    for (int i = 0; i < 3; ++i) {
+        f.c_in[i] = kDynFcIn[i];
+        f.c_out[i] = kDynFcOut[i];
+        f.relu[i] = i < 2;
+        f.w[i] = cur.take((size_t)kDynFcIn[i] * kDynFcOut[i]);
+        f.b[i] = cur.take((kDynFcOut[i] + 31) / 32 * 32);
+    }
+    return f;
+}
+size_t fc_head_packed_floats() {
+    Cursor c{nullptr, 0};
+    fc_head_walk(c);
+    return c.off;
+}
+FcW fc_head_view(const float* base) {
+    Cursor c{base, 0};
+    return fc_head_walk(c);
+}
+
+// ---------------------------------------------------------------------------------- packing
+static float* mut(const void* p) { return const_cast<float*>(reinterpret_cast<const float*>(p)); }
+
+static int check_layer(const dal3_layer& L, int c_in, int c_out, const char* what) {
+    if (!L.weight || !L.bias) return fail(DAL3_EINVAL, "%s: null weight/bias", what);
+    if (L.c_in != c_in || L.c_out != c_out)
+        return fail(DAL3_EINVAL, "%s: expected (%d -> %d), got (%d -> %d)", what, c_in, c_out, L.c_in, L.c_out);
+    const bool any = L.bn_weight || L.bn_bias || L.bn_mean || L.bn_var;
+    const bool all = L.bn_weight && L.bn_bias && L.bn_mean && L.bn_var;
+    if (any && !all) return fail(DAL3_EINVAL, "%s: BN pointers must be all set or all NULL", what);
+    return 0;
+}
+
+static int pack_frag(const dal3_layer& L, int mode, int col_off, int n_cols, const f32x4* w, const float* b,
+                     hipStream_t s) {
+    HIP_TRY(launch_pack_weight(L, mode, col_off, n_cols, L.c_out / 32, n_cols / 32, mut(w), s));
+    if (b) HIP_TRY(launch_pack_bias(L, mut(b), s));
+    return 0;
+}
+
+static int pack_fc(const dal3_layer* L, const FcW& f, hipStream_t s) {
+    for (int i = 0; i < f.n; ++i) {
+        TRY(check_layer(L[i], f.c_in[i], f.c_out[i], "fc layer"));
+        HIP_TRY(launch_pack_weight(L[i], PACK_ROWMAJOR, 0, f.c_in[i], 0, 0, mut(f.w[i]), s));
+        HIP_TRY(launch_pack_bias(L[i], mut(f.b[i]), s));
+    }
+    return 0;
+}
+
+extern "C" int dal3_pack_weights(int head_kind, const dal3_layer* L, int n_layers, int dtype, void* packed_dev,
+                                 size_t* bytes_inout, dal3_stream stream) {
+    if (dtype != DAL3_F32) return fail(DAL3_EINVAL, "dal3_pack_weights: only DAL3_F32 is built in this version");
+    if (!bytes_inout) return fail(DAL3_EINVAL, "dal3_pack_weights: bytes_inout is NULL");
+    size_t need;
+    switch (head_kind) {
+        case DAL3_HEAD_INS_SEG: need = ins_seg_packed_floats(0); break;
+        case DAL3_HEAD_STATIC_BOX_EST:
+        case DAL3_HEAD_POINT_EMB:
+        case DAL3_HEAD_BOX_EMB: need = point_head_packed_floats(head_kind); break;
+        case DAL3_HEAD_DYNAMIC_BOX_EST: need = fc_head_packed_floats(); break;
+        default: return fail(DAL3_EINVAL, "dal3_pack_weights: unknown head_kind %d", head_kind);
+    }
+    need *= sizeof(float);
+    if (!packed_dev) {
+        *bytes_inout = need;
+        return 0;
+    }
+    if (*bytes_inout < need) return fail(DAL3_EWORKSPACE, "dal3_pack_weights: need %zu bytes, got %zu", need, *bytes_inout);
+    if (!L) return fail(DAL3_EINVAL, "dal3_pack_weights: layers is NULL");
+    if (reinterpret_cast<uintptr_t>(packed_dev) & 255) return fail(DAL3_EINVAL, "packed_dev must be 256-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float* base = static_cast<const float*>(packed_dev);
+    HIP_TRY(hipMemsetAsync(packed_dev, 0, need, s));
+
+    if (head_kind == DAL3_HEAD_INS_SEG) {
+        if (n_layers != 10) return fail(DAL3_EINVAL, "ins_seg expects 10 layers, got %d", n_layers);
+        const int c_in = L[0].c_in;
+        if (c_in != 3 && c_in != 4) return fail(DAL3_EINVAL, "ins_seg c_in must be 3 or 4, got %d", c_in);
+        static const int co[10] = {64, 64, 64, 128, 1024, 512, 256, 128, 128, 2};
+        static const int ci[10] = {0, 64, 64, 64, 128, 1088, 512, 256, 128, 128};
+        for (int i = 0; i < 10; ++i) TRY(check_layer(L[i], i == 0 ? c_in : ci[i], co[i], "ins_seg layer"));
+        InsSegW w = ins_seg_view(base, c_in);
+        HIP_TRY(launch_pack_weight(L[0], PACK_FIRST, 0, c_in, 2, 2, mut(w.w1), s));
+        HIP_TRY(launch_pack_bias(L[0], mut(w.b1), s));
+        TRY(pack_frag(L[1], PACK_FRAG_MT_MAJOR, 0, 64, w.w2, w.b2, s));
+        TRY(pack_frag(L[2], PACK_FRAG_MT_MAJOR, 0, 64, w.w3, w.b3, s));
+        TRY(pack_frag(L[3], PACK_FRAG_MT_MAJOR, 0, 64, w.w4, w.b4, s));
+        TRY(pack_frag(L[4], PACK_FRAG_MT_MAJOR, 0, 128, w.w5, w.b5, s));
+        TRY(pack_frag(L[5], PACK_FRAG_MT_MAJOR, 0, 64, w.dw1a, w.db1, s));                 // columns of out2
+        HIP_TRY(launch_pack_weight(L[5], PACK_ROWMAJOR, 64, 1024, 0, 0, mut(w.dw1g), s));   // columns of g
+        TRY(pack_frag(L[6], PACK_FRAG_KT_MAJOR, 0, 512, w.dw2, w.db2, s));
+        TRY(pack_frag(L[7], PACK_FRAG_MT_MAJOR, 0, 256, w.dw3, w.db3, s));
+        TRY(pack_frag(L[8], PACK_FRAG_MT_MAJOR, 0, 128, w.dw4, w.db4, s));
+        HIP_TRY(launch_pack_weight(L[9], PACK_ROWMAJOR, 0, 128, 0, 0, mut(w.dw5), s));
+        HIP_TRY(launch_pack_bias(L[9], mut(w.db5), s));
+        return 0;
+    }
+    if (head_kind == DAL3_HEAD_DYNAMIC_BOX_EST) {
+        if (n_layers != 3) return fail(DAL3_EINVAL, "dynamic box_est expects 3 layers, got %d", n_layers);
+        return pack_fc(L, fc_head_view(base), s);
+    }
+    int c_in, ks, c[4], n_fc, fi[3], fo[3];
+    point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
+    if (n_layers != 4 + n_fc) return fail(DAL3_EINVAL, "head %d expects %d layers, got %d", head_kind, 4 + n_fc, n_layers);
+    TRY(check_layer(L[0], c_in, c[0], "conv1"));
+    for (int i = 1; i < 4; ++i) TRY(check_layer(L[i], c[i - 1], c[i], "conv"));
+    PointHeadW w = point_head_view(base, head_kind);
+    HIP_TRY(launch_pack_weight(L[0], PACK_FIRST, 0, c_in, c[0] / 32, ks, mut(w.w1), s));
+    HIP_TRY(launch_pack_bias(L[0], mut(w.b1), s));
+    TRY(pack_frag(L[1], PACK_FRAG_MT_MAJOR, 0, c[0], w.w2, w.b2, s));
+    TRY(pack_frag(L[2], PACK_FRAG_MT_MAJOR, 0, c[1], w.w3, w.b3, s));
+    TRY(pack_frag(L[3], PACK_FRAG_MT_MAJOR, 0, c[2], w.w4, w.b4, s));
+    return pack_fc(L + 4, w.fc, s);
+}
+
+// ---------------------------------------------------------------------------------- workspace carving
+struct Carver {
+    char* base;
+    size_t size, off;
+    bool ok;
+    Carver(void* p, size_t n) : base(static_cast<char*>(p)), size(n), off(0), ok(true) {}
+    template <typename T>
+    T* take(size_t count) {
+        const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        char* p = base ? base + off : nullptr;
+        off += bytes;
+        if (base && off > size) ok = false;
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+static BCN to_bcn(const dal3_bcn& t) { return BCN{t.data, t.stride_b, t.stride_c, t.stride_n}; }
+
+static int check_bcn(const dal3_bcn& t, const char* what) {
+    if (!t.data) return fail(DAL3_EINVAL, "%s: null data pointer", what);
+    if (t.stride_n <= 0 || t.stride_c <= 0) return fail(DAL3_EINVAL, "%s: strides must be positive", what);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- ins_seg
+struct InsSegWs { float* g; float* gb; };
+static InsSegWs carve_ins_seg(Carver& c, int B) {
+    InsSegWs w;
+    w.g = c.take<float>((size_t)B * 1024);
+    w.gb = c.take<float>((size_t)B * 512);
+    return w;
+}
+extern "C" size_t dal3_ins_seg_workspace_bytes(int B) {
+    Carver c(nullptr, 0);
+    carve_ins_seg(c, B);
+    return c.off;
+}
+
+static int ins_seg_run(const void* packed, int c_in, const dal3_bcn& pts, int B, int N, float* logits, uint8_t* mask,
+                       float* global_feat_out, const InsSegWs& ws, hipStream_t s) {
+    if (!packed || !logits || !mask) return fail(DAL3_EINVAL, "ins_seg: null pointer");
+    if (B <= 0 || N <= 0) return fail(DAL3_EINVAL, "ins_seg: B and N must be positive (B=%d N=%d)", B, N);
+    if (c_in != 3 && c_in != 4) return fail(DAL3_EINVAL, "ins_seg: c_in must be 3 or 4");
+    TRY(check_bcn(pts, "pts"));
+    const InsSegW w = ins_seg_view(static_cast<const float*>(packed), c_in);
+    const BCN x = to_bcn(pts);
+    HIP_TRY(hipMemsetAsync(ws.g, 0, (size_t)B * 1024 * sizeof(float), s));
+    HIP_TRY(launch_ins_seg_encode(w, x, c_in, B, N, ws.g, s));
+    // per-crop part of dconv1: gb = W1g' . g + b1'   (static_model.py:286-289 without the repeat+cat)
+    HIP_TRY(launch_fc(w.dw1g, w.db1, ws.g, 1024, ws.gb, 512, B, 1024, 512, 0, s));
+    HIP_TRY(launch_ins_seg_decode(w, x, c_in, B, N, ws.gb, logits, mask, s));
+    if (global_feat_out)
+        HIP_TRY(hipMemcpyAsync(global_feat_out, ws.g, (size_t)B * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+extern "C" int dal3_ins_seg_forward(const void* packed, int c_in, dal3_bcn pts, int B, int N, float* logits,
+                                    uint8_t* mask, float* global_feat_out, void* workspace, size_t workspace_bytes,
+                                    dal3_stream stream) {
+    if (!workspace) return fail(DAL3_EINVAL, "ins_seg: workspace is NULL");
+    Carver c(workspace, workspace_bytes);
+    const InsSegWs ws = carve_ins_seg(c, B);
+    if (!c.ok) return fail(DAL3_EWORKSPACE, "ins_seg: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
+    return ins_seg_run(packed, c_in, pts, B, N, logits, mask, global_feat_out, ws, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------- gather
+extern "C" size_t dal3_gather_workspace_bytes(int B, int N) {
+    Carver c(nullptr, 0);
+    c.take<int32_t>((size_t)B * N);
+    return c.off;
+}
+
+extern "C" int dal3_segment_counts(const uint8_t* mask, int B, int N, int32_t* counts, dal3_stream stream) {
+    if (!mask || !counts || B <= 0 || N <= 0) return fail(DAL3_EINVAL, "segment_counts: bad argument");
+    HIP_TRY(launch_segment_counts(mask, B, N, counts, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+static int gather_run(const uint8_t* mask, const dal3_bcn& pts, int B, int N, int C, int M, int sampler,
+                      const int32_t* choice, uint64_t seed, int64_t item_offset, int32_t* counts, int32_t* obj_idx,
+                      float* obj_pts, int32_t* pos, hipStream_t s) {
+    if (!mask || !counts || !obj_idx || !obj_pts) return fail(DAL3_EINVAL, "gather: null pointer");
+    if (B <= 0 || N <= 0 || M <= 0 || C <= 0 || C > 8) return fail(DAL3_EINVAL, "gather: bad shape");
+    if (sampler == DAL3_SAMPLER_CHOICE && !choice) return fail(DAL3_EINVAL, "gather: DAL3_SAMPLER_CHOICE needs choice");
+    if (sampler != DAL3_SAMPLER_CHOICE && sampler != DAL3_SAMPLER_DEVICE) return fail(DAL3_EINVAL, "gather: bad sampler");
+    TRY(check_bcn(pts, "pts"));
+    HIP_TRY(launch_compact_sample(mask, to_bcn(pts), B, N, C, M, sampler, choice, seed, item_offset, counts, pos,
+                                  obj_idx, obj_pts, s));
+    return 0;
+}
+
+extern "C" int dal3_mask_compact_sample(const uint8_t* mask, dal3_bcn pts, int B, int N, int C, int M, int sampler,
+                                        const int32_t* choice, uint64_t seed, int64_t item_offset, int32_t* counts,
+                                        int32_t* obj_idx, float* obj_pts, void* workspace, size_t workspace_bytes,
+                                        dal3_stream stream) {
+    if (!workspace) return fail(DAL3_EINVAL, "gather: workspace is NULL");
+    Carver c(workspace, workspace_bytes);
+    int32_t* pos = c.take<int32_t>((size_t)B * N);
+    if (!c.ok) return fail(DAL3_EWORKSPACE, "gather: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
+    return gather_run(mask, pts, B, N, C, M, sampler, choice, seed, item_offset, counts, obj_idx, obj_pts, pos,
+                      static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------- point heads
+struct HeadWs { float* feat; float* t1; float* t2; };
+static HeadWs carve_head(Carver& c, int B) {
+    HeadWs w;
+    w.feat = c.take<float>((size_t)B * 512);
+    w.t1 = c.take<float>((size_t)B * 512);
+    w.t2 = c.take<float>((size_t)B * 512);
+    return w;
+}
+extern "C" size_t dal3_point_head_workspace_bytes(int B) {
+    Carver c(nullptr, 0);
+    carve_head(c, B);
+    return c.off;
+}
+
+static int fc_chain(const FcW& f, const float* x, int64_t xs, float* out, int64_t out_stride, int B, float* t1,
+                    float* t2, hipStream_t s) {
+    const float* cur = x;
+    int64_t cs = xs;
+    for (int i = 0; i < f.n; ++i) {
+        const bool last = i == f.n - 1;
+        float* dst = last ? out : (i % 2 == 0 ? t1 : t2);
+        const int64_t ds = last ? out_stride : f.c_out[i];
+        HIP_TRY(launch_fc(f.w[i], f.b[i], cur, cs, dst, ds, B, f.c_in[i], f.c_out[i], f.relu[i], s));
+        cur = dst;
+        cs = ds;
+    }
+    return 0;
+}
+
+static int point_head_run(int head_kind, const void* packed, const dal3_bcn& x, int B, int M, float* out,
+                          int64_t out_stride, const HeadWs& ws, hipStream_t s) {
+    if (head_kind != DAL3_HEAD_STATIC_BOX_EST && head_kind != DAL3_HEAD_POINT_EMB && head_kind != DAL3_HEAD_BOX_EMB)
+        return fail(DAL3_EINVAL, "point_head: head_kind %d is not a point head", head_kind);
+    if (!packed || !out) return fail(DAL3_EINVAL, "point_head: null pointer");
+    if (B <= 0 || M <= 0) return fail(DAL3_EINVAL, "point_head: B and M must be positive");
+    TRY(check_bcn(x, "x"));
+    int c_in, ks, c[4], n_fc, fi[3], fo[3];
+    point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
+    const PointHeadW w = point_head_view(static_cast<const float*>(packed), head_kind);
+    HIP_TRY(hipMemsetAsync(ws.feat, 0, (size_t)B * 512 * sizeof(float), s));
+    HIP_TRY(launch_point_head(head_kind, w, to_bcn(x), c_in, B, M, ws.feat, s));
+    return fc_chain(w.fc, ws.feat, 512, out, out_stride, B, ws.t1, ws.t2, s);
+}
+
+extern "C" int dal3_point_head_forward(int head_kind, const void* packed, dal3_bcn x, int B, int M, float* out,
+                                       int64_t out_stride, void* workspace, size_t workspace_bytes,
+                                       dal3_stream stream) {
+    if (!workspace) return fail(DAL3_EINVAL, "point_head: workspace is NULL");
+    Carver c(workspace, workspace_bytes);
+    const HeadWs ws = carve_head(c, B);
+    if (!c.ok) return fail(DAL3_EWORKSPACE, "point_head: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
+    return point_head_run(head_kind, packed, x, B, M, out, out_stride, ws, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dal3_dynamic_box_est_forward(const void* packed, const float* embedding, int B, float* box_pred,
+                                            void* workspace, size_t workspace_bytes, dal3_stream stream) {
+    if (!packed || !embedding || !box_pred || !workspace || B <= 0) return fail(DAL3_EINVAL, "dynamic_box_est: bad argument");
+    Carver c(workspace, workspace_bytes);
+    const HeadWs ws = carve_head(c, B);
+    if (!c.ok) return fail(DAL3_EWORKSPACE, "dynamic_box_est: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
+    return fc_chain(fc_head_view(static_cast<const float*>(packed)), embedding, 384, box_pred, 39, B, ws.t1, ws.t2,
+                    static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------- small entries
+extern "C" int dal3_decode_boxes(float* box_pred, int B, const float* center_add, int64_t center_add_stride,
+                                 int center_inplace, const float* boxes_center_add, int64_t boxes_center_add_stride,
+                                 const float* yaw_base, int64_t yaw_stride, float* heading_residuals,
+                                 float* size_residuals, float* center, float* boxes7, dal3_stream stream) {
+    if (!box_pred || B <= 0) return fail(DAL3_EINVAL, "decode_boxes: bad argument");
+    HIP_TRY(launch_decode_boxes(box_pred, B, center_add, center_add_stride, center_inplace, boxes_center_add,
+                                boxes_center_add_stride, yaw_base, yaw_stride, heading_residuals, size_residuals,
+                                center, boxes7, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_recenter_rotz(const float* obj_pts, int B, int M, const float* init_box7, const float* box_one7,
+                                  const float* bbox_gt7, float* obj_pts_two, int64_t* heading_class_label,
+                                  float* heading_residual_label, dal3_stream stream) {
+    if (!obj_pts || !init_box7 || !box_one7 || !obj_pts_two || B <= 0 || M <= 0)
+        return fail(DAL3_EINVAL, "recenter_rotz: bad argument");
+    if (bbox_gt7 && (!heading_class_label || !heading_residual_label))
+        return fail(DAL3_EINVAL, "recenter_rotz: bbox_gt given without label outputs");
+    HIP_TRY(launch_recenter(obj_pts, B, M, init_box7, box_one7, bbox_gt7, obj_pts_two, heading_class_label,
+                            heading_residual_label, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, dal3_stream stream) {
+    if (!x || !out || rows <= 0 || n <= 0) return fail(DAL3_EINVAL, "maxpool_n: bad argument");
+    HIP_TRY(launch_maxpool_n(x, rows, n, out, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" size_t dal3_shared_mlp_layer_workspace_bytes(int c_in, int c_out) {
+    const size_t mt = (size_t)(c_out + 31) / 32;
+    const size_t w = c_in <= 8 ? mt * 4 * 64 : mt * (size_t)(c_in / 32) * 1024;
+    return (al(w) + al(mt * 32)) * sizeof(float);
+}
+
+extern "C" int dal3_shared_mlp_layer(const dal3_layer* layer, int relu, dal3_bcn x, int B, int N, float* y,
+                                     void* workspace, size_t workspace_bytes, dal3_stream stream) {
+    if (!layer || !y || !workspace || B <= 0 || N <= 0) return fail(DAL3_EINVAL, "shared_mlp_layer: bad argument");
+    TRY(check_bcn(x, "x"));
+    const dal3_layer& L = *layer;
+    if (L.c_out % 32 != 0) return fail(DAL3_EINVAL, "shared_mlp_layer: c_out must be a multiple of 32");
+    const bool first = L.c_in <= 8;
+    if (!first && L.c_in % 32 != 0) return fail(DAL3_EINVAL, "shared_mlp_layer: c_in must be <= 8 or a multiple of 32");
+    TRY(check_layer(L, L.c_in, L.c_out, "layer"));
+    const size_t need = dal3_shared_mlp_layer_workspace_bytes(L.c_in, L.c_out);
+    if (workspace_bytes < need) return fail(DAL3_EWORKSPACE, "shared_mlp_layer: workspace needs %zu bytes", need);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int mt = L.c_out / 32;
+    const int ks = first ? (L.c_in + 1) / 2 : 0;
+    const int kt = first ? 0 : L.c_in / 32;
+    float* wbuf = static_cast<float*>(workspace);
+    float* bbuf = wbuf + al(first ? (size_t)mt * 4 * 64 : (size_t)mt * kt * 1024);
+    if (first) HIP_TRY(launch_pack_weight(L, PACK_FIRST, 0, L.c_in, mt, ks, wbuf, s));
+    else HIP_TRY(launch_pack_weight(L, PACK_FRAG_MT_MAJOR, 0, L.c_in, mt, kt, wbuf, s));
+    HIP_TRY(launch_pack_bias(L, bbuf, s));
+    HIP_TRY(launch_generic_layer(reinterpret_cast<const f32x4*>(wbuf), wbuf, bbuf, kt, ks, mt, relu, to_bcn(x), L.c_in,
+                                 B, N, y, s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- static model
+struct StaticWs { InsSegWs seg; int32_t* pos; float* obj; float* obj2; HeadWs head; };
+static StaticWs carve_static(Carver& c, int B, int N, int two_stage) {
+    StaticWs w;
+    w.seg = carve_ins_seg(c, B);
+    w.pos = c.take<int32_t>((size_t)B * N);
+    w.obj = c.take<float>((size_t)B * 512 * 3);
+    w.obj2 = two_stage ? c.take<float>((size_t)B * 512 * 3) : nullptr;
+    w.head = carve_head(c, B);
+    return w;
+}
+extern "C" size_t dal3_static_workspace_bytes(int B, int N, int two_stage) {
+    Carver c(nullptr, 0);
+    carve_static(c, B, N, two_stage);
+    return c.off;
+}
+
+extern "C" int dal3_static_forward(const dal3_static_args* a, int phases, dal3_stream stream) {
+    if (!a) return fail(DAL3_EINVAL, "static_forward: args is NULL");
+    if (a->B <= 0 || a->N <= 0) return fail(DAL3_EINVAL, "static_forward: B and N must be positive");
+    if (!a->workspace) return fail(DAL3_EINVAL, "static_forward: workspace is NULL");
+    if (!(phases & DAL3_PHASE_ALL)) return fail(DAL3_EINVAL, "static_forward: no phase selected");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Carver c(a->workspace, a->workspace_bytes);
+    const StaticWs ws = carve_static(c, a->B, a->N, a->two_stage);
+    if (!c.ok) return fail(DAL3_EWORKSPACE, "static_forward: workspace needs %zu bytes, got %zu", c.off, a->workspace_bytes);
+    const int B = a->B, N = a->N, M = 512;
+
+    if (phases & DAL3_PHASE_SEG) {
+        TRY(ins_seg_run(a->w_ins_seg, 3, a->pts, B, N, a->logits, a->mask, nullptr, ws.seg, s));
+        if (a->counts) HIP_TRY(launch_segment_counts(a->mask, B, N, a->counts, s));
+    }
+    if (!(phases & DAL3_PHASE_BOX)) return 0;
+
+    if (!a->init_box || !a->box_pred_one || !a->counts || !a->obj_idx || !a->w_box_est_one)
+        return fail(DAL3_EINVAL, "static_forward: null pointer in box phase");
+    TRY(gather_run(a->mask, a->pts, B, N, 3, M, a->sampler, a->choice, a->seed, a->item_offset, a->counts, a->obj_idx,
+                   ws.obj, ws.pos, s));
+    const dal3_bcn obj{ws.obj, (int64_t)M * 3, 1, 3};
+    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_one, obj, B, M, a->box_pred_one, 39, ws.head, s));
+    if (!a->two_stage) {
+        // center = center_boxnet + init_box[:, :3] (static_model.py:132); yaw += init yaw (static_eval.py:280)
+        HIP_TRY(launch_decode_boxes(a->box_pred_one, B, a->init_box, 7, 0, nullptr, 0, a->init_box + 6, 7,
+                                    a->heading_residuals_one, a->size_residuals_one, a->center_one, a->boxes7, s));
+        return 0;
+    }
+    if (!a->w_box_est_two || !a->box_pred_two || !a->box_one || !a->center_one)
+        return fail(DAL3_EINVAL, "static_forward: two_stage needs w_box_est_two, box_pred_two, box_one, center_one");
+    // center_one += init_box[:, :3] in place (static_model.py:174); box_one (:176-190)
+    HIP_TRY(launch_decode_boxes(a->box_pred_one, B, a->init_box, 7, 1, nullptr, 0, a->init_box + 6, 7,
+                                a->heading_residuals_one, a->size_residuals_one, a->center_one, a->box_one, s));
+    HIP_TRY(launch_recenter(ws.obj, B, M, a->init_box, a->box_one, a->bbox_gt, ws.obj2,
+                            a->bbox_gt ? a->heading_class_label_two : nullptr,
+                            a->bbox_gt ? a->heading_residuals_label_two : nullptr, s));
+    const dal3_bcn obj2{ws.obj2, (int64_t)M * 3, 1, 3};
+    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_two, obj2, B, M, a->box_pred_two, 39, ws.head, s));
+    // center_two += center_one (static_model.py:211); final yaw += box_one yaw (static_eval.py:282)
+    HIP_TRY(launch_decode_boxes(a->box_pred_two, B, a->center_one, 3, 1, nullptr, 0, a->box_one + 6, 7,
+                                a->heading_residuals_two, a->size_residuals_two, a->center_two, a->boxes7, s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- dynamic model
+struct DynamicWs { InsSegWs seg; int32_t* pos; float* obj; HeadWs head; };
+static DynamicWs carve_dynamic(Carver& c, int B, int N, int M) {
+    DynamicWs w;
+    w.seg = carve_ins_seg(c, B);
+    w.pos = c.take<int32_t>((size_t)B * N);
+    w.obj = c.take<float>((size_t)B * M * 4);
+    w.head = carve_head(c, B);
+    return w;
+}
+extern "C" size_t dal3_dynamic_workspace_bytes(int B, int N, int) {
+    Carver c(nullptr, 0);
+    carve_dynamic(c, B, N, 2560);
+    return c.off;
+}
+
+extern "C" int dal3_dynamic_forward(const dal3_dynamic_args* a, int phases, dal3_stream stream) {
+    if (!a) return fail(DAL3_EINVAL, "dynamic_forward: args is NULL");
+    if (a->B <= 0 || a->N <= 0 || a->n_box <= 0) return fail(DAL3_EINVAL, "dynamic_forward: B, N, n_box must be positive");
+    if (!a->workspace) return fail(DAL3_EINVAL, "dynamic_forward: workspace is NULL");
+    if (!(phases & DAL3_PHASE_ALL)) return fail(DAL3_EINVAL, "dynamic_forward: no phase selected");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int B = a->B, N = a->N, M = 2560;
+    Carver c(a->workspace, a->workspace_bytes);
+    const DynamicWs ws = carve_dynamic(c, B, N, M);
+    if (!c.ok) return fail(DAL3_EWORKSPACE, "dynamic_forward: workspace needs %zu bytes, got %zu", c.off, a->workspace_bytes);
+
+    if (phases & DAL3_PHASE_SEG) {
+        TRY(ins_seg_run(a->w_ins_seg, 4, a->pts, B, N, a->logits, a->mask, nullptr, ws.seg, s));
+        if (a->counts) HIP_TRY(launch_segment_counts(a->mask, B, N, a->counts, s));
+    }
+    if (!(phases & DAL3_PHASE_BOX)) return 0;
+
+    if (!a->embedding || !a->box_pred || !a->counts || !a->obj_idx || !a->w_point_emb || !a->w_box_emb || !a->w_box_est)
+        return fail(DAL3_EINVAL, "dynamic_forward: null pointer in box phase");
+    TRY(gather_run(a->mask, a->pts, B, N, 4, M, a->sampler, a->choice, a->seed, a->item_offset, a->counts, a->obj_idx,
+                   ws.obj, ws.pos, s));
+    const dal3_bcn obj{ws.obj, (int64_t)M * 4, 1, 4};
+    // embedding = cat[point_e (256), box_e (128)] (dynamic_model.py:133-137): written side by side
+    TRY(point_head_run(DAL3_HEAD_POINT_EMB, a->w_point_emb, obj, B, M, a->embedding, 384, ws.head, s));
+    TRY(point_head_run(DAL3_HEAD_BOX_EMB, a->w_box_emb, a->box, B, a->n_box, a->embedding + 256, 384, ws.head, s));
+    TRY(fc_chain(fc_head_view(static_cast<const float*>(a->w_box_est)), a->embedding, 384, a->box_pred, 39, B,
+                 ws.head.t1, ws.head.t2, s));
+    // forward() adds nothing to the centre; the eval driver adds init_box[:, :3] and yaw init_box[:, -2]
+    HIP_TRY(launch_decode_boxes(a->box_pred, B, nullptr, 0, 0, a->init_box8, 8, a->init_box8 ? a->init_box8 + 6 : nullptr,
+                                8, a->heading_residuals, a->size_residuals, nullptr, a->boxes7, s));
+    return 0;
+}

@@ -1,0 +1,449 @@
+// dal3_misc.hip — weight packing (BN fold), batched FC heads, the standalone N-axis max-pool,
+// device-side mask compaction + object-point sampling, the two-stage re-centring, box decode.
+#include "dal3_device.h"
+#include "dal3_kernels.h"
+
+#define BN_EPS 1e-5f
+
+// ================================================================================== packing
+__device__ __forceinline__ float bn_scale(const dal3_layer& L, int row) {
+    return L.bn_weight ? L.bn_weight[row] / sqrtf(L.bn_var[row] + BN_EPS) : 1.0f;
+}
+
+// W'[row][col] = W[row][col_off + col] * gamma/sqrt(var+eps), zero outside the layer
+__device__ __forceinline__ float folded_w(const dal3_layer& L, int row, int col, int col_off, int n_cols) {
+    if (row >= L.c_out || col >= n_cols) return 0.0f;
+    return L.weight[(int64_t)row * L.c_in + col_off + col] * bn_scale(L, row);
+}
+
+__global__ void pack_weight_kernel(dal3_layer L, int mode, int col_off, int n_cols, int mt_n, int kt_n,
+                                   float* __restrict__ out, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (mode == PACK_ROWMAJOR) {
+        const int row = (int)(i / n_cols), col = (int)(i % n_cols);
+        out[i] = folded_w(L, row, col, col_off, n_cols);
+    } else if (mode == PACK_FIRST) {                      // [mt][ks][64]: row = lane&31, k = 2s + (lane>>5)
+        const int lane = (int)(i & 63);
+        const int s = (int)((i >> 6) % kt_n), mt = (int)((i >> 6) / kt_n);
+        out[i] = folded_w(L, 32 * mt + (lane & 31), 2 * s + (lane >> 5), col_off, n_cols);
+    } else {                                              // fragment order, see mma_block
+        const int e = (int)(i & 3), lane = (int)((i >> 2) & 63), q = (int)((i >> 8) & 3);
+        const int blk = (int)(i >> 10);
+        const int mt = mode == PACK_FRAG_MT_MAJOR ? blk / kt_n : blk % mt_n;
+        const int kt = mode == PACK_FRAG_MT_MAJOR ? blk % kt_n : blk / mt_n;
+        out[i] = folded_w(L, 32 * mt + (lane & 31), 32 * kt + tile_chan(4 * q + e, lane >> 5), col_off, n_cols);
+    }
+}
+
+// b' = (b - mean) * s + beta, zero padded to a multiple of 32
+__global__ void pack_bias_kernel(dal3_layer L, float* __restrict__ out, int padded) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= padded) return;
+    float v = 0.0f;
+    if (i < L.c_out) {
+        v = L.bias[i];
+        if (L.bn_weight) v = (v - L.bn_mean[i]) * bn_scale(L, i) + L.bn_bias[i];
+    }
+    out[i] = v;
+}
+
+hipError_t launch_pack_weight(const dal3_layer& L, int mode, int col_off, int n_cols, int mt_n, int kt_n, float* out,
+                              hipStream_t s) {
+    int64_t total;
+    if (mode == PACK_ROWMAJOR) total = (int64_t)L.c_out * n_cols;
+    else if (mode == PACK_FIRST) total = (int64_t)mt_n * kt_n * 64;
+    else total = (int64_t)mt_n * kt_n * 1024;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L, mode, col_off,
+                       n_cols, mt_n, kt_n, out, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_bias(const dal3_layer& L, float* out, hipStream_t s) {
+    const int padded = (L.c_out + 31) / 32 * 32;
+    hipLaunchKernelGGL(pack_bias_kernel, dim3((padded + 255) / 256), dim3(256), 0, s, L, out, padded);
+    return hipGetLastError();
+}
+
+// ================================================================================== FC heads
+// One wave = one 32(out) x 32(items) tile; out channels on MFMA rows, items on columns, K in steps
+// of 8 with the same k <-> (lane half, element) map on both operands (k = k0 + 4h + e).
+__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                 const float* __restrict__ x, int64_t xs, float* __restrict__ y,
+                                                 int64_t ys, int B, int c_in, int c_out, int relu, int n_mt, int n_bt) {
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int mt = wid % n_mt, bt = wid / n_mt;
+    if (bt >= n_bt) return;
+    const int row = 32 * mt + (lane & 31);
+    const int item = 32 * bt + (lane & 31);
+    const bool row_ok = row < c_out, item_ok = item < B;
+    const float* wp = W + (int64_t)(row_ok ? row : 0) * c_in + 4 * h;
+    const float* xp = x + (int64_t)(item_ok ? item : 0) * xs + 4 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = 32 * mt + tile_chan(r, h);
+        acc[r] = ch < c_out ? bias[ch] : 0.0f;
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k0 = 0; k0 < c_in; k0 += 8) {
+        const f32x4 a = row_ok ? *reinterpret_cast<const f32x4*>(wp + k0) : zero;
+        const f32x4 bv = item_ok ? *reinterpret_cast<const f32x4*>(xp + k0) : zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(a[e], bv[e], acc);
+    }
+    if (!item_ok) return;
+    float* yp = y + (int64_t)item * ys;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = 32 * mt + tile_chan(r, h);
+        if (ch < c_out) yp[ch] = relu ? fmaxf(acc[r], 0.0f) : acc[r];
+    }
+}
+
+hipError_t launch_fc(const float* W, const float* bias, const float* x, int64_t xs, float* y, int64_t ys, int B,
+                     int c_in, int c_out, int relu, hipStream_t s) {
+    if (c_in % 8 != 0 || xs % 4 != 0) return hipErrorInvalidValue;
+    const int n_mt = (c_out + 31) / 32, n_bt = (B + 31) / 32;
+    const int waves = n_mt * n_bt;
+    hipLaunchKernelGGL(fc_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, W, bias, x, xs, y, ys, B, c_in, c_out, relu,
+                       n_mt, n_bt);
+    return hipGetLastError();
+}
+
+// ================================================================================== max-pool over N
+// torch.max(x, 2)[0] for contiguous (rows, n) fp32: one wave per row, 16-byte loads coalesced along
+// N (1 KiB per wave-instruction), per-lane running max, then a wave64 butterfly. HBM-bound.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void maxpool_rows_kernel(const float* __restrict__ x, int64_t rows, int64_t n,
+                                                           float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int64_t n4 = n >> 2;                              // float4 per row (n % 4 == 0 on this path)
+    for (int64_t row = wave0; row < rows; row += n_waves) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(x + row * n);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int64_t i = lane;
+        for (; i + (UNROLL - 1) * 64 < n4; i += UNROLL * 64) {
+            f32x4 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(p + i + u * 64);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                m[0] = fmaxf(m[0], v[u][0]);
+                m[1] = fmaxf(m[1], v[u][1]);
+                m[2] = fmaxf(m[2], v[u][2]);
+                m[3] = fmaxf(m[3], v[u][3]);
+            }
+        }
+        for (; i < n4; i += 64) {
+            const f32x4 v = __builtin_nontemporal_load(p + i);
+            m[0] = fmaxf(m[0], v[0]);
+            m[1] = fmaxf(m[1], v[1]);
+            m[2] = fmaxf(m[2], v[2]);
+            m[3] = fmaxf(m[3], v[3]);
+        }
+        float r = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) r = fmaxf(r, __shfl_xor(r, off));
+        if (lane == 0) out[row] = r;
+    }
+}
+
+// generic fallback (n % 4 != 0 or unaligned base): scalar loads
+__global__ __launch_bounds__(256) void maxpool_rows_scalar_kernel(const float* __restrict__ x, int64_t rows, int64_t n,
+                                                                  float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave0; row < rows; row += n_waves) {
+        float r = -INFINITY;
+        for (int64_t i = lane; i < n; i += 64) r = fmaxf(r, x[row * n + i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) r = fmaxf(r, __shfl_xor(r, off));
+        if (lane == 0) out[row] = r;
+    }
+}
+
+hipError_t launch_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, hipStream_t s) {
+    if (rows <= 0 || n <= 0) return hipErrorInvalidValue;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (vec) hipLaunchKernelGGL(maxpool_rows_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, x, rows, n, out);
+    else hipLaunchKernelGGL(maxpool_rows_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, rows, n, out);
+    return hipGetLastError();
+}
+
+// ================================================================================== mask -> object points
+__device__ __forceinline__ uint32_t hash_key(uint64_t seed, uint64_t item, uint32_t i) {
+    uint64_t z = seed ^ (item * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)i << 32 | i);
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+
+// exclusive prefix of `flag` over the 256 threads of the block (thread order); *total = block sum
+__device__ __forceinline__ int block_scan_flag(bool flag, int* total, int* lds_wave /*[8]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int within = __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();                                        // lds_wave reuse
+    if (lane == 0) lds_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) {
+        const int c = lds_wave[wv];
+        base += wv < wave ? c : 0;
+        tot += c;
+    }
+    *total = tot;
+    return base + within;
+}
+
+__device__ __forceinline__ int block_sum(int v, int* lds_wave) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return lds_wave[0] + lds_wave[1] + lds_wave[2] + lds_wave[3];
+}
+
+__global__ __launch_bounds__(256) void segment_counts_kernel(const uint8_t* __restrict__ mask, int N,
+                                                             int32_t* __restrict__ counts) {
+    __shared__ int lds_wave[8];
+    const int64_t b = blockIdx.x;
+    int c = 0;
+    for (int i = threadIdx.x; i < N; i += 256) c += mask[b * N + i] ? 1 : 0;
+    c = block_sum(c, lds_wave);
+    if (threadIdx.x == 0) counts[b] = c;
+}
+
+// One 256-thread workgroup per item:
+//  1. ordered compaction of the segmented point indices (== torch.nonzero order) into pos[b,:count]
+//  2. choose M of them: count == 0 -> zero row; CHOICE sampler -> pos[choice[k]];
+//     count < M -> every segmented point plus duplicates (the reference tops up with random
+//     duplicates; every consumer is a max over points, so which duplicates is immaterial);
+//     count >= M -> the M smallest 32-bit hash keys (uniform subset without replacement), found by
+//     a 32-step bisection on the key value, ties taken in index order.
+//  3. gather obj_pts[b,k,:C] = pts[b,:C,idx[k]]
+__global__ __launch_bounds__(256) void compact_sample_kernel(const uint8_t* __restrict__ mask, BCN pts, int N, int C,
+                                                             int M, int sampler, const int32_t* __restrict__ choice,
+                                                             uint64_t seed, int64_t item_offset,
+                                                             int32_t* __restrict__ counts, int32_t* __restrict__ pos,
+                                                             int32_t* __restrict__ obj_idx, float* __restrict__ obj_pts) {
+    __shared__ int lds_wave[8];
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    int32_t* pos_b = pos + b * N;
+    int32_t* idx_b = obj_idx + b * M;
+    int count = 0;
+    for (int base = 0; base < N; base += 256) {
+        const int i = base + tid;
+        const bool f = i < N && mask[b * N + i];
+        int tot;
+        const int p = block_scan_flag(f, &tot, lds_wave);
+        if (f) pos_b[count + p] = i;
+        count += tot;
+    }
+    if (tid == 0) counts[b] = count;
+    __syncthreads();                                        // pos_b visible to the whole block (same CU)
+    __threadfence_block();
+
+    if (count == 0) {
+        for (int k = tid; k < M; k += 256) idx_b[k] = 0;
+        for (int k = tid; k < M * C; k += 256) obj_pts[b * M * C + k] = 0.0f;
+        return;
+    }
+    if (sampler == DAL3_SAMPLER_CHOICE) {
+        for (int k = tid; k < M; k += 256) {
+            int c = choice[b * M + k];
+            c = c < 0 ? 0 : (c >= count ? count - 1 : c);
+            idx_b[k] = pos_b[c];
+        }
+    } else if (count < M) {
+        for (int k = tid; k < M; k += 256) idx_b[k] = pos_b[k % count];
+    } else {
+        const uint64_t item = (uint64_t)(item_offset + b);
+        // smallest thr with #{key <= thr} >= M
+        uint32_t lo = 0, hi = 0xFFFFFFFFu;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            int c = 0;
+            for (int i = tid; i < count; i += 256) c += hash_key(seed, item, (uint32_t)i) <= mid ? 1 : 0;
+            c = block_sum(c, lds_wave);
+            if (c >= M) hi = mid; else lo = mid + 1;
+        }
+        const uint32_t thr = lo;
+        int n_less = 0;
+        for (int i = tid; i < count; i += 256) n_less += hash_key(seed, item, (uint32_t)i) < thr ? 1 : 0;
+        n_less = block_sum(n_less, lds_wave);
+        const int need = M - n_less;                        // taken from the ties, in index order
+        int out_less = 0, out_tie = 0;
+        for (int base = 0; base < count; base += 256) {
+            const int i = base + tid;
+            const uint32_t key = i < count ? hash_key(seed, item, (uint32_t)i) : 0xFFFFFFFFu;
+            const bool fl = i < count && key < thr;
+            const bool ft = i < count && key == thr;
+            int tl, tt;
+            const int pl = block_scan_flag(fl, &tl, lds_wave);
+            const int pt = block_scan_flag(ft, &tt, lds_wave);
+            if (fl) idx_b[out_less + pl] = pos_b[i];
+            if (ft && out_tie + pt < need) idx_b[n_less + out_tie + pt] = pos_b[i];
+            out_less += tl;
+            out_tie += tt;
+        }
+    }
+    __syncthreads();
+    __threadfence_block();
+    for (int k = tid; k < M; k += 256) {
+        const int n = idx_b[k];
+        const float* p = pts.data + b * pts.sb + (int64_t)n * pts.sn;
+        for (int c = 0; c < C; ++c) obj_pts[(b * M + k) * C + c] = p[c * pts.sc];
+    }
+}
+
+hipError_t launch_segment_counts(const uint8_t* mask, int B, int N, int32_t* counts, hipStream_t s) {
+    hipLaunchKernelGGL(segment_counts_kernel, dim3(B), dim3(256), 0, s, mask, N, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_sample(const uint8_t* mask, BCN pts, int B, int N, int C, int M, int sampler,
+                                 const int32_t* choice, uint64_t seed, int64_t item_offset, int32_t* counts,
+                                 int32_t* pos, int32_t* obj_idx, float* obj_pts, hipStream_t s) {
+    hipLaunchKernelGGL(compact_sample_kernel, dim3(B), dim3(256), 0, s, mask, pts, N, C, M, sampler, choice, seed,
+                       item_offset, counts, pos, obj_idx, obj_pts);
+    return hipGetLastError();
+}
+
+// ================================================================================== decode / parse
+__constant__ float c_mean_size[9] = {4.8f, 1.8f, 1.5f, 10.0f, 2.6f, 3.2f, 2.0f, 1.0f, 1.6f};
+__constant__ double c_mean_size_d[9] = {4.8, 1.8, 1.5, 10.0, 2.6, 3.2, 2.0, 1.0, 1.6};
+
+// One thread per crop. fp32 where the reference computes in fp32 tensors (parse_output_to_tensors),
+// fp64 where its eval driver computes in NumPy float64 (class2angle / class2size), rounded to fp32
+// on store.
+__global__ void decode_boxes_kernel(float* __restrict__ box_pred, int B, const float* __restrict__ center_add,
+                                    int64_t ca_stride, int center_inplace, const float* __restrict__ boxes_center_add,
+                                    int64_t bca_stride, const float* __restrict__ yaw_base, int64_t yaw_stride,
+                                    float* __restrict__ heading_residuals, float* __restrict__ size_residuals,
+                                    float* __restrict__ center, float* __restrict__ boxes7) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float* bp = box_pred + (int64_t)b * 39;
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        c[k] = bp[k] + (center_add ? center_add[b * ca_stride + k] : 0.0f);
+        if (center_inplace) bp[k] = c[k];
+        if (center) center[b * 3 + k] = c[k];
+    }
+    const float hr_scale = (float)(3.14159265358979323846 / 12.0);
+    int hc = 0;
+    float hbest = bp[3];
+    float hr_sel = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const float hr = bp[15 + i] * hr_scale;
+        if (heading_residuals) heading_residuals[b * 12 + i] = hr;
+        if (i == 0) hr_sel = hr;
+        if (bp[3 + i] > hbest) {                                // first maximum, as np.argmax
+            hbest = bp[3 + i];
+            hc = i;
+            hr_sel = hr;
+        }
+    }
+    int sc = 0;
+    float sbest = bp[27];
+#pragma unroll
+    for (int i = 1; i < 3; ++i) {
+        if (bp[27 + i] > sbest) {
+            sbest = bp[27 + i];
+            sc = i;
+        }
+    }
+    float sr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        sr[i] = bp[30 + i] * c_mean_size[i];
+        if (size_residuals) size_residuals[b * 9 + i] = sr[i];
+    }
+    if (!boxes7) return;
+    double ang = (double)hc * (2.0 * 3.14159265358979323846 / 12.0) + (double)hr_sel;
+    if (ang > 3.14159265358979323846) ang -= 2.0 * 3.14159265358979323846;
+    if (yaw_base) ang += (double)yaw_base[b * yaw_stride];
+    float* o = boxes7 + (int64_t)b * 7;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = c[k] + (boxes_center_add ? boxes_center_add[b * bca_stride + k] : 0.0f);
+        o[3 + k] = (float)(c_mean_size_d[sc * 3 + k] + (double)sr[sc * 3 + k]);
+    }
+    o[6] = (float)ang;
+}
+
+hipError_t launch_decode_boxes(float* box_pred, int B, const float* center_add, int64_t center_add_stride,
+                               int center_inplace, const float* boxes_center_add, int64_t boxes_center_add_stride,
+                               const float* yaw_base, int64_t yaw_stride, float* heading_residuals,
+                               float* size_residuals, float* center, float* boxes7, hipStream_t s) {
+    hipLaunchKernelGGL(decode_boxes_kernel, dim3((B + 127) / 128), dim3(128), 0, s, box_pred, B, center_add,
+                       center_add_stride, center_inplace, boxes_center_add, boxes_center_add_stride, yaw_base,
+                       yaw_stride, heading_residuals, size_residuals, center, boxes7);
+    return hipGetLastError();
+}
+
+// ================================================================================== two-stage re-centring
+__device__ __forceinline__ float torch_remainder(float a, float m) {   // aten remainder for floats
+    float r = fmodf(a, m);
+    if (r != 0.0f && ((r < 0.0f) != (m < 0.0f))) r += m;
+    return r;
+}
+
+__global__ void recenter_kernel(const float* __restrict__ obj, int B, int M, const float* __restrict__ init_box,
+                                const float* __restrict__ box_one, const float* __restrict__ bbox_gt,
+                                float* __restrict__ obj2, int64_t* __restrict__ hcl, float* __restrict__ hrl) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * M) return;
+    const int b = (int)(i / M);
+    const float* ib = init_box + b * 7;
+    const float* bo = box_one + b * 7;
+    const float c0 = cosf(ib[6]), s0 = sinf(ib[6]);
+    const float c1 = cosf(-bo[6]), s1 = sinf(-bo[6]);
+    const float x = obj[i * 3 + 0], y = obj[i * 3 + 1], z = obj[i * 3 + 2];
+    float px = c0 * x - s0 * y, py = s0 * x + c0 * y, pz = z;
+    px = px + ib[0];
+    py = py + ib[1];
+    pz = pz + ib[2];
+    px = px - bo[0];
+    py = py - bo[1];
+    pz = pz - bo[2];
+    obj2[i * 3 + 0] = c1 * px - s1 * py;
+    obj2[i * 3 + 1] = s1 * px + c1 * py;
+    obj2[i * 3 + 2] = pz;
+    if (bbox_gt && hcl && (i % M) == 0) {
+        // angle2class (utils.py:53-60) evaluated on fp32 tensors as the reference does
+        const float two_pi = (float)(2.0 * 3.14159265358979323846);
+        const double per_d = 2.0 * 3.14159265358979323846 / 12.0;
+        float a = bbox_gt[b * 7 + 6] - bo[6];
+        a = torch_remainder(a, two_pi);
+        const float shifted = torch_remainder(a + (float)(per_d / 2.0), two_pi);
+        const int cid = (int)(shifted / (float)per_d);
+        hcl[b] = cid;
+        hrl[b] = shifted - (float)((double)cid * per_d + per_d / 2.0);
+    }
+}
+
+hipError_t launch_recenter(const float* obj_pts, int B, int M, const float* init_box7, const float* box_one7,
+                           const float* bbox_gt7, float* obj_pts_two, int64_t* hcl, float* hrl, hipStream_t s) {
+    const int64_t total = (int64_t)B * M;
+    hipLaunchKernelGGL(recenter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, obj_pts, B, M,
+                       init_box7, box_one7, bbox_gt7, obj_pts_two, hcl, hrl);
+    return hipGetLastError();
+}

@@ -1,0 +1,275 @@
+// dal3_pointmlp.hip — the per-point shared-MLP kernels (fp32 MFMA, activations in registers).
+//
+//   ins_seg_encode : conv1..conv5 + BN + ReLU, channel-wise max over N fused into conv5's epilogue
+//                    (static_model.py:279-284) -> g (B,1024). The (B,1024,N) tensor never exists.
+//   ins_seg_decode : recomputes conv1-2 from the points, then dconv1 (per-point 64->512 part; the
+//                    global-feature part arrives as the per-crop vector gb) streamed in 32-channel
+//                    chunks straight into dconv2's K loop, dconv3, dconv4, dconv5 + the '<' mask
+//                    (static_model.py:286-295, :59) -> logits (B,N,2), mask (B,N).
+//   point_head     : conv1..conv4 + max over M (static_model.py:330-334, dynamic_model.py:241-245,
+//                    278-282) -> feat (B,512).
+//
+// One wave owns T tiles of 32 points; waves never talk to each other (no LDS, no barrier): the
+// cross-wave max is an atomic on g / feat. Weights stream from L2 as 1-KiB coalesced dwordx4
+// fragments shared by all waves of the chip.
+#include "dal3_device.h"
+#include "dal3_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(256) void ins_seg_encode_kernel(InsSegW w, BCN pts, int c_in, int n_pts,
+                                                             int tiles_per_item, float* __restrict__ g) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t b = blockIdx.x / tiles_per_item;
+    const int n0 = ((blockIdx.x % tiles_per_item) * 4 + wave) * (32 * T);
+    if (n0 >= n_pts) return;
+
+    float in[T][2];
+    load_points<2, T>(pts, b, n0, n_pts, c_in, in, lane);
+    f32x16 x1[T][2], x2[T][2], x3[T][2], x4[T][4];
+    first_layer<2, 2, T>(w.w1, w.b1, in, x1, lane);
+    mlp_layer<2, 2, T>(w.w2, w.b2, x1, x2, lane);
+    mlp_layer<2, 2, T>(w.w3, w.b3, x2, x3, lane);
+    mlp_layer<2, 4, T>(w.w4, w.b4, x3, x4, lane);
+
+    const int h = lane >> 5;
+    float* gb = g + b * 1024;
+    for (int mt = 0; mt < 32; ++mt) {
+        f32x16 acc[T];
+        const f32x16 bias = tile_from_channels(w.b5 + 32 * mt, h);
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = bias;
+        mma_block<4, T>(w.w5 + mt * 4 * 256, x4, acc, lane);
+        tile_max_atomic<T>(acc, gb + 32 * mt, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(256) void ins_seg_decode_kernel(InsSegW w, BCN pts, int c_in, int n_pts,
+                                                             int tiles_per_item, const float* __restrict__ gbias,
+                                                             float* __restrict__ logits, uint8_t* __restrict__ mask) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
+    const int64_t b = blockIdx.x / tiles_per_item;
+    const int n0 = ((blockIdx.x % tiles_per_item) * 4 + wave) * (32 * T);
+    if (n0 >= n_pts) return;
+
+    f32x16 x2[T][2];
+    {
+        float in[T][2];
+        load_points<2, T>(pts, b, n0, n_pts, c_in, in, lane);
+        f32x16 x1[T][2];
+        first_layer<2, 2, T>(w.w1, w.b1, in, x1, lane);
+        mlp_layer<2, 2, T>(w.w2, w.b2, x1, x2, lane);
+    }
+
+    // dconv1 (512 outputs, 16 chunks) streamed into dconv2 (256 outputs = 8 accumulator tiles)
+    f32x16 a2[T][8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const f32x16 bias = tile_from_channels(w.db2 + 32 * mt, h);
+#pragma unroll
+        for (int j = 0; j < T; ++j) a2[j][mt] = bias;
+    }
+    const float* gb = gbias + b * 512;                 // W1g . g + b1' of this crop
+    for (int c = 0; c < 16; ++c) {
+        f32x16 t[T];
+        const f32x16 init = tile_from_channels(gb + 32 * c, h);
+#pragma unroll
+        for (int j = 0; j < T; ++j) t[j] = init;
+        mma_block<2, T>(w.dw1a + c * 2 * 256, x2, t, lane);
+#pragma unroll
+        for (int j = 0; j < T; ++j) t[j] = relu16(t[j]);
+        const f32x4* w2c = w.dw2 + c * 8 * 256;       // K-major: [chunk][mt][q][lane]
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = w2c[(mt * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int j = 0; j < T; ++j) a2[j][mt] = mfma32(a[e], t[j][4 * q + e], a2[j][mt]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) a2[j][mt] = relu16(a2[j][mt]);
+    }
+
+    f32x16 y3[T][4], y4[T][4];
+    mlp_layer<8, 4, T>(w.dw3, w.db3, a2, y3, lane);
+    mlp_layer<4, 4, T>(w.dw4, w.db4, y3, y4, lane);
+
+    // dconv5 (128 -> 2, no BN/ReLU) on the VALU: each lane holds 64 of its point's 128 channels
+    float l0[T], l1[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) l0[j] = l1[j] = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(w.dw5 + 32 * kt + 8 * q + 4 * h);
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(w.dw5 + 128 + 32 * kt + 8 * q + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    l0[j] = fmaf(wa[e], y4[j][kt][4 * q + e], l0[j]);
+                    l1[j] = fmaf(wb[e], y4[j][kt][4 * q + e], l1[j]);
+                }
+            }
+        }
+    }
+    const float bias0 = w.db5[0], bias1 = w.db5[1];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const float s0 = l0[j] + __shfl_xor(l0[j], 32) + bias0;
+        const float s1 = l1[j] + __shfl_xor(l1[j], 32) + bias1;
+        const int n = n0 + 32 * j + (lane & 31);
+        if (h == 0 && n < n_pts) {
+            f32x2 o;
+            o[0] = s0;
+            o[1] = s1;
+            *reinterpret_cast<f32x2*>(logits + (b * n_pts + n) * 2) = o;
+            mask[b * n_pts + n] = s0 < s1 ? 1 : 0;      // strict '<': ties are background
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int KS, int C1, int C2, int C3, int T>
+__global__ __launch_bounds__(256) void point_head_kernel(PointHeadW w, BCN x, int c_in, int n_pts,
+                                                         int tiles_per_item, float* __restrict__ feat) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
+    const int64_t b = blockIdx.x / tiles_per_item;
+    const int n0 = ((blockIdx.x % tiles_per_item) * 4 + wave) * (32 * T);
+    if (n0 >= n_pts) return;
+
+    f32x16 x3[T][C3 / 32];
+    {
+        float in[T][KS];
+        load_points<KS, T>(x, b, n0, n_pts, c_in, in, lane);
+        f32x16 x1[T][C1 / 32], x2[T][C2 / 32];
+        first_layer<KS, C1 / 32, T>(w.w1, w.b1, in, x1, lane);
+        mlp_layer<C1 / 32, C2 / 32, T>(w.w2, w.b2, x1, x2, lane);
+        mlp_layer<C2 / 32, C3 / 32, T>(w.w3, w.b3, x2, x3, lane);
+    }
+    float* fb = feat + b * 512;
+    for (int mt = 0; mt < 16; ++mt) {
+        f32x16 acc[T];
+        const f32x16 bias = tile_from_channels(w.b4 + 32 * mt, h);
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = bias;
+        mma_block<C3 / 32, T>(w.w4 + mt * (C3 / 32) * 256, x3, acc, lane);
+        tile_max_atomic<T>(acc, fb + 32 * mt, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One layer, any Cin = 32*KT (or a raw first layer when kt == 0 && ks > 0) -> y (B,N,Cout)
+// point-major. Layer-wise test entry (dal3_shared_mlp_layer); not on the production path.
+__global__ __launch_bounds__(256) void generic_layer_kernel(const f32x4* __restrict__ wf, const float* __restrict__ w1,
+                                                            const float* __restrict__ bias, int kt_n, int ks_n, int mt_n,
+                                                            int relu, BCN x, int c_in, int n_pts, int tiles_per_item,
+                                                            float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
+    const int64_t b = blockIdx.x / tiles_per_item;
+    const int n0 = ((blockIdx.x % tiles_per_item) * 4 + wave) * 32;
+    if (n0 >= n_pts) return;
+    int n = n0 + (lane & 31);
+    const bool valid = n < n_pts;
+    n = valid ? n : n_pts - 1;
+    const float* p = x.data + b * x.sb + (int64_t)n * x.sn;
+    const int c_out = 32 * mt_n;
+    for (int mt = 0; mt < mt_n; ++mt) {
+        f32x16 acc = tile_from_channels(bias + 32 * mt, h);
+        if (ks_n > 0) {
+            for (int s = 0; s < ks_n; ++s) {
+                const int c = 2 * s + h;
+                const float bv = c < c_in ? p[c * x.sc] : 0.0f;
+                acc = mfma32(w1[(mt * ks_n + s) * 64 + lane], bv, acc);
+            }
+        } else {
+            for (int kt = 0; kt < kt_n; ++kt) {
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 a = wf[((mt * kt_n + kt) * 4 + q) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = 32 * kt + 8 * q + 4 * h + e;
+                        acc = mfma32(a[e], p[c * x.sc], acc);
+                    }
+                }
+            }
+        }
+        if (relu) acc = relu16(acc);
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 o;
+                o[0] = acc[4 * q + 0];
+                o[1] = acc[4 * q + 1];
+                o[2] = acc[4 * q + 2];
+                o[3] = acc[4 * q + 3];
+                *reinterpret_cast<f32x4*>(y + (b * n_pts + n) * c_out + 32 * mt + 8 * q + 4 * h) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline int tiles_per_item(int n_pts, int T) { return (n_pts + 128 * T - 1) / (128 * T); }
+
+hipError_t launch_ins_seg_encode(const InsSegW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
+    constexpr int T = DAL3_ENC_T;
+    const int tpi = tiles_per_item(N, T);
+    hipLaunchKernelGGL(ins_seg_encode_kernel<T>, dim3((unsigned)((int64_t)B * tpi)), dim3(256), 0, s, w, pts, c_in, N, tpi, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int N, const float* gbias,
+                                 float* logits, uint8_t* mask, hipStream_t s) {
+    constexpr int T = DAL3_DEC_T;
+    const int tpi = tiles_per_item(N, T);
+    hipLaunchKernelGGL(ins_seg_decode_kernel<T>, dim3((unsigned)((int64_t)B * tpi)), dim3(256), 0, s, w, pts, c_in, N, tpi,
+                       gbias, logits, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat, hipStream_t s) {
+    constexpr int T = DAL3_HEAD_T;
+    const int tpi = tiles_per_item(M, T);
+    const dim3 grid((unsigned)((int64_t)B * tpi)), block(256);
+    switch (head_kind) {
+        case 1:  // static box_est 3 -> 128 -> 128 -> 256 -> 512
+            hipLaunchKernelGGL((point_head_kernel<2, 128, 128, 256, T>), grid, block, 0, s, w, x, c_in, M, tpi, feat);
+            break;
+        case 2:  // point_emb 4 -> 64 -> 128 -> 256 -> 512
+            hipLaunchKernelGGL((point_head_kernel<2, 64, 128, 256, T>), grid, block, 0, s, w, x, c_in, M, tpi, feat);
+            break;
+        case 3:  // box_emb 8 -> 64 -> 64 -> 128 -> 512
+            hipLaunchKernelGGL((point_head_kernel<4, 64, 64, 128, T>), grid, block, 0, s, w, x, c_in, M, tpi, feat);
+            break;
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_generic_layer(const f32x4* wf, const float* w1, const float* bias, int kt_n, int ks_n, int mt_n,
+                                int relu, BCN x, int c_in, int B, int N, float* y, hipStream_t s) {
+    const int tpi = (N + 127) / 128;
+    hipLaunchKernelGGL(generic_layer_kernel, dim3((unsigned)((int64_t)B * tpi)), dim3(256), 0, s, wf, w1, bias, kt_n,
+                       ks_n, mt_n, relu, x, c_in, N, tpi, y);
+    return hipGetLastError();
+}

@@ -1,0 +1,262 @@
+"""Drop-in for the model classes of the reference's tools/static_model.py, running on MI355X.
+
+Same constructors, `.name`, `forward(pts, init_box, bbox_gt) -> dict` (same keys, shapes and
+dtypes) and state_dict key set as StaticModelOneBoxEst (static_model.py:108-146) and
+StaticModelTwoBoxEst (:148-239). In eval mode forward() runs entirely in lib3dal_hip.so through
+dal3_static_forward (include/dal3.h); in train mode it runs a stock-torch composite so that
+tools/static_train.py keeps working (not accelerated, SURVEY.md 8(a) note T).
+
+Extras the reference does not have:
+  .sampler      "device" (default; counter-based RNG on the GPU, no host round trip) or "numpy"
+                (the reference's np.random draws in its exact order -> bit-reproducible eval runs)
+  .refine(pts, init_box, bbox_gt=None) -> (B,7) refined boxes on the device, i.e. forward +
+                the decode loop of static_eval.py:269-288 without leaving the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _hip, arch
+from ._heads import (PackedCache, PointNetInstanceSeg, StaticPointNetEstimation as PointNetEstimation,
+                     Workspace, as_f32, numpy_choice, rows_contiguous)
+
+NUM_HEADING_BIN = arch.NUM_HEADING_BIN
+NUM_SIZE_CLUSTER = arch.NUM_SIZE_CLUSTER
+NUM_OBJECT_POINT = arch.NUM_OBJECT_POINT
+NUM_POINT = 4096                                   # static_model.py:15
+MEAN_SIZE_ARR = np.array(arch.MEAN_SIZE)
+
+
+class _StaticBase(nn.Module):
+    two_stage = False
+
+    def __init__(self, n_classes=3, n_channel=3):
+        super().__init__()
+        if n_channel != 3:
+            raise ValueError("the static heads take xyz points (n_channel=3, static_eval.py:345)")
+        self.n_classes = n_classes
+        self.n_channel = n_channel
+        self.sampler = "device"
+        self.seed = 10922081
+        self.item_offset = 0
+        self._cache = PackedCache()
+        self._ws = Workspace()
+        self.last = {}                              # side outputs of the last eval forward (boxes7, counts, obj_idx)
+
+    # ------------------------------------------------------------------ HIP path
+    def _run(self, pts, init_box, bbox_gt, choice=None, mask_override=None):
+        lib = _hip.lib()
+        pts = as_f32(pts, "pts")
+        init_box = rows_contiguous(as_f32(init_box, "init_box"))
+        if bbox_gt is not None:
+            bbox_gt = rows_contiguous(as_f32(bbox_gt, "bbox_gt"))
+        if pts.dim() != 3 or pts.shape[1] != 3:
+            raise RuntimeError(f"pts must be (B,3,N), got {tuple(pts.shape)}")
+        B, _, N = pts.shape
+        if init_box.shape != (B, 7):
+            raise RuntimeError(f"init_box must be (B,7), got {tuple(init_box.shape)}")
+        dev = pts.device
+        two = self.two_stage
+        f32 = dict(dtype=torch.float32, device=dev)
+        o = {
+            "logits": torch.empty((B, N, 2), **f32),
+            "mask": torch.empty((B, N), dtype=torch.uint8, device=dev),
+            "bp1": torch.empty((B, 39), **f32), "hr1": torch.empty((B, 12), **f32),
+            "sr1": torch.empty((B, 3, 3), **f32), "c1": torch.empty((B, 3), **f32),
+            "boxes7": torch.empty((B, 7), **f32),
+            "counts": torch.empty((B,), dtype=torch.int32, device=dev),
+            "obj_idx": torch.empty((B, NUM_OBJECT_POINT), dtype=torch.int32, device=dev),
+        }
+        if two:
+            o.update({
+                "box_one": torch.empty((B, 7), **f32), "bp2": torch.empty((B, 39), **f32),
+                "hr2": torch.empty((B, 12), **f32), "sr2": torch.empty((B, 3, 3), **f32),
+                "c2": torch.empty((B, 3), **f32),
+                "hcl": torch.zeros((B,), dtype=torch.int64, device=dev), "hrl": torch.zeros((B,), **f32),
+            })
+        ws_bytes = lib.dal3_static_workspace_bytes(B, N, int(two))
+        ws = self._ws.get(ws_bytes, dev)
+        a = _hip.StaticArgs()
+        a.B, a.N, a.two_stage = B, N, int(two)
+        a.seed, a.item_offset = self.seed, self.item_offset
+        a.pts = _hip.bcn(pts)
+        a.init_box, a.bbox_gt = _hip.ptr(init_box), _hip.ptr(bbox_gt)
+        a.w_ins_seg = _hip.ptr(self._cache.get("ins_seg", self.ins_seg, _hip.HEAD_INS_SEG))
+        if two:
+            a.w_box_est_one = _hip.ptr(self._cache.get("one", self.box_est_one, _hip.HEAD_STATIC_BOX_EST))
+            a.w_box_est_two = _hip.ptr(self._cache.get("two", self.box_est_two, _hip.HEAD_STATIC_BOX_EST))
+        else:
+            a.w_box_est_one = _hip.ptr(self._cache.get("one", self.box_est, _hip.HEAD_STATIC_BOX_EST))
+        a.logits, a.mask = _hip.ptr(o["logits"]), _hip.ptr(o["mask"])
+        a.box_pred_one, a.heading_residuals_one = _hip.ptr(o["bp1"]), _hip.ptr(o["hr1"])
+        a.size_residuals_one, a.center_one = _hip.ptr(o["sr1"]), _hip.ptr(o["c1"])
+        if two:
+            a.box_one, a.box_pred_two = _hip.ptr(o["box_one"]), _hip.ptr(o["bp2"])
+            a.heading_residuals_two, a.size_residuals_two = _hip.ptr(o["hr2"]), _hip.ptr(o["sr2"])
+            a.center_two = _hip.ptr(o["c2"])
+            a.heading_class_label_two, a.heading_residuals_label_two = _hip.ptr(o["hcl"]), _hip.ptr(o["hrl"])
+        a.boxes7, a.counts, a.obj_idx = _hip.ptr(o["boxes7"]), _hip.ptr(o["counts"]), _hip.ptr(o["obj_idx"])
+        a.workspace, a.workspace_bytes = _hip.ptr(ws), ws.numel()
+
+        st = _hip.stream()
+        if choice is None and self.sampler == "device" and mask_override is None:
+            a.sampler = _hip.SAMPLER_DEVICE
+            _hip.check(lib.dal3_static_forward(C.byref(a), _hip.PHASE_ALL, st))
+        else:
+            _hip.check(lib.dal3_static_forward(C.byref(a), _hip.PHASE_SEG, st))
+            if mask_override is not None:               # teacher forcing (tests)
+                o["mask"].copy_(mask_override.to(device=dev, dtype=torch.uint8))
+                _hip.check(lib.dal3_segment_counts(_hip.ptr(o["mask"]), B, N, _hip.ptr(o["counts"]), st))
+            if choice is None and self.sampler == "numpy":
+                choice = torch.from_numpy(numpy_choice(o["counts"].cpu().numpy(), NUM_OBJECT_POINT))
+            elif choice is None and self.sampler != "device":
+                raise ValueError(f"unknown sampler {self.sampler!r}")
+            if choice is not None:
+                choice = choice.to(device=dev, dtype=torch.int32).contiguous()
+                a.sampler, a.choice = _hip.SAMPLER_CHOICE, _hip.ptr(choice)
+            else:
+                a.sampler = _hip.SAMPLER_DEVICE
+            _hip.check(lib.dal3_static_forward(C.byref(a), _hip.PHASE_BOX, st))
+        o["_keep"] = (pts, init_box, bbox_gt, choice, ws)   # keep inputs alive until the stream catches up
+        return o
+
+    def refine(self, pts, init_box, bbox_gt=None):
+        """(B,7) fp32 refined boxes [cx,cy,cz,l,w,h,yaw] on the device (forward + static_eval.py:269-288)."""
+        if self.training:
+            raise RuntimeError("refine() is the eval-mode path; call model.eval() first")
+        return self._run(pts, init_box, bbox_gt)["boxes7"]
+
+
+class StaticModelOneBoxEst(_StaticBase):
+    """tools/static_model.py:108-146."""
+    two_stage = False
+
+    def __init__(self, n_classes=3, n_channel=3):
+        super().__init__(n_classes, n_channel)
+        self.name = "one_box_est"
+        self.ins_seg = PointNetInstanceSeg(n_classes=n_classes, n_channel=n_channel)
+        self.box_est = PointNetEstimation(n_classes=n_classes)
+
+    def forward(self, pts, init_box, bbox_gt):
+        if self.training:
+            return _train_forward_one(self, pts, init_box)
+        o = self._run(pts, init_box, bbox_gt)
+        bp = o["bp1"]
+        B = bp.shape[0]
+        self.last = {k: o[k] for k in ("boxes7", "counts", "obj_idx")}
+        return {
+            "logits": o["logits"], "mask": o["mask"].view(torch.bool),
+            "center_boxnet": bp[:, 0:3], "heading_scores": bp[:, 3:15],
+            "heading_residuals_normalized": bp[:, 15:27], "heading_residuals": o["hr1"],
+            "size_scores": bp[:, 27:30], "size_residuals_normalized": bp[:, 30:39].view(B, 3, 3),
+            "size_residuals": o["sr1"], "center": o["c1"],
+        }
+
+
+class StaticModelTwoBoxEst(_StaticBase):
+    """tools/static_model.py:148-239."""
+    two_stage = True
+
+    def __init__(self, n_classes=3, n_channel=3):
+        super().__init__(n_classes, n_channel)
+        self.name = "two_box_est"
+        self.ins_seg = PointNetInstanceSeg(n_classes=n_classes, n_channel=n_channel)
+        self.box_est_one = PointNetEstimation(n_classes=n_classes)
+        self.box_est_two = PointNetEstimation(n_classes=n_classes)
+
+    def forward(self, pts, init_box, bbox_gt):
+        if self.training:
+            return _train_forward_two(self, pts, init_box, bbox_gt)
+        o = self._run(pts, init_box, bbox_gt)
+        b1, b2 = o["bp1"], o["bp2"]
+        B = b1.shape[0]
+        self.last = {k: o[k] for k in ("boxes7", "counts", "obj_idx")}
+        return {
+            "logits": o["logits"], "mask": o["mask"].view(torch.bool),
+            "heading_scores_one": b1[:, 3:15], "heading_residuals_normalized_one": b1[:, 15:27],
+            "heading_residuals_one": o["hr1"], "size_scores_one": b1[:, 27:30],
+            "size_residuals_normalized_one": b1[:, 30:39].view(B, 3, 3), "size_residuals_one": o["sr1"],
+            "center_one": b1[:, 0:3], "box_one": o["box_one"],
+            "heading_scores_two": b2[:, 3:15], "heading_residuals_normalized_two": b2[:, 15:27],
+            "heading_residuals_two": o["hr2"], "size_scores_two": b2[:, 27:30],
+            "size_residuals_normalized_two": b2[:, 30:39].view(B, 3, 3), "size_residuals_two": o["sr2"],
+            "center_two": b2[:, 0:3],
+            "heading_class_label_two": o["hcl"], "heading_residuals_label_two": o["hrl"],
+            "center": b2[:, 0:3], "heading_scores": b2[:, 3:15], "heading_residuals": o["hr2"],
+            "size_scores": b2[:, 27:30], "size_residuals": o["sr2"],
+        }
+
+
+# ---------------------------------------------------------------------- train mode (stock torch)
+def _mask_and_gather(pts, logits, n_obj, n_ch):
+    """point_cloud_masking + gather_object_pts (static_model.py:23-62) with the reference's NumPy
+    draws; index bookkeeping on the host, the gather itself on the tensor's device."""
+    mask = logits[:, :, 0] < logits[:, :, 1]
+    counts = mask.sum(1).cpu().numpy()
+    choice = numpy_choice(counts, n_obj)
+    obj = torch.zeros((pts.shape[0], n_ch, n_obj), dtype=torch.float32, device=pts.device)
+    for i, k in enumerate(counts):
+        if k > 0:
+            pos = torch.nonzero(mask[i]).squeeze(1)
+            idx = pos[torch.from_numpy(choice[i]).long().to(pos.device)]
+            obj[i] = pts[i, :n_ch, idx]
+    return obj, mask
+
+
+def _parse(box_pred):
+    B = box_pred.shape[0]
+    hrn = box_pred[:, 15:27]
+    srn = box_pred[:, 30:39].contiguous().view(B, 3, 3)
+    mean = torch.tensor(arch.MEAN_SIZE, dtype=torch.float32, device=box_pred.device)
+    return (box_pred[:, 0:3], box_pred[:, 3:15], hrn, hrn * (np.pi / NUM_HEADING_BIN),
+            box_pred[:, 27:30], srn, srn * mean[None])
+
+
+def _train_forward_one(m, pts, init_box):
+    logits = m.ins_seg(pts)
+    obj, mask = _mask_and_gather(pts, logits, NUM_OBJECT_POINT, 3)
+    c, hs, hrn, hr, ss, srn, sr = _parse(m.box_est(obj))
+    return {"logits": logits, "mask": mask, "center_boxnet": c, "heading_scores": hs,
+            "heading_residuals_normalized": hrn, "heading_residuals": hr, "size_scores": ss,
+            "size_residuals_normalized": srn, "size_residuals": sr, "center": c + init_box[:, :3]}
+
+
+def _train_forward_two(m, pts, init_box, bbox_gt):
+    logits = m.ins_seg(pts)
+    obj, mask = _mask_and_gather(pts, logits, NUM_OBJECT_POINT, 3)
+    c1, hs1, hrn1, hr1, ss1, srn1, sr1 = _parse(m.box_est_one(obj))
+    c1 = c1 + init_box[:, :3]
+    with torch.no_grad():
+        B = c1.shape[0]
+        ar = torch.arange(B, device=c1.device)
+        hc = hs1.argmax(1)
+        sc = ss1.argmax(1)
+        mean = torch.tensor(arch.MEAN_SIZE, dtype=torch.float64, device=c1.device)
+        size = mean[sc] + sr1[ar, sc].double()
+        ang = hc.double() * (2 * np.pi / NUM_HEADING_BIN) + hr1[ar, hc].double()
+        ang = torch.where(ang > np.pi, ang - 2 * np.pi, ang) + init_box[:, -1].double()
+        box_one = torch.cat([c1.double(), size, ang[:, None]], 1).float()
+        y0, y1 = init_box[:, -1], -box_one[:, -1]
+        x, y, z = obj[:, 0], obj[:, 1], obj[:, 2]
+        px = torch.cos(y0)[:, None] * x - torch.sin(y0)[:, None] * y + init_box[:, 0:1] - box_one[:, 0:1]
+        py = torch.sin(y0)[:, None] * x + torch.cos(y0)[:, None] * y + init_box[:, 1:2] - box_one[:, 1:2]
+        pz = z + init_box[:, 2:3] - box_one[:, 2:3]
+        obj2 = torch.stack([torch.cos(y1)[:, None] * px - torch.sin(y1)[:, None] * py,
+                            torch.sin(y1)[:, None] * px + torch.cos(y1)[:, None] * py, pz], 1)
+        two_pi = 2 * np.pi
+        per = two_pi / NUM_HEADING_BIN
+        shifted = torch.remainder(torch.remainder(bbox_gt[:, -1] - box_one[:, -1], two_pi) + per / 2, two_pi)
+        hcl = (shifted / per).long()
+        hrl = shifted - (hcl.float() * per + per / 2)
+    c2, hs2, hrn2, hr2, ss2, srn2, sr2 = _parse(m.box_est_two(obj2))
+    c2 = c2 + c1
+    return {"logits": logits, "mask": mask, "heading_scores_one": hs1,
+            "heading_residuals_normalized_one": hrn1, "heading_residuals_one": hr1, "size_scores_one": ss1,
+            "size_residuals_normalized_one": srn1, "size_residuals_one": sr1, "center_one": c1,
+            "box_one": box_one, "heading_scores_two": hs2, "heading_residuals_normalized_two": hrn2,
+            "heading_residuals_two": hr2, "size_scores_two": ss2, "size_residuals_normalized_two": srn2,
+            "size_residuals_two": sr2, "center_two": c2, "heading_class_label_two": hcl,
+            "heading_residuals_label_two": hrl, "center": c2, "heading_scores": hs2,
+            "heading_residuals": hr2, "size_scores": ss2, "size_residuals": sr2}

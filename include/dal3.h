@@ -1,0 +1,236 @@
+/* dal3.h — C ABI of lib3dal_hip.so: the MI355X (gfx950) implementation of the 3DAL
+ * Frustum-PointNet auto-labeling heads (eval-mode forward + box decode).
+ *
+ * Boundary contract:
+ *   - plain C, no torch types, no C++ mangling; every pointer is a raw DEVICE pointer unless a
+ *     parameter says "host"; the caller (the PyTorch caching allocator, via tensor.data_ptr())
+ *     owns every buffer including the workspace and the packed weights;
+ *   - every call is asynchronous on the given HIP stream; the library never synchronises the
+ *     device, allocates nothing persistent and keeps no mutable global state except a
+ *     thread-local error string;
+ *   - return 0 on success, a negative DAL3_E* code on failure; dal3_last_error() describes it.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * jacky121298/3DAL_PyTorch checkout).
+ */
+#ifndef DAL3_H
+#define DAL3_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dal3_stream;               /* hipStream_t */
+
+#define DAL3_VERSION 100                 /* 0.1.0 */
+
+enum {
+    DAL3_OK = 0,
+    DAL3_EINVAL = -1,                    /* bad shape / stride / alignment / null pointer */
+    DAL3_EWORKSPACE = -2,                /* workspace too small */
+    DAL3_EHIP = -3                       /* a HIP runtime call failed (message has hipGetErrorString) */
+};
+
+enum { DAL3_F32 = 0 };                   /* arithmetic dtype of a packed head (bf16/fp16: later rounds) */
+
+/* which sub-network a packed-weight blob belongs to */
+enum {
+    DAL3_HEAD_INS_SEG = 0,               /* PointNetInstanceSeg: 10 layers, c_in 3 (static) or 4 (dynamic) */
+    DAL3_HEAD_STATIC_BOX_EST = 1,        /* static PointNetEstimation: 4 conv + 3 fc */
+    DAL3_HEAD_POINT_EMB = 2,             /* PointEmbedding: 4 conv + 2 fc */
+    DAL3_HEAD_BOX_EMB = 3,               /* BoxEmbedding: 4 conv + 2 fc */
+    DAL3_HEAD_DYNAMIC_BOX_EST = 4        /* dynamic PointNetEstimation: 3 fc */
+};
+
+/* how the M object points of a crop are drawn from its segmented points
+ * (replaces gather_object_pts, tools/static_model.py:23-49) */
+enum {
+    DAL3_SAMPLER_DEVICE = 0,             /* counter-based RNG keyed on (seed, global item index, point) */
+    DAL3_SAMPLER_CHOICE = 1              /* caller supplies `choice` (B,M): positions into the ordered
+                                            list of segmented points, e.g. NumPy's legacy stream drawn
+                                            in the reference's order for bit-reproducible eval runs */
+};
+
+/* One Conv1d(k=1)/Linear layer with its optional eval-mode BatchNorm1d, as the reference's
+ * state_dict holds it: weight (c_out, c_in[,1]) row-major, the rest (c_out). bn_* all NULL => no BN. */
+typedef struct {
+    const float* weight;
+    const float* bias;
+    const float* bn_weight;
+    const float* bn_bias;
+    const float* bn_mean;
+    const float* bn_var;
+    int32_t c_in;
+    int32_t c_out;
+} dal3_layer;
+
+/* ------------------------------------------------------------------------------------------ */
+int dal3_version(void);
+const char* dal3_last_error(void);       /* thread-local, static storage */
+
+/* Fold BN (eps 1e-5) into each layer and write the MFMA-fragment-ordered / row-major image the
+ * kernels consume. Call with packed_dev == NULL to query *bytes_inout. Layers come in forward
+ * order (ins_seg: conv1..5, dconv1..5; *_BOX_EST / *_EMB: conv1..4 then fc1..).
+ * Replaces: nothing in the reference (it keeps nn.Conv1d/nn.BatchNorm1d modules,
+ * static_model.py:249-269); this is the derived cache of SURVEY.md 8(b). */
+int dal3_pack_weights(int head_kind, const dal3_layer* layers, int n_layers, int dtype,
+                      void* packed_dev, size_t* bytes_inout, dal3_stream stream);
+
+/* logical (B, C, N) tensor with element strides: the callers hand pts.transpose(2,1) of a
+ * point-major buffer, i.e. strides (N*C, 1, C) (static_eval.py:265); contiguous (C*N, N, 1)
+ * is accepted too. */
+typedef struct {
+    const float* data;
+    int64_t stride_b, stride_c, stride_n;
+} dal3_bcn;
+
+/* ---- PointNetInstanceSeg.forward (static_model.py:271-296, dynamic_model.py:187-212) plus
+ * the mask of point_cloud_masking (static_model.py:59). logits (B,N,2) fp32, mask (B,N) u8.
+ * workspace: dal3_ins_seg_workspace_bytes(B). global_feat_out optional (B,1024). */
+size_t dal3_ins_seg_workspace_bytes(int B);
+int dal3_ins_seg_forward(const void* packed, int c_in, dal3_bcn pts, int B, int N,
+                         float* logits, uint8_t* mask, float* global_feat_out,
+                         void* workspace, size_t workspace_bytes, dal3_stream stream);
+
+/* ---- gather_object_pts (static_model.py:23-49 / dynamic_model.py:24-50) on the device.
+ * counts (B) i32 = number of segmented points; obj_idx (B,M) i32 = chosen point indices;
+ * obj_pts (B,M,C) fp32 point-major = pts[:, :C, idx] (all-zero rows where count == 0, as the
+ * reference leaves them). choice: see DAL3_SAMPLER_CHOICE (NULL for DAL3_SAMPLER_DEVICE).
+ * item_offset = global index of item 0 (multi-GPU shards draw the same subset as one GPU).
+ * workspace: dal3_gather_workspace_bytes(B, N). */
+size_t dal3_gather_workspace_bytes(int B, int N);
+int dal3_segment_counts(const uint8_t* mask, int B, int N, int32_t* counts, dal3_stream stream);
+int dal3_mask_compact_sample(const uint8_t* mask, dal3_bcn pts, int B, int N, int C, int M,
+                             int sampler, const int32_t* choice, uint64_t seed, int64_t item_offset,
+                             int32_t* counts, int32_t* obj_idx, float* obj_pts,
+                             void* workspace, size_t workspace_bytes, dal3_stream stream);
+
+/* ---- shared MLP (4 x Conv1d k=1 + BN + ReLU) + channel-wise max over the point axis + the FC
+ * stack of the head: static PointNetEstimation.forward (static_model.py:320-339) -> (B,39);
+ * PointEmbedding.forward (dynamic_model.py:234-249) -> (B,256); BoxEmbedding.forward
+ * (:271-286) -> (B,128). out has row stride out_stride floats (so the two embeddings can be
+ * written side by side: the torch.cat of dynamic_model.py:137).
+ * workspace: dal3_point_head_workspace_bytes(B). */
+size_t dal3_point_head_workspace_bytes(int B);
+int dal3_point_head_forward(int head_kind, const void* packed, dal3_bcn x, int B, int M,
+                            float* out, int64_t out_stride,
+                            void* workspace, size_t workspace_bytes, dal3_stream stream);
+
+/* ---- dynamic PointNetEstimation.forward (dynamic_model.py:300-312): (B,384) -> (B,39). */
+int dal3_dynamic_box_est_forward(const void* packed, const float* embedding, int B, float* box_pred,
+                                 void* workspace, size_t workspace_bytes, dal3_stream stream);
+
+/* ---- parse_output_to_tensors (static_model.py:64-96) + the eval drivers' box decode
+ * (static_eval.py:269-288, dynamic_eval.py:226-242, utils.py:69-79).
+ * box_pred (B,39) -> heading_residuals (B,12), size_residuals (B,9), center (B,3), boxes7 (B,7)
+ * [cx,cy,cz,l,w,h,yaw]. center = box_pred[:, :3] + center_add[:, :3] (center_add may be NULL),
+ * written back into box_pred[:, :3] too when center_inplace != 0 (the reference's
+ * `center_one += init_box[:, :3]` mutates box_pred through a view, static_model.py:174).
+ * boxes7 centre = center (+ boxes_center_add[:, :3] when not NULL: the dynamic driver adds
+ * init_box[:, :3] only at decode time). yaw = class2angle(argmax) + yaw_base[b*yaw_stride]. */
+int dal3_decode_boxes(float* box_pred, int B,
+                      const float* center_add, int64_t center_add_stride, int center_inplace,
+                      const float* boxes_center_add, int64_t boxes_center_add_stride,
+                      const float* yaw_base, int64_t yaw_stride,
+                      float* heading_residuals, float* size_residuals, float* center, float* boxes7,
+                      dal3_stream stream);
+
+/* ---- the re-centring between the two box estimators of StaticModelTwoBoxEst
+ * (static_model.py:192-205, rotz :98-106): p <- Rz(-yaw_one) (Rz(yaw_init) p + c_init - c_one),
+ * plus the stage-two heading labels angle2class(bbox_gt[:, -1] - box_one[:, -1], 12)
+ * (utils.py:53-60). obj_pts/obj_pts_two (B,M,3) point-major. bbox_gt may be NULL. */
+int dal3_recenter_rotz(const float* obj_pts, int B, int M, const float* init_box7,
+                       const float* box_one7, const float* bbox_gt7, float* obj_pts_two,
+                       int64_t* heading_class_label, float* heading_residual_label,
+                       dal3_stream stream);
+
+/* ---- torch.max(x, 2)[0] as a standalone kernel (static_model.py:284,334): x (B,C,N)
+ * contiguous fp32 -> out (B,C). The HBM-roofline kernel of BASELINE.json. */
+int dal3_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, dal3_stream stream);
+
+/* ---- one fused shared-MLP layer, for layer-wise tests: y = relu?(W' x + b') with BN folded,
+ * x (B,C_in,N) strided -> y (B,N,C_out) point-major. */
+int dal3_shared_mlp_layer(const dal3_layer* layer, int relu, dal3_bcn x, int B, int N, float* y,
+                          void* workspace, size_t workspace_bytes, dal3_stream stream);
+size_t dal3_shared_mlp_layer_workspace_bytes(int c_in, int c_out);
+
+/* ---- whole-model sequencers --------------------------------------------------------------- */
+typedef struct {
+    int32_t B, N;                        /* crops, points per crop */
+    int32_t two_stage;                   /* 0: StaticModelOneBoxEst, 1: StaticModelTwoBoxEst */
+    int32_t sampler;                     /* DAL3_SAMPLER_* */
+    uint64_t seed;
+    int64_t item_offset;
+    dal3_bcn pts;                        /* (B,3,N) logical */
+    const float* init_box;               /* (B,7) */
+    const float* bbox_gt;                /* (B,7) or NULL (only feeds the stage-two labels) */
+    const int32_t* choice;               /* (B,512) for DAL3_SAMPLER_CHOICE, else NULL */
+    const void* w_ins_seg;
+    const void* w_box_est_one;           /* the only estimator when two_stage == 0 */
+    const void* w_box_est_two;           /* NULL when two_stage == 0 */
+    /* outputs */
+    float* logits;                       /* (B,N,2) */
+    uint8_t* mask;                       /* (B,N) */
+    float* box_pred_one;                 /* (B,39); [:, :3] comes back with init_box[:, :3] added when two_stage */
+    float* heading_residuals_one;        /* (B,12) */
+    float* size_residuals_one;           /* (B,9) */
+    float* center_one;                   /* (B,3) = box_pred_one[:, :3] + init_box[:, :3] */
+    float* box_one;                      /* (B,7) decoded stage-one box (yaw + init yaw) */
+    float* box_pred_two;                 /* two_stage only from here */
+    float* heading_residuals_two;
+    float* size_residuals_two;
+    float* center_two;                   /* (B,3) = box_pred_two[:, :3] + center_one */
+    int64_t* heading_class_label_two;    /* (B) */
+    float* heading_residuals_label_two;  /* (B) */
+    float* boxes7;                       /* (B,7) refined boxes (static_eval.py:269-288) */
+    int32_t* counts;                     /* (B) segmented points per crop */
+    int32_t* obj_idx;                    /* (B,512) */
+    void* workspace;
+    size_t workspace_bytes;
+} dal3_static_args;
+
+/* phases: the CHOICE sampler needs `counts` on the host between them */
+enum { DAL3_PHASE_SEG = 1, DAL3_PHASE_BOX = 2, DAL3_PHASE_ALL = 3 };
+
+size_t dal3_static_workspace_bytes(int B, int N, int two_stage);
+/* StaticModelOneBoxEst.forward / StaticModelTwoBoxEst.forward (static_model.py:117-146,158-239)
+ * + refined-box decode (static_eval.py:269-288) */
+int dal3_static_forward(const dal3_static_args* args, int phases, dal3_stream stream);
+
+typedef struct {
+    int32_t B, N, n_box;                 /* items, points per item (5*1024), boxes per window (101) */
+    int32_t sampler;
+    uint64_t seed;
+    int64_t item_offset;
+    dal3_bcn pts;                        /* (B,4,N) logical */
+    dal3_bcn box;                        /* (B,8,n_box) logical */
+    const float* init_box8;              /* (B,8) or NULL: decode adds [:, :3] and yaw [:, 6] (dynamic_eval.py:236-240) */
+    const int32_t* choice;               /* (B,2560) for DAL3_SAMPLER_CHOICE */
+    const void* w_ins_seg;
+    const void* w_point_emb;
+    const void* w_box_emb;
+    const void* w_box_est;
+    float* logits;                       /* (B,N,2) */
+    uint8_t* mask;                       /* (B,N) */
+    float* embedding;                    /* (B,384) = [point_e | box_e] */
+    float* box_pred;                     /* (B,39) */
+    float* heading_residuals;            /* (B,12) */
+    float* size_residuals;               /* (B,9) */
+    float* boxes7;                       /* (B,7) */
+    int32_t* counts;                     /* (B) */
+    int32_t* obj_idx;                    /* (B,2560) */
+    void* workspace;
+    size_t workspace_bytes;
+} dal3_dynamic_args;
+
+size_t dal3_dynamic_workspace_bytes(int B, int N, int n_box);
+/* DynamicModel.forward (dynamic_model.py:121-155) + decode (dynamic_eval.py:226-242) */
+int dal3_dynamic_forward(const dal3_dynamic_args* args, int phases, dal3_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAL3_H */

@@ -46,3 +46,29 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# ------------------------------------------------------------------------------- GPU helpers
+def build_model(kind, sd_np, device="cuda"):
+    """The product nn.Module for 'static_one' | 'static_two' | 'dynamic' with the given weights."""
+    sm = importlib.import_module("3dal_pytorch_amd.static_model")
+    dm = importlib.import_module("3dal_pytorch_amd.dynamic_model")
+    m = {"static_one": sm.StaticModelOneBoxEst, "static_two": sm.StaticModelTwoBoxEst,
+         "dynamic": dm.DynamicModel}[kind]()
+    m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+    return m.to(device).eval()
+
+
+def positions_from_indices(mask_row, idx_row):
+    """oracle point indices -> positions in the ordered list of segmented points (the `choice`
+    the C ABI's DAL3_SAMPLER_CHOICE takes)."""
+    pos = np.nonzero(np.asarray(mask_row))[0]
+    lut = -np.ones(len(mask_row), np.int64)
+    lut[pos] = np.arange(len(pos))
+    return lut[np.asarray(idx_row)]
+
+
+def confident(margin, scale, tol=1e-4):
+    """points whose segmentation margin is far enough from the tie for a 1e-4-relative error in
+    the logits not to flip the mask"""
+    return np.abs(margin) > tol * scale

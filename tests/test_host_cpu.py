@@ -1,0 +1,104 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/dal3.h declares,
+the nn.Module mirrors carry the reference's state_dict key set, host-side sampler/sharding logic.
+No GPU compute here."""
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from _common import ROOT, arch, golden, rel_err, static_case, synth
+from oracle import ref_heads as R
+
+hip = importlib.import_module("3dal_pytorch_amd._hip")
+static_model = importlib.import_module("3dal_pytorch_amd.static_model")
+dynamic_model = importlib.import_module("3dal_pytorch_amd.dynamic_model")
+heads = importlib.import_module("3dal_pytorch_amd._heads")
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "dal3.h")).read()
+    declared = set(re.findall(r"\b(dal3_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert hip.lib().dal3_version() == 100
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    lib = hip.lib()
+    n = ctypes.c_size_t(0)
+    assert lib.dal3_pack_weights(99, None, 0, hip.F32, None, ctypes.byref(n), None) == hip.EINVAL
+    assert b"head_kind" in lib.dal3_last_error()
+    assert lib.dal3_pack_weights(hip.HEAD_INS_SEG, None, 0, hip.F32, None, ctypes.byref(n), None) == 0
+    assert n.value > 3_000_000                       # ~3.6 MB of folded fp32 weights
+    assert lib.dal3_static_forward(None, 3, None) == hip.EINVAL
+    assert lib.dal3_static_workspace_bytes(8, 1024, 0) > 8 * 1024 * 4
+
+
+@pytest.mark.parametrize("kind,ctor", [
+    ("static_one", lambda: static_model.StaticModelOneBoxEst(3, 3)),
+    ("static_two", lambda: static_model.StaticModelTwoBoxEst(3, 3)),
+    ("dynamic", lambda: dynamic_model.DynamicModel(3, 4)),
+])
+def test_state_dict_keys_match_reference(kind, ctor):
+    g = golden("state_dict_keys")
+    m = ctor()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g[kind + "_keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g[kind + "_shapes"])
+    # a reference-shaped checkpoint loads strictly
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict(kind).items()}, strict=True)
+
+
+def test_model_attributes_and_constants():
+    one, two, dyn = (static_model.StaticModelOneBoxEst(), static_model.StaticModelTwoBoxEst(),
+                     dynamic_model.DynamicModel())
+    assert one.name == "one_box_est" and two.name == "two_box_est"
+    assert (dyn.r, dyn.s) == (2, 50)
+    assert static_model.NUM_POINT == 4096 and dynamic_model.NUM_POINT == 1024
+    assert static_model.NUM_OBJECT_POINT == 512 and dynamic_model.NUM_FRAME == 5
+    assert np.allclose(static_model.MEAN_SIZE_ARR, R.MEAN_SIZE_ARR)
+
+
+def test_eval_forward_refuses_cpu_tensors():
+    m = static_model.StaticModelOneBoxEst().eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 64), torch.zeros(1, 7), torch.zeros(1, 7))
+
+
+def test_submodule_composites_equal_oracle_in_eval():
+    """The stock-torch composites used in train mode share the parameter containers; with BN in
+    eval mode they must equal the oracle (guards the layer wiring of _heads.py)."""
+    g = golden("static_one_b1_n512")
+    sd, pts, init, _ = static_case("static_one", 1, 512, g)
+    m = static_model.StaticModelOneBoxEst()
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.eval()
+    with torch.no_grad():
+        logits = m.ins_seg(pts)
+        box = m.box_est(torch.from_numpy(g["object_pts"]))
+    assert rel_err(logits.numpy(), g["logits"]) < 1e-6
+    assert rel_err(box.numpy(), g["box_pred"]) < 1e-6
+
+
+def test_numpy_choice_follows_reference_stream():
+    g = golden("gather_rng")
+    np.random.seed(12345)
+    ch = heads.numpy_choice(g["counts"], 512)
+    assert np.random.randint(0, 1 << 30) == int(g["next_draw"])
+    for row, c in enumerate(g["counts"]):
+        if c:
+            pos = np.nonzero(g["mask"][row])[0]
+            assert np.array_equal(pos[ch[row]], g["indices"][row])
+
+
+def test_flop_model_matches_survey():
+    assert arch.static_one_flop(1024) == 2 * 462_956_288
+    assert arch.static_two_flop(1024) == 2 * 555_830_784
+    assert arch.static_one_flop(4096) == 2 * 1_571_628_800
+    assert arch.dynamic_flop() == 2 * 2_298_154_368
