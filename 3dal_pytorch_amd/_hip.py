@@ -64,6 +64,9 @@ SIGNATURES = {
     "dal3_pack_weights": (_i, [_i, C.POINTER(Layer), _i, _i, vp, C.POINTER(_sz), vp]),
     "dal3_ins_seg_workspace_bytes": (_sz, [_i]),
     "dal3_ins_seg_forward": (_i, [vp, _i, BCN, _i, _i, vp, vp, vp, vp, _sz, vp]),
+    "dal3_ins_seg_encode": (_i, [vp, _i, BCN, _i, _i, vp, vp]),
+    "dal3_ins_seg_global_bias": (_i, [vp, vp, _i, vp, vp]),
+    "dal3_ins_seg_decode": (_i, [vp, _i, BCN, _i, _i, vp, vp, vp, vp]),
     "dal3_gather_workspace_bytes": (_sz, [_i, _i]),
     "dal3_segment_counts": (_i, [vp, _i, _i, vp, vp]),
     "dal3_mask_compact_sample": (_i, [vp, BCN, _i, _i, _i, _i, _i, vp, _u64, _i64, vp, vp, vp, vp, _sz, vp]),

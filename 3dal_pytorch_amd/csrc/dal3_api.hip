@@ -299,6 +299,34 @@ extern "C" int dal3_ins_seg_forward(const void* packed, int c_in, dal3_bcn pts, 
     return ins_seg_run(packed, c_in, pts, B, N, logits, mask, global_feat_out, ws, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int dal3_ins_seg_encode(const void* packed, int c_in, dal3_bcn pts, int B, int N, float* global_feat,
+                                   dal3_stream stream) {
+    if (!packed || !global_feat || B <= 0 || N <= 0 || (c_in != 3 && c_in != 4))
+        return fail(DAL3_EINVAL, "ins_seg_encode: bad argument");
+    TRY(check_bcn(pts, "pts"));
+    HIP_TRY(launch_ins_seg_encode(ins_seg_view(static_cast<const float*>(packed), c_in), to_bcn(pts), c_in, B, N,
+                                  global_feat, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_ins_seg_global_bias(const void* packed, const float* global_feat, int B, float* gbias,
+                                        dal3_stream stream) {
+    if (!packed || !global_feat || !gbias || B <= 0) return fail(DAL3_EINVAL, "ins_seg_global_bias: bad argument");
+    const InsSegW w = ins_seg_view(static_cast<const float*>(packed), 3);
+    HIP_TRY(launch_fc(w.dw1g, w.db1, global_feat, 1024, gbias, 512, B, 1024, 512, 0, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_ins_seg_decode(const void* packed, int c_in, dal3_bcn pts, int B, int N, const float* gbias,
+                                   float* logits, uint8_t* mask, dal3_stream stream) {
+    if (!packed || !gbias || !logits || !mask || B <= 0 || N <= 0 || (c_in != 3 && c_in != 4))
+        return fail(DAL3_EINVAL, "ins_seg_decode: bad argument");
+    TRY(check_bcn(pts, "pts"));
+    HIP_TRY(launch_ins_seg_decode(ins_seg_view(static_cast<const float*>(packed), c_in), to_bcn(pts), c_in, B, N, gbias,
+                                  logits, mask, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------- gather
 extern "C" size_t dal3_gather_workspace_bytes(int B, int N) {
     Carver c(nullptr, 0);

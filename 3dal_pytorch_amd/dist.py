@@ -1,0 +1,52 @@
+"""Object-sharded multi-GPU refinement: one process per GPU, crops split in contiguous index
+ranges, weights replicated, and ONE all-gather of the refined (B,7) boxes per batch over
+RCCL/xGMI (torch.distributed backend "nccl" on ROCm). Replaces the reference's pickle-based
+all_gather of per-rank results (det3d/torchie/trainer/utils.py:114-154); the heads themselves are
+single-GPU in the reference.
+
+No data-path collective exists besides that gather: every crop is independent in eval mode.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world_size):
+    """Contiguous [lo, hi) of rank `rank`: ceil(n/world) items per rank, ragged (possibly empty) tail."""
+    per = (n_items + world_size - 1) // world_size
+    lo = min(rank * per, n_items)
+    return lo, min(lo + per, n_items)
+
+
+def all_gather_boxes(local_boxes, n_items, group=None):
+    """local_boxes (hi-lo, 7) of this rank's shard -> (n_items, 7) on every rank. The ragged tail
+    is padded to ceil(n/world) rows so that one fixed-size all_gather_into_tensor moves it
+    (a 14 KiB-per-rank message at B=4096, W=8: latency-bound, so one collective, not W)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local_boxes
+    world = dist.get_world_size(group)
+    per = (n_items + world - 1) // world
+    width = local_boxes.shape[1]
+    if local_boxes.shape[0] == per:
+        send = local_boxes.contiguous()
+    else:
+        send = local_boxes.new_zeros((per, width))
+        send[: local_boxes.shape[0]] = local_boxes
+    out = local_boxes.new_empty((world * per, width))
+    dist.all_gather_into_tensor(out, send, group=group)
+    return out[:n_items]
+
+
+def refine_sharded(model, n_items, make_shard, group=None):
+    """Run `model.refine` on this rank's shard and gather. make_shard(lo, hi) returns the refine()
+    arguments for items [lo, hi) already resident on this rank's GPU. The device sampler is keyed
+    on the global item index, so the gathered result equals the single-GPU result bit for bit."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    lo, hi = shard_range(n_items, rank, world)
+    if hi > lo:
+        model.item_offset = lo
+        local = model.refine(*make_shard(lo, hi))
+    else:
+        dev = next(model.parameters()).device
+        local = torch.zeros((0, 7), dtype=torch.float32, device=dev)
+    return all_gather_boxes(local, n_items, group)

@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py — object-crops/sec through the refinement heads on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--head static|dynamic]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[1] — StaticModelOneBoxEst, 4096 crops x 1024
+points, fp32, per GPU, synthetic crops and random-init weights from 3dal_pytorch_amd/synth.py
+(no dataset / checkpoint is reachable). One step = one pass of the hot path over the batch:
+ins_seg -> mask -> object-point sampling -> box estimator -> decode to (B,7) boxes, inputs
+already resident in HBM; with N > 1 every rank refines its own 4096 crops (weak scaling, crops
+are independent) and one RCCL all-gather of the (N*4096, 7) boxes closes the step.
+
+The JSON line also carries
+  roofline      the dominant kernel (an fp32-MFMA shared-MLP kernel) timed live with HIP events
+                on the launch stream: algorithmic FLOP per launch / average duration vs the
+                157.3 TFLOP/s f32 MFMA peak of gfx950
+  maxpool       the standalone N-axis max-pool kernel on (4096,1024,1024) fp32 vs 8 TB/s HBM
+  cpu_baseline  the oracle (reference-formulation torch-CPU port) on this box's host cores, on
+                a bounded sample of the same workload
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+hip = importlib.import_module("3dal_pytorch_amd._hip")
+arch = importlib.import_module("3dal_pytorch_amd.arch")
+synth = importlib.import_module("3dal_pytorch_amd.synth")
+sm = importlib.import_module("3dal_pytorch_amd.static_model")
+dm = importlib.import_module("3dal_pytorch_amd.dynamic_model")
+dal3_dist = importlib.import_module("3dal_pytorch_amd.dist")
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
+
+
+def events_ms(fn, iters, warmup=2):
+    """average duration of fn() in ms, HIP events on torch's current stream (= the launch stream)"""
+    for _ in range(warmup):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def make_static(B, N, dev, first):
+    pts_np, init_np, gt_np = synth.static_crops(B, N, first=first)
+    model = sm.StaticModelOneBoxEst()
+    sd = synth.state_dict("static_one")
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    pts = torch.from_numpy(pts_np).to(dev).transpose(2, 1)          # the callers' layout (static_eval.py:265)
+    init, gt = torch.from_numpy(init_np).to(dev), torch.from_numpy(gt_np).to(dev)
+    # re-centre the segmentation bias so that about half the points are segmented (synth.py);
+    # done with one full-size pass so that every profiled launch of a kernel has the same shape
+    with torch.no_grad():
+        lg = model(pts, init, gt)["logits"]
+        model.ins_seg.dconv5.bias[1] -= (lg[:, :, 1] - lg[:, :, 0]).mean()
+        del lg
+    model.item_offset = first
+    return model, (pts, init, gt), (pts_np, init_np, sd)
+
+
+def make_dynamic(B, dev, first):
+    pts_np, box_np, init8_np, gt_np = synth.dynamic_items(B, first=first)
+    model = dm.DynamicModel()
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict("dynamic").items()})
+    model = model.to(dev).eval()
+    pts = torch.from_numpy(pts_np).to(dev).transpose(2, 1)
+    box = torch.from_numpy(box_np).to(dev).transpose(2, 1)
+    init8 = torch.from_numpy(init8_np).to(dev)
+    with torch.no_grad():
+        lg = model(pts, box, None)["logits"]
+        model.ins_seg.dconv5.bias[1] -= (lg[:, :, 1] - lg[:, :, 0]).mean()
+        del lg
+    model.item_offset = first
+    return model, (pts, box, init8)
+
+
+def kernel_rooflines(model, pts, c_in, B, N, iters):
+    """per-kernel HIP-event timing of the two shared-MLP kernels of ins_seg (per-kernel C-ABI entries)"""
+    lib = hip.lib()
+    w = model._cache.get("ins_seg", model.ins_seg, hip.HEAD_INS_SEG)
+    g = torch.zeros((B, 1024), device=pts.device)
+    gb = torch.empty((B, 512), device=pts.device)
+    logits = torch.empty((B, N, 2), device=pts.device)
+    mask = torch.empty((B, N), dtype=torch.uint8, device=pts.device)
+    x = hip.bcn(pts)
+
+    def enc():
+        hip.check(lib.dal3_ins_seg_encode(hip.ptr(w), c_in, x, B, N, hip.ptr(g), hip.stream()))
+
+    def dec():
+        hip.check(lib.dal3_ins_seg_decode(hip.ptr(w), c_in, x, B, N, hip.ptr(gb), hip.ptr(logits), hip.ptr(mask),
+                                          hip.stream()))
+    enc()
+    hip.check(lib.dal3_ins_seg_global_bias(hip.ptr(w), hip.ptr(g), B, hip.ptr(gb), hip.stream()))
+    t_enc = events_ms(enc, iters)
+    t_dec = events_ms(dec, iters)
+    mac_enc = c_in * 64 + 64 * 64 * 2 + 64 * 128 + 128 * 1024
+    mac_dec = 64 * 512 + 512 * 256 + 256 * 128 + 128 * 128 + 128 * 2
+    out = {}
+    for name, t, mac in (("ins_seg_encode_kernel", t_enc, mac_enc), ("ins_seg_decode_kernel", t_dec, mac_dec)):
+        tf = 2.0 * mac * B * N / (t * 1e-3) / 1e12
+        out[name] = {"ms": round(t, 4), "algorithmic_gflop": round(2.0 * mac * B * N / 1e9, 2),
+                     "tflops": round(tf, 2), "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4)}
+    return out
+
+
+def maxpool_roofline(dev, iters):
+    rows, n = 4096 * 1024, 1024
+    try:
+        x = torch.empty((rows, n), device=dev)
+    except RuntimeError:
+        rows = 1024 * 1024
+        x = torch.empty((rows, n), device=dev)
+    x.normal_()
+    out = torch.empty(rows, device=dev)
+    lib = hip.lib()
+    t = events_ms(lambda: hip.check(lib.dal3_maxpool_n(hip.ptr(x), rows, n, hip.ptr(out), hip.stream())), iters)
+    nbytes = rows * n * 4 + rows * 4
+    gbs = nbytes / (t * 1e-3) / 1e9
+    ok = bool(torch.equal(out[:4096], x[:4096].max(1)[0]))
+    del x
+    return {"kernel": "maxpool_rows_kernel", "shape": [rows // 1024, 1024, n], "bound": "hbm", "ms": round(t, 4),
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "exact": ok}
+
+
+def cpu_baseline(host, budget_s=20.0):
+    """the oracle (reference formulation) on the host cores, B=64 sample of the same crops"""
+    R = importlib.import_module("oracle.ref_heads")
+    pts_np, init_np, sd = host
+    # tools/cpu_threads.py on the GPU box (256 logical cores): 8 thr 64, 16 thr 76, 32 thr 80, 64 thr 53,
+    # 128 thr 27 crops/s -> the port saturates at 32 threads; more only adds contention
+    n = min(len(os.sched_getaffinity(0)), 32)
+    torch.set_num_threads(n)
+    sample = 64
+    tsd = R.as_torch_sd(sd)
+    pts = torch.from_numpy(pts_np[:sample]).transpose(2, 1)
+    init = torch.from_numpy(init_np[:sample])
+    with torch.no_grad():
+        np.random.seed(0)
+        R.decode_static(R.static_one_forward(tsd, pts, init), init, False)        # warm-up
+        t0 = time.perf_counter()
+        it = 0
+        while it < 3 or (time.perf_counter() - t0 < budget_s and it < 50):
+            R.decode_static(R.static_one_forward(tsd, pts, init), init, False)
+            it += 1
+        dt = (time.perf_counter() - t0) / it
+    return {"value": round(sample / dt, 2), "unit": "object-crops/s", "cores": n, "kind": "port",
+            "sample": f"oracle/ref_heads.py static_one_forward+decode, {it} x (B={sample}, N={pts.shape[2]}) fp32, "
+                      f"torch {torch.__version__} CPU kernels, {n} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--head", default="static", choices=["static", "dynamic"])
+    ap.add_argument("--batch", type=int, default=0, help="items per GPU (default: 4096 static, 1024 dynamic)")
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / maxpool / cpu_baseline legs")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    static = args.head == "static"
+    B = args.batch or (4096 if static else 1024)
+    N = args.points if static else 5 * args.points
+    first = rank * B                                            # weak scaling: B items per GPU
+    if static:
+        model, inputs, host = make_static(B, N, dev, first)
+        step_fn = lambda: model.refine(*inputs)                 # noqa: E731
+        flop_item = arch.static_one_flop(N)
+    else:
+        model, inputs = make_dynamic(B, dev, first)
+        step_fn = lambda: model.refine(*inputs)                 # noqa: E731
+        flop_item = arch.dynamic_flop(N)
+        host = None
+    n_total = B * world
+
+    def step():
+        boxes = step_fn()
+        return dal3_dist.all_gather_boxes(boxes, n_total) if world > 1 else boxes
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        boxes = step()
+    fence()
+    dt = time.perf_counter() - t0
+    assert boxes.shape == (n_total, 7) and bool(torch.isfinite(boxes).all())
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = n_total * args.steps / dt
+    rec = {
+        "metric": "object-crops/sec through static+dynamic refinement heads",
+        "value": round(value, 1), "unit": "object-crops/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (f"StaticModelOneBoxEst forward+decode, {B} crops x {N} pts per GPU, fp32 "
+                                "(BASELINE.json configs[1])") if static else
+                               (f"DynamicModel forward+decode, {B} items x {N} pts + 101 boxes per GPU, fp32 "
+                                "arithmetic (BASELINE.json configs[2] shape)"),
+                   "items_per_gpu": B, "points_per_item": N, "sampler": model.sampler,
+                   "parallelism": f"object-sharded x{world}, one all-gather of (B,7) boxes" if world > 1 else "single GPU",
+                   "algorithmic_gflop_per_item": round(flop_item / 1e9, 4)},
+        "whole_path_tflops": round(value * flop_item / 1e12, 2),
+        "whole_path_mfma_frac": round(value / world * flop_item / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+    }
+    if rank == 0 and world == 1 and not args.no_extras:
+        kr = kernel_rooflines(model, inputs[0], 3 if static else 4, B, N, iters=max(3, min(args.steps, 10)))
+        dom = max(kr, key=lambda k: kr[k]["ms"])
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")          # HBM bytes per launch from rocprofv3 --pmc
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(dom)
+        rec["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kr[dom]["tflops"],
+                           "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kr[dom]["frac"],
+                           "traffic": traffic, "ms_per_launch": kr[dom]["ms"],
+                           "algorithmic_gflop_per_launch": kr[dom]["algorithmic_gflop"]}
+        rec["kernels"] = kr
+        rec["maxpool"] = maxpool_roofline(dev, iters=5)
+        if static:
+            rec["cpu_baseline"] = cpu_baseline(host)
+    if world > 1:
+        fence()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()

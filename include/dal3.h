@@ -95,6 +95,19 @@ int dal3_ins_seg_forward(const void* packed, int c_in, dal3_bcn pts, int B, int 
                          float* logits, uint8_t* mask, float* global_feat_out,
                          void* workspace, size_t workspace_bytes, dal3_stream stream);
 
+/* The three kernels of dal3_ins_seg_forward as separate launches (per-kernel timing and tests):
+ *   encode      conv1..conv5 + BN + ReLU with the max over N fused (static_model.py:279-284):
+ *               pts -> global_feat (B,1024); global_feat must be zero-filled by the caller
+ *   global_bias the per-crop part of dconv1 (its 1024 global-feature columns, :286-289):
+ *               global_feat -> gbias (B,512) = W1g' g + b1'
+ *   decode      dconv1 (64 per-point columns) .. dconv5 + mask (:289-295, :59) */
+int dal3_ins_seg_encode(const void* packed, int c_in, dal3_bcn pts, int B, int N, float* global_feat,
+                        dal3_stream stream);
+int dal3_ins_seg_global_bias(const void* packed, const float* global_feat, int B, float* gbias,
+                             dal3_stream stream);
+int dal3_ins_seg_decode(const void* packed, int c_in, dal3_bcn pts, int B, int N, const float* gbias,
+                        float* logits, uint8_t* mask, dal3_stream stream);
+
 /* ---- gather_object_pts (static_model.py:23-49 / dynamic_model.py:24-50) on the device.
  * counts (B) i32 = number of segmented points; obj_idx (B,M) i32 = chosen point indices;
  * obj_pts (B,M,C) fp32 point-major = pts[:, :C, idx] (all-zero rows where count == 0, as the

@@ -355,9 +355,10 @@ def test_recenter_rotz_vs_oracle():
     out = torch.empty_like(obj)
     hcl = torch.empty(4, dtype=torch.int64, device="cuda")
     hrl = torch.empty(4, device="cuda")
-    hip.check(hip.lib().dal3_recenter_rotz(hip.ptr(obj), 4, 512, hip.ptr(init.cuda()), hip.ptr(dev(g["box_one"])),
-                                           hip.ptr(gt.cuda()), hip.ptr(out), hip.ptr(hcl), hip.ptr(hrl), hip.stream()))
-    assert np.abs(out.cpu().numpy().transpose(0, 2, 1) - want["_object_pts_two"].numpy()).max() < 2e-5
+    init_d, one_d, gt_d = init.cuda(), dev(g["box_one"]), gt.cuda()      # keep alive: ptr() holds no reference
+    hip.check(hip.lib().dal3_recenter_rotz(hip.ptr(obj), 4, 512, hip.ptr(init_d), hip.ptr(one_d), hip.ptr(gt_d),
+                                           hip.ptr(out), hip.ptr(hcl), hip.ptr(hrl), hip.stream()))
+    assert rel_err(out.cpu().numpy().transpose(0, 2, 1), want["_object_pts_two"].numpy()) < 1e-5
     assert np.array_equal(hcl.cpu().numpy(), g["heading_class_label_two"])
     assert np.abs(hrl.cpu().numpy() - g["heading_residuals_label_two"]).max() < 1e-6
 

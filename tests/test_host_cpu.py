@@ -102,3 +102,17 @@ def test_flop_model_matches_survey():
     assert arch.static_two_flop(1024) == 2 * 555_830_784
     assert arch.static_one_flop(4096) == 2 * 1_571_628_800
     assert arch.dynamic_flop() == 2 * 2_298_154_368
+
+
+def test_dropin_modules_resolve():
+    """`from static_model import ...` as the reference's drivers write it"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); "
+            "from static_model import StaticModelOneBoxEst, StaticModelTwoBoxEst, NUM_POINT, MEAN_SIZE_ARR; "
+            "from dynamic_model import DynamicModel, NUM_FRAME; "
+            "m = StaticModelTwoBoxEst(3, 3); assert m.name == 'two_box_est' and NUM_POINT == 4096; "
+            "assert DynamicModel(3, 4).s == 50 and NUM_FRAME == 5; print('ok')"
+            % os.path.join(ROOT, "3dal_pytorch_amd", "dropin"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr

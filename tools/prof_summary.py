@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (gpurun_out/prof_*) into the small summaries kept under profiles/.
+
+  python tools/prof_summary.py <round-tag> <gpurun_out dir>
+
+Writes profiles/<tag>_kernel_stats.csv (the --kernel-trace --stats table, our kernels only),
+profiles/<tag>_pmc.json (per-kernel counter averages over the full-size launches; FETCH_SIZE is
+doubled per MI355X_MICROARCH.md "HBM": gfx950 tallies 128-B requests at 64 B for wide streams)
+and profiles/traffic.json (HBM bytes per launch, read by bench.py's roofline.traffic)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+tag, src = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = os.path.join(root, "profiles")
+os.makedirs(out_dir, exist_ok=True)
+OURS = ("ins_seg_", "point_head_kernel", "maxpool_rows", "fc_kernel", "compact_sample", "decode_boxes",
+        "segment_counts", "recenter_kernel", "pack_", "generic_layer")
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").split("<")[0]
+
+
+stats = glob.glob(os.path.join(src, "prof_kt", "*", "*_kernel_stats.csv"))
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            if any(k in r["Name"] for k in OURS) or float(r["Percentage"]) > 0.5:
+                w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+pmc = defaultdict(lambda: defaultdict(list))
+for d in ("prof_fetch", "prof_write", "prof_mfma"):
+    for fn in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(fn)):
+            k = short(r["Kernel_Name"])
+            if not any(o in k for o in OURS):
+                continue
+            pmc[k][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"]),
+                                              int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+summary, traffic = {}, {}
+for k, ctrs in pmc.items():
+    s = {}
+    for c, vals in ctrs.items():
+        gmax = max(g for g, _, _ in vals)
+        full = [(v, t) for g, v, t in vals if g == gmax]          # full-size launches only
+        s[c] = sum(v for v, _ in full) / len(full)
+        s.setdefault("launches", len(full))
+        s[f"avg_ns_under_{c}"] = sum(t for _, t in full) / len(full)
+    if "FETCH_SIZE" in s and "WRITE_SIZE" in s:
+        # rocprofv3 reports both in KiB; FETCH_SIZE x2 on gfx950 for wide coalesced streams
+        s["hbm_read_bytes_corrected"] = s["FETCH_SIZE"] * 1024 * 2
+        s["hbm_write_bytes"] = s["WRITE_SIZE"] * 1024
+        traffic[k] = round(s["hbm_read_bytes_corrected"] + s["hbm_write_bytes"])
+    summary[k] = s
+json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+json.dump(traffic, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(summary, indent=1, sort_keys=True))
