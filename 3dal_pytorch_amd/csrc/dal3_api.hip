@@ -47,23 +47,21 @@ struct Cursor {
 
 static InsSegW ins_seg_walk(Cursor& c) {
     InsSegW w;
-    w.w1 = c.take(2 * 2 * 64);        w.b1 = c.take(64);
-    w.w2 = c.take4(2 * 2 * 1024);     w.b2 = c.take(64);
-    w.w3 = c.take4(2 * 2 * 1024);     w.b3 = c.take(64);
-    w.w4 = c.take4(4 * 2 * 1024);     w.b4 = c.take(128);
-    w.w5 = c.take4(32 * 4 * 1024);    w.b5 = c.take(1024);
-    w.dw1a = c.take4(16 * 2 * 1024);  w.dw1g = c.take(512 * 1024);   w.db1 = c.take(512);
-    w.dw2 = c.take4(16 * 8 * 1024);   w.db2 = c.take(256);
-    w.dw3 = c.take4(4 * 8 * 1024);    w.db3 = c.take(128);
-    w.dw4 = c.take4(4 * 4 * 1024);    w.db4 = c.take(128);
-    w.dw5 = c.take(2 * 128);          w.db5 = c.take(32);
+    w.w1 = c.take(2 * 2 * 64);
+    w.b1 = c.take(64);    w.b2 = c.take(64);    w.b3 = c.take(64);    w.b4 = c.take(128);   w.b5 = c.take(1024);
+    w.dw1g = c.take(512 * 1024);
+    w.db1 = c.take(512);  w.db2 = c.take(256);  w.db3 = c.take(128);  w.db4 = c.take(128);
+    w.dw5 = c.take(2 * 128);
+    w.db5 = c.take(32);
+    w.enc_stream = c.take4((size_t)ENC_FRAGS * 256);
+    w.dec_stream = c.take4((size_t)DEC_FRAGS * 256);
     return w;
 }
 
 size_t ins_seg_packed_floats(int) {
     Cursor c{nullptr, 0};
     ins_seg_walk(c);
-    return c.off;
+    return c.off + DAL3_BLOB_TAIL_FLOATS;
 }
 InsSegW ins_seg_view(const float* base, int) {
     Cursor c{base, 0};
@@ -91,10 +89,10 @@ static PointHeadW point_head_walk(Cursor& cur, int head_kind) {
     int c_in, ks, c[4], n_fc, fi[3], fo[3];
     point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
     PointHeadW w;
-    w.w1 = cur.take((size_t)(c[0] / 32) * ks * 64);                   w.b1 = cur.take(c[0]);
-    w.w2 = cur.take4((size_t)(c[1] / 32) * (c[0] / 32) * 1024);       w.b2 = cur.take(c[1]);
-    w.w3 = cur.take4((size_t)(c[2] / 32) * (c[1] / 32) * 1024);       w.b3 = cur.take(c[2]);
-    w.w4 = cur.take4((size_t)(c[3] / 32) * (c[2] / 32) * 1024);       w.b4 = cur.take(c[3]);
+    w.w1 = cur.take((size_t)(c[0] / 32) * ks * 64);
+    w.b1 = cur.take(c[0]);    w.b2 = cur.take(c[1]);    w.b3 = cur.take(c[2]);    w.b4 = cur.take(c[3]);
+    w.stream = cur.take4(((size_t)(c[1] / 32) * (c[0] / 32) + (size_t)(c[2] / 32) * (c[1] / 32) +
+                          (size_t)(c[3] / 32) * (c[2] / 32)) * 1024);
     w.fc.n = n_fc;
     for (int i = 0; i < 3; ++i) {
         w.fc.c_in[i] = fi[i];
@@ -108,7 +106,7 @@ static PointHeadW point_head_walk(Cursor& cur, int head_kind) {
 size_t point_head_packed_floats(int head_kind) {
     Cursor c{nullptr, 0};
     point_head_walk(c, head_kind);
-    return c.off;
+    return c.off + DAL3_BLOB_TAIL_FLOATS;
 }
 PointHeadW point_head_view(const float* base, int head_kind) {
     Cursor c{base, 0};
@@ -151,9 +149,12 @@ static int check_layer(const dal3_layer& L, int c_in, int c_out, const char* wha
     return 0;
 }
 
-static int pack_frag(const dal3_layer& L, int mode, int col_off, int n_cols, const f32x4* w, const float* b,
-                     hipStream_t s) {
-    HIP_TRY(launch_pack_weight(L, mode, col_off, n_cols, L.c_out / 32, n_cols / 32, mut(w), s));
+// fragment blocks of one layer written at fragment offset `frag` of a stream (+ its folded bias)
+static int pack_frag(const dal3_layer& L, int mode, int col_off, int n_cols, const f32x4* stream, int frag,
+                     const float* b, hipStream_t s, int grp_blocks = 0, int64_t a0 = 0, int64_t a1 = 0,
+                     int64_t stride = 0) {
+    HIP_TRY(launch_pack_weight(L, mode, col_off, n_cols, L.c_out / 32, n_cols / 32, mut(stream) + (size_t)frag * 256, s,
+                               grp_blocks, a0, a1, stride));
     if (b) HIP_TRY(launch_pack_bias(L, mut(b), s));
     return 0;
 }
@@ -202,15 +203,20 @@ extern "C" int dal3_pack_weights(int head_kind, const dal3_layer* L, int n_layer
         InsSegW w = ins_seg_view(base, c_in);
         HIP_TRY(launch_pack_weight(L[0], PACK_FIRST, 0, c_in, 2, 2, mut(w.w1), s));
         HIP_TRY(launch_pack_bias(L[0], mut(w.b1), s));
-        TRY(pack_frag(L[1], PACK_FRAG_MT_MAJOR, 0, 64, w.w2, w.b2, s));
-        TRY(pack_frag(L[2], PACK_FRAG_MT_MAJOR, 0, 64, w.w3, w.b3, s));
-        TRY(pack_frag(L[3], PACK_FRAG_MT_MAJOR, 0, 64, w.w4, w.b4, s));
-        TRY(pack_frag(L[4], PACK_FRAG_MT_MAJOR, 0, 128, w.w5, w.b5, s));
-        TRY(pack_frag(L[5], PACK_FRAG_MT_MAJOR, 0, 64, w.dw1a, w.db1, s));                 // columns of out2
+        // encode stream: conv2 | conv3 | conv4 | conv5
+        TRY(pack_frag(L[1], PACK_FRAG_MT_MAJOR, 0, 64, w.enc_stream, ENC_W2, w.b2, s));
+        TRY(pack_frag(L[2], PACK_FRAG_MT_MAJOR, 0, 64, w.enc_stream, ENC_W3, w.b3, s));
+        TRY(pack_frag(L[3], PACK_FRAG_MT_MAJOR, 0, 64, w.enc_stream, ENC_W4, w.b4, s));
+        TRY(pack_frag(L[4], PACK_FRAG_MT_MAJOR, 0, 128, w.enc_stream, ENC_W5, w.b5, s));
+        // decode stream: conv2 | dconv1a(0) | { dconv1a(c+1), dconv2(c) } | dconv3 | dconv4 (fragments of 256 floats)
+        TRY(pack_frag(L[1], PACK_FRAG_MT_MAJOR, 0, 64, w.dec_stream, DEC_W2, nullptr, s));
+        TRY(pack_frag(L[5], PACK_FRAG_MT_MAJOR, 0, 64, w.dec_stream, DEC_MIX, w.db1, s, /*chunk = 2 blocks*/ 2,
+                      0, 8 * 256, 40 * 256));                                              // columns of out2
         HIP_TRY(launch_pack_weight(L[5], PACK_ROWMAJOR, 64, 1024, 0, 0, mut(w.dw1g), s));   // columns of g
-        TRY(pack_frag(L[6], PACK_FRAG_KT_MAJOR, 0, 512, w.dw2, w.db2, s));
-        TRY(pack_frag(L[7], PACK_FRAG_MT_MAJOR, 0, 256, w.dw3, w.db3, s));
-        TRY(pack_frag(L[8], PACK_FRAG_MT_MAJOR, 0, 128, w.dw4, w.db4, s));
+        TRY(pack_frag(L[6], PACK_FRAG_KT_MAJOR, 0, 512, w.dec_stream, DEC_MIX, w.db2, s, /*chunk = 8 blocks*/ 8,
+                      16 * 256, 56 * 256, 40 * 256));
+        TRY(pack_frag(L[7], PACK_FRAG_MT_MAJOR, 0, 256, w.dec_stream, DEC_W3, w.db3, s));
+        TRY(pack_frag(L[8], PACK_FRAG_MT_MAJOR, 0, 128, w.dec_stream, DEC_W4, w.db4, s));
         HIP_TRY(launch_pack_weight(L[9], PACK_ROWMAJOR, 0, 128, 0, 0, mut(w.dw5), s));
         HIP_TRY(launch_pack_bias(L[9], mut(w.db5), s));
         return 0;
@@ -227,9 +233,10 @@ extern "C" int dal3_pack_weights(int head_kind, const dal3_layer* L, int n_layer
     PointHeadW w = point_head_view(base, head_kind);
     HIP_TRY(launch_pack_weight(L[0], PACK_FIRST, 0, c_in, c[0] / 32, ks, mut(w.w1), s));
     HIP_TRY(launch_pack_bias(L[0], mut(w.b1), s));
-    TRY(pack_frag(L[1], PACK_FRAG_MT_MAJOR, 0, c[0], w.w2, w.b2, s));
-    TRY(pack_frag(L[2], PACK_FRAG_MT_MAJOR, 0, c[1], w.w3, w.b3, s));
-    TRY(pack_frag(L[3], PACK_FRAG_MT_MAJOR, 0, c[2], w.w4, w.b4, s));
+    const int f3 = (c[1] / 32) * (c[0] / 32) * 4, f4 = f3 + (c[2] / 32) * (c[1] / 32) * 4;   // fragment offsets
+    TRY(pack_frag(L[1], PACK_FRAG_MT_MAJOR, 0, c[0], w.stream, 0, w.b2, s));
+    TRY(pack_frag(L[2], PACK_FRAG_MT_MAJOR, 0, c[1], w.stream, f3, w.b3, s));
+    TRY(pack_frag(L[3], PACK_FRAG_MT_MAJOR, 0, c[2], w.stream, f4, w.b4, s));
     return pack_fc(L + 4, w.fc, s);
 }
 

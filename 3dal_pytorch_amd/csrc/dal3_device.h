@@ -44,9 +44,17 @@ __device__ __forceinline__ f32x16 tile_from_channels(const float* __restrict__ v
     return t;
 }
 
+// max(x, 0) as ONE integer v_max_i32 on the bit pattern (negatives and -0.0 have the sign bit set ->
+// +0; positives unchanged). fmaxf() on an MFMA result makes hipcc emit a canonicalising v_max_f32 x,x
+// in front of it, doubling the ReLU's VALU cost; an inline-asm v_max_f32 would read the MFMA result
+// without the hazard wait states hipcc only inserts for instructions it models (cdna guide 5.7).
+__device__ __forceinline__ float relu1(float x) {
+    const int b = __float_as_int(x);
+    return __int_as_float(b > 0 ? b : 0);
+}
 __device__ __forceinline__ f32x16 relu16(f32x16 a) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
+    for (int r = 0; r < 16; ++r) a[r] = relu1(a[r]);
     return a;
 }
 
@@ -70,21 +78,107 @@ __device__ __forceinline__ void mma_block(const f32x4* __restrict__ wblk, const 
     }
 }
 
-// Y = relu(W' X + b') for a Cin=32*KT -> Cout=32*MT layer; w is [MT][KT][4][64] float4.
-template <int KT, int MT, int T>
-__device__ __forceinline__ void mlp_layer(const f32x4* __restrict__ w, const float* __restrict__ b,
-                                          const f32x16 (&X)[T][KT], f32x16 (&Y)[T][MT], int lane) {
+// Rolling prefetch of a fragment stream. The packed layouts put the fragments of the big layers in
+// exactly the order they are consumed (conv5 / conv4: [out-tile][k-tile][q]; dconv1a: [chunk][kt][q];
+// dconv2: [chunk][out-tile][q]), so a layer is ONE contiguous stream of 1-KiB wave-fragments. The
+// ring keeps D of them in flight ahead of the MFMAs, across the runtime loop over output chunks;
+// without it every chunk starts with an exposed L2 round trip. The last D fetches run past the
+// stream's end into the next section of the blob (blobs carry tail padding); their values are unused.
+#ifndef DAL3_SCHED_FENCE
+#define DAL3_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+template <int D>
+struct WRing {
+    const f32x4* next;
+    f32x4 slot[D];
+    __device__ __forceinline__ void init(const f32x4* stream, int lane) {
+        next = stream + lane;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            slot[i] = *next;
+            next += 64;
+        }
+    }
+};
+
+// On gfx950 the f32 MFMA shares the vector ALU's issue (tools/ubench/mfma_bubble.hip: every VALU op
+// between two MFMAs adds ~6 cycles, every s_waitcnt ~17, a global_load ~1), so the loops keep the
+// non-MFMA instruction count down. One of the levers: hipcc puts an s_waitcnt vmcnt(N) in front of the
+// first use of EVERY fragment; touching the youngest fragment of a batch of DAL3_WAIT_BATCH first makes
+// it emit one wait per batch (loads retire in order, so the older fragments of the batch are then known
+// to have landed).
+#ifndef DAL3_WAIT_BATCH
+#define DAL3_WAIT_BATCH 4
+#endif
+template <int D>
+__device__ __forceinline__ void ring_batch_wait(WRing<D>& ring, int i) {
+    static_assert(D % DAL3_WAIT_BATCH == 0, "wait batch must divide the ring depth");
+    if (DAL3_WAIT_BATCH > 1 && i % DAL3_WAIT_BATCH == 0)
+        asm volatile("" : "+v"(ring.slot[(i + DAL3_WAIT_BATCH - 1) % D][0]));
+}
+
+// acc[j] += W'(32 x 32*KT) . X[j], fragments taken from the ring (KT*4 of them, in stream order).
+// side(i) runs after fragment i's MFMAs have been issued: VALU work placed there (the previous
+// chunk's epilogue, a ReLU of the other buffer) executes in the shadow of those 64-cycle MFMAs
+// instead of leaving the matrix pipe idle at a chunk seam. The sched_barriers pin both the fetch
+// (D fragments ahead of its use; left alone hipcc sinks every load to just before its first use and
+// each group of MFMAs waits out an L2 round trip) and the side jobs.
+struct NoSide {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int KT, int T, int D, typename Side = NoSide>
+__device__ __forceinline__ void mma_block_ring(WRing<D>& ring, const f32x16 (&X)[T][KT], f32x16 (&acc)[T],
+                                               Side side = Side()) {
+    static_assert((KT * 4) % D == 0, "ring depth must divide the fragments per block");
+#pragma unroll
+    for (int i = 0; i < KT * 4; ++i) {
+        ring_batch_wait<D>(ring, i);
+        const f32x4 a = ring.slot[i % D];
+        ring.slot[i % D] = *ring.next;
+#ifdef DAL3_ABLATE_WINDOW   // timing experiment only: every fetch hits the same 8 KiB (L1-resident)
+        ring.next = reinterpret_cast<const f32x4*>(reinterpret_cast<uintptr_t>(ring.next + 64) & ~(uintptr_t)0x2000);
+#else
+        ring.next += 64;
+#endif
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[j] = mfma32(a[e], X[j][i / 4][4 * (i % 4) + e], acc[j]);
+        }
+        DAL3_SCHED_FENCE();
+        side(i);
+        DAL3_SCHED_FENCE();
+    }
+}
+
+// Y = relu(W' X + b') for a Cin=32*KT -> Cout=32*MT layer whose fragments are next on the kernel's
+// weight stream. Two accumulator sets alternate so that the ReLU of tile mt-1 and the bias fetch of
+// tile mt+1 ride under the MFMAs of tile mt. bias_cur arrives holding this layer's tile-0 bias and
+// leaves holding the first tile's bias of the NEXT layer (b_next), fetched a whole tile ahead.
+template <int KT, int MT, int T, int D>
+__device__ __forceinline__ void mlp_layer_ring(WRing<D>& ring, const float* __restrict__ b,
+                                               const float* __restrict__ b_next, f32x16& bias_cur,
+                                               const f32x16 (&X)[T][KT], f32x16 (&Y)[T][MT], int lane) {
     const int h = lane >> 5;
+    f32x16 acc[2][T];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        f32x16 acc[T];
-        const f32x16 bias = tile_from_channels(b + 32 * mt, h);
 #pragma unroll
-        for (int j = 0; j < T; ++j) acc[j] = bias;
-        mma_block<KT, T>(w + mt * KT * 256, X, acc, lane);
+        for (int j = 0; j < T; ++j) acc[mt & 1][j] = bias_cur;
+        mma_block_ring<KT, T, D>(ring, X, acc[mt & 1], [&](int i) {
+            if (i == 0) bias_cur = tile_from_channels(mt + 1 < MT ? b + 32 * (mt + 1) : b_next, h);
+            if (mt > 0 && i < 8) {                     // ReLU of the previous tile, two registers per fragment group
 #pragma unroll
-        for (int j = 0; j < T; ++j) Y[j][mt] = relu16(acc[j]);
+                for (int j = 0; j < T; ++j) {
+                    Y[j][mt - 1][2 * i] = relu1(acc[(mt - 1) & 1][j][2 * i]);
+                    Y[j][mt - 1][2 * i + 1] = relu1(acc[(mt - 1) & 1][j][2 * i + 1]);
+                }
+            }
+        });
     }
+#pragma unroll
+    for (int j = 0; j < T; ++j) Y[j][MT - 1] = relu16(acc[(MT - 1) & 1][j]);
 }
 
 // First layer (raw input, Cin <= 2*KS channels in natural order): in[j][s] is this lane's B
@@ -136,57 +230,125 @@ __device__ __forceinline__ float swz_xor(float v) {
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (XOR << 10) | 0x1F));
 }
 
-// Channel-wise max over the 32 points of a tile (and the T tiles of the wave), post-ReLU,
-// combined across waves / workgroups by an integer atomic max on the bit pattern (values are
-// >= +0, so the order of unsigned bit patterns is the order of the floats; dst is zero-filled
-// before the launch). Transposing butterfly: each step halves the live registers, 16 swizzles
-// instead of 80. dst points at the 32 channels of this output tile for this item.
+// Channel-wise max over the 32 points of a tile (and the T tiles of the wave), post-ReLU, combined
+// across waves / workgroups by an integer atomic max on the bit pattern (values are >= +0, so the
+// order of the bit patterns is the order of the floats; dst is zero-filled before the launch).
+// Transposing butterfly: each exchange halves the live registers (16 swizzles instead of 80).
+// The folded bias is added AFTER the max (x -> fl(x + b) is monotone, so max_p fl(acc_p + b) ==
+// fl(max_p acc_p + b)): accumulators start at zero and no load sits in front of a chunk's MFMAs.
+//
+// The work is cut into 10 micro-steps of <= ~12 VALU instructions; step k is issued right after
+// fragment group k of the NEXT tile (mma_block_ring's side job), i.e. in the shadow of that group's
+// last 64-cycle MFMA, so the matrix pipe never waits for the epilogue. Every ds_swizzle is consumed one
+// step after it is issued: its latency passes under a whole group of MFMAs.
 template <int T>
-__device__ __forceinline__ void tile_max_atomic(const f32x16 (&acc)[T], float* __restrict__ dst, int lane) {
-    f32x16 m = acc[0];
+struct MaxEpilogue {
+    static constexpr int STEPS = 10;
+    float keep[8], recv[8], bias_v;
+
+    __device__ __forceinline__ static float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
+
+    __device__ __forceinline__ void step(int k, const f32x16 (&acc)[T], const float* __restrict__ bias,
+                                         float* __restrict__ dst, int lane) {
+        if (k < 4) {                                   // max over the wave's tiles + first exchange, 2 pairs per step
+            const bool up = lane & 1;
 #pragma unroll
-    for (int j = 1; j < T; ++j) {
+            for (int i = 2 * k; i < 2 * k + 2; ++i) {
+                float lo = acc[0][i], hi = acc[0][i + 8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m[r] = fmaxf(m[r], acc[j][r]);
-    }
-    float v8[8], v4[4], v2[2], v1;
-    {
-        const bool up = lane & 1;
+                for (int j = 1; j < T; ++j) {
+                    lo = vmax(lo, acc[j][i]);
+                    hi = vmax(hi, acc[j][i + 8]);
+                }
+                keep[i] = up ? hi : lo;
+                recv[i] = swz_xor<1>(up ? lo : hi);
+            }
+            if (k == 0) {                              // bias: LDS copy (an lgkmcnt wait, never a vmcnt drain of the ring)
+                const int r = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+                bias_v = bias[tile_chan(r, lane >> 5)];
+            }
+        } else if (k == 4) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float send = up ? m[i] : m[i + 8];
-            const float keep = up ? m[i + 8] : m[i];
-            v8[i] = fmaxf(keep, swz_xor<1>(send));
+            for (int i = 0; i < 8; ++i) keep[i] = vmax(keep[i], recv[i]);
+        } else if (k == 5) {
+            const bool up = lane & 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float lo = keep[i], hi = keep[i + 4];
+                keep[i] = up ? hi : lo;
+                recv[i] = swz_xor<2>(up ? lo : hi);
+            }
+        } else if (k == 6) {
+            const bool up = lane & 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) keep[i] = vmax(keep[i], recv[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float lo = keep[i], hi = keep[i + 2];
+                keep[i] = up ? hi : lo;
+                recv[i] = swz_xor<4>(up ? lo : hi);
+            }
+        } else if (k == 7) {
+            const bool up = lane & 8;
+            const float v0 = vmax(keep[0], recv[0]), v1 = vmax(keep[1], recv[1]);
+            keep[0] = up ? v1 : v0;
+            recv[0] = swz_xor<8>(up ? v0 : v1);
+        } else if (k == 8) {
+            keep[0] = vmax(keep[0], recv[0]);
+            recv[0] = swz_xor<16>(keep[0]);
+        } else if (k == 9) {
+            // lane bits 0..3 selected register bits 3..0; lane bit 4 holds a replica
+            const int r = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+            int bits = __float_as_int(vmax(keep[0], recv[0]) + bias_v);
+            bits = bits > 0 ? bits : 0;                  // ReLU on the bit pattern (-0.0 and negatives -> +0)
+            if ((lane & 16) == 0) atomicMax(reinterpret_cast<int*>(dst) + tile_chan(r, lane >> 5), bits);
         }
     }
-    {
-        const bool up = lane & 2;
+    __device__ __forceinline__ void all(const f32x16 (&acc)[T], const float* bias, float* dst, int lane) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float send = up ? v8[i] : v8[i + 4];
-            const float keep = up ? v8[i + 4] : v8[i];
-            v4[i] = fmaxf(keep, swz_xor<2>(send));
+        for (int k = 0; k < STEPS; ++k) step(k, acc, bias, dst, lane);
+    }
+};
+
+// The last layer of a shared MLP with the max over points fused: n_tiles (even) output tiles of 32
+// channels, swept with two accumulator sets; the epilogue of tile mt-1 rides under the MFMAs of tile mt.
+// The fragments [n_tiles][KT][4][64] are next on the kernel's weight stream; bias/dst: the n_tiles*32 channels.
+template <int KT, int T, int D>
+__device__ __forceinline__ void conv_max_layer(WRing<D>& ring, const float* __restrict__ bias,
+                                               const f32x16 (&X)[T][KT], float* __restrict__ dst, int n_tiles,
+                                               int lane) {
+    f32x16 accA[T], accB[T];
+    MaxEpilogue<T> ep;
+#ifdef DAL3_ABLATE_EPILOGUE
+    for (int mt = 0; mt < n_tiles; ++mt) {
+#pragma unroll
+        for (int j = 0; j < T; ++j) accA[j] = f32x16{};
+        mma_block_ring<KT, T, D>(ring, X, accA);
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(accA[j][r]));
         }
     }
-    {
-        const bool up = lane & 4;
+    return;
+#endif
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float send = up ? v4[i] : v4[i + 2];
-            const float keep = up ? v4[i + 2] : v4[i];
-            v2[i] = fmaxf(keep, swz_xor<4>(send));
+    for (int j = 0; j < T; ++j) accA[j] = f32x16{};
+    mma_block_ring<KT, T, D>(ring, X, accA);                              // tile 0
+    for (int mt = 1; mt < n_tiles; mt += 2) {
+#pragma unroll
+        for (int j = 0; j < T; ++j) accB[j] = f32x16{};
+        mma_block_ring<KT, T, D>(ring, X, accB, [&](int i) {              // tile mt, epilogue of tile mt-1
+            if (i < MaxEpilogue<T>::STEPS) ep.step(i, accA, bias + 32 * (mt - 1), dst + 32 * (mt - 1), lane);
+        });
+        if (mt + 1 < n_tiles) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) accA[j] = f32x16{};
+            mma_block_ring<KT, T, D>(ring, X, accA, [&](int i) {          // tile mt+1, epilogue of tile mt
+                if (i < MaxEpilogue<T>::STEPS) ep.step(i, accB, bias + 32 * mt, dst + 32 * mt, lane);
+            });
+        } else {
+            ep.all(accB, bias + 32 * mt, dst + 32 * mt, lane);            // last tile: nothing left to hide under
         }
     }
-    {
-        const bool up = lane & 8;
-        const float send = up ? v2[0] : v2[1];
-        const float keep = up ? v2[1] : v2[0];
-        v1 = fmaxf(keep, swz_xor<8>(send));
-    }
-    v1 = fmaxf(v1, swz_xor<16>(v1));
-    // lane bits 0..3 selected register bits 3..0
-    const int r = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-    int bits = __float_as_int(v1);
-    bits = bits > 0 ? bits : 0;                       // ReLU on the bit pattern (-0.0 and negatives -> +0)
-    if ((lane & 16) == 0) atomicMax(reinterpret_cast<int*>(dst) + tile_chan(r, lane >> 5), bits);
 }

@@ -18,31 +18,47 @@
 #define DAL3_HEAD_T 1
 #endif
 
-// ---- packed PointNetInstanceSeg (BN folded). "frag" = [MT][KT][4][64] float4 fragment order of
-// dal3_device.h::mma_block; dw2 is K-major ([KT][MT][4][64]) because dconv2 consumes dconv1's
-// output chunk by chunk.
+// waves per workgroup of the shared-MLP kernels (waves never cooperate, so this only sets the
+// granularity at which the dispatcher refills a CU)
+#ifndef DAL3_WG_WAVES
+#define DAL3_WG_WAVES 4
+#endif
+
+// weight-fragment prefetch depth (fragments of 1 KiB per wave kept in flight), see WRing
+#ifndef DAL3_PF
+#define DAL3_PF 8
+#endif
+#define DAL3_BLOB_TAIL_FLOATS 8192   // 32 KiB: room for a ring's over-read past the last stream
+
+// ---- packed PointNetInstanceSeg (BN folded). A "frag block" is [4 q][64 lanes] float4 x KT k-tiles
+// of one 32-row output tile, see dal3_device.h::mma_block_ring. Each kernel reads ONE stream of
+// blocks laid out in the order it consumes them:
+//   enc_stream  conv2 (64->64) | conv3 (64->64) | conv4 (64->128) | conv5 (128->1024), out-tile major
+//   dec_stream  conv2 | dconv1a chunk 0 | { dconv1a chunk c+1 (8 frags), dconv2 chunk c (32 frags) }
+//               for c = 0..15 (chunk 16 = zeros) | dconv3 (256->128) | dconv4 (128->128)
+// where dconv1a = dconv1 columns 0..63 (the per-point out2 part, one 32-output chunk = 8 fragments)
+// and dconv2 is K-major (the 32 fragments that multiply dconv1 chunk c into the 8 output tiles).
 struct InsSegW {
-    const float* w1;     // first layer [2][2][64]
-    const float* b1;     // 64
-    const f32x4* w2;     // frag 64->64
+    const float* w1;          // first layer [2][2][64]
+    const float* b1;          // 64
     const float* b2;
-    const f32x4* w3;     // frag 64->64
     const float* b3;
-    const f32x4* w4;     // frag 64->128
     const float* b4;
-    const f32x4* w5;     // frag 128->1024
-    const float* b5;
-    const f32x4* dw1a;   // frag 64->512: dconv1 columns 0..63 (the out2 part)
-    const float* dw1g;   // row-major (512,1024): dconv1 columns 64..1087 (the global-feature part)
-    const float* db1;    // 512
-    const f32x4* dw2;    // frag 512->256, K-major
+    const float* b5;          // 1024
+    const float* dw1g;        // row-major (512,1024): dconv1 columns 64..1087 (the global-feature part)
+    const float* db1;         // 512
     const float* db2;
-    const f32x4* dw3;    // frag 256->128
     const float* db3;
-    const f32x4* dw4;    // frag 128->128
     const float* db4;
-    const float* dw5;    // row-major (2,128)
-    const float* db5;    // 2
+    const float* dw5;         // row-major (2,128)
+    const float* db5;         // 2
+    const f32x4* enc_stream;
+    const f32x4* dec_stream;
+};
+enum {                        // stream geometry in fragments of 256 floats
+    ENC_W2 = 0, ENC_W3 = 16, ENC_W4 = 32, ENC_W5 = 64, ENC_FRAGS = 64 + 512,
+    DEC_W2 = 0, DEC_MIX = 16, DEC_MIX_FRAGS = 8 + 16 * 40, DEC_W3 = 16 + 648, DEC_W4 = 16 + 648 + 128,
+    DEC_FRAGS = 16 + 648 + 128 + 64
 };
 
 struct FcW {
@@ -55,12 +71,10 @@ struct FcW {
 struct PointHeadW {
     const float* w1;     // first layer [C1/32][KS][64]
     const float* b1;
-    const f32x4* w2;
     const float* b2;
-    const f32x4* w3;
     const float* b3;
-    const f32x4* w4;     // frag C3->512
     const float* b4;
+    const f32x4* stream; // conv2 | conv3 | conv4 fragment blocks, out-tile major, back to back
     FcW fc;
 };
 
@@ -86,8 +100,11 @@ hipError_t launch_fc(const float* W, const float* bias, const float* x, int64_t 
                      int c_in, int c_out, int relu, hipStream_t s);
 
 enum { PACK_FRAG_MT_MAJOR = 0, PACK_FRAG_KT_MAJOR = 1, PACK_FIRST = 2, PACK_ROWMAJOR = 3 };
+// grp_blocks > 0: the (mt,kt) blocks are written in groups of grp_blocks; group 0 at out + grp_a0, group g >= 1 at
+// out + grp_a1 + (g-1)*grp_stride (floats). grp_blocks == 0: dense.
 hipError_t launch_pack_weight(const dal3_layer& L, int mode, int col_off, int n_cols, int mt_n, int kt_n, float* out,
-                              hipStream_t s);
+                              hipStream_t s, int grp_blocks = 0, int64_t grp_a0 = 0, int64_t grp_a1 = 0,
+                              int64_t grp_stride = 0);
 hipError_t launch_pack_bias(const dal3_layer& L, float* out, hipStream_t s);
 
 hipError_t launch_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, hipStream_t s);

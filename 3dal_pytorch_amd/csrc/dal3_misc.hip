@@ -17,7 +17,8 @@ __device__ __forceinline__ float folded_w(const dal3_layer& L, int row, int col,
 }
 
 __global__ void pack_weight_kernel(dal3_layer L, int mode, int col_off, int n_cols, int mt_n, int kt_n,
-                                   float* __restrict__ out, int64_t total) {
+                                   float* __restrict__ out, int64_t total, int grp_blocks, int64_t grp_a0,
+                                   int64_t grp_a1, int64_t grp_stride) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     if (mode == PACK_ROWMAJOR) {
@@ -32,7 +33,12 @@ __global__ void pack_weight_kernel(dal3_layer L, int mode, int col_off, int n_co
         const int blk = (int)(i >> 10);
         const int mt = mode == PACK_FRAG_MT_MAJOR ? blk / kt_n : blk % mt_n;
         const int kt = mode == PACK_FRAG_MT_MAJOR ? blk % kt_n : blk / mt_n;
-        out[i] = folded_w(L, 32 * mt + (lane & 31), 32 * kt + tile_chan(4 * q + e, lane >> 5), col_off, n_cols);
+        int64_t o = i;
+        if (grp_blocks > 0) {
+            const int g = blk / grp_blocks;
+            o = (g == 0 ? grp_a0 : grp_a1 + (int64_t)(g - 1) * grp_stride) + (int64_t)(blk % grp_blocks) * 1024 + (i & 1023);
+        }
+        out[o] = folded_w(L, 32 * mt + (lane & 31), 32 * kt + tile_chan(4 * q + e, lane >> 5), col_off, n_cols);
     }
 }
 
@@ -49,13 +55,13 @@ __global__ void pack_bias_kernel(dal3_layer L, float* __restrict__ out, int padd
 }
 
 hipError_t launch_pack_weight(const dal3_layer& L, int mode, int col_off, int n_cols, int mt_n, int kt_n, float* out,
-                              hipStream_t s) {
+                              hipStream_t s, int grp_blocks, int64_t grp_a0, int64_t grp_a1, int64_t grp_stride) {
     int64_t total;
     if (mode == PACK_ROWMAJOR) total = (int64_t)L.c_out * n_cols;
     else if (mode == PACK_FIRST) total = (int64_t)mt_n * kt_n * 64;
     else total = (int64_t)mt_n * kt_n * 1024;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L, mode, col_off,
-                       n_cols, mt_n, kt_n, out, total);
+                       n_cols, mt_n, kt_n, out, total, grp_blocks, grp_a0, grp_a1, grp_stride);
     return hipGetLastError();
 }
 
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ W, co
         acc[r] = ch < c_out ? bias[ch] : 0.0f;
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+
     for (int k0 = 0; k0 < c_in; k0 += 8) {
         const f32x4 a = row_ok ? *reinterpret_cast<const f32x4*>(wp + k0) : zero;
         const f32x4 bv = item_ok ? *reinterpret_cast<const f32x4*>(xp + k0) : zero;

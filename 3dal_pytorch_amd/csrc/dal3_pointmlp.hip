@@ -15,47 +15,72 @@
 #include "dal3_device.h"
 #include "dal3_kernels.h"
 
+// Diagnostic build only (-DDAL3_STAMP): s_memtime stamps of the decode kernel's phases, written to a
+// buffer of their own (dal3_debug_set_stamps). No stamp executes in the shipped library.
+#ifdef DAL3_STAMP
+__device__ long long* g_stamps = nullptr;
+extern "C" int dal3_debug_set_stamps(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p));
+}
+#define STAMP(k)                                                                                  \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (lane == 0 && blockIdx.x < 2048) g_stamps[(blockIdx.x * DAL3_WG_WAVES + wave) * 8 + (k)] = t_; \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
 // ------------------------------------------------------------------------------------------------
+// Every kernel reads its MFMA weights as ONE fragment stream in consumption order (see InsSegW /
+// PointHeadW) through one prefetch ring that never restarts between layers.
 template <int T>
-__global__ __launch_bounds__(256) void ins_seg_encode_kernel(InsSegW w, BCN pts, int c_in, int n_pts,
+__global__ __launch_bounds__(64 * DAL3_WG_WAVES) void ins_seg_encode_kernel(InsSegW w, BCN pts, int c_in, int n_pts,
                                                              int tiles_per_item, float* __restrict__ g) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
     const int64_t b = blockIdx.x / tiles_per_item;
-    const int n0 = ((blockIdx.x % tiles_per_item) * 4 + wave) * (32 * T);
+    const int n0 = ((blockIdx.x % tiles_per_item) * DAL3_WG_WAVES + wave) * (32 * T);
+    __shared__ float s_b5[1024];                       // conv5's folded bias, read by the max epilogue
+    for (int i = threadIdx.x; i < 1024; i += 64 * DAL3_WG_WAVES) s_b5[i] = w.b5[i];
+    __syncthreads();
     if (n0 >= n_pts) return;
 
+    WRing<DAL3_PF> ring;
+    ring.init(w.enc_stream, lane);                     // conv2 | conv3 | conv4 | conv5
+    f32x16 bias = tile_from_channels(w.b2, h);
     float in[T][2];
     load_points<2, T>(pts, b, n0, n_pts, c_in, in, lane);
     f32x16 x1[T][2], x2[T][2], x3[T][2], x4[T][4];
     first_layer<2, 2, T>(w.w1, w.b1, in, x1, lane);
-    mlp_layer<2, 2, T>(w.w2, w.b2, x1, x2, lane);
-    mlp_layer<2, 2, T>(w.w3, w.b3, x2, x3, lane);
-    mlp_layer<2, 4, T>(w.w4, w.b4, x3, x4, lane);
-
-    const int h = lane >> 5;
-    float* gb = g + b * 1024;
-    for (int mt = 0; mt < 32; ++mt) {
-        f32x16 acc[T];
-        const f32x16 bias = tile_from_channels(w.b5 + 32 * mt, h);
-#pragma unroll
-        for (int j = 0; j < T; ++j) acc[j] = bias;
-        mma_block<4, T>(w.w5 + mt * 4 * 256, x4, acc, lane);
-        tile_max_atomic<T>(acc, gb + 32 * mt, lane);
-    }
+    mlp_layer_ring<2, 2, T>(ring, w.b2, w.b3, bias, x1, x2, lane);
+    mlp_layer_ring<2, 2, T>(ring, w.b3, w.b4, bias, x2, x3, lane);
+    mlp_layer_ring<2, 4, T>(ring, w.b4, w.b4, bias, x3, x4, lane);
+    conv_max_layer<4, T>(ring, s_b5, x4, g + b * 1024, 32, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
 template <int T>
-__global__ __launch_bounds__(256) void ins_seg_decode_kernel(InsSegW w, BCN pts, int c_in, int n_pts,
+__global__ __launch_bounds__(64 * DAL3_WG_WAVES) void ins_seg_decode_kernel(InsSegW w, BCN pts, int c_in, int n_pts,
                                                              int tiles_per_item, const float* __restrict__ gbias,
                                                              float* __restrict__ logits, uint8_t* __restrict__ mask) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
     const int64_t b = blockIdx.x / tiles_per_item;
-    const int n0 = ((blockIdx.x % tiles_per_item) * 4 + wave) * (32 * T);
+    const int n0 = ((blockIdx.x % tiles_per_item) * DAL3_WG_WAVES + wave) * (32 * T);
     if (n0 >= n_pts) return;
+
+    STAMP(0);
+    // stream: conv2 | dconv1a(0) | { dconv1a(c+1), dconv2(c) } c = 0..15 | dconv3 | dconv4
+    WRing<DAL3_PF> ring;
+    ring.init(w.dec_stream, lane);
+    f32x16 bias = tile_from_channels(w.b2, h);
+    const float* gb = gbias + b * 512;                 // W1g . g + b1' of this crop
 
     f32x16 x2[T][2];
     {
@@ -63,40 +88,72 @@ __global__ __launch_bounds__(256) void ins_seg_decode_kernel(InsSegW w, BCN pts,
         load_points<2, T>(pts, b, n0, n_pts, c_in, in, lane);
         f32x16 x1[T][2];
         first_layer<2, 2, T>(w.w1, w.b1, in, x1, lane);
-        mlp_layer<2, 2, T>(w.w2, w.b2, x1, x2, lane);
+        mlp_layer_ring<2, 2, T>(ring, w.b2, gb, bias, x1, x2, lane);       // leaves bias = gb chunk 0
     }
 
-    // dconv1 (512 outputs, 16 chunks) streamed into dconv2 (256 outputs = 8 accumulator tiles)
+    // dconv1 (512 outputs, 16 chunks of 32) streamed into dconv2 (256 outputs = 8 accumulator tiles).
+    // dconv1 chunk c+1 is computed (into the other t buffer) BEFORE dconv2 consumes chunk c, and the
+    // ReLU of chunk c rides under those MFMAs: no MFMA -> VALU -> MFMA bubble at the chunk seam.
     f32x16 a2[T][8];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
-        const f32x16 bias = tile_from_channels(w.db2 + 32 * mt, h);
+        const f32x16 b2v = tile_from_channels(w.db2 + 32 * mt, h);
 #pragma unroll
-        for (int j = 0; j < T; ++j) a2[j][mt] = bias;
+        for (int j = 0; j < T; ++j) a2[j][mt] = b2v;
     }
-    const float* gb = gbias + b * 512;                 // W1g . g + b1' of this crop
-    for (int c = 0; c < 16; ++c) {
-        f32x16 t[T];
-        const f32x16 init = tile_from_channels(gb + 32 * c, h);
+    STAMP(1);
+    f32x16 tA[T], tB[T];
+    auto dconv2_part = [&](const f32x16 (&t)[T]) {
 #pragma unroll
-        for (int j = 0; j < T; ++j) t[j] = init;
-        mma_block<2, T>(w.dw1a + c * 2 * 256, x2, t, lane);
+        for (int i = 0; i < 32; ++i) {                 // fragment i of the chunk: out-tile i/4, q = i%4
+            ring_batch_wait<DAL3_PF>(ring, i);
+            const f32x4 a = ring.slot[i % DAL3_PF];
+            ring.slot[i % DAL3_PF] = *ring.next;
+#ifdef DAL3_ABLATE_WINDOW
+            ring.next = reinterpret_cast<const f32x4*>(reinterpret_cast<uintptr_t>(ring.next + 64) & ~(uintptr_t)0x2000);
+#else
+            ring.next += 64;
+#endif
 #pragma unroll
-        for (int j = 0; j < T; ++j) t[j] = relu16(t[j]);
-        const f32x4* w2c = w.dw2 + c * 8 * 256;       // K-major: [chunk][mt][q][lane]
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 a = w2c[(mt * 4 + q) * 64 + lane];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                    for (int j = 0; j < T; ++j) a2[j][mt] = mfma32(a[e], t[j][4 * q + e], a2[j][mt]);
-                }
+                for (int j = 0; j < T; ++j) a2[j][i / 4] = mfma32(a[e], t[j][4 * (i % 4) + e], a2[j][i / 4]);
             }
+            DAL3_SCHED_FENCE();
         }
+    };
+#pragma unroll
+    for (int j = 0; j < T; ++j) tA[j] = bias;
+    mma_block_ring<2, T>(ring, x2, tA, [&](int i) {
+        if (i == 0) bias = tile_from_channels(gb + 32, h);
+    });
+    for (int c = 0; c < 16; c += 2) {
+#pragma unroll
+        for (int j = 0; j < T; ++j) tB[j] = bias;
+        mma_block_ring<2, T>(ring, x2, tB, [&](int i) {                // chunk c+1; ReLU(chunk c) in its shadow
+            if (i == 0) bias = tile_from_channels(gb + 32 * ((c + 2) & 15), h);
+#pragma unroll
+            for (int j = 0; j < T; ++j) {              // two registers per fragment group
+                tA[j][2 * i] = relu1(tA[j][2 * i]);
+                tA[j][2 * i + 1] = relu1(tA[j][2 * i + 1]);
+            }
+        });
+        dconv2_part(tA);
+#pragma unroll
+        for (int j = 0; j < T; ++j) tA[j] = bias;
+        // chunk c+2 (on the last round its 8 fragments are the stream's zero filler; the result is unused)
+        mma_block_ring<2, T>(ring, x2, tA, [&](int i) {
+            if (i == 0)
+                bias = c + 2 < 16 ? tile_from_channels(gb + 32 * ((c + 3) & 15), h) : tile_from_channels(w.db3, h);
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                tB[j][2 * i] = relu1(tB[j][2 * i]);
+                tB[j][2 * i + 1] = relu1(tB[j][2 * i + 1]);
+            }
+        });
+        dconv2_part(tB);
     }
+    STAMP(2);
 #pragma unroll
     for (int j = 0; j < T; ++j) {
 #pragma unroll
@@ -104,9 +161,10 @@ __global__ __launch_bounds__(256) void ins_seg_decode_kernel(InsSegW w, BCN pts,
     }
 
     f32x16 y3[T][4], y4[T][4];
-    mlp_layer<8, 4, T>(w.dw3, w.db3, a2, y3, lane);
-    mlp_layer<4, 4, T>(w.dw4, w.db4, y3, y4, lane);
+    mlp_layer_ring<8, 4, T>(ring, w.db3, w.db4, bias, a2, y3, lane);
+    mlp_layer_ring<4, 4, T>(ring, w.db4, w.db4, bias, y3, y4, lane);
 
+    STAMP(3);
     // dconv5 (128 -> 2, no BN/ReLU) on the VALU: each lane holds 64 of its point's 128 channels
     float l0[T], l1[T];
 #pragma unroll
@@ -141,37 +199,36 @@ __global__ __launch_bounds__(256) void ins_seg_decode_kernel(InsSegW w, BCN pts,
             mask[b * n_pts + n] = s0 < s1 ? 1 : 0;      // strict '<': ties are background
         }
     }
+    STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------------
 template <int KS, int C1, int C2, int C3, int T>
-__global__ __launch_bounds__(256) void point_head_kernel(PointHeadW w, BCN x, int c_in, int n_pts,
+__global__ __launch_bounds__(64 * DAL3_WG_WAVES) void point_head_kernel(PointHeadW w, BCN x, int c_in, int n_pts,
                                                          int tiles_per_item, float* __restrict__ feat) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
     const int64_t b = blockIdx.x / tiles_per_item;
-    const int n0 = ((blockIdx.x % tiles_per_item) * 4 + wave) * (32 * T);
+    const int n0 = ((blockIdx.x % tiles_per_item) * DAL3_WG_WAVES + wave) * (32 * T);
+    __shared__ float s_b4[512];                        // conv4's folded bias, read by the max epilogue
+    for (int i = threadIdx.x; i < 512; i += 64 * DAL3_WG_WAVES) s_b4[i] = w.b4[i];
+    __syncthreads();
     if (n0 >= n_pts) return;
 
+    WRing<DAL3_PF> ring;
+    ring.init(w.stream, lane);                         // conv2 | conv3 | conv4
+    f32x16 bias = tile_from_channels(w.b2, h);
     f32x16 x3[T][C3 / 32];
     {
         float in[T][KS];
         load_points<KS, T>(x, b, n0, n_pts, c_in, in, lane);
         f32x16 x1[T][C1 / 32], x2[T][C2 / 32];
         first_layer<KS, C1 / 32, T>(w.w1, w.b1, in, x1, lane);
-        mlp_layer<C1 / 32, C2 / 32, T>(w.w2, w.b2, x1, x2, lane);
-        mlp_layer<C2 / 32, C3 / 32, T>(w.w3, w.b3, x2, x3, lane);
+        mlp_layer_ring<C1 / 32, C2 / 32, T>(ring, w.b2, w.b3, bias, x1, x2, lane);
+        mlp_layer_ring<C2 / 32, C3 / 32, T>(ring, w.b3, w.b3, bias, x2, x3, lane);
     }
-    float* fb = feat + b * 512;
-    for (int mt = 0; mt < 16; ++mt) {
-        f32x16 acc[T];
-        const f32x16 bias = tile_from_channels(w.b4 + 32 * mt, h);
-#pragma unroll
-        for (int j = 0; j < T; ++j) acc[j] = bias;
-        mma_block<C3 / 32, T>(w.w4 + mt * (C3 / 32) * 256, x3, acc, lane);
-        tile_max_atomic<T>(acc, fb + 32 * mt, lane);
-    }
+    conv_max_layer<C3 / 32, T>(ring, s_b4, x3, feat + b * 512, 16, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -228,12 +285,14 @@ __global__ __launch_bounds__(256) void generic_layer_kernel(const f32x4* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-static inline int tiles_per_item(int n_pts, int T) { return (n_pts + 128 * T - 1) / (128 * T); }
+static inline int tiles_per_item(int n_pts, int T) {
+    return (n_pts + 32 * DAL3_WG_WAVES * T - 1) / (32 * DAL3_WG_WAVES * T);
+}
 
 hipError_t launch_ins_seg_encode(const InsSegW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
     constexpr int T = DAL3_ENC_T;
     const int tpi = tiles_per_item(N, T);
-    hipLaunchKernelGGL(ins_seg_encode_kernel<T>, dim3((unsigned)((int64_t)B * tpi)), dim3(256), 0, s, w, pts, c_in, N, tpi, g);
+    hipLaunchKernelGGL(ins_seg_encode_kernel<T>, dim3((unsigned)((int64_t)B * tpi)), dim3(64 * DAL3_WG_WAVES), 0, s, w, pts, c_in, N, tpi, g);
     return hipGetLastError();
 }
 
@@ -241,7 +300,7 @@ hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int
                                  float* logits, uint8_t* mask, hipStream_t s) {
     constexpr int T = DAL3_DEC_T;
     const int tpi = tiles_per_item(N, T);
-    hipLaunchKernelGGL(ins_seg_decode_kernel<T>, dim3((unsigned)((int64_t)B * tpi)), dim3(256), 0, s, w, pts, c_in, N, tpi,
+    hipLaunchKernelGGL(ins_seg_decode_kernel<T>, dim3((unsigned)((int64_t)B * tpi)), dim3(64 * DAL3_WG_WAVES), 0, s, w, pts, c_in, N, tpi,
                        gbias, logits, mask);
     return hipGetLastError();
 }
@@ -249,7 +308,7 @@ hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int
 hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat, hipStream_t s) {
     constexpr int T = DAL3_HEAD_T;
     const int tpi = tiles_per_item(M, T);
-    const dim3 grid((unsigned)((int64_t)B * tpi)), block(256);
+    const dim3 grid((unsigned)((int64_t)B * tpi)), block(64 * DAL3_WG_WAVES);
     switch (head_kind) {
         case 1:  // static box_est 3 -> 128 -> 128 -> 256 -> 512
             hipLaunchKernelGGL((point_head_kernel<2, 128, 128, 256, T>), grid, block, 0, s, w, x, c_in, M, tpi, feat);
