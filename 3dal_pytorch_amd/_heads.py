@@ -129,13 +129,21 @@ class PackedCache:
             s = (s * 1000003 + t._version * 31 + t.data_ptr()) & 0xFFFFFFFFFFFF
         return s
 
-    def get(self, key, module, head_kind):
-        stamp = self._stamp_of(module)
+    def get(self, key, module, head_kind, dtype=_hip.F32):
+        stamp = (self._stamp_of(module), dtype)
         if self._stamp.get(key) != stamp:
             dev = next(module.parameters()).device
-            self._blob[key] = _hip.pack(head_kind, module.pairs(), dev)
+            self._blob[key] = _hip.pack(head_kind, module.pairs(), dev, dtype)
             self._stamp[key] = stamp
         return self._blob[key]
+
+
+def dtype_of(precision):
+    """'fp32' (default, exact-fp32 MFMA) | 'bf16' | 'fp16' (16-bit MFMA operands, fp32 accumulate)."""
+    try:
+        return _hip.DTYPES[precision]
+    except KeyError:
+        raise ValueError(f"unknown precision {precision!r}; use one of {sorted(_hip.DTYPES)}") from None
 
 
 def numpy_choice(counts, m):

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib3dal_hip.so")
 
 OK, EINVAL, EWORKSPACE, EHIP = 0, -1, -2, -3
-F32 = 0
+F32, BF16, F16 = 0, 1, 2
+DTYPES = {"fp32": F32, "bf16": BF16, "fp16": F16}
 HEAD_INS_SEG, HEAD_STATIC_BOX_EST, HEAD_POINT_EMB, HEAD_BOX_EMB, HEAD_DYNAMIC_BOX_EST = range(5)
 SAMPLER_DEVICE, SAMPLER_CHOICE = 0, 1
 PHASE_SEG, PHASE_BOX, PHASE_ALL = 1, 2, 3
@@ -33,7 +34,7 @@ class BCN(C.Structure):
 
 class StaticArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("two_stage", C.c_int32), ("sampler", C.c_int32),
-                ("seed", C.c_uint64), ("item_offset", C.c_int64), ("pts", BCN),
+                ("dtype", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64), ("item_offset", C.c_int64), ("pts", BCN),
                 ("init_box", vp), ("bbox_gt", vp), ("choice", vp),
                 ("w_ins_seg", vp), ("w_box_est_one", vp), ("w_box_est_two", vp),
                 ("logits", vp), ("mask", vp),
@@ -47,7 +48,7 @@ class StaticArgs(C.Structure):
 
 class DynamicArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n_box", C.c_int32), ("sampler", C.c_int32),
-                ("seed", C.c_uint64), ("item_offset", C.c_int64), ("pts", BCN), ("box", BCN),
+                ("dtype", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64), ("item_offset", C.c_int64), ("pts", BCN), ("box", BCN),
                 ("init_box8", vp), ("choice", vp),
                 ("w_ins_seg", vp), ("w_point_emb", vp), ("w_box_emb", vp), ("w_box_est", vp),
                 ("logits", vp), ("mask", vp), ("embedding", vp), ("box_pred", vp),
@@ -63,15 +64,15 @@ SIGNATURES = {
     "dal3_last_error": (C.c_char_p, []),
     "dal3_pack_weights": (_i, [_i, C.POINTER(Layer), _i, _i, vp, C.POINTER(_sz), vp]),
     "dal3_ins_seg_workspace_bytes": (_sz, [_i]),
-    "dal3_ins_seg_forward": (_i, [vp, _i, BCN, _i, _i, vp, vp, vp, vp, _sz, vp]),
-    "dal3_ins_seg_encode": (_i, [vp, _i, BCN, _i, _i, vp, vp]),
-    "dal3_ins_seg_global_bias": (_i, [vp, vp, _i, vp, vp]),
-    "dal3_ins_seg_decode": (_i, [vp, _i, BCN, _i, _i, vp, vp, vp, vp]),
+    "dal3_ins_seg_forward": (_i, [vp, _i, _i, BCN, _i, _i, vp, vp, vp, vp, _sz, vp]),
+    "dal3_ins_seg_encode": (_i, [vp, _i, _i, BCN, _i, _i, vp, vp]),
+    "dal3_ins_seg_global_bias": (_i, [vp, _i, vp, _i, vp, vp]),
+    "dal3_ins_seg_decode": (_i, [vp, _i, _i, BCN, _i, _i, vp, vp, vp, vp]),
     "dal3_gather_workspace_bytes": (_sz, [_i, _i]),
     "dal3_segment_counts": (_i, [vp, _i, _i, vp, vp]),
     "dal3_mask_compact_sample": (_i, [vp, BCN, _i, _i, _i, _i, _i, vp, _u64, _i64, vp, vp, vp, vp, _sz, vp]),
     "dal3_point_head_workspace_bytes": (_sz, [_i]),
-    "dal3_point_head_forward": (_i, [_i, vp, BCN, _i, _i, vp, _i64, vp, _sz, vp]),
+    "dal3_point_head_forward": (_i, [_i, vp, _i, BCN, _i, _i, vp, _i64, vp, _sz, vp]),
     "dal3_dynamic_box_est_forward": (_i, [vp, vp, _i, vp, vp, _sz, vp]),
     "dal3_decode_boxes": (_i, [vp, _i, vp, _i64, _i, vp, _i64, vp, _i64, vp, vp, vp, vp, vp]),
     "dal3_recenter_rotz": (_i, [vp, _i, _i, vp, vp, vp, vp, vp, vp, vp]),
@@ -145,12 +146,12 @@ def layer_struct(conv, bn):
     return L
 
 
-def pack(head_kind, pairs, device):
+def pack(head_kind, pairs, device, dtype=F32):
     """pairs: [(conv_or_linear, bn_or_None), ...] in forward order -> packed uint8 device tensor."""
     arr = (Layer * len(pairs))(*[layer_struct(c, b) for c, b in pairs])
     need = _sz(0)
-    check(lib().dal3_pack_weights(head_kind, arr, len(pairs), F32, None, C.byref(need), None))
+    check(lib().dal3_pack_weights(head_kind, arr, len(pairs), dtype, None, C.byref(need), None))
     buf = torch.empty(need.value, dtype=torch.uint8, device=device)
     assert buf.data_ptr() % 256 == 0
-    check(lib().dal3_pack_weights(head_kind, arr, len(pairs), F32, ptr(buf), C.byref(need), stream()))
+    check(lib().dal3_pack_weights(head_kind, arr, len(pairs), dtype, ptr(buf), C.byref(need), stream()))
     return buf

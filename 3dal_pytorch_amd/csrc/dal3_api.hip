@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "dal3_kernels.h"
+#include "dal3_lp.h"
 
 // ---------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
@@ -136,6 +137,64 @@ FcW fc_head_view(const float* base) {
     return fc_head_walk(c);
 }
 
+// ---- 16-bit heads: fp32 sections first (float cursor), then the fragment streams (bytes)
+static InsSegLpW ins_seg_lp_walk(Cursor& c) {
+    InsSegLpW w;
+    w.w1 = c.take(2 * 2 * 64);
+    w.b1 = c.take(64);
+    w.bias_enc = c.take(1280);
+    w.bias_dec = c.take(864);
+    w.dw1g = c.take(512 * 1024);
+    w.db1 = c.take(512);
+    w.enc_stream = reinterpret_cast<const uint16_t*>(c.take((size_t)LP_ENC_SEGS * LP_ENC_SEG * 256));
+    w.dec_stream = reinterpret_cast<const uint16_t*>(c.take((size_t)LP_DEC_SEGS * LP_DEC_SEG * 256));
+    return w;
+}
+size_t ins_seg_lp_packed_bytes() {
+    Cursor c{nullptr, 0};
+    ins_seg_lp_walk(c);
+    return c.off * sizeof(float);
+}
+InsSegLpW ins_seg_lp_view(const void* base) {
+    Cursor c{static_cast<const float*>(base), 0};
+    return ins_seg_lp_walk(c);
+}
+static int lp_tps(int kt, int mt) { return lp_tiles_per_seg(kt, mt); }
+int point_head_lp_segments(int head_kind) {
+    int c_in, ks, c[4], n_fc, fi[3], fo[3];
+    point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
+    int n = 0;
+    for (int l = 1; l < 4; ++l) n += (c[l] / 32) / lp_tps(c[l - 1] / 32, c[l] / 32);
+    return n;
+}
+static PointHeadLpW point_head_lp_walk(Cursor& cur, int head_kind) {
+    int c_in, ks, c[4], n_fc, fi[3], fo[3];
+    point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
+    PointHeadLpW w;
+    w.w1 = cur.take((size_t)(c[0] / 32) * ks * 64);
+    w.b1 = cur.take(c[0]);
+    w.bias = cur.take(c[1] + c[2] + c[3]);
+    w.fc.n = n_fc;
+    for (int i = 0; i < 3; ++i) {
+        w.fc.c_in[i] = fi[i];
+        w.fc.c_out[i] = fo[i];
+        w.fc.relu[i] = !(head_kind == DAL3_HEAD_STATIC_BOX_EST && i == 2);
+        w.fc.w[i] = i < n_fc ? cur.take((size_t)fi[i] * fo[i]) : nullptr;
+        w.fc.b[i] = i < n_fc ? cur.take((fo[i] + 31) / 32 * 32) : nullptr;
+    }
+    w.stream = reinterpret_cast<const uint16_t*>(cur.take((size_t)point_head_lp_segments(head_kind) * LP_HEAD_SEG * 256));
+    return w;
+}
+size_t point_head_lp_packed_bytes(int head_kind) {
+    Cursor c{nullptr, 0};
+    point_head_lp_walk(c, head_kind);
+    return c.off * sizeof(float);
+}
+PointHeadLpW point_head_lp_view(const void* base, int head_kind) {
+    Cursor c{static_cast<const float*>(base), 0};
+    return point_head_lp_walk(c, head_kind);
+}
+
 // ---------------------------------------------------------------------------------- packing
 static float* mut(const void* p) { return const_cast<float*>(reinterpret_cast<const float*>(p)); }
 
@@ -170,18 +229,21 @@ static int pack_fc(const dal3_layer* L, const FcW& f, hipStream_t s) {
 
 extern "C" int dal3_pack_weights(int head_kind, const dal3_layer* L, int n_layers, int dtype, void* packed_dev,
                                  size_t* bytes_inout, dal3_stream stream) {
-    if (dtype != DAL3_F32) return fail(DAL3_EINVAL, "dal3_pack_weights: only DAL3_F32 is built in this version");
+    if (dtype != DAL3_F32 && dtype != DAL3_BF16 && dtype != DAL3_F16)
+        return fail(DAL3_EINVAL, "dal3_pack_weights: unknown dtype %d", dtype);
     if (!bytes_inout) return fail(DAL3_EINVAL, "dal3_pack_weights: bytes_inout is NULL");
+    const bool lp = dtype != DAL3_F32;
     size_t need;
     switch (head_kind) {
-        case DAL3_HEAD_INS_SEG: need = ins_seg_packed_floats(0); break;
+        case DAL3_HEAD_INS_SEG: need = lp ? ins_seg_lp_packed_bytes() : ins_seg_packed_floats(0) * sizeof(float); break;
         case DAL3_HEAD_STATIC_BOX_EST:
         case DAL3_HEAD_POINT_EMB:
-        case DAL3_HEAD_BOX_EMB: need = point_head_packed_floats(head_kind); break;
-        case DAL3_HEAD_DYNAMIC_BOX_EST: need = fc_head_packed_floats(); break;
+        case DAL3_HEAD_BOX_EMB:
+            need = lp ? point_head_lp_packed_bytes(head_kind) : point_head_packed_floats(head_kind) * sizeof(float);
+            break;
+        case DAL3_HEAD_DYNAMIC_BOX_EST: need = fc_head_packed_floats() * sizeof(float); break;   // FC only: fp32 in every dtype
         default: return fail(DAL3_EINVAL, "dal3_pack_weights: unknown head_kind %d", head_kind);
     }
-    need *= sizeof(float);
     if (!packed_dev) {
         *bytes_inout = need;
         return 0;
@@ -200,6 +262,40 @@ extern "C" int dal3_pack_weights(int head_kind, const dal3_layer* L, int n_layer
         static const int co[10] = {64, 64, 64, 128, 1024, 512, 256, 128, 128, 2};
         static const int ci[10] = {0, 64, 64, 64, 128, 1088, 512, 256, 128, 128};
         for (int i = 0; i < 10; ++i) TRY(check_layer(L[i], i == 0 ? c_in : ci[i], co[i], "ins_seg layer"));
+        if (lp) {
+            const InsSegLpW w = ins_seg_lp_view(packed_dev);
+            uint16_t* enc = const_cast<uint16_t*>(w.enc_stream);
+            uint16_t* dec = const_cast<uint16_t*>(w.dec_stream);
+            float* be = mut(w.bias_enc);
+            float* bd = mut(w.bias_dec);
+            const int64_t F = 512;                                    // 16-bit elements per fragment
+            HIP_TRY(launch_pack_weight(L[0], PACK_FIRST, 0, c_in, 2, 2, mut(w.w1), s));
+            HIP_TRY(launch_pack_bias(L[0], mut(w.b1), s));
+            HIP_TRY(launch_pack_bias(L[1], be, s));
+            HIP_TRY(launch_pack_bias(L[2], be + 64, s));
+            HIP_TRY(launch_pack_bias(L[3], be + 128, s));
+            HIP_TRY(launch_pack_bias(L[4], be + 256, s));
+            HIP_TRY(launch_pack_bias(L[1], bd, s));
+            HIP_TRY(launch_pack_bias(L[6], bd + 64, s));
+            HIP_TRY(launch_pack_bias(L[7], bd + 320, s));
+            HIP_TRY(launch_pack_bias(L[8], bd + 448, s));
+            HIP_TRY(launch_pack_weight(L[9], PACK_ROWMAJOR, 0, 128, 0, 0, bd + 576, s));
+            HIP_TRY(launch_pack_bias(L[9], bd + 832, s));
+            HIP_TRY(launch_pack_weight(L[5], PACK_ROWMAJOR, 64, 1024, 0, 0, mut(w.dw1g), s));
+            HIP_TRY(launch_pack_bias(L[5], mut(w.db1), s));
+            // encode stream (fragments): conv2 @0 | conv3 @8 | conv4 @16 | conv5 @32
+            HIP_TRY(launch_pack_weight_lp(L[1], dtype, 0, 0, 64, 2, 2, enc, s));
+            HIP_TRY(launch_pack_weight_lp(L[2], dtype, 0, 0, 64, 2, 2, enc + 8 * F, s));
+            HIP_TRY(launch_pack_weight_lp(L[3], dtype, 0, 0, 64, 4, 2, enc + 16 * F, s));
+            HIP_TRY(launch_pack_weight_lp(L[4], dtype, 0, 0, 128, 32, 4, enc + 32 * F, s));
+            // decode stream, segments of 40: [conv2 @0, 1a(0) @8] ; 1a(c>=1) @40+20(c-1) ; 2(c) @44+20c ; dconv3 @360,@400 ; dconv4 @440
+            HIP_TRY(launch_pack_weight_lp(L[1], dtype, 0, 0, 64, 2, 2, dec, s));
+            HIP_TRY(launch_pack_weight_lp(L[5], dtype, 0, 0, 64, 16, 2, dec, s, 2, 8 * F, 40 * F, 20 * F));
+            HIP_TRY(launch_pack_weight_lp(L[6], dtype, 1, 0, 512, 8, 16, dec, s, 8, 44 * F, 64 * F, 20 * F));
+            HIP_TRY(launch_pack_weight_lp(L[7], dtype, 0, 0, 256, 4, 8, dec, s, 16, 360 * F, 400 * F, 40 * F));
+            HIP_TRY(launch_pack_weight_lp(L[8], dtype, 0, 0, 128, 4, 4, dec + 440 * F, s));
+            return 0;
+        }
         InsSegW w = ins_seg_view(base, c_in);
         HIP_TRY(launch_pack_weight(L[0], PACK_FIRST, 0, c_in, 2, 2, mut(w.w1), s));
         HIP_TRY(launch_pack_bias(L[0], mut(w.b1), s));
@@ -230,6 +326,24 @@ extern "C" int dal3_pack_weights(int head_kind, const dal3_layer* L, int n_layer
     if (n_layers != 4 + n_fc) return fail(DAL3_EINVAL, "head %d expects %d layers, got %d", head_kind, 4 + n_fc, n_layers);
     TRY(check_layer(L[0], c_in, c[0], "conv1"));
     for (int i = 1; i < 4; ++i) TRY(check_layer(L[i], c[i - 1], c[i], "conv"));
+    if (lp) {
+        const PointHeadLpW w = point_head_lp_view(packed_dev, head_kind);
+        HIP_TRY(launch_pack_weight(L[0], PACK_FIRST, 0, c_in, c[0] / 32, ks, mut(w.w1), s));
+        HIP_TRY(launch_pack_bias(L[0], mut(w.b1), s));
+        HIP_TRY(launch_pack_bias(L[1], mut(w.bias), s));
+        HIP_TRY(launch_pack_bias(L[2], mut(w.bias) + c[1], s));
+        HIP_TRY(launch_pack_bias(L[3], mut(w.bias) + c[1] + c[2], s));
+        uint16_t* st = const_cast<uint16_t*>(w.stream);
+        const int64_t SEGE = (int64_t)LP_HEAD_SEG * 512;           // elements per ring segment
+        int seg = 0;
+        for (int l = 1; l < 4; ++l) {                              // each layer: TPS out-tiles per segment
+            const int kt = c[l - 1] / 32, mt = c[l] / 32, tps = lp_tps(kt, mt);
+            HIP_TRY(launch_pack_weight_lp(L[l], dtype, 0, 0, c[l - 1], mt, kt, st, s, tps * kt, seg * SEGE,
+                                          (seg + 1) * SEGE, SEGE));
+            seg += mt / tps;
+        }
+        return pack_fc(L + 4, w.fc, s);
+    }
     PointHeadW w = point_head_view(base, head_kind);
     HIP_TRY(launch_pack_weight(L[0], PACK_FIRST, 0, c_in, c[0] / 32, ks, mut(w.w1), s));
     HIP_TRY(launch_pack_bias(L[0], mut(w.b1), s));
@@ -278,59 +392,84 @@ extern "C" size_t dal3_ins_seg_workspace_bytes(int B) {
     return c.off;
 }
 
-static int ins_seg_run(const void* packed, int c_in, const dal3_bcn& pts, int B, int N, float* logits, uint8_t* mask,
-                       float* global_feat_out, const InsSegWs& ws, hipStream_t s) {
+static int check_dtype(int dtype) {
+    if (dtype != DAL3_F32 && dtype != DAL3_BF16 && dtype != DAL3_F16) return fail(DAL3_EINVAL, "unknown dtype %d", dtype);
+    return 0;
+}
+
+static int ins_seg_run(const void* packed, int dtype, int c_in, const dal3_bcn& pts, int B, int N, float* logits,
+                       uint8_t* mask, float* global_feat_out, const InsSegWs& ws, hipStream_t s) {
+    TRY(check_dtype(dtype));
     if (!packed || !logits || !mask) return fail(DAL3_EINVAL, "ins_seg: null pointer");
     if (B <= 0 || N <= 0) return fail(DAL3_EINVAL, "ins_seg: B and N must be positive (B=%d N=%d)", B, N);
     if (c_in != 3 && c_in != 4) return fail(DAL3_EINVAL, "ins_seg: c_in must be 3 or 4");
     TRY(check_bcn(pts, "pts"));
-    const InsSegW w = ins_seg_view(static_cast<const float*>(packed), c_in);
     const BCN x = to_bcn(pts);
     HIP_TRY(hipMemsetAsync(ws.g, 0, (size_t)B * 1024 * sizeof(float), s));
-    HIP_TRY(launch_ins_seg_encode(w, x, c_in, B, N, ws.g, s));
-    // per-crop part of dconv1: gb = W1g' . g + b1'   (static_model.py:286-289 without the repeat+cat)
-    HIP_TRY(launch_fc(w.dw1g, w.db1, ws.g, 1024, ws.gb, 512, B, 1024, 512, 0, s));
-    HIP_TRY(launch_ins_seg_decode(w, x, c_in, B, N, ws.gb, logits, mask, s));
+    if (dtype == DAL3_F32) {
+        const InsSegW w = ins_seg_view(static_cast<const float*>(packed), c_in);
+        HIP_TRY(launch_ins_seg_encode(w, x, c_in, B, N, ws.g, s));
+        // per-crop part of dconv1: gb = W1g' . g + b1'   (static_model.py:286-289 without the repeat+cat)
+        HIP_TRY(launch_fc(w.dw1g, w.db1, ws.g, 1024, ws.gb, 512, B, 1024, 512, 0, s));
+        HIP_TRY(launch_ins_seg_decode(w, x, c_in, B, N, ws.gb, logits, mask, s));
+    } else {
+        const InsSegLpW w = ins_seg_lp_view(packed);
+        HIP_TRY(launch_ins_seg_encode_lp(dtype, w, x, c_in, B, N, ws.g, s));
+        HIP_TRY(launch_fc(w.dw1g, w.db1, ws.g, 1024, ws.gb, 512, B, 1024, 512, 0, s));
+        HIP_TRY(launch_ins_seg_decode_lp(dtype, w, x, c_in, B, N, ws.gb, logits, mask, s));
+    }
     if (global_feat_out)
         HIP_TRY(hipMemcpyAsync(global_feat_out, ws.g, (size_t)B * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
-extern "C" int dal3_ins_seg_forward(const void* packed, int c_in, dal3_bcn pts, int B, int N, float* logits,
+extern "C" int dal3_ins_seg_forward(const void* packed, int dtype, int c_in, dal3_bcn pts, int B, int N, float* logits,
                                     uint8_t* mask, float* global_feat_out, void* workspace, size_t workspace_bytes,
                                     dal3_stream stream) {
     if (!workspace) return fail(DAL3_EINVAL, "ins_seg: workspace is NULL");
     Carver c(workspace, workspace_bytes);
     const InsSegWs ws = carve_ins_seg(c, B);
     if (!c.ok) return fail(DAL3_EWORKSPACE, "ins_seg: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
-    return ins_seg_run(packed, c_in, pts, B, N, logits, mask, global_feat_out, ws, static_cast<hipStream_t>(stream));
+    return ins_seg_run(packed, dtype, c_in, pts, B, N, logits, mask, global_feat_out, ws, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int dal3_ins_seg_encode(const void* packed, int c_in, dal3_bcn pts, int B, int N, float* global_feat,
-                                   dal3_stream stream) {
+extern "C" int dal3_ins_seg_encode(const void* packed, int dtype, int c_in, dal3_bcn pts, int B, int N,
+                                   float* global_feat, dal3_stream stream) {
+    TRY(check_dtype(dtype));
     if (!packed || !global_feat || B <= 0 || N <= 0 || (c_in != 3 && c_in != 4))
         return fail(DAL3_EINVAL, "ins_seg_encode: bad argument");
     TRY(check_bcn(pts, "pts"));
-    HIP_TRY(launch_ins_seg_encode(ins_seg_view(static_cast<const float*>(packed), c_in), to_bcn(pts), c_in, B, N,
-                                  global_feat, static_cast<hipStream_t>(stream)));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == DAL3_F32)
+        HIP_TRY(launch_ins_seg_encode(ins_seg_view(static_cast<const float*>(packed), c_in), to_bcn(pts), c_in, B, N,
+                                      global_feat, s));
+    else
+        HIP_TRY(launch_ins_seg_encode_lp(dtype, ins_seg_lp_view(packed), to_bcn(pts), c_in, B, N, global_feat, s));
     return 0;
 }
 
-extern "C" int dal3_ins_seg_global_bias(const void* packed, const float* global_feat, int B, float* gbias,
+extern "C" int dal3_ins_seg_global_bias(const void* packed, int dtype, const float* global_feat, int B, float* gbias,
                                         dal3_stream stream) {
+    TRY(check_dtype(dtype));
     if (!packed || !global_feat || !gbias || B <= 0) return fail(DAL3_EINVAL, "ins_seg_global_bias: bad argument");
-    const InsSegW w = ins_seg_view(static_cast<const float*>(packed), 3);
-    HIP_TRY(launch_fc(w.dw1g, w.db1, global_feat, 1024, gbias, 512, B, 1024, 512, 0, static_cast<hipStream_t>(stream)));
+    const float* dw1g = dtype == DAL3_F32 ? ins_seg_view(static_cast<const float*>(packed), 3).dw1g : ins_seg_lp_view(packed).dw1g;
+    const float* db1 = dtype == DAL3_F32 ? ins_seg_view(static_cast<const float*>(packed), 3).db1 : ins_seg_lp_view(packed).db1;
+    HIP_TRY(launch_fc(dw1g, db1, global_feat, 1024, gbias, 512, B, 1024, 512, 0, static_cast<hipStream_t>(stream)));
     return 0;
 }
 
-extern "C" int dal3_ins_seg_decode(const void* packed, int c_in, dal3_bcn pts, int B, int N, const float* gbias,
-                                   float* logits, uint8_t* mask, dal3_stream stream) {
+extern "C" int dal3_ins_seg_decode(const void* packed, int dtype, int c_in, dal3_bcn pts, int B, int N,
+                                   const float* gbias, float* logits, uint8_t* mask, dal3_stream stream) {
+    TRY(check_dtype(dtype));
     if (!packed || !gbias || !logits || !mask || B <= 0 || N <= 0 || (c_in != 3 && c_in != 4))
         return fail(DAL3_EINVAL, "ins_seg_decode: bad argument");
     TRY(check_bcn(pts, "pts"));
-    HIP_TRY(launch_ins_seg_decode(ins_seg_view(static_cast<const float*>(packed), c_in), to_bcn(pts), c_in, B, N, gbias,
-                                  logits, mask, static_cast<hipStream_t>(stream)));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == DAL3_F32)
+        HIP_TRY(launch_ins_seg_decode(ins_seg_view(static_cast<const float*>(packed), c_in), to_bcn(pts), c_in, B, N,
+                                      gbias, logits, mask, s));
+    else
+        HIP_TRY(launch_ins_seg_decode_lp(dtype, ins_seg_lp_view(packed), to_bcn(pts), c_in, B, N, gbias, logits, mask, s));
     return 0;
 }
 
@@ -402,8 +541,9 @@ static int fc_chain(const FcW& f, const float* x, int64_t xs, float* out, int64_
     return 0;
 }
 
-static int point_head_run(int head_kind, const void* packed, const dal3_bcn& x, int B, int M, float* out,
+static int point_head_run(int head_kind, const void* packed, int dtype, const dal3_bcn& x, int B, int M, float* out,
                           int64_t out_stride, const HeadWs& ws, hipStream_t s) {
+    TRY(check_dtype(dtype));
     if (head_kind != DAL3_HEAD_STATIC_BOX_EST && head_kind != DAL3_HEAD_POINT_EMB && head_kind != DAL3_HEAD_BOX_EMB)
         return fail(DAL3_EINVAL, "point_head: head_kind %d is not a point head", head_kind);
     if (!packed || !out) return fail(DAL3_EINVAL, "point_head: null pointer");
@@ -411,20 +551,25 @@ static int point_head_run(int head_kind, const void* packed, const dal3_bcn& x, 
     TRY(check_bcn(x, "x"));
     int c_in, ks, c[4], n_fc, fi[3], fo[3];
     point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
-    const PointHeadW w = point_head_view(static_cast<const float*>(packed), head_kind);
     HIP_TRY(hipMemsetAsync(ws.feat, 0, (size_t)B * 512 * sizeof(float), s));
+    if (dtype != DAL3_F32) {
+        const PointHeadLpW w = point_head_lp_view(packed, head_kind);
+        HIP_TRY(launch_point_head_lp(dtype, head_kind, w, to_bcn(x), c_in, B, M, ws.feat, s));
+        return fc_chain(w.fc, ws.feat, 512, out, out_stride, B, ws.t1, ws.t2, s);
+    }
+    const PointHeadW w = point_head_view(static_cast<const float*>(packed), head_kind);
     HIP_TRY(launch_point_head(head_kind, w, to_bcn(x), c_in, B, M, ws.feat, s));
     return fc_chain(w.fc, ws.feat, 512, out, out_stride, B, ws.t1, ws.t2, s);
 }
 
-extern "C" int dal3_point_head_forward(int head_kind, const void* packed, dal3_bcn x, int B, int M, float* out,
+extern "C" int dal3_point_head_forward(int head_kind, const void* packed, int dtype, dal3_bcn x, int B, int M, float* out,
                                        int64_t out_stride, void* workspace, size_t workspace_bytes,
                                        dal3_stream stream) {
     if (!workspace) return fail(DAL3_EINVAL, "point_head: workspace is NULL");
     Carver c(workspace, workspace_bytes);
     const HeadWs ws = carve_head(c, B);
     if (!c.ok) return fail(DAL3_EWORKSPACE, "point_head: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
-    return point_head_run(head_kind, packed, x, B, M, out, out_stride, ws, static_cast<hipStream_t>(stream));
+    return point_head_run(head_kind, packed, dtype, x, B, M, out, out_stride, ws, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dal3_dynamic_box_est_forward(const void* packed, const float* embedding, int B, float* box_pred,
@@ -527,7 +672,7 @@ extern "C" int dal3_static_forward(const dal3_static_args* a, int phases, dal3_s
     const int B = a->B, N = a->N, M = 512;
 
     if (phases & DAL3_PHASE_SEG) {
-        TRY(ins_seg_run(a->w_ins_seg, 3, a->pts, B, N, a->logits, a->mask, nullptr, ws.seg, s));
+        TRY(ins_seg_run(a->w_ins_seg, a->dtype, 3, a->pts, B, N, a->logits, a->mask, nullptr, ws.seg, s));
         if (a->counts) HIP_TRY(launch_segment_counts(a->mask, B, N, a->counts, s));
     }
     if (!(phases & DAL3_PHASE_BOX)) return 0;
@@ -537,7 +682,7 @@ extern "C" int dal3_static_forward(const dal3_static_args* a, int phases, dal3_s
     TRY(gather_run(a->mask, a->pts, B, N, 3, M, a->sampler, a->choice, a->seed, a->item_offset, a->counts, a->obj_idx,
                    ws.obj, ws.pos, s));
     const dal3_bcn obj{ws.obj, (int64_t)M * 3, 1, 3};
-    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_one, obj, B, M, a->box_pred_one, 39, ws.head, s));
+    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_one, a->dtype, obj, B, M, a->box_pred_one, 39, ws.head, s));
     if (!a->two_stage) {
         // center = center_boxnet + init_box[:, :3] (static_model.py:132); yaw += init yaw (static_eval.py:280)
         HIP_TRY(launch_decode_boxes(a->box_pred_one, B, a->init_box, 7, 0, nullptr, 0, a->init_box + 6, 7,
@@ -553,7 +698,7 @@ extern "C" int dal3_static_forward(const dal3_static_args* a, int phases, dal3_s
                             a->bbox_gt ? a->heading_class_label_two : nullptr,
                             a->bbox_gt ? a->heading_residuals_label_two : nullptr, s));
     const dal3_bcn obj2{ws.obj2, (int64_t)M * 3, 1, 3};
-    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_two, obj2, B, M, a->box_pred_two, 39, ws.head, s));
+    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_two, a->dtype, obj2, B, M, a->box_pred_two, 39, ws.head, s));
     // center_two += center_one (static_model.py:211); final yaw += box_one yaw (static_eval.py:282)
     HIP_TRY(launch_decode_boxes(a->box_pred_two, B, a->center_one, 3, 1, nullptr, 0, a->box_one + 6, 7,
                                 a->heading_residuals_two, a->size_residuals_two, a->center_two, a->boxes7, s));
@@ -588,7 +733,7 @@ extern "C" int dal3_dynamic_forward(const dal3_dynamic_args* a, int phases, dal3
     if (!c.ok) return fail(DAL3_EWORKSPACE, "dynamic_forward: workspace needs %zu bytes, got %zu", c.off, a->workspace_bytes);
 
     if (phases & DAL3_PHASE_SEG) {
-        TRY(ins_seg_run(a->w_ins_seg, 4, a->pts, B, N, a->logits, a->mask, nullptr, ws.seg, s));
+        TRY(ins_seg_run(a->w_ins_seg, a->dtype, 4, a->pts, B, N, a->logits, a->mask, nullptr, ws.seg, s));
         if (a->counts) HIP_TRY(launch_segment_counts(a->mask, B, N, a->counts, s));
     }
     if (!(phases & DAL3_PHASE_BOX)) return 0;
@@ -599,8 +744,8 @@ extern "C" int dal3_dynamic_forward(const dal3_dynamic_args* a, int phases, dal3
                    ws.obj, ws.pos, s));
     const dal3_bcn obj{ws.obj, (int64_t)M * 4, 1, 4};
     // embedding = cat[point_e (256), box_e (128)] (dynamic_model.py:133-137): written side by side
-    TRY(point_head_run(DAL3_HEAD_POINT_EMB, a->w_point_emb, obj, B, M, a->embedding, 384, ws.head, s));
-    TRY(point_head_run(DAL3_HEAD_BOX_EMB, a->w_box_emb, a->box, B, a->n_box, a->embedding + 256, 384, ws.head, s));
+    TRY(point_head_run(DAL3_HEAD_POINT_EMB, a->w_point_emb, a->dtype, obj, B, M, a->embedding, 384, ws.head, s));
+    TRY(point_head_run(DAL3_HEAD_BOX_EMB, a->w_box_emb, a->dtype, a->box, B, a->n_box, a->embedding + 256, 384, ws.head, s));
     TRY(fc_chain(fc_head_view(static_cast<const float*>(a->w_box_est)), a->embedding, 384, a->box_pred, 39, B,
                  ws.head.t1, ws.head.t2, s));
     // forward() adds nothing to the centre; the eval driver adds init_box[:, :3] and yaw init_box[:, -2]

@@ -78,6 +78,54 @@ struct PointHeadW {
     FcW fc;
 };
 
+// ---- 16-bit (bf16 / fp16) packed heads: fp32 first layer, biases and FC; MFMA weights as one stream of
+// 1-KiB fragments (512 16-bit elements) per kernel, cut into ring segments (dal3_lp.h)
+#define LP_ENC_SEG 32     // fragments per ring segment
+#define LP_ENC_SEGS 9     // conv2|conv3|conv4 , then conv5 four out-tiles per segment
+#define LP_DEC_SEG 40
+#define LP_DEC_SEGS 12    // [conv2, dconv1a(0)] , 8 x [1a(2i+1), 2(2i), 1a(2i+2), 2(2i+1)] , dconv3 x2 , dconv4
+#define LP_HEAD_SEG 32
+#ifndef DAL3_LP_ENC_T
+#define DAL3_LP_ENC_T 4
+#endif
+#ifndef DAL3_LP_DEC_T
+#define DAL3_LP_DEC_T 2
+#endif
+#ifndef DAL3_LP_HEAD_T
+#define DAL3_LP_HEAD_T 2
+#endif
+struct InsSegLpW {
+    const float* w1;          // fp32 first layer [2][2][64]
+    const float* b1;
+    const float* bias_enc;    // b2 64 | b3 64 | b4 128 | b5 1024
+    const float* bias_dec;    // b2 64 | db2 256 | db3 128 | db4 128 | dw5 (2,128) | db5 (32)
+    const float* dw1g;        // fp32 row-major (512,1024)
+    const float* db1;         // 512
+    const uint16_t* enc_stream;
+    const uint16_t* dec_stream;
+};
+struct PointHeadLpW {
+    const float* w1;
+    const float* b1;
+    const float* bias;        // b2 C2 | b3 C3 | b4 512
+    const uint16_t* stream;
+    FcW fc;
+};
+size_t ins_seg_lp_packed_bytes();
+InsSegLpW ins_seg_lp_view(const void* base);
+size_t point_head_lp_packed_bytes(int head_kind);
+PointHeadLpW point_head_lp_view(const void* base, int head_kind);
+int point_head_lp_segments(int head_kind);
+hipError_t launch_ins_seg_encode_lp(int dtype, const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s);
+hipError_t launch_ins_seg_decode_lp(int dtype, const InsSegLpW& w, BCN pts, int c_in, int B, int N, const float* gbias,
+                                    float* logits, uint8_t* mask, hipStream_t s);
+hipError_t launch_point_head_lp(int dtype, int head_kind, const PointHeadLpW& w, BCN x, int c_in, int B, int M,
+                                float* feat, hipStream_t s);
+// 16-bit fragment packing: element j of lane l of fragment (mt,kt,s) = W'[32mt + (l&31)][32kt + 16s + 8(j>>2) + 4(l>>5) + (j&3)]
+hipError_t launch_pack_weight_lp(const dal3_layer& L, int dtype, int kt_major, int col_off, int n_cols, int mt_n, int kt_n,
+                                 uint16_t* out, hipStream_t s, int grp_blocks = 0, int64_t grp_a0 = 0, int64_t grp_a1 = 0,
+                                 int64_t grp_stride = 0);
+
 // layout (offsets in floats from the blob start); all sections 256-byte aligned
 size_t ins_seg_packed_floats(int c_in);
 InsSegW ins_seg_view(const float* base, int c_in);

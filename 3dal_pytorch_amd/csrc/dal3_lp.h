@@ -1,0 +1,192 @@
+// dal3_lp.h — building blocks of the bf16 / fp16 MFMA path (v_mfma_f32_32x32x16_{bf16,f16}, fp32
+// accumulate). Same orientation as the fp32 path (channels on MFMA rows, points on columns): the
+// fp32 accumulator of layer k, ReLU'd and rounded to 16 bits pairwise, IS the B operand of layer k+1
+// (cdna guide "An accumulator tile as the next MFMA's operand": registers 8s..8s+7 are the fragment
+// of k-step s, element j of lane half h being channel 16s + 8(j>>2) + 4h + (j&3); the weight packer
+// permutes the A operand's k order to match), so activations never leave registers.
+//
+// Weights: at 32 cycles per MFMA a wave would need 1 KiB of A operand every 32*T cycles — far more
+// than per-wave L2 streams can deliver — so the four waves of a workgroup share them through LDS.
+// Each kernel's fragments form one stream in consumption order, cut into fixed segments of SEG
+// fragments (1 KiB each); a 3-slot LDS ring is filled by LDS-DMA (global_load_lds, 16 B per lane,
+// lane-linear = exactly one fragment per wave-instruction) two segments ahead of the MFMAs. Per
+// segment: every wave waits for its own DMA share with a COUNTED vmcnt (the next segment's loads stay
+// in flight), one raw s_barrier publishes the slot and frees the oldest one, the next fill is issued,
+// and the fragments are read back with ds_read_b128. Ordinary global loads are kept out of the loops
+// (biases and the per-crop dconv1 term are staged in LDS once) because hipcc drains vmcnt(0) for them.
+#pragma once
+#include "dal3_device.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+struct BF16 {
+    typedef bf16x8_t v8;
+    typedef __bf16 elem;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+struct FP16 {
+    typedef f16x8_t v8;
+    typedef _Float16 elem;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// B-operand fragments of one 32-channel x 32-point activation tile (two k-steps of 16 channels)
+template <class DT>
+struct ActTile {
+    typename DT::v8 k[2];
+};
+
+template <class DT>
+__device__ __forceinline__ ActTile<DT> pack_relu(const f32x16& acc) {
+    ActTile<DT> t;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t.k[s][j] = (typename DT::elem)relu1(acc[8 * s + j]);
+    }
+    return t;
+}
+
+#define LP_SLOTS 3
+
+// LDS ring of weight segments. All state is wave-uniform.
+template <int SEG>
+struct LdsRing {
+    static constexpr int SLOT_BYTES = SEG * 1024;
+    static constexpr int MY_LOADS = SEG / 4;              // LDS-DMA instructions per wave per segment (4 waves)
+    static_assert(SEG % 4 == 0, "segment must split evenly over the 4 waves");
+    const char* stream;                                   // global: this kernel's fragment stream
+    char* lds;                                            // LDS: LP_SLOTS * SLOT_BYTES
+    int n_segs, seg_issue, slot_issue, slot_use, wave, lane;
+
+    __device__ __forceinline__ void init(const void* stream_, char* lds_, int n_segs_, int wave_, int lane_) {
+        stream = static_cast<const char*>(stream_);
+        lds = lds_;
+        n_segs = n_segs_;
+        wave = __builtin_amdgcn_readfirstlane(wave_);
+        lane = lane_;
+        seg_issue = 0;
+        slot_issue = 0;
+        slot_use = LP_SLOTS - 1;
+        issue();                                          // segments 0 and 1 in flight before the first acquire
+        issue();
+    }
+    // this wave's quarter of the next segment -> slot_issue (past the stream's end: re-read the last one)
+    __device__ __forceinline__ void issue() {
+        const int seg = seg_issue < n_segs ? seg_issue : n_segs - 1;
+        const char* src = stream + (size_t)seg * SLOT_BYTES + lane * 16;
+        char* dst = lds + slot_issue * SLOT_BYTES;
+#pragma unroll
+        for (int k = 0; k < MY_LOADS; ++k) {
+            const int f = wave + 4 * k;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+        }
+        ++seg_issue;
+        slot_issue = slot_issue + 1 == LP_SLOTS ? 0 : slot_issue + 1;
+    }
+    // make the next segment readable: my share landed (the following segment's MY_LOADS loads may stay in
+    // flight), everyone's share landed and everyone is done with the slot about to be refilled (barrier)
+    __device__ __forceinline__ void acquire() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MY_LOADS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        slot_use = slot_use + 1 == LP_SLOTS ? 0 : slot_use + 1;
+        issue();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <class DT>
+    __device__ __forceinline__ typename DT::v8 frag(int f) const {
+        return *reinterpret_cast<const typename DT::v8*>(lds + slot_use * SLOT_BYTES + f * 1024 + lane * 16);
+    }
+};
+
+// acc[j] += W'(32 x 32*KT) . X[j] with the block's KT*2 fragments starting at fragment f0 of the slot
+template <class DT, int KT, int T, int SEG>
+__device__ __forceinline__ void lp_block(const LdsRing<SEG>& ring, int f0, const ActTile<DT> (&X)[T][KT],
+                                         f32x16 (&acc)[T]) {
+#pragma unroll
+    for (int i = 0; i < KT * 2; ++i) {
+        const typename DT::v8 a = ring.template frag<DT>(f0 + i);
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = DT::mfma(a, X[j][i >> 1].k[i & 1], acc[j]);
+    }
+}
+
+// Y[.][MT0 .. MT0+MTN) = relu(W' X + b') for the MTN out-tiles whose blocks start at fragment f0 of the
+// current slot (bias: LDS pointer to the layer's folded bias); output rounded to 16 bits for the next layer
+template <class DT, int KT, int MT, int T, int SEG, int MT0, int MTN>
+__device__ __forceinline__ void lp_layer(const LdsRing<SEG>& ring, int f0, const float* bias,
+                                         const ActTile<DT> (&X)[T][KT], ActTile<DT> (&Y)[T][MT], int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int m = MT0; m < MT0 + MTN; ++m) {
+        f32x16 acc[T];
+        const f32x16 b = tile_from_channels(bias + 32 * m, h);
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = b;
+        lp_block<DT, KT, T, SEG>(ring, f0 + (m - MT0) * KT * 2, X, acc);
+#pragma unroll
+        for (int j = 0; j < T; ++j) Y[j][m] = pack_relu<DT>(acc[j]);
+    }
+}
+
+// tiles of one layer per ring segment: as many whole out-tiles (KT*2 fragments each) as fit 32 fragments
+__host__ __device__ constexpr int lp_tiles_per_seg(int kt, int mt) {
+    return (32 / (kt * 2) < 1 ? 1 : 32 / (kt * 2)) < mt ? (32 / (kt * 2) < 1 ? 1 : 32 / (kt * 2)) : mt;
+}
+
+// a whole layer, one ring segment per TPS out-tiles
+template <class DT, int KT, int MT, int T, int SEG, int TPS, int M0>
+__device__ __forceinline__ void lp_seg_layers(LdsRing<SEG>& ring, const float* bias, const ActTile<DT> (&X)[T][KT],
+                                              ActTile<DT> (&Y)[T][MT], int lane) {
+    if constexpr (M0 < MT) {
+        ring.acquire();
+        lp_layer<DT, KT, MT, T, SEG, M0, TPS>(ring, 0, bias, X, Y, lane);
+        lp_seg_layers<DT, KT, MT, T, SEG, TPS, M0 + TPS>(ring, bias, X, Y, lane);
+    }
+}
+
+// max epilogue into an LDS int array (zero-initialised, flushed to global once per workgroup)
+template <int T>
+__device__ __forceinline__ void lp_tile_max(const f32x16 (&acc)[T], const float* bias, int* smax, int lane) {
+    f32x16 m = acc[0];
+#pragma unroll
+    for (int j = 1; j < T; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[r] = __builtin_fmaxf(m[r], acc[j][r]);
+    }
+    float v8[8], v4[4], v2[2], v1;
+    {
+        const bool up = lane & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v8[i] = __builtin_fmaxf(up ? m[i + 8] : m[i], swz_xor<1>(up ? m[i] : m[i + 8]));
+    }
+    {
+        const bool up = lane & 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v4[i] = __builtin_fmaxf(up ? v8[i + 4] : v8[i], swz_xor<2>(up ? v8[i] : v8[i + 4]));
+    }
+    {
+        const bool up = lane & 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) v2[i] = __builtin_fmaxf(up ? v4[i + 2] : v4[i], swz_xor<4>(up ? v4[i] : v4[i + 2]));
+    }
+    {
+        const bool up = lane & 8;
+        v1 = __builtin_fmaxf(up ? v2[1] : v2[0], swz_xor<8>(up ? v2[0] : v2[1]));
+    }
+    v1 = __builtin_fmaxf(v1, swz_xor<16>(v1));
+    const int r = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+    const int ch = tile_chan(r, lane >> 5);
+    int bits = __float_as_int(v1 + bias[ch]);
+    bits = bits > 0 ? bits : 0;
+    if ((lane & 16) == 0) atomicMax(smax + ch, bits);
+}

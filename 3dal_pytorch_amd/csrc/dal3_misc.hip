@@ -42,6 +42,44 @@ __global__ void pack_weight_kernel(dal3_layer L, int mode, int col_off, int n_co
     }
 }
 
+// 16-bit fragments for v_mfma_f32_32x32x16_{bf16,f16}: a block (mt,kt) is two 1-KiB fragments (k-steps s = 0,1)
+// of [64 lanes][8 elements]; the k order inside a step matches the C/D layout of the producing MFMA (dal3_lp.h).
+__global__ void pack_weight_lp_kernel(dal3_layer L, int dtype, int kt_major, int col_off, int n_cols, int mt_n, int kt_n,
+                                      uint16_t* __restrict__ out, int64_t total, int grp_blocks, int64_t grp_a0,
+                                      int64_t grp_a1, int64_t grp_stride) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63), s = (int)((i >> 9) & 1);
+    const int blk = (int)(i >> 10);
+    const int mt = kt_major ? blk % mt_n : blk / kt_n;
+    const int kt = kt_major ? blk / mt_n : blk % kt_n;
+    const float v = folded_w(L, 32 * mt + (lane & 31), 32 * kt + 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3), col_off,
+                             n_cols);
+    uint16_t bits;
+    if (dtype == DAL3_BF16) {
+        const __bf16 h = (__bf16)v;
+        bits = __builtin_bit_cast(uint16_t, h);
+    } else {
+        const _Float16 h = (_Float16)v;
+        bits = __builtin_bit_cast(uint16_t, h);
+    }
+    int64_t o = i;
+    if (grp_blocks > 0) {
+        const int g = blk / grp_blocks;
+        o = (g == 0 ? grp_a0 : grp_a1 + (int64_t)(g - 1) * grp_stride) + (int64_t)(blk % grp_blocks) * 1024 + (i & 1023);
+    }
+    out[o] = bits;
+}
+
+hipError_t launch_pack_weight_lp(const dal3_layer& L, int dtype, int kt_major, int col_off, int n_cols, int mt_n, int kt_n,
+                                 uint16_t* out, hipStream_t s, int grp_blocks, int64_t grp_a0, int64_t grp_a1,
+                                 int64_t grp_stride) {
+    const int64_t total = (int64_t)mt_n * kt_n * 1024;
+    hipLaunchKernelGGL(pack_weight_lp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L, dtype, kt_major,
+                       col_off, n_cols, mt_n, kt_n, out, total, grp_blocks, grp_a0, grp_a1, grp_stride);
+    return hipGetLastError();
+}
+
 // b' = (b - mean) * s + beta, zero padded to a multiple of 32
 __global__ void pack_bias_kernel(dal3_layer L, float* __restrict__ out, int padded) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,320 @@
+// dal3_pointmlp_lp.hip — bf16 / fp16 MFMA versions of the three shared-MLP kernels (configs C3 / C5 of
+// BASELINE.json). Same math and fusion as dal3_pointmlp.hip; see dal3_lp.h for the operand layout and
+// the LDS-DMA weight ring. The K=3/4/8 first layer stays on the fp32 MFMA (raw coordinates are not
+// rounded to 16 bits); accumulation is fp32 throughout; dconv5 and the mask stay fp32 on the VALU.
+#include "dal3_kernels.h"
+#include "dal3_lp.h"
+
+#define LP_WAVES 4
+
+// ------------------------------------------------------------------------------------------------
+template <class DT, int T>
+__global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN pts, int c_in, int n_pts,
+                                                                int tiles_per_item, float* __restrict__ g) {
+    constexpr int SEG = LP_ENC_SEG;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_bias = reinterpret_cast<float*>(smem + LP_SLOTS * SEG * 1024);   // b2 64 | b3 64 | b4 128 | b5 1024
+    int* s_max = reinterpret_cast<int*>(s_bias + 1280);                       // 1024 channel maxima of this workgroup
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t b = blockIdx.x / tiles_per_item;
+    const int n0 = ((blockIdx.x % tiles_per_item) * LP_WAVES + wave) * (32 * T);   // past the end: duplicates of the last point
+
+    for (int i = threadIdx.x; i < 1280; i += 256) s_bias[i] = w.bias_enc[i];
+    for (int i = threadIdx.x; i < 1024; i += 256) s_max[i] = 0;
+    __syncthreads();
+    LdsRing<SEG> ring;
+    ring.init(w.enc_stream, smem, LP_ENC_SEGS, wave, lane);
+
+    ActTile<DT> x1[T][2], x2[T][2], x3[T][2], x4[T][4];
+    {
+        float in[T][2];
+        load_points<2, T>(pts, b, n0, n_pts, c_in, in, lane);
+        f32x16 x1f[T][2];
+        first_layer<2, 2, T>(w.w1, w.b1, in, x1f, lane);
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            x1[j][0] = pack_relu<DT>(x1f[j][0]);
+            x1[j][1] = pack_relu<DT>(x1f[j][1]);
+        }
+    }
+    ring.acquire();                                        // segment 0: conv2 | conv3 | conv4
+    lp_layer<DT, 2, 2, T, SEG, 0, 2>(ring, 0, s_bias, x1, x2, lane);
+    lp_layer<DT, 2, 2, T, SEG, 0, 2>(ring, 8, s_bias + 64, x2, x3, lane);
+    lp_layer<DT, 2, 4, T, SEG, 0, 4>(ring, 16, s_bias + 128, x3, x4, lane);
+    for (int seg = 0; seg < 8; ++seg) {                    // conv5: 4 out-tiles (32 fragments) per segment
+        ring.acquire();
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            f32x16 acc[T];
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[j] = f32x16{};
+            lp_block<DT, 4, T, SEG>(ring, tl * 8, x4, acc);
+            const int ch = 32 * (seg * 4 + tl);
+            lp_tile_max<T>(acc, s_bias + 256 + ch, s_max + ch, lane);
+        }
+    }
+    __syncthreads();
+    int* gi = reinterpret_cast<int*>(g + b * 1024);
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const int v = s_max[i];
+        if (v > 0) atomicMax(gi + i, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <class DT, int T>
+__global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN pts, int c_in, int n_pts,
+                                                                int tiles_per_item, const float* __restrict__ gbias,
+                                                                float* __restrict__ logits, uint8_t* __restrict__ mask) {
+    constexpr int SEG = LP_DEC_SEG;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // b2 64 | db2 256 | db3 128 | db4 128 | dw5 256 | db5 32  (= 864 floats), then the crop's dconv1 term (512)
+    float* s_bias = reinterpret_cast<float*>(smem + LP_SLOTS * SEG * 1024);
+    float* s_gb = s_bias + 864;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
+    const int64_t b = blockIdx.x / tiles_per_item;
+    const int n0 = ((blockIdx.x % tiles_per_item) * LP_WAVES + wave) * (32 * T);
+
+    for (int i = threadIdx.x; i < 864; i += 256) s_bias[i] = w.bias_dec[i];
+    for (int i = threadIdx.x; i < 512; i += 256) s_gb[i] = gbias[b * 512 + i];
+    __syncthreads();
+    const float* s_db2 = s_bias + 64;
+    const float* s_db3 = s_bias + 320;
+    const float* s_db4 = s_bias + 448;
+    const float* s_dw5 = s_bias + 576;
+    const float* s_db5 = s_bias + 832;
+    LdsRing<SEG> ring;
+    ring.init(w.dec_stream, smem, LP_DEC_SEGS, wave, lane);
+
+    ActTile<DT> x1[T][2], x2[T][2];
+    {
+        float in[T][2];
+        load_points<2, T>(pts, b, n0, n_pts, c_in, in, lane);
+        f32x16 x1f[T][2];
+        first_layer<2, 2, T>(w.w1, w.b1, in, x1f, lane);
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            x1[j][0] = pack_relu<DT>(x1f[j][0]);
+            x1[j][1] = pack_relu<DT>(x1f[j][1]);
+        }
+    }
+    ring.acquire();                                        // segment 0: conv2 (0..7) | dconv1a chunk 0 (8..11)
+    lp_layer<DT, 2, 2, T, SEG, 0, 2>(ring, 0, s_bias, x1, x2, lane);
+
+    f32x16 a2[T][8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const f32x16 bv = tile_from_channels(s_db2 + 32 * mt, h);
+#pragma unroll
+        for (int j = 0; j < T; ++j) a2[j][mt] = bv;
+    }
+    f32x16 tA[T], tB[T];
+    auto dconv1_chunk = [&](f32x16 (&t)[T], int chunk, int f0) {
+        const f32x16 init = tile_from_channels(s_gb + 32 * (chunk & 15), h);
+#pragma unroll
+        for (int j = 0; j < T; ++j) t[j] = init;
+        lp_block<DT, 2, T, SEG>(ring, f0, x2, t);
+    };
+    auto dconv2_part = [&](const f32x16 (&t)[T], int f0) {
+        ActTile<DT> p[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) p[j] = pack_relu<DT>(t[j]);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const typename DT::v8 a = ring.template frag<DT>(f0 + mt * 2 + s);
+#pragma unroll
+                for (int j = 0; j < T; ++j) a2[j][mt] = DT::mfma(a, p[j].k[s], a2[j][mt]);
+            }
+        }
+    };
+    dconv1_chunk(tA, 0, 8);
+    for (int i = 0; i < 8; ++i) {                          // segment 1+i: 1a(2i+1) | 2(2i) | 1a(2i+2) | 2(2i+1)
+        ring.acquire();
+        dconv1_chunk(tB, 2 * i + 1, 0);
+        dconv2_part(tA, 4);
+        dconv1_chunk(tA, 2 * i + 2, 20);                   // chunk 16 = zero filler, result unused
+        dconv2_part(tB, 24);
+    }
+    ActTile<DT> xd[T][8], y3[T][4];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) xd[j][mt] = pack_relu<DT>(a2[j][mt]);
+    }
+    ring.acquire();                                        // dconv3 out-tiles 0,1
+    lp_layer<DT, 8, 4, T, SEG, 0, 2>(ring, 0, s_db3, xd, y3, lane);
+    ring.acquire();                                        // dconv3 out-tiles 2,3
+    lp_layer<DT, 8, 4, T, SEG, 2, 2>(ring, 0, s_db3, xd, y3, lane);
+    ring.acquire();                                        // dconv4
+    f32x16 y4[T][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f32x16 acc[T];
+        const f32x16 bv = tile_from_channels(s_db4 + 32 * m, h);
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = bv;
+        lp_block<DT, 4, T, SEG>(ring, m * 8, y3, acc);
+#pragma unroll
+        for (int j = 0; j < T; ++j) y4[j][m] = relu16(acc[j]);
+    }
+
+    float l0[T], l1[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) l0[j] = l1[j] = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(s_dw5 + 32 * kt + 8 * q + 4 * h);
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(s_dw5 + 128 + 32 * kt + 8 * q + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    l0[j] = fmaf(wa[e], y4[j][kt][4 * q + e], l0[j]);
+                    l1[j] = fmaf(wb[e], y4[j][kt][4 * q + e], l1[j]);
+                }
+            }
+        }
+    }
+    const float bias0 = s_db5[0], bias1 = s_db5[1];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const float s0 = l0[j] + __shfl_xor(l0[j], 32) + bias0;
+        const float s1 = l1[j] + __shfl_xor(l1[j], 32) + bias1;
+        const int n = n0 + 32 * j + (lane & 31);
+        if (h == 0 && n < n_pts) {
+            f32x2 o;
+            o[0] = s0;
+            o[1] = s1;
+            *reinterpret_cast<f32x2*>(logits + (b * n_pts + n) * 2) = o;
+            mask[b * n_pts + n] = s0 < s1 ? 1 : 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv1..4 + max over the points. Per layer the out-tiles are grouped into segments of <= 32 fragments.
+template <class DT, int KS, int C1, int C2, int C3, int T>
+__global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN x, int c_in, int n_pts,
+                                                            int tiles_per_item, float* __restrict__ feat) {
+    constexpr int SEG = LP_HEAD_SEG;
+    constexpr int K2 = C1 / 32, M2 = C2 / 32, K3 = C2 / 32, M3 = C3 / 32, K4 = C3 / 32, M4 = 16;
+    constexpr int TPS2 = lp_tiles_per_seg(K2, M2), TPS3 = lp_tiles_per_seg(K3, M3), TPS4 = lp_tiles_per_seg(K4, M4);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_bias = reinterpret_cast<float*>(smem + LP_SLOTS * SEG * 1024);   // b2 C2 | b3 C3 | b4 512
+    int* s_max = reinterpret_cast<int*>(s_bias + C2 + C3 + 512);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t b = blockIdx.x / tiles_per_item;
+    const int n0 = ((blockIdx.x % tiles_per_item) * LP_WAVES + wave) * (32 * T);
+
+    for (int i = threadIdx.x; i < C2 + C3 + 512; i += 256) s_bias[i] = w.bias[i];
+    for (int i = threadIdx.x; i < 512; i += 256) s_max[i] = 0;
+    __syncthreads();
+    LdsRing<SEG> ring;
+    ring.init(w.stream, smem, M2 / TPS2 + M3 / TPS3 + M4 / TPS4, wave, lane);
+
+    ActTile<DT> x1[T][K2], x2[T][M2], x3[T][M3];
+    {
+        float in[T][KS];
+        load_points<KS, T>(x, b, n0, n_pts, c_in, in, lane);
+        f32x16 x1f[T][K2];
+        first_layer<KS, K2, T>(w.w1, w.b1, in, x1f, lane);
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+#pragma unroll
+            for (int m = 0; m < K2; ++m) x1[j][m] = pack_relu<DT>(x1f[j][m]);
+        }
+    }
+    lp_seg_layers<DT, K2, M2, T, SEG, TPS2, 0>(ring, s_bias, x1, x2, lane);
+    lp_seg_layers<DT, K3, M3, T, SEG, TPS3, 0>(ring, s_bias + C2, x2, x3, lane);
+    const float* s_b4 = s_bias + C2 + C3;
+    for (int seg = 0; seg < M4 / TPS4; ++seg) {
+        ring.acquire();
+#pragma unroll
+        for (int tl = 0; tl < TPS4; ++tl) {
+            f32x16 acc[T];
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[j] = f32x16{};
+            lp_block<DT, K4, T, SEG>(ring, tl * K4 * 2, x3, acc);
+            const int ch = 32 * (seg * TPS4 + tl);
+            lp_tile_max<T>(acc, s_b4 + ch, s_max + ch, lane);
+        }
+    }
+    __syncthreads();
+    int* fi = reinterpret_cast<int*>(feat + b * 512);
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int v = s_max[i];
+        if (v > 0) atomicMax(fi + i, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline int lp_tiles(int n_pts, int T) { return (n_pts + 32 * LP_WAVES * T - 1) / (32 * LP_WAVES * T); }
+
+template <class DT>
+static hipError_t enc_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
+    constexpr int T = DAL3_LP_ENC_T;
+    const size_t lds = LP_SLOTS * LP_ENC_SEG * 1024 + (1280 + 1024) * 4;
+    auto k = ins_seg_encode_lp_kernel<DT, T>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int tpi = lp_tiles(N, T);
+    hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * tpi)), dim3(256), lds, s, w, pts, c_in, N, tpi, g);
+    return hipGetLastError();
+}
+template <class DT>
+static hipError_t dec_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, const float* gbias, float* logits,
+                         uint8_t* mask, hipStream_t s) {
+    constexpr int T = DAL3_LP_DEC_T;
+    const size_t lds = LP_SLOTS * LP_DEC_SEG * 1024 + (864 + 512) * 4;
+    auto k = ins_seg_decode_lp_kernel<DT, T>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int tpi = lp_tiles(N, T);
+    hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * tpi)), dim3(256), lds, s, w, pts, c_in, N, tpi, gbias, logits, mask);
+    return hipGetLastError();
+}
+template <class DT, int KS, int C1, int C2, int C3>
+static hipError_t head_lp(const PointHeadLpW& w, BCN x, int c_in, int B, int M, float* feat, hipStream_t s) {
+    constexpr int T = DAL3_LP_HEAD_T;
+    const size_t lds = LP_SLOTS * LP_HEAD_SEG * 1024 + (C2 + C3 + 512 + 512) * 4;
+    auto k = point_head_lp_kernel<DT, KS, C1, C2, C3, T>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int tpi = lp_tiles(M, T);
+    hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * tpi)), dim3(256), lds, s, w, x, c_in, M, tpi, feat);
+    return hipGetLastError();
+}
+
+hipError_t launch_ins_seg_encode_lp(int dtype, const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
+    return dtype == DAL3_BF16 ? enc_lp<BF16>(w, pts, c_in, B, N, g, s) : enc_lp<FP16>(w, pts, c_in, B, N, g, s);
+}
+hipError_t launch_ins_seg_decode_lp(int dtype, const InsSegLpW& w, BCN pts, int c_in, int B, int N, const float* gbias,
+                                    float* logits, uint8_t* mask, hipStream_t s) {
+    return dtype == DAL3_BF16 ? dec_lp<BF16>(w, pts, c_in, B, N, gbias, logits, mask, s)
+                              : dec_lp<FP16>(w, pts, c_in, B, N, gbias, logits, mask, s);
+}
+hipError_t launch_point_head_lp(int dtype, int head_kind, const PointHeadLpW& w, BCN x, int c_in, int B, int M,
+                                float* feat, hipStream_t s) {
+    const bool bf = dtype == DAL3_BF16;
+    switch (head_kind) {
+        case DAL3_HEAD_STATIC_BOX_EST:
+            return bf ? head_lp<BF16, 2, 128, 128, 256>(w, x, c_in, B, M, feat, s)
+                      : head_lp<FP16, 2, 128, 128, 256>(w, x, c_in, B, M, feat, s);
+        case DAL3_HEAD_POINT_EMB:
+            return bf ? head_lp<BF16, 2, 64, 128, 256>(w, x, c_in, B, M, feat, s)
+                      : head_lp<FP16, 2, 64, 128, 256>(w, x, c_in, B, M, feat, s);
+        case DAL3_HEAD_BOX_EMB:
+            return bf ? head_lp<BF16, 4, 64, 64, 128>(w, x, c_in, B, M, feat, s)
+                      : head_lp<FP16, 4, 64, 64, 128>(w, x, c_in, B, M, feat, s);
+        default:
+            return hipErrorInvalidValue;
+    }
+}

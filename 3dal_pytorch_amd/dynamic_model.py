@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import _hip, arch
 from ._heads import (BoxEmbedding, DynamicPointNetEstimation as PointNetEstimation, PackedCache,
-                     PointEmbedding, PointNetInstanceSeg, Workspace, as_f32, numpy_choice, rows_contiguous)
+                     PointEmbedding, PointNetInstanceSeg, Workspace, as_f32, dtype_of, numpy_choice, rows_contiguous)
 from .static_model import _mask_and_gather, _parse
 
 NUM_HEADING_BIN = arch.NUM_HEADING_BIN
@@ -39,6 +39,7 @@ class DynamicModel(nn.Module):
         self.box_emb = BoxEmbedding(n_classes=n_classes)
         self.box_est = PointNetEstimation(n_classes=n_classes)
         self.sampler = "device"
+        self.precision = "fp32"                      # "bf16" / "fp16": 16-bit MFMA operands (configs C3/C5)
         self.seed = 10922081
         self.item_offset = 0
         self._cache = PackedCache()
@@ -72,12 +73,13 @@ class DynamicModel(nn.Module):
         a = _hip.DynamicArgs()
         a.B, a.N, a.n_box = B, N, n_box
         a.seed, a.item_offset = self.seed, self.item_offset
+        dt = a.dtype = dtype_of(self.precision)
         a.pts, a.box = _hip.bcn(pts), _hip.bcn(box)
         a.init_box8 = _hip.ptr(init_box8)
-        a.w_ins_seg = _hip.ptr(self._cache.get("ins_seg", self.ins_seg, _hip.HEAD_INS_SEG))
-        a.w_point_emb = _hip.ptr(self._cache.get("pe", self.point_emb, _hip.HEAD_POINT_EMB))
-        a.w_box_emb = _hip.ptr(self._cache.get("be", self.box_emb, _hip.HEAD_BOX_EMB))
-        a.w_box_est = _hip.ptr(self._cache.get("est", self.box_est, _hip.HEAD_DYNAMIC_BOX_EST))
+        a.w_ins_seg = _hip.ptr(self._cache.get("ins_seg", self.ins_seg, _hip.HEAD_INS_SEG, dt))
+        a.w_point_emb = _hip.ptr(self._cache.get("pe", self.point_emb, _hip.HEAD_POINT_EMB, dt))
+        a.w_box_emb = _hip.ptr(self._cache.get("be", self.box_emb, _hip.HEAD_BOX_EMB, dt))
+        a.w_box_est = _hip.ptr(self._cache.get("est", self.box_est, _hip.HEAD_DYNAMIC_BOX_EST, dt))
         a.logits, a.mask = _hip.ptr(o["logits"]), _hip.ptr(o["mask"])
         a.embedding, a.box_pred = _hip.ptr(o["embedding"]), _hip.ptr(o["bp"])
         a.heading_residuals, a.size_residuals = _hip.ptr(o["hr"]), _hip.ptr(o["sr"])

@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import _hip, arch
 from ._heads import (PackedCache, PointNetInstanceSeg, StaticPointNetEstimation as PointNetEstimation,
-                     Workspace, as_f32, numpy_choice, rows_contiguous)
+                     Workspace, as_f32, dtype_of, numpy_choice, rows_contiguous)
 
 NUM_HEADING_BIN = arch.NUM_HEADING_BIN
 NUM_SIZE_CLUSTER = arch.NUM_SIZE_CLUSTER
@@ -39,6 +39,7 @@ class _StaticBase(nn.Module):
         self.n_classes = n_classes
         self.n_channel = n_channel
         self.sampler = "device"
+        self.precision = "fp32"                      # "bf16" / "fp16": 16-bit MFMA operands (configs C3/C5)
         self.seed = 10922081
         self.item_offset = 0
         self._cache = PackedCache()
@@ -81,14 +82,15 @@ class _StaticBase(nn.Module):
         a = _hip.StaticArgs()
         a.B, a.N, a.two_stage = B, N, int(two)
         a.seed, a.item_offset = self.seed, self.item_offset
+        dt = a.dtype = dtype_of(self.precision)
         a.pts = _hip.bcn(pts)
         a.init_box, a.bbox_gt = _hip.ptr(init_box), _hip.ptr(bbox_gt)
-        a.w_ins_seg = _hip.ptr(self._cache.get("ins_seg", self.ins_seg, _hip.HEAD_INS_SEG))
+        a.w_ins_seg = _hip.ptr(self._cache.get("ins_seg", self.ins_seg, _hip.HEAD_INS_SEG, dt))
         if two:
-            a.w_box_est_one = _hip.ptr(self._cache.get("one", self.box_est_one, _hip.HEAD_STATIC_BOX_EST))
-            a.w_box_est_two = _hip.ptr(self._cache.get("two", self.box_est_two, _hip.HEAD_STATIC_BOX_EST))
+            a.w_box_est_one = _hip.ptr(self._cache.get("one", self.box_est_one, _hip.HEAD_STATIC_BOX_EST, dt))
+            a.w_box_est_two = _hip.ptr(self._cache.get("two", self.box_est_two, _hip.HEAD_STATIC_BOX_EST, dt))
         else:
-            a.w_box_est_one = _hip.ptr(self._cache.get("one", self.box_est, _hip.HEAD_STATIC_BOX_EST))
+            a.w_box_est_one = _hip.ptr(self._cache.get("one", self.box_est, _hip.HEAD_STATIC_BOX_EST, dt))
         a.logits, a.mask = _hip.ptr(o["logits"]), _hip.ptr(o["mask"])
         a.box_pred_one, a.heading_residuals_one = _hip.ptr(o["bp1"]), _hip.ptr(o["hr1"])
         a.size_residuals_one, a.center_one = _hip.ptr(o["sr1"]), _hip.ptr(o["c1"])

@@ -40,6 +40,8 @@ dm = importlib.import_module("3dal_pytorch_amd.dynamic_model")
 dal3_dist = importlib.import_module("3dal_pytorch_amd.dist")
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
+# dense peaks per arithmetic dtype (MI355X_MICROARCH.md "Chip-level parameters"; bf16/fp16 ~2.5 PF dense)
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -93,7 +95,9 @@ def make_dynamic(B, dev, first):
 def kernel_rooflines(model, pts, c_in, B, N, iters):
     """per-kernel HIP-event timing of the two shared-MLP kernels of ins_seg (per-kernel C-ABI entries)"""
     lib = hip.lib()
-    w = model._cache.get("ins_seg", model.ins_seg, hip.HEAD_INS_SEG)
+    dt = hip.DTYPES[model.precision]
+    peak = MFMA_PEAK_TFLOPS[model.precision]
+    w = model._cache.get("ins_seg", model.ins_seg, hip.HEAD_INS_SEG, dt)
     g = torch.zeros((B, 1024), device=pts.device)
     gb = torch.empty((B, 512), device=pts.device)
     logits = torch.empty((B, N, 2), device=pts.device)
@@ -101,13 +105,13 @@ def kernel_rooflines(model, pts, c_in, B, N, iters):
     x = hip.bcn(pts)
 
     def enc():
-        hip.check(lib.dal3_ins_seg_encode(hip.ptr(w), c_in, x, B, N, hip.ptr(g), hip.stream()))
+        hip.check(lib.dal3_ins_seg_encode(hip.ptr(w), dt, c_in, x, B, N, hip.ptr(g), hip.stream()))
 
     def dec():
-        hip.check(lib.dal3_ins_seg_decode(hip.ptr(w), c_in, x, B, N, hip.ptr(gb), hip.ptr(logits), hip.ptr(mask),
+        hip.check(lib.dal3_ins_seg_decode(hip.ptr(w), dt, c_in, x, B, N, hip.ptr(gb), hip.ptr(logits), hip.ptr(mask),
                                           hip.stream()))
     enc()
-    hip.check(lib.dal3_ins_seg_global_bias(hip.ptr(w), hip.ptr(g), B, hip.ptr(gb), hip.stream()))
+    hip.check(lib.dal3_ins_seg_global_bias(hip.ptr(w), dt, hip.ptr(g), B, hip.ptr(gb), hip.stream()))
     t_enc = events_ms(enc, iters)
     t_dec = events_ms(dec, iters)
     mac_enc = c_in * 64 + 64 * 64 * 2 + 64 * 128 + 128 * 1024
@@ -116,7 +120,7 @@ def kernel_rooflines(model, pts, c_in, B, N, iters):
     for name, t, mac in (("ins_seg_encode_kernel", t_enc, mac_enc), ("ins_seg_decode_kernel", t_dec, mac_dec)):
         tf = 2.0 * mac * B * N / (t * 1e-3) / 1e12
         out[name] = {"ms": round(t, 4), "algorithmic_gflop": round(2.0 * mac * B * N / 1e9, 2),
-                     "tflops": round(tf, 2), "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4)}
+                     "tflops": round(tf, 2), "frac": round(tf / peak, 4)}
     return out
 
 
@@ -174,6 +178,8 @@ def main():
     ap.add_argument("--head", default="static", choices=["static", "dynamic"])
     ap.add_argument("--batch", type=int, default=0, help="items per GPU (default: 4096 static, 1024 dynamic)")
     ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16"],
+                    help="arithmetic of the shared-MLP kernels (fp32 = the reference's; bf16/fp16 = configs C3/C5)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / maxpool / cpu_baseline legs")
     args = ap.parse_args()
 
@@ -203,6 +209,9 @@ def main():
         flop_item = arch.dynamic_flop(N)
         host = None
     n_total = B * world
+    model.precision = args.precision
+    peak = MFMA_PEAK_TFLOPS[args.precision]
+    dname = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.precision]
 
     def step():
         boxes = step_fn()
@@ -233,16 +242,16 @@ def main():
         "metric": "object-crops/sec through static+dynamic refinement heads",
         "value": round(value, 1), "unit": "object-crops/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": (f"StaticModelOneBoxEst forward+decode, {B} crops x {N} pts per GPU, fp32 "
-                                "(BASELINE.json configs[1])") if static else
-                               (f"DynamicModel forward+decode, {B} items x {N} pts + 101 boxes per GPU, fp32 "
+        "scaling": "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
+        "config": {"workload": (f"StaticModelOneBoxEst forward+decode, {B} crops x {N} pts per GPU, {args.precision}"
+                                + (" (BASELINE.json configs[1])" if (B, N) == (4096, 1024) else "")) if static else
+                               (f"DynamicModel forward+decode, {B} items x {N} pts + 101 boxes per GPU, {args.precision} "
                                 "arithmetic (BASELINE.json configs[2] shape)"),
                    "items_per_gpu": B, "points_per_item": N, "sampler": model.sampler,
                    "parallelism": f"object-sharded x{world}, one all-gather of (B,7) boxes" if world > 1 else "single GPU",
                    "algorithmic_gflop_per_item": round(flop_item / 1e9, 4)},
         "whole_path_tflops": round(value * flop_item / 1e12, 2),
-        "whole_path_mfma_frac": round(value / world * flop_item / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+        "whole_path_mfma_frac": round(value / world * flop_item / 1e12 / peak, 4),
     }
     if rank == 0 and world == 1 and not args.no_extras:
         kr = kernel_rooflines(model, inputs[0], 3 if static else 4, B, N, iters=max(3, min(args.steps, 10)))
@@ -251,8 +260,8 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic.json")          # HBM bytes per launch from rocprofv3 --pmc
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get(dom)
-        rec["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kr[dom]["tflops"],
-                           "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kr[dom]["frac"],
+        rec["roofline"] = {"kernel": dom + ("" if args.precision == "fp32" else "_lp"), "bound": "mfma",
+                           "achieved": kr[dom]["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kr[dom]["frac"],
                            "traffic": traffic, "ms_per_launch": kr[dom]["ms"],
                            "algorithmic_gflop_per_launch": kr[dom]["algorithmic_gflop"]}
         rec["kernels"] = kr

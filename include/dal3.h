@@ -34,7 +34,11 @@ enum {
     DAL3_EHIP = -3                       /* a HIP runtime call failed (message has hipGetErrorString) */
 };
 
-enum { DAL3_F32 = 0 };                   /* arithmetic dtype of a packed head (bf16/fp16: later rounds) */
+/* arithmetic dtype of the shared-MLP kernels of a packed head. DAL3_F32: exact-fp32 MFMA (the reference's
+ * precision). DAL3_BF16 / DAL3_F16: weights and inter-layer activations rounded to 16 bits, fp32 accumulate,
+ * v_mfma_f32_32x32x16_{bf16,f16} (BASELINE.json configs C3 / C5); first layer, FC heads, dconv5, mask and all
+ * I/O stay fp32. The same dtype must be given to dal3_pack_weights and to the forward calls. */
+enum { DAL3_F32 = 0, DAL3_BF16 = 1, DAL3_F16 = 2 };
 
 /* which sub-network a packed-weight blob belongs to */
 enum {
@@ -91,7 +95,7 @@ typedef struct {
  * the mask of point_cloud_masking (static_model.py:59). logits (B,N,2) fp32, mask (B,N) u8.
  * workspace: dal3_ins_seg_workspace_bytes(B). global_feat_out optional (B,1024). */
 size_t dal3_ins_seg_workspace_bytes(int B);
-int dal3_ins_seg_forward(const void* packed, int c_in, dal3_bcn pts, int B, int N,
+int dal3_ins_seg_forward(const void* packed, int dtype, int c_in, dal3_bcn pts, int B, int N,
                          float* logits, uint8_t* mask, float* global_feat_out,
                          void* workspace, size_t workspace_bytes, dal3_stream stream);
 
@@ -101,11 +105,11 @@ int dal3_ins_seg_forward(const void* packed, int c_in, dal3_bcn pts, int B, int 
  *   global_bias the per-crop part of dconv1 (its 1024 global-feature columns, :286-289):
  *               global_feat -> gbias (B,512) = W1g' g + b1'
  *   decode      dconv1 (64 per-point columns) .. dconv5 + mask (:289-295, :59) */
-int dal3_ins_seg_encode(const void* packed, int c_in, dal3_bcn pts, int B, int N, float* global_feat,
+int dal3_ins_seg_encode(const void* packed, int dtype, int c_in, dal3_bcn pts, int B, int N, float* global_feat,
                         dal3_stream stream);
-int dal3_ins_seg_global_bias(const void* packed, const float* global_feat, int B, float* gbias,
+int dal3_ins_seg_global_bias(const void* packed, int dtype, const float* global_feat, int B, float* gbias,
                              dal3_stream stream);
-int dal3_ins_seg_decode(const void* packed, int c_in, dal3_bcn pts, int B, int N, const float* gbias,
+int dal3_ins_seg_decode(const void* packed, int dtype, int c_in, dal3_bcn pts, int B, int N, const float* gbias,
                         float* logits, uint8_t* mask, dal3_stream stream);
 
 /* ---- gather_object_pts (static_model.py:23-49 / dynamic_model.py:24-50) on the device.
@@ -128,7 +132,7 @@ int dal3_mask_compact_sample(const uint8_t* mask, dal3_bcn pts, int B, int N, in
  * written side by side: the torch.cat of dynamic_model.py:137).
  * workspace: dal3_point_head_workspace_bytes(B). */
 size_t dal3_point_head_workspace_bytes(int B);
-int dal3_point_head_forward(int head_kind, const void* packed, dal3_bcn x, int B, int M,
+int dal3_point_head_forward(int head_kind, const void* packed, int dtype, dal3_bcn x, int B, int M,
                             float* out, int64_t out_stride,
                             void* workspace, size_t workspace_bytes, dal3_stream stream);
 
@@ -175,6 +179,8 @@ typedef struct {
     int32_t B, N;                        /* crops, points per crop */
     int32_t two_stage;                   /* 0: StaticModelOneBoxEst, 1: StaticModelTwoBoxEst */
     int32_t sampler;                     /* DAL3_SAMPLER_* */
+    int32_t dtype;                       /* DAL3_F32 | DAL3_BF16 | DAL3_F16: what the w_* blobs were packed as */
+    int32_t reserved;
     uint64_t seed;
     int64_t item_offset;
     dal3_bcn pts;                        /* (B,3,N) logical */
@@ -216,6 +222,8 @@ int dal3_static_forward(const dal3_static_args* args, int phases, dal3_stream st
 typedef struct {
     int32_t B, N, n_box;                 /* items, points per item (5*1024), boxes per window (101) */
     int32_t sampler;
+    int32_t dtype;                       /* DAL3_F32 | DAL3_BF16 | DAL3_F16 */
+    int32_t reserved;
     uint64_t seed;
     int64_t item_offset;
     dal3_bcn pts;                        /* (B,4,N) logical */

@@ -1,0 +1,104 @@
+"""bf16 / fp16 MFMA paths (BASELINE.json configs C3 / C5). The reference is fp32 only, so the checker
+is the fp32 oracle / the fp32 HIP path with a stated looser tolerance: 16-bit operands carry 8 (bf16) or
+11 (fp16) significant bits through ten layers. Measured on MI355X: logits 1.6e-2 (bf16) / 2.1e-3 (fp16)
+relative, box parameters 4e-3 / 4e-4 when the segmentation is teacher-forced."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from _common import build_model, rel_err, synth
+from oracle import ref_heads as R
+
+hip = importlib.import_module("3dal_pytorch_amd._hip")
+pytestmark = pytest.mark.gpu
+TOL_LOGITS = {"bf16": 4e-2, "fp16": 6e-3}
+TOL_BOX = {"bf16": 2e-2, "fp16": 3e-3}
+MASK_AGREE = {"bf16": 0.93, "fp16": 0.99}
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x)).cuda()
+
+
+def _static(kind, B, N, seed):
+    pts_np, init_np, gt_np = synth.static_crops(B, N, seed=seed)
+    sd = synth.state_dict(kind, seed=seed)
+    lg = R.ins_seg(R.as_torch_sd(sd), torch.from_numpy(pts_np[:16]).transpose(2, 1))
+    sd = synth.recentre_seg_bias(sd, float((lg[:, :, 1] - lg[:, :, 0]).mean()))
+    return build_model(kind, sd), sd, pts_np, dev(pts_np).transpose(2, 1), dev(init_np), dev(gt_np)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("n", [1024, 700, 33])
+def test_ins_seg_lowprec_vs_fp32_oracle(prec, n):
+    model, sd, pts_np, pts, init, gt = _static("static_one", 8, n, seed=5)
+    want = R.ins_seg(R.as_torch_sd(sd), torch.from_numpy(pts_np).transpose(2, 1)).numpy()
+    model.precision = prec
+    out = model(pts, init, gt)
+    assert rel_err(out["logits"].cpu().numpy(), want) < TOL_LOGITS[prec]
+    margin = want[:, :, 1] - want[:, :, 0]
+    sure = np.abs(margin) > 2 * TOL_LOGITS[prec] * np.abs(want).max()
+    assert np.array_equal(out["mask"].cpu().numpy()[sure], (margin > 0)[sure])   # only near-ties may flip
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_static_two_lowprec_vs_fp32_path(prec):
+    model, sd, pts_np, pts, init, gt = _static("static_two", 64, 1024, seed=6)
+    ref = model._run(pts, init, gt)
+    model.precision = prec
+    o = model._run(pts, init, gt)
+    agree = (o["mask"] == ref["mask"]).float().mean().item()
+    assert agree > MASK_AGREE[prec], agree
+    # teacher-force the fp32 segmentation (the device sampler then draws the same points)
+    t = model._run(pts, init, gt, mask_override=ref["mask"])
+    assert torch.equal(t["obj_idx"], ref["obj_idx"])
+    assert rel_err(t["bp1"].cpu().numpy(), ref["bp1"].cpu().numpy()) < TOL_BOX[prec]
+    # stage two re-centres on the DECODED stage-one box: a flipped heading/size argmax is a different problem,
+    # so compare the crops whose stage-one classes agree (nearly all of them)
+    b1, r1 = t["bp1"].cpu().numpy(), ref["bp1"].cpu().numpy()
+    same = (b1[:, 3:15].argmax(1) == r1[:, 3:15].argmax(1)) & (b1[:, 27:30].argmax(1) == r1[:, 27:30].argmax(1))
+    assert same.mean() > 0.8
+    assert rel_err(t["bp2"].cpu().numpy()[same], ref["bp2"].cpu().numpy()[same]) < 2.5 * TOL_BOX[prec]
+    b2, r2 = t["bp2"].cpu().numpy(), ref["bp2"].cpu().numpy()
+    same2 = same & (b2[:, 3:15].argmax(1) == r2[:, 3:15].argmax(1)) & (b2[:, 27:30].argmax(1) == r2[:, 27:30].argmax(1))
+    d = np.abs(t["boxes7"].cpu().numpy()[same2] - ref["boxes7"].cpu().numpy()[same2])
+    assert d[:, :6].max() < 2.5 * TOL_BOX[prec] * np.abs(ref["boxes7"].cpu().numpy()[:, :6]).max()
+    # deterministic, and a shard equals the whole job
+    again = model._run(pts, init, gt)
+    assert torch.equal(again["logits"], o["logits"]) and torch.equal(again["boxes7"], o["boxes7"])
+    model.item_offset = 16
+    part = model.refine(pts[16:40], init[16:40], gt[16:40])
+    model.item_offset = 0
+    assert torch.equal(part, o["boxes7"][16:40])
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_dynamic_lowprec_vs_fp32_path(prec):
+    B = 6
+    p, bx, i8, g7 = synth.dynamic_items(B, seed=9)
+    model = build_model("dynamic", synth.state_dict("dynamic", seed=9))
+    dp, dbx, di8 = dev(p).transpose(2, 1), dev(bx).transpose(2, 1), dev(i8)
+    ref = model._run(dp, dbx, init_box8=di8)
+    model.precision = prec
+    o = model._run(dp, dbx, init_box8=di8, mask_override=ref["mask"])
+    assert rel_err(o["logits"].cpu().numpy(), ref["logits"].cpu().numpy()) < TOL_LOGITS[prec]
+    assert rel_err(o["embedding"].cpu().numpy(), ref["embedding"].cpu().numpy()) < TOL_BOX[prec]
+    assert rel_err(o["bp"].cpu().numpy(), ref["bp"].cpu().numpy()) < 2 * TOL_BOX[prec]
+
+
+def test_lowprec_api_errors():
+    lib = hip.lib()
+    n = C.c_size_t(0)
+    assert lib.dal3_pack_weights(hip.HEAD_INS_SEG, None, 0, 7, None, C.byref(n), None) == hip.EINVAL
+    sizes = {}
+    for dt in (hip.F32, hip.BF16, hip.F16):
+        assert lib.dal3_pack_weights(hip.HEAD_INS_SEG, None, 0, dt, None, C.byref(n), None) == 0
+        sizes[dt] = n.value
+    assert sizes[hip.BF16] == sizes[hip.F16] < sizes[hip.F32]
+    model = build_model("static_one", synth.state_dict("static_one"))
+    model.precision = "int8"
+    with pytest.raises(ValueError):
+        model(torch.zeros((1, 3, 64), device="cuda"), torch.zeros((1, 7), device="cuda"), None)

@@ -81,7 +81,7 @@ def _ins_seg(model, pts):
     logits = torch.empty((B, N, 2), device="cuda")
     mask = torch.empty((B, N), dtype=torch.uint8, device="cuda")
     g = torch.empty((B, 1024), device="cuda")
-    hip.check(lib.dal3_ins_seg_forward(hip.ptr(w), c_in, hip.bcn(pts), B, N, hip.ptr(logits), hip.ptr(mask),
+    hip.check(lib.dal3_ins_seg_forward(hip.ptr(w), hip.F32, c_in, hip.bcn(pts), B, N, hip.ptr(logits), hip.ptr(mask),
                                        hip.ptr(g), hip.ptr(ws), ws.numel(), hip.stream()))
     return logits.cpu().numpy(), mask.cpu().numpy().astype(bool), g.cpu().numpy()
 
@@ -367,7 +367,7 @@ def test_recenter_rotz_vs_oracle():
 def test_errors_are_loud():
     lib = hip.lib()
     x = torch.zeros((2, 64, 3), device="cuda").transpose(2, 1)
-    assert lib.dal3_ins_seg_forward(None, 3, hip.bcn(x), 2, 64, None, None, None, None, 0, hip.stream()) == hip.EINVAL
+    assert lib.dal3_ins_seg_forward(None, hip.F32, 3, hip.bcn(x), 2, 64, None, None, None, None, 0, hip.stream()) == hip.EINVAL
     model = build_model("static_one", synth.state_dict("static_one"))
     with pytest.raises(RuntimeError):
         model(torch.zeros((2, 4, 64), device="cuda"), torch.zeros((2, 7), device="cuda"), None)

@@ -65,13 +65,13 @@ for name, lib in libs:
     ws = torch.empty(lib.dal3_point_head_workspace_bytes(B), dtype=torch.uint8, device=dev)
     bp = torch.empty((B, 39), device=dev)
     d = dict(w_seg=w_seg, w_box=w_box, g=g, gb=gb, logits=logits, mask=mask, ws=ws, bp=bp)
-    d["enc"] = lambda lib=lib, d=d: lib.dal3_ins_seg_encode(hip.ptr(d["w_seg"]), 3, x, B, N, hip.ptr(d["g"]), st)
-    d["dec"] = lambda lib=lib, d=d: lib.dal3_ins_seg_decode(hip.ptr(d["w_seg"]), 3, x, B, N, hip.ptr(d["gb"]),
+    d["enc"] = lambda lib=lib, d=d: lib.dal3_ins_seg_encode(hip.ptr(d["w_seg"]), 0, 3, x, B, N, hip.ptr(d["g"]), st)
+    d["dec"] = lambda lib=lib, d=d: lib.dal3_ins_seg_decode(hip.ptr(d["w_seg"]), 0, 3, x, B, N, hip.ptr(d["gb"]),
                                                             hip.ptr(d["logits"]), hip.ptr(d["mask"]), st)
-    d["head"] = lambda lib=lib, d=d: lib.dal3_point_head_forward(hip.HEAD_STATIC_BOX_EST, hip.ptr(d["w_box"]), xo, B, 512,
+    d["head"] = lambda lib=lib, d=d: lib.dal3_point_head_forward(hip.HEAD_STATIC_BOX_EST, hip.ptr(d["w_box"]), 0, xo, B, 512,
                                                                  hip.ptr(d["bp"]), 39, hip.ptr(d["ws"]), d["ws"].numel(), st)
     assert d["enc"]() == 0, lib.dal3_last_error()
-    assert lib.dal3_ins_seg_global_bias(hip.ptr(w_seg), hip.ptr(g), B, hip.ptr(gb), st) == 0
+    assert lib.dal3_ins_seg_global_bias(hip.ptr(w_seg), 0, hip.ptr(g), B, hip.ptr(gb), st) == 0
     assert d["dec"]() == 0 and d["head"]() == 0, lib.dal3_last_error()
     state.append(d)
 torch.cuda.synchronize()

@@ -26,7 +26,7 @@ assert lib.dal3_debug_set_stamps(stamps.data_ptr()) == 0
 gb = torch.zeros((B, 512), device=dev)
 logits = torch.empty((B, N, 2), device=dev); mask = torch.empty((B, N), dtype=torch.uint8, device=dev)
 for _ in range(3):
-    assert lib.dal3_ins_seg_decode(hip.ptr(w), 3, hip.bcn(pts), B, N, hip.ptr(gb), hip.ptr(logits), hip.ptr(mask), hip.stream()) == 0
+    assert lib.dal3_ins_seg_decode(hip.ptr(w), 0, 3, hip.bcn(pts), B, N, hip.ptr(gb), hip.ptr(logits), hip.ptr(mask), hip.stream()) == 0
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().reshape(-1, 8)
 s = s[s[:, 4] > 0]
