@@ -258,9 +258,8 @@ __global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN 
 // ------------------------------------------------------------------------------------------------
 static inline int lp_tiles(int n_pts, int T) { return (n_pts + 32 * LP_WAVES * T - 1) / (32 * LP_WAVES * T); }
 
-template <class DT>
-static hipError_t enc_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
-    constexpr int T = DAL3_LP_ENC_T;
+template <class DT, int T>
+static hipError_t enc_lp_t(const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
     const size_t lds = LP_SLOTS * LP_ENC_SEG * 1024 + (1280 + 1024) * 4;
     auto k = ins_seg_encode_lp_kernel<DT, T>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -268,6 +267,14 @@ static hipError_t enc_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, fl
     const int tpi = lp_tiles(N, T);
     hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * tpi)), dim3(256), lds, s, w, pts, c_in, N, tpi, g);
     return hipGetLastError();
+}
+// points per workgroup = 128*T: T = 8 (one workgroup per 1024 points, fewest flushes of the channel maxima)
+// unless the padding to a multiple of 1024 points would waste more than 1/8 of the work; then T = 4
+template <class DT>
+static hipError_t enc_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
+    const int64_t pad8 = (int64_t)lp_tiles(N, 8) * 1024, pad4 = (int64_t)lp_tiles(N, 4) * 512;
+    if (pad8 * 8 <= pad4 * 9) return enc_lp_t<DT, 8>(w, pts, c_in, B, N, g, s);
+    return enc_lp_t<DT, 4>(w, pts, c_in, B, N, g, s);
 }
 template <class DT>
 static hipError_t dec_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, const float* gbias, float* logits,

@@ -265,6 +265,29 @@ def main():
                            "traffic": traffic, "ms_per_launch": kr[dom]["ms"],
                            "algorithmic_gflop_per_launch": kr[dom]["algorithmic_gflop"]}
         rec["kernels"] = kr
+        if static and args.precision == "fp32":
+            # the same workload on the 16-bit MFMA path (BASELINE.json configs C3/C5 arithmetic): reported beside
+            # the fp32 headline, never as `value`
+            rec["lowprec"] = {}
+            for prec in ("bf16", "fp16"):
+                model.precision = prec
+                for _ in range(2):
+                    step_fn()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step_fn()
+                torch.cuda.synchronize()
+                d = (time.perf_counter() - t1) / args.steps
+                k2 = kernel_rooflines(model, inputs[0], 3, B, N, iters=max(3, min(args.steps, 10)))
+                d2 = max(k2, key=lambda k: k2[k]["ms"])
+                rec["lowprec"][prec] = {"value": round(B / d, 1), "unit": "object-crops/s", "ms_per_step": round(d * 1e3, 3),
+                                        "whole_path_tflops": round(B / d * flop_item / 1e12, 1),
+                                        "roofline": {"kernel": d2 + "_lp", "bound": "mfma", "achieved": k2[d2]["tflops"],
+                                                     "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+                                                     "frac": k2[d2]["frac"], "ms_per_launch": k2[d2]["ms"]},
+                                        "kernels": k2}
+            model.precision = args.precision
         rec["maxpool"] = maxpool_roofline(dev, iters=5)
         if static:
             rec["cpu_baseline"] = cpu_baseline(host)

@@ -23,8 +23,10 @@ ap.add_argument("libs", nargs="+")
 ap.add_argument("--B", type=int, default=4096)
 ap.add_argument("--N", type=int, default=1024)
 ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--dtype", type=int, default=0, help="0 fp32, 1 bf16, 2 fp16")
 args = ap.parse_args()
 B, N = args.B, args.N
+DT = args.dtype
 dev = torch.device("cuda:0")
 
 
@@ -51,9 +53,9 @@ for name, lib in libs:
     need = C.c_size_t(0)
     def pack(kind, pairs):
         arr = (hip.Layer * len(pairs))(*[hip.layer_struct(c, b) for c, b in pairs])
-        lib.dal3_pack_weights(kind, arr, len(pairs), 0, None, C.byref(need), None)
+        lib.dal3_pack_weights(kind, arr, len(pairs), DT, None, C.byref(need), None)
         buf = torch.zeros(need.value, dtype=torch.uint8, device=dev)
-        rc = lib.dal3_pack_weights(kind, arr, len(pairs), 0, hip.ptr(buf), C.byref(need), st)
+        rc = lib.dal3_pack_weights(kind, arr, len(pairs), DT, hip.ptr(buf), C.byref(need), st)
         assert rc == 0, lib.dal3_last_error()
         return buf
     w_seg = pack(hip.HEAD_INS_SEG, model.ins_seg.pairs())
@@ -65,13 +67,13 @@ for name, lib in libs:
     ws = torch.empty(lib.dal3_point_head_workspace_bytes(B), dtype=torch.uint8, device=dev)
     bp = torch.empty((B, 39), device=dev)
     d = dict(w_seg=w_seg, w_box=w_box, g=g, gb=gb, logits=logits, mask=mask, ws=ws, bp=bp)
-    d["enc"] = lambda lib=lib, d=d: lib.dal3_ins_seg_encode(hip.ptr(d["w_seg"]), 0, 3, x, B, N, hip.ptr(d["g"]), st)
-    d["dec"] = lambda lib=lib, d=d: lib.dal3_ins_seg_decode(hip.ptr(d["w_seg"]), 0, 3, x, B, N, hip.ptr(d["gb"]),
+    d["enc"] = lambda lib=lib, d=d: lib.dal3_ins_seg_encode(hip.ptr(d["w_seg"]), DT, 3, x, B, N, hip.ptr(d["g"]), st)
+    d["dec"] = lambda lib=lib, d=d: lib.dal3_ins_seg_decode(hip.ptr(d["w_seg"]), DT, 3, x, B, N, hip.ptr(d["gb"]),
                                                             hip.ptr(d["logits"]), hip.ptr(d["mask"]), st)
-    d["head"] = lambda lib=lib, d=d: lib.dal3_point_head_forward(hip.HEAD_STATIC_BOX_EST, hip.ptr(d["w_box"]), 0, xo, B, 512,
+    d["head"] = lambda lib=lib, d=d: lib.dal3_point_head_forward(hip.HEAD_STATIC_BOX_EST, hip.ptr(d["w_box"]), DT, xo, B, 512,
                                                                  hip.ptr(d["bp"]), 39, hip.ptr(d["ws"]), d["ws"].numel(), st)
     assert d["enc"]() == 0, lib.dal3_last_error()
-    assert lib.dal3_ins_seg_global_bias(hip.ptr(w_seg), 0, hip.ptr(g), B, hip.ptr(gb), st) == 0
+    assert lib.dal3_ins_seg_global_bias(hip.ptr(w_seg), DT, hip.ptr(g), B, hip.ptr(gb), st) == 0
     assert d["dec"]() == 0 and d["head"]() == 0, lib.dal3_last_error()
     state.append(d)
 torch.cuda.synchronize()
@@ -82,7 +84,7 @@ for (name, _), d in zip(libs, state):
     print(f"{name}: bitwise-equal to first (g, logits, box_pred) = {same}, logits rel diff {dl:.2e}")
 
 
-def timed(fn, iters=3):
+def timed(fn, iters=5):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
