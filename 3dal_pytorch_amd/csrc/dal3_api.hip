@@ -606,6 +606,30 @@ extern "C" int dal3_recenter_rotz(const float* obj_pts, int B, int M, const floa
     return 0;
 }
 
+extern "C" int dal3_static_crop_prep(const double* points, const int64_t* offsets, const int32_t* choice,
+                                     const double* pose, const double* box, int B, int N, uint64_t seed,
+                                     int64_t item_offset, float* pts_out, float* init_box_out, dal3_stream stream) {
+    if (!points || !offsets || !pose || !box || !pts_out || !init_box_out || B <= 0 || N < 7)
+        return fail(DAL3_EINVAL, "static_crop_prep: bad argument (N must be >= 7)");
+    HIP_TRY(launch_static_crop_prep(points, offsets, choice, pose, box, B, N, seed, item_offset, pts_out, init_box_out,
+                                    static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_dynamic_item_prep(const double* points, const int64_t* frame_offsets, const double* boxes,
+                                      const int64_t* track_first, const int32_t* item_track, const int32_t* item_frame,
+                                      const int32_t* choice, const double* pose, int B, int n_per, int r, int s,
+                                      uint64_t seed, int64_t item_offset, float* pts_out, float* box_out,
+                                      float* init_box_out, dal3_stream stream) {
+    if (!points || !frame_offsets || !boxes || !track_first || !item_track || !item_frame || !pose || !pts_out ||
+        !box_out || !init_box_out || B <= 0 || n_per <= 0 || r < 0 || s < 0)
+        return fail(DAL3_EINVAL, "dynamic_item_prep: bad argument");
+    HIP_TRY(launch_dynamic_item_prep(points, frame_offsets, boxes, track_first, item_track, item_frame, choice, pose, B,
+                                     n_per, r, s, seed, item_offset, pts_out, box_out, init_box_out,
+                                     static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, dal3_stream stream) {
     if (!x || !out || rows <= 0 || n <= 0) return fail(DAL3_EINVAL, "maxpool_n: bad argument");
     HIP_TRY(launch_maxpool_n(x, rows, n, out, static_cast<hipStream_t>(stream)));

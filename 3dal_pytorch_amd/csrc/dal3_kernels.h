@@ -155,6 +155,14 @@ hipError_t launch_pack_weight(const dal3_layer& L, int mode, int col_off, int n_
                               int64_t grp_stride = 0);
 hipError_t launch_pack_bias(const dal3_layer& L, float* out, hipStream_t s);
 
+hipError_t launch_static_crop_prep(const double* points, const int64_t* offsets, const int32_t* choice, const double* pose,
+                                   const double* box, int B, int N, uint64_t seed, int64_t item_offset, float* pts_out,
+                                   float* init_box_out, hipStream_t s);
+hipError_t launch_dynamic_item_prep(const double* points, const int64_t* frame_offsets, const double* boxes,
+                                    const int64_t* track_first, const int32_t* item_track, const int32_t* item_frame,
+                                    const int32_t* choice, const double* pose, int B, int n_per, int r, int s_,
+                                    uint64_t seed, int64_t item_offset, float* pts_out, float* box_out,
+                                    float* init_box_out, hipStream_t st);
 hipError_t launch_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, hipStream_t s);
 hipError_t launch_segment_counts(const uint8_t* mask, int B, int N, int32_t* counts, hipStream_t s);
 hipError_t launch_compact_sample(const uint8_t* mask, BCN pts, int B, int N, int C, int M, int sampler,

@@ -1,0 +1,151 @@
+// dal3_prep.hip — crop preparation on the device: what STATICTRACK.__getitem__
+// (tools/static_model.py:529-572) and DYNAMICTRACK.__getitem__ (tools/dynamic_model.py:419-509) do per item on
+// the host — resample with replacement, global -> vehicle frame, re-centre on the box, rotate by -yaw, assemble
+// the 5-frame point window and the 101-box window — as two HBM-bound gather kernels. float64 arithmetic as in the
+// reference (global coordinates are kilometres; fp32 would lose centimetres), fp32 on store (the drivers' .float()).
+#include "dal3_device.h"
+#include "dal3_kernels.h"
+
+__device__ __forceinline__ uint32_t prep_hash(uint64_t seed, uint64_t item, uint32_t i) {
+    uint64_t z = seed ^ (item * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)i << 32 | i);
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+
+// p' = Rz(-yaw) ( pose[:3,:3] p + pose[:3,3] - c ), pose row-major 4x4 (vehicle <- global)
+__device__ __forceinline__ void to_box_frame(const double* __restrict__ pose, double x, double y, double z, double cx,
+                                             double cy, double cz, double cosn, double sinn, float* __restrict__ o) {
+    const double vx = pose[0] * x + pose[1] * y + pose[2] * z + pose[3] - cx;
+    const double vy = pose[4] * x + pose[5] * y + pose[6] * z + pose[7] - cy;
+    const double vz = pose[8] * x + pose[9] * y + pose[10] * z + pose[11] - cz;
+    o[0] = (float)(cosn * vx - sinn * vy);             // rotz(-yaw) = [[c, s],[-s, c]] with c = cos(yaw), s = sin(yaw):
+    o[1] = (float)(sinn * vx + cosn * vy);             //   passed in as cosn = cos(-yaw), sinn = sin(-yaw)
+    o[2] = (float)vz;
+}
+
+// static: one thread per output point. box = best detection already in the vehicle frame (host: transform_box).
+__global__ void static_crop_prep_kernel(const double* __restrict__ points, const int64_t* __restrict__ offsets,
+                                        const int32_t* __restrict__ choice, const double* __restrict__ pose,
+                                        const double* __restrict__ box, int B, int N, uint64_t seed, int64_t item_offset,
+                                        float* __restrict__ pts_out, float* __restrict__ init_box_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * N) return;
+    const int b = (int)(i / N), n = (int)(i % N);
+    const int64_t p0 = offsets[b], cnt = offsets[b + 1] - p0;
+    const double* bx = box + (int64_t)b * 7;
+    if (n < 7) init_box_out[b * 7 + n] = (float)bx[n];
+    float* o = pts_out + i * 3;
+    if (cnt <= 0) {
+        o[0] = o[1] = o[2] = 0.0f;
+        return;
+    }
+    int64_t k = choice ? choice[i] : (int64_t)(((uint64_t)prep_hash(seed, (uint64_t)(item_offset + b), (uint32_t)n) * (uint64_t)cnt) >> 32);
+    k = k < 0 ? 0 : (k >= cnt ? cnt - 1 : k);
+    const double* p = points + (p0 + k) * 3;
+    const double yaw = -bx[6];
+    to_box_frame(pose + (int64_t)b * 16, p[0], p[1], p[2], bx[0], bx[1], bx[2], cos(yaw), sin(yaw), o);
+}
+
+// dynamic: blocks [0, B*(2r+1)*n_per) -> points, then B*(2s+1) threads -> boxes
+__global__ void dynamic_item_prep_kernel(const double* __restrict__ points, const int64_t* __restrict__ frame_offsets,
+                                         const double* __restrict__ boxes, const int64_t* __restrict__ track_first,
+                                         const int32_t* __restrict__ item_track, const int32_t* __restrict__ item_frame,
+                                         const int32_t* __restrict__ choice, const double* __restrict__ pose_all, int B,
+                                         int n_per, int r, int s, uint64_t seed, int64_t item_offset,
+                                         float* __restrict__ pts_out, float* __restrict__ box_out,
+                                         float* __restrict__ init_box_out) {
+    const int64_t n_pts_total = (int64_t)B * (2 * r + 1) * n_per;
+    const int64_t n_box_total = (int64_t)B * (2 * s + 1);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pts_total + n_box_total) return;
+    const bool is_pt = i < n_pts_total;
+    const int b = is_pt ? (int)(i / ((int64_t)(2 * r + 1) * n_per)) : (int)((i - n_pts_total) / (2 * s + 1));
+    const double* pose = pose_all + (int64_t)b * 16;
+    const int trk = item_track[b], it = item_frame[b];
+    const int64_t f0 = track_first[trk];
+    const int n_frames = (int)(track_first[trk + 1] - f0);
+    // centre box in the vehicle frame (transform_box of the item's own box; out-of-range cannot happen for it)
+    const double* cb = boxes + (f0 + it) * 7;
+    const double ccx = pose[0] * cb[0] + pose[1] * cb[1] + pose[2] * cb[2] + pose[3];
+    const double ccy = pose[4] * cb[0] + pose[5] * cb[1] + pose[6] * cb[2] + pose[7];
+    const double ccz = pose[8] * cb[0] + pose[9] * cb[1] + pose[10] * cb[2] + pose[11];
+    const double dyaw = atan2(pose[4], pose[0]);
+    const double cyaw = cb[6] + dyaw;
+    if (is_pt) {
+        const int64_t w = i - (int64_t)b * (2 * r + 1) * n_per;
+        const int j = (int)(w / n_per);
+        const int fr = it - r + j;
+        double x = 0.0, y = 0.0, z = 0.0;                 // missing / empty frame: zero points, still transformed
+        if (fr >= 0 && fr < n_frames) {
+            const int64_t p0 = frame_offsets[f0 + fr], cnt = frame_offsets[f0 + fr + 1] - p0;
+            if (cnt > 0) {
+                int64_t k = choice ? choice[i] : (int64_t)(((uint64_t)prep_hash(seed, (uint64_t)(item_offset + b), (uint32_t)w) * (uint64_t)cnt) >> 32);
+                k = k < 0 ? 0 : (k >= cnt ? cnt - 1 : k);
+                const double* p = points + (p0 + k) * 3;
+                x = p[0];
+                y = p[1];
+                z = p[2];
+            }
+        }
+        float* o = pts_out + i * 4;
+        to_box_frame(pose, x, y, z, ccx, ccy, ccz, cos(-cyaw), sin(-cyaw), o);
+        o[3] = (float)(0.1 * (j - r));
+    } else {
+        const int j = (int)((i - n_pts_total) % (2 * s + 1));
+        const int fr = it - s + j;
+        double bx[7] = {0, 0, 0, 0, 0, 0, 0};            // missing box: a zero row, still pose-transformed
+        if (fr >= 0 && fr < n_frames) {
+            const double* q = boxes + (f0 + fr) * 7;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) bx[k] = q[k];
+        }
+        const double tx = pose[0] * bx[0] + pose[1] * bx[1] + pose[2] * bx[2] + pose[3];
+        const double ty = pose[4] * bx[0] + pose[5] * bx[1] + pose[6] * bx[2] + pose[7];
+        const double tz = pose[8] * bx[0] + pose[9] * bx[1] + pose[10] * bx[2] + pose[11];
+        const double tyaw = bx[6] + dyaw;
+        float* o = box_out + ((int64_t)b * (2 * s + 1) + j) * 8;
+        o[0] = (float)(tx - ccx);
+        o[1] = (float)(ty - ccy);
+        o[2] = (float)(tz - ccz);
+        o[3] = (float)bx[3];
+        o[4] = (float)bx[4];
+        o[5] = (float)bx[5];
+        o[6] = (float)(tyaw - cyaw);
+        o[7] = (float)(0.1 * (j - s));
+        if (j == s) {                                     // init_box = the centre box BEFORE re-centring
+            float* ib = init_box_out + (int64_t)b * 8;
+            ib[0] = (float)tx;
+            ib[1] = (float)ty;
+            ib[2] = (float)tz;
+            ib[3] = (float)bx[3];
+            ib[4] = (float)bx[4];
+            ib[5] = (float)bx[5];
+            ib[6] = (float)tyaw;
+            ib[7] = 0.0f;
+        }
+    }
+}
+
+hipError_t launch_static_crop_prep(const double* points, const int64_t* offsets, const int32_t* choice, const double* pose,
+                                   const double* box, int B, int N, uint64_t seed, int64_t item_offset, float* pts_out,
+                                   float* init_box_out, hipStream_t s) {
+    const int64_t total = (int64_t)B * N;
+    hipLaunchKernelGGL(static_crop_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, points, offsets,
+                       choice, pose, box, B, N, seed, item_offset, pts_out, init_box_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_dynamic_item_prep(const double* points, const int64_t* frame_offsets, const double* boxes,
+                                    const int64_t* track_first, const int32_t* item_track, const int32_t* item_frame,
+                                    const int32_t* choice, const double* pose, int B, int n_per, int r, int s_,
+                                    uint64_t seed, int64_t item_offset, float* pts_out, float* box_out,
+                                    float* init_box_out, hipStream_t st) {
+    const int64_t total = (int64_t)B * (2 * r + 1) * n_per + (int64_t)B * (2 * s_ + 1);
+    hipLaunchKernelGGL(dynamic_item_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, points,
+                       frame_offsets, boxes, track_first, item_track, item_frame, choice, pose, B, n_per, r, s_, seed,
+                       item_offset, pts_out, box_out, init_box_out);
+    return hipGetLastError();
+}

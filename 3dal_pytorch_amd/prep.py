@@ -1,0 +1,100 @@
+"""Crop preparation on the device: the per-item work of the reference's Dataset classes
+`STATICTRACK.__getitem__` (tools/static_model.py:529-572) and `DYNAMICTRACK.__getitem__`
+(tools/dynamic_model.py:419-509) — minus pickle I/O and minus the training labels — batched into one
+lib3dal_hip.so kernel per batch (dal3_static_crop_prep / dal3_dynamic_item_prep).
+
+Tracks use the reference's schema: dict with per-frame lists 'bbox' (7,) global frame,
+'point' (k,3) float64 global frame, 'score'. The host side only concatenates arrays, inverts the 4x4 poses,
+moves ONE box per static track to the vehicle frame and (sampler="numpy") draws the resampling indices from the
+global NumPy stream in the reference's order; every per-point operation runs on the GPU in float64.
+"""
+import numpy as np
+import torch
+
+from . import _hip
+
+
+def _transform_box(box, pose):
+    """static_model.py:574-588 for one box / one pose (float64)."""
+    heading = box[..., -1] + np.arctan2(pose[1, 0], pose[0, 0])
+    center = np.einsum("...ij,...nj->...ni", pose[0:3, 0:3], box[..., 0:3]) + np.expand_dims(pose[0:3, 3], axis=-2)
+    return np.concatenate([center, box[..., 3:6], heading[..., None]], axis=-1)
+
+
+def _dev(a, device, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(device)
+
+
+def prepare_static_batch(tracks, veh_to_global, n_points=4096, sampler="numpy", seed=10922081, item_offset=0,
+                         device="cuda"):
+    """tracks: list of track dicts; veh_to_global: list of flat-16 poses of each track's BEST-score frame
+    (annos['veh_to_global'], static_model.py:538). Returns (pts (B,3,N) fp32 view of point-major storage,
+    init_box (B,7) fp32) — exactly what static_eval.py:265-266 feeds forward()."""
+    B = len(tracks)
+    pts_list, boxes, poses, offsets = [], [], [], [0]
+    choice = np.empty((B, n_points), np.int32) if sampler == "numpy" else None
+    for b, tr in enumerate(tracks):
+        p = np.vstack(tr["point"])
+        best = int(np.argmax(np.stack(tr["score"])))
+        pose = np.linalg.inv(np.reshape(veh_to_global[b], [4, 4]))
+        boxes.append(_transform_box(np.asarray(tr["bbox"][best], np.float64)[None, :], pose)[0])
+        poses.append(pose.reshape(16))
+        pts_list.append(p)
+        offsets.append(offsets[-1] + p.shape[0])
+        if choice is not None:
+            choice[b] = np.random.choice(p.shape[0], n_points, replace=True)     # static_model.py:546
+    dev = torch.device(device)
+    d_pts = _dev(np.vstack(pts_list), dev, np.float64)
+    d_off = _dev(np.array(offsets), dev, np.int64)
+    d_pose = _dev(np.stack(poses), dev, np.float64)
+    d_box = _dev(np.stack(boxes), dev, np.float64)
+    d_choice = _dev(choice, dev, np.int32) if choice is not None else None
+    out = torch.empty((B, n_points, 3), dtype=torch.float32, device=dev)
+    init = torch.empty((B, 7), dtype=torch.float32, device=dev)
+    _hip.check(_hip.lib().dal3_static_crop_prep(_hip.ptr(d_pts), _hip.ptr(d_off), _hip.ptr(d_choice), _hip.ptr(d_pose),
+                                                _hip.ptr(d_box), B, n_points, seed, item_offset, _hip.ptr(out),
+                                                _hip.ptr(init), _hip.stream()))
+    return out.transpose(2, 1), init
+
+
+def prepare_dynamic_batch(tracks, items, veh_to_global, n_per_frame=1024, r=2, s=50, sampler="numpy", seed=10922081,
+                          item_offset=0, device="cuda"):
+    """tracks: list of track dicts; items: list of (track_index, frame_index); veh_to_global: flat-16 pose of each
+    item's own frame (dynamic_model.py:449-451). Returns (pts (B,4,5*n) view, box (B,8,2s+1) view, init_box (B,8))
+    as dynamic_eval.py:222-223 builds them."""
+    B = len(items)
+    frame_pts, frame_off, boxes, track_first = [], [0], [], [0]
+    for tr in tracks:
+        for p, bx in zip(tr["point"], tr["bbox"]):
+            p = np.asarray(p, np.float64).reshape(-1, 3)
+            frame_pts.append(p)
+            frame_off.append(frame_off[-1] + p.shape[0])
+            boxes.append(np.asarray(bx, np.float64).reshape(7))
+        track_first.append(track_first[-1] + len(tr["point"]))
+    poses = np.linalg.inv(np.reshape(np.asarray(veh_to_global, np.float64), [B, 4, 4])).reshape(B, 16)
+    choice = None
+    if sampler == "numpy":
+        choice = np.zeros((B, 2 * r + 1, n_per_frame), np.int32)
+        for b, (t, it) in enumerate(items):
+            n_frames = len(tracks[t]["point"])
+            for j, i in enumerate(range(it - r, it + r + 1)):                     # dynamic_model.py:430-437
+                if 0 <= i < n_frames and len(tracks[t]["point"][i]) > 0:
+                    choice[b, j] = np.random.choice(len(tracks[t]["point"][i]), n_per_frame, replace=True)
+    dev = torch.device(device)
+    d_pts = _dev(np.vstack(frame_pts) if frame_pts else np.zeros((0, 3)), dev, np.float64)
+    d_foff = _dev(np.array(frame_off), dev, np.int64)
+    d_boxes = _dev(np.stack(boxes), dev, np.float64)
+    d_first = _dev(np.array(track_first), dev, np.int64)
+    d_it = _dev(np.array([t for t, _ in items]), dev, np.int32)
+    d_if = _dev(np.array([i for _, i in items]), dev, np.int32)
+    d_pose = _dev(poses, dev, np.float64)
+    d_choice = _dev(choice, dev, np.int32) if choice is not None else None
+    n = (2 * r + 1) * n_per_frame
+    pts = torch.empty((B, n, 4), dtype=torch.float32, device=dev)
+    box = torch.empty((B, 2 * s + 1, 8), dtype=torch.float32, device=dev)
+    init = torch.empty((B, 8), dtype=torch.float32, device=dev)
+    _hip.check(_hip.lib().dal3_dynamic_item_prep(_hip.ptr(d_pts), _hip.ptr(d_foff), _hip.ptr(d_boxes), _hip.ptr(d_first),
+                                                 _hip.ptr(d_it), _hip.ptr(d_if), _hip.ptr(d_choice), _hip.ptr(d_pose), B,
+                                                 n_per_frame, r, s, seed, item_offset, _hip.ptr(pts), _hip.ptr(box),
+                                                 _hip.ptr(init), _hip.stream()))
+    return pts.transpose(2, 1), box.transpose(2, 1), init

@@ -148,3 +148,39 @@ def _boxes(seed, tag, g):
     gt = init + np.concatenate([normal(seed, tag + "g", (6,), 0.0, 0.1),
                                 normal(seed, tag + "gy", (1,), 0.0, 0.2)]).astype(np.float32)
     return init, gt.astype(np.float32)
+
+
+# --------------------------------------------------------------------------- tracks (crop preparation, N1)
+def pose_veh_to_global(seed, tag):
+    """flat 16 (row-major 4x4) rigid transform like Waymo's veh_to_global: yaw + a translation of kilometres
+    (which is why the preparation is done in float64)"""
+    yaw = uniform(seed, tag + "yaw", (1,), -np.pi, np.pi)[0]
+    t = uniform(seed, tag + "t", (3,), -2.0e4, 2.0e4) * np.array([1.0, 1.0, 0.01])
+    c, s = np.cos(yaw), np.sin(yaw)
+    m = np.array([[c, -s, 0.0, t[0]], [s, c, 0.0, t[1]], [0.0, 0.0, 1.0, t[2]], [0.0, 0.0, 0.0, 1.0]])
+    return m.reshape(16)
+
+
+def track(seed, tid, n_frames, max_pts=400, empty_every=0):
+    """One synthetic track in the reference's schema (SURVEY.md 8(g) `track.pkl`): per-frame lists of global-frame
+    boxes (7,), global-frame point arrays (k,3) float64 (some empty when empty_every > 0), scores, tokens."""
+    tag = f"trk{tid}"
+    base = uniform(seed, tag + "c", (3,), -2.0e4, 2.0e4) * np.array([1.0, 1.0, 0.01])
+    vel = normal(seed, tag + "v", (3,), 0.0, 0.5) * np.array([1.0, 1.0, 0.0])
+    size = np.array(arch.MEAN_SIZE[tid % 3]) + normal(seed, tag + "s", (3,), 0.0, 0.1)
+    yaw0 = uniform(seed, tag + "y", (1,), -np.pi, np.pi)[0]
+    out = {"bbox": [], "point": [], "score": [], "token": [], "match": []}
+    for f in range(n_frames):
+        c = base + vel * f + normal(seed, f"{tag}f{f}n", (3,), 0.0, 0.05)
+        yaw = yaw0 + 0.01 * f
+        out["bbox"].append(np.concatenate([c, size, [yaw]]))
+        k = 0 if (empty_every and f % empty_every == empty_every - 1) else \
+            int(20 + uniform(seed, f"{tag}f{f}k", (1,))[0] * (max_pts - 20))
+        local = uniform(seed, f"{tag}f{f}p", (k, 3), -1.0, 1.0) * (size / 2 * 1.3)
+        cy, sy = np.cos(yaw), np.sin(yaw)
+        rot = np.array([[cy, -sy, 0.0], [sy, cy, 0.0], [0.0, 0.0, 1.0]])
+        out["point"].append(local @ rot.T + c)
+        out["score"].append(float(uniform(seed, f"{tag}f{f}s", (1,))[0]))
+        out["token"].append(f"tok_{tid}_{f}")
+        out["match"].append(f"gt_{tid}")
+    return out

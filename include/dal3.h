@@ -168,6 +168,32 @@ int dal3_recenter_rotz(const float* obj_pts, int B, int M, const float* init_box
  * contiguous fp32 -> out (B,C). The HBM-roofline kernel of BASELINE.json. */
 int dal3_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, dal3_stream stream);
 
+/* ---- crop preparation right before the heads, float64 in, fp32 out ------------------
+ * STATICTRACK.__getitem__ (static_model.py:529-546, 568-572) for B tracks at once: points = all frames' points
+ * of every track stacked, global frame, (P_total,3) f64; offsets (B+1) delimit the tracks; pose (B,16) =
+ * inv(veh_to_global) of each track's best-score frame, row-major; box (B,7) f64 = that frame's detection
+ * already moved to the vehicle frame (transform_box, :574-588; a per-track scalar job the host does).
+ * pts_out (B,N,3) fp32 point-major = Rz(-yaw)(pose p - centre) of N points drawn WITH replacement: choice
+ * (B,N) i32 holds the draws (np.random.choice(P_b, N) for bit-reproducing the reference) or is NULL for the
+ * device RNG keyed on (seed, item_offset + b, n). init_box_out (B,7) fp32 = box. */
+int dal3_static_crop_prep(const double* points, const int64_t* offsets, const int32_t* choice,
+                          const double* pose, const double* box, int B, int N, uint64_t seed,
+                          int64_t item_offset, float* pts_out, float* init_box_out, dal3_stream stream);
+
+/* DYNAMICTRACK.__getitem__ (dynamic_model.py:429-453, 490-507) for B items: per-frame point arrays of all
+ * tracks concatenated (points (P_total,3) f64, frame_offsets (F_total+1)), per-frame global boxes (F_total,7)
+ * f64, track_first (n_tracks+1) = first frame of each track in those arrays; item b = frame item_frame[b] of
+ * track item_track[b]; pose (B,16) = inv(veh_to_global) of that frame. Outputs: pts_out (B,(2r+1)*n_per,4) with
+ * the 0.1*(j-r) time channel, box_out (B,2s+1,8) with 0.1*(j-s), init_box_out (B,8) (the centre box before
+ * re-centring). The reference's quirks are kept: missing/empty frames give zero points that are still moved by
+ * the pose and the re-centring; missing boxes are zero rows that are still pose-transformed; points are rotated
+ * by -yaw of the centre box, boxes only translated (yaw made relative). choice (B,2r+1,n_per) i32 or NULL. */
+int dal3_dynamic_item_prep(const double* points, const int64_t* frame_offsets, const double* boxes,
+                           const int64_t* track_first, const int32_t* item_track, const int32_t* item_frame,
+                           const int32_t* choice, const double* pose, int B, int n_per, int r, int s,
+                           uint64_t seed, int64_t item_offset, float* pts_out, float* box_out,
+                           float* init_box_out, dal3_stream stream);
+
 /* ---- one fused shared-MLP layer, for layer-wise tests: y = relu?(W' x + b') with BN folded,
  * x (B,C_in,N) strided -> y (B,N,C_out) point-major. */
 int dal3_shared_mlp_layer(const dal3_layer* layer, int relu, dal3_bcn x, int B, int N, float* y,

@@ -191,6 +191,49 @@ def main():
                         s2c_res=np.array([r for _, r in s2c]),
                         c2s=np.array([ut.class2size(c, np.array([0.1, -0.2, 0.3])) for c in range(3)]))
 
+    # ------------------------------------------------------------------ crop preparation (N1): the real Datasets
+    import pickle
+    import tempfile
+    # labels go through a numba-only routine that cannot run here; they are not captured (see oracle/ref_prep.py)
+    sys.modules["det3d.core.bbox.box_np_ops"].points_in_rbbox = lambda p, b: np.zeros((p.shape[0], 1))
+    with tempfile.TemporaryDirectory() as tmp:
+        def make_infos(tracks):
+            infos = {}
+            for tid, tr in tracks.items():
+                for f, tok in enumerate(tr["token"]):
+                    path = os.path.join(tmp, tok + ".pkl")
+                    gt = np.concatenate([tr["bbox"][f][:6], [0.0, 0.0], tr["bbox"][f][6:]]).astype(np.float32)
+                    with open(path, "wb") as fh:
+                        pickle.dump({"veh_to_global": synth.pose_veh_to_global(31, tok),
+                                     "objects": [{"name": tr["match"][-1], "box": gt}]}, fh)
+                    infos[tok] = {"anno_path": path}
+            return infos
+        # static: three tracks, 4096-point resample
+        tracks = {f"s{t}": synth.track(31, t, n_frames=7 + 3 * t) for t in range(3)}
+        ds = sm.STATICTRACK(tracks, make_infos(tracks), npoints=4096)
+        out = {}
+        for i in range(len(ds)):
+            np.random.seed(100 + i)
+            item = ds[i]
+            out[f"init_box{i}"] = item[1].numpy()
+            out[f"point{i}"] = item[3].numpy()
+            out[f"token{i}"] = np.array(item[4])
+        np.savez_compressed(os.path.join(out_dir, "prep_static.npz"), **out)
+        # dynamic: two tracks (one with empty frames), items at the borders and in the middle
+        dtracks = {"d0": synth.track(32, 10, n_frames=9, empty_every=4), "d1": synth.track(32, 11, n_frames=60)}
+        dds = dm.DYNAMICTRACK(dtracks, make_infos(dtracks), npoints=1024)
+        out = {"len": len(dds)}
+        for k, idx in enumerate([0, 1, 4, 8, 9, 9 + 30, 9 + 59]):
+            np.random.seed(200 + k)
+            item = dds[idx]
+            out[f"index{k}"] = idx
+            out[f"init_box{k}"] = item[1].numpy()
+            out[f"bbox{k}"] = item[2].numpy()
+            out[f"point{k}"] = item[4].numpy().astype(np.float32)          # what the driver's .float() keeps
+            out[f"point64_head{k}"] = item[4].numpy()[:8]
+        np.savez_compressed(os.path.join(out_dir, "prep_dynamic.npz"), **out)
+        print("prep fixtures: static", len(ds), "dynamic items", len(dds))
+
     # ------------------------------------------------------------------ state_dict key pin
     keys = {}
     for kind, ctor in (("static_one", lambda: sm.StaticModelOneBoxEst(3, 3)),

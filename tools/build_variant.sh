@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p variants/obj_$1
-for f in dal3_api dal3_pointmlp dal3_pointmlp_lp dal3_misc; do
+for f in dal3_api dal3_pointmlp dal3_pointmlp_lp dal3_misc dal3_prep; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-honor-nans $2 \
       -c 3dal_pytorch_amd/csrc/$f.hip -o variants/obj_$1/$f.o &
 done
