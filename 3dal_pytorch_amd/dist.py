@@ -6,6 +6,8 @@ single-GPU in the reference.
 
 No data-path collective exists besides that gather: every crop is independent in eval mode.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -21,8 +23,10 @@ def all_gather_boxes(local_boxes, n_items, group=None):
     """local_boxes (hi-lo, 7) of this rank's shard -> (n_items, 7) on every rank. The ragged tail
     is padded to ceil(n/world) rows so that one fixed-size all_gather_into_tensor moves it
     (a 14 KiB-per-rank message at B=4096, W=8: latency-bound, so one collective, not W)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return local_boxes
+    if dist.get_world_size(group) == 1 and os.environ.get("DAL3_FORCE_DIST") != "1":
+        return local_boxes                       # (DAL3_FORCE_DIST=1: run the collective even on one rank)
     world = dist.get_world_size(group)
     per = (n_items + world - 1) // world
     width = local_boxes.shape[1]

@@ -191,8 +191,11 @@ def main():
             sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # DAL3_FORCE_DIST=1 runs the RCCL path even with one rank (exercises init + all-gather on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("DAL3_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     static = args.head == "static"
@@ -215,10 +218,10 @@ def main():
 
     def step():
         boxes = step_fn()
-        return dal3_dist.all_gather_boxes(boxes, n_total) if world > 1 else boxes
+        return dal3_dist.all_gather_boxes(boxes, n_total) if use_dist else boxes
 
     def fence():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -231,7 +234,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     assert boxes.shape == (n_total, 7) and bool(torch.isfinite(boxes).all())
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -291,7 +294,7 @@ def main():
         rec["maxpool"] = maxpool_roofline(dev, iters=5)
         if static:
             rec["cpu_baseline"] = cpu_baseline(host)
-    if world > 1:
+    if use_dist:
         fence()
         torch.distributed.destroy_process_group()
     if rank == 0:
