@@ -78,6 +78,7 @@ SIGNATURES = {
     "dal3_recenter_rotz": (_i, [vp, _i, _i, vp, vp, vp, vp, vp, vp, vp]),
     "dal3_static_crop_prep": (_i, [vp, vp, vp, vp, vp, _i, _i, _u64, _i64, vp, vp, vp]),
     "dal3_dynamic_item_prep": (_i, [vp, vp, vp, vp, vp, vp, vp, vp, _i, _i, _i, _i, _u64, _i64, vp, vp, vp, vp]),
+    "dal3_writeback_boxes": (_i, [vp, vp, vp, vp, vp, vp, vp, vp, vp, _i, _i64, vp, vp, vp]),
     "dal3_maxpool_n": (_i, [vp, _i64, _i64, vp, vp]),
     "dal3_shared_mlp_layer": (_i, [C.POINTER(Layer), _i, BCN, _i, _i, vp, vp, _sz, vp]),
     "dal3_shared_mlp_layer_workspace_bytes": (_sz, [_i, _i]),

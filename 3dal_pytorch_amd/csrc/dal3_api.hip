@@ -630,6 +630,18 @@ extern "C" int dal3_dynamic_item_prep(const double* points, const int64_t* frame
     return 0;
 }
 
+extern "C" int dal3_writeback_boxes(const double* final_boxes, const int32_t* final_idx, const double* pose_best,
+                                    const double* pose_inv, const double* track_box, float* det,
+                                    const int64_t* det_start, const int32_t* det_count, const uint8_t* active, int P,
+                                    int64_t n_det, int32_t* match, int32_t* owner, dal3_stream stream) {
+    if (!final_boxes || !final_idx || !pose_inv || !track_box || !det || !det_start || !det_count || !active || !match ||
+        !owner || P <= 0 || n_det <= 0)
+        return fail(DAL3_EINVAL, "writeback_boxes: bad argument");
+    HIP_TRY(launch_writeback(final_boxes, final_idx, pose_best, pose_inv, track_box, det, det_start, det_count, active, P,
+                             n_det, match, owner, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, dal3_stream stream) {
     if (!x || !out || rows <= 0 || n <= 0) return fail(DAL3_EINVAL, "maxpool_n: bad argument");
     HIP_TRY(launch_maxpool_n(x, rows, n, out, static_cast<hipStream_t>(stream)));

@@ -163,6 +163,10 @@ hipError_t launch_dynamic_item_prep(const double* points, const int64_t* frame_o
                                     const int32_t* choice, const double* pose, int B, int n_per, int r, int s_,
                                     uint64_t seed, int64_t item_offset, float* pts_out, float* box_out,
                                     float* init_box_out, hipStream_t st);
+hipError_t launch_writeback(const double* final_boxes, const int32_t* final_idx, const double* pose_best,
+                            const double* pose_inv, const double* track_box, float* det, const int64_t* det_start,
+                            const int32_t* det_count, const uint8_t* active, int P, int64_t n_det, int32_t* match,
+                            int32_t* owner, hipStream_t s);
 hipError_t launch_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, hipStream_t s);
 hipError_t launch_segment_counts(const uint8_t* mask, int B, int N, int32_t* counts, hipStream_t s);
 hipError_t launch_compact_sample(const uint8_t* mask, BCN pts, int B, int N, int C, int M, int sampler,

@@ -149,3 +149,74 @@ hipError_t launch_dynamic_item_prep(const double* points, const int64_t* frame_o
                        item_offset, pts_out, box_out, init_box_out);
     return hipGetLastError();
 }
+
+// ================================================================================== write-back (N3)
+// The step right after the heads (static_eval.py:71-87,148-155; dynamic_eval.py:53-64,121-129): carry each refined
+// box into a frame of its track and overwrite the first detection of that frame whose centre lies within 0.1 m of
+// the track's own box there. One thread per (track, frame) pair; float64 like the reference.
+__device__ __forceinline__ void tbox(const double* __restrict__ m, const double* in, double* out) {   // transform_box
+    out[0] = m[0] * in[0] + m[1] * in[1] + m[2] * in[2] + m[3];
+    out[1] = m[4] * in[0] + m[5] * in[1] + m[6] * in[2] + m[7];
+    out[2] = m[8] * in[0] + m[9] * in[1] + m[10] * in[2] + m[11];
+    out[3] = in[3];
+    out[4] = in[4];
+    out[5] = in[5];
+    out[6] = in[6] + atan2(m[4], m[0]);
+}
+
+__global__ void writeback_match_kernel(const double* __restrict__ track_box, const double* __restrict__ pose_inv,
+                                       const float* __restrict__ det, const int64_t* __restrict__ det_start,
+                                       const int32_t* __restrict__ det_count, const uint8_t* __restrict__ active, int P,
+                                       int32_t* __restrict__ match, int32_t* __restrict__ owner) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    int found = -1;
+    if (active[p]) {
+        double c[7];
+        tbox(pose_inv + (int64_t)p * 16, track_box + (int64_t)p * 7, c);
+        const float* d = det + det_start[p] * 7;
+        for (int k = 0; k < det_count[p]; ++k) {
+            const double dx = (double)d[k * 7 + 0] - c[0], dy = (double)d[k * 7 + 1] - c[1], dz = (double)d[k * 7 + 2] - c[2];
+            if (sqrt(dx * dx + dy * dy + dz * dz) < 0.1) {
+                found = k;
+                break;
+            }
+        }
+        if (found >= 0) atomicMax(owner + det_start[p] + found, p);      // a later pair wins, as in the sequential loop
+    }
+    match[p] = found;
+}
+
+__global__ void writeback_apply_kernel(const double* __restrict__ final_boxes, const int32_t* __restrict__ final_idx,
+                                       const double* __restrict__ pose_best, const double* __restrict__ pose_inv,
+                                       const int64_t* __restrict__ det_start, const int32_t* __restrict__ match,
+                                       const int32_t* __restrict__ owner, int P, float* __restrict__ det) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P || match[p] < 0) return;
+    const int64_t row = det_start[p] + match[p];
+    if (owner[row] != p) return;
+    double a[7], b[7];
+    const double* f = final_boxes + (int64_t)final_idx[p] * 7;
+    if (pose_best) {                                       // static: best-frame vehicle -> global -> this frame's vehicle
+        tbox(pose_best + (int64_t)p * 16, f, a);
+        tbox(pose_inv + (int64_t)p * 16, a, b);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) b[k] = f[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) det[row * 7 + k] = (float)b[k];
+}
+
+hipError_t launch_writeback(const double* final_boxes, const int32_t* final_idx, const double* pose_best,
+                            const double* pose_inv, const double* track_box, float* det, const int64_t* det_start,
+                            const int32_t* det_count, const uint8_t* active, int P, int64_t n_det, int32_t* match,
+                            int32_t* owner, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(owner, 0xFF, (size_t)n_det * sizeof(int32_t), s);     // -1
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(writeback_match_kernel, dim3((P + 127) / 128), dim3(128), 0, s, track_box, pose_inv, det, det_start,
+                       det_count, active, P, match, owner);
+    hipLaunchKernelGGL(writeback_apply_kernel, dim3((P + 127) / 128), dim3(128), 0, s, final_boxes, final_idx, pose_best,
+                       pose_inv, det_start, match, owner, P, det);
+    return hipGetLastError();
+}

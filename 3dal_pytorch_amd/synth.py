@@ -184,3 +184,52 @@ def track(seed, tid, n_frames, max_pts=400, empty_every=0):
         out["token"].append(f"tok_{tid}_{f}")
         out["match"].append(f"gt_{tid}")
     return out
+
+
+def scene(seed, n_frames, n_tracks, n_clutter=5):
+    """A segment for the write-back step (N3): tracks that SHARE frames. Returns
+    tracks (list of track dicts whose tokens are 'fr_<f>' and whose boxes lie near the ego path),
+    poses {token: flat-16 veh_to_global}, dets {token: (n,7) float32 vehicle-frame detections = every track's box
+    of that frame plus clutter, in a shuffled order}, has_gt {(track, token): bool}."""
+    poses, dets = {}, {}
+    ego0 = uniform(seed, "ego0", (3,), -2.0e4, 2.0e4) * np.array([1.0, 1.0, 0.01])
+    for f in range(n_frames):
+        yaw = 0.3 + 0.02 * f
+        t = ego0 + np.array([1.5 * f, 0.4 * f, 0.0])
+        c, s = np.cos(yaw), np.sin(yaw)
+        poses[f"fr_{f}"] = np.array([[c, -s, 0.0, t[0]], [s, c, 0.0, t[1]], [0.0, 0.0, 1.0, t[2]],
+                                     [0.0, 0.0, 0.0, 1.0]]).reshape(16)
+    tracks, has_gt = [], {}
+    for k in range(n_tracks):
+        f0 = int(uniform(seed, f"sc{k}f0", (1,))[0] * (n_frames // 2))
+        f1 = min(n_frames, f0 + 7 + int(uniform(seed, f"sc{k}f1", (1,))[0] * n_frames))
+        rel = uniform(seed, f"sc{k}rel", (3,), -1.0, 1.0) * np.array([40.0, 15.0, 0.5])
+        size = np.array(arch.MEAN_SIZE[k % 3]) + normal(seed, f"sc{k}s", (3,), 0.0, 0.1)
+        yaw0 = uniform(seed, f"sc{k}y", (1,), -np.pi, np.pi)[0]
+        tr = {"bbox": [], "point": [], "score": [], "token": [], "match": [], "type": []}
+        for f in range(f0, f1):
+            ctr = ego0 + rel + np.array([1.5 * f0, 0.4 * f0, 0.0]) + normal(seed, f"sc{k}n{f}", (3,), 0.0, 0.03)
+            tr["bbox"].append(np.concatenate([ctr, size, [yaw0 + 0.005 * f]]))
+            tr["point"].append(np.zeros((0, 3)))
+            tr["score"].append(float(uniform(seed, f"sc{k}sc{f}", (1,))[0]))
+            tr["token"].append(f"fr_{f}")
+            tr["match"].append(f"gt_{k}")
+            tr["type"].append(1 if k % 2 == 0 else 4)
+            has_gt[(k, f"fr_{f}")] = uniform(seed, f"sc{k}g{f}", (1,))[0] > 0.15
+        tracks.append(tr)
+    for f in range(n_frames):
+        tok = f"fr_{f}"
+        pose = np.linalg.inv(poses[tok].reshape(4, 4))
+        rows = []
+        for tr in tracks:
+            if tok in tr["token"]:
+                b = tr["bbox"][tr["token"].index(tok)]
+                ctr = pose[:3, :3] @ b[:3] + pose[:3, 3]
+                rows.append(np.concatenate([ctr, b[3:6], [b[6] + np.arctan2(pose[1, 0], pose[0, 0])]]))
+        for c in range(n_clutter):
+            rows.append(np.concatenate([uniform(seed, f"cl{f}_{c}", (3,), -60.0, 60.0),
+                                        uniform(seed, f"cls{f}_{c}", (3,), 1.0, 5.0),
+                                        uniform(seed, f"cly{f}_{c}", (1,), -np.pi, np.pi)]))
+        order = np.argsort(uniform(seed, f"ord{f}", (len(rows),)))
+        dets[tok] = np.stack(rows)[order].astype(np.float32)
+    return tracks, poses, dets, has_gt

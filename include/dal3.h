@@ -194,6 +194,20 @@ int dal3_dynamic_item_prep(const double* points, const int64_t* frame_offsets, c
                            uint64_t seed, int64_t item_offset, float* pts_out, float* box_out,
                            float* init_box_out, dal3_stream stream);
 
+/* ---- write-back of refined boxes into the per-frame detections: the det_annos update of
+ * postprocessing() in static_eval.py:71-87,148-155 and dynamic_eval.py:53-64,121-129, for P (track, frame) pairs.
+ * final_boxes (n,7) f64, final_idx (P): which refined box a pair carries; pose_best (P,16) f64 veh_to_global of the
+ * track's best frame (static) or NULL (dynamic: the box already is in the pair's frame); pose_inv (P,16) f64
+ * inv(veh_to_global) of the pair's frame; track_box (P,7) f64 the track's own global box in that frame (the search
+ * key); det (n_det,7) fp32 all frames' detections concatenated, UPDATED IN PLACE; det_start/det_count (P): the
+ * pair's frame in det; active (P) u8: the reference skips frames that lack the matched GT object.
+ * match (P) i32 out: matched row within the frame or -1; owner (n_det) i32 scratch. When two pairs hit one row
+ * the later pair wins, as in the reference's sequential loop. */
+int dal3_writeback_boxes(const double* final_boxes, const int32_t* final_idx, const double* pose_best,
+                         const double* pose_inv, const double* track_box, float* det, const int64_t* det_start,
+                         const int32_t* det_count, const uint8_t* active, int P, int64_t n_det, int32_t* match,
+                         int32_t* owner, dal3_stream stream);
+
 /* ---- one fused shared-MLP layer, for layer-wise tests: y = relu?(W' x + b') with BN folded,
  * x (B,C_in,N) strided -> y (B,N,C_out) point-major. */
 int dal3_shared_mlp_layer(const dal3_layer* layer, int relu, dal3_bcn x, int B, int N, float* y,

@@ -234,6 +234,41 @@ def main():
         np.savez_compressed(os.path.join(out_dir, "prep_dynamic.npz"), **out)
         print("prep fixtures: static", len(ds), "dynamic items", len(dds))
 
+        # -------------------------------------------------------------- write-back (N3): the real postprocessing()
+        # IoU metrics need the un-vendored provider_fpointnet: stubbed, not captured; det_annos (the product) is.
+        import logging
+        se.compute_box3d_iou = de.compute_box3d_iou = lambda *a: (np.zeros(1), np.zeros(1))
+        tracks_l, poses_s, dets_s, has_gt = synth.scene(33, n_frames=24, n_tracks=9)
+        infos, token2idx, det_annos = {}, {}, []
+        for f, (tok, pose) in enumerate(poses_s.items()):
+            objs = [{"name": f"gt_{k}", "box": np.concatenate([tr["bbox"][tr["token"].index(tok)][:6], [0.0, 0.0],
+                                                                  tr["bbox"][tr["token"].index(tok)][6:]]).astype(np.float32)}
+                    for k, tr in enumerate(tracks_l) if tok in tr["token"] and has_gt[(k, tok)]]
+            path = os.path.join(tmp, tok + ".pkl")
+            with open(path, "wb") as fh:
+                pickle.dump({"veh_to_global": pose, "objects": objs}, fh)
+            infos[tok] = {"anno_path": path}
+            token2idx[tok] = f
+            det_annos.append({"boxes_lidar": dets_s[tok].copy(), "frame_id": tok})
+        track_dict = {f"trk{k}": tr for k, tr in enumerate(tracks_l)}
+        n_static = len(tracks_l)
+        final_static = np.stack([np.concatenate([synth.normal(34, f"fs{k}", (3,), 0.0, 2.0),
+                                                 np.array(synth.arch.MEAN_SIZE[k % 3]) + 0.2,
+                                                 synth.uniform(34, f"fsy{k}", (1,), -3.0, 3.0)]) for k in range(n_static)])
+        out_s = se.postprocessing(track_dict, infos, token2idx, final_static.copy(),
+                                  [dict(d, boxes_lidar=d["boxes_lidar"].copy()) for d in det_annos],
+                                  os.path.join(tmp, "res_s.pkl"), logging.getLogger("gen"))[3]
+        n_dyn = sum(len(tr["token"]) for tr in tracks_l)
+        final_dyn = synth.normal(35, "fd", (n_dyn, 7), 0.0, 5.0)
+        out_d = de.postprocessing(track_dict, infos, token2idx, final_dyn.copy(),
+                                  [dict(d, boxes_lidar=d["boxes_lidar"].copy()) for d in det_annos],
+                                  os.path.join(tmp, "res_d.pkl"), logging.getLogger("gen"))[3]
+        np.savez_compressed(os.path.join(out_dir, "post_writeback.npz"), final_static=final_static, final_dyn=final_dyn,
+                            **{f"static_{d['frame_id']}": d["boxes_lidar"] for d in out_s},
+                            **{f"dynamic_{d['frame_id']}": d["boxes_lidar"] for d in out_d})
+        changed = sum(int((a["boxes_lidar"] != b["boxes_lidar"]).any(1).sum()) for a, b in zip(out_s, det_annos))
+        print("write-back fixtures: frames", len(det_annos), "static rows changed", changed)
+
     # ------------------------------------------------------------------ state_dict key pin
     keys = {}
     for kind, ctor in (("static_one", lambda: sm.StaticModelOneBoxEst(3, 3)),
