@@ -20,8 +20,12 @@
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
 struct BF16 {
     typedef bf16x8_t v8;
+    typedef bf16x2_t v2;
     typedef __bf16 elem;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -29,6 +33,7 @@ struct BF16 {
 };
 struct FP16 {
     typedef f16x8_t v8;
+    typedef f16x2_t v2;
     typedef _Float16 elem;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -41,13 +46,29 @@ struct ActTile {
     typename DT::v8 k[2];
 };
 
+// round to 16 bits first, then ReLU on the packed pairs with ONE integer v_pk_max_i16 per dword (the sign bit
+// of a bf16 / fp16 is the sign bit of its int16 pattern; rounding never changes the sign, so
+// relu(round(x)) == round(relu(x))): 8 cvt_pk + 8 pk_max per tile instead of 16 max + 8 cvt_pk
+// (written pair by pair: converting the whole vector and then taking the max makes hipcc split and re-merge
+// the halves with v_perm_b32, 16 instructions instead of 8)
+typedef short short2_t __attribute__((ext_vector_type(2)));
+typedef int int4_t __attribute__((ext_vector_type(4)));
 template <class DT>
 __device__ __forceinline__ ActTile<DT> pack_relu(const f32x16& acc) {
     ActTile<DT> t;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+        int4_t w;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t.k[s][j] = (typename DT::elem)relu1(acc[8 * s + j]);
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 p = {acc[8 * s + 2 * i], acc[8 * s + 2 * i + 1]};
+            const typename DT::v2 q = __builtin_convertvector(p, typename DT::v2);
+            short2_t b = __builtin_bit_cast(short2_t, q);
+            const short2_t zero = {0, 0};
+            b = __builtin_elementwise_max(b, zero);
+            w[i] = __builtin_bit_cast(int, b);
+        }
+        t.k[s] = __builtin_bit_cast(typename DT::v8, w);
     }
     return t;
 }

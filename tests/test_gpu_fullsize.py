@@ -1,0 +1,82 @@
+"""BASELINE.json's full sizes, through size-independent properties (the oracle needs minutes per 64 crops on a
+CPU, so at 4096 crops the checks are structural): a slice of the big batch equals the same crops run alone,
+bit for bit; logits are invariant under a permutation of a crop's points; every output is finite; the
+standalone max-pool equals the fused one."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from _common import build_model, synth
+
+hip = importlib.import_module("3dal_pytorch_amd._hip")
+pytestmark = pytest.mark.gpu
+
+
+def test_static_c2_full_batch_properties():
+    B, N = 4096, 1024
+    base, init_np, gt_np = synth.static_crops(256, N, seed=4)
+    pts_np = np.tile(base, (16, 1, 1))
+    pts_np[256:] += synth.normal(4, "jit", (1, 1, 3), 0.0, 0.01).astype(np.float32)   # not exact copies
+    init_np, gt_np = np.tile(init_np, (16, 1)), np.tile(gt_np, (16, 1))
+    model = build_model("static_two", synth.state_dict("static_two", seed=4))
+    pts, init, gt = (torch.from_numpy(a).cuda() for a in (pts_np, init_np, gt_np))
+    full = model._run(pts.transpose(2, 1), init, gt)
+    for k in ("logits", "bp1", "bp2", "boxes7"):
+        assert bool(torch.isfinite(full[k]).all()), k
+    lo, hi = 1000, 1064
+    model.item_offset = lo
+    part = model._run(pts[lo:hi].transpose(2, 1), init[lo:hi], gt[lo:hi])
+    model.item_offset = 0
+    for k in ("logits", "mask", "obj_idx", "bp1", "box_one", "bp2", "boxes7"):
+        assert torch.equal(part[k], full[k][lo:hi]), k
+    perm = torch.from_numpy(np.argsort(synth.uniform(4, "perm", (N,)))).cuda()
+    permuted = model._run(pts[:64][:, perm].transpose(2, 1), init[:64], gt[:64])
+    assert torch.equal(permuted["logits"], full["logits"][:64][:, perm])
+
+
+def test_dynamic_c3_shape_properties():
+    B = 64                                                  # the C3 item shape (5 x 1024 points, 101 boxes)
+    p, bx, i8, _ = synth.dynamic_items(B, seed=8)
+    model = build_model("dynamic", synth.state_dict("dynamic", seed=8))
+    dp, db, di = torch.from_numpy(p).cuda(), torch.from_numpy(bx).cuda(), torch.from_numpy(i8).cuda()
+    full = model._run(dp.transpose(2, 1), db.transpose(2, 1), init_box8=di)
+    assert bool(torch.isfinite(full["boxes7"]).all()) and full["logits"].shape == (B, 5120, 2)
+    model.item_offset = 40
+    part = model._run(dp[40:56].transpose(2, 1), db[40:56].transpose(2, 1), init_box8=di[40:56])
+    model.item_offset = 0
+    for k in ("logits", "embedding", "bp", "boxes7"):
+        assert torch.equal(part[k], full[k][40:56]), k
+    # the box window is max-pooled: reversing the 101 boxes cannot change the box embedding
+    rev = model._run(dp.transpose(2, 1), db.flip(1).transpose(2, 1), init_box8=di)
+    assert torch.equal(rev["embedding"][:, 256:], full["embedding"][:, 256:])
+
+
+def test_fused_max_equals_standalone_maxpool():
+    """global feature of ins_seg (max fused into conv5's epilogue) == dal3_maxpool_n over a materialised conv5
+    output computed layer by layer with dal3_shared_mlp_layer"""
+    import ctypes as C
+    B, N = 4, 1024
+    pts_np, _, _ = synth.static_crops(B, N, seed=2)
+    sd = synth.state_dict("static_one", seed=2)
+    model = build_model("static_one", sd)
+    lib = hip.lib()
+    x = torch.from_numpy(pts_np).cuda().transpose(2, 1)
+    w = model._cache.get("ins_seg", model.ins_seg, hip.HEAD_INS_SEG)
+    g = torch.zeros((B, 1024), device="cuda")
+    hip.check(lib.dal3_ins_seg_encode(hip.ptr(w), hip.F32, 3, hip.bcn(x), B, N, hip.ptr(g), hip.stream()))
+    cur = x
+    for name, bn, ci, co in [("conv1", "bn1", 3, 64), ("conv2", "bn2", 64, 64), ("conv3", "bn3", 64, 64),
+                             ("conv4", "bn4", 64, 128), ("conv5", "bn5", 128, 1024)]:
+        L = hip.layer_struct(getattr(model.ins_seg, name), getattr(model.ins_seg, bn))
+        ws = torch.empty(lib.dal3_shared_mlp_layer_workspace_bytes(ci, co), dtype=torch.uint8, device="cuda")
+        y = torch.empty((B, N, co), device="cuda")
+        hip.check(lib.dal3_shared_mlp_layer(C.byref(L), 1, hip.bcn(cur), B, N, hip.ptr(y), hip.ptr(ws), ws.numel(),
+                                            hip.stream()))
+        cur = y.transpose(2, 1)
+    conv5 = cur.contiguous()                                 # (B,1024,N)
+    out = torch.empty((B, 1024), device="cuda")
+    hip.check(lib.dal3_maxpool_n(hip.ptr(conv5), B * 1024, N, hip.ptr(out), hip.stream()))
+    # both are fp32 FMA chains over the same folded weights; only the position of the bias add differs
+    assert float((out - g).abs().max() / g.abs().max()) < 2e-6

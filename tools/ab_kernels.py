@@ -33,6 +33,8 @@ dev = torch.device("cuda:0")
 def load(path):
     h = C.CDLL(os.path.abspath(path))
     for name, (res, a) in hip.SIGNATURES.items():
+        if not hasattr(h, name):                      # an older build may predate some entry points
+            continue
         fn = getattr(h, name)
         fn.restype, fn.argtypes = res, a
     return h
