@@ -300,14 +300,26 @@ static hipError_t head_lp(const PointHeadLpW& w, BCN x, int c_in, int B, int M, 
     return hipGetLastError();
 }
 
+// This file is compiled twice (Makefile): LP_PART=1 -> encode + point heads, with `-mllvm
+// -amdgpu-mfma-vgpr-form` (accumulators in arch VGPRs: the pack/ReLU/max epilogues then need no
+// v_accvgpr_read; encode 1.18 -> 1.00 ms, heads 0.90 -> 0.86 ms), LP_PART=2 -> decode without it (its 256
+// accumulator registers only fit beside the rest in the AGPR half; with the flag it slows 1.92 -> 2.27 ms).
+#ifndef LP_PART
+#define LP_PART 3
+#endif
+#if LP_PART & 1
 hipError_t launch_ins_seg_encode_lp(int dtype, const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
     return dtype == DAL3_BF16 ? enc_lp<BF16>(w, pts, c_in, B, N, g, s) : enc_lp<FP16>(w, pts, c_in, B, N, g, s);
 }
+#endif
+#if LP_PART & 2
 hipError_t launch_ins_seg_decode_lp(int dtype, const InsSegLpW& w, BCN pts, int c_in, int B, int N, const float* gbias,
                                     float* logits, uint8_t* mask, hipStream_t s) {
     return dtype == DAL3_BF16 ? dec_lp<BF16>(w, pts, c_in, B, N, gbias, logits, mask, s)
                               : dec_lp<FP16>(w, pts, c_in, B, N, gbias, logits, mask, s);
 }
+#endif
+#if LP_PART & 1
 hipError_t launch_point_head_lp(int dtype, int head_kind, const PointHeadLpW& w, BCN x, int c_in, int B, int M,
                                 float* feat, hipStream_t s) {
     const bool bf = dtype == DAL3_BF16;
@@ -325,3 +337,4 @@ hipError_t launch_point_head_lp(int dtype, int head_kind, const PointHeadLpW& w,
             return hipErrorInvalidValue;
     }
 }
+#endif

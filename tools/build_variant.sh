@@ -1,12 +1,15 @@
 #!/bin/bash
 # tools/build_variant.sh NAME "-DDAL3_ENC_T=2 ..."  -> variants/NAME.so (for tools/ab_kernels.py)
+# mirrors 3dal_pytorch_amd/csrc/Makefile (the 16-bit kernels are compiled twice, see dal3_pointmlp_lp.hip)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p variants/obj_$1
-for f in dal3_api dal3_pointmlp dal3_pointmlp_lp dal3_misc dal3_prep; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-honor-nans $2 \
-      -c 3dal_pytorch_amd/csrc/$f.hip -o variants/obj_$1/$f.o &
+CC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-honor-nans"
+for f in dal3_api dal3_pointmlp dal3_misc dal3_prep; do
+  $CC $2 -c 3dal_pytorch_amd/csrc/$f.hip -o variants/obj_$1/$f.o &
 done
+$CC $2 -DLP_PART=1 -mllvm -amdgpu-mfma-vgpr-form -c 3dal_pytorch_amd/csrc/dal3_pointmlp_lp.hip -o variants/obj_$1/lp_enc.o &
+$CC $2 -DLP_PART=2 -c 3dal_pytorch_amd/csrc/dal3_pointmlp_lp.hip -o variants/obj_$1/lp_dec.o &
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 variants/obj_$1/*.o -o variants/$1.so
 rm -rf variants/obj_$1
