@@ -542,7 +542,7 @@ static int fc_chain(const FcW& f, const float* x, int64_t xs, float* out, int64_
 }
 
 static int point_head_run(int head_kind, const void* packed, int dtype, const dal3_bcn& x, int B, int M, float* out,
-                          int64_t out_stride, const HeadWs& ws, hipStream_t s) {
+                          int64_t out_stride, const HeadWs& ws, hipStream_t s, const int32_t* distinct = nullptr) {
     TRY(check_dtype(dtype));
     if (head_kind != DAL3_HEAD_STATIC_BOX_EST && head_kind != DAL3_HEAD_POINT_EMB && head_kind != DAL3_HEAD_BOX_EMB)
         return fail(DAL3_EINVAL, "point_head: head_kind %d is not a point head", head_kind);
@@ -554,11 +554,11 @@ static int point_head_run(int head_kind, const void* packed, int dtype, const da
     HIP_TRY(hipMemsetAsync(ws.feat, 0, (size_t)B * 512 * sizeof(float), s));
     if (dtype != DAL3_F32) {
         const PointHeadLpW w = point_head_lp_view(packed, head_kind);
-        HIP_TRY(launch_point_head_lp(dtype, head_kind, w, to_bcn(x), c_in, B, M, ws.feat, s));
+        HIP_TRY(launch_point_head_lp(dtype, head_kind, w, to_bcn(x), c_in, B, M, ws.feat, distinct, s));
         return fc_chain(w.fc, ws.feat, 512, out, out_stride, B, ws.t1, ws.t2, s);
     }
     const PointHeadW w = point_head_view(static_cast<const float*>(packed), head_kind);
-    HIP_TRY(launch_point_head(head_kind, w, to_bcn(x), c_in, B, M, ws.feat, s));
+    HIP_TRY(launch_point_head(head_kind, w, to_bcn(x), c_in, B, M, ws.feat, distinct, s));
     return fc_chain(w.fc, ws.feat, 512, out, out_stride, B, ws.t1, ws.t2, s);
 }
 
@@ -718,7 +718,9 @@ extern "C" int dal3_static_forward(const dal3_static_args* a, int phases, dal3_s
     TRY(gather_run(a->mask, a->pts, B, N, 3, M, a->sampler, a->choice, a->seed, a->item_offset, a->counts, a->obj_idx,
                    ws.obj, ws.pos, s));
     const dal3_bcn obj{ws.obj, (int64_t)M * 3, 1, 3};
-    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_one, a->dtype, obj, B, M, a->box_pred_one, 39, ws.head, s));
+    // device sampler: the first min(count, M) object points are distinct, the rest are copies -> skipped by the head
+    const int32_t* distinct = a->sampler == DAL3_SAMPLER_DEVICE ? a->counts : nullptr;
+    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_one, a->dtype, obj, B, M, a->box_pred_one, 39, ws.head, s, distinct));
     if (!a->two_stage) {
         // center = center_boxnet + init_box[:, :3] (static_model.py:132); yaw += init yaw (static_eval.py:280)
         HIP_TRY(launch_decode_boxes(a->box_pred_one, B, a->init_box, 7, 0, nullptr, 0, a->init_box + 6, 7,
@@ -734,7 +736,7 @@ extern "C" int dal3_static_forward(const dal3_static_args* a, int phases, dal3_s
                             a->bbox_gt ? a->heading_class_label_two : nullptr,
                             a->bbox_gt ? a->heading_residuals_label_two : nullptr, s));
     const dal3_bcn obj2{ws.obj2, (int64_t)M * 3, 1, 3};
-    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_two, a->dtype, obj2, B, M, a->box_pred_two, 39, ws.head, s));
+    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_two, a->dtype, obj2, B, M, a->box_pred_two, 39, ws.head, s, distinct));
     // center_two += center_one (static_model.py:211); final yaw += box_one yaw (static_eval.py:282)
     HIP_TRY(launch_decode_boxes(a->box_pred_two, B, a->center_one, 3, 1, nullptr, 0, a->box_one + 6, 7,
                                 a->heading_residuals_two, a->size_residuals_two, a->center_two, a->boxes7, s));
@@ -780,7 +782,8 @@ extern "C" int dal3_dynamic_forward(const dal3_dynamic_args* a, int phases, dal3
                    ws.obj, ws.pos, s));
     const dal3_bcn obj{ws.obj, (int64_t)M * 4, 1, 4};
     // embedding = cat[point_e (256), box_e (128)] (dynamic_model.py:133-137): written side by side
-    TRY(point_head_run(DAL3_HEAD_POINT_EMB, a->w_point_emb, a->dtype, obj, B, M, a->embedding, 384, ws.head, s));
+    TRY(point_head_run(DAL3_HEAD_POINT_EMB, a->w_point_emb, a->dtype, obj, B, M, a->embedding, 384, ws.head, s,
+                       a->sampler == DAL3_SAMPLER_DEVICE ? a->counts : nullptr));
     TRY(point_head_run(DAL3_HEAD_BOX_EMB, a->w_box_emb, a->dtype, a->box, B, a->n_box, a->embedding + 256, 384, ws.head, s));
     TRY(fc_chain(fc_head_view(static_cast<const float*>(a->w_box_est)), a->embedding, 384, a->box_pred, 39, B,
                  ws.head.t1, ws.head.t2, s));

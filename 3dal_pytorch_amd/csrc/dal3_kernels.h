@@ -120,7 +120,7 @@ hipError_t launch_ins_seg_encode_lp(int dtype, const InsSegLpW& w, BCN pts, int 
 hipError_t launch_ins_seg_decode_lp(int dtype, const InsSegLpW& w, BCN pts, int c_in, int B, int N, const float* gbias,
                                     float* logits, uint8_t* mask, hipStream_t s);
 hipError_t launch_point_head_lp(int dtype, int head_kind, const PointHeadLpW& w, BCN x, int c_in, int B, int M,
-                                float* feat, hipStream_t s);
+                                float* feat, const int32_t* distinct, hipStream_t s);
 // 16-bit fragment packing: element j of lane l of fragment (mt,kt,s) = W'[32mt + (l&31)][32kt + 16s + 8(j>>2) + 4(l>>5) + (j&3)]
 hipError_t launch_pack_weight_lp(const dal3_layer& L, int dtype, int kt_major, int col_off, int n_cols, int mt_n, int kt_n,
                                  uint16_t* out, hipStream_t s, int grp_blocks = 0, int64_t grp_a0 = 0, int64_t grp_a1 = 0,
@@ -139,7 +139,9 @@ void point_head_dims(int head_kind, int* c_in, int* ks, int c[4], int* n_fc, int
 hipError_t launch_ins_seg_encode(const InsSegW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s);
 hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int N, const float* gbias,
                                  float* logits, uint8_t* mask, hipStream_t s);
-hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat, hipStream_t s);
+// distinct (B) i32 or NULL: only the first distinct[b] points of item b are distinct (the rest duplicate them)
+hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat,
+                             const int32_t* distinct, hipStream_t s);
 hipError_t launch_generic_layer(const f32x4* wf, const float* w1, const float* bias, int kt_n, int ks_n, int mt_n,
                                 int relu, BCN x, int c_in, int B, int N, float* y, hipStream_t s);
 

@@ -205,15 +205,27 @@ __global__ __launch_bounds__(64 * DAL3_WG_WAVES) void ins_seg_decode_kernel(InsS
 // ------------------------------------------------------------------------------------------------
 template <int KS, int C1, int C2, int C3, int T>
 __global__ __launch_bounds__(64 * DAL3_WG_WAVES) void point_head_kernel(PointHeadW w, BCN x, int c_in, int n_pts,
-                                                         int tiles_per_item, float* __restrict__ feat) {
+                                                         int tiles_per_item, float* __restrict__ feat,
+                                                         const int32_t* __restrict__ distinct) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
-    const int64_t b = blockIdx.x / tiles_per_item;
-    const int n0 = ((blockIdx.x % tiles_per_item) * DAL3_WG_WAVES + wave) * (32 * T);
+    // item-minor block order: workgroups are dealt round-robin over the 8 XCDs, and with duplicate skipping only
+    // an item's FIRST tiles carry work; (item, tile) = (id % B, id / B) spreads those over every XCD (with
+    // item-major order and 4 tiles per item they all landed on 2 of the 8 XCDs: 4.6x slower)
+    const int n_items = gridDim.x / tiles_per_item;
+    const int64_t b = blockIdx.x % n_items;
+    const int n0 = ((blockIdx.x / n_items) * DAL3_WG_WAVES + wave) * (32 * T);
     __shared__ float s_b4[512];                        // conv4's folded bias, read by the max epilogue
     for (int i = threadIdx.x; i < 512; i += 64 * DAL3_WG_WAVES) s_b4[i] = w.b4[i];
     __syncthreads();
+    // distinct[b] (optional): only the first distinct[b] points of the item differ, the rest are duplicates of
+    // them (gather: count < M tops up with copies; count == 0 is an all-zero row). The head is per-point work
+    // followed by a max over points, so the duplicates cannot change the result and are not computed.
+    if (distinct) {
+        const int d = distinct[b];
+        n_pts = d <= 0 ? 1 : (d < n_pts ? d : n_pts);
+    }
     if (n0 >= n_pts) return;
 
     WRing<DAL3_PF> ring;
@@ -305,19 +317,20 @@ hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int
     return hipGetLastError();
 }
 
-hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat, hipStream_t s) {
+hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat,
+                             const int32_t* distinct, hipStream_t s) {
     constexpr int T = DAL3_HEAD_T;
     const int tpi = tiles_per_item(M, T);
     const dim3 grid((unsigned)((int64_t)B * tpi)), block(64 * DAL3_WG_WAVES);
     switch (head_kind) {
         case 1:  // static box_est 3 -> 128 -> 128 -> 256 -> 512
-            hipLaunchKernelGGL((point_head_kernel<2, 128, 128, 256, T>), grid, block, 0, s, w, x, c_in, M, tpi, feat);
+            hipLaunchKernelGGL((point_head_kernel<2, 128, 128, 256, T>), grid, block, 0, s, w, x, c_in, M, tpi, feat, distinct);
             break;
         case 2:  // point_emb 4 -> 64 -> 128 -> 256 -> 512
-            hipLaunchKernelGGL((point_head_kernel<2, 64, 128, 256, T>), grid, block, 0, s, w, x, c_in, M, tpi, feat);
+            hipLaunchKernelGGL((point_head_kernel<2, 64, 128, 256, T>), grid, block, 0, s, w, x, c_in, M, tpi, feat, distinct);
             break;
         case 3:  // box_emb 8 -> 64 -> 64 -> 128 -> 512
-            hipLaunchKernelGGL((point_head_kernel<4, 64, 64, 128, T>), grid, block, 0, s, w, x, c_in, M, tpi, feat);
+            hipLaunchKernelGGL((point_head_kernel<4, 64, 64, 128, T>), grid, block, 0, s, w, x, c_in, M, tpi, feat, distinct);
             break;
         default:
             return hipErrorInvalidValue;

@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
 // conv1..4 + max over the points. Per layer the out-tiles are grouped into segments of <= 32 fragments.
 template <class DT, int KS, int C1, int C2, int C3, int T>
 __global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN x, int c_in, int n_pts,
-                                                            int tiles_per_item, float* __restrict__ feat) {
+                                                            int tiles_per_item, float* __restrict__ feat,
+                                                            const int32_t* __restrict__ distinct) {
     constexpr int SEG = LP_HEAD_SEG;
     constexpr int K2 = C1 / 32, M2 = C2 / 32, K3 = C2 / 32, M3 = C3 / 32, K4 = C3 / 32, M4 = 16;
     constexpr int TPS2 = lp_tiles_per_seg(K2, M2), TPS3 = lp_tiles_per_seg(K3, M3), TPS4 = lp_tiles_per_seg(K4, M4);
@@ -211,8 +212,15 @@ __global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN 
     int* s_max = reinterpret_cast<int*>(s_bias + C2 + C3 + 512);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t b = blockIdx.x / tiles_per_item;
-    const int n0 = ((blockIdx.x % tiles_per_item) * LP_WAVES + wave) * (32 * T);
+    const int n_items = gridDim.x / tiles_per_item;        // item-minor block order (XCD balance): see point_head_kernel
+    const int64_t b = blockIdx.x % n_items;
+    const int wg_tile = blockIdx.x / n_items;
+    const int n0 = (wg_tile * LP_WAVES + wave) * (32 * T);
+    if (distinct) {                                        // duplicates beyond the first distinct[b] points: see point_head_kernel
+        const int d = distinct[b];
+        n_pts = d <= 0 ? 1 : (d < n_pts ? d : n_pts);
+        if (wg_tile * LP_WAVES * 32 * T >= n_pts) return;  // whole workgroup: uniform exit
+    }
 
     for (int i = threadIdx.x; i < C2 + C3 + 512; i += 256) s_bias[i] = w.bias[i];
     for (int i = threadIdx.x; i < 512; i += 256) s_max[i] = 0;
@@ -289,14 +297,15 @@ static hipError_t dec_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, co
     return hipGetLastError();
 }
 template <class DT, int KS, int C1, int C2, int C3>
-static hipError_t head_lp(const PointHeadLpW& w, BCN x, int c_in, int B, int M, float* feat, hipStream_t s) {
+static hipError_t head_lp(const PointHeadLpW& w, BCN x, int c_in, int B, int M, float* feat, const int32_t* distinct,
+                          hipStream_t s) {
     constexpr int T = DAL3_LP_HEAD_T;
     const size_t lds = LP_SLOTS * LP_HEAD_SEG * 1024 + (C2 + C3 + 512 + 512) * 4;
     auto k = point_head_lp_kernel<DT, KS, C1, C2, C3, T>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int tpi = lp_tiles(M, T);
-    hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * tpi)), dim3(256), lds, s, w, x, c_in, M, tpi, feat);
+    hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * tpi)), dim3(256), lds, s, w, x, c_in, M, tpi, feat, distinct);
     return hipGetLastError();
 }
 
@@ -321,18 +330,18 @@ hipError_t launch_ins_seg_decode_lp(int dtype, const InsSegLpW& w, BCN pts, int 
 #endif
 #if LP_PART & 1
 hipError_t launch_point_head_lp(int dtype, int head_kind, const PointHeadLpW& w, BCN x, int c_in, int B, int M,
-                                float* feat, hipStream_t s) {
+                                float* feat, const int32_t* distinct, hipStream_t s) {
     const bool bf = dtype == DAL3_BF16;
     switch (head_kind) {
         case DAL3_HEAD_STATIC_BOX_EST:
-            return bf ? head_lp<BF16, 2, 128, 128, 256>(w, x, c_in, B, M, feat, s)
-                      : head_lp<FP16, 2, 128, 128, 256>(w, x, c_in, B, M, feat, s);
+            return bf ? head_lp<BF16, 2, 128, 128, 256>(w, x, c_in, B, M, feat, distinct, s)
+                      : head_lp<FP16, 2, 128, 128, 256>(w, x, c_in, B, M, feat, distinct, s);
         case DAL3_HEAD_POINT_EMB:
-            return bf ? head_lp<BF16, 2, 64, 128, 256>(w, x, c_in, B, M, feat, s)
-                      : head_lp<FP16, 2, 64, 128, 256>(w, x, c_in, B, M, feat, s);
+            return bf ? head_lp<BF16, 2, 64, 128, 256>(w, x, c_in, B, M, feat, distinct, s)
+                      : head_lp<FP16, 2, 64, 128, 256>(w, x, c_in, B, M, feat, distinct, s);
         case DAL3_HEAD_BOX_EMB:
-            return bf ? head_lp<BF16, 4, 64, 64, 128>(w, x, c_in, B, M, feat, s)
-                      : head_lp<FP16, 4, 64, 64, 128>(w, x, c_in, B, M, feat, s);
+            return bf ? head_lp<BF16, 4, 64, 64, 128>(w, x, c_in, B, M, feat, distinct, s)
+                      : head_lp<FP16, 4, 64, 64, 128>(w, x, c_in, B, M, feat, distinct, s);
         default:
             return hipErrorInvalidValue;
     }

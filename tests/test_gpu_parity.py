@@ -387,3 +387,26 @@ def test_packed_cache_tracks_parameter_updates():
     b = model(pts.cuda(), init.cuda(), gt.cuda())["logits"]
     assert not torch.equal(a, b)
     assert rel_err(b.cpu().numpy(), g["logits"]) < TOL
+
+
+def test_skipping_duplicate_object_points_is_exact():
+    """device sampler: crops with fewer than 512 segmented points get copies as filler and the head skips them;
+    feeding the very same indices through the CHOICE path (which computes all 512) must give identical bits"""
+    B, N = 48, 1024
+    pts_np, init_np, gt_np = synth.static_crops(B, N, seed=15)
+    sd = synth.state_dict("static_two", seed=15)
+    lg = R.ins_seg(R.as_torch_sd(sd), torch.from_numpy(pts_np[:8]).transpose(2, 1))
+    sd = synth.recentre_seg_bias(sd, float((lg[:, :, 1] - lg[:, :, 0]).mean()))
+    model = build_model("static_two", sd)
+    pts, init, gt = dev(pts_np).transpose(2, 1), dev(init_np), dev(gt_np)
+    a = model._run(pts, init, gt)                                         # device sampler, duplicates skipped
+    counts = a["counts"].cpu().numpy()
+    assert ((counts > 0) & (counts < 512)).any() and (counts >= 512).any()
+    mask = a["mask"].cpu().numpy().astype(bool)
+    idx = a["obj_idx"].cpu().numpy()
+    choice = np.stack([positions_from_indices(mask[i], idx[i]) if counts[i] else np.zeros(512, np.int64)
+                       for i in range(B)])
+    b = model._run(pts, init, gt, choice=torch.from_numpy(choice))       # same points, nothing skipped
+    assert torch.equal(a["obj_idx"], b["obj_idx"])
+    for k in ("bp1", "box_one", "bp2", "boxes7"):
+        assert torch.equal(a[k], b[k]), k
