@@ -233,3 +233,42 @@ def scene(seed, n_frames, n_tracks, n_clutter=5):
         order = np.argsort(uniform(seed, f"ord{f}", (len(rows),)))
         dets[tok] = np.stack(rows)[order].astype(np.float32)
     return tracks, poses, dets, has_gt
+
+
+def sweep(seed, tag, n_points=20000, n_boxes=12):
+    """One synthetic lidar sweep with detections, in the formats either side of the crop extraction (SURVEY.md 8(f)
+    N2 / 8(g)): points_xyz (P,3) float32 vehicle frame; box3d_lidar (K,9) float32 in the DETECTOR's convention
+    [x,y,z,w,l,h,vx,vy,r2] (waymo_common.py:105-111 turns it into [x,y,z,l,w,h,-r2-pi/2]); scores (K,), labels (K,)
+    in {0,1,2}; flat-16 veh_to_global. About an eighth of the points fall inside some box; box 0 is axis-aligned
+    with a few points exactly on its faces (the `>= 0` edge of the test); the last box is empty."""
+    t = f"swp{tag}"
+    cls = (uniform(seed, t + "cls", (n_boxes,)) * 3).astype(np.int64)
+    centre = uniform(seed, t + "c", (n_boxes, 3), -60.0, 60.0) * np.array([1.0, 1.0, 0.02])
+    size = np.array(arch.MEAN_SIZE)[cls % 3] + normal(seed, t + "s", (n_boxes, 3), 0.0, 0.15)
+    yaw = uniform(seed, t + "y", (n_boxes,), -np.pi, np.pi)
+    centre[0], size[0], yaw[0] = [8.0, -4.0, 0.5], [4.0, 2.0, 1.5], 0.0
+    centre[-1] = [500.0, 500.0, 0.0]                                              # far away: no points
+    n_obj = n_points // 3
+    owner = (uniform(seed, t + "o", (n_obj,)) * (n_boxes - 1)).astype(np.int64)
+    local = uniform(seed, t + "p", (n_obj, 3), -0.65, 0.65) * size[owner]             # 1.3x the box: in and out
+    c, s = np.cos(yaw[owner]), np.sin(yaw[owner])
+    obj = np.stack([c * local[:, 0] - s * local[:, 1], s * local[:, 0] + c * local[:, 1], local[:, 2]], 1) + centre[owner]
+    clutter = uniform(seed, t + "g", (n_points - n_obj - 6, 3), -75.0, 75.0) * np.array([1.0, 1.0, 0.03])
+    edge = np.array([[10.0, -4.0, 0.5], [6.0, -4.0, 0.5], [8.0, -3.0, 0.5], [8.0, -5.0, 0.5], [8.0, -4.0, 1.25],
+                     [8.0, -4.0, -0.25]])                                          # on the six faces of box 0
+    pts = np.concatenate([obj, clutter, edge]).astype(np.float32)
+    pts = pts[np.argsort(uniform(seed, t + "sh", (pts.shape[0],)))]
+    r2 = -yaw - np.pi / 2
+    box = np.concatenate([centre, size[:, [1, 0, 2]], normal(seed, t + "v", (n_boxes, 2), 0.0, 1.0), r2[:, None]], 1)
+    scores = uniform(seed, t + "sc", (n_boxes,), 0.1, 1.0).astype(np.float32)
+    return pts, box.astype(np.float32), scores, cls, pose_veh_to_global(seed, t)
+
+
+def gt_box_in_vehicle(box_global, veh_to_global):
+    """A ground-truth annotation for a synthetic track frame, in the annotation files' format (SURVEY.md 8(g):
+    float32 (9,) [cx,cy,cz,l,w,h,vx,vy,heading], VEHICLE frame): the track's global box moved into the frame's
+    vehicle frame and shrunk by 10 % so that some of the track's points fall outside it."""
+    m = np.reshape(veh_to_global, [4, 4])
+    c = m[:3, :3].T @ (np.asarray(box_global[:3]) - m[:3, 3])
+    yaw = box_global[6] - np.arctan2(m[1, 0], m[0, 0])
+    return np.concatenate([c, 0.9 * np.asarray(box_global[3:6]), [0.0, 0.0], [yaw]]).astype(np.float32)

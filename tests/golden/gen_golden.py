@@ -12,6 +12,7 @@ of 3dal_pytorch_amd/synth.py. Only inputs' checksums and the reference's OUTPUTS
 the inputs are rebuilt from synth.py wherever the fixtures are used.
 """
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -41,6 +42,71 @@ def import_reference():
     sys.path.insert(0, os.path.join(REF, "tools"))
     import static_model, dynamic_model, static_eval, dynamic_eval, utils  # noqa: E401
     return static_model, dynamic_model, static_eval, dynamic_eval, utils
+
+
+def _identity_jit(*a, **k):
+    """stand-in for numba.njit / numba.jit: `@njit` and `@jit(nopython=True)` both leave the function as it is"""
+    if len(a) == 1 and callable(a[0]) and not k:
+        return a[0]
+    return lambda f: f
+
+
+def _load_file(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def import_reference_geometry():
+    """The reference's det3d/core/bbox/{geometry,box_np_ops}.py and det3d/datasets/waymo/waymo_common.py, loaded
+    from their files (the det3d package __init__ needs torchvision/numba). numba is absent: its decorators become
+    identities and the njit bodies run as the plain Python they are. The sinks of _create_pd_detection that are
+    not captured (Waymo protobuf objects, IoU matching against GT on a CUDA op) are attribute bags / zeros."""
+    nb = types.ModuleType("numba")
+    nb.njit = nb.jit = _identity_jit
+    nb.prange = range
+    sys.modules["numba"] = nb
+    geo = _load_file("det3d.core.bbox.geometry", os.path.join(REF, "det3d/core/bbox/geometry.py"))
+    stub = sys.modules["det3d.core.bbox.box_np_ops"]                 # the object the Dataset modules already hold
+    ops = _load_file("det3d.core.bbox.box_np_ops", os.path.join(REF, "det3d/core/bbox/box_np_ops.py"))
+    stub.points_in_rbbox = ops.points_in_rbbox
+    sys.modules["det3d.core.bbox"].box_np_ops = ops
+
+    class Bag:
+        def __init__(self, *a, **k):
+            self.objects = []
+
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            b = Bag()
+            object.__setattr__(self, name, b)
+            return b
+
+        def CopyFrom(self, other):
+            pass
+
+        def SerializeToString(self):
+            return b""
+    for name in ["pyquaternion", "nuscenes", "nuscenes.utils", "nuscenes.utils.geometry_utils", "pcdet", "pcdet.ops",
+                 "pcdet.ops.iou3d_nms", "pcdet.ops.iou3d_nms.iou3d_nms_utils", "waymo_open_dataset",
+                 "waymo_open_dataset.protos", "waymo_open_dataset.label_pb2", "waymo_open_dataset.protos.metrics_pb2"]:
+        mod = types.ModuleType(name)
+        mod.__path__ = []
+        sys.modules[name] = mod
+    sys.modules["pyquaternion"].Quaternion = Bag
+    sys.modules["nuscenes.utils.geometry_utils"].transform_matrix = None
+    sys.modules["pcdet.ops.iou3d_nms.iou3d_nms_utils"].boxes_iou3d_gpu = lambda a, b: torch.zeros((a.shape[0], b.shape[0]))
+    lab, met = sys.modules["waymo_open_dataset.label_pb2"], sys.modules["waymo_open_dataset.protos.metrics_pb2"]
+    lab.Label = Bag
+    Bag.Box = Bag
+    met.Object = met.Objects = Bag
+    sys.modules["waymo_open_dataset"].label_pb2 = lab
+    sys.modules["waymo_open_dataset.protos"].metrics_pb2 = met
+    wc = _load_file("det3d.datasets.waymo.waymo_common", os.path.join(REF, "det3d/datasets/waymo/waymo_common.py"))
+    return geo, ops, wc
 
 
 def load(model, sd_np):
@@ -192,20 +258,70 @@ def main():
                         c2s=np.array([ut.class2size(c, np.array([0.1, -0.2, 0.3])) for c in range(3)]))
 
     # ------------------------------------------------------------------ crop preparation (N1): the real Datasets
+    # ------------------------------------------------------------------ points-in-rotated-box (N1 labels, N2)
+    geo, ops, wc = import_reference_geometry()
+    g = {}
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        pts, box9, _, _, _ = synth.sweep(40, "geom", n_points=6000, n_boxes=9)
+        boxes = np.concatenate([box9[:, :3], box9[:, [4, 3, 5]], (-box9[:, -1:] - np.pi / 2)], 1).astype(dt)
+        boxes[1, 6], boxes[2, 6], boxes[3, 6] = np.pi, -np.pi / 2, 1e-3                # special yaws
+        pts = pts.astype(dt)
+        pts[:3] = [[np.nan, 0.0, 0.0], [8.0, np.nan, 0.5], [8.0, -4.0, 0.5]]           # NaN counts as inside
+        corners = ops.center_to_corner_box3d(boxes[:, :3], boxes[:, 3:6], boxes[:, -1])
+        nv, d = geo.surface_equ_3d_jitv2(ops.corner_to_surfaces_3d(corners)[:, :, :3, :])
+        g.update({f"boxes_{tag}": boxes, f"corners_{tag}": corners, f"normal_{tag}": nv, f"d_{tag}": d,
+                  f"inside_{tag}": ops.points_in_rbbox(pts, boxes), f"nan_rows_{tag}": np.arange(3)})
+    # the mixed case of the Datasets: float64 points against a float32 annotation box
+    pts64 = synth.sweep(40, "geom", n_points=6000, n_boxes=9)[0].astype(np.float64) + 1e-9
+    g["inside_mixed"] = ops.points_in_rbbox(pts64, g["boxes_f32"])
+    np.savez_compressed(os.path.join(out_dir, "geom_rbbox.npz"), **g)
+    print("geometry fixture: inside counts f32", g["inside_f32"].sum(0), "mixed", g["inside_mixed"].sum(0))
+
+    # ------------------------------------------------------------------ crop extraction (N2): _create_pd_detection
     import pickle
     import tempfile
-    # labels go through a numba-only routine that cannot run here; they are not captured (see oracle/ref_prep.py)
-    sys.modules["det3d.core.bbox.box_np_ops"].points_in_rbbox = lambda p, b: np.zeros((p.shape[0], 1))
+    with tempfile.TemporaryDirectory() as tmp:
+        res = os.path.join(tmp, "val")
+        os.makedirs(res)
+        dets, infos = {}, {}
+        for f in range(3):
+            pts, box9, scores, labels, pose = synth.sweep(41, f"fr{f}", n_points=12000 + 1000 * f, n_boxes=10 + f)
+            tok = f"seg0_frame_{f}"
+            with open(os.path.join(tmp, f"anno{f}.pkl"), "wb") as fh:
+                pickle.dump({"veh_to_global": pose, "objects": [], "scene_name": "seg0", "frame_name": f"seg0_{1000 + f}",
+                             "frame_id": f}, fh)
+            with open(os.path.join(tmp, f"lidar{f}.pkl"), "wb") as fh:
+                pickle.dump({"lidars": {"points_xyz": pts}}, fh)
+            infos[tok] = {"anno_path": os.path.join(tmp, f"anno{f}.pkl"), "path": os.path.join(tmp, f"lidar{f}.pkl"),
+                          "timestamp": 1000.0 + f}
+            dets[tok] = {"box3d_lidar": torch.from_numpy(box9.copy()), "scores": torch.from_numpy(scores),
+                         "label_preds": torch.from_numpy(labels), "tracking_ids": list(range(box9.shape[0]))}
+        wc._create_pd_detection(dets, infos, res, tracking=True)
+        with open(os.path.join(res, "trackData.pkl"), "rb") as fh:
+            td = pickle.load(fh)
+        with open(os.path.join(res, "det_annos.pkl"), "rb") as fh:
+            da = pickle.load(fh)
+        c = {}
+        for f, tok in enumerate(dets):
+            c[f"boxes_lidar{f}"] = da[f]["boxes_lidar"]
+            c[f"bbox{f}"] = np.stack(td[tok]["bbox"])
+            c[f"count{f}"] = np.array([p.shape[0] for p in td[tok]["point"]])
+            c[f"point{f}"] = np.concatenate(td[tok]["point"])
+            c[f"type{f}"] = np.array(td[tok]["type"])
+        np.savez_compressed(os.path.join(out_dir, "crops_extract.npz"), **c)
+        print("crop-extraction fixture: points per detection", [c[f"count{f}"].tolist() for f in range(3)])
     with tempfile.TemporaryDirectory() as tmp:
         def make_infos(tracks):
             infos = {}
             for tid, tr in tracks.items():
                 for f, tok in enumerate(tr["token"]):
                     path = os.path.join(tmp, tok + ".pkl")
-                    gt = np.concatenate([tr["bbox"][f][:6], [0.0, 0.0], tr["bbox"][f][6:]]).astype(np.float32)
+                    pose = synth.pose_veh_to_global(31, tok)
+                    objs = [{"name": "other", "box": np.zeros(9, np.float32)}]
+                    if not (tok.startswith("tok_10_") and tok.endswith(("_2", "_6"))):   # d0 lacks its GT in 2 frames
+                        objs.append({"name": tr["match"][-1], "box": synth.gt_box_in_vehicle(tr["bbox"][f], pose)})
                     with open(path, "wb") as fh:
-                        pickle.dump({"veh_to_global": synth.pose_veh_to_global(31, tok),
-                                     "objects": [{"name": tr["match"][-1], "box": gt}]}, fh)
+                        pickle.dump({"veh_to_global": pose, "objects": objs}, fh)
                     infos[tok] = {"anno_path": path}
             return infos
         # static: three tracks, 4096-point resample
@@ -218,6 +334,10 @@ def main():
             out[f"init_box{i}"] = item[1].numpy()
             out[f"point{i}"] = item[3].numpy()
             out[f"token{i}"] = np.array(item[4])
+            out[f"bbox_gt{i}"] = item[2].numpy()
+            for name, v in zip(("mask_label", "center_label", "heading_class_label", "heading_residuals_label",
+                                "size_class_label", "size_residual_label"), item[5:11]):
+                out[f"{name}{i}"] = np.asarray(v)
         np.savez_compressed(os.path.join(out_dir, "prep_static.npz"), **out)
         # dynamic: two tracks (one with empty frames), items at the borders and in the middle
         dtracks = {"d0": synth.track(32, 10, n_frames=9, empty_every=4), "d1": synth.track(32, 11, n_frames=60)}
@@ -231,6 +351,10 @@ def main():
             out[f"bbox{k}"] = item[2].numpy()
             out[f"point{k}"] = item[4].numpy().astype(np.float32)          # what the driver's .float() keeps
             out[f"point64_head{k}"] = item[4].numpy()[:8]
+            out[f"bbox_gt{k}"] = item[3].numpy()
+            for name, v in zip(("mask_label", "center_label", "heading_class_label", "heading_residual_label",
+                                "size_class_label", "size_residual_label"), item[6:12]):
+                out[f"{name}{k}"] = np.asarray(v)
         np.savez_compressed(os.path.join(out_dir, "prep_dynamic.npz"), **out)
         print("prep fixtures: static", len(ds), "dynamic items", len(dds))
 

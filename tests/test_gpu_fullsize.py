@@ -80,3 +80,35 @@ def test_fused_max_equals_standalone_maxpool():
     hip.check(lib.dal3_maxpool_n(hip.ptr(conv5), B * 1024, N, hip.ptr(out), hip.stream()))
     # both are fp32 FMA chains over the same folded weights; only the position of the bias add differs
     assert float((out - g).abs().max() / g.abs().max()) < 2e-6
+
+
+def test_c4_mixed_segment_sharded_over_8_equals_whole_job():
+    """BASELINE.json configs[3]: one synthetic 198-frame segment = 64 static crops at N=4096 plus 40 dynamic tracks
+    of rng.integers(20,199) frames (~4,400 track-frames), contiguous index ranges over 8 ranks, static and dynamic
+    batches back to back. The 8 shards are run one after another on this GPU with the ranks' item offsets;
+    their concatenation must equal the one-rank job bit for bit (what the all-gather would return)."""
+    dal3_dist = importlib.import_module("3dal_pytorch_amd.dist")
+    rng = np.random.default_rng(10922081)
+    n_static, n_dynamic = 64, int(rng.integers(20, 199, size=40).sum())
+    assert 3000 < n_dynamic < 6000
+    sp, si, sg = synth.static_crops(n_static, 4096, seed=12)
+    static = build_model("static_one", synth.state_dict("static_one", seed=12))
+    s_in = [torch.from_numpy(a).cuda() for a in (sp, si, sg)]
+    dp, db, di, _ = synth.dynamic_items(n_dynamic, seed=13)
+    dynamic = build_model("dynamic", synth.state_dict("dynamic", seed=13))
+    d_in = [torch.from_numpy(a).cuda() for a in (dp, db, di)]
+
+    def run_static(lo, hi):
+        static.item_offset = lo
+        return static.refine(s_in[0][lo:hi].transpose(2, 1), s_in[1][lo:hi], s_in[2][lo:hi])
+
+    def run_dynamic(lo, hi):
+        dynamic.item_offset = lo
+        return dynamic.refine(d_in[0][lo:hi].transpose(2, 1), d_in[1][lo:hi].transpose(2, 1), d_in[2][lo:hi])
+
+    for n, run in ((n_static, run_static), (n_dynamic, run_dynamic)):
+        whole = run(0, n)
+        assert whole.shape == (n, 7) and bool(torch.isfinite(whole).all())
+        parts = [run(*dal3_dist.shard_range(n, r, 8)) for r in range(8)]
+        assert sum(p.shape[0] for p in parts) == n
+        assert torch.equal(torch.cat(parts), whole)
