@@ -79,6 +79,12 @@ SIGNATURES = {
     "dal3_static_crop_prep": (_i, [vp, vp, vp, vp, vp, _i, _i, _u64, _i64, vp, vp, vp]),
     "dal3_dynamic_item_prep": (_i, [vp, vp, vp, vp, vp, vp, vp, vp, _i, _i, _i, _i, _u64, _i64, vp, vp, vp, vp]),
     "dal3_writeback_boxes": (_i, [vp, vp, vp, vp, vp, vp, vp, vp, vp, _i, _i64, vp, vp, vp]),
+    "dal3_static_crop_labels": (_i, [vp, vp, vp, vp, _i, _i, _u64, _i64, vp, vp, vp]),
+    "dal3_dynamic_item_labels": (_i, [vp, vp, vp, vp, vp, vp, vp, _i, _i, _i, _u64, _i64, vp, vp, vp, vp, vp]),
+    "dal3_points_in_boxes": (_i, [vp, _i, _i64, _i64, vp, _i, _i, vp, vp]),
+    "dal3_crop_workspace_bytes": (_sz, [_i64, _i64]),
+    "dal3_crop_count": (_i, [vp, vp, vp, vp, vp, _i, _i64, _i64, vp, vp, _sz, vp]),
+    "dal3_crop_fill": (_i, [vp, vp, vp, vp, vp, _i, _i64, _i64, vp, vp, vp, vp, vp, vp, _sz, vp]),
     "dal3_maxpool_n": (_i, [vp, _i64, _i64, vp, vp]),
     "dal3_shared_mlp_layer": (_i, [C.POINTER(Layer), _i, BCN, _i, _i, vp, vp, _sz, vp]),
     "dal3_shared_mlp_layer_workspace_bytes": (_sz, [_i, _i]),

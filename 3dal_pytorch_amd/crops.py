@@ -1,0 +1,80 @@
+"""Crop extraction from full sweeps on the device: the track-data part of
+`_create_pd_detection` (det3d/datasets/waymo/waymo_common.py:67-218) — for every tracked detection of every frame,
+the sweep's points inside its rotated box, moved to the global frame — for a whole batch of frames in three
+launches (count, scan, fill) instead of one Python iteration per detection.
+
+In: per frame, the sweep `points_xyz` (P,3) float32 (lidar pickle), the detector's boxes
+`box3d_lidar` (K,7|9) float32 and the frame's flat-16 `veh_to_global`. Out: the `trackData` fields the downstream
+tracker files hold: 'bbox' (7,) global frame, 'point' (k,3) float64 global frame, plus `boxes_lidar` (the det_annos
+rows). Proto serialisation, uuid assignment and the IoU match against ground truth stay with the reference.
+"""
+import numpy as np
+import torch
+
+from . import _hip, geom
+
+
+def waymo_boxes(box3d_lidar):
+    """detector boxes [x,y,z,w,l,h,(vx,vy,)r2] -> Waymo [x,y,z,l,w,h,r1 = -r2 - pi/2] (waymo_common.py:105-111)"""
+    b = np.array(box3d_lidar, copy=True)
+    b[:, -1] = -b[:, -1] - np.pi / 2
+    return b[:, [0, 1, 2, 4, 3, 5, -1]]
+
+
+def transform_box(box, pose):
+    """waymo_common.py:52-65 for (K,7) boxes and one 4x4 pose; O(K) host work"""
+    heading = box[..., -1] + np.arctan2(pose[1, 0], pose[0, 0])
+    center = np.einsum("...ij,...nj->...ni", pose[0:3, 0:3], box[..., 0:3]) + np.expand_dims(pose[0:3, 3], axis=-2)
+    return np.concatenate([center, box[..., 3:6], heading[..., np.newaxis]], axis=-1)
+
+
+def extract_crops(sweeps, detections, veh_to_global, device="cuda", return_index=False):
+    """sweeps: list of (P_f,3) float32 arrays or CUDA tensors; detections: list of (K_f,7|9) float32 detector
+    boxes; veh_to_global: list of flat-16 poses. Returns a list (one entry per frame) of dicts
+      'boxes_lidar' (K_f,7) float32 NumPy — Waymo-convention boxes, vehicle frame (det_annos rows)
+      'bbox'        (K_f,7) float64 NumPy — the same boxes in the global frame (trackData 'bbox')
+      'point'       list of K_f CUDA float64 tensors (k,3), global frame, in sweep order (trackData 'point')
+      'index'       (return_index) list of K_f CUDA int32 tensors: which sweep points they are
+    """
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("extract_crops runs on the GPU only (lib3dal_hip.so has no CPU fallback)")
+    F = len(sweeps)
+    if not (F == len(detections) == len(veh_to_global)) or F == 0:
+        raise ValueError("extract_crops: need the same non-zero number of sweeps, detection sets and poses")
+    boxes = [waymo_boxes(np.asarray(d, dtype=np.float32).reshape(-1, np.asarray(d).shape[-1])) for d in detections]
+    poses = [np.reshape(np.asarray(p, dtype=np.float64), [4, 4]) for p in veh_to_global]
+    planes = np.concatenate([geom.box_planes(b) for b in boxes])
+    n_pts = [int(s.shape[0]) for s in sweeps]
+    n_box = [int(b.shape[0]) for b in boxes]
+    K, max_pts = sum(n_box), max(n_pts)
+    d_pts = torch.cat([(s if torch.is_tensor(s) else torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32))).to(dev)
+                       .to(torch.float32).reshape(-1, 3) for s in sweeps]).contiguous()
+    d_poff = torch.from_numpy(np.concatenate([[0], np.cumsum(n_pts)]).astype(np.int64)).to(dev)
+    d_boff = torch.from_numpy(np.concatenate([[0], np.cumsum(n_box)]).astype(np.int64)).to(dev)
+    d_planes = geom.planes_to_device(planes, dev)
+    d_sph = torch.from_numpy(np.ascontiguousarray(np.concatenate([geom.cull_spheres(b) for b in boxes]))).to(dev)
+    d_pose = torch.from_numpy(np.stack(poses).reshape(F, 16)).to(dev)
+    lib = _hip.lib()
+    ws = torch.empty(max(int(lib.dal3_crop_workspace_bytes(K, max_pts)), 4), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(max(K, 1), dtype=torch.int64, device=dev)
+    _hip.check(lib.dal3_crop_count(_hip.ptr(d_pts), _hip.ptr(d_poff), _hip.ptr(d_planes), _hip.ptr(d_sph), _hip.ptr(d_boff), F, K, max_pts,
+                                   _hip.ptr(counts), _hip.ptr(ws), ws.numel(), _hip.stream()))
+    start = torch.zeros(K + 1, dtype=torch.int64, device=dev)
+    start[1:] = torch.cumsum(counts[:K], 0)
+    h_start = start.cpu().numpy()                                   # the one host sync: sizes of the ragged outputs
+    total = int(h_start[-1])
+    out = torch.empty((max(total, 1), 3), dtype=torch.float64, device=dev)
+    idx = torch.empty(max(total, 1), dtype=torch.int32, device=dev) if return_index else None
+    _hip.check(lib.dal3_crop_fill(_hip.ptr(d_pts), _hip.ptr(d_poff), _hip.ptr(d_planes), _hip.ptr(d_sph), _hip.ptr(d_boff), F,
+                                  K, max_pts, _hip.ptr(d_pose), _hip.ptr(counts), _hip.ptr(start), _hip.ptr(out),
+                                  _hip.ptr(idx), _hip.ptr(ws), ws.numel(), _hip.stream()))
+    frames, k = [], 0
+    for f in range(F):
+        rec = {"boxes_lidar": boxes[f], "bbox": transform_box(boxes[f], poses[f]),
+               "point": [out[h_start[k + i]:h_start[k + i + 1]] for i in range(n_box[f])]}
+        if return_index:
+            rec["index"] = [idx[h_start[k + i]:h_start[k + i + 1]] for i in range(n_box[f])]
+        frames.append(rec)
+        k += n_box[f]
+    return frames

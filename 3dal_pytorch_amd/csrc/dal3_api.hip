@@ -630,6 +630,86 @@ extern "C" int dal3_dynamic_item_prep(const double* points, const int64_t* frame
     return 0;
 }
 
+extern "C" int dal3_static_crop_labels(const double* points, const int64_t* offsets, const int32_t* choice,
+                                       const double* pose, int B, int N, uint64_t seed, int64_t item_offset,
+                                       const double* gt_planes, uint8_t* mask_label, dal3_stream stream) {
+    if (!points || !offsets || !pose || !gt_planes || !mask_label || B <= 0 || N <= 0)
+        return fail(DAL3_EINVAL, "static_crop_labels: bad argument");
+    HIP_TRY(launch_static_crop_labels(points, offsets, choice, pose, B, N, seed, item_offset, gt_planes, mask_label,
+                                      static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_dynamic_item_labels(const double* points, const int64_t* frame_offsets, const int64_t* track_first,
+                                        const int32_t* item_track, const int32_t* item_frame, const int32_t* choice,
+                                        const double* pose, int B, int n_per, int r, uint64_t seed, int64_t item_offset,
+                                        const double* xform, const double* planes, const uint8_t* valid,
+                                        uint8_t* mask_label, dal3_stream stream) {
+    if (!points || !frame_offsets || !track_first || !item_track || !item_frame || !pose || !xform || !planes || !valid ||
+        !mask_label || B <= 0 || n_per <= 0 || r < 0)
+        return fail(DAL3_EINVAL, "dynamic_item_labels: bad argument");
+    HIP_TRY(launch_dynamic_item_labels(points, frame_offsets, track_first, item_track, item_frame, choice, pose, B, n_per, r,
+                                       seed, item_offset, xform, planes, valid, mask_label,
+                                       static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_points_in_boxes(const void* points, int points_f64, int64_t P, int64_t stride, const double* planes,
+                                    int K, int f32_math, uint8_t* inside, dal3_stream stream) {
+    if (P < 0 || K < 0 || stride < 3 || ((P > 0 && K > 0) && (!points || !planes || !inside)))
+        return fail(DAL3_EINVAL, "points_in_boxes: bad argument (stride must be >= 3)");
+    if (points_f64 && f32_math) return fail(DAL3_EINVAL, "points_in_boxes: float32 arithmetic needs float32 points");
+    HIP_TRY(launch_points_in_boxes(points, points_f64, P, stride, planes, K, f32_math, inside,
+                                   static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" size_t dal3_crop_workspace_bytes(int64_t K_total, int64_t max_points_per_frame) {
+    if (K_total <= 0 || max_points_per_frame < 0) return 0;
+    return crop_workspace_bytes(K_total, max_points_per_frame);
+}
+
+static int crop_args_ok(const float* points, const int64_t* point_offsets, const double* planes, const float* spheres,
+                        const int64_t* box_offsets, int F, int64_t K_total, int64_t max_pts, const void* ws,
+                        size_t ws_bytes) {
+    if (!point_offsets || !box_offsets || F <= 0 || F > 65535 || K_total < 0 || max_pts < 0)
+        return fail(DAL3_EINVAL, "crop: bad argument (1 <= F <= 65535)");
+    if (K_total > 0 && max_pts > 0 && (!points || !planes || !spheres))
+        return fail(DAL3_EINVAL, "crop: null points / planes / spheres");
+    if (K_total > 0 && (!ws || ws_bytes < crop_workspace_bytes(K_total, max_pts)))
+        return fail(DAL3_EWORKSPACE, "crop: workspace smaller than dal3_crop_workspace_bytes()");
+    return 0;
+}
+
+extern "C" int dal3_crop_count(const float* points, const int64_t* point_offsets, const double* planes,
+                               const float* spheres, const int64_t* box_offsets, int F, int64_t K_total,
+                               int64_t max_points_per_frame, int64_t* counts, void* workspace, size_t workspace_bytes,
+                               dal3_stream stream) {
+    if (int e = crop_args_ok(points, point_offsets, planes, spheres, box_offsets, F, K_total, max_points_per_frame,
+                             workspace, workspace_bytes))
+        return e;
+    if (K_total > 0 && !counts) return fail(DAL3_EINVAL, "crop_count: null counts");
+    HIP_TRY(launch_crop_count(points, point_offsets, planes, spheres, box_offsets, F, K_total, max_points_per_frame, counts,
+                              static_cast<int32_t*>(workspace), static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_crop_fill(const float* points, const int64_t* point_offsets, const double* planes,
+                              const float* spheres, const int64_t* box_offsets, int F, int64_t K_total,
+                              int64_t max_points_per_frame, const double* pose, const int64_t* counts,
+                              const int64_t* box_start, double* out_points, int32_t* out_index, const void* workspace,
+                              size_t workspace_bytes, dal3_stream stream) {
+    if (int e = crop_args_ok(points, point_offsets, planes, spheres, box_offsets, F, K_total, max_points_per_frame,
+                             workspace, workspace_bytes))
+        return e;
+    if (K_total > 0 && (!pose || !counts || !box_start || !out_points))
+        return fail(DAL3_EINVAL, "crop_fill: null pose / counts / box_start / out");
+    HIP_TRY(launch_crop_fill(points, point_offsets, planes, spheres, box_offsets, F, K_total, max_points_per_frame, pose,
+                             counts, box_start, static_cast<const int32_t*>(workspace), out_points, out_index,
+                             static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_writeback_boxes(const double* final_boxes, const int32_t* final_idx, const double* pose_best,
                                     const double* pose_inv, const double* track_box, float* det,
                                     const int64_t* det_start, const int32_t* det_count, const uint8_t* active, int P,

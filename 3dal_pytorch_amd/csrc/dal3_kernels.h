@@ -165,6 +165,26 @@ hipError_t launch_dynamic_item_prep(const double* points, const int64_t* frame_o
                                     const int32_t* choice, const double* pose, int B, int n_per, int r, int s_,
                                     uint64_t seed, int64_t item_offset, float* pts_out, float* box_out,
                                     float* init_box_out, hipStream_t st);
+hipError_t launch_static_crop_labels(const double* points, const int64_t* offsets, const int32_t* choice, const double* pose,
+                                     int B, int N, uint64_t seed, int64_t item_offset, const double* gt_planes,
+                                     uint8_t* mask_label, hipStream_t s);
+hipError_t launch_dynamic_item_labels(const double* points, const int64_t* frame_offsets, const int64_t* track_first,
+                                      const int32_t* item_track, const int32_t* item_frame, const int32_t* choice,
+                                      const double* pose, int B, int n_per, int r, uint64_t seed, int64_t item_offset,
+                                      const double* xform, const double* planes, const uint8_t* valid, uint8_t* mask_label,
+                                      hipStream_t st);
+// dal3_crops.hip
+size_t crop_workspace_bytes(int64_t K_total, int64_t max_points_per_frame);
+hipError_t launch_crop_count(const float* points, const int64_t* point_offsets, const double* planes,
+                             const float* spheres, const int64_t* box_offsets, int F, int64_t K_total, int64_t max_points_per_frame,
+                             int64_t* counts, int32_t* cc, hipStream_t s);
+hipError_t launch_crop_fill(const float* points, const int64_t* point_offsets, const double* planes,
+                            const float* spheres, const int64_t* box_offsets, int F, int64_t K_total,
+                            int64_t max_points_per_frame, const double* pose, const int64_t* counts,
+                            const int64_t* box_start, const int32_t* cc, double* out_points, int32_t* out_index,
+                            hipStream_t s);
+hipError_t launch_points_in_boxes(const void* points, int points_f64, int64_t P, int64_t stride, const double* planes,
+                                  int K, int f32_math, uint8_t* inside, hipStream_t s);
 hipError_t launch_writeback(const double* final_boxes, const int32_t* final_idx, const double* pose_best,
                             const double* pose_inv, const double* track_box, float* det, const int64_t* det_start,
                             const int32_t* det_count, const uint8_t* active, int P, int64_t n_det, int32_t* match,

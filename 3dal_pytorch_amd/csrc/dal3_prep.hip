@@ -4,6 +4,7 @@
 // the 5-frame point window and the 101-box window — as two HBM-bound gather kernels. float64 arithmetic as in the
 // reference (global coordinates are kilometres; fp32 would lose centimetres), fp32 on store (the drivers' .float()).
 #include "dal3_device.h"
+#include "dal3_geom.h"
 #include "dal3_kernels.h"
 
 __device__ __forceinline__ uint32_t prep_hash(uint64_t seed, uint64_t item, uint32_t i) {
@@ -127,6 +128,99 @@ __global__ void dynamic_item_prep_kernel(const double* __restrict__ points, cons
             ib[7] = 0.0f;
         }
     }
+}
+
+// ---- the mask labels of the same items (training only): static_model.py:548-556, dynamic_model.py:455-487.
+// The SAME draws as the prep kernels (choice, or the device hash of (seed, item, n)), the same float64 vehicle-frame
+// point, tested against the matched annotation's box with the reference's points_in_rbbox (dal3_geom.h; float64
+// points against float32-valued face equations -> float64 arithmetic).
+__global__ void static_crop_labels_kernel(const double* __restrict__ points, const int64_t* __restrict__ offsets,
+                                          const int32_t* __restrict__ choice, const double* __restrict__ pose_all,
+                                          int B, int N, uint64_t seed, int64_t item_offset,
+                                          const double* __restrict__ gt_planes, uint8_t* __restrict__ mask_label) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * N) return;
+    const int b = (int)(i / N), n = (int)(i % N);
+    const int64_t p0 = offsets[b], cnt = offsets[b + 1] - p0;
+    if (cnt <= 0) {
+        mask_label[i] = 0;
+        return;
+    }
+    int64_t k = choice ? choice[i] : (int64_t)(((uint64_t)prep_hash(seed, (uint64_t)(item_offset + b), (uint32_t)n) * (uint64_t)cnt) >> 32);
+    k = k < 0 ? 0 : (k >= cnt ? cnt - 1 : k);
+    const double* p = points + (p0 + k) * 3;
+    const double* pose = pose_all + (int64_t)b * 16;
+    const double vx = pose[0] * p[0] + pose[1] * p[1] + pose[2] * p[2] + pose[3];
+    const double vy = pose[4] * p[0] + pose[5] * p[1] + pose[6] * p[2] + pose[7];
+    const double vz = pose[8] * p[0] + pose[9] * p[1] + pose[10] * p[2] + pose[11];
+    mask_label[i] = inside_box_f64(gt_planes + (int64_t)b * DAL3_PLANE_DOUBLES, vx, vy, vz) ? 1 : 0;
+}
+
+// dynamic: window frame j of item b is labelled in THAT frame's vehicle frame: q = xform[b][j] (pose p), with
+// xform = inv(veh_to_global_j) @ inv(pose) from the host (dynamic_model.py:481); frames without a matched
+// annotation (valid == 0) or outside the track give zeros. Empty frames' zero points are moved and tested too.
+__global__ void dynamic_item_labels_kernel(const double* __restrict__ points, const int64_t* __restrict__ frame_offsets,
+                                           const int64_t* __restrict__ track_first, const int32_t* __restrict__ item_track,
+                                           const int32_t* __restrict__ item_frame, const int32_t* __restrict__ choice,
+                                           const double* __restrict__ pose_all, int B, int n_per, int r, uint64_t seed,
+                                           int64_t item_offset, const double* __restrict__ xform,
+                                           const double* __restrict__ planes, const uint8_t* __restrict__ valid,
+                                           uint8_t* __restrict__ mask_label) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_item = (int64_t)(2 * r + 1) * n_per;
+    if (i >= (int64_t)B * per_item) return;
+    const int b = (int)(i / per_item);
+    const int64_t w = i - (int64_t)b * per_item;
+    const int j = (int)(w / n_per);
+    const int64_t seg = (int64_t)b * (2 * r + 1) + j;
+    const int trk = item_track[b], it = item_frame[b];
+    const int64_t f0 = track_first[trk];
+    const int n_frames = (int)(track_first[trk + 1] - f0);
+    const int fr = it - r + j;
+    if (fr < 0 || fr >= n_frames || !valid[seg]) {
+        mask_label[i] = 0;
+        return;
+    }
+    double x = 0.0, y = 0.0, z = 0.0;
+    const int64_t p0 = frame_offsets[f0 + fr], cnt = frame_offsets[f0 + fr + 1] - p0;
+    if (cnt > 0) {
+        int64_t k = choice ? choice[i] : (int64_t)(((uint64_t)prep_hash(seed, (uint64_t)(item_offset + b), (uint32_t)w) * (uint64_t)cnt) >> 32);
+        k = k < 0 ? 0 : (k >= cnt ? cnt - 1 : k);
+        const double* p = points + (p0 + k) * 3;
+        x = p[0];
+        y = p[1];
+        z = p[2];
+    }
+    const double* pose = pose_all + (int64_t)b * 16;
+    const double vx = pose[0] * x + pose[1] * y + pose[2] * z + pose[3];
+    const double vy = pose[4] * x + pose[5] * y + pose[6] * z + pose[7];
+    const double vz = pose[8] * x + pose[9] * y + pose[10] * z + pose[11];
+    const double* t = xform + seg * 16;
+    const double qx = t[0] * vx + t[1] * vy + t[2] * vz + t[3];
+    const double qy = t[4] * vx + t[5] * vy + t[6] * vz + t[7];
+    const double qz = t[8] * vx + t[9] * vy + t[10] * vz + t[11];
+    mask_label[i] = inside_box_f64(planes + seg * DAL3_PLANE_DOUBLES, qx, qy, qz) ? 1 : 0;
+}
+
+hipError_t launch_static_crop_labels(const double* points, const int64_t* offsets, const int32_t* choice, const double* pose,
+                                     int B, int N, uint64_t seed, int64_t item_offset, const double* gt_planes,
+                                     uint8_t* mask_label, hipStream_t s) {
+    const int64_t total = (int64_t)B * N;
+    hipLaunchKernelGGL(static_crop_labels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, points, offsets,
+                       choice, pose, B, N, seed, item_offset, gt_planes, mask_label);
+    return hipGetLastError();
+}
+
+hipError_t launch_dynamic_item_labels(const double* points, const int64_t* frame_offsets, const int64_t* track_first,
+                                      const int32_t* item_track, const int32_t* item_frame, const int32_t* choice,
+                                      const double* pose, int B, int n_per, int r, uint64_t seed, int64_t item_offset,
+                                      const double* xform, const double* planes, const uint8_t* valid, uint8_t* mask_label,
+                                      hipStream_t st) {
+    const int64_t total = (int64_t)B * (2 * r + 1) * n_per;
+    hipLaunchKernelGGL(dynamic_item_labels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, points,
+                       frame_offsets, track_first, item_track, item_frame, choice, pose, B, n_per, r, seed, item_offset, xform,
+                       planes, valid, mask_label);
+    return hipGetLastError();
 }
 
 hipError_t launch_static_crop_prep(const double* points, const int64_t* offsets, const int32_t* choice, const double* pose,

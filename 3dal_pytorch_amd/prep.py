@@ -1,7 +1,10 @@
 """Crop preparation on the device: the per-item work of the reference's Dataset classes
 `STATICTRACK.__getitem__` (tools/static_model.py:529-572) and `DYNAMICTRACK.__getitem__`
 (tools/dynamic_model.py:419-509) — minus pickle I/O and minus the training labels — batched into one
-lib3dal_hip.so kernel per batch (dal3_static_crop_prep / dal3_dynamic_item_prep).
+lib3dal_hip.so kernel per batch (dal3_static_crop_prep / dal3_dynamic_item_prep). With the matched annotation
+boxes given (`gt_boxes` / `gt_of_frame`) the training labels of those methods come back too: the per-point
+mask label from a second kernel over the same draws (dal3_*_labels: det3d's points_in_rbbox), the per-item
+centre / heading / size labels from O(B) host arithmetic (tools/utils.py:53-67).
 
 Tracks use the reference's schema: dict with per-frame lists 'bbox' (7,) global frame,
 'point' (k,3) float64 global frame, 'score'. The host side only concatenates arrays, inverts the 4x4 poses,
@@ -11,7 +14,44 @@ global NumPy stream in the reference's order; every per-point operation runs on 
 import numpy as np
 import torch
 
-from . import _hip
+from . import _hip, arch, geom
+
+_MEAN_SIZE = np.array(arch.MEAN_SIZE)
+_N_HEADING = 12
+
+
+def _angle2class(angle, num_class=_N_HEADING):
+    """tools/utils.py:53-60"""
+    angle = angle % (2 * np.pi)
+    per = 2 * np.pi / float(num_class)
+    shifted = (angle + per / 2) % (2 * np.pi)
+    cid = int(shifted / per)
+    return cid, shifted - (cid * per + per / 2)
+
+
+def _size2class(lwh):
+    """tools/utils.py:62-67"""
+    cid = int(np.argmin(np.linalg.norm(lwh[np.newaxis, ...] - _MEAN_SIZE, axis=1)))
+    return cid, lwh - _MEAN_SIZE[cid]
+
+
+def _item_labels(bbox_gt, heading_ref, center_ref, dev):
+    """per-item labels from the (B,7) float32 annotation boxes; heading_ref (B,) / center_ref (B,3) or None"""
+    hc, hr, sc, sr = [], [], [], []
+    for g, h in zip(bbox_gt, heading_ref):
+        c, r = _angle2class(g[-1] - h)
+        hc.append(c)
+        hr.append(r)
+        c, r = _size2class(g[3:6])
+        sc.append(c)
+        sr.append(r)
+    center = bbox_gt[:, :3] if center_ref is None else bbox_gt[:, :3] - center_ref
+    return {"bbox_gt": torch.from_numpy(np.ascontiguousarray(bbox_gt)).to(dev),
+            "center_label": torch.from_numpy(np.ascontiguousarray(center)).to(dev),
+            "heading_class_label": torch.tensor(hc, dtype=torch.int64, device=dev),
+            "heading_residuals_label": torch.tensor(np.array(hr, dtype=np.float64), device=dev),
+            "size_class_label": torch.tensor(sc, dtype=torch.int64, device=dev),
+            "size_residual_label": torch.from_numpy(np.stack(sr)).to(dev)}
 
 
 def _transform_box(box, pose):
@@ -26,10 +66,14 @@ def _dev(a, device, dtype):
 
 
 def prepare_static_batch(tracks, veh_to_global, n_points=4096, sampler="numpy", seed=10922081, item_offset=0,
-                         device="cuda"):
+                         device="cuda", gt_boxes=None):
     """tracks: list of track dicts; veh_to_global: list of flat-16 poses of each track's BEST-score frame
     (annos['veh_to_global'], static_model.py:538). Returns (pts (B,3,N) fp32 view of point-major storage,
-    init_box (B,7) fp32) — exactly what static_eval.py:265-266 feeds forward()."""
+    init_box (B,7) fp32) — exactly what static_eval.py:265-266 feeds forward().
+    gt_boxes: optional list of the matched annotation's float32 (9,) `box` of that frame (static_model.py:550-553);
+    then a third value is returned, the labels of static_model.py:548-566 as a dict of device tensors:
+    bbox_gt (B,7), mask_label (B,N) u8, center_label, heading_class_label, heading_residuals_label,
+    size_class_label, size_residual_label."""
     B = len(tracks)
     pts_list, boxes, poses, offsets = [], [], [], [0]
     choice = np.empty((B, n_points), np.int32) if sampler == "numpy" else None
@@ -54,14 +98,29 @@ def prepare_static_batch(tracks, veh_to_global, n_points=4096, sampler="numpy", 
     _hip.check(_hip.lib().dal3_static_crop_prep(_hip.ptr(d_pts), _hip.ptr(d_off), _hip.ptr(d_choice), _hip.ptr(d_pose),
                                                 _hip.ptr(d_box), B, n_points, seed, item_offset, _hip.ptr(out),
                                                 _hip.ptr(init), _hip.stream()))
-    return out.transpose(2, 1), init
+    if gt_boxes is None:
+        return out.transpose(2, 1), init
+    bbox_gt = np.stack([np.asarray(g)[[0, 1, 2, 3, 4, 5, -1]] for g in gt_boxes])          # float32, as stored
+    d_planes = geom.planes_to_device(geom.box_planes(bbox_gt), dev)
+    mask = torch.empty((B, n_points), dtype=torch.uint8, device=dev)
+    _hip.check(_hip.lib().dal3_static_crop_labels(_hip.ptr(d_pts), _hip.ptr(d_off), _hip.ptr(d_choice), _hip.ptr(d_pose), B,
+                                                  n_points, seed, item_offset, _hip.ptr(d_planes), _hip.ptr(mask),
+                                                  _hip.stream()))
+    labels = _item_labels(bbox_gt, [b[-1] for b in boxes], None, dev)
+    labels["mask_label"] = mask
+    return out.transpose(2, 1), init, labels
 
 
 def prepare_dynamic_batch(tracks, items, veh_to_global, n_per_frame=1024, r=2, s=50, sampler="numpy", seed=10922081,
-                          item_offset=0, device="cuda"):
+                          item_offset=0, device="cuda", gt_of_frame=None, pose_of_frame=None):
     """tracks: list of track dicts; items: list of (track_index, frame_index); veh_to_global: flat-16 pose of each
     item's own frame (dynamic_model.py:449-451). Returns (pts (B,4,5*n) view, box (B,8,2s+1) view, init_box (B,8))
-    as dynamic_eval.py:222-223 builds them."""
+    as dynamic_eval.py:222-223 builds them.
+    Labels (dynamic_model.py:455-501) when gt_of_frame(track_index, frame) -> float32 (9,) annotation box or None
+    and pose_of_frame(track_index, frame) -> flat-16 veh_to_global are given: a fourth return value, dict with
+    bbox_gt, mask_label (B,5*n) u8, center_label, heading_class_label, heading_residuals_label, size_class_label,
+    size_residual_label. Every item's own frame must have its annotation (the reference redraws another item
+    otherwise, dynamic_model.py:487-489; that choice is the caller's)."""
     B = len(items)
     frame_pts, frame_off, boxes, track_first = [], [0], [], [0]
     for tr in tracks:
@@ -97,4 +156,37 @@ def prepare_dynamic_batch(tracks, items, veh_to_global, n_per_frame=1024, r=2, s
                                                  _hip.ptr(d_it), _hip.ptr(d_if), _hip.ptr(d_choice), _hip.ptr(d_pose), B,
                                                  n_per_frame, r, s, seed, item_offset, _hip.ptr(pts), _hip.ptr(box),
                                                  _hip.ptr(init), _hip.stream()))
-    return pts.transpose(2, 1), box.transpose(2, 1), init
+    if gt_of_frame is None:
+        return pts.transpose(2, 1), box.transpose(2, 1), init
+    w = 2 * r + 1
+    xform = np.zeros((B, w, 16))
+    win_box = np.zeros((B, w, 7), np.float32)
+    valid = np.zeros((B, w), np.uint8)
+    bbox_gt, centre_box = [], []
+    for b, (t, it) in enumerate(items):
+        pose = poses[b].reshape(4, 4)
+        pose_back = np.linalg.inv(pose)                                          # dynamic_model.py:481
+        for j, i in enumerate(range(it - r, it + r + 1)):
+            g = gt_of_frame(t, i) if 0 <= i < len(tracks[t]["bbox"]) else None
+            if g is None:
+                continue
+            valid[b, j] = 1
+            win_box[b, j] = np.asarray(g)[[0, 1, 2, 3, 4, 5, -1]]
+            xform[b, j] = (np.linalg.inv(np.reshape(pose_of_frame(t, i), [4, 4])) @ pose_back).reshape(16)
+        if not valid[b, r]:
+            raise ValueError(f"item {b} (track {t}, frame {it}) has no matched annotation in its own frame")
+        bbox_gt.append(win_box[b, r].copy())
+        cb = np.asarray(tracks[t]["bbox"][it], np.float64)
+        centre_box.append(_transform_box(cb[None, :], pose)[0])
+    bbox_gt, centre_box = np.stack(bbox_gt), np.stack(centre_box)
+    d_planes = geom.planes_to_device(geom.box_planes(win_box.reshape(B * w, 7)), dev)
+    d_xform = _dev(xform, dev, np.float64)
+    d_valid = _dev(valid, dev, np.uint8)
+    mask = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    _hip.check(_hip.lib().dal3_dynamic_item_labels(_hip.ptr(d_pts), _hip.ptr(d_foff), _hip.ptr(d_first), _hip.ptr(d_it),
+                                                   _hip.ptr(d_if), _hip.ptr(d_choice), _hip.ptr(d_pose), B, n_per_frame, r,
+                                                   seed, item_offset, _hip.ptr(d_xform), _hip.ptr(d_planes),
+                                                   _hip.ptr(d_valid), _hip.ptr(mask), _hip.stream()))
+    labels = _item_labels(bbox_gt, centre_box[:, 6], centre_box[:, :3], dev)
+    labels["mask_label"] = mask
+    return pts.transpose(2, 1), box.transpose(2, 1), init, labels

@@ -208,6 +208,52 @@ int dal3_writeback_boxes(const double* final_boxes, const int32_t* final_idx, co
                          const int32_t* det_count, const uint8_t* active, int P, int64_t n_det, int32_t* match,
                          int32_t* owner, dal3_stream stream);
 
+/* ---- the mask labels of the prepared items (training side of SURVEY.md 8(f) N1): static_model.py:548-556,
+ * dynamic_model.py:455-487. Same inputs and the same draws (choice, or seed/item_offset) as the *_prep calls
+ * above, so label n belongs to output point n. Face equations: (.,6,4) f64 rows [nx,ny,nz,d] of the matched
+ * annotation's box as det3d's surface_equ_3d_jitv2 gives them (geometry.py:351-377) — O(#boxes) host work with
+ * NumPy, see dal3_points_in_boxes. mask_label u8 in {0,1}.
+ * static: gt_planes (B,6,4); the test runs on the vehicle-frame point `pose p` (before re-centring).
+ * dynamic: window frame j of item b is tested in frame j's own vehicle frame: q = xform[b][j] (pose p) with
+ * xform (B,2r+1,16) = inv(veh_to_global_j) @ inv(pose_b) (dynamic_model.py:481), planes (B,2r+1,6,4),
+ * valid (B,2r+1) u8 = frame j has the matched annotation; out-of-track or invalid frames give zeros. */
+int dal3_static_crop_labels(const double* points, const int64_t* offsets, const int32_t* choice, const double* pose,
+                            int B, int N, uint64_t seed, int64_t item_offset, const double* gt_planes,
+                            uint8_t* mask_label, dal3_stream stream);
+int dal3_dynamic_item_labels(const double* points, const int64_t* frame_offsets, const int64_t* track_first,
+                             const int32_t* item_track, const int32_t* item_frame, const int32_t* choice,
+                             const double* pose, int B, int n_per, int r, uint64_t seed, int64_t item_offset,
+                             const double* xform, const double* planes, const uint8_t* valid, uint8_t* mask_label,
+                             dal3_stream stream);
+
+/* ---- points-in-rotated-box: det3d box_np_ops.points_in_rbbox (det3d/core/bbox/box_np_ops.py:641-647 ->
+ * geometry.py:240-275) as a (P,K) u8 table. points: P rows of >= 3 values, `stride` values apart, float32
+ * (points_f64 = 0) or float64; planes (K,6,4) f64. A point is outside as soon as ((x nx + y ny) + z nz) + d >= 0
+ * for a face, each operation rounded on its own; evaluated in float32 when f32_math != 0 (float32 points AND
+ * float32 boxes, the reference's sweep case), in float64 otherwise. NaN coordinates count as inside (as there). */
+int dal3_points_in_boxes(const void* points, int points_f64, int64_t P, int64_t stride, const double* planes, int K,
+                         int f32_math, uint8_t* inside, dal3_stream stream);
+
+/* ---- crop extraction from full sweeps: the per-detection loop of _create_pd_detection
+ * (det3d/datasets/waymo/waymo_common.py:166-171, 193) for F frames at once. points (P_total,3) f32 vehicle-frame
+ * sweeps concatenated, point_offsets (F+1); planes (K_total,6,4) f64 face equations of every frame's detections
+ * (already in Waymo convention), box_offsets (F+1); max_points_per_frame bounds the launch. spheres (K_total,4)
+ * f32 [cx,cy,cz,r^2]: a ball that CONTAINS the detection with a margin well above fp32 rounding (the library
+ * culls with it before the exact test; it never decides membership; r^2 = +inf disables the cull).
+ * dal3_crop_count -> counts (K_total) i64 = points inside each detection. The caller forms box_start (K_total+1)
+ * = exclusive prefix of counts and allocates out_points (box_start[K_total],3) f64, then
+ * dal3_crop_fill -> out_points = veh_to_global (pose (F,16) f64 row-major) applied to the members, per detection
+ * in sweep order (what `pose @ [lidars[indices]; 1]` yields); out_index (optional, i32) = index within the sweep.
+ * workspace: dal3_crop_workspace_bytes(K_total, max_points_per_frame); it carries state from count to fill. */
+size_t dal3_crop_workspace_bytes(int64_t K_total, int64_t max_points_per_frame);
+int dal3_crop_count(const float* points, const int64_t* point_offsets, const double* planes, const float* spheres,
+                    const int64_t* box_offsets, int F, int64_t K_total, int64_t max_points_per_frame, int64_t* counts,
+                    void* workspace, size_t workspace_bytes, dal3_stream stream);
+int dal3_crop_fill(const float* points, const int64_t* point_offsets, const double* planes, const float* spheres,
+                   const int64_t* box_offsets, int F, int64_t K_total, int64_t max_points_per_frame, const double* pose,
+                   const int64_t* counts, const int64_t* box_start, double* out_points, int32_t* out_index,
+                   const void* workspace, size_t workspace_bytes, dal3_stream stream);
+
 /* ---- one fused shared-MLP layer, for layer-wise tests: y = relu?(W' x + b') with BN folded,
  * x (B,C_in,N) strided -> y (B,N,C_out) point-major. */
 int dal3_shared_mlp_layer(const dal3_layer* layer, int relu, dal3_bcn x, int B, int N, float* y,

@@ -1,0 +1,139 @@
+"""Points-in-rotated-box and crop extraction on the device (SURVEY.md 8(f) N2, and the labels' test of N1)
+through the C ABI, against fixtures produced by the reference's own det3d geometry code and by its
+_create_pd_detection (tests/golden/gen_golden.py) and against the oracle (oracle/ref_geom.py).
+Membership, counts, order and indices: exact. Global-frame coordinates: float64, |diff| <= 1e-9 m at
+|x| ~ 2e4 m (the 4x4 product's summation order differs from BLAS)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from _common import golden, synth
+from oracle import ref_geom as G
+
+geom = importlib.import_module("3dal_pytorch_amd.geom")
+crops = importlib.import_module("3dal_pytorch_amd.crops")
+hip = importlib.import_module("3dal_pytorch_amd._hip")
+pytestmark = pytest.mark.gpu
+
+
+def _geom_points(dt):
+    pts = synth.sweep(40, "geom", n_points=6000, n_boxes=9)[0].astype(dt)
+    pts[:3] = [[np.nan, 0.0, 0.0], [8.0, np.nan, 0.5], [8.0, -4.0, 0.5]]
+    return pts
+
+
+def test_points_in_rbbox_vs_reference():
+    g = golden("geom_rbbox")
+    for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+        got = geom.points_in_rbbox(torch.from_numpy(_geom_points(dt)).cuda(), g[f"boxes_{tag}"])
+        assert got.dtype == torch.bool and np.array_equal(got.cpu().numpy(), g[f"inside_{tag}"])
+    pts64 = synth.sweep(40, "geom", n_points=6000, n_boxes=9)[0].astype(np.float64) + 1e-9
+    got = geom.points_in_rbbox(torch.from_numpy(pts64).cuda(), g["boxes_f32"])        # the Datasets' mixed case
+    assert np.array_equal(got.cpu().numpy(), g["inside_mixed"])
+    # float32 points against float64 boxes promote to float64 as well
+    got = geom.points_in_rbbox(torch.from_numpy(_geom_points(np.float32)).cuda(), g["boxes_f64"])
+    assert np.array_equal(got.cpu().numpy(), G.points_in_rbbox(_geom_points(np.float32), g["boxes_f64"]))
+
+
+def test_points_on_a_face_are_outside_and_rows_may_be_strided():
+    box = np.array([[8.0, -4.0, 0.5, 4.0, 2.0, 1.5, 0.0]], np.float32)
+    face = np.array([[10.0, -4.0, 0.5], [6.0, -4.0, 0.5], [8.0, -3.0, 0.5], [8.0, -5.0, 0.5], [8.0, -4.0, 1.25],
+                     [8.0, -4.0, -0.25], [9.99, -4.0, 0.5]], np.float32)
+    assert geom.points_in_rbbox(torch.from_numpy(face).cuda(), box)[:, 0].tolist() == [False] * 6 + [True]
+    wide = torch.zeros((7, 5), device="cuda")                                 # (P,5) rows: xyz + two features
+    wide[:, :3] = torch.from_numpy(face).cuda()
+    assert geom.points_in_rbbox(wide, box)[:, 0].tolist() == [False] * 6 + [True]
+    assert geom.points_in_rbbox(wide[:0], box).shape == (0, 1)
+    assert geom.points_in_rbbox(wide, box[:0]).shape == (7, 0)
+
+
+def test_membership_at_sweep_size_vs_oracle():
+    pts, box9, _, _, _ = synth.sweep(44, "big", n_points=180000, n_boxes=64)
+    boxes = G.waymo_boxes(box9)
+    got = geom.points_in_rbbox(torch.from_numpy(pts).cuda(), boxes).cpu().numpy()
+    assert np.array_equal(got, G.points_in_rbbox(pts, boxes))
+    assert got.sum() > 10000
+
+
+def test_crop_extraction_vs_reference_create_pd_detection():
+    g = golden("crops_extract")
+    sweeps, dets, poses = [], [], []
+    for f in range(3):
+        pts, box9, _, _, pose = synth.sweep(41, f"fr{f}", n_points=12000 + 1000 * f, n_boxes=10 + f)
+        sweeps.append(pts)
+        dets.append(box9)
+        poses.append(pose)
+    frames = crops.extract_crops(sweeps, dets, poses, return_index=True)
+    for f, rec in enumerate(frames):
+        assert np.array_equal(rec["boxes_lidar"], g[f"boxes_lidar{f}"])
+        assert np.array_equal(rec["bbox"], g[f"bbox{f}"])
+        assert [int(p.shape[0]) for p in rec["point"]] == g[f"count{f}"].tolist()
+        got = torch.cat(rec["point"]).cpu().numpy()
+        assert got.dtype == np.float64 and np.abs(got - g[f"point{f}"]).max() < 1e-9
+        # sweep order inside every detection, and the indices are the members
+        inside = G.points_in_rbbox(sweeps[f], rec["boxes_lidar"])
+        for k, idx in enumerate(rec["index"]):
+            assert np.array_equal(idx.cpu().numpy(), np.nonzero(inside[:, k])[0])
+    # one frame at a time gives the same as the batch
+    solo = crops.extract_crops(sweeps[1:2], dets[1:2], poses[1:2])[0]
+    assert all(torch.equal(a, b) for a, b in zip(solo["point"], frames[1]["point"]))
+
+
+def test_crop_extraction_ragged_frames_vs_oracle():
+    """frames of very different sizes, a frame without detections, a sweep shorter than one chunk"""
+    spec = [(70000, 40), (300, 3), (5000, 0), (1025, 7), (40000, 25)]
+    sweeps, dets, poses = [], [], []
+    for f, (n, k) in enumerate(spec):
+        pts, box9, _, _, pose = synth.sweep(45, f"rg{f}", n_points=n, n_boxes=max(k, 2))
+        sweeps.append(pts)
+        dets.append(box9[:k])
+        poses.append(pose)
+    frames = crops.extract_crops(sweeps, dets, poses)
+    for f, rec in enumerate(frames):
+        _, boxes_g, pts_g = G.extract_crops(sweeps[f], dets[f], poses[f]) if spec[f][1] else (None, [], [])
+        assert len(rec["point"]) == spec[f][1]
+        for k in range(spec[f][1]):
+            got = rec["point"][k].cpu().numpy()
+            assert got.shape == pts_g[k].shape
+            if got.size:
+                assert np.abs(got - pts_g[k]).max() < 1e-9
+            assert np.array_equal(rec["bbox"][k], boxes_g[k])
+
+
+def test_crop_api_errors():
+    lib = hip.lib()
+    z = torch.zeros(8, dtype=torch.int64, device="cuda")
+    assert lib.dal3_crop_count(None, hip.ptr(z), None, None, hip.ptr(z), 0, 0, 0, None, None, 0, hip.stream()) != 0
+    assert "F" in lib.dal3_last_error().decode()
+    pts = torch.zeros((10, 3), device="cuda")
+    off = torch.tensor([0, 10], dtype=torch.int64, device="cuda")
+    planes = torch.zeros((1, 6, 4), dtype=torch.float64, device="cuda")
+    boff = torch.tensor([0, 1], dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    sph = torch.zeros((1, 4), device="cuda")
+    rc = lib.dal3_crop_count(hip.ptr(pts), hip.ptr(off), hip.ptr(planes), hip.ptr(sph), hip.ptr(boff), 1, 1, 10, hip.ptr(cnt),
+                             None, 0, hip.stream())
+    assert rc != 0 and "workspace" in lib.dal3_last_error().decode()
+    with pytest.raises(RuntimeError):
+        geom.points_in_rbbox(torch.zeros((4, 3)), np.zeros((1, 7), np.float32))
+
+
+def test_crop_extraction_keeps_the_reference_treatment_of_non_finite_points():
+    """a NaN coordinate never fails `>= 0`: the reference puts such a point into EVERY detection; the cull in front
+    of the exact test must not change that (nor what happens to infinite coordinates)"""
+    pts, box9, _, _, pose = synth.sweep(47, "nan", n_points=3000, n_boxes=5)
+    pts[10] = [np.nan, 1.0, 2.0]
+    pts[20] = [np.inf, 0.0, 0.0]
+    pts[30] = [3.0, -np.inf, 0.0]
+    pts[2999] = [np.nan, np.nan, np.nan]
+    rec = crops.extract_crops([pts], [box9], [pose], return_index=True)[0]
+    inside = G.points_in_rbbox(pts, rec["boxes_lidar"])
+    assert inside[10].all() and inside[2999].all()
+    for k, idx in enumerate(rec["index"]):
+        assert np.array_equal(idx.cpu().numpy(), np.nonzero(inside[:, k])[0])
+        assert 10 in idx.cpu().numpy() and 2999 in idx.cpu().numpy()
+    _, _, pts_g = G.extract_crops(pts, box9, pose)
+    for k in range(5):
+        assert np.allclose(rec["point"][k].cpu().numpy(), pts_g[k], rtol=0, atol=1e-9, equal_nan=True)

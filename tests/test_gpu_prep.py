@@ -94,3 +94,82 @@ def test_prepared_crops_feed_the_heads():
     dmodel = build_model("dynamic", synth.state_dict("dynamic"))
     out = dmodel.refine(dp, db, di)
     assert out.shape == (12, 7) and bool(torch.isfinite(out).all())
+
+
+_LABELS = ("bbox_gt", "center_label", "heading_class_label", "heading_residuals_label", "size_class_label",
+           "size_residual_label")
+
+
+def test_static_labels_vs_reference_dataset():
+    """the training labels of STATICTRACK.__getitem__ (static_model.py:548-566), mask label on the device"""
+    g = golden("prep_static")
+    tracks = [synth.track(31, i, n_frames=7 + 3 * i) for i in range(3)]
+    for i, tr in enumerate(tracks):
+        best = int(np.argmax(tr["score"]))
+        pose = synth.pose_veh_to_global(31, tr["token"][best])
+        gt9 = synth.gt_box_in_vehicle(tr["bbox"][best], pose)
+        np.random.seed(100 + i)
+        pts, init, lab = prep.prepare_static_batch([tr], [pose], n_points=4096, sampler="numpy", gt_boxes=[gt9])
+        assert np.abs(pts.transpose(2, 1).cpu().numpy()[0] - g[f"point{i}"].astype(np.float32)).max() < TOL
+        mask = lab["mask_label"].cpu().numpy()[0]
+        assert mask.dtype == np.uint8 and np.array_equal(mask, g[f"mask_label{i}"].astype(np.uint8))
+        assert 100 < mask.sum() < 4000
+        for name in _LABELS:
+            assert np.array_equal(lab[name].cpu().numpy()[0], g[f"{name}{i}"]), name
+
+
+def test_dynamic_labels_vs_reference_dataset():
+    """DYNAMICTRACK.__getitem__ labels (dynamic_model.py:455-501): every window frame labelled in its own vehicle
+    frame; frames without the matched annotation (d0: frames 2 and 6) and out-of-track frames give zeros"""
+    g = golden("prep_dynamic")
+    tracks = [synth.track(32, 10, n_frames=9, empty_every=4), synth.track(32, 11, n_frames=60)]
+
+    def pose_of(t, i):
+        return synth.pose_veh_to_global(31, tracks[t]["token"][i])
+
+    def gt_of(t, i):
+        return None if (t == 0 and i in (2, 6)) else synth.gt_box_in_vehicle(tracks[t]["bbox"][i], pose_of(t, i))
+    k = 0
+    while f"index{k}" in g:
+        idx = int(g[f"index{k}"])
+        t, it = (0, idx) if idx < 9 else (1, idx - 9)
+        np.random.seed(200 + k)
+        pts, box, init, lab = prep.prepare_dynamic_batch(tracks, [(t, it)], [pose_of(t, it)], sampler="numpy",
+                                                         gt_of_frame=gt_of, pose_of_frame=pose_of)
+        assert np.array_equal(lab["mask_label"].cpu().numpy()[0], g[f"mask_label{k}"].astype(np.uint8)), k
+        for name in _LABELS:
+            ref = g[f"{name.replace('residuals_label', 'residual_label') if name.startswith('heading') else name}{k}"]
+            got = lab[name].cpu().numpy()[0]
+            if name in ("center_label", "heading_residuals_label"):     # differences of float64 numbers: 1 ulp of 2e4
+                assert np.abs(got - ref).max() < 1e-11, name
+            else:
+                assert np.array_equal(got, ref), name
+        k += 1
+    assert k == 7
+    with pytest.raises(ValueError):                                      # the item's own frame lacks its annotation
+        prep.prepare_dynamic_batch(tracks, [(0, 2)], [pose_of(0, 2)], gt_of_frame=gt_of, pose_of_frame=pose_of)
+
+
+def test_labels_with_device_sampler_follow_the_points(monkeypatch):
+    """device sampler: label n belongs to output point n (the label kernel repeats the prep kernel's draw).
+    A table (box-frame point -> label) over ALL the track's points comes from the numpy path with the draw
+    replaced by arange; every device-sampled point is then looked up in it by its exact fp32 coordinates."""
+    tr = synth.track(61, 0, n_frames=9)
+    best = int(np.argmax(tr["score"]))
+    pose = synth.pose_veh_to_global(61, tr["token"][best])
+    gt9 = synth.gt_box_in_vehicle(tr["bbox"][best], pose)
+    n_all = sum(len(p) for p in tr["point"])
+    monkeypatch.setattr(np.random, "choice", lambda n, size, replace=True: np.arange(size) % n)
+    tpts, _, tlab = prep.prepare_static_batch([tr], [pose], n_points=n_all, sampler="numpy", gt_boxes=[gt9])
+    monkeypatch.undo()
+    table = {}
+    for xyz, m in zip(tpts[0].t().cpu().numpy(), tlab["mask_label"][0].cpu().numpy()):
+        assert table.setdefault(xyz.tobytes(), int(m)) == int(m)
+    pts, init, lab = prep.prepare_static_batch([tr], [pose], n_points=2048, sampler="device", gt_boxes=[gt9], seed=5)
+    got = lab["mask_label"][0].cpu().numpy()
+    want = np.array([table[xyz.tobytes()] for xyz in pts[0].t().cpu().numpy()])
+    assert np.array_equal(got, want) and 100 < got.sum() < 1950
+    # a shard of a batch draws, and therefore labels, what the whole batch does
+    two = prep.prepare_static_batch([tr, tr], [pose, pose], n_points=2048, sampler="device", gt_boxes=[gt9, gt9], seed=5)
+    one = prep.prepare_static_batch([tr], [pose], n_points=2048, sampler="device", gt_boxes=[gt9], seed=5, item_offset=1)
+    assert torch.equal(two[2]["mask_label"][1:], one[2]["mask_label"]) and torch.equal(two[0][1:], one[0])

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Crop extraction at segment size: F frames x ~180k points x K detections.
+  python tools/bench_crops.py [--frames 192] [--points 180000] [--boxes 60]
+Prints one JSON line: device time of count+scan+fill (HIP events on the launch stream), the HBM roofline figure
+(algorithmic bytes: every sweep point read once per pass = 2 x 12 B, members written once = 24 B + 4 B index),
+the end-to-end call including the host set-up (face equations, concatenation, H2D), and the oracle's rate."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+synth = importlib.import_module("3dal_pytorch_amd.synth")
+crops = importlib.import_module("3dal_pytorch_amd.crops")
+geom = importlib.import_module("3dal_pytorch_amd.geom")
+hip = importlib.import_module("3dal_pytorch_amd._hip")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=192)
+    ap.add_argument("--points", type=int, default=180000)
+    ap.add_argument("--boxes", type=int, default=60)
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (replicated to --frames)")
+    ap.add_argument("--order", default="shuffled", choices=["shuffled", "range_image"],
+                    help="point order inside a sweep: synth.sweep's random order (worst case for the cull: every 64-point "
+                         "round touches every detection's neighbourhood) or beam-major / azimuth-minor like a lidar "
+                         "range image (what real sweeps look like)")
+    args = ap.parse_args()
+    base = [list(synth.sweep(46, f"b{f}", n_points=args.points, n_boxes=args.boxes)) for f in range(args.distinct)]
+    if args.order == "range_image":
+        for b in base:
+            p = b[0]
+            rng = np.linalg.norm(p[:, :2], axis=1)
+            beam = np.clip(((np.arctan2(p[:, 2] - 2.0, rng) + 0.35) / 0.4 * 64).astype(np.int64), 0, 63)
+            b[0] = np.ascontiguousarray(p[np.lexsort((np.arctan2(p[:, 1], p[:, 0]), beam))])
+    sweeps = [torch.from_numpy(base[f % args.distinct][0]).cuda() for f in range(args.frames)]
+    dets = [base[f % args.distinct][1] for f in range(args.frames)]
+    poses = [base[f % args.distinct][4] for f in range(args.frames)]
+    crops.extract_crops(sweeps[:2], dets[:2], poses[:2])                       # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames = crops.extract_crops(sweeps, dets, poses, return_index=True)
+    torch.cuda.synchronize()
+    t_call = time.perf_counter() - t0
+    members = sum(int(p.shape[0]) for fr in frames for p in fr["point"])
+
+    # device part alone, through the C ABI
+    F, K = args.frames, args.frames * args.boxes
+    lib = hip.lib()
+    d_pts = torch.cat(sweeps)
+    n_pts = [int(s.shape[0]) for s in sweeps]
+    d_poff = torch.tensor(np.concatenate([[0], np.cumsum(n_pts)]), dtype=torch.int64, device="cuda")
+    d_boff = torch.arange(0, K + 1, args.boxes, dtype=torch.int64, device="cuda")
+    planes = geom.planes_to_device(np.concatenate([geom.box_planes(crops.waymo_boxes(d)) for d in dets]), "cuda")
+    sph = torch.from_numpy(np.ascontiguousarray(np.concatenate([geom.cull_spheres(crops.waymo_boxes(d)) for d in dets]))).cuda()
+    d_pose = torch.from_numpy(np.stack(poses)).cuda()
+    ws = torch.empty(int(lib.dal3_crop_workspace_bytes(K, max(n_pts))), dtype=torch.uint8, device="cuda")
+    counts = torch.zeros(K, dtype=torch.int64, device="cuda")
+    start = torch.zeros(K + 1, dtype=torch.int64, device="cuda")
+    out = torch.empty((members, 3), dtype=torch.float64, device="cuda")
+    idx = torch.empty(members, dtype=torch.int32, device="cuda")
+
+    def device_part():
+        hip.check(lib.dal3_crop_count(hip.ptr(d_pts), hip.ptr(d_poff), hip.ptr(planes), hip.ptr(sph), hip.ptr(d_boff), F, K, max(n_pts),
+                                      hip.ptr(counts), hip.ptr(ws), ws.numel(), hip.stream()))
+        start[1:] = torch.cumsum(counts, 0)
+        hip.check(lib.dal3_crop_fill(hip.ptr(d_pts), hip.ptr(d_poff), hip.ptr(planes), hip.ptr(sph), hip.ptr(d_boff), F, K,
+                                     max(n_pts), hip.ptr(d_pose), hip.ptr(counts), hip.ptr(start), hip.ptr(out), hip.ptr(idx),
+                                     hip.ptr(ws), ws.numel(), hip.stream()))
+    for _ in range(2):
+        device_part()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        device_part()
+    b.record()
+    b.synchronize()
+    ms = a.elapsed_time(b) / 10
+    n_total = sum(n_pts)
+    nbytes = 2 * 12 * n_total + 28 * members
+    # oracle on one frame (NumPy, vectorised over the frame's boxes)
+    from oracle import ref_geom as G
+    t1 = time.perf_counter()
+    G.extract_crops(base[0][0], base[0][1], base[0][4])
+    t_cpu = time.perf_counter() - t1
+    print(json.dumps({"workload": f"{F} frames x {args.points} pts x {args.boxes} detections, {args.order} point order",
+                      "members": members,
+                      "device_ms": round(ms, 3), "frames_per_s_device": round(F / (ms * 1e-3), 1),
+                      "point_box_tests_per_s": round(n_total * args.boxes / (ms * 1e-3) / 1e9, 1),
+                      "roofline": {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                                   "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 4),
+                                   "algorithmic_bytes": nbytes},
+                      "call_ms_with_host_setup": round(t_call * 1e3, 1),
+                      "frames_per_s_call": round(F / t_call, 1),
+                      "cpu_oracle_frames_per_s": round(1.0 / t_cpu, 2)}))
+
+
+if __name__ == "__main__":
+    main()
