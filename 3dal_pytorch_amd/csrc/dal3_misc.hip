@@ -110,16 +110,19 @@ hipError_t launch_pack_bias(const dal3_layer& L, float* out, hipStream_t s) {
 }
 
 // ================================================================================== FC heads
-// One wave = one 32(out) x 32(items) tile; out channels on MFMA rows, items on columns, K in steps
-// of 8 with the same k <-> (lane half, element) map on both operands (k = k0 + 4h + e).
+// One workgroup = one 32(out) x 32(items) tile; out channels on MFMA rows, items on columns. The contraction is
+// split over the 4 waves (each takes a contiguous quarter of K, in steps of 8 with the same k <-> (lane half,
+// element) map on both operands, k = k0 + 4h + e) and summed through LDS in a fixed order, so the result does not
+// depend on the batch size or on timing. Two k-steps are loaded before their MFMAs: at small batches this kernel
+// is a chain of dependent L2 round trips, not arithmetic.
 __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                                  const float* __restrict__ x, int64_t xs, float* __restrict__ y,
-                                                 int64_t ys, int B, int c_in, int c_out, int relu, int n_mt, int n_bt) {
+                                                 int64_t ys, int B, int c_in, int c_out, int relu, int n_mt) {
+    __shared__ float red[3][16][64];
     const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int mt = wid % n_mt, bt = wid / n_mt;
-    if (bt >= n_bt) return;
+    const int mt = blockIdx.x % n_mt, bt = blockIdx.x / n_mt;
     const int row = 32 * mt + (lane & 31);
     const int item = 32 * bt + (lane & 31);
     const bool row_ok = row < c_out, item_ok = item < B;
@@ -129,22 +132,40 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ W, co
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ch = 32 * mt + tile_chan(r, h);
-        acc[r] = ch < c_out ? bias[ch] : 0.0f;
+        acc[r] = (wave == 0 && ch < c_out) ? bias[ch] : 0.0f;
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-
-    for (int k0 = 0; k0 < c_in; k0 += 8) {
+    const int chunk = ((c_in + 31) / 32) * 8;              // per-wave share of K, a multiple of 8
+    const int k_end = min(c_in, (wave + 1) * chunk);
+    int k0 = wave * chunk;
+    for (; k0 + 16 <= k_end; k0 += 16) {
+        const f32x4 a0 = row_ok ? *reinterpret_cast<const f32x4*>(wp + k0) : zero;
+        const f32x4 a1 = row_ok ? *reinterpret_cast<const f32x4*>(wp + k0 + 8) : zero;
+        const f32x4 b0 = item_ok ? *reinterpret_cast<const f32x4*>(xp + k0) : zero;
+        const f32x4 b1 = item_ok ? *reinterpret_cast<const f32x4*>(xp + k0 + 8) : zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(a0[e], b0[e], acc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(a1[e], b1[e], acc);
+    }
+    for (; k0 < k_end; k0 += 8) {
         const f32x4 a = row_ok ? *reinterpret_cast<const f32x4*>(wp + k0) : zero;
         const f32x4 bv = item_ok ? *reinterpret_cast<const f32x4*>(xp + k0) : zero;
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = mfma32(a[e], bv[e], acc);
     }
-    if (!item_ok) return;
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0 || !item_ok) return;
     float* yp = y + (int64_t)item * ys;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ch = 32 * mt + tile_chan(r, h);
-        if (ch < c_out) yp[ch] = relu ? fmaxf(acc[r], 0.0f) : acc[r];
+        const float v = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+        if (ch < c_out) yp[ch] = relu ? fmaxf(v, 0.0f) : v;
     }
 }
 
@@ -152,9 +173,8 @@ hipError_t launch_fc(const float* W, const float* bias, const float* x, int64_t 
                      int c_in, int c_out, int relu, hipStream_t s) {
     if (c_in % 8 != 0 || xs % 4 != 0) return hipErrorInvalidValue;
     const int n_mt = (c_out + 31) / 32, n_bt = (B + 31) / 32;
-    const int waves = n_mt * n_bt;
-    hipLaunchKernelGGL(fc_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, W, bias, x, xs, y, ys, B, c_in, c_out, relu,
-                       n_mt, n_bt);
+    hipLaunchKernelGGL(fc_kernel, dim3((unsigned)(n_mt * n_bt)), dim3(256), 0, s, W, bias, x, xs, y, ys, B, c_in, c_out,
+                       relu, n_mt);
     return hipGetLastError();
 }
 

@@ -303,6 +303,14 @@ static inline int tiles_per_item(int n_pts, int T) {
 
 hipError_t launch_ins_seg_encode(const InsSegW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
     constexpr int T = DAL3_ENC_T;
+    // A wave runs its T tiles through the whole encoder one after the other (~150 us per tile at 2.4 GHz). When the
+    // job cannot fill the chip's 1024 SIMDs anyway (small eval batches), one tile per wave halves that serial
+    // chain; per-point arithmetic and the atomicMax combine are the same, so the result is bit-identical.
+    if (T > 1 && (int64_t)B * N <= 1024 * 64) {
+        const int tpi1 = tiles_per_item(N, 1);
+        hipLaunchKernelGGL(ins_seg_encode_kernel<1>, dim3((unsigned)((int64_t)B * tpi1)), dim3(64 * DAL3_WG_WAVES), 0, s, w, pts, c_in, N, tpi1, g);
+        return hipGetLastError();
+    }
     const int tpi = tiles_per_item(N, T);
     hipLaunchKernelGGL(ins_seg_encode_kernel<T>, dim3((unsigned)((int64_t)B * tpi)), dim3(64 * DAL3_WG_WAVES), 0, s, w, pts, c_in, N, tpi, g);
     return hipGetLastError();

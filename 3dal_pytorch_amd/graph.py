@@ -1,0 +1,41 @@
+"""hipGraph capture of the refinement path for fixed shapes (launch-bound small batches).
+
+One eval forward is a dozen kernel launches plus a few memsets issued from Python through ctypes; at the batch
+sizes the reference's eval drivers use (tens of crops) the host issue time, not the GPU, sets the latency.
+`CapturedRefine(model, *example_inputs)` records `model.refine(...)` once into a hipGraph (torch.cuda.CUDAGraph =
+hipStreamBeginCapture on ROCm; lib3dal_hip.so only ever enqueues on the stream it is given and allocates
+nothing, so its launches are captured as they are) and replays it per call. Requirements: eval mode, the device
+sampler (the NumPy sampler needs a host round trip in the middle), fixed (B, N).
+"""
+import torch
+
+
+class CapturedRefine:
+    def __init__(self, model, *example_inputs):
+        if model.training:
+            raise RuntimeError("capture the eval-mode path: call model.eval() first")
+        if getattr(model, "sampler", "device") != "device":
+            raise RuntimeError("graph capture needs sampler='device' (the NumPy sampler synchronises with the host)")
+        self.model = model
+        # static input buffers in the callers' layout (same strides as the examples, e.g. point-major pts)
+        self.inputs = [None if t is None else torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
+                       .copy_(t) for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up outside the capture: packs weights, sizes workspace
+            model.refine(*self.inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.boxes = model.refine(*self.inputs)
+        self._keep = dict(model.last) if hasattr(model, "last") else None
+
+    def __call__(self, *inputs):
+        """copies the inputs into the captured buffers, replays, returns the (B,7) boxes (a buffer that the next
+        call overwrites)"""
+        for dst, src in zip(self.inputs, inputs):
+            if dst is not None:
+                dst.copy_(src)
+        self.graph.replay()
+        return self.boxes
