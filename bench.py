@@ -170,6 +170,37 @@ def cpu_baseline(host, budget_s=20.0):
                       f"torch {torch.__version__} CPU kernels, {n} threads"}
 
 
+def torch_gpu_baseline(model, inputs, sample=256, iters=3):
+    """The reference's own formulation on this GPU: stock PyTorch-ROCm ops (Conv1d/BatchNorm1d/Linear/max through
+    MIOpen / rocBLAS, the per-sample NumPy gather loop with its device->host syncs, materialised repeat+cat) — the
+    eval-mode run of the train-mode composite in 3dal_pytorch_amd/static_model.py, which mirrors
+    tools/static_model.py:117-146 op for op — plus an on-device decode. What a user gets from the reference
+    unchanged on an MI355X; reported beside the HIP path, never as `value`."""
+    pts, init, _ = inputs
+    pts, init = pts[:sample], init[:sample]
+    mean = torch.tensor(arch.MEAN_SIZE, device=pts.device)
+
+    def run():
+        with torch.no_grad():
+            o = sm._train_forward_one(model, pts, init)
+            hc, sc = o["heading_scores"].argmax(1), o["size_scores"].argmax(1)
+            ar = torch.arange(pts.shape[0], device=pts.device)
+            ang = hc.float() * (2 * np.pi / 12) + o["heading_residuals"][ar, hc]
+            ang = torch.where(ang > np.pi, ang - 2 * np.pi, ang) + init[:, -1]
+            return torch.cat([o["center"], mean[sc] + o["size_residuals"][ar, sc], ang[:, None]], 1)
+    np.random.seed(0)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(pts.shape[0] / dt, 1), "unit": "object-crops/s", "kind": "port",
+            "sample": f"stock PyTorch-ROCm ops (torch {torch.__version__}), reference formulation incl. the host gather "
+                      f"loop, {iters} x (B={pts.shape[0]}, N={pts.shape[2]}) fp32 on the same GPU"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,6 +332,8 @@ def main():
             model.precision = args.precision
         rec["maxpool"] = maxpool_roofline(dev, iters=5)
         if static:
+            if args.precision == "fp32":
+                rec["torch_gpu_baseline"] = torch_gpu_baseline(model, inputs)
             rec["cpu_baseline"] = cpu_baseline(host)
     if use_dist:
         fence()
