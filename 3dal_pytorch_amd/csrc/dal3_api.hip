@@ -722,6 +722,82 @@ extern "C" int dal3_writeback_boxes(const double* final_boxes, const int32_t* fi
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- training blocks (N4)
+static bool mult32(int64_t v) { return v > 0 && v % 32 == 0; }
+
+extern "C" int dal3_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                              int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
+                              int c_out, float* z, int64_t ldz, int accumulate, dal3_stream stream) {
+    if (!a || !W || !z || !mult32(M) || !mult32(c_in) || !mult32(c_out) || lda < c_in || ldz < c_out || lda % 4 || ldz % 4 ||
+        (!transpose_w && (ldw < c_in || ldw % 4)) || (transpose_w && ldw < c_out) || (scale && !shift) || seg < 0)
+        return fail(DAL3_EINVAL, "tr_linear: bad argument (M, c_in, c_out multiples of 32; strides multiples of 4)");
+    HIP_TRY(launch_tr_linear(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
+                             accumulate, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" size_t dal3_tr_colred_workspace_bytes(int64_t M, int C) {
+    return (M > 0 && C > 0) ? tr_colred_workspace_bytes(M, C) : 0;
+}
+
+extern "C" int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
+                              const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
+                              const float* mu, const float* rstd, void* workspace, size_t workspace_bytes, double* out,
+                              dal3_stream stream) {
+    if (!z || M <= 0 || C <= 0 || ldz < C || !out || (mode != 0 && mode != 1))
+        return fail(DAL3_EINVAL, "tr_colred: bad argument");
+    if (mode == 1 && (!scale || !shift || !mu || !rstd || (!da && (!dg || !arg || seg <= 0))))
+        return fail(DAL3_EINVAL, "tr_colred: mode 1 needs scale/shift/mu/rstd and da or (dg, arg, seg)");
+    if (!workspace || workspace_bytes < tr_colred_workspace_bytes(M, C))
+        return fail(DAL3_EWORKSPACE, "tr_colred: workspace smaller than dal3_tr_colred_workspace_bytes()");
+    HIP_TRY(launch_tr_colred(z, M, C, ldz, mode, da, ldda, dg, arg, seg, scale, shift, mu, rstd,
+                             static_cast<double*>(workspace), out, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda,
+                                   const float* dg, const int32_t* arg, int64_t seg, const float* scale,
+                                   const float* shift, const float* mu, const float* rstd, const float* k1,
+                                   const float* k2, const float* k3, float* dz, int64_t lddz, dal3_stream stream) {
+    if (!z || M <= 0 || C <= 0 || !scale || !shift || !mu || !rstd || !k1 || !k2 || !k3 || !dz || ldz < C || lddz < C ||
+        (!da && (!dg || !arg || seg <= 0)))
+        return fail(DAL3_EINVAL, "tr_bnbwd_apply: bad argument");
+    HIP_TRY(launch_tr_bnbwd_apply(z, M, C, ldz, da, ldda, dg, arg, seg, scale, shift, mu, rstd, k1, k2, k3, dz, lddz,
+                                  static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" size_t dal3_tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in) {
+    return (M > 0 && c_out > 0 && c_in > 0) ? tr_wgrad_workspace_bytes(M, c_out, c_in) : 0;
+}
+
+extern "C" int dal3_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale,
+                             const float* shift, int relu_in, int64_t M, int c_out, int c_in, void* workspace,
+                             size_t workspace_bytes, float* dW, dal3_stream stream) {
+    if (!dz || !a || !dW || !mult32(M) || !mult32(c_out) || !mult32(c_in) || lddz < c_out || lda < c_in || (scale && !shift))
+        return fail(DAL3_EINVAL, "tr_wgrad: bad argument (M, c_in, c_out multiples of 32)");
+    if (!workspace || workspace_bytes < tr_wgrad_workspace_bytes(M, c_out, c_in))
+        return fail(DAL3_EWORKSPACE, "tr_wgrad: workspace smaller than dal3_tr_wgrad_workspace_bytes()");
+    HIP_TRY(launch_tr_wgrad(dz, lddz, a, lda, scale, shift, relu_in, M, c_out, c_in, static_cast<float*>(workspace), dW,
+                            static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float* scale, const float* shift,
+                              float* g, int32_t* arg, int64_t n_seg, dal3_stream stream) {
+    if (!z || !scale || !shift || !g || !arg || seg <= 0 || C <= 0 || n_seg <= 0 || ldz < C)
+        return fail(DAL3_EINVAL, "tr_segmax: bad argument");
+    HIP_TRY(launch_tr_segmax(z, ldz, seg, C, scale, shift, g, arg, n_seg, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_segsum(const float* x, int64_t ldx, int64_t seg, int C, float* out, int64_t n_seg,
+                              dal3_stream stream) {
+    if (!x || !out || seg <= 0 || C <= 0 || n_seg <= 0 || ldx < C) return fail(DAL3_EINVAL, "tr_segsum: bad argument");
+    HIP_TRY(launch_tr_segsum(x, ldx, seg, C, out, n_seg, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, dal3_stream stream) {
     if (!x || !out || rows <= 0 || n <= 0) return fail(DAL3_EINVAL, "maxpool_n: bad argument");
     HIP_TRY(launch_maxpool_n(x, rows, n, out, static_cast<hipStream_t>(stream)));

@@ -200,3 +200,24 @@ hipError_t launch_decode_boxes(float* box_pred, int B, const float* center_add, 
                                float* size_residuals, float* center, float* boxes7, hipStream_t s);
 hipError_t launch_recenter(const float* obj_pts, int B, int M, const float* init_box7, const float* box_one7,
                            const float* bbox_gt7, float* obj_pts_two, int64_t* hcl, float* hrl, hipStream_t s);
+
+// dal3_train.hip: training-mode building blocks over point-major (M x C) fp32 activations
+hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                            int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
+                            int c_out, float* z, int64_t ldz, int accumulate, hipStream_t s);
+size_t tr_colred_workspace_bytes(int64_t M, int C);
+hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
+                            const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
+                            const float* mu, const float* rstd, double* part, double* out, hipStream_t s);
+hipError_t launch_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda,
+                                 const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
+                                 const float* mu, const float* rstd, const float* k1, const float* k2, const float* k3,
+                                 float* dz, int64_t lddz, hipStream_t s);
+size_t tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in);
+hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale,
+                           const float* shift, int relu_in, int64_t M, int c_out, int c_in, float* part, float* dW,
+                           hipStream_t s);
+hipError_t launch_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float* scale, const float* shift,
+                            float* g, int32_t* arg, int64_t n_seg, hipStream_t s);
+hipError_t launch_tr_segsum(const float* x, int64_t ldx, int64_t seg, int C, float* out, int64_t n_seg, hipStream_t s);
+

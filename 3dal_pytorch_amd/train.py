@@ -1,0 +1,322 @@
+"""Training forward/backward of the shared-MLP stacks on the MI355X (first slice).
+
+`loss.backward()` in the reference's train drivers (tools/static_train.py:53-166) spends its time in the per-point
+stacks Conv1d(k=1) -> BatchNorm1d (batch statistics) -> ReLU (-> max over points) of `PointNetInstanceSeg`
+(tools/static_model.py:271-295) and `PointNetEstimation` (:326-334). Here those stacks are two
+`torch.autograd.Function`s whose forward AND backward run on lib3dal_hip.so's training kernels (csrc/dal3_train.hip:
+fp32 MFMA linear / dgrad / wgrad over point-major activations, fixed-order batch-statistics and BN-backward
+reductions, arg-max pooling); the per-crop tails (three Linear+BN1d layers on (B,512) vectors), Dropout's random
+mask and the loss stay stock torch ops — together < 0.1 % of the arithmetic.
+
+Semantics follow torch exactly: biased batch variance for normalisation, unbiased for `running_var`, momentum 0.1,
+eps 1e-5 (static_model.py:250-269 uses the defaults), ReLU gradient 0 at 0, the max routes its gradient to one
+arg-max point. A Conv1d bias in front of a train-mode BatchNorm has an exactly zero gradient (BN subtracts the
+mean); autograd's numerically-noisy ~1e-7 is returned as 0.
+
+Parity: tests/test_gpu_train.py compares outputs, running statistics and every parameter gradient with
+torch autograd over the stock-torch composite (`PointNetInstanceSeg.forward`, `_PointHead.forward`), which
+tests/test_host_cpu.py ties to the oracle.
+"""
+import torch
+
+from . import _hip
+
+_EPS = 1e-5
+_MOM = 0.1
+
+
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=dev)
+
+
+def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False, out=None, accumulate=False):
+    """z (M,c_out) (+)= act(a) @ Wop^T + bias through dal3_tr_linear"""
+    M = a.shape[0]
+    z = out if out is not None else torch.empty((M, c_out), dtype=torch.float32, device=a.device)
+    sc, sh, relu = (act if act is not None else (None, None, False))
+    _hip.check(_hip.lib().dal3_tr_linear(_hip.ptr(a), M, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu),
+                                         _hip.ptr(W), ldw, int(transpose), _hip.ptr(bias), seg, c_out, _hip.ptr(z),
+                                         z.stride(0), int(accumulate), _hip.stream()))
+    return z
+
+
+def _colred(z, mode, da=None, dg=None, arg=None, seg=0, bn=None):
+    M, C = z.shape
+    lib = _hip.lib()
+    ws = _ws(lib.dal3_tr_colred_workspace_bytes(M, C), z.device)
+    out = torch.empty(2 * C, dtype=torch.float64, device=z.device)
+    sc, sh, mu, rstd = bn if bn is not None else (None, None, None, None)
+    _hip.check(lib.dal3_tr_colred(_hip.ptr(z), M, C, z.stride(0), mode, _hip.ptr(da), da.stride(0) if da is not None else 0,
+                                  _hip.ptr(dg), _hip.ptr(arg), seg, _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(mu), _hip.ptr(rstd),
+                                  _hip.ptr(ws), ws.numel(), _hip.ptr(out), _hip.stream()))
+    return out[:C], out[C:]
+
+
+def _wgrad(dz, a, c_out, c_in, act=None):
+    M = dz.shape[0]
+    lib = _hip.lib()
+    ws = _ws(lib.dal3_tr_wgrad_workspace_bytes(M, c_out, c_in), dz.device)
+    dW = torch.empty((c_out, c_in), dtype=torch.float32, device=dz.device)
+    sc, sh, relu = (act if act is not None else (None, None, False))
+    _hip.check(lib.dal3_tr_wgrad(_hip.ptr(dz), dz.stride(0), _hip.ptr(a), a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu),
+                                 M, c_out, c_in, _hip.ptr(ws), ws.numel(), _hip.ptr(dW), _hip.stream()))
+    return dW
+
+
+class _BN:
+    """batch statistics of one layer's pre-BN output and everything derived from them"""
+
+    def __init__(self, z, gamma, beta, running_mean, running_var):
+        M = z.shape[0]
+        s0, s1 = _colred(z, 0)
+        mean = s0 / M
+        var = (s1 / M - mean * mean).clamp_(min=0.0)                    # biased, float64
+        self.mu = mean.float()
+        self.rstd = torch.rsqrt(var + _EPS).float()
+        self.scale = (gamma.double() * torch.rsqrt(var + _EPS)).float()
+        self.shift = (beta.double() - mean * gamma.double() * torch.rsqrt(var + _EPS)).float()
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - _MOM).add_(self.mu, alpha=_MOM)
+                running_var.mul_(1 - _MOM).add_((var * (M / (M - 1))).float(), alpha=_MOM)
+        self.gamma = gamma
+        self.M = M
+
+    @property
+    def act(self):
+        return (self.scale, self.shift, True)
+
+    def backward(self, z, da=None, dg=None, arg=None, seg=0):
+        """(dz, dgamma, dbeta) from the gradient w.r.t. relu(bn(z))"""
+        bn = (self.scale, self.shift, self.mu, self.rstd)
+        dbeta, dgamma = _colred(z, 1, da=da, dg=dg, arg=arg, seg=seg, bn=bn)
+        k1 = (self.gamma * self.rstd).float().contiguous()
+        k2 = (dbeta / self.M).float()
+        k3 = (dgamma / self.M).float()
+        dz = torch.empty_like(z)
+        M, C = z.shape
+        _hip.check(_hip.lib().dal3_tr_bnbwd_apply(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(da),
+                                                  da.stride(0) if da is not None else 0, _hip.ptr(dg), _hip.ptr(arg), seg,
+                                                  _hip.ptr(self.scale), _hip.ptr(self.shift), _hip.ptr(self.mu),
+                                                  _hip.ptr(self.rstd), _hip.ptr(k1), _hip.ptr(k2), _hip.ptr(k3), _hip.ptr(dz),
+                                                  dz.stride(0), _hip.stream()))
+        return dz, dgamma.float(), dbeta.float()
+
+
+def _segmax(z, bn, seg):
+    M, C = z.shape
+    n_seg = M // seg
+    g = torch.empty((n_seg, C), dtype=torch.float32, device=z.device)
+    arg = torch.empty((n_seg, C), dtype=torch.int32, device=z.device)
+    _hip.check(_hip.lib().dal3_tr_segmax(_hip.ptr(z), z.stride(0), seg, C, _hip.ptr(bn.scale), _hip.ptr(bn.shift), _hip.ptr(g),
+                                         _hip.ptr(arg), n_seg, _hip.stream()))
+    return g, arg
+
+
+def _segsum(x, seg):
+    M, C = x.shape
+    out = torch.empty((M // seg, C), dtype=torch.float32, device=x.device)
+    _hip.check(_hip.lib().dal3_tr_segsum(_hip.ptr(x), x.stride(0), seg, C, _hip.ptr(out), M // seg, _hip.stream()))
+    return out
+
+
+def _pad_cols(w, n):
+    """(r, c) -> contiguous (r, n), zero-padded"""
+    out = torch.zeros((w.shape[0], n), dtype=torch.float32, device=w.device)
+    out[:, :w.shape[1]] = w
+    return out
+
+
+def _points_major(pts, c_pad=32):
+    """(B,C,N) logical -> (B*N, c_pad) row-major, zero-padded channels"""
+    B, C, N = pts.shape
+    a0 = torch.zeros((B * N, c_pad), dtype=torch.float32, device=pts.device)
+    a0[:, :C] = pts.transpose(2, 1).reshape(B * N, C)
+    return a0
+
+
+def _check(pts, what):
+    _hip.require_gpu(pts, what)
+    if pts.shape[2] % 32:
+        raise RuntimeError(f"{what}: the training kernels need a multiple of 32 points per item, got {pts.shape[2]}")
+
+
+class _PointStack(torch.autograd.Function):
+    """conv1..4 (+BN+ReLU) and the max over points of a `_PointHead` (static box_est / point_emb): (B,C,N) -> (B,512)"""
+
+    @staticmethod
+    def forward(ctx, pts, stats, *params):
+        _check(pts, "pts")
+        B, _, N = pts.shape
+        a = _points_major(pts.detach())
+        Ws, bns, zs = [], [], []
+        act = None
+        for k in range(4):
+            W, b, gamma, beta = (p.detach() for p in params[4 * k:4 * k + 4])
+            W2 = W.reshape(W.shape[0], -1)
+            W2 = _pad_cols(W2, 32) if k == 0 else W2.contiguous()
+            z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous())
+            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)))
+            Ws.append(W2)
+            bns.append(bn)
+            zs.append(z)
+            a, act = z, bn.act
+        g, arg = _segmax(zs[3], bns[3], N)
+        ctx.saved = (_points_major(pts.detach()), Ws, bns, zs, arg, N, [tuple(p.shape) for p in params])
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        a0, Ws, bns, zs, arg, N, shapes = ctx.saved
+        grads = [None] * 16
+        da = None
+        for k in (3, 2, 1, 0):
+            if k == 3:
+                dz, dgam, dbet = bns[k].backward(zs[k], dg=dg.contiguous(), arg=arg, seg=N)
+            else:
+                dz, dgam, dbet = bns[k].backward(zs[k], da=da)
+            src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a0, None)
+            dW = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
+            grads[4 * k] = dW[:, :shapes[4 * k][1]].reshape(shapes[4 * k])
+            grads[4 * k + 1] = torch.zeros(shapes[4 * k + 1], device=dz.device)
+            grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
+            if k > 0:
+                da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
+        return (None, None, *grads)
+
+
+class _InsSeg(torch.autograd.Function):
+    """PointNetInstanceSeg in train mode: (B,C,N) -> logits (B,N,2). params: conv1..5 then dconv1..4 as
+    (W, b, gamma, beta) each, then dconv5 (W, b); drop: (B*N,128) multiplier (0 or 1/(1-p)) or None."""
+
+    @staticmethod
+    def forward(ctx, pts, drop, stats, *params):
+        _check(pts, "pts")
+        B, C_in, N = pts.shape
+        M = B * N
+        P = [p.detach() for p in params]
+        a0 = _points_major(pts.detach())
+        Ws, bns, zs = [], [], []
+        a, act = a0, None
+        for k in range(5):                                              # conv1..5
+            W, b, gamma, beta = P[4 * k:4 * k + 4]
+            W2 = W.reshape(W.shape[0], -1)
+            W2 = _pad_cols(W2, 32) if k == 0 else W2.contiguous()
+            z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous())
+            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)))
+            Ws.append(W2)
+            bns.append(bn)
+            zs.append(z)
+            a, act = z, bn.act
+        g, arg = _segmax(zs[4], bns[4], N)                              # (B,1024)
+        # dconv1 on cat([out2, g.expand]): per-point part W[:, :64] out2, per-crop part W[:, 64:] g + b
+        Wd1 = P[20].reshape(P[20].shape[0], -1).contiguous()            # (512, 1088)
+        gb = torch.addmm(P[21], g, Wd1[:, 64:].t())                     # (B,512)
+        z = _linear(zs[1], Wd1, Wd1.shape[1], 64, 512, act=bns[1].act, bias=gb.contiguous(), seg=N)
+        bn = _BN(z, P[22], P[23], *(stats[5] if stats is not None else (None, None)))
+        Ws.append(Wd1)
+        bns.append(bn)
+        zs.append(z)
+        a, act = z, bn.act
+        for k in range(6, 9):                                           # dconv2..4
+            W, b, gamma, beta = P[4 * k:4 * k + 4]
+            W2 = W.reshape(W.shape[0], -1).contiguous()
+            z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous())
+            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)))
+            Ws.append(W2)
+            bns.append(bn)
+            zs.append(z)
+            a, act = z, bn.act
+        a4 = torch.relu(zs[8] * bns[8].scale + bns[8].shift)           # Dropout sits between dbn4's ReLU and dconv5
+        if drop is not None:
+            a4 = a4 * drop
+        W5 = torch.zeros((32, 128), dtype=torch.float32, device=pts.device)
+        W5[:2] = P[36].reshape(2, 128)
+        b5 = torch.zeros(32, dtype=torch.float32, device=pts.device)
+        b5[:2] = P[37]
+        zl = _linear(a4, W5, 128, 128, 32, bias=b5)
+        ctx.saved = (a0, Ws, bns, zs, g, arg, a4, drop, W5, N, [tuple(p.shape) for p in params])
+        return zl[:, :2].reshape(B, N, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        a0, Ws, bns, zs, g, arg, a4, drop, W5, N, shapes = ctx.saved
+        M = a0.shape[0]
+        dev = a0.device
+        grads = [None] * 38
+        dzl = torch.zeros((M, 32), dtype=torch.float32, device=dev)
+        dzl[:, :2] = dlogits.reshape(M, 2)
+        grads[36] = _wgrad(dzl, a4, 32, 128)[:2].reshape(shapes[36])
+        grads[37] = dzl[:, :2].sum(0)
+        da = _linear(dzl, W5, 128, 32, 128, transpose=True)
+        if drop is not None:
+            da = da * drop
+        for k in (8, 7, 6):                                             # dconv4..2
+            dz, dgam, dbet = bns[k].backward(zs[k], da=da)
+            grads[4 * k] = _wgrad(dz, zs[k - 1], Ws[k].shape[0], Ws[k].shape[1], bns[k - 1].act).reshape(shapes[4 * k])
+            grads[4 * k + 1] = torch.zeros(shapes[4 * k + 1], device=dev)
+            grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
+            da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
+        # dconv1: per-point part against out2, per-crop part against g
+        dz, dgam, dbet = bns[5].backward(zs[5], da=da)
+        Wd1 = Ws[5]
+        dWa = _wgrad(dz, zs[1], 512, 64, bns[1].act)
+        dgb = _segsum(dz, N)                                            # (B,512)
+        dW1 = torch.cat([dWa, dgb.t() @ g], 1)
+        grads[20] = dW1.reshape(shapes[20])
+        grads[21] = torch.zeros(shapes[21], device=dev)
+        grads[22], grads[23] = dgam, dbet
+        dg = dgb @ Wd1[:, 64:]                                          # (B,1024)
+        da2_dec = _linear(dz, Wd1, Wd1.shape[1], 512, 64, transpose=True)
+        # conv5..1
+        da = None
+        for k in (4, 3, 2, 1, 0):
+            if k == 4:
+                dz, dgam, dbet = bns[k].backward(zs[k], dg=dg.contiguous(), arg=arg, seg=N)
+            else:
+                dz, dgam, dbet = bns[k].backward(zs[k], da=da)
+            src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a0, None)
+            dW = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
+            grads[4 * k] = dW[:, :shapes[4 * k][1]].reshape(shapes[4 * k])
+            grads[4 * k + 1] = torch.zeros(shapes[4 * k + 1], device=dev)
+            grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
+            if k == 2:                                                  # out2 also feeds the decoder
+                da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, out=da2_dec,
+                             accumulate=True)
+            elif k > 0:
+                da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
+        return (None, None, None, *grads)
+
+
+def _bn_stats(mod, names):
+    out = []
+    for n in names:
+        bn = getattr(mod, n)
+        out.append((bn.running_mean, bn.running_var))
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+    return out
+
+
+def ins_seg_train_forward(ins_seg, pts, p_drop=0.5, drop_mask=None):
+    """train-mode PointNetInstanceSeg.forward on the HIP training kernels: logits (B,N,2), autograd-connected to the
+    module's parameters; updates the BatchNorm running statistics like torch does. drop_mask: optional (B*N,128)
+    multiplier replacing the random Dropout draw (tests)."""
+    B, _, N = pts.shape
+    if drop_mask is None and p_drop > 0:
+        drop_mask = (torch.rand((B * N, 128), device=pts.device) >= p_drop).float() / (1.0 - p_drop)
+    params = []
+    for conv, bn in ins_seg.pairs():
+        params += [conv.weight, conv.bias] + ([bn.weight, bn.bias] if bn is not None else [])
+    stats = _bn_stats(ins_seg, ["bn1", "bn2", "bn3", "bn4", "bn5", "dbn1", "dbn2", "dbn3", "dbn4"])
+    return _InsSeg.apply(pts, drop_mask, stats, *params)
+
+
+def point_stack_train_forward(head, pts):
+    """conv1..4 + max of a point head (static box_est, point_emb) in train mode: (B,512) global feature"""
+    params = []
+    for k in range(1, 5):
+        conv, bn = getattr(head, f"conv{k}"), getattr(head, f"bn{k}")
+        params += [conv.weight, conv.bias, bn.weight, bn.bias]
+    stats = _bn_stats(head, ["bn1", "bn2", "bn3", "bn4"])
+    return _PointStack.apply(pts, stats, *params)

@@ -254,6 +254,47 @@ int dal3_crop_fill(const float* points, const int64_t* point_offsets, const doub
                    const int64_t* counts, const int64_t* box_start, double* out_points, int32_t* out_index,
                    const void* workspace, size_t workspace_bytes, dal3_stream stream);
 
+/* ---- training-mode building blocks of the shared-MLP stacks (first slice) --------------
+ * What loss.backward() drives through Conv1d(k=1) + BatchNorm1d (batch statistics) + ReLU + max over points
+ * (tools/static_model.py:271-295,326-339). Activations are POINT-MAJOR row-major fp32 (M x C), M = B*N points
+ * (the memory of (B,C,N).transpose(2,1)); every channel count and M are multiples of 32 (the host pads). Each
+ * layer's pre-BN output z is materialised; the consumer applies "act": y = z*scale[c] + shift[c], then max(y,0) if
+ * relu_in (scale == NULL: identity). The host composes these per layer (3dal_pytorch_amd/train.py).
+ *
+ * dal3_tr_linear   z[p][co] (+)= sum_ci act(a[p][ci]) * Wop[co][ci] + bias.  transpose_w == 0: Wop = W, row-major
+ *                  (c_out, c_in) with row stride ldw (forward); != 0: Wop[co][ci] = W[ci][co], W row-major
+ *                  (c_in, c_out) (dgrad through a layer's own weight). bias: NULL | (c_out) when seg == 0 | per
+ *                  segment bias[(p / seg) * c_out + co] (the decoder's per-crop global-feature term).
+ * dal3_tr_colred   fixed-order column reductions over the points into out[2*C] f64:
+ *                  mode 0: sum z, sum z^2 (batch statistics);
+ *                  mode 1: dy = da * [act(z) > 0]: sum dy (= dbeta), sum dy * (z - mu)*rstd (= dgamma).
+ *                  da: dense (M x C, row stride ldda) or NULL with (dg, arg, seg): da[p][c] = dg[s][c] if p is the
+ *                  arg-max point arg[s][c] of its segment s = p / seg, else 0 (gradient of the max over points).
+ * dal3_tr_bnbwd_apply  dz = k1[c] * (dy - k2[c] - xhat*k3[c])  (k1 = gamma*rstd, k2 = dbeta/M, k3 = dgamma/M).
+ * dal3_tr_wgrad    dW[co][ci] = sum_p dz[p][co] * act(a[p][ci]); partial sums of 2048-point slices are added in
+ *                  slice order (deterministic).
+ * dal3_tr_segmax   g[s][c] = max_p act(z[p][c]) over segment s (relu), arg = index of the first maximum.
+ * dal3_tr_segsum   out[s][c] = sum of x[p][c] over segment s. */
+int dal3_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift, int relu_in,
+                   const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg, int c_out, float* z,
+                   int64_t ldz, int accumulate, dal3_stream stream);
+size_t dal3_tr_colred_workspace_bytes(int64_t M, int C);
+int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
+                   const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
+                   const float* mu, const float* rstd, void* workspace, size_t workspace_bytes, double* out,
+                   dal3_stream stream);
+int dal3_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda, const float* dg,
+                        const int32_t* arg, int64_t seg, const float* scale, const float* shift, const float* mu,
+                        const float* rstd, const float* k1, const float* k2, const float* k3, float* dz, int64_t lddz,
+                        dal3_stream stream);
+size_t dal3_tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in);
+int dal3_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale, const float* shift,
+                  int relu_in, int64_t M, int c_out, int c_in, void* workspace, size_t workspace_bytes, float* dW,
+                  dal3_stream stream);
+int dal3_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float* scale, const float* shift, float* g,
+                   int32_t* arg, int64_t n_seg, dal3_stream stream);
+int dal3_tr_segsum(const float* x, int64_t ldx, int64_t seg, int C, float* out, int64_t n_seg, dal3_stream stream);
+
 /* ---- one fused shared-MLP layer, for layer-wise tests: y = relu?(W' x + b') with BN folded,
  * x (B,C_in,N) strided -> y (B,N,C_out) point-major. */
 int dal3_shared_mlp_layer(const dal3_layer* layer, int relu, dal3_bcn x, int B, int N, float* y,
