@@ -82,6 +82,9 @@ class _PointHead(nn.Module):
             x = F.relu(getattr(self, bn)(getattr(self, name)(x)))
         if self.TABLE["convs"]:
             x = torch.max(x, 2)[0]
+        return self.tail(x)
+
+    def tail(self, x):        # the per-item FC layers after the max over points
         for name, bn, _, _ in self.TABLE["fcs"]:
             x = getattr(self, name)(x)
             if bn:

@@ -12,9 +12,11 @@ import torch
 import torch.nn as nn
 
 from . import _hip, arch
+from .datasets import DYNAMICTRACK                                  # noqa: F401  (the drivers import it from here)
+from .losses import DynamicModelLoss, huber_loss                    # noqa: F401
 from ._heads import (BoxEmbedding, DynamicPointNetEstimation as PointNetEstimation, PackedCache,
                      PointEmbedding, PointNetInstanceSeg, Workspace, as_f32, dtype_of, numpy_choice, rows_contiguous)
-from .static_model import _mask_and_gather, _parse
+from .static_model import _box_pred, _mask_and_gather, _parse, _seg_logits
 
 NUM_HEADING_BIN = arch.NUM_HEADING_BIN
 NUM_SIZE_CLUSTER = arch.NUM_SIZE_CLUSTER
@@ -39,6 +41,7 @@ class DynamicModel(nn.Module):
         self.box_emb = BoxEmbedding(n_classes=n_classes)
         self.box_est = PointNetEstimation(n_classes=n_classes)
         self.sampler = "device"
+        self.train_backend = "hip"                   # train-mode per-point stacks: "hip" (train.py) or "torch"
         self.precision = "fp32"                      # "bf16" / "fp16": 16-bit MFMA operands (configs C3/C5)
         self.seed = 10922081
         self.item_offset = 0
@@ -130,9 +133,11 @@ class DynamicModel(nn.Module):
 
 
 def _train_forward(m, pts, box):
-    logits = m.ins_seg(pts)
+    # per-point stacks (ins_seg, point_emb) on the HIP training kernels when train_backend == "hip"; the 101-box
+    # embedding (not a multiple of 32 columns, 0.2 % of the work) and the FC heads are stock torch ops
+    logits = _seg_logits(m, pts)
     obj, mask = _mask_and_gather(pts, logits, _M, 4)
-    emb = torch.cat([m.point_emb(obj), m.box_emb(box)], dim=1)
+    emb = torch.cat([_box_pred(m, m.point_emb, obj), m.box_emb(box)], dim=1)
     c, hs, hrn, hr, ss, srn, sr = _parse(m.box_est(emb))
     return {"logits": logits, "mask": mask, "center": c, "heading_scores": hs,
             "heading_residuals_normalized": hrn, "heading_residuals": hr, "size_scores": ss,

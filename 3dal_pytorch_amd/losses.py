@@ -1,0 +1,90 @@
+"""The loss modules the reference's train drivers import next to the models: `FrustumPointNetLossOneBoxEst`,
+`FrustumPointNetLossTwoBoxEst` (tools/static_model.py:348-517) and `DynamicModelLoss` (tools/dynamic_model.py:321-398),
+with `huber_loss` (:341-346). Same call signature, same keys in the returned dict, same weights
+(mask + w_box * (10 center + heading class + size class + 20 heading residual + 20 size residual), per stage).
+
+Stock torch ops on whatever device the outputs live on (the reference hard-codes `.cuda()` on its one-hot
+tables): next to the per-point stacks this is O(B) work plus one log-softmax over the (B*N, 2) logits.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import arch
+
+
+def huber_loss(error, delta=1.0):
+    """mean of 0.5 q^2 + delta (|e| - q), q = min(|e|, delta)"""
+    abs_error = torch.abs(error)
+    quadratic = torch.clamp(abs_error, max=delta)
+    return torch.mean(0.5 * quadratic ** 2 + delta * (abs_error - quadratic))
+
+
+def _mask_loss(logits, mask_label):
+    return F.nll_loss(F.log_softmax(logits.view(-1, 2), dim=1), mask_label.view(-1).long())
+
+
+def _box_terms(center, heading_scores, heading_residuals_normalized, size_scores, size_residuals_normalized, center_label,
+               heading_class_label, heading_residuals_label, size_class_label, size_residuals_label):
+    """(center, heading class, heading residual, size class, size residual) losses of ONE box estimate"""
+    dev = center.device
+    center_loss = huber_loss(torch.norm(center - center_label, dim=1), delta=2.0)
+    hcl, scl = heading_class_label.long(), size_class_label.long()
+    heading_class_loss = F.nll_loss(F.log_softmax(heading_scores, dim=1), hcl)
+    h_onehot = torch.eye(arch.NUM_HEADING_BIN, device=dev)[hcl]
+    h_pred = torch.sum(heading_residuals_normalized * h_onehot.float(), dim=1)
+    heading_res_loss = huber_loss(h_pred - heading_residuals_label / (np.pi / arch.NUM_HEADING_BIN), delta=1.0)
+    size_class_loss = F.nll_loss(F.log_softmax(size_scores, dim=1), scl)
+    s_onehot = torch.eye(arch.NUM_SIZE_CLUSTER, device=dev)[scl].view(-1, arch.NUM_SIZE_CLUSTER, 1).repeat(1, 1, 3)
+    s_pred = torch.sum(size_residuals_normalized * s_onehot, dim=1)
+    mean_size = torch.from_numpy(np.array(arch.MEAN_SIZE)).float().to(dev).view(1, arch.NUM_SIZE_CLUSTER, 3)
+    mean_size_label = torch.sum(s_onehot * mean_size, dim=1)
+    size_res_loss = huber_loss(torch.norm(size_residuals_label / mean_size_label - s_pred, dim=1), delta=1.0)
+    return center_loss, heading_class_loss, heading_res_loss, size_class_loss, size_res_loss
+
+
+class _OneBoxLoss(nn.Module):
+    def forward(self, output, mask_label, center_label, heading_class_label, heading_residuals_label, size_class_label,
+                size_residuals_label, w_box=1.0):
+        mask_loss = _mask_loss(output["logits"], mask_label)
+        c, hc, hr, sc, sr = _box_terms(output["center"], output["heading_scores"], output["heading_residuals_normalized"],
+                                       output["size_scores"], output["size_residuals_normalized"], center_label,
+                                       heading_class_label, heading_residuals_label, size_class_label,
+                                       size_residuals_label)
+        total = mask_loss + w_box * (c * 10 + hc + sc + hr * 20 + sr * 20)
+        return {"total_loss": total, "mask_loss": mask_loss, "center_loss": w_box * c * 10,
+                "heading_class_loss": w_box * hc, "size_class_loss": w_box * sc,
+                "heading_residuals_normalized_loss": w_box * hr * 20, "size_residuals_normalized_loss": w_box * sr * 20}
+
+
+class FrustumPointNetLossOneBoxEst(_OneBoxLoss):
+    """tools/static_model.py:348-428"""
+
+
+class DynamicModelLoss(_OneBoxLoss):
+    """tools/dynamic_model.py:321-398 (the same terms on DynamicModel's output dict)"""
+
+
+class FrustumPointNetLossTwoBoxEst(nn.Module):
+    """tools/static_model.py:430-517: both box estimates; stage two is scored against the stage-two heading labels
+    the model itself emits (`heading_class_label_two`, `heading_residuals_label_two`)."""
+
+    def forward(self, output, mask_label, center_label, heading_class_label, heading_residuals_label, size_class_label,
+                size_residuals_label, w_box=1.0):
+        mask_loss = _mask_loss(output["logits"], mask_label)
+        one = _box_terms(output["center_one"], output["heading_scores_one"], output["heading_residuals_normalized_one"],
+                         output["size_scores_one"], output["size_residuals_normalized_one"], center_label,
+                         heading_class_label, heading_residuals_label, size_class_label, size_residuals_label)
+        two = _box_terms(output["center_two"], output["heading_scores_two"], output["heading_residuals_normalized_two"],
+                         output["size_scores_two"], output["size_residuals_normalized_two"], center_label,
+                         output["heading_class_label_two"], output["heading_residuals_label_two"], size_class_label,
+                         size_residuals_label)
+        total = mask_loss + w_box * sum(c * 10 + hc + sc + hr * 20 + sr * 20 for c, hc, hr, sc, sr in (one, two))
+        out = {"total_loss": total, "mask_loss": mask_loss}
+        for tag, (c, hc, hr, sc, sr) in (("one", one), ("two", two)):
+            out.update({f"center_loss_{tag}": w_box * c * 10, f"heading_class_loss_{tag}": w_box * hc,
+                        f"size_class_loss_{tag}": w_box * sc,
+                        f"heading_residuals_normalized_loss_{tag}": w_box * hr * 20,
+                        f"size_residuals_normalized_loss_{tag}": w_box * sr * 20})
+        return out

@@ -19,6 +19,9 @@ import torch
 import torch.nn as nn
 
 from . import _hip, arch
+from . import train as _train
+from .datasets import STATICTRACK                                   # noqa: F401  (the drivers import it from here)
+from .losses import FrustumPointNetLossOneBoxEst, FrustumPointNetLossTwoBoxEst, huber_loss   # noqa: F401
 from ._heads import (PackedCache, PointNetInstanceSeg, StaticPointNetEstimation as PointNetEstimation,
                      Workspace, as_f32, dtype_of, numpy_choice, rows_contiguous)
 
@@ -39,6 +42,7 @@ class _StaticBase(nn.Module):
         self.n_classes = n_classes
         self.n_channel = n_channel
         self.sampler = "device"
+        self.train_backend = "hip"                   # train-mode per-point stacks: "hip" (train.py) or "torch"
         self.precision = "fp32"                      # "bf16" / "fp16": 16-bit MFMA operands (configs C3/C5)
         self.seed = 10922081
         self.item_offset = 0
@@ -216,19 +220,40 @@ def _parse(box_pred):
             box_pred[:, 27:30], srn, srn * mean[None])
 
 
+def _hip_training(m, pts):
+    """train_backend "hip" (default): the per-point stacks run on lib3dal_hip.so's training kernels (train.py);
+    "torch": the stock composite. The HIP kernels need CUDA tensors and a multiple of 32 points per item."""
+    backend = getattr(m, "train_backend", "hip")
+    if backend not in ("hip", "torch"):
+        raise ValueError(f"unknown train_backend {backend!r}")
+    return backend == "hip" and pts.is_cuda and pts.shape[2] % 32 == 0
+
+
+def _seg_logits(m, pts):
+    if _hip_training(m, pts):
+        return _train.ins_seg_train_forward(m.ins_seg, pts.float(), p_drop=m.ins_seg.dropout.p)
+    return m.ins_seg(pts)
+
+
+def _box_pred(m, head, obj):
+    if _hip_training(m, obj):
+        return head.tail(_train.point_stack_train_forward(head, obj))
+    return head(obj)
+
+
 def _train_forward_one(m, pts, init_box):
-    logits = m.ins_seg(pts)
+    logits = _seg_logits(m, pts)
     obj, mask = _mask_and_gather(pts, logits, NUM_OBJECT_POINT, 3)
-    c, hs, hrn, hr, ss, srn, sr = _parse(m.box_est(obj))
+    c, hs, hrn, hr, ss, srn, sr = _parse(_box_pred(m, m.box_est, obj))
     return {"logits": logits, "mask": mask, "center_boxnet": c, "heading_scores": hs,
             "heading_residuals_normalized": hrn, "heading_residuals": hr, "size_scores": ss,
             "size_residuals_normalized": srn, "size_residuals": sr, "center": c + init_box[:, :3]}
 
 
 def _train_forward_two(m, pts, init_box, bbox_gt):
-    logits = m.ins_seg(pts)
+    logits = _seg_logits(m, pts)
     obj, mask = _mask_and_gather(pts, logits, NUM_OBJECT_POINT, 3)
-    c1, hs1, hrn1, hr1, ss1, srn1, sr1 = _parse(m.box_est_one(obj))
+    c1, hs1, hrn1, hr1, ss1, srn1, sr1 = _parse(_box_pred(m, m.box_est_one, obj))
     c1 = c1 + init_box[:, :3]
     with torch.no_grad():
         B = c1.shape[0]
@@ -252,7 +277,7 @@ def _train_forward_two(m, pts, init_box, bbox_gt):
         shifted = torch.remainder(torch.remainder(bbox_gt[:, -1] - box_one[:, -1], two_pi) + per / 2, two_pi)
         hcl = (shifted / per).long()
         hrl = shifted - (hcl.float() * per + per / 2)
-    c2, hs2, hrn2, hr2, ss2, srn2, sr2 = _parse(m.box_est_two(obj2))
+    c2, hs2, hrn2, hr2, ss2, srn2, sr2 = _parse(_box_pred(m, m.box_est_two, obj2))
     c2 = c2 + c1
     return {"logits": logits, "mask": mask, "heading_scores_one": hs1,
             "heading_residuals_normalized_one": hrn1, "heading_residuals_one": hr1, "size_scores_one": ss1,

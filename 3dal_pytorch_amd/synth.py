@@ -272,3 +272,26 @@ def gt_box_in_vehicle(box_global, veh_to_global):
     c = m[:3, :3].T @ (np.asarray(box_global[:3]) - m[:3, 3])
     yaw = box_global[6] - np.arctan2(m[1, 0], m[0, 0])
     return np.concatenate([c, 0.9 * np.asarray(box_global[3:6]), [0.0, 0.0], [yaw]]).astype(np.float32)
+
+
+def loss_case(seed, two_stage=False, batch=6, n_pts=64):
+    """Synthetic model outputs + labels for the loss modules (tools/static_model.py:348-517): returns
+    (output dict of float32 arrays, labels tuple in the criterion's argument order)."""
+    t = f"loss{int(two_stage)}"
+    f32 = lambda name, shape, std=1.0: normal(seed, t + name, shape, 0.0, std).astype(np.float32)   # noqa: E731
+    out = {"logits": f32("lg", (batch, n_pts, 2))}
+    for tag in (("_one", "_two") if two_stage else ("",)):
+        out["center" + tag] = f32("c" + tag, (batch, 3), 2.0)
+        out["heading_scores" + tag] = f32("hs" + tag, (batch, 12))
+        out["heading_residuals_normalized" + tag] = f32("hrn" + tag, (batch, 12), 0.7)
+        out["heading_residuals" + tag] = out["heading_residuals_normalized" + tag] * np.float32(np.pi / 12)
+        out["size_scores" + tag] = f32("ss" + tag, (batch, 3))
+        out["size_residuals_normalized" + tag] = f32("srn" + tag, (batch, 3, 3), 0.5)
+        out["size_residuals" + tag] = out["size_residuals_normalized" + tag] * np.array(arch.MEAN_SIZE, np.float32)[None]
+    if two_stage:
+        out["heading_class_label_two"] = (uniform(seed, t + "hcl2", (batch,)) * 12).astype(np.int64)
+        out["heading_residuals_label_two"] = f32("hrl2", (batch,), 0.1)
+    labels = ((uniform(seed, t + "ml", (batch, n_pts)) > 0.6).astype(np.float32), f32("cl", (batch, 3), 2.0),
+              (uniform(seed, t + "hcl", (batch,)) * 12).astype(np.int64), f32("hrl", (batch,), 0.1),
+              (uniform(seed, t + "scl", (batch,)) * 3).astype(np.int64), f32("srl", (batch, 3), 0.3))
+    return out, labels

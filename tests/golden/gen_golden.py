@@ -393,6 +393,25 @@ def main():
         changed = sum(int((a["boxes_lidar"] != b["boxes_lidar"]).any(1).sum()) for a, b in zip(out_s, det_annos))
         print("write-back fixtures: frames", len(det_annos), "static rows changed", changed)
 
+    # ------------------------------------------------------------------ loss modules (N4): the reference's criteria
+    torch.set_grad_enabled(True)
+    lz = {}
+    for tag, crit, two in (("one", sm.FrustumPointNetLossOneBoxEst(), False), ("two", sm.FrustumPointNetLossTwoBoxEst(), True),
+                           ("dyn", dm.DynamicModelLoss(), False)):
+        out_np, labels_np = synth.loss_case(36, two_stage=two)
+        out_t = {k: torch.from_numpy(v).requires_grad_(v.dtype == np.float32) for k, v in out_np.items()}
+        for w_box in (1.0, 0.3):
+            losses = crit(out_t, *[torch.from_numpy(a) for a in labels_np], w_box=w_box)
+            for k, v in losses.items():
+                lz[f"{tag}_w{w_box}_{k}"] = v.detach().numpy()
+        grads = torch.autograd.grad(losses["total_loss"], [out_t["logits"], out_t["center_two" if two else "center"],
+                                                          out_t["size_residuals_normalized_two" if two else
+                                                                "size_residuals_normalized"]])
+        lz[f"{tag}_dlogits"], lz[f"{tag}_dcenter"], lz[f"{tag}_dsrn"] = (g.numpy() for g in grads)
+    np.savez_compressed(os.path.join(out_dir, "losses.npz"), **lz)
+    torch.set_grad_enabled(False)
+    print("loss fixtures:", {k: float(v) for k, v in lz.items() if k.endswith("total_loss")})
+
     # ------------------------------------------------------------------ state_dict key pin
     keys = {}
     for kind, ctor in (("static_one", lambda: sm.StaticModelOneBoxEst(3, 3)),

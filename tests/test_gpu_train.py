@@ -225,3 +225,53 @@ def test_training_kernels_reject_bad_shapes():
     with pytest.raises(RuntimeError):
         train.point_stack_train_forward(build_model("static_one", synth.state_dict("static_one")).box_est.train(),
                                         torch.zeros((2, 3, 100), device="cuda"))
+
+
+def _labels_for(B, N, seed, dev):
+    rnd = lambda tag, shape, std=1.0: torch.from_numpy(synth.normal(seed, tag, shape, 0.0, std).astype(np.float32)).to(dev)
+    return ((torch.from_numpy(synth.uniform(seed, "ml", (B, N))).to(dev) > 0.6).float(), rnd("cl", (B, 3)),
+            (torch.from_numpy(synth.uniform(seed, "hc", (B,))).to(dev) * 12).long(), rnd("hr", (B,), 0.1),
+            (torch.from_numpy(synth.uniform(seed, "sc", (B,))).to(dev) * 3).long(), rnd("sr", (B, 3), 0.3))
+
+
+@pytest.mark.parametrize("kind", ["static_one", "static_two", "dynamic"])
+def test_whole_train_step_hip_backend_vs_torch_backend(kind):
+    """model.train(); forward; the reference's criterion; backward; Adam step — as static_train.py:76-86 does —
+    with the per-point stacks on the HIP training kernels vs the stock-torch composite. Dropout off (its draw is
+    random); same NumPy stream for the object-point sampling. The two runs share every discrete decision here, so
+    losses agree to 1e-4 and the parameters after the step stay within Adam's lr of each other."""
+    losses = importlib.import_module("3dal_pytorch_amd.losses")
+    B = 4
+    out = {}
+    for backend in ("hip", "torch"):
+        model = build_model(kind, synth.state_dict(kind, seed=24)).train()
+        model.train_backend = backend
+        model.ins_seg.dropout.p = 0.0
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        if kind == "dynamic":
+            p, bx, _, g = synth.dynamic_items(B, n_per_frame=256, seed=24)
+            args = (torch.from_numpy(p).cuda().transpose(2, 1), torch.from_numpy(bx).cuda().transpose(2, 1),
+                    torch.from_numpy(g).cuda())
+            crit, n = losses.DynamicModelLoss(), p.shape[1]
+        else:
+            p, i, g = synth.static_crops(B, 1024, seed=24)
+            args = (torch.from_numpy(p).cuda().transpose(2, 1), torch.from_numpy(i).cuda(), torch.from_numpy(g).cuda())
+            crit = losses.FrustumPointNetLossTwoBoxEst() if kind == "static_two" else losses.FrustumPointNetLossOneBoxEst()
+            n = 1024
+        np.random.seed(77)
+        o = model(*args)
+        loss = crit(o, *_labels_for(B, n, 25, "cuda"))
+        opt.zero_grad()
+        loss["total_loss"].backward()
+        grads = {k: v.grad.clone() for k, v in model.named_parameters()}
+        opt.step()
+        out[backend] = (float(loss["total_loss"].detach()), grads, {k: v.detach().clone() for k, v in model.named_parameters()},
+                        o["mask"].clone())
+    assert torch.equal(out["hip"][3], out["torch"][3])
+    assert abs(out["hip"][0] - out["torch"][0]) <= 1e-4 * abs(out["torch"][0])
+    scale = max(float(g.norm()) for g in out["torch"][1].values())
+    for k, gt in out["torch"][1].items():
+        gh = out["hip"][1][k]                                # conv biases in front of a BN: exactly 0 vs autograd's noise
+        assert float((gh - gt).norm()) <= 2e-2 * float(gt.norm()) + 1e-6 * scale, k
+    for k, pt in out["torch"][2].items():
+        assert float((out["hip"][2][k] - pt).abs().max()) <= 2.5e-3, k        # Adam moves every weight by <= lr (+ decay)
