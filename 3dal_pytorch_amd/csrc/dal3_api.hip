@@ -744,8 +744,8 @@ extern "C" int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int
                               const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                               const float* mu, const float* rstd, void* workspace, size_t workspace_bytes, double* out,
                               dal3_stream stream) {
-    if (!z || M <= 0 || C <= 0 || ldz < C || !out || (mode != 0 && mode != 1))
-        return fail(DAL3_EINVAL, "tr_colred: bad argument");
+    if (!z || M <= 0 || C <= 0 || C % 4 || ldz < C || ldz % 4 || !out || (mode != 0 && mode != 1) || (da && ldda % 4))
+        return fail(DAL3_EINVAL, "tr_colred: bad argument (C and the row strides must be multiples of 4)");
     if (mode == 1 && (!scale || !shift || !mu || !rstd || (!da && (!dg || !arg || seg <= 0))))
         return fail(DAL3_EINVAL, "tr_colred: mode 1 needs scale/shift/mu/rstd and da or (dg, arg, seg)");
     if (!workspace || workspace_bytes < tr_colred_workspace_bytes(M, C))
@@ -759,9 +759,9 @@ extern "C" int dal3_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz
                                    const float* dg, const int32_t* arg, int64_t seg, const float* scale,
                                    const float* shift, const float* mu, const float* rstd, const float* k1,
                                    const float* k2, const float* k3, float* dz, int64_t lddz, dal3_stream stream) {
-    if (!z || M <= 0 || C <= 0 || !scale || !shift || !mu || !rstd || !k1 || !k2 || !k3 || !dz || ldz < C || lddz < C ||
-        (!da && (!dg || !arg || seg <= 0)))
-        return fail(DAL3_EINVAL, "tr_bnbwd_apply: bad argument");
+    if (!z || M <= 0 || C <= 0 || C % 4 || !scale || !shift || !mu || !rstd || !k1 || !k2 || !k3 || !dz || ldz < C ||
+        lddz < C || ldz % 4 || lddz % 4 || (da && ldda % 4) || (!da && (!dg || !arg || seg <= 0)))
+        return fail(DAL3_EINVAL, "tr_bnbwd_apply: bad argument (C and the row strides must be multiples of 4)");
     HIP_TRY(launch_tr_bnbwd_apply(z, M, C, ldz, da, ldda, dg, arg, seg, scale, shift, mu, rstd, k1, k2, k3, dz, lddz,
                                   static_cast<hipStream_t>(stream)));
     return 0;
@@ -784,10 +784,14 @@ extern "C" int dal3_tr_wgrad(const float* dz, int64_t lddz, const float* a, int6
 }
 
 extern "C" int dal3_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float* scale, const float* shift,
-                              float* g, int32_t* arg, int64_t n_seg, dal3_stream stream) {
+                              float* g, int32_t* arg, int64_t n_seg, void* workspace, size_t workspace_bytes,
+                              dal3_stream stream) {
     if (!z || !scale || !shift || !g || !arg || seg <= 0 || C <= 0 || n_seg <= 0 || ldz < C)
         return fail(DAL3_EINVAL, "tr_segmax: bad argument");
-    HIP_TRY(launch_tr_segmax(z, ldz, seg, C, scale, shift, g, arg, n_seg, static_cast<hipStream_t>(stream)));
+    if (!workspace || workspace_bytes < (size_t)n_seg * C * 8 || (reinterpret_cast<uintptr_t>(workspace) & 7))
+        return fail(DAL3_EWORKSPACE, "tr_segmax: workspace needs n_seg * C * 8 bytes, 8-byte aligned");
+    HIP_TRY(launch_tr_segmax(z, ldz, seg, C, scale, shift, g, arg, n_seg, static_cast<unsigned long long*>(workspace),
+                             static_cast<hipStream_t>(stream)));
     return 0;
 }
 

@@ -218,6 +218,6 @@ hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_
                            const float* shift, int relu_in, int64_t M, int c_out, int c_in, float* part, float* dW,
                            hipStream_t s);
 hipError_t launch_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float* scale, const float* shift,
-                            float* g, int32_t* arg, int64_t n_seg, hipStream_t s);
+                            float* g, int32_t* arg, int64_t n_seg, unsigned long long* packed, hipStream_t s);
 hipError_t launch_tr_segsum(const float* x, int64_t ldx, int64_t seg, int C, float* out, int64_t n_seg, hipStream_t s);
 

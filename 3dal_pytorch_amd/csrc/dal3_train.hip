@@ -29,6 +29,70 @@
 //   act: scale == NULL -> identity; else y = z*scale[ci] + shift[ci], then max(y,0) if relu_in
 //   bias: NULL, per-channel (seg == 0) or per-segment (bias[(p / seg) * c_out + co], the decoder's per-crop term)
 // grid: (M/32/TR_T, c_out/32/TR_MTB rounded up); one wave per block of 64 threads x 4 waves? -> 1 wave = 1 unit.
+// One k-tile (32 input channels) of operands for a wave: the activation tiles of its TR_T point tiles and the weight
+// fragments of its TR_MTB output tiles. Two of these ping-pong: the loads of k-tile kt+1 are issued before the 128
+// MFMAs of k-tile kt, so their L2 latency passes under the matrix work (hipcc left alone sinks each load to its
+// first use; the sched_barrier between "load next" and "compute current" keeps them apart).
+struct TrStage {
+    f32x16 X[TR_T];
+    f32x4 Wf[TR_MTB][4];
+};
+
+__device__ __forceinline__ void tr_load_stage(TrStage& st, int kt, const float* __restrict__ a, int64_t lda,
+                                              const int64_t (&prow)[TR_T], const float* __restrict__ scale,
+                                              const float* __restrict__ shift, int relu_in, const float* __restrict__ W,
+                                              int64_t ldw, int transpose_w, int mt0, int n_mt, int h, int m) {
+#pragma unroll
+    for (int j = 0; j < TR_T; ++j) {
+        const float* ap = a + prow[j] * lda + 32 * kt + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(ap + 8 * q);
+            if (scale) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 32 * kt + 8 * q + 4 * h);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + 32 * kt + 8 * q + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = v[e] * sc[e] + sh[e];
+                    if (relu_in) v[e] = fmaxf(v[e], 0.0f);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st.X[j][4 * q + e] = v[e];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TR_MTB; ++t) {
+        if (t >= n_mt) break;
+        const int row = 32 * (mt0 + t) + m;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = 32 * kt + 8 * q + 4 * h;
+            if (!transpose_w) {
+                st.Wf[t][q] = *reinterpret_cast<const f32x4*>(W + (int64_t)row * ldw + col);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st.Wf[t][q][e] = W[(int64_t)(col + e) * ldw + row];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void tr_compute_stage(const TrStage& st, f32x16 (&acc)[TR_T][TR_MTB], int n_mt) {
+#pragma unroll
+    for (int t = 0; t < TR_MTB; ++t) {
+        if (t >= n_mt) break;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int j = 0; j < TR_T; ++j) acc[j][t] = mfma32(st.Wf[t][q][e], st.X[j][4 * q + e], acc[j][t]);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void tr_linear_kernel(const float* __restrict__ a, int64_t M, int c_in, int64_t lda,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         int relu_in, const float* __restrict__ W, int64_t ldw,
@@ -43,64 +107,36 @@ __global__ __launch_bounds__(256) void tr_linear_kernel(const float* __restrict_
     const int mt0 = mblk * TR_MTB;
     const int n_mt = min(TR_MTB, c_out / 32 - mt0);
     const int KT = c_in / 32;
+    int64_t prow[TR_T];
+#pragma unroll
+    for (int j = 0; j < TR_T; ++j) prow[j] = min(pt0 + 32 * j, M - 32) + m;     // a tile past the end recomputes the last one
 
     f32x16 acc[TR_T][TR_MTB];
 #pragma unroll
     for (int j = 0; j < TR_T; ++j) {
-        const int64_t p = min(pt0 + 32 * j, M - 32) + m;
 #pragma unroll
         for (int t = 0; t < TR_MTB; ++t) {
             if (t < n_mt && bias) {
-                const float* bp = bias + (seg > 0 ? (p / seg) * c_out : 0) + 32 * (mt0 + t);
+                const float* bp = bias + (seg > 0 ? (prow[j] / seg) * c_out : 0) + 32 * (mt0 + t);
                 acc[j][t] = tile_from_channels(bp, h);
             } else {
                 acc[j][t] = f32x16{};
             }
         }
     }
-    for (int kt = 0; kt < KT; ++kt) {
-        f32x16 X[TR_T];
-#pragma unroll
-        for (int j = 0; j < TR_T; ++j) {
-            const int64_t p = min(pt0 + 32 * j, M - 32) + m;
-            const float* ap = a + p * lda + 32 * kt + 4 * h;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(ap + 8 * q);
-                if (scale) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 32 * kt + 8 * q + 4 * h);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + 32 * kt + 8 * q + 4 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = v[e] * sc[e] + sh[e];
-                        if (relu_in) v[e] = fmaxf(v[e], 0.0f);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) X[j][4 * q + e] = v[e];
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < TR_MTB; ++t) {
-            if (t >= n_mt) break;
-            const int row = 32 * (mt0 + t) + m;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = 32 * kt + 8 * q + 4 * h;
-                f32x4 w;
-                if (!transpose_w) {
-                    w = *reinterpret_cast<const f32x4*>(W + (int64_t)row * ldw + col);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = W[(int64_t)(col + e) * ldw + row];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                    for (int j = 0; j < TR_T; ++j) acc[j][t] = mfma32(w[e], X[j][4 * q + e], acc[j][t]);
-                }
-            }
-        }
+    // ping-pong over the k-tiles; the k index of a load past the end is clamped (valid memory, values unused) so that
+    // no load sits behind a data-dependent branch, and only the matching compute is skipped
+    TrStage s0, s1;
+    tr_load_stage(s0, 0, a, lda, prow, scale, shift, relu_in, W, ldw, transpose_w, mt0, n_mt, h, m);
+    for (int kt = 0; kt < KT; kt += 2) {
+        tr_load_stage(s1, min(kt + 1, KT - 1), a, lda, prow, scale, shift, relu_in, W, ldw, transpose_w, mt0, n_mt, h, m);
+        DAL3_SCHED_FENCE();
+        tr_compute_stage(s0, acc, n_mt);
+        DAL3_SCHED_FENCE();
+        tr_load_stage(s0, min(kt + 2, KT - 1), a, lda, prow, scale, shift, relu_in, W, ldw, transpose_w, mt0, n_mt, h, m);
+        DAL3_SCHED_FENCE();
+        if (kt + 1 < KT) tr_compute_stage(s1, acc, n_mt);
+        DAL3_SCHED_FENCE();
     }
 #pragma unroll
     for (int j = 0; j < TR_T; ++j) {
@@ -160,53 +196,95 @@ __global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict_
                                                         DaSrc src, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ mu,
                                                         const float* __restrict__ rstd, double* __restrict__ part) {
-    // block: 64 channels x 4 row-lanes; rows [blockIdx.y*TR_RED_ROWS, +TR_RED_ROWS)
-    __shared__ double sm[2][4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    // block: 16 groups of 4 channels (float4 loads: a 256-B row segment per 16 lanes) x 16 row-lanes;
+    // rows [blockIdx.y*TR_RED_ROWS, +TR_RED_ROWS); C % 4 == 0 (channels are padded to 32)
+    __shared__ double sm[2][16][64];
+    const int gl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = (blockIdx.x * 16 + gl) * 4;
     const int64_t r0 = (int64_t)blockIdx.y * TR_RED_ROWS;
-    double s0 = 0.0, s1 = 0.0;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     if (c < C) {
-        float sc = 0.f, sh = 0.f, mean = 0.f, rs = 0.f;
+        f32x4 sc = {0, 0, 0, 0}, sh = sc, mean = sc, rs = sc;
         if (mode == 1) {
-            sc = scale[c];
-            sh = shift[c];
-            mean = mu[c];
-            rs = rstd[c];
+            sc = *reinterpret_cast<const f32x4*>(scale + c);
+            sh = *reinterpret_cast<const f32x4*>(shift + c);
+            mean = *reinterpret_cast<const f32x4*>(mu + c);
+            rs = *reinterpret_cast<const f32x4*>(rstd + c);
         }
-        for (int64_t p = r0 + rl; p < min(M, r0 + TR_RED_ROWS); p += 4) {
-            const float v = z[p * ldz + c];
+        const int64_t r1 = min(M, r0 + TR_RED_ROWS);
+        for (int64_t p = r0 + rl; p < r1; p += 16) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(z + p * ldz + c);
             if (mode == 0) {
-                s0 += v;
-                s1 += (double)v * v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s0[e] += v[e];
+                    s1[e] += (double)v[e] * v[e];
+                }
             } else {
-                const float y = v * sc + sh;
-                const float dy = y > 0.0f ? src.at(p, c, C) : 0.0f;
-                s0 += dy;
-                s1 += (double)dy * ((v - mean) * rs);
+                f32x4 d;
+                if (src.da) {
+                    d = *reinterpret_cast<const f32x4*>(src.da + p * src.ldda + c);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = src.at(p, c + e, C);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = v[e] * sc[e] + sh[e];
+                    const float dy = y > 0.0f ? d[e] : 0.0f;
+                    s0[e] += dy;
+                    s1[e] += (double)dy * ((v[e] - mean[e]) * rs[e]);
+                }
             }
         }
     }
-    sm[0][rl][cl] = s0;
-    sm[1][rl][cl] = s1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sm[0][rl][gl * 4 + e] = s0[e];
+        sm[1][rl][gl * 4 + e] = s1[e];
+    }
     __syncthreads();
-    if (rl == 0 && c < C) {
-        const int64_t o = ((int64_t)blockIdx.y * C + c) * 2;
-        part[o] = ((sm[0][0][cl] + sm[0][1][cl]) + sm[0][2][cl]) + sm[0][3][cl];
-        part[o + 1] = ((sm[1][0][cl] + sm[1][1][cl]) + sm[1][2][cl]) + sm[1][3][cl];
+    if (threadIdx.x < 64) {
+        const int cc = blockIdx.x * 64 + threadIdx.x;
+        if (cc < C) {
+            double t0 = 0.0, t1 = 0.0;
+            for (int i = 0; i < 16; ++i) {
+                t0 += sm[0][i][threadIdx.x];
+                t1 += sm[1][i][threadIdx.x];
+            }
+            const int64_t o = ((int64_t)blockIdx.y * C + cc) * 2;
+            part[o] = t0;
+            part[o + 1] = t1;
+        }
     }
 }
 
-__global__ void tr_colred_final_kernel(const double* __restrict__ part, int n_blocks, int C, double* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// 16 channels x 16 partial-lanes per block: lane l adds the partials l, l+16, l+32, ... in that order, then the 16
+// lane sums are added in lane order — a fixed association, so the result is reproducible.
+__global__ __launch_bounds__(256) void tr_colred_final_kernel(const double* __restrict__ part, int n_blocks, int C,
+                                                              double* __restrict__ out) {
+    __shared__ double sm[2][16][16];
+    const int cl = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < n_blocks; ++b) {
-        s0 += part[((int64_t)b * C + c) * 2];
-        s1 += part[((int64_t)b * C + c) * 2 + 1];
+    if (c < C) {
+        for (int b = l; b < n_blocks; b += 16) {
+            s0 += part[((int64_t)b * C + c) * 2];
+            s1 += part[((int64_t)b * C + c) * 2 + 1];
+        }
     }
-    out[c] = s0;
-    out[C + c] = s1;
+    sm[0][l][cl] = s0;
+    sm[1][l][cl] = s1;
+    __syncthreads();
+    if (l == 0 && c < C) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int i = 0; i < 16; ++i) {
+            t0 += sm[0][i][cl];
+            t1 += sm[1][i][cl];
+        }
+        out[c] = t0;
+        out[C + c] = t1;
+    }
 }
 
 size_t tr_colred_workspace_bytes(int64_t M, int C) {
@@ -220,7 +298,7 @@ hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int m
     DaSrc src{da, ldda, dg, arg, seg};
     hipLaunchKernelGGL(tr_colred_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, s, z, M, C, ldz, mode, src, scale, shift, mu,
                        rstd, part);
-    hipLaunchKernelGGL(tr_colred_final_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, nb, C, out);
+    hipLaunchKernelGGL(tr_colred_final_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, nb, C, out);
     return hipGetLastError();
 }
 
@@ -232,15 +310,34 @@ __global__ __launch_bounds__(256) void tr_bnbwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ rstd, const float* __restrict__ k1,
                                                              const float* __restrict__ k2, const float* __restrict__ k3,
                                                              float* __restrict__ dz, int64_t lddz) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M * C) return;
-    const int64_t p = i / C;
-    const int c = (int)(i - p * C);
-    const float v = z[p * ldz + c];
-    const float y = v * scale[c] + shift[c];
-    const float dy = y > 0.0f ? src.at(p, c, C) : 0.0f;
-    const float xhat = (v - mu[c]) * rstd[c];
-    dz[p * lddz + c] = k1[c] * (dy - k2[c] - xhat * k3[c]);
+    // block: 16 groups of 4 channels x 16 rows; grid (C/64, M/64): a thread walks 4 rows
+    const int c = (blockIdx.x * 16 + (threadIdx.x & 15)) * 4;
+    if (c >= C) return;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(mu + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(k1 + c), a2 = *reinterpret_cast<const f32x4*>(k2 + c);
+    const f32x4 a3 = *reinterpret_cast<const f32x4*>(k3 + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t p = (int64_t)blockIdx.y * 64 + i * 16 + (threadIdx.x >> 4);
+        if (p >= M) return;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(z + p * ldz + c);
+        f32x4 d;
+        if (src.da) {
+            d = *reinterpret_cast<const f32x4*>(src.da + p * src.ldda + c);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = src.at(p, c + e, C);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y = v[e] * sc[e] + sh[e];
+            const float dy = y > 0.0f ? d[e] : 0.0f;
+            o[e] = a1[e] * (dy - a2[e] - (v[e] - mean[e]) * rs[e] * a3[e]);
+        }
+        *reinterpret_cast<f32x4*>(dz + p * lddz + c) = o;
+    }
 }
 
 hipError_t launch_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda,
@@ -248,9 +345,8 @@ hipError_t launch_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, 
                                  const float* mu, const float* rstd, const float* k1, const float* k2, const float* k3,
                                  float* dz, int64_t lddz, hipStream_t s) {
     DaSrc src{da, ldda, dg, arg, seg};
-    const int64_t total = M * C;
-    hipLaunchKernelGGL(tr_bnbwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, M, C, ldz, src,
-                       scale, shift, mu, rstd, k1, k2, k3, dz, lddz);
+    hipLaunchKernelGGL(tr_bnbwd_apply_kernel, dim3((C + 63) / 64, (unsigned)((M + 63) / 64)), dim3(256), 0, s, z, M, C, ldz,
+                       src, scale, shift, mu, rstd, k1, k2, k3, dz, lddz);
     return hipGetLastError();
 }
 
@@ -260,20 +356,59 @@ hipError_t launch_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, 
 // segment per half-wave. A wave owns a WG_MT x WG_KT block of tiles and a slice of the points; the slices' partial
 // sums go to part[slice][co][ci] and are added in slice order by tr_wgrad_final_kernel (deterministic).
 #define WG_MT 4
-#define WG_KT 4
-#define WG_SLICE 2048                    // points per wave
+#define WG_KT 2
+#define WG_MIN_SLICE 128                 // fewest points per wave
+
+#define WG_KS 8                           // k-steps (pairs of points) per operand block
+
+struct WgBlock {
+    float av[WG_KS][WG_MT], bv[WG_KS][WG_KT];
+};
+
+// pa / pb point at this lane's element of the block's first point row: dz[(p0 + h)][32*mt0 + m], a[(p0 + h)][32*kt0 + m];
+// the tiles of the block are 32 floats apart (an immediate offset), successive k-steps two rows apart.
+__device__ __forceinline__ void wg_load(WgBlock& bk, const float* __restrict__ pa, int64_t lddz, const float* __restrict__ pb,
+                                        int64_t lda, int n_mt, int n_kt, const float (&sc)[WG_KT], const float (&sh)[WG_KT],
+                                        bool act, int relu_in) {
+#pragma unroll
+    for (int s = 0; s < WG_KS; ++s) {
+        const float* ra = pa + 2 * s * lddz;
+        const float* rb = pb + 2 * s * lda;
+#pragma unroll
+        for (int t = 0; t < WG_MT; ++t) bk.av[s][t] = t < n_mt ? ra[32 * t] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < WG_KT; ++k) {
+            float v = k < n_kt ? rb[32 * k] : 0.0f;
+            if (act) {
+                v = v * sc[k] + sh[k];
+                if (relu_in) v = fmaxf(v, 0.0f);
+            }
+            bk.bv[s][k] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void wg_compute(const WgBlock& bk, f32x16 (&acc)[WG_MT][WG_KT]) {
+#pragma unroll
+    for (int s = 0; s < WG_KS; ++s)
+#pragma unroll
+        for (int t = 0; t < WG_MT; ++t)
+#pragma unroll
+            for (int k = 0; k < WG_KT; ++k) acc[t][k] = mfma32(bk.av[s][t], bk.bv[s][k], acc[t][k]);
+}
 
 __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ a,
                                                        int64_t lda, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int relu_in, int64_t M, int c_out,
-                                                       int c_in, float* __restrict__ part, int n_mb, int n_kb) {
+                                                       int c_in, float* __restrict__ part, int n_mb, int n_kb,
+                                                       int64_t slice_pts) {
     const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
     const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int blk = (int)(unit % (n_mb * n_kb));
     const int64_t slice = unit / (n_mb * n_kb);
-    const int64_t p_begin = slice * WG_SLICE;
+    const int64_t p_begin = slice * slice_pts;
     if (p_begin >= M) return;
-    const int64_t p_end = min(M, p_begin + WG_SLICE);
+    const int64_t p_end = min(M, p_begin + slice_pts);         // M, slice_pts % 32 == 0: whole blocks of 2*WG_KS = 16 points
     const int mt0 = (blk / n_kb) * WG_MT, kt0 = (blk % n_kb) * WG_KT;
     const int n_mt = min(WG_MT, c_out / 32 - mt0), n_kt = min(WG_KT, c_in / 32 - kt0);
     float sc[WG_KT], sh[WG_KT];
@@ -287,23 +422,30 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
     for (int t = 0; t < WG_MT; ++t)
 #pragma unroll
         for (int k = 0; k < WG_KT; ++k) acc[t][k] = f32x16{};
-    for (int64_t p = p_begin + h; p < p_end; p += 2) {
-        float av[WG_MT], bv[WG_KT];
-#pragma unroll
-        for (int t = 0; t < WG_MT; ++t) av[t] = t < n_mt ? dz[p * lddz + 32 * (mt0 + t) + m] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < WG_KT; ++k) {
-            float v = k < n_kt ? a[p * lda + 32 * (kt0 + k) + m] : 0.0f;
-            if (scale) {
-                v = v * sc[k] + sh[k];
-                if (relu_in) v = fmaxf(v, 0.0f);
-            }
-            bv[k] = v;
-        }
-#pragma unroll
-        for (int t = 0; t < WG_MT; ++t)
-#pragma unroll
-            for (int k = 0; k < WG_KT; ++k) acc[t][k] = mfma32(av[t], bv[k], acc[t][k]);
+    const bool act = scale != nullptr;
+    WgBlock b0, b1;                                            // ping-pong: loads of the next 16 points before these MFMAs
+    const float* pa = dz + (p_begin + h) * lddz + 32 * mt0 + m;
+    const float* pb = a + (p_begin + h) * lda + 32 * kt0 + m;
+    const int64_t sa = 2 * WG_KS * lddz, sb = 2 * WG_KS * lda;
+    // steady state without data-dependent branches around the loads: the slice is an even number of 16-point blocks
+    // (slice_pts % 32 == 0); the load issued during the LAST compute re-reads the slice's first block (valid memory,
+    // values unused) instead of being skipped.
+    const int64_t n_blk = (p_end - p_begin) / (2 * WG_KS);
+    const float* const pa0 = pa;
+    const float* const pb0 = pb;
+    wg_load(b0, pa, lddz, pb, lda, n_mt, n_kt, sc, sh, act, relu_in);
+    for (int64_t i = 0; i < n_blk; i += 2) {
+        wg_load(b1, pa + sa, lddz, pb + sb, lda, n_mt, n_kt, sc, sh, act, relu_in);
+        DAL3_SCHED_FENCE();
+        wg_compute(b0, acc);
+        DAL3_SCHED_FENCE();
+        const bool more = i + 2 < n_blk;
+        pa = more ? pa + 2 * sa : pa0;
+        pb = more ? pb + 2 * sb : pb0;
+        wg_load(b0, pa, lddz, pb, lda, n_mt, n_kt, sc, sh, act, relu_in);
+        DAL3_SCHED_FENCE();
+        wg_compute(b1, acc);
+        DAL3_SCHED_FENCE();
     }
     // D tile: row (co) = tile_chan(r, h), col (ci) = lane & 31
     float* out = part + slice * (int64_t)c_out * c_in;
@@ -320,80 +462,128 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
     }
 }
 
-__global__ void tr_wgrad_final_kernel(const float* __restrict__ part, int n_slices, int64_t n, float* __restrict__ dW) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// 64 elements x 4 slice-lanes per block; lane l adds slices l, l+4, ... in order, then the 4 lane sums in lane order
+__global__ __launch_bounds__(256) void tr_wgrad_final_kernel(const float* __restrict__ part, int n_slices, int64_t n,
+                                                             float* __restrict__ dW) {
+    __shared__ float sm[4][64];
+    const int el = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + el;
     float s = 0.0f;
-    for (int k = 0; k < n_slices; ++k) s += part[(int64_t)k * n + i];
-    dW[i] = s;
+    if (i < n)
+        for (int k = l; k < n_slices; k += 4) s += part[(int64_t)k * n + i];
+    sm[l][el] = s;
+    __syncthreads();
+    if (l == 0 && i < n) dW[i] = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
+}
+
+// slice length: enough (tile block, slice) units to occupy the chip (>= ~2048 waves) without going below
+// WG_MIN_SLICE points per wave; a multiple of 32
+static int64_t wgrad_slice_pts(int64_t M, int c_out, int c_in) {
+    const int64_t blocks = (int64_t)((c_out / 32 + WG_MT - 1) / WG_MT) * ((c_in / 32 + WG_KT - 1) / WG_KT);
+    const int64_t want_slices = (2048 + blocks - 1) / blocks;
+    int64_t pts = (M + want_slices - 1) / want_slices;
+    pts = (pts + 31) / 32 * 32;
+    return pts < WG_MIN_SLICE ? WG_MIN_SLICE : pts;
 }
 
 size_t tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in) {
-    return (size_t)((M + WG_SLICE - 1) / WG_SLICE) * c_out * c_in * sizeof(float);
+    const int64_t pts = wgrad_slice_pts(M, c_out, c_in);
+    return (size_t)((M + pts - 1) / pts) * c_out * c_in * sizeof(float);
 }
 
 hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale,
                            const float* shift, int relu_in, int64_t M, int c_out, int c_in, float* part, float* dW,
                            hipStream_t s) {
     const int n_mb = (c_out / 32 + WG_MT - 1) / WG_MT, n_kb = (c_in / 32 + WG_KT - 1) / WG_KT;
-    const int64_t n_slices = (M + WG_SLICE - 1) / WG_SLICE;
+    const int64_t pts = wgrad_slice_pts(M, c_out, c_in);
+    const int64_t n_slices = (M + pts - 1) / pts;
     const int64_t units = n_slices * n_mb * n_kb;
     hipLaunchKernelGGL(tr_wgrad_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, dz, lddz, a, lda, scale, shift,
-                       relu_in, M, c_out, c_in, part, n_mb, n_kb);
+                       relu_in, M, c_out, c_in, part, n_mb, n_kb, pts);
     const int64_t n = (int64_t)c_out * c_in;
-    hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, (int)n_slices, n, dW);
+    hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, (int)n_slices, n, dW);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------- max over points
-// g[s][c] = max_p act(z[p][c]) over the `seg` points of segment s, with the index of the (first) maximum for the
-// backward pass. One thread per (segment, channel) walking the segment: consecutive threads read consecutive
-// channels of one row, so a warp-row of 64 channels is one 256-B segment per step.
+// g[s][c] = max_p act(z[p][c]) over the `seg` points of segment s, with the index of the FIRST maximum for the
+// backward pass. Block = 64 channels x 4 row-lanes over one of SEG_CHUNKS chunks of the segment; candidates meet
+// through a packed 64-bit atomicMax: high word = the value's bit pattern (values are >= +0 after the ReLU, so the
+// bits order like the floats), low word = ~index, so that among equal values the smallest index wins.
+#define SEG_CHUNKS 16
 __global__ __launch_bounds__(256) void tr_segmax_kernel(const float* __restrict__ z, int64_t ldz, int64_t seg, int C,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                        float* __restrict__ g, int32_t* __restrict__ arg, int64_t n_seg) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_seg * C) return;
-    const int64_t s = i / C;
-    const int c = (int)(i - s * C);
-    const float sc = scale[c], sh = shift[c];
-    float best = -INFINITY;
-    int32_t bi = 0;
-    const float* zp = z + s * seg * ldz + c;
-    for (int64_t p = 0; p < seg; ++p) {
-        const float y = fmaxf(zp[p * ldz] * sc + sh, 0.0f);
-        if (y > best) {
-            best = y;
-            bi = (int32_t)p;
+                                                        unsigned long long* __restrict__ packed) {
+    __shared__ unsigned long long sm[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int64_t s = blockIdx.y / SEG_CHUNKS;
+    const int chunk = blockIdx.y % SEG_CHUNKS;
+    const int64_t len = (seg + SEG_CHUNKS - 1) / SEG_CHUNKS;
+    const int64_t p0 = chunk * len, p1 = min(seg, p0 + len);
+    unsigned long long best = 0ull;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c];
+        const float* zp = z + s * seg * ldz + c;
+        float bv = -1.0f;
+        int64_t bi = 0;
+        for (int64_t p = p0 + rl; p < p1; p += 4) {
+            const float y = fmaxf(zp[p * ldz] * sc + sh, 0.0f);
+            if (y > bv) {
+                bv = y;
+                bi = p;
+            }
         }
+        if (bv >= 0.0f) best = ((unsigned long long)__float_as_uint(bv) << 32) | (0xffffffffu - (uint32_t)bi);
     }
-    g[i] = best;
-    arg[i] = bi;
+    sm[rl][cl] = best;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        unsigned long long b = sm[0][cl];
+        for (int i = 1; i < 4; ++i) b = sm[i][cl] > b ? sm[i][cl] : b;
+        atomicMax(packed + s * C + c, b);
+    }
+}
+
+__global__ void tr_segmax_unpack_kernel(const unsigned long long* __restrict__ packed, int64_t n, float* __restrict__ g,
+                                        int32_t* __restrict__ arg) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long b = packed[i];
+    g[i] = __uint_as_float((uint32_t)(b >> 32));
+    arg[i] = (int32_t)(0xffffffffu - (uint32_t)b);
 }
 
 hipError_t launch_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float* scale, const float* shift,
-                            float* g, int32_t* arg, int64_t n_seg, hipStream_t s) {
+                            float* g, int32_t* arg, int64_t n_seg, unsigned long long* packed, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(packed, 0, (size_t)n_seg * C * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tr_segmax_kernel, dim3((C + 63) / 64, (unsigned)(n_seg * SEG_CHUNKS)), dim3(256), 0, s, z, ldz, seg, C,
+                       scale, shift, packed);
     const int64_t total = n_seg * C;
-    hipLaunchKernelGGL(tr_segmax_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, ldz, seg, C, scale, shift,
-                       g, arg, n_seg);
+    hipLaunchKernelGGL(tr_segmax_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, packed, total, g, arg);
     return hipGetLastError();
 }
 
-// per-segment column sums: out[s][c] = sum_{p in segment s} x[p][c]  (gradient of the decoder's per-crop term)
+// per-segment column sums: out[s][c] = sum_{p in segment s} x[p][c]  (gradient of the decoder's per-crop term).
+// Block = 64 channels x 4 row-lanes over a whole segment; lane sums in double, added in lane order.
 __global__ __launch_bounds__(256) void tr_segsum_kernel(const float* __restrict__ x, int64_t ldx, int64_t seg, int C,
-                                                        float* __restrict__ out, int64_t n_seg) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_seg * C) return;
-    const int64_t s = i / C;
-    const int c = (int)(i - s * C);
-    const float* xp = x + s * seg * ldx + c;
+                                                        float* __restrict__ out) {
+    __shared__ double sm[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int64_t s = blockIdx.y;
     double acc = 0.0;
-    for (int64_t p = 0; p < seg; ++p) acc += xp[p * ldx];
-    out[i] = (float)acc;
+    if (c < C) {
+        const float* xp = x + s * seg * ldx + c;
+        for (int64_t p = rl; p < seg; p += 4) acc += xp[p * ldx];
+    }
+    sm[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) out[s * C + c] = (float)(((sm[0][cl] + sm[1][cl]) + sm[2][cl]) + sm[3][cl]);
 }
 
 hipError_t launch_tr_segsum(const float* x, int64_t ldx, int64_t seg, int C, float* out, int64_t n_seg, hipStream_t s) {
-    const int64_t total = n_seg * C;
-    hipLaunchKernelGGL(tr_segsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, seg, C, out, n_seg);
+    hipLaunchKernelGGL(tr_segsum_kernel, dim3((C + 63) / 64, (unsigned)n_seg), dim3(256), 0, s, x, ldx, seg, C, out);
     return hipGetLastError();
 }

@@ -108,8 +108,9 @@ def _segmax(z, bn, seg):
     n_seg = M // seg
     g = torch.empty((n_seg, C), dtype=torch.float32, device=z.device)
     arg = torch.empty((n_seg, C), dtype=torch.int32, device=z.device)
+    ws = torch.empty(n_seg * C, dtype=torch.int64, device=z.device)
     _hip.check(_hip.lib().dal3_tr_segmax(_hip.ptr(z), z.stride(0), seg, C, _hip.ptr(bn.scale), _hip.ptr(bn.shift), _hip.ptr(g),
-                                         _hip.ptr(arg), n_seg, _hip.stream()))
+                                         _hip.ptr(arg), n_seg, _hip.ptr(ws), ws.numel() * 8, _hip.stream()))
     return g, arg
 
 

@@ -271,8 +271,8 @@ int dal3_crop_fill(const float* points, const int64_t* point_offsets, const doub
  *                  da: dense (M x C, row stride ldda) or NULL with (dg, arg, seg): da[p][c] = dg[s][c] if p is the
  *                  arg-max point arg[s][c] of its segment s = p / seg, else 0 (gradient of the max over points).
  * dal3_tr_bnbwd_apply  dz = k1[c] * (dy - k2[c] - xhat*k3[c])  (k1 = gamma*rstd, k2 = dbeta/M, k3 = dgamma/M).
- * dal3_tr_wgrad    dW[co][ci] = sum_p dz[p][co] * act(a[p][ci]); partial sums of 2048-point slices are added in
- *                  slice order (deterministic).
+ * dal3_tr_wgrad    dW[co][ci] = sum_p dz[p][co] * act(a[p][ci]); partial sums of point slices are added in a fixed
+ *                  order (deterministic).
  * dal3_tr_segmax   g[s][c] = max_p act(z[p][c]) over segment s (relu), arg = index of the first maximum.
  * dal3_tr_segsum   out[s][c] = sum of x[p][c] over segment s. */
 int dal3_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift, int relu_in,
@@ -292,7 +292,8 @@ int dal3_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, co
                   int relu_in, int64_t M, int c_out, int c_in, void* workspace, size_t workspace_bytes, float* dW,
                   dal3_stream stream);
 int dal3_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float* scale, const float* shift, float* g,
-                   int32_t* arg, int64_t n_seg, dal3_stream stream);
+                   int32_t* arg, int64_t n_seg, void* workspace /* n_seg*C*8 bytes, 8-byte aligned */,
+                   size_t workspace_bytes, dal3_stream stream);
 int dal3_tr_segsum(const float* x, int64_t ldx, int64_t seg, int C, float* out, int64_t n_seg, dal3_stream stream);
 
 /* ---- one fused shared-MLP layer, for layer-wise tests: y = relu?(W' x + b') with BN folded,

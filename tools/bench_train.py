@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""One training step of the static head as static_train.py:76-86 runs it (forward, criterion, backward, Adam) at the
+reference's batch (64 crops x 4096 points): per-point stacks on the HIP training kernels vs the stock-torch composite
+on the same GPU.   python tools/bench_train.py [--batch 64] [--points 4096] [--kind static_one]"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+synth = importlib.import_module("3dal_pytorch_amd.synth")
+arch = importlib.import_module("3dal_pytorch_amd.arch")
+sm = importlib.import_module("3dal_pytorch_amd.static_model")
+losses = importlib.import_module("3dal_pytorch_amd.losses")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--points", type=int, default=4096)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--backends", default="hip,torch")
+    args = ap.parse_args()
+    B, N = args.batch, args.points
+    dev = torch.device("cuda", 0)
+    p, i, g = synth.static_crops(min(B, 64), N, seed=3)
+    reps = (B + p.shape[0] - 1) // p.shape[0]
+    pts = torch.from_numpy(np.tile(p, (reps, 1, 1))[:B]).to(dev).transpose(2, 1)
+    init = torch.from_numpy(np.tile(i, (reps, 1))[:B]).to(dev)
+    gt = torch.from_numpy(np.tile(g, (reps, 1))[:B]).to(dev)
+    labels = ((torch.rand((B, N), device=dev) > 0.6).float(), torch.randn((B, 3), device=dev),
+              torch.randint(0, 12, (B,), device=dev), 0.1 * torch.randn((B,), device=dev),
+              torch.randint(0, 3, (B,), device=dev), 0.3 * torch.randn((B, 3), device=dev))
+    crit = losses.FrustumPointNetLossOneBoxEst()
+    out = {"workload": f"StaticModelOneBoxEst train step, {B} crops x {N} pts, fp32, Adam", "unit": "ms per step"}
+    # algorithmic FLOP of the per-point stacks: forward + dgrad + wgrad = 3x forward (nominal formulation)
+    mac_pt = sum(ci * co for _, _, ci, co in arch.ins_seg_layers(3)) - 1024 * 512      # per-crop part of dconv1 excluded
+    mac_obj = sum(ci * co for _, _, ci, co in arch.STATIC_BOX_EST["convs"])
+    flop = 3 * 2.0 * (B * N * mac_pt + B * 512 * mac_obj)
+    for backend in args.backends.split(","):
+        model = sm.StaticModelOneBoxEst()
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict("static_one").items()})
+        model = model.to(dev).train()
+        model.train_backend = backend
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+
+        def step():
+            o = model(pts, init, gt)
+            loss = crit(o, *labels)["total_loss"]
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+        np.random.seed(0)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            loss = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.iters * 1e3
+        out[backend] = {"ms": round(ms, 2), "crops_per_s": round(B / ms * 1e3, 1), "tflops_per_point_stacks": round(flop / ms / 1e9, 1),
+                        "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "loss": round(float(loss), 4)}
+        del model, opt
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+    if "torch" in out and "hip" in out:
+        out["speedup"] = round(out["torch"]["ms"] / out["hip"]["ms"], 2)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
