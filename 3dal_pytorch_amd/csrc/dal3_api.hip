@@ -727,13 +727,21 @@ static bool mult32(int64_t v) { return v > 0 && v % 32 == 0; }
 
 extern "C" int dal3_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                               int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
-                              int c_out, float* z, int64_t ldz, int accumulate, dal3_stream stream) {
+                              int c_out, float* z, int64_t ldz, int accumulate, void* workspace, size_t workspace_bytes,
+                              dal3_stream stream) {
     if (!a || !W || !z || !mult32(M) || !mult32(c_in) || !mult32(c_out) || lda < c_in || ldz < c_out || lda % 4 || ldz % 4 ||
         (!transpose_w && (ldw < c_in || ldw % 4)) || (transpose_w && ldw < c_out) || (scale && !shift) || seg < 0)
         return fail(DAL3_EINVAL, "tr_linear: bad argument (M, c_in, c_out multiples of 32; strides multiples of 4)");
+    const size_t need = tr_linear_workspace_bytes(c_in, c_out);
+    if (need && (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15)))
+        return fail(DAL3_EWORKSPACE, "tr_linear: workspace smaller than dal3_tr_linear_workspace_bytes() or not 16-byte aligned");
     HIP_TRY(launch_tr_linear(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
-                             accumulate, static_cast<hipStream_t>(stream)));
+                             accumulate, need ? static_cast<float*>(workspace) : nullptr, static_cast<hipStream_t>(stream)));
     return 0;
+}
+
+extern "C" size_t dal3_tr_linear_workspace_bytes(int c_in, int c_out) {
+    return (c_in > 0 && c_out > 0) ? tr_linear_workspace_bytes(c_in, c_out) : 0;
 }
 
 extern "C" size_t dal3_tr_colred_workspace_bytes(int64_t M, int C) {
@@ -752,6 +760,24 @@ extern "C" int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int
         return fail(DAL3_EWORKSPACE, "tr_colred: workspace smaller than dal3_tr_colred_workspace_bytes()");
     HIP_TRY(launch_tr_colred(z, M, C, ldz, mode, da, ldda, dg, arg, seg, scale, shift, mu, rstd,
                              static_cast<double*>(workspace), out, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_bn_finalize(const double* sums, int C, int64_t M, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, float* mu,
+                                   float* rstd, float* scale, float* shift, dal3_stream stream) {
+    if (!sums || C <= 0 || M < 2 || !gamma || !beta || !mu || !rstd || !scale || !shift || (!running_mean != !running_var))
+        return fail(DAL3_EINVAL, "tr_bn_finalize: bad argument");
+    HIP_TRY(launch_tr_bn_finalize(sums, C, M, gamma, beta, running_mean, running_var, momentum, eps, mu, rstd, scale, shift,
+                                  static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_bnbwd_coef(const double* sums, int C, int64_t M, const float* gamma, const float* rstd, float* dgamma,
+                                  float* dbeta, float* k1, float* k2, float* k3, dal3_stream stream) {
+    if (!sums || C <= 0 || M <= 0 || !gamma || !rstd || !dgamma || !dbeta || !k1 || !k2 || !k3)
+        return fail(DAL3_EINVAL, "tr_bnbwd_coef: bad argument");
+    HIP_TRY(launch_tr_bnbwd_coef(sums, C, M, gamma, rstd, dgamma, dbeta, k1, k2, k3, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

@@ -204,11 +204,17 @@ hipError_t launch_recenter(const float* obj_pts, int B, int M, const float* init
 // dal3_train.hip: training-mode building blocks over point-major (M x C) fp32 activations
 hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                             int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
-                            int c_out, float* z, int64_t ldz, int accumulate, hipStream_t s);
+                            int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s);
+size_t tr_linear_workspace_bytes(int c_in, int c_out);
 size_t tr_colred_workspace_bytes(int64_t M, int C);
 hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                             const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                             const float* mu, const float* rstd, double* part, double* out, hipStream_t s);
+hipError_t launch_tr_bn_finalize(const double* sums, int C, int64_t M, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
+                                 float* scale, float* shift, hipStream_t s);
+hipError_t launch_tr_bnbwd_coef(const double* sums, int C, int64_t M, const float* gamma, const float* rstd, float* dgamma,
+                                float* dbeta, float* k1, float* k2, float* k3, hipStream_t s);
 hipError_t launch_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda,
                                  const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                                  const float* mu, const float* rstd, const float* k1, const float* k2, const float* k3,

@@ -162,11 +162,148 @@ __global__ __launch_bounds__(256) void tr_linear_kernel(const float* __restrict_
     }
 }
 
+// ---- fast path for c_out % 128 == 0 (every big layer): the weights are first re-ordered into MFMA fragment order
+// ([output block][k-tile][tile][q] x 1 KiB, tr_pack_kernel: a few microseconds) so that a fragment is ONE coalesced
+// 1-KiB load, and they are streamed through the 8-deep prefetch ring of the eval kernels (dal3_device.h) instead of
+// being double-buffered per k-tile: 128 accumulator + 64 activation + 32 ring registers leave room for two waves per
+// SIMD, so one wave's prologue/epilogue hides under the other's MFMAs.
+__global__ void tr_pack_kernel(const float* __restrict__ W, int64_t ldw, int transpose_w, int c_out, int c_in,
+                               float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)c_out * c_in) return;
+    const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    int64_t f = i >> 8;                                       // fragment index
+    const int q = (int)(f & 3), t = (int)((f >> 2) & 3);
+    f >>= 4;
+    const int KT = c_in / 32;
+    const int kt = (int)(f % KT), mblk = (int)(f / KT);
+    const int row = 32 * (4 * mblk + t) + (lane & 31), col = 32 * kt + 8 * q + 4 * (lane >> 5) + e;
+    out[i] = transpose_w ? W[(int64_t)col * ldw + row] : W[(int64_t)row * ldw + col];
+}
+
+__device__ __forceinline__ void tr_load_x(f32x16 (&X)[TR_T], int kt, const float* __restrict__ a, int64_t lda,
+                                          const int64_t (&prow)[TR_T], const float* __restrict__ scale,
+                                          const float* __restrict__ shift, int relu_in, int h) {
+#pragma unroll
+    for (int j = 0; j < TR_T; ++j) {
+        const float* ap = a + prow[j] * lda + 32 * kt + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(ap + 8 * q);
+            if (scale) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 32 * kt + 8 * q + 4 * h);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + 32 * kt + 8 * q + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = v[e] * sc[e] + sh[e];
+                    if (relu_in) v[e] = fmaxf(v[e], 0.0f);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) X[j][4 * q + e] = v[e];
+        }
+    }
+}
+
+// the 16 fragments (4 output tiles x 4 q) of one k-tile, taken from the ring
+__device__ __forceinline__ void tr_ring_block(WRing<DAL3_PF>& ring, const f32x16 (&X)[TR_T], f32x16 (&acc)[TR_T][TR_MTB]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        ring_batch_wait<DAL3_PF>(ring, i);
+        const f32x4 w = ring.slot[i % DAL3_PF];
+        ring.slot[i % DAL3_PF] = *ring.next;
+        ring.next += 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int j = 0; j < TR_T; ++j) acc[j][i / 4] = mfma32(w[e], X[j][4 * (i % 4) + e], acc[j][i / 4]);
+        }
+        DAL3_SCHED_FENCE();
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void tr_linear_ring_kernel(const float* __restrict__ a, int64_t M, int c_in, int64_t lda,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int relu_in,
+                                                                const f32x4* __restrict__ wpk, const float* __restrict__ bias,
+                                                                int64_t seg, int c_out, float* __restrict__ z, int64_t ldz,
+                                                                int accumulate, int n_mblk) {
+    static_assert(TR_MTB == 4 && DAL3_PF == 8, "fragment order of tr_pack_kernel");
+    const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int mblk = (int)(unit % n_mblk);
+    const int64_t pt0 = (unit / n_mblk) * (32 * TR_T);
+    if (pt0 >= M) return;
+    const int mt0 = mblk * TR_MTB;
+    const int KT = c_in / 32;
+    int64_t prow[TR_T];
+#pragma unroll
+    for (int j = 0; j < TR_T; ++j) prow[j] = min(pt0 + 32 * j, M - 32) + m;
+    WRing<DAL3_PF> ring;
+    ring.init(wpk + (int64_t)mblk * KT * 16 * 64, lane);
+    f32x16 acc[TR_T][TR_MTB];
+#pragma unroll
+    for (int j = 0; j < TR_T; ++j) {
+#pragma unroll
+        for (int t = 0; t < TR_MTB; ++t) {
+            if (bias) {
+                const float* bp = bias + (seg > 0 ? (prow[j] / seg) * c_out : 0) + 32 * (mt0 + t);
+                acc[j][t] = tile_from_channels(bp, h);
+            } else {
+                acc[j][t] = f32x16{};
+            }
+        }
+    }
+    f32x16 Xa[TR_T], Xb[TR_T];
+    tr_load_x(Xa, 0, a, lda, prow, scale, shift, relu_in, h);
+    for (int kt = 0; kt < KT; kt += 2) {
+        tr_load_x(Xb, min(kt + 1, KT - 1), a, lda, prow, scale, shift, relu_in, h);
+        DAL3_SCHED_FENCE();
+        tr_ring_block(ring, Xa, acc);
+        tr_load_x(Xa, min(kt + 2, KT - 1), a, lda, prow, scale, shift, relu_in, h);
+        DAL3_SCHED_FENCE();
+        if (kt + 1 < KT) tr_ring_block(ring, Xb, acc);
+    }
+#pragma unroll
+    for (int j = 0; j < TR_T; ++j) {
+        if (pt0 + 32 * j >= M) break;
+        float* zp = z + (pt0 + 32 * j + m) * ldz + 4 * h;
+#pragma unroll
+        for (int t = 0; t < TR_MTB; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4* dst = reinterpret_cast<f32x4*>(zp + 32 * (mt0 + t) + 8 * q);
+                f32x4 o = {acc[j][t][4 * q], acc[j][t][4 * q + 1], acc[j][t][4 * q + 2], acc[j][t][4 * q + 3]};
+                if (accumulate) {
+                    const f32x4 old = *dst;
+                    o[0] += old[0];
+                    o[1] += old[1];
+                    o[2] += old[2];
+                    o[3] += old[3];
+                }
+                *dst = o;
+            }
+        }
+    }
+}
+
+size_t tr_linear_workspace_bytes(int c_in, int c_out) {
+    return c_out % 128 == 0 ? (size_t)c_out * c_in * sizeof(float) + DAL3_PF * 1024 : 0;
+}
+
 hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                             int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
-                            int c_out, float* z, int64_t ldz, int accumulate, hipStream_t s) {
+                            int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s) {
     const int n_mblk = (c_out / 32 + TR_MTB - 1) / TR_MTB;
     const int64_t units = ((M + 32 * TR_T - 1) / (32 * TR_T)) * n_mblk;
+    if (ws && c_out % 128 == 0) {
+        const int64_t n = (int64_t)c_out * c_in;
+        hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, transpose_w, c_out, c_in,
+                           ws);
+        hipLaunchKernelGGL(tr_linear_ring_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda, scale,
+                           shift, relu_in, reinterpret_cast<const f32x4*>(ws), bias, seg, c_out, z, ldz, accumulate, n_mblk);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(tr_linear_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda, scale, shift,
                        relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz, accumulate, n_mblk);
     return hipGetLastError();
@@ -299,6 +436,59 @@ hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int m
     hipLaunchKernelGGL(tr_colred_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, s, z, M, C, ldz, mode, src, scale, shift, mu,
                        rstd, part);
     hipLaunchKernelGGL(tr_colred_final_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, nb, C, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- per-channel epilogues
+// One launch instead of a dozen tiny framework ops per layer (the step is otherwise host-bound at these sizes).
+// Forward: batch mean / biased variance from the float64 sums, the folded affine (scale = gamma*rstd, shift = beta -
+// mean*scale), and the running statistics' update (momentum, unbiased variance) exactly as torch's BatchNorm1d does.
+__global__ void tr_bn_finalize_kernel(const double* __restrict__ sums, int C, int64_t M, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float* __restrict__ running_mean,
+                                      float* __restrict__ running_var, float momentum, float eps, float* __restrict__ mu,
+                                      float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / (double)M;
+    double var = sums[C + c] / (double)M - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rs = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[c] * rs;
+    mu[c] = (float)mean;
+    rstd[c] = (float)rs;
+    scale[c] = (float)sc;
+    shift[c] = (float)((double)beta[c] - mean * sc);
+    if (running_mean) {
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * ((double)M / (double)(M - 1)));
+    }
+}
+
+// Backward: dbeta = sum dy, dgamma = sum dy*xhat, and the three coefficients of dz = k1*(dy - k2 - xhat*k3).
+__global__ void tr_bnbwd_coef_kernel(const double* __restrict__ sums, int C, int64_t M, const float* __restrict__ gamma,
+                                     const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)sums[c];
+    dgamma[c] = (float)sums[C + c];
+    k1[c] = gamma[c] * rstd[c];
+    k2[c] = (float)(sums[c] / (double)M);
+    k3[c] = (float)(sums[C + c] / (double)M);
+}
+
+hipError_t launch_tr_bn_finalize(const double* sums, int C, int64_t M, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
+                                 float* scale, float* shift, hipStream_t s) {
+    hipLaunchKernelGGL(tr_bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, sums, C, M, gamma, beta, running_mean,
+                       running_var, momentum, eps, mu, rstd, scale, shift);
+    return hipGetLastError();
+}
+
+hipError_t launch_tr_bnbwd_coef(const double* sums, int C, int64_t M, const float* gamma, const float* rstd, float* dgamma,
+                                float* dbeta, float* k1, float* k2, float* k3, hipStream_t s) {
+    hipLaunchKernelGGL(tr_bnbwd_coef_kernel, dim3((C + 127) / 128), dim3(128), 0, s, sums, C, M, gamma, rstd, dgamma, dbeta, k1,
+                       k2, k3);
     return hipGetLastError();
 }
 

@@ -196,10 +196,26 @@ class StaticModelTwoBoxEst(_StaticBase):
 
 
 # ---------------------------------------------------------------------- train mode (stock torch)
-def _mask_and_gather(pts, logits, n_obj, n_ch):
-    """point_cloud_masking + gather_object_pts (static_model.py:23-62) with the reference's NumPy
-    draws; index bookkeeping on the host, the gather itself on the tensor's device."""
+def _mask_and_gather(pts, logits, n_obj, n_ch, model=None):
+    """point_cloud_masking + gather_object_pts (static_model.py:23-62). Default: the reference's NumPy draws — index
+    bookkeeping on the host (one device->host sync and a Python iteration per sample), the gather itself on the
+    tensor's device. With model.sampler == "device" on the GPU: the eval path's compaction + sampling kernel
+    (dal3_mask_compact_sample), no host round trip; the sampled points carry no gradient either way."""
     mask = logits[:, :, 0] < logits[:, :, 1]
+    if model is not None and getattr(model, "sampler", "numpy") == "device" and pts.is_cuda:
+        lib = _hip.lib()
+        B, _, N = pts.shape
+        p32 = as_f32(pts.detach(), "pts")
+        m8 = mask.to(torch.uint8).contiguous()
+        counts = torch.empty((B,), dtype=torch.int32, device=pts.device)
+        idx = torch.empty((B, n_obj), dtype=torch.int32, device=pts.device)
+        obj = torch.empty((B, n_obj, n_ch), dtype=torch.float32, device=pts.device)
+        need = lib.dal3_gather_workspace_bytes(B, N)
+        ws = torch.empty(max(int(need), 8), dtype=torch.uint8, device=pts.device)
+        _hip.check(lib.dal3_mask_compact_sample(_hip.ptr(m8), _hip.bcn(p32), B, N, n_ch, n_obj, _hip.SAMPLER_DEVICE, None,
+                                                model.seed, model.item_offset, _hip.ptr(counts), _hip.ptr(idx),
+                                                _hip.ptr(obj), _hip.ptr(ws), ws.numel(), _hip.stream()))
+        return obj.transpose(2, 1), mask
     counts = mask.sum(1).cpu().numpy()
     choice = numpy_choice(counts, n_obj)
     obj = torch.zeros((pts.shape[0], n_ch, n_obj), dtype=torch.float32, device=pts.device)
@@ -243,7 +259,7 @@ def _box_pred(m, head, obj):
 
 def _train_forward_one(m, pts, init_box):
     logits = _seg_logits(m, pts)
-    obj, mask = _mask_and_gather(pts, logits, NUM_OBJECT_POINT, 3)
+    obj, mask = _mask_and_gather(pts, logits, NUM_OBJECT_POINT, 3, m)
     c, hs, hrn, hr, ss, srn, sr = _parse(_box_pred(m, m.box_est, obj))
     return {"logits": logits, "mask": mask, "center_boxnet": c, "heading_scores": hs,
             "heading_residuals_normalized": hrn, "heading_residuals": hr, "size_scores": ss,
@@ -252,7 +268,7 @@ def _train_forward_one(m, pts, init_box):
 
 def _train_forward_two(m, pts, init_box, bbox_gt):
     logits = _seg_logits(m, pts)
-    obj, mask = _mask_and_gather(pts, logits, NUM_OBJECT_POINT, 3)
+    obj, mask = _mask_and_gather(pts, logits, NUM_OBJECT_POINT, 3, m)
     c1, hs1, hrn1, hr1, ss1, srn1, sr1 = _parse(_box_pred(m, m.box_est_one, obj))
     c1 = c1 + init_box[:, :3]
     with torch.no_grad():

@@ -25,8 +25,18 @@ _EPS = 1e-5
 _MOM = 0.1
 
 
+_SCRATCH = {}
+
+
 def _ws(nbytes, dev):
-    return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=dev)
+    """grow-only scratch per device. Every user enqueues on the current stream and is done with the buffer when its
+    last kernel has run, so consecutive calls can share it (stream order); a per-call torch.empty costs more host
+    time than the small kernels it serves."""
+    buf = _SCRATCH.get(dev)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
+        _SCRATCH[dev] = buf
+    return buf
 
 
 def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False, out=None, accumulate=False):
@@ -34,32 +44,38 @@ def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False,
     M = a.shape[0]
     z = out if out is not None else torch.empty((M, c_out), dtype=torch.float32, device=a.device)
     sc, sh, relu = (act if act is not None else (None, None, False))
-    _hip.check(_hip.lib().dal3_tr_linear(_hip.ptr(a), M, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu),
-                                         _hip.ptr(W), ldw, int(transpose), _hip.ptr(bias), seg, c_out, _hip.ptr(z),
-                                         z.stride(0), int(accumulate), _hip.stream()))
+    lib = _hip.lib()
+    need = lib.dal3_tr_linear_workspace_bytes(c_in, c_out)
+    ws = _ws(need, a.device) if need else None
+    _hip.check(lib.dal3_tr_linear(_hip.ptr(a), M, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu), _hip.ptr(W), ldw,
+                                  int(transpose), _hip.ptr(bias), seg, c_out, _hip.ptr(z), z.stride(0), int(accumulate),
+                                  _hip.ptr(ws), need, _hip.stream()))
     return z
 
 
 def _colred(z, mode, da=None, dg=None, arg=None, seg=0, bn=None):
+    """float64 column sums (2*C,) on the device: see dal3_tr_colred"""
     M, C = z.shape
     lib = _hip.lib()
-    ws = _ws(lib.dal3_tr_colred_workspace_bytes(M, C), z.device)
+    need = lib.dal3_tr_colred_workspace_bytes(M, C)
+    ws = _ws(need, z.device)
     out = torch.empty(2 * C, dtype=torch.float64, device=z.device)
     sc, sh, mu, rstd = bn if bn is not None else (None, None, None, None)
     _hip.check(lib.dal3_tr_colred(_hip.ptr(z), M, C, z.stride(0), mode, _hip.ptr(da), da.stride(0) if da is not None else 0,
                                   _hip.ptr(dg), _hip.ptr(arg), seg, _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(mu), _hip.ptr(rstd),
-                                  _hip.ptr(ws), ws.numel(), _hip.ptr(out), _hip.stream()))
-    return out[:C], out[C:]
+                                  _hip.ptr(ws), need, _hip.ptr(out), _hip.stream()))
+    return out
 
 
 def _wgrad(dz, a, c_out, c_in, act=None):
     M = dz.shape[0]
     lib = _hip.lib()
-    ws = _ws(lib.dal3_tr_wgrad_workspace_bytes(M, c_out, c_in), dz.device)
+    need = lib.dal3_tr_wgrad_workspace_bytes(M, c_out, c_in)
+    ws = _ws(need, dz.device)
     dW = torch.empty((c_out, c_in), dtype=torch.float32, device=dz.device)
     sc, sh, relu = (act if act is not None else (None, None, False))
     _hip.check(lib.dal3_tr_wgrad(_hip.ptr(dz), dz.stride(0), _hip.ptr(a), a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu),
-                                 M, c_out, c_in, _hip.ptr(ws), ws.numel(), _hip.ptr(dW), _hip.stream()))
+                                 M, c_out, c_in, _hip.ptr(ws), need, _hip.ptr(dW), _hip.stream()))
     return dW
 
 
@@ -67,19 +83,15 @@ class _BN:
     """batch statistics of one layer's pre-BN output and everything derived from them"""
 
     def __init__(self, z, gamma, beta, running_mean, running_var):
-        M = z.shape[0]
-        s0, s1 = _colred(z, 0)
-        mean = s0 / M
-        var = (s1 / M - mean * mean).clamp_(min=0.0)                    # biased, float64
-        self.mu = mean.float()
-        self.rstd = torch.rsqrt(var + _EPS).float()
-        self.scale = (gamma.double() * torch.rsqrt(var + _EPS)).float()
-        self.shift = (beta.double() - mean * gamma.double() * torch.rsqrt(var + _EPS)).float()
-        if running_mean is not None:
-            with torch.no_grad():
-                running_mean.mul_(1 - _MOM).add_(self.mu, alpha=_MOM)
-                running_var.mul_(1 - _MOM).add_((var * (M / (M - 1))).float(), alpha=_MOM)
-        self.gamma = gamma
+        M, C = z.shape
+        sums = _colred(z, 0)
+        st = torch.empty((4, C), dtype=torch.float32, device=z.device)
+        self.mu, self.rstd, self.scale, self.shift = st[0], st[1], st[2], st[3]
+        self.gamma = gamma.contiguous()
+        _hip.check(_hip.lib().dal3_tr_bn_finalize(_hip.ptr(sums), C, M, _hip.ptr(self.gamma), _hip.ptr(beta.contiguous()),
+                                                  _hip.ptr(running_mean), _hip.ptr(running_var), _MOM, _EPS, _hip.ptr(self.mu),
+                                                  _hip.ptr(self.rstd), _hip.ptr(self.scale), _hip.ptr(self.shift),
+                                                  _hip.stream()))
         self.M = M
 
     @property
@@ -88,19 +100,18 @@ class _BN:
 
     def backward(self, z, da=None, dg=None, arg=None, seg=0):
         """(dz, dgamma, dbeta) from the gradient w.r.t. relu(bn(z))"""
-        bn = (self.scale, self.shift, self.mu, self.rstd)
-        dbeta, dgamma = _colred(z, 1, da=da, dg=dg, arg=arg, seg=seg, bn=bn)
-        k1 = (self.gamma * self.rstd).float().contiguous()
-        k2 = (dbeta / self.M).float()
-        k3 = (dgamma / self.M).float()
-        dz = torch.empty_like(z)
         M, C = z.shape
-        _hip.check(_hip.lib().dal3_tr_bnbwd_apply(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(da),
-                                                  da.stride(0) if da is not None else 0, _hip.ptr(dg), _hip.ptr(arg), seg,
-                                                  _hip.ptr(self.scale), _hip.ptr(self.shift), _hip.ptr(self.mu),
-                                                  _hip.ptr(self.rstd), _hip.ptr(k1), _hip.ptr(k2), _hip.ptr(k3), _hip.ptr(dz),
-                                                  dz.stride(0), _hip.stream()))
-        return dz, dgamma.float(), dbeta.float()
+        lib = _hip.lib()
+        sums = _colred(z, 1, da=da, dg=dg, arg=arg, seg=seg, bn=(self.scale, self.shift, self.mu, self.rstd))
+        co = torch.empty((5, C), dtype=torch.float32, device=z.device)      # dgamma, dbeta, k1, k2, k3
+        _hip.check(lib.dal3_tr_bnbwd_coef(_hip.ptr(sums), C, M, _hip.ptr(self.gamma), _hip.ptr(self.rstd), _hip.ptr(co[0]),
+                                          _hip.ptr(co[1]), _hip.ptr(co[2]), _hip.ptr(co[3]), _hip.ptr(co[4]), _hip.stream()))
+        dz = torch.empty_like(z)
+        _hip.check(lib.dal3_tr_bnbwd_apply(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(da), da.stride(0) if da is not None else 0,
+                                           _hip.ptr(dg), _hip.ptr(arg), seg, _hip.ptr(self.scale), _hip.ptr(self.shift),
+                                           _hip.ptr(self.mu), _hip.ptr(self.rstd), _hip.ptr(co[2]), _hip.ptr(co[3]),
+                                           _hip.ptr(co[4]), _hip.ptr(dz), dz.stride(0), _hip.stream()))
+        return dz, co[0], co[1]
 
 
 def _segmax(z, bn, seg):

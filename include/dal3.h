@@ -277,12 +277,21 @@ int dal3_crop_fill(const float* points, const int64_t* point_offsets, const doub
  * dal3_tr_segsum   out[s][c] = sum of x[p][c] over segment s. */
 int dal3_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift, int relu_in,
                    const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg, int c_out, float* z,
-                   int64_t ldz, int accumulate, dal3_stream stream);
+                   int64_t ldz, int accumulate, void* workspace, size_t workspace_bytes, dal3_stream stream);
+size_t dal3_tr_linear_workspace_bytes(int c_in, int c_out);   /* 0 when the layer needs none (c_out % 128 != 0) */
 size_t dal3_tr_colred_workspace_bytes(int64_t M, int C);
 int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                    const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                    const float* mu, const float* rstd, void* workspace, size_t workspace_bytes, double* out,
                    dal3_stream stream);
+/* per-channel epilogues of the two reductions, one launch each: batch mean / biased variance -> mu, rstd, the folded
+ * affine scale = gamma*rstd, shift = beta - mu*scale, and torch's running-statistics update (unbiased variance,
+ * `momentum`; running_* may both be NULL); backward sums -> dgamma, dbeta and k1..k3 of dal3_tr_bnbwd_apply. */
+int dal3_tr_bn_finalize(const double* sums, int C, int64_t M, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float momentum, float eps, float* mu, float* rstd, float* scale,
+                        float* shift, dal3_stream stream);
+int dal3_tr_bnbwd_coef(const double* sums, int C, int64_t M, const float* gamma, const float* rstd, float* dgamma,
+                       float* dbeta, float* k1, float* k2, float* k3, dal3_stream stream);
 int dal3_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda, const float* dg,
                         const int32_t* arg, int64_t seg, const float* scale, const float* shift, const float* mu,
                         const float* rstd, const float* k1, const float* k2, const float* k3, float* dz, int64_t lddz,

@@ -220,7 +220,7 @@ def test_training_kernels_reject_bad_shapes():
     w = torch.zeros((32, 32), device="cuda")
     z = torch.zeros((64, 32), device="cuda")
     assert lib.dal3_tr_linear(hip.ptr(a), 60, 32, 32, None, None, 0, hip.ptr(w), 32, 0, None, 0, 32, hip.ptr(z), 32, 0,
-                              hip.stream()) != 0
+                              None, 0, hip.stream()) != 0
     assert "multiples of 32" in lib.dal3_last_error().decode()
     with pytest.raises(RuntimeError):
         train.point_stack_train_forward(build_model("static_one", synth.state_dict("static_one")).box_est.train(),
@@ -246,6 +246,7 @@ def test_whole_train_step_hip_backend_vs_torch_backend(kind):
     for backend in ("hip", "torch"):
         model = build_model(kind, synth.state_dict(kind, seed=24)).train()
         model.train_backend = backend
+        model.sampler = "numpy"                              # the reference's draws, identical for both backends
         model.ins_seg.dropout.p = 0.0
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
         if kind == "dynamic":
@@ -275,3 +276,27 @@ def test_whole_train_step_hip_backend_vs_torch_backend(kind):
         assert float((gh - gt).norm()) <= 2e-2 * float(gt.norm()) + 1e-6 * scale, k
     for k, pt in out["torch"][2].items():
         assert float((out["hip"][2][k] - pt).abs().max()) <= 2.5e-3, k        # Adam moves every weight by <= lr (+ decay)
+
+
+def test_train_mode_with_the_device_sampler_needs_no_host_round_trip():
+    """model.sampler == "device" (the default) also picks the object points of the TRAIN-mode forward on the GPU:
+    same mask, every sampled point is a segmented point of its crop, gradients flow, and the step is deterministic"""
+    losses = importlib.import_module("3dal_pytorch_amd.losses")
+    B, N = 4, 1024
+    p, i, g = synth.static_crops(B, N, seed=26)
+    args = (torch.from_numpy(p).cuda().transpose(2, 1), torch.from_numpy(i).cuda(), torch.from_numpy(g).cuda())
+    runs = []
+    for _ in range(2):
+        model = build_model("static_one", synth.state_dict("static_one", seed=26)).train()
+        model.ins_seg.dropout.p = 0.0
+        assert model.sampler == "device"
+        o = model(*args)
+        loss = losses.FrustumPointNetLossOneBoxEst()(o, *_labels_for(B, N, 27, "cuda"))["total_loss"]
+        loss.backward()
+        runs.append((float(loss.detach()), model.box_est.conv1.weight.grad.clone(), o["mask"].clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    assert float(runs[0][1].abs().max()) > 0 and bool(torch.isfinite(runs[0][1]).all())
+    ref = build_model("static_one", synth.state_dict("static_one", seed=26)).train()
+    ref.sampler, ref.ins_seg.dropout.p = "numpy", 0.0
+    np.random.seed(1)
+    assert torch.equal(ref(*args)["mask"], runs[0][2])

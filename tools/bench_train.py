@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--backends", default="hip,torch")
+    ap.add_argument("--sampler", default="numpy", choices=["numpy", "device"],
+                    help="object-point sampling in the train-mode forward: the reference's host loop or the GPU kernel")
     args = ap.parse_args()
     B, N = args.batch, args.points
     dev = torch.device("cuda", 0)
@@ -38,7 +40,8 @@ def main():
               torch.randint(0, 12, (B,), device=dev), 0.1 * torch.randn((B,), device=dev),
               torch.randint(0, 3, (B,), device=dev), 0.3 * torch.randn((B, 3), device=dev))
     crit = losses.FrustumPointNetLossOneBoxEst()
-    out = {"workload": f"StaticModelOneBoxEst train step, {B} crops x {N} pts, fp32, Adam", "unit": "ms per step"}
+    out = {"workload": f"StaticModelOneBoxEst train step, {B} crops x {N} pts, fp32, Adam, {args.sampler} sampler",
+           "unit": "ms per step"}
     # algorithmic FLOP of the per-point stacks: forward + dgrad + wgrad = 3x forward (nominal formulation)
     mac_pt = sum(ci * co for _, _, ci, co in arch.ins_seg_layers(3)) - 1024 * 512      # per-crop part of dconv1 excluded
     mac_obj = sum(ci * co for _, _, ci, co in arch.STATIC_BOX_EST["convs"])
@@ -48,6 +51,7 @@ def main():
         model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict("static_one").items()})
         model = model.to(dev).train()
         model.train_backend = backend
+        model.sampler = args.sampler
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
 
         def step():
