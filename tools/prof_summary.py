@@ -26,7 +26,7 @@ def short(name):
     return name.split("(")[0].replace("void ", "").split("<")[0]
 
 
-stats = glob.glob(os.path.join(src, "prof_kt", "*", "*_kernel_stats.csv"))
+stats = glob.glob(os.path.join(src, "prof_kt", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
@@ -39,7 +39,7 @@ if stats:
 
 pmc = defaultdict(lambda: defaultdict(list))
 for d in ("prof_fetch", "prof_write", "prof_mfma"):
-    for fn in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
+    for fn in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(fn)):
             k = short(r["Kernel_Name"])
             if not any(o in k for o in OURS):
