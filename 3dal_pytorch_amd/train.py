@@ -29,13 +29,14 @@ _SCRATCH = {}
 
 
 def _ws(nbytes, dev):
-    """grow-only scratch per device. Every user enqueues on the current stream and is done with the buffer when its
+    """grow-only scratch per (device, stream). Every user enqueues on the current stream and is done with the buffer when its
     last kernel has run, so consecutive calls can share it (stream order); a per-call torch.empty costs more host
     time than the small kernels it serves."""
-    buf = _SCRATCH.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)       # one buffer per stream: stream order is the only fence
+    buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
-        _SCRATCH[dev] = buf
+        _SCRATCH[key] = buf
     return buf
 
 
