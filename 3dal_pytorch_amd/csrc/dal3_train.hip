@@ -20,6 +20,7 @@
 
 #define TR_T 2                          // point tiles (32 points each) per wave in the linear kernel
 #define TR_MTB 4                        // output tiles (32 channels each) per wave: 4*2*16 = 128 accumulator registers
+#define TR_MAX_ACT_CIN 1024              // most input channels of a layer whose input carries an activation
 
 // ---------------------------------------------------------------------------------------------- linear
 // z[p][co] (+)= sum_ci act(a[p][ci]) * Wop[co][ci] + bias
@@ -35,30 +36,31 @@
 // first use; the sched_barrier between "load next" and "compute current" keeps them apart).
 struct TrStage {
     f32x16 X[TR_T];
+    f32x4 sc[4], sh[4];                 // the k-tile's per-channel affine for this lane's channel groups
     f32x4 Wf[TR_MTB][4];
 };
 
+// Loads only. The activation (affine + ReLU) is applied by tr_act_stage right before the stage is consumed: doing
+// it here would make the wave wait for the data it has just requested, i.e. expose the full load latency per k-tile.
 __device__ __forceinline__ void tr_load_stage(TrStage& st, int kt, const float* __restrict__ a, int64_t lda,
                                               const int64_t (&prow)[TR_T], const float* __restrict__ scale,
-                                              const float* __restrict__ shift, int relu_in, const float* __restrict__ W,
+                                              const float* __restrict__ shift, const float* __restrict__ W,
                                               int64_t ldw, int transpose_w, int mt0, int n_mt, int h, int m) {
 #pragma unroll
     for (int j = 0; j < TR_T; ++j) {
         const float* ap = a + prow[j] * lda + 32 * kt + 4 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(ap + 8 * q);
-            if (scale) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 32 * kt + 8 * q + 4 * h);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + 32 * kt + 8 * q + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = v[e] * sc[e] + sh[e];
-                    if (relu_in) v[e] = fmaxf(v[e], 0.0f);
-                }
-            }
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 8 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) st.X[j][4 * q + e] = v[e];
+        }
+    }
+    if (scale) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            st.sc[q] = *reinterpret_cast<const f32x4*>(scale + 32 * kt + 8 * q + 4 * h);
+            st.sh[q] = *reinterpret_cast<const f32x4*>(shift + 32 * kt + 8 * q + 4 * h);
         }
     }
 #pragma unroll
@@ -76,6 +78,17 @@ __device__ __forceinline__ void tr_load_stage(TrStage& st, int kt, const float* 
             }
         }
     }
+}
+
+__device__ __forceinline__ void tr_act(f32x16 (&X)[TR_T], const f32x4 (&sc)[4], const f32x4 (&sh)[4], bool act, int relu_in) {
+    if (!act) return;
+#pragma unroll
+    for (int j = 0; j < TR_T; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = X[j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3];
+            X[j][r] = relu_in ? fmaxf(v, 0.0f) : v;
+        }
 }
 
 __device__ __forceinline__ void tr_compute_stage(const TrStage& st, f32x16 (&acc)[TR_T][TR_MTB], int n_mt) {
@@ -127,15 +140,19 @@ __global__ __launch_bounds__(256) void tr_linear_kernel(const float* __restrict_
     // ping-pong over the k-tiles; the k index of a load past the end is clamped (valid memory, values unused) so that
     // no load sits behind a data-dependent branch, and only the matching compute is skipped
     TrStage s0, s1;
-    tr_load_stage(s0, 0, a, lda, prow, scale, shift, relu_in, W, ldw, transpose_w, mt0, n_mt, h, m);
+    tr_load_stage(s0, 0, a, lda, prow, scale, shift, W, ldw, transpose_w, mt0, n_mt, h, m);
     for (int kt = 0; kt < KT; kt += 2) {
-        tr_load_stage(s1, min(kt + 1, KT - 1), a, lda, prow, scale, shift, relu_in, W, ldw, transpose_w, mt0, n_mt, h, m);
+        tr_load_stage(s1, min(kt + 1, KT - 1), a, lda, prow, scale, shift, W, ldw, transpose_w, mt0, n_mt, h, m);
         DAL3_SCHED_FENCE();
+        tr_act(s0.X, s0.sc, s0.sh, scale != nullptr, relu_in);
         tr_compute_stage(s0, acc, n_mt);
         DAL3_SCHED_FENCE();
-        tr_load_stage(s0, min(kt + 2, KT - 1), a, lda, prow, scale, shift, relu_in, W, ldw, transpose_w, mt0, n_mt, h, m);
+        tr_load_stage(s0, min(kt + 2, KT - 1), a, lda, prow, scale, shift, W, ldw, transpose_w, mt0, n_mt, h, m);
         DAL3_SCHED_FENCE();
-        if (kt + 1 < KT) tr_compute_stage(s1, acc, n_mt);
+        if (kt + 1 < KT) {
+            tr_act(s1.X, s1.sc, s1.sh, scale != nullptr, relu_in);
+            tr_compute_stage(s1, acc, n_mt);
+        }
         DAL3_SCHED_FENCE();
     }
 #pragma unroll
@@ -181,26 +198,38 @@ __global__ void tr_pack_kernel(const float* __restrict__ W, int64_t ldw, int tra
     out[i] = transpose_w ? W[(int64_t)col * ldw + row] : W[(int64_t)row * ldw + col];
 }
 
-__device__ __forceinline__ void tr_load_x(f32x16 (&X)[TR_T], int kt, const float* __restrict__ a, int64_t lda,
-                                          const int64_t (&prow)[TR_T], const float* __restrict__ scale,
-                                          const float* __restrict__ shift, int relu_in, int h) {
+struct TrX {
+    f32x16 X[TR_T];
+};
+
+// y = max(x*scale + shift, 0) with the per-channel affine read from LDS (copied there once per workgroup): keeping
+// it in registers from load to use costs 32 VGPRs per stage and pushed the kernel into scratch
+__device__ __forceinline__ void tr_act_lds(f32x16 (&X)[TR_T], const float* __restrict__ s_sc, const float* __restrict__ s_sh,
+                                           int kt, int h, int relu_in) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc + 32 * kt + 8 * q + 4 * h);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(s_sh + 32 * kt + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < TR_T; ++j) {
+                const float v = X[j][4 * q + e] * sc[e] + sh[e];
+                X[j][4 * q + e] = relu_in ? fmaxf(v, 0.0f) : v;
+            }
+    }
+}
+
+__device__ __forceinline__ void tr_load_x(TrX& st, int kt, const float* __restrict__ a, int64_t lda,
+                                          const int64_t (&prow)[TR_T], int h) {
 #pragma unroll
     for (int j = 0; j < TR_T; ++j) {
         const float* ap = a + prow[j] * lda + 32 * kt + 4 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(ap + 8 * q);
-            if (scale) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 32 * kt + 8 * q + 4 * h);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + 32 * kt + 8 * q + 4 * h);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 8 * q);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = v[e] * sc[e] + sh[e];
-                    if (relu_in) v[e] = fmaxf(v[e], 0.0f);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) X[j][4 * q + e] = v[e];
+            for (int e = 0; e < 4; ++e) st.X[j][4 * q + e] = v[e];
         }
     }
 }
@@ -229,6 +258,15 @@ __global__ __launch_bounds__(256, 2) void tr_linear_ring_kernel(const float* __r
                                                                 int64_t seg, int c_out, float* __restrict__ z, int64_t ldz,
                                                                 int accumulate, int n_mblk) {
     static_assert(TR_MTB == 4 && DAL3_PF == 8, "fragment order of tr_pack_kernel");
+    __shared__ float s_sc[TR_MAX_ACT_CIN], s_sh[TR_MAX_ACT_CIN];
+    const bool act = scale != nullptr;
+    if (act) {
+        for (int i = threadIdx.x; i < c_in; i += 256) {
+            s_sc[i] = scale[i];
+            s_sh[i] = shift[i];
+        }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
     const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int mblk = (int)(unit % n_mblk);
@@ -254,15 +292,19 @@ __global__ __launch_bounds__(256, 2) void tr_linear_ring_kernel(const float* __r
             }
         }
     }
-    f32x16 Xa[TR_T], Xb[TR_T];
-    tr_load_x(Xa, 0, a, lda, prow, scale, shift, relu_in, h);
+    TrX xa, xb;                                              // raw loads one k-tile ahead; activation applied at use
+    tr_load_x(xa, 0, a, lda, prow, h);
     for (int kt = 0; kt < KT; kt += 2) {
-        tr_load_x(Xb, min(kt + 1, KT - 1), a, lda, prow, scale, shift, relu_in, h);
+        tr_load_x(xb, min(kt + 1, KT - 1), a, lda, prow, h);
         DAL3_SCHED_FENCE();
-        tr_ring_block(ring, Xa, acc);
-        tr_load_x(Xa, min(kt + 2, KT - 1), a, lda, prow, scale, shift, relu_in, h);
+        if (act) tr_act_lds(xa.X, s_sc, s_sh, kt, h, relu_in);
+        tr_ring_block(ring, xa.X, acc);
+        tr_load_x(xa, min(kt + 2, KT - 1), a, lda, prow, h);
         DAL3_SCHED_FENCE();
-        if (kt + 1 < KT) tr_ring_block(ring, Xb, acc);
+        if (kt + 1 < KT) {
+            if (act) tr_act_lds(xb.X, s_sc, s_sh, kt + 1, h, relu_in);
+            tr_ring_block(ring, xb.X, acc);
+        }
     }
 #pragma unroll
     for (int j = 0; j < TR_T; ++j) {
@@ -296,7 +338,7 @@ hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, co
                             int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s) {
     const int n_mblk = (c_out / 32 + TR_MTB - 1) / TR_MTB;
     const int64_t units = ((M + 32 * TR_T - 1) / (32 * TR_T)) * n_mblk;
-    if (ws && c_out % 128 == 0) {
+    if (ws && c_out % 128 == 0 && (!scale || c_in <= TR_MAX_ACT_CIN)) {
         const int64_t n = (int64_t)c_out * c_in;
         hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, transpose_w, c_out, c_in,
                            ws);
@@ -558,8 +600,7 @@ struct WgBlock {
 // pa / pb point at this lane's element of the block's first point row: dz[(p0 + h)][32*mt0 + m], a[(p0 + h)][32*kt0 + m];
 // the tiles of the block are 32 floats apart (an immediate offset), successive k-steps two rows apart.
 __device__ __forceinline__ void wg_load(WgBlock& bk, const float* __restrict__ pa, int64_t lddz, const float* __restrict__ pb,
-                                        int64_t lda, int n_mt, int n_kt, const float (&sc)[WG_KT], const float (&sh)[WG_KT],
-                                        bool act, int relu_in) {
+                                        int64_t lda, int n_mt, int n_kt) {
 #pragma unroll
     for (int s = 0; s < WG_KS; ++s) {
         const float* ra = pa + 2 * s * lddz;
@@ -567,18 +608,21 @@ __device__ __forceinline__ void wg_load(WgBlock& bk, const float* __restrict__ p
 #pragma unroll
         for (int t = 0; t < WG_MT; ++t) bk.av[s][t] = t < n_mt ? ra[32 * t] : 0.0f;
 #pragma unroll
-        for (int k = 0; k < WG_KT; ++k) {
-            float v = k < n_kt ? rb[32 * k] : 0.0f;
-            if (act) {
-                v = v * sc[k] + sh[k];
-                if (relu_in) v = fmaxf(v, 0.0f);
-            }
-            bk.bv[s][k] = v;
-        }
+        for (int k = 0; k < WG_KT; ++k) bk.bv[s][k] = k < n_kt ? rb[32 * k] : 0.0f;   // raw; activation at use
     }
 }
 
-__device__ __forceinline__ void wg_compute(const WgBlock& bk, f32x16 (&acc)[WG_MT][WG_KT]) {
+__device__ __forceinline__ void wg_compute(WgBlock& bk, f32x16 (&acc)[WG_MT][WG_KT], const float (&sc)[WG_KT],
+                                           const float (&sh)[WG_KT], bool act, int relu_in, int n_kt) {
+    if (act) {
+#pragma unroll
+        for (int s = 0; s < WG_KS; ++s)
+#pragma unroll
+            for (int k = 0; k < WG_KT; ++k) {
+                const float v = bk.bv[s][k] * sc[k] + sh[k];
+                bk.bv[s][k] = k < n_kt ? (relu_in ? fmaxf(v, 0.0f) : v) : 0.0f;
+            }
+    }
 #pragma unroll
     for (int s = 0; s < WG_KS; ++s)
 #pragma unroll
@@ -623,18 +667,18 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
     const int64_t n_blk = (p_end - p_begin) / (2 * WG_KS);
     const float* const pa0 = pa;
     const float* const pb0 = pb;
-    wg_load(b0, pa, lddz, pb, lda, n_mt, n_kt, sc, sh, act, relu_in);
+    wg_load(b0, pa, lddz, pb, lda, n_mt, n_kt);
     for (int64_t i = 0; i < n_blk; i += 2) {
-        wg_load(b1, pa + sa, lddz, pb + sb, lda, n_mt, n_kt, sc, sh, act, relu_in);
+        wg_load(b1, pa + sa, lddz, pb + sb, lda, n_mt, n_kt);
         DAL3_SCHED_FENCE();
-        wg_compute(b0, acc);
+        wg_compute(b0, acc, sc, sh, act, relu_in, n_kt);
         DAL3_SCHED_FENCE();
         const bool more = i + 2 < n_blk;
         pa = more ? pa + 2 * sa : pa0;
         pb = more ? pb + 2 * sb : pb0;
-        wg_load(b0, pa, lddz, pb, lda, n_mt, n_kt, sc, sh, act, relu_in);
+        wg_load(b0, pa, lddz, pb, lda, n_mt, n_kt);
         DAL3_SCHED_FENCE();
-        wg_compute(b1, acc);
+        wg_compute(b1, acc, sc, sh, act, relu_in, n_kt);
         DAL3_SCHED_FENCE();
     }
     // D tile: row (co) = tile_chan(r, h), col (ci) = lane & 31
@@ -659,8 +703,18 @@ __global__ __launch_bounds__(256) void tr_wgrad_final_kernel(const float* __rest
     const int el = threadIdx.x & 63, l = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + el;
     float s = 0.0f;
-    if (i < n)
-        for (int k = l; k < n_slices; k += 4) s += part[(int64_t)k * n + i];
+    if (i < n) {
+        float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;       // four independent chains: the loop is load-latency bound
+        int k = l;
+        for (; k + 12 < n_slices; k += 16) {
+            u0 += part[(int64_t)k * n + i];
+            u1 += part[(int64_t)(k + 4) * n + i];
+            u2 += part[(int64_t)(k + 8) * n + i];
+            u3 += part[(int64_t)(k + 12) * n + i];
+        }
+        for (; k < n_slices; k += 4) u0 += part[(int64_t)k * n + i];
+        s = (u0 + u1) + (u2 + u3);
+    }
     sm[l][el] = s;
     __syncthreads();
     if (l == 0 && i < n) dW[i] = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
@@ -766,7 +820,16 @@ __global__ __launch_bounds__(256) void tr_segsum_kernel(const float* __restrict_
     double acc = 0.0;
     if (c < C) {
         const float* xp = x + s * seg * ldx + c;
-        for (int64_t p = rl; p < seg; p += 4) acc += xp[p * ldx];
+        double u0 = 0, u1 = 0, u2 = 0, u3 = 0;              // independent chains against the load latency
+        int64_t p = rl;
+        for (; p + 12 < seg; p += 16) {
+            u0 += xp[p * ldx];
+            u1 += xp[(p + 4) * ldx];
+            u2 += xp[(p + 8) * ldx];
+            u3 += xp[(p + 12) * ldx];
+        }
+        for (; p < seg; p += 4) u0 += xp[p * ldx];
+        acc = (u0 + u1) + (u2 + u3);
     }
     sm[rl][cl] = acc;
     __syncthreads();
