@@ -108,7 +108,7 @@ def test_ins_seg_dynamic_vs_reference_golden():
     assert np.array_equal(mask[ok], g["mask"][ok])
 
 
-@pytest.mark.parametrize("n", [33, 96, 700, 1000, 4096])
+@pytest.mark.parametrize("n", [1, 5, 31, 33, 96, 700, 1000, 4096])
 def test_ins_seg_ragged_n_vs_oracle(n):
     B = 3
     pts_np, _, _ = synth.static_crops(B, n, seed=n)
@@ -410,3 +410,22 @@ def test_skipping_duplicate_object_points_is_exact():
     assert torch.equal(a["obj_idx"], b["obj_idx"])
     for k in ("bp1", "box_one", "bp2", "boxes7"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("n", [1, 7, 40])
+def test_whole_static_forward_on_tiny_crops_vs_oracle(n):
+    """crops with fewer points than one MFMA tile / than the 512 object points: the whole forward incl. sampling with
+    replacement and decode, teacher-forced on the oracle's draws"""
+    B = 3
+    pts_np, init_np, _ = synth.static_crops(B, n, seed=100 + n)
+    sd = synth.state_dict("static_one", seed=100 + n)
+    np.random.seed(9)
+    want = R.static_one_forward(R.as_torch_sd(sd), torch.from_numpy(pts_np).transpose(2, 1), torch.from_numpy(init_np))
+    model = build_model("static_one", sd)
+    model.sampler = "numpy"
+    np.random.seed(9)
+    got = model(dev(pts_np).transpose(2, 1), dev(init_np), None)
+    assert np.array_equal(got["mask"].cpu().numpy(), want["mask"].numpy())
+    assert rel_err(got["logits"].cpu().numpy(), want["logits"].numpy()) < TOL
+    for k in ("center", "heading_scores", "size_scores", "size_residuals"):
+        assert rel_err(got[k].cpu().numpy(), want[k].numpy()) < TOL, k
