@@ -229,6 +229,11 @@ def main():
     dev = torch.device("cuda", local)
     # DAL3_FORCE_DIST=1 runs the RCCL path even with one rank (exercises init + all-gather on a 1-GPU box)
     use_dist = world > 1 or os.environ.get("DAL3_FORCE_DIST") == "1"
+    # stdout carries exactly one JSON line. RCCL prints its version banner to the C-level stdout (and flushes it at
+    # exit), so while anything but that line can be written, file descriptor 1 points at stderr.
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -343,8 +348,11 @@ def main():
     if use_dist:
         fence()
         torch.distributed.destroy_process_group()
+    sys.stdout.flush()
+    C.CDLL(None).fflush(None)                                   # whatever C stdio still holds goes to stderr too
     if rank == 0:
-        print(json.dumps(rec), flush=True)
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":
