@@ -44,7 +44,8 @@ def extract_crops(sweeps, detections, veh_to_global, device="cuda", return_index
         raise ValueError("extract_crops: need the same non-zero number of sweeps, detection sets and poses")
     boxes = [waymo_boxes(np.asarray(d, dtype=np.float32).reshape(-1, np.asarray(d).shape[-1])) for d in detections]
     poses = [np.reshape(np.asarray(p, dtype=np.float64), [4, 4]) for p in veh_to_global]
-    planes = np.concatenate([geom.box_planes(b) for b in boxes])
+    all_boxes = np.concatenate(boxes) if boxes else np.zeros((0, 7), np.float32)
+    planes = geom.box_planes(all_boxes)                            # per-box arithmetic: one call for every frame
     n_pts = [int(s.shape[0]) for s in sweeps]
     n_box = [int(b.shape[0]) for b in boxes]
     K, max_pts = sum(n_box), max(n_pts)
@@ -53,7 +54,7 @@ def extract_crops(sweeps, detections, veh_to_global, device="cuda", return_index
     d_poff = torch.from_numpy(np.concatenate([[0], np.cumsum(n_pts)]).astype(np.int64)).to(dev)
     d_boff = torch.from_numpy(np.concatenate([[0], np.cumsum(n_box)]).astype(np.int64)).to(dev)
     d_planes = geom.planes_to_device(planes, dev)
-    d_sph = torch.from_numpy(np.ascontiguousarray(np.concatenate([geom.cull_spheres(b) for b in boxes]))).to(dev)
+    d_sph = torch.from_numpy(geom.cull_spheres(all_boxes)).to(dev)
     d_pose = torch.from_numpy(np.stack(poses).reshape(F, 16)).to(dev)
     lib = _hip.lib()
     ws = torch.empty(max(int(lib.dal3_crop_workspace_bytes(K, max_pts)), 4), dtype=torch.uint8, device=dev)
@@ -69,12 +70,15 @@ def extract_crops(sweeps, detections, veh_to_global, device="cuda", return_index
     _hip.check(lib.dal3_crop_fill(_hip.ptr(d_pts), _hip.ptr(d_poff), _hip.ptr(d_planes), _hip.ptr(d_sph), _hip.ptr(d_boff), F,
                                   K, max_pts, _hip.ptr(d_pose), _hip.ptr(counts), _hip.ptr(start), _hip.ptr(out),
                                   _hip.ptr(idx), _hip.ptr(ws), ws.numel(), _hip.stream()))
+    # one C++ split instead of a Python slice per detection (thousands of them per segment)
+    cuts = torch.from_numpy(h_start[1:-1].astype(np.int64))
+    views = torch.tensor_split(out[:total], cuts) if K > 0 else ()
+    iviews = torch.tensor_split(idx[:total], cuts) if (return_index and K > 0) else ()
     frames, k = [], 0
     for f in range(F):
-        rec = {"boxes_lidar": boxes[f], "bbox": transform_box(boxes[f], poses[f]),
-               "point": [out[h_start[k + i]:h_start[k + i + 1]] for i in range(n_box[f])]}
+        rec = {"boxes_lidar": boxes[f], "bbox": transform_box(boxes[f], poses[f]), "point": list(views[k:k + n_box[f]])}
         if return_index:
-            rec["index"] = [idx[h_start[k + i]:h_start[k + i + 1]] for i in range(n_box[f])]
+            rec["index"] = list(iviews[k:k + n_box[f]])
         frames.append(rec)
         k += n_box[f]
     return frames
