@@ -126,6 +126,13 @@ def _segmax(z, bn, seg):
     return g, arg
 
 
+def _gather_at(z, arg, seg):
+    """z[item*seg + arg[item,c], c] -> (items, C): the pre-BN value at each pooled point"""
+    n_seg, C = arg.shape
+    rows = arg.long() + torch.arange(n_seg, device=z.device)[:, None] * seg
+    return z[rows, torch.arange(C, device=z.device)[None, :]]
+
+
 def _segsum(x, seg):
     M, C = x.shape
     out = torch.empty((M // seg, C), dtype=torch.float32, device=x.device)
@@ -159,6 +166,46 @@ def _check(pts, what):
         raise RuntimeError(f"{what}: the training kernels need B*N to be a multiple of 32, got {pts.shape[0]} x {pts.shape[2]}")
 
 
+def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N):
+    """Backward of  conv (W,b) -> BN (batch statistics) -> ReLU -> max over the N points of each item  WITHOUT the
+    (M x C) gradient tensor of the conv output (C = 1024 for ins_seg: 1 GB at 64 x 4096 points, read three times).
+
+    The max sends gradient to one point per (item, channel), so dy = d relu(bn(z)) is zero except at B*C entries,
+    and the BN backward  dz = k1*(dy - k2 - xhat*k3)  is therefore AFFINE in z everywhere else:
+        dz[p,c] = A_c + Bc_c * z[p,c] + k1_c*dy[p,c],   A = -k1*k2 + k1*k3*rstd*mu,   Bc = -k1*k3*rstd.
+    With z[p] = W a[p] + b (a = the layer's input activation, K channels) both GEMMs of the layer collapse to K x K
+    work plus B*C sparse terms:
+        da[p]  = a[p] (W^T diag(Bc) W) + (A + Bc*b)^T W            + sum_{c: arg=p} k1_c dy_c W[c,:]
+        dW[c]  = A_c m1 + Bc_c (W[c,:] S + b_c m1)                  + k1_c sum_items dy[item,c] a[arg[item,c]]
+    with S = sum_p a[p] a[p]^T (a K x K Gram matrix: the wgrad of a K->K layer) and m1 = sum_p a[p]. The K x K
+    products are float64 torch matmuls (tiny); the per-point work stays on the MFMA kernels.
+    Returns (da (M,K), dW (C,K), dgamma, dbeta)."""
+    M, K = z_prev.shape
+    C = W.shape[0]
+    dev = z_prev.device
+    a = torch.relu(z_prev * bn_prev.scale + bn_prev.shift)                 # (M,K), materialised once (K << C)
+    D = (dg * (g > 0)).double()                                            # ReLU gate at the pooled point
+    xhat = (zarg.double() - bn.mu.double()) * bn.rstd.double()             # (B,C) at the arg-max points
+    dbeta = D.sum(0)
+    dgamma = (D * xhat).sum(0)
+    k1 = bn.gamma.double() * bn.rstd.double()
+    k2, k3 = dbeta / M, dgamma / M
+    A = -k1 * k2 + k1 * k3 * bn.rstd.double() * bn.mu.double()
+    Bc = -k1 * k3 * bn.rstd.double()
+    W64, b64 = W.double(), b.double()
+    G = W64.t() @ (Bc[:, None] * W64)                                       # (K,K)
+    v = (A + Bc * b64) @ W64                                                # (K,)
+    da = _linear(a, G.float().contiguous(), K, K, K, transpose=True, bias=v.float().contiguous())
+    rows = (arg.long() + torch.arange(arg.shape[0], device=dev)[:, None] * N).reshape(-1)      # global point index
+    kd = (k1 * D).float()                                                   # (B,C)
+    da.index_put_((rows,), (kd[:, :, None] * W[None]).reshape(-1, K), accumulate=True)        # sorted: deterministic
+    S = _wgrad(a, a, K, K).double()                                         # Gram matrix on the MFMA wgrad kernel
+    m1 = a.sum(0, dtype=torch.float64)
+    dW = A[:, None] * m1[None] + Bc[:, None] * (W64 @ S + b64[:, None] * m1[None])
+    dW = dW + (kd.double()[:, :, None] * a[rows].reshape(arg.shape[0], C, K).double()).sum(0)
+    return da, dW.float(), dgamma.float(), dbeta.float()
+
+
 class _PointStack(torch.autograd.Function):
     """conv1..4 (+BN+ReLU) and the max over points of a `_PointHead` (static box_est / point_emb): (B,C,N) -> (B,512)"""
 
@@ -180,19 +227,26 @@ class _PointStack(torch.autograd.Function):
             zs.append(z)
             a, act = z, bn.act
         g, arg = _segmax(zs[3], bns[3], N)
-        ctx.saved = (_points_major(pts.detach()), Ws, bns, zs, arg, N, [tuple(p.shape) for p in params])
+        zarg = _gather_at(zs[3], arg, N)
+        zs[3] = None                                          # the pooled layer's output is not needed again
+        biases = [params[4 * k + 1].detach().contiguous() for k in range(4)]
+        ctx.saved = (_points_major(pts.detach()), Ws, bns, zs, arg, N, [tuple(p.shape) for p in params], zarg, g, biases)
         return g
 
     @staticmethod
     def backward(ctx, dg):
-        a0, Ws, bns, zs, arg, N, shapes = ctx.saved
+        a0, Ws, bns, zs, arg, N, shapes, zarg, g, biases = ctx.saved
         grads = [None] * 16
         da = None
         for k in (3, 2, 1, 0):
             if k == 3:
-                dz, dgam, dbet = bns[k].backward(zs[k], dg=dg.contiguous(), arg=arg, seg=N)
-            else:
-                dz, dgam, dbet = bns[k].backward(zs[k], da=da)
+                da, dW, dgam, dbet = _pooled_layer_backward(zs[2], bns[2], Ws[3], biases[3], bns[3], zarg, g, arg,
+                                                            dg, N)
+                grads[12] = dW.reshape(shapes[12])
+                grads[13] = torch.zeros(shapes[13], device=dW.device)
+                grads[14], grads[15] = dgam, dbet
+                continue
+            dz, dgam, dbet = bns[k].backward(zs[k], da=da)
             src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a0, None)
             dW = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
             grads[4 * k] = dW[:, :shapes[4 * k][1]].reshape(shapes[4 * k])
@@ -227,6 +281,8 @@ class _InsSeg(torch.autograd.Function):
             zs.append(z)
             a, act = z, bn.act
         g, arg = _segmax(zs[4], bns[4], N)                              # (B,1024)
+        zarg = _gather_at(zs[4], arg, N)
+        zs[4] = None                                                    # 1 GB at 64 x 4096: not needed again
         # dconv1 on cat([out2, g.expand]): per-point part W[:, :64] out2, per-crop part W[:, 64:] g + b
         Wd1 = P[20].reshape(P[20].shape[0], -1).contiguous()            # (512, 1088)
         gb = torch.addmm(P[21], g, Wd1[:, 64:].t())                     # (B,512)
@@ -253,12 +309,12 @@ class _InsSeg(torch.autograd.Function):
         b5 = torch.zeros(32, dtype=torch.float32, device=pts.device)
         b5[:2] = P[37]
         zl = _linear(a4, W5, 128, 128, 32, bias=b5)
-        ctx.saved = (a0, Ws, bns, zs, g, arg, a4, drop, W5, N, [tuple(p.shape) for p in params])
+        ctx.saved = (a0, Ws, bns, zs, g, arg, a4, drop, W5, N, [tuple(p.shape) for p in params], zarg, P[17].contiguous())
         return zl[:, :2].reshape(B, N, 2).contiguous()
 
     @staticmethod
     def backward(ctx, dlogits):
-        a0, Ws, bns, zs, g, arg, a4, drop, W5, N, shapes = ctx.saved
+        a0, Ws, bns, zs, g, arg, a4, drop, W5, N, shapes, zarg, b_conv5 = ctx.saved
         M = a0.shape[0]
         dev = a0.device
         grads = [None] * 38
@@ -289,10 +345,13 @@ class _InsSeg(torch.autograd.Function):
         # conv5..1
         da = None
         for k in (4, 3, 2, 1, 0):
-            if k == 4:
-                dz, dgam, dbet = bns[k].backward(zs[k], dg=dg.contiguous(), arg=arg, seg=N)
-            else:
-                dz, dgam, dbet = bns[k].backward(zs[k], da=da)
+            if k == 4:                                                  # conv5 -> max: the algebraic shortcut
+                da, dW, dgam, dbet = _pooled_layer_backward(zs[3], bns[3], Ws[4], b_conv5, bns[4], zarg, g, arg, dg, N)
+                grads[16] = dW.reshape(shapes[16])
+                grads[17] = torch.zeros(shapes[17], device=dev)
+                grads[18], grads[19] = dgam, dbet
+                continue
+            dz, dgam, dbet = bns[k].backward(zs[k], da=da)
             src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a0, None)
             dW = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
             grads[4 * k] = dW[:, :shapes[4 * k][1]].reshape(shapes[4 * k])
