@@ -21,6 +21,10 @@ them in CPython. numba compiles the same IEEE operation sequence (no fastmath is
 files), so the fixtures tests/golden/geom_rbbox.npz and crops_extract.npz are outputs of the reference's code;
 tests/test_oracle_geom.py checks this file against them bit for bit.
 
+Quirk kept: `rotation_3d_in_axis` turns the corners CLOCKWISE by the yaw (row vectors times [[c,-s],[s,c]]), the
+convention of det3d's own [w,l,h,r2] boxes; the reference calls it with Waymo-convention boxes (counter-clockwise
+yaw), so the tested region is the box mirrored in yaw. The restatement does what the reference does.
+
 dtype rules kept from NumPy: planes are computed in the boxes' dtype (float32 boxes -> float32 planes); the
 per-point expression is evaluated in the promoted type of point and plane (float32 only when both are float32).
 """
