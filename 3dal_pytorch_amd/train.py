@@ -162,6 +162,9 @@ def supported(pts):
 
 def _check(pts, what):
     _hip.require_gpu(pts, what)
+    if pts.requires_grad:
+        raise NotImplementedError(f"{what}: the HIP training path does not produce a gradient for the input points "
+                                  "(the reference never asks for one); use train_backend='torch' for that")
     if not supported(pts):
         raise RuntimeError(f"{what}: the training kernels need B*N to be a multiple of 32, got {pts.shape[0]} x {pts.shape[2]}")
 
