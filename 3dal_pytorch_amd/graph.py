@@ -39,3 +39,50 @@ class CapturedRefine:
                 dst.copy_(src)
         self.graph.replay()
         return self.boxes
+
+
+class CapturedTrainStep:
+    """One whole training step — forward, criterion, backward, optimizer — as a hipGraph.
+
+    At the train drivers' batch the step issues several hundred launches (per layer: GEMM, two-stage reductions,
+    per-channel epilogues; the optimizer; the criterion) and a third of its wall time is their host-side issue.
+    Capturing the step once and replaying it removes that. Requirements: the device sampler (no host round trip),
+    fixed shapes, an optimizer built with `capturable=True` (torch.optim.Adam supports it), and a criterion made of
+    torch ops. `step_fn(*inputs)` must run forward + criterion and return the scalar loss; backward and
+    `optimizer.step()` are added here. Capture BEFORE the parameters take part in any eager backward (PyTorch binds a
+    parameter's gradient accumulator to the stream of its first backward; one bound to the default stream cannot be
+    used from the capture stream).
+
+        cap = CapturedTrainStep(model, optimizer, step_fn, *example_inputs)
+        loss = cap(*batch)            # copies the batch into the captured buffers, replays, returns the loss tensor
+    """
+
+    def __init__(self, model, optimizer, step_fn, *example_inputs, warmup=3):
+        if not model.training:
+            raise RuntimeError("capture the train-mode path: call model.train() first")
+        if getattr(model, "sampler", "device") != "device":
+            raise RuntimeError("graph capture needs sampler='device' (the NumPy sampler synchronises with the host)")
+        self.inputs = [None if t is None else torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
+                       .copy_(t) for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                                  # also sizes every scratch buffer
+                optimizer.zero_grad(set_to_none=True)
+                step_fn(*self.inputs).backward()
+                optimizer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = step_fn(*self.inputs)
+            self.loss.backward()
+            optimizer.step()
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.inputs, inputs):
+            if dst is not None:
+                dst.copy_(src)
+        self.graph.replay()
+        return self.loss

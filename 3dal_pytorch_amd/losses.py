@@ -21,6 +21,18 @@ def huber_loss(error, delta=1.0):
     return torch.mean(0.5 * quadratic ** 2 + delta * (abs_error - quadratic))
 
 
+_CONST = {}
+
+
+def _consts(dev):
+    """one-hot tables and MEAN_SIZE_ARR on the device, built once (also keeps the criterion hipGraph-capturable)"""
+    c = _CONST.get(dev)
+    if c is None:
+        c = _CONST[dev] = (torch.eye(arch.NUM_HEADING_BIN, device=dev), torch.eye(arch.NUM_SIZE_CLUSTER, device=dev),
+                           torch.tensor(arch.MEAN_SIZE, dtype=torch.float32, device=dev).view(1, arch.NUM_SIZE_CLUSTER, 3))
+    return c
+
+
 def _mask_loss(logits, mask_label):
     return F.nll_loss(F.log_softmax(logits.view(-1, 2), dim=1), mask_label.view(-1).long())
 
@@ -32,13 +44,13 @@ def _box_terms(center, heading_scores, heading_residuals_normalized, size_scores
     center_loss = huber_loss(torch.norm(center - center_label, dim=1), delta=2.0)
     hcl, scl = heading_class_label.long(), size_class_label.long()
     heading_class_loss = F.nll_loss(F.log_softmax(heading_scores, dim=1), hcl)
-    h_onehot = torch.eye(arch.NUM_HEADING_BIN, device=dev)[hcl]
+    eye_h, eye_s, mean_size = _consts(dev)
+    h_onehot = eye_h[hcl]
     h_pred = torch.sum(heading_residuals_normalized * h_onehot.float(), dim=1)
     heading_res_loss = huber_loss(h_pred - heading_residuals_label / (np.pi / arch.NUM_HEADING_BIN), delta=1.0)
     size_class_loss = F.nll_loss(F.log_softmax(size_scores, dim=1), scl)
-    s_onehot = torch.eye(arch.NUM_SIZE_CLUSTER, device=dev)[scl].view(-1, arch.NUM_SIZE_CLUSTER, 1).repeat(1, 1, 3)
+    s_onehot = eye_s[scl].view(-1, arch.NUM_SIZE_CLUSTER, 1).repeat(1, 1, 3)
     s_pred = torch.sum(size_residuals_normalized * s_onehot, dim=1)
-    mean_size = torch.from_numpy(np.array(arch.MEAN_SIZE)).float().to(dev).view(1, arch.NUM_SIZE_CLUSTER, 3)
     mean_size_label = torch.sum(s_onehot * mean_size, dim=1)
     size_res_loss = huber_loss(torch.norm(size_residuals_label / mean_size_label - s_pred, dim=1), delta=1.0)
     return center_loss, heading_class_loss, heading_res_loss, size_class_loss, size_res_loss

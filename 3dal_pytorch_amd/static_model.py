@@ -227,11 +227,23 @@ def _mask_and_gather(pts, logits, n_obj, n_ch, model=None):
     return obj, mask
 
 
+_MEAN_SIZE_ON = {}
+
+
+def _mean_size(device):
+    """MEAN_SIZE_ARR as a device tensor, uploaded once per device (an upload inside a step would also break hipGraph
+    capture of the step)"""
+    t = _MEAN_SIZE_ON.get(device)
+    if t is None:
+        t = _MEAN_SIZE_ON[device] = torch.tensor(arch.MEAN_SIZE, dtype=torch.float32, device=device)
+    return t
+
+
 def _parse(box_pred):
     B = box_pred.shape[0]
     hrn = box_pred[:, 15:27]
     srn = box_pred[:, 30:39].contiguous().view(B, 3, 3)
-    mean = torch.tensor(arch.MEAN_SIZE, dtype=torch.float32, device=box_pred.device)
+    mean = _mean_size(box_pred.device)
     return (box_pred[:, 0:3], box_pred[:, 3:15], hrn, hrn * (np.pi / NUM_HEADING_BIN),
             box_pred[:, 27:30], srn, srn * mean[None])
 
@@ -276,7 +288,7 @@ def _train_forward_two(m, pts, init_box, bbox_gt):
         ar = torch.arange(B, device=c1.device)
         hc = hs1.argmax(1)
         sc = ss1.argmax(1)
-        mean = torch.tensor(arch.MEAN_SIZE, dtype=torch.float64, device=c1.device)
+        mean = _mean_size(c1.device).double()
         size = mean[sc] + sr1[ar, sc].double()
         ang = hc.double() * (2 * np.pi / NUM_HEADING_BIN) + hr1[ar, hc].double()
         ang = torch.where(ang > np.pi, ang - 2 * np.pi, ang) + init_box[:, -1].double()

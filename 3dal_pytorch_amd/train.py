@@ -83,9 +83,11 @@ def _wgrad(dz, a, c_out, c_in, act=None):
 class _BN:
     """batch statistics of one layer's pre-BN output and everything derived from them"""
 
-    def __init__(self, z, gamma, beta, running_mean, running_var):
+    def __init__(self, z, gamma, beta, running_mean, running_var, sums=None):
+        """sums: optional float64 (2*C,) [sum z, sum z^2] obtained without a pass over z (see _moments_through)"""
         M, C = z.shape
-        sums = _colred(z, 0)
+        if sums is None:
+            sums = _colred(z, 0)
         st = torch.empty((4, C), dtype=torch.float32, device=z.device)
         self.mu, self.rstd, self.scale, self.shift = st[0], st[1], st[2], st[3]
         self.gamma = gamma.contiguous()
@@ -169,7 +171,28 @@ def _check(pts, what):
         raise RuntimeError(f"{what}: the training kernels need B*N to be a multiple of 32, got {pts.shape[0]} x {pts.shape[2]}")
 
 
-def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N):
+def _moments_through(z_prev, bn_prev, W, b):
+    """[sum z, sum z^2] of z = W a + b over all points, from the K x K second moments of the layer's INPUT a =
+    relu(bn(z_prev)) instead of a pass over the C-channel output (C = 1024, K = 128 for conv5: 1 GB not re-read):
+        mean(z) = W mean(a) + b,    var(z)_c = w_c^T Cov(a) w_c.
+    Cov(a) is accumulated on CENTRED activations by the MFMA wgrad kernel (no mean^2 to cancel) and the small
+    products are float64. Returns (sums, a, S, m1) with S = sum a a^T and m1 = sum a for the backward shortcut."""
+    M, K = z_prev.shape
+    a = torch.relu(z_prev * bn_prev.scale + bn_prev.shift)
+    m1 = a.sum(0, dtype=torch.float64)
+    mean_a = m1 / M
+    ac = a - mean_a.float()
+    Sc = _wgrad(ac, ac, K, K).double()
+    del ac
+    W64 = W.double()
+    mu = W64 @ mean_a + b.double()
+    var = ((W64 @ (Sc / M)) * W64).sum(1).clamp_(min=0.0)
+    sums = torch.cat([mu * M, (var + mu * mu) * M])
+    S = Sc + m1[:, None] * m1[None, :] / M
+    return sums, a, S, m1
+
+
+def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N, cached=None):
     """Backward of  conv (W,b) -> BN (batch statistics) -> ReLU -> max over the N points of each item  WITHOUT the
     (M x C) gradient tensor of the conv output (C = 1024 for ins_seg: 1 GB at 64 x 4096 points, read three times).
 
@@ -186,7 +209,11 @@ def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N):
     M, K = z_prev.shape
     C = W.shape[0]
     dev = z_prev.device
-    a = torch.relu(z_prev * bn_prev.scale + bn_prev.shift)                 # (M,K), materialised once (K << C)
+    if cached is not None:
+        a, S, m1 = cached                                                   # from _moments_through in the forward
+    else:
+        a = torch.relu(z_prev * bn_prev.scale + bn_prev.shift)             # (M,K), materialised once (K << C)
+        S = m1 = None
     D = (dg * (g > 0)).double()                                            # ReLU gate at the pooled point
     xhat = (zarg.double() - bn.mu.double()) * bn.rstd.double()             # (B,C) at the arg-max points
     dbeta = D.sum(0)
@@ -202,8 +229,9 @@ def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N):
     rows = (arg.long() + torch.arange(arg.shape[0], device=dev)[:, None] * N).reshape(-1)      # global point index
     kd = (k1 * D).float()                                                   # (B,C)
     da.index_put_((rows,), (kd[:, :, None] * W[None]).reshape(-1, K), accumulate=True)        # sorted: deterministic
-    S = _wgrad(a, a, K, K).double()                                         # Gram matrix on the MFMA wgrad kernel
-    m1 = a.sum(0, dtype=torch.float64)
+    if S is None:
+        S = _wgrad(a, a, K, K).double()                                     # Gram matrix on the MFMA wgrad kernel
+        m1 = a.sum(0, dtype=torch.float64)
     dW = A[:, None] * m1[None] + Bc[:, None] * (W64 @ S + b64[:, None] * m1[None])
     dW = dW + (kd.double()[:, :, None] * a[rows].reshape(arg.shape[0], C, K).double()).sum(0)
     return da, dW.float(), dgamma.float(), dbeta.float()
@@ -278,7 +306,10 @@ class _InsSeg(torch.autograd.Function):
             W2 = W.reshape(W.shape[0], -1)
             W2 = _pad_cols(W2, 32) if k == 0 else W2.contiguous()
             z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous())
-            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)))
+            sums = None
+            if k == 4:                                                  # conv5: moments through its 128-channel input
+                sums, a4c, S4, m14 = _moments_through(zs[3], bns[3], W2, b)
+            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), sums=sums)
             Ws.append(W2)
             bns.append(bn)
             zs.append(z)
@@ -312,12 +343,13 @@ class _InsSeg(torch.autograd.Function):
         b5 = torch.zeros(32, dtype=torch.float32, device=pts.device)
         b5[:2] = P[37]
         zl = _linear(a4, W5, 128, 128, 32, bias=b5)
-        ctx.saved = (a0, Ws, bns, zs, g, arg, a4, drop, W5, N, [tuple(p.shape) for p in params], zarg, P[17].contiguous())
+        ctx.saved = (a0, Ws, bns, zs, g, arg, a4, drop, W5, N, [tuple(p.shape) for p in params], zarg, P[17].contiguous(),
+                     (a4c, S4, m14))
         return zl[:, :2].reshape(B, N, 2).contiguous()
 
     @staticmethod
     def backward(ctx, dlogits):
-        a0, Ws, bns, zs, g, arg, a4, drop, W5, N, shapes, zarg, b_conv5 = ctx.saved
+        a0, Ws, bns, zs, g, arg, a4, drop, W5, N, shapes, zarg, b_conv5, conv5_cache = ctx.saved
         M = a0.shape[0]
         dev = a0.device
         grads = [None] * 38
@@ -349,7 +381,8 @@ class _InsSeg(torch.autograd.Function):
         da = None
         for k in (4, 3, 2, 1, 0):
             if k == 4:                                                  # conv5 -> max: the algebraic shortcut
-                da, dW, dgam, dbet = _pooled_layer_backward(zs[3], bns[3], Ws[4], b_conv5, bns[4], zarg, g, arg, dg, N)
+                da, dW, dgam, dbet = _pooled_layer_backward(zs[3], bns[3], Ws[4], b_conv5, bns[4], zarg, g, arg, dg, N,
+                                                            cached=conv5_cache)
                 grads[16] = dW.reshape(shapes[16])
                 grads[17] = torch.zeros(shapes[17], device=dev)
                 grads[18], grads[19] = dgam, dbet

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--backends", default="hip,torch")
+    ap.add_argument("--graph", action="store_true", help="also time the step captured into a hipGraph (device sampler)")
     ap.add_argument("--sampler", default="numpy", choices=["numpy", "device"],
                     help="object-point sampling in the train-mode forward: the reference's host loop or the GPU kernel")
     args = ap.parse_args()
@@ -70,7 +71,29 @@ def main():
             loss = step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / args.iters * 1e3
-        out[backend] = {"ms": round(ms, 2), "crops_per_s": round(B / ms * 1e3, 1), "tflops_per_point_stacks": round(flop / ms / 1e9, 1),
+        g_ms = None
+        if args.graph and args.sampler == "device":
+            # a FRESH model: a parameter that has already taken part in an eager backward keeps a gradient accumulator
+            # bound to that stream, which a capture on another stream cannot use
+            graph = importlib.import_module("3dal_pytorch_amd.graph")
+            del model, opt
+            gm = sm.StaticModelOneBoxEst()
+            gm.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict("static_one").items()})
+            gm = gm.to(dev).train()
+            gm.train_backend, gm.sampler = backend, "device"
+            gopt = torch.optim.Adam(gm.parameters(), lr=1e-3, weight_decay=1e-4, capturable=True)
+            cap = graph.CapturedTrainStep(gm, gopt, lambda p_, i_, g_: crit(gm(p_, i_, g_), *labels)["total_loss"],
+                                          pts, init, gt)
+            for _ in range(2):
+                cap(pts, init, gt)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.iters):
+                cap(pts, init, gt)
+            torch.cuda.synchronize()
+            g_ms = round((time.perf_counter() - t0) / args.iters * 1e3, 2)
+            model, opt = gm, gopt
+        out[backend] = {"ms": round(ms, 2), "graph_ms": g_ms, "crops_per_s": round(B / ms * 1e3, 1), "tflops_per_point_stacks": round(flop / ms / 1e9, 1),
                         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "loss": round(float(loss), 4)}
         del model, opt
         torch.cuda.empty_cache()
