@@ -244,7 +244,7 @@ class _PointStack(torch.autograd.Function):
     def forward(ctx, pts, stats, *params):
         _check(pts, "pts")
         B, _, N = pts.shape
-        a = _points_major(pts.detach())
+        a0 = a = _points_major(pts.detach())
         Ws, bns, zs = [], [], []
         act = None
         for k in range(4):
@@ -261,7 +261,7 @@ class _PointStack(torch.autograd.Function):
         zarg = _gather_at(zs[3], arg, N)
         zs[3] = None                                          # the pooled layer's output is not needed again
         biases = [params[4 * k + 1].detach().contiguous() for k in range(4)]
-        ctx.saved = (_points_major(pts.detach()), Ws, bns, zs, arg, N, [tuple(p.shape) for p in params], zarg, g, biases)
+        ctx.saved = (a0, Ws, bns, zs, arg, N, [tuple(p.shape) for p in params], zarg, g, biases)
         return g
 
     @staticmethod
