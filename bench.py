@@ -219,7 +219,14 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16"],
                     help="arithmetic of the shared-MLP kernels (fp32 = the reference's; bf16/fp16 = configs C3/C5)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / maxpool / cpu_baseline legs")
+    ap.add_argument("--config", default=None, choices=["C2", "C3", "C5"],
+                    help="BASELINE.json configs by name: C2 = the default (static, 4096 x 1024, fp32); C3 = dynamic head, "
+                         "1024 items x 5 x 1024 pts, bf16; C5 = static, N=4096, 2048 crops per GPU, fp16 MFMA")
     args = ap.parse_args()
+    if args.config == "C3":
+        args.head, args.precision, args.batch, args.points = "dynamic", "bf16", 1024, 1024
+    elif args.config == "C5":
+        args.head, args.precision, args.batch, args.points = "static", "fp16", 2048, 4096
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
