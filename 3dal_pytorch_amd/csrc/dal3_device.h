@@ -88,17 +88,29 @@ __device__ __forceinline__ void mma_block(const f32x4* __restrict__ wblk, const 
 #define DAL3_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// The stream is read through a buffer descriptor: address = base (4 SGPRs) + lane*16 (one VGPR, never changes) +
+// a SCALAR byte offset that advances 1 KiB per fragment with one s_add_u32. With a flat pointer per lane, every
+// fragment cost two VALU adds on a 64-bit VGPR pair (hipcc folds the lane into the pointer and strength-reduces it,
+// whatever the source says) — on this chip VALU slots are MFMA slots (see below), and those adds were the largest
+// single group of VALU instructions in the fp32 kernels. Reads past the stream's end stay inside the 2 GiB window
+// of the descriptor (blobs carry tail padding); their values are unused.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int D>
 struct WRing {
-    const f32x4* next;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff, soff;
     f32x4 slot[D];
+    __device__ __forceinline__ f32x4 fetch() {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        soff += 1024;
+        return __builtin_bit_cast(f32x4, v);
+    }
     __device__ __forceinline__ void init(const f32x4* stream, int lane) {
-        next = stream + lane;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(stream), 0, 0x7fffffff, 0x00020000);
+        voff = (uint32_t)lane * 16u;
+        soff = 0;
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            slot[i] = *next;
-            next += 64;
-        }
+        for (int i = 0; i < D; ++i) slot[i] = fetch();
     }
 };
 
@@ -135,11 +147,9 @@ __device__ __forceinline__ void mma_block_ring(WRing<D>& ring, const f32x16 (&X)
     for (int i = 0; i < KT * 4; ++i) {
         ring_batch_wait<D>(ring, i);
         const f32x4 a = ring.slot[i % D];
-        ring.slot[i % D] = *ring.next;
+        ring.slot[i % D] = ring.fetch();
 #ifdef DAL3_ABLATE_WINDOW   // timing experiment only: every fetch hits the same 8 KiB (L1-resident)
-        ring.next = reinterpret_cast<const f32x4*>(reinterpret_cast<uintptr_t>(ring.next + 64) & ~(uintptr_t)0x2000);
-#else
-        ring.next += 64;
+        ring.soff &= ~0x2000u;
 #endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

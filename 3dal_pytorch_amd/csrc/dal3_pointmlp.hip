@@ -108,11 +108,9 @@ __global__ __launch_bounds__(64 * DAL3_WG_WAVES) void ins_seg_decode_kernel(InsS
         for (int i = 0; i < 32; ++i) {                 // fragment i of the chunk: out-tile i/4, q = i%4
             ring_batch_wait<DAL3_PF>(ring, i);
             const f32x4 a = ring.slot[i % DAL3_PF];
-            ring.slot[i % DAL3_PF] = *ring.next;
+            ring.slot[i % DAL3_PF] = ring.fetch();
 #ifdef DAL3_ABLATE_WINDOW
-            ring.next = reinterpret_cast<const f32x4*>(reinterpret_cast<uintptr_t>(ring.next + 64) & ~(uintptr_t)0x2000);
-#else
-            ring.next += 64;
+            ring.soff &= ~0x2000u;
 #endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

@@ -240,8 +240,7 @@ __device__ __forceinline__ void tr_ring_block(WRing<DAL3_PF>& ring, const f32x16
     for (int i = 0; i < 16; ++i) {
         ring_batch_wait<DAL3_PF>(ring, i);
         const f32x4 w = ring.slot[i % DAL3_PF];
-        ring.slot[i % DAL3_PF] = *ring.next;
-        ring.next += 64;
+        ring.slot[i % DAL3_PF] = ring.fetch();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
