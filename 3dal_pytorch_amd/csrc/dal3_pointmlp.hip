@@ -211,11 +211,15 @@ __global__ __launch_bounds__(64 * DAL3_WG_WAVES) void point_head_kernel(PointHea
     // item-minor block order: workgroups are dealt round-robin over the 8 XCDs, and with duplicate skipping only
     // an item's FIRST tiles carry work; (item, tile) = (id % B, id / B) spreads those over every XCD (with
     // item-major order and 4 tiles per item they all landed on 2 of the 8 XCDs: 4.6x slower)
+    // ONE wave per workgroup: a wave that has nothing to do (below) exits at once, and inside a 4-wave workgroup its
+    // SIMD would then idle until the slowest sibling is done (the workgroup keeps the CU: one wave per SIMD at this
+    // register count) — 12 % of this kernel's time on the bench mix of crops.
+    const int wg_waves = blockDim.x >> 6;
     const int n_items = gridDim.x / tiles_per_item;
     const int64_t b = blockIdx.x % n_items;
-    const int n0 = ((blockIdx.x / n_items) * DAL3_WG_WAVES + wave) * (32 * T);
+    const int n0 = ((blockIdx.x / n_items) * wg_waves + wave) * (32 * T);
     __shared__ float s_b4[512];                        // conv4's folded bias, read by the max epilogue
-    for (int i = threadIdx.x; i < 512; i += 64 * DAL3_WG_WAVES) s_b4[i] = w.b4[i];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) s_b4[i] = w.b4[i];
     __syncthreads();
     // distinct[b] (optional): only the first distinct[b] points of the item differ, the rest are duplicates of
     // them (gather: count < M tops up with copies; count == 0 is an all-zero row). The head is per-point work
@@ -326,8 +330,8 @@ hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int
 hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat,
                              const int32_t* distinct, hipStream_t s) {
     constexpr int T = DAL3_HEAD_T;
-    const int tpi = tiles_per_item(M, T);
-    const dim3 grid((unsigned)((int64_t)B * tpi)), block(64 * DAL3_WG_WAVES);
+    const int tpi = (M + 32 * T - 1) / (32 * T);       // one-wave workgroups
+    const dim3 grid((unsigned)((int64_t)B * tpi)), block(64);
     switch (head_kind) {
         case 1:  // static box_est 3 -> 128 -> 128 -> 256 -> 512
             hipLaunchKernelGGL((point_head_kernel<2, 128, 128, 256, T>), grid, block, 0, s, w, x, c_in, M, tpi, feat, distinct);
