@@ -40,6 +40,40 @@ struct FP16 {
     }
 };
 
+// The four k-steps of a 64-channel -> 32-channel block for TWO point tiles with the accumulators in ARCH VGPRs, as one
+// asm statement. hipcc picks the accumulator register class per FUNCTION: the decode kernel's eight resident dconv2
+// tiles fill the AGPR half exactly (2 x 8 x 16), so with AGPR-form MFMAs everywhere the short-lived dconv1 chunk
+// accumulators overflow it and the compiler shuttles 64 registers between the two halves in every iteration (PMC:
+// 5.3 VALU instructions per MFMA in the main loop, 320 of 420 of them v_accvgpr_read/write). Written out, these eight
+// MFMAs take VGPR C/D — legal for any single instruction — and their results are read by the pack/ReLU directly.
+// Wait states are inside the string (cdna guide 5.7 item 2: hipcc pads nothing inside asm): `s_nop 1` covers a VALU
+// write of an operand just before, `s_nop 11` the 8-pass XDL write -> any reader after the statement.
+template <class DT>
+struct MfmaAsm;
+#define DAL3_LP_MFMA4X2(MN)                                                                                          \
+    asm volatile("s_nop 1\n\t" MN " %0, %2, %6, %0\n\t" MN " %1, %2, %10, %1\n\t" MN " %0, %3, %7, %0\n\t" MN           \
+                 " %1, %3, %11, %1\n\t" MN " %0, %4, %8, %0\n\t" MN " %1, %4, %12, %1\n\t" MN " %0, %5, %9, %0\n\t" MN  \
+                 " %1, %5, %13, %1\n\ts_nop 11"                                                                       \
+                 : "+v"(acc0), "+v"(acc1)                                                                            \
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b00), "v"(b01), "v"(b02), "v"(b03), "v"(b10), "v"(b11),      \
+                   "v"(b12), "v"(b13))
+template <>
+struct MfmaAsm<BF16> {
+    typedef BF16::v8 v8;
+    static __device__ __forceinline__ void block4x2(f32x16& acc0, f32x16& acc1, v8 a0, v8 a1, v8 a2, v8 a3, v8 b00, v8 b01,
+                                                    v8 b02, v8 b03, v8 b10, v8 b11, v8 b12, v8 b13) {
+        DAL3_LP_MFMA4X2("v_mfma_f32_32x32x16_bf16");
+    }
+};
+template <>
+struct MfmaAsm<FP16> {
+    typedef FP16::v8 v8;
+    static __device__ __forceinline__ void block4x2(f32x16& acc0, f32x16& acc1, v8 a0, v8 a1, v8 a2, v8 a3, v8 b00, v8 b01,
+                                                    v8 b02, v8 b03, v8 b10, v8 b11, v8 b12, v8 b13) {
+        DAL3_LP_MFMA4X2("v_mfma_f32_32x32x16_f16");
+    }
+};
+
 // B-operand fragments of one 32-channel x 32-point activation tile (two k-steps of 16 channels)
 template <class DT>
 struct ActTile {

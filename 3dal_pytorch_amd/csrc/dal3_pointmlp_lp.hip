@@ -112,33 +112,77 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         for (int j = 0; j < T; ++j) a2[j][mt] = bv;
     }
     f32x16 tA[T], tB[T];
-    auto dconv1_chunk = [&](f32x16 (&t)[T], int chunk, int f0) {
+    typedef typename DT::v8 frag_t;
+    // LDS fragment reads are issued a whole group of four (= 8 MFMAs, 256 cycles) before their MFMAs: with the read
+    // right in front of its MFMA (what the compiler does on its own) every fragment exposed the LDS latency
+    auto load4 = [&](frag_t (&d)[4], int f0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = ring.template frag<DT>(f0 + i);
+    };
+    auto dconv1_chunk = [&](f32x16 (&t)[T], int chunk, const frag_t (&q)[4]) {
         const f32x16 init = tile_from_channels(s_gb + 32 * (chunk & 15), h);
 #pragma unroll
         for (int j = 0; j < T; ++j) t[j] = init;
-        lp_block<DT, 2, T, SEG>(ring, f0, x2, t);
+        static_assert(T == 2, "MfmaAsm::block4x2 is written for two point tiles");
+        MfmaAsm<DT>::block4x2(t[0], t[1], q[0], q[1], q[2], q[3], x2[0][0].k[0], x2[0][0].k[1], x2[0][1].k[0],
+                              x2[0][1].k[1], x2[1][0].k[0], x2[1][0].k[1], x2[1][1].k[0], x2[1][1].k[1]);
     };
-    auto dconv2_part = [&](const f32x16 (&t)[T], int f0) {
-        ActTile<DT> p[T];
+    auto mma4 = [&](const frag_t (&a)[4], const ActTile<DT> (&p)[T], int mt0) {   // out-tiles mt0, mt0+1 x two k-steps
 #pragma unroll
-        for (int j = 0; j < T; ++j) p[j] = pack_relu<DT>(t[j]);
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const typename DT::v8 a = ring.template frag<DT>(f0 + mt * 2 + s);
-#pragma unroll
-                for (int j = 0; j < T; ++j) a2[j][mt] = DT::mfma(a, p[j].k[s], a2[j][mt]);
-            }
+            for (int j = 0; j < T; ++j) a2[j][mt0 + (i >> 1)] = DT::mfma(a[i], p[j].k[i & 1], a2[j][mt0 + (i >> 1)]);
         }
     };
-    dconv1_chunk(tA, 0, 8);
+    {
+        frag_t q[4];
+        load4(q, 8);
+        dconv1_chunk(tA, 0, q);
+    }
     for (int i = 0; i < 8; ++i) {                          // segment 1+i: 1a(2i+1) | 2(2i) | 1a(2i+2) | 2(2i+1)
         ring.acquire();
-        dconv1_chunk(tB, 2 * i + 1, 0);
-        dconv2_part(tA, 4);
-        dconv1_chunk(tA, 2 * i + 2, 20);                   // chunk 16 = zero filler, result unused
-        dconv2_part(tB, 24);
+        frag_t q[4], ga[4], gb[4];
+        ActTile<DT> p[T];
+        load4(q, 0);
+        load4(ga, 4);
+        DAL3_SCHED_FENCE();
+        dconv1_chunk(tB, 2 * i + 1, q);
+#pragma unroll
+        for (int j = 0; j < T; ++j) p[j] = pack_relu<DT>(tA[j]);
+        load4(gb, 8);
+        DAL3_SCHED_FENCE();
+        mma4(ga, p, 0);
+        DAL3_SCHED_FENCE();
+        load4(ga, 12);
+        DAL3_SCHED_FENCE();
+        mma4(gb, p, 2);
+        DAL3_SCHED_FENCE();
+        load4(gb, 16);
+        DAL3_SCHED_FENCE();
+        mma4(ga, p, 4);
+        DAL3_SCHED_FENCE();
+        load4(q, 20);
+        load4(ga, 24);
+        DAL3_SCHED_FENCE();
+        mma4(gb, p, 6);
+        DAL3_SCHED_FENCE();
+        dconv1_chunk(tA, 2 * i + 2, q);                    // chunk 16 = zero filler, result unused
+#pragma unroll
+        for (int j = 0; j < T; ++j) p[j] = pack_relu<DT>(tB[j]);
+        load4(gb, 28);
+        DAL3_SCHED_FENCE();
+        mma4(ga, p, 0);
+        DAL3_SCHED_FENCE();
+        load4(ga, 32);
+        DAL3_SCHED_FENCE();
+        mma4(gb, p, 2);
+        DAL3_SCHED_FENCE();
+        load4(gb, 36);
+        DAL3_SCHED_FENCE();
+        mma4(ga, p, 4);
+        DAL3_SCHED_FENCE();
+        mma4(gb, p, 6);
+        DAL3_SCHED_FENCE();
     }
     ActTile<DT> xd[T][8], y3[T][4];
 #pragma unroll
