@@ -163,33 +163,74 @@ struct LdsRing {
     }
 };
 
-// acc[j] += W'(32 x 32*KT) . X[j] with the block's KT*2 fragments starting at fragment f0 of the slot
+// acc[j] += W'(32 x 32*KT) . X[j] with the block's KT*2 fragments starting at fragment f0 of the slot; the
+// fragments are read in groups of four, a group ahead of their MFMAs (see lp_layer)
 template <class DT, int KT, int T, int SEG>
 __device__ __forceinline__ void lp_block(const LdsRing<SEG>& ring, int f0, const ActTile<DT> (&X)[T][KT],
                                          f32x16 (&acc)[T]) {
+    typedef typename DT::v8 frag_t;
+    constexpr int NG = KT * 2 / 4;
+    static_assert((KT * 2) % 4 == 0, "whole groups of four fragments");
+    frag_t g[2][4];
 #pragma unroll
-    for (int i = 0; i < KT * 2; ++i) {
-        const typename DT::v8 a = ring.template frag<DT>(f0 + i);
+    for (int i = 0; i < 4; ++i) g[0][i] = ring.template frag<DT>(f0 + i);
 #pragma unroll
-        for (int j = 0; j < T; ++j) acc[j] = DT::mfma(a, X[j][i >> 1].k[i & 1], acc[j]);
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[(gi + 1) & 1][i] = ring.template frag<DT>(f0 + 4 * (gi + 1) + i);
+        }
+        DAL3_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 4 * gi + i;
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[j] = DT::mfma(g[gi & 1][i], X[j][k >> 1].k[k & 1], acc[j]);
+        }
+        DAL3_SCHED_FENCE();
     }
 }
 
 // Y[.][MT0 .. MT0+MTN) = relu(W' X + b') for the MTN out-tiles whose blocks start at fragment f0 of the
-// current slot (bias: LDS pointer to the layer's folded bias); output rounded to 16 bits for the next layer
+// current slot (bias: LDS pointer to the layer's folded bias); output rounded to 16 bits for the next layer.
+// The MTN*KT*2 fragments are walked as ONE stream in groups of four, each group's ds_reads issued before the
+// previous group's MFMAs (also across out-tile boundaries): left to itself hipcc puts every read right in front
+// of its MFMAs and each fragment exposes the LDS latency (T = 2: only 64 MFMA cycles per fragment to hide it).
 template <class DT, int KT, int MT, int T, int SEG, int MT0, int MTN>
 __device__ __forceinline__ void lp_layer(const LdsRing<SEG>& ring, int f0, const float* bias,
                                          const ActTile<DT> (&X)[T][KT], ActTile<DT> (&Y)[T][MT], int lane) {
+    typedef typename DT::v8 frag_t;
+    constexpr int FPT = KT * 2;                            // fragments per out-tile
+    constexpr int NG = MTN * FPT / 4;                      // groups of four
+    static_assert(FPT % 4 == 0, "a tile's fragments must be whole groups of four");
     const int h = lane >> 5;
+    frag_t g[2][4];
+    f32x16 acc[T];
 #pragma unroll
-    for (int m = MT0; m < MT0 + MTN; ++m) {
-        f32x16 acc[T];
-        const f32x16 b = tile_from_channels(bias + 32 * m, h);
+    for (int i = 0; i < 4; ++i) g[0][i] = ring.template frag<DT>(f0 + i);
 #pragma unroll
-        for (int j = 0; j < T; ++j) acc[j] = b;
-        lp_block<DT, KT, T, SEG>(ring, f0 + (m - MT0) * KT * 2, X, acc);
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) {
 #pragma unroll
-        for (int j = 0; j < T; ++j) Y[j][m] = pack_relu<DT>(acc[j]);
+            for (int i = 0; i < 4; ++i) g[(gi + 1) & 1][i] = ring.template frag<DT>(f0 + 4 * (gi + 1) + i);
+        }
+        DAL3_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = 4 * gi + i, m = MT0 + f / FPT, k = f % FPT;
+            if (k == 0) {
+                const f32x16 b = tile_from_channels(bias + 32 * m, h);
+#pragma unroll
+                for (int j = 0; j < T; ++j) acc[j] = b;
+            }
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[j] = DT::mfma(g[gi & 1][i], X[j][k >> 1].k[k & 1], acc[j]);
+            if (k == FPT - 1) {
+#pragma unroll
+                for (int j = 0; j < T; ++j) Y[j][m] = pack_relu<DT>(acc[j]);
+            }
+        }
+        DAL3_SCHED_FENCE();
     }
 }
 
@@ -245,3 +286,39 @@ __device__ __forceinline__ void lp_tile_max(const f32x16 (&acc)[T], const float*
     bits = bits > 0 ? bits : 0;
     if ((lane & 16) == 0) atomicMax(smax + ch, bits);
 }
+
+// The last layer of a stack with the max over points fused, for the TPS out-tiles of the current ring slot (their
+// fragments start at fragment 0): one fragment stream, groups of four read a group ahead — across tile boundaries
+// too, so that a tile's max epilogue (VALU + LDS atomics) runs while the next tile's first fragments are in flight.
+template <class DT, int KT, int T, int SEG, int TPS>
+__device__ __forceinline__ void lp_max_tiles(const LdsRing<SEG>& ring, const ActTile<DT> (&X)[T][KT], const float* bias,
+                                             int* smax, int lane) {
+    typedef typename DT::v8 frag_t;
+    constexpr int FPT = KT * 2, NG = TPS * FPT / 4;
+    static_assert(FPT % 4 == 0, "whole groups of four fragments per tile");
+    frag_t g[2][4];
+    f32x16 acc[T];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[0][i] = ring.template frag<DT>(i);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[(gi + 1) & 1][i] = ring.template frag<DT>(4 * (gi + 1) + i);
+        }
+        DAL3_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = 4 * gi + i, k = f % FPT;
+            if (k == 0) {
+#pragma unroll
+                for (int j = 0; j < T; ++j) acc[j] = f32x16{};
+            }
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[j] = DT::mfma(g[gi & 1][i], X[j][k >> 1].k[k & 1], acc[j]);
+            if (k == FPT - 1) lp_tile_max<T>(acc, bias + 32 * (f / FPT), smax + 32 * (f / FPT), lane);
+        }
+        DAL3_SCHED_FENCE();
+    }
+}
+

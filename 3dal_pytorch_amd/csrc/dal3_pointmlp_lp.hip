@@ -44,15 +44,7 @@ __global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN
     lp_layer<DT, 2, 4, T, SEG, 0, 4>(ring, 16, s_bias + 128, x3, x4, lane);
     for (int seg = 0; seg < 8; ++seg) {                    // conv5: 4 out-tiles (32 fragments) per segment
         ring.acquire();
-#pragma unroll
-        for (int tl = 0; tl < 4; ++tl) {
-            f32x16 acc[T];
-#pragma unroll
-            for (int j = 0; j < T; ++j) acc[j] = f32x16{};
-            lp_block<DT, 4, T, SEG>(ring, tl * 8, x4, acc);
-            const int ch = 32 * (seg * 4 + tl);
-            lp_tile_max<T>(acc, s_bias + 256 + ch, s_max + ch, lane);
-        }
+        lp_max_tiles<DT, 4, T, SEG, 4>(ring, x4, s_bias + 256 + 128 * seg, s_max + 128 * seg, lane);
     }
     __syncthreads();
     int* gi = reinterpret_cast<int*>(g + b * 1024);
@@ -289,15 +281,7 @@ __global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN 
     const float* s_b4 = s_bias + C2 + C3;
     for (int seg = 0; seg < M4 / TPS4; ++seg) {
         ring.acquire();
-#pragma unroll
-        for (int tl = 0; tl < TPS4; ++tl) {
-            f32x16 acc[T];
-#pragma unroll
-            for (int j = 0; j < T; ++j) acc[j] = f32x16{};
-            lp_block<DT, K4, T, SEG>(ring, tl * K4 * 2, x3, acc);
-            const int ch = 32 * (seg * TPS4 + tl);
-            lp_tile_max<T>(acc, s_b4 + ch, s_max + ch, lane);
-        }
+        lp_max_tiles<DT, K4, T, SEG, TPS4>(ring, x3, s_b4 + 32 * TPS4 * seg, s_max + 32 * TPS4 * seg, lane);
     }
     __syncthreads();
     int* fi = reinterpret_cast<int*>(feat + b * 512);
