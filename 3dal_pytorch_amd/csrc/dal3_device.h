@@ -116,12 +116,13 @@ struct WRing {
 
 // On gfx950 the f32 MFMA shares the vector ALU's issue (tools/ubench/mfma_bubble.hip: every VALU op
 // between two MFMAs adds ~6 cycles, every s_waitcnt ~17, a global_load ~1), so the loops keep the
-// non-MFMA instruction count down. One of the levers: hipcc puts an s_waitcnt vmcnt(N) in front of the
-// first use of EVERY fragment; touching the youngest fragment of a batch of DAL3_WAIT_BATCH first makes
-// it emit one wait per batch (loads retire in order, so the older fragments of the batch are then known
-// to have landed).
+// non-MFMA instruction count down. A lever that used to pay and no longer does: hipcc puts an s_waitcnt vmcnt(N)
+// in front of the first use of EVERY fragment; touching the youngest fragment of a batch of DAL3_WAIT_BATCH first
+// makes it emit one wait per batch (loads retire in order). With flat loads a batch of 4 was worth ~1 %; since the
+// ring reads through a buffer descriptor, waiting for a younger fragment than needed costs more than the waits
+// saved (decode 13.15 -> 12.89 ms with the batch at 1), so the default is 1 (= off).
 #ifndef DAL3_WAIT_BATCH
-#define DAL3_WAIT_BATCH 4
+#define DAL3_WAIT_BATCH 1
 #endif
 template <int D>
 __device__ __forceinline__ void ring_batch_wait(WRing<D>& ring, int i) {
