@@ -102,3 +102,22 @@ def test_lowprec_api_errors():
     model.precision = "int8"
     with pytest.raises(ValueError):
         model(torch.zeros((1, 3, 64), device="cuda"), torch.zeros((1, 7), device="cuda"), None)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_lowprec_kernels_are_bitwise_repeatable(prec):
+    """the 16-bit decode kernel carries hand-written MFMA statements whose wait states are the author's
+    responsibility (dal3_lp.h, MfmaAsm): a missing one shows up as values that differ between launches on some
+    waves. 25 launches of 512 crops x 1024 points (8192 waves each) must agree bit for bit."""
+    model = build_model("static_one", synth.state_dict("static_one", seed=9))
+    model.precision = prec
+    p, i, _ = synth.static_crops(64, 1024, seed=9)
+    pts = torch.from_numpy(np.tile(p, (8, 1, 1))).cuda().transpose(2, 1)
+    init = torch.from_numpy(np.tile(i, (8, 1))).cuda()
+    first = model._run(pts, init, None)
+    ref = {k: first[k].clone() for k in ("logits", "mask", "bp1", "boxes7")}
+    assert torch.equal(ref["logits"][:64], ref["logits"][64:128])            # identical crops, different waves
+    for _ in range(25):
+        out = model._run(pts, init, None)
+        for k, v in ref.items():
+            assert torch.equal(out[k], v), k
