@@ -321,10 +321,19 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic.json")          # HBM bytes per launch from rocprofv3 --pmc
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get(dom)
+        pmc = None                                                      # MFMA-busy and clock from the committed PMC passes
+        pfile = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if args.precision == "fp32" and os.path.exists(pfile):
+            d = json.load(open(pfile)).get(dom, {})
+            if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+                cyc = d["GRBM_GUI_ACTIVE"] / 8.0                        # the counter sums the 8 XCDs
+                pmc = {"source": "profiles/r01_pmc.json (rocprofv3 --pmc, separate passes)",
+                       "mfma_busy": round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), 4),
+                       "clock_ghz": round(cyc / d["avg_ns_under_GRBM_GUI_ACTIVE"], 3)}
         rec["roofline"] = {"kernel": dom + ("" if args.precision == "fp32" else "_lp"), "bound": "mfma",
                            "achieved": kr[dom]["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kr[dom]["frac"],
                            "traffic": traffic, "ms_per_launch": kr[dom]["ms"],
-                           "algorithmic_gflop_per_launch": kr[dom]["algorithmic_gflop"]}
+                           "algorithmic_gflop_per_launch": kr[dom]["algorithmic_gflop"], "pmc": pmc}
         rec["kernels"] = kr
         if static and args.precision == "fp32":
             # the same workload on the 16-bit MFMA path (BASELINE.json configs C3/C5 arithmetic): reported beside
