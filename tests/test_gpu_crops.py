@@ -137,3 +137,9 @@ def test_crop_extraction_keeps_the_reference_treatment_of_non_finite_points():
     _, _, pts_g = G.extract_crops(pts, box9, pose)
     for k in range(5):
         assert np.allclose(rec["point"][k].cpu().numpy(), pts_g[k], rtol=0, atol=1e-9, equal_nan=True)
+
+
+def test_crop_extraction_without_any_detection():
+    pts, box9, _, _, pose = synth.sweep(48, "none", n_points=2000, n_boxes=3)
+    frames = crops.extract_crops([pts, pts[:100]], [box9[:0], box9[:0]], [pose, pose], return_index=True)
+    assert len(frames) == 2 and all(f["point"] == [] and f["index"] == [] and f["bbox"].shape == (0, 7) for f in frames)
