@@ -116,3 +116,20 @@ def test_dropin_modules_resolve():
             % os.path.join(ROOT, "3dal_pytorch_amd", "dropin"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_header_is_plain_c():
+    """include/dal3.h is the boundary for non-Python hosts: it must compile as C99 on its own"""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "t.c")
+        with open(src, "w") as f:
+            f.write('#include "dal3.h"\nint main(void) { dal3_static_args a = {0}; dal3_dynamic_args d = {0}; (void)a; (void)d; '
+                    'return dal3_version() < 0; }\n')
+        out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I",
+                              os.path.join(ROOT, "include"), src], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
