@@ -51,7 +51,9 @@ class CapturedTrainStep:
     torch ops. `step_fn(*inputs)` must run forward + criterion and return the scalar loss; backward and
     `optimizer.step()` are added here. Capture BEFORE the parameters take part in any eager backward (PyTorch binds a
     parameter's gradient accumulator to the stream of its first backward; one bound to the default stream cannot be
-    used from the capture stream).
+    used from the capture stream). The object-point draw and the Dropout draw are part of the recording: Dropout
+    advances with torch's graph-safe RNG on every replay, the device sampler's key is a kernel argument and stays
+    what it was at capture time.
 
         cap = CapturedTrainStep(model, optimizer, step_fn, *example_inputs)
         loss = cap(*batch)            # copies the batch into the captured buffers, replays, returns the loss tensor

@@ -302,6 +302,9 @@ def test_train_mode_with_the_device_sampler_needs_no_host_round_trip():
         runs.append((float(loss.detach()), model.box_est.conv1.weight.grad.clone(), o["mask"].clone()))
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
     assert float(runs[0][1].abs().max()) > 0 and bool(torch.isfinite(runs[0][1]).all())
+    # consecutive steps of ONE model draw different subsets (as np.random would): same logits, other box inputs
+    again = model(*args)
+    assert torch.equal(again["logits"], o["logits"]) and not torch.equal(again["center"], o["center"])
     ref = build_model("static_one", synth.state_dict("static_one", seed=26)).train()
     ref.sampler, ref.ins_seg.dropout.p = "numpy", 0.0
     np.random.seed(1)
