@@ -133,3 +133,13 @@ def test_header_is_plain_c():
         out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I",
                               os.path.join(ROOT, "include"), src], capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """no CPU/eager fallback: with the shared library absent every entry point raises, naming the build step"""
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "lib3dal_hip.so"))
+    with pytest.raises(RuntimeError, match="build the HIP library"):
+        hip.lib()
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        hip.lib().dal3_last_error()
