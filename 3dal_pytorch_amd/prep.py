@@ -111,25 +111,43 @@ def prepare_static_batch(tracks, veh_to_global, n_points=4096, sampler="numpy", 
     return out.transpose(2, 1), init, labels
 
 
+class TrackStore:
+    """All frames of a list of tracks resident on the device, uploaded once: the global-frame points of every frame
+    stacked (float64), the frame offsets into them, the per-frame boxes, and each track's first frame. Pass it to
+    prepare_dynamic_batch in place of the list of tracks when many batches draw from the same tracks
+    (eval.refine_dynamic_tracks does)."""
+
+    def __init__(self, tracks, device="cuda"):
+        dev = torch.device(device)
+        frame_pts, frame_off, boxes, track_first = [], [0], [], [0]
+        for tr in tracks:
+            for p, bx in zip(tr["point"], tr["bbox"]):
+                p = np.asarray(p, np.float64).reshape(-1, 3)
+                frame_pts.append(p)
+                frame_off.append(frame_off[-1] + p.shape[0])
+                boxes.append(np.asarray(bx, np.float64).reshape(7))
+            track_first.append(track_first[-1] + len(tr["point"]))
+        self.tracks = tracks
+        self.pts = _dev(np.vstack(frame_pts) if frame_pts else np.zeros((0, 3)), dev, np.float64)
+        self.frame_off = _dev(np.array(frame_off), dev, np.int64)
+        self.boxes = _dev(np.stack(boxes), dev, np.float64)
+        self.track_first = _dev(np.array(track_first), dev, np.int64)
+
+
 def prepare_dynamic_batch(tracks, items, veh_to_global, n_per_frame=1024, r=2, s=50, sampler="numpy", seed=10922081,
                           item_offset=0, device="cuda", gt_of_frame=None, pose_of_frame=None):
-    """tracks: list of track dicts; items: list of (track_index, frame_index); veh_to_global: flat-16 pose of each
-    item's own frame (dynamic_model.py:449-451). Returns (pts (B,4,5*n) view, box (B,8,2s+1) view, init_box (B,8))
-    as dynamic_eval.py:222-223 builds them.
+    """tracks: list of track dicts (or a TrackStore of them); items: list of (track_index, frame_index);
+    veh_to_global: flat-16 pose of each item's own frame (dynamic_model.py:449-451). Returns (pts (B,4,5*n) view,
+    box (B,8,2s+1) view, init_box (B,8)) as dynamic_eval.py:222-223 builds them.
     Labels (dynamic_model.py:455-501) when gt_of_frame(track_index, frame) -> float32 (9,) annotation box or None
     and pose_of_frame(track_index, frame) -> flat-16 veh_to_global are given: a fourth return value, dict with
     bbox_gt, mask_label (B,5*n) u8, center_label, heading_class_label, heading_residuals_label, size_class_label,
     size_residual_label. Every item's own frame must have its annotation (the reference redraws another item
     otherwise, dynamic_model.py:487-489; that choice is the caller's)."""
     B = len(items)
-    frame_pts, frame_off, boxes, track_first = [], [0], [], [0]
-    for tr in tracks:
-        for p, bx in zip(tr["point"], tr["bbox"]):
-            p = np.asarray(p, np.float64).reshape(-1, 3)
-            frame_pts.append(p)
-            frame_off.append(frame_off[-1] + p.shape[0])
-            boxes.append(np.asarray(bx, np.float64).reshape(7))
-        track_first.append(track_first[-1] + len(tr["point"]))
+    dev = torch.device(device)
+    store = tracks if isinstance(tracks, TrackStore) else TrackStore(tracks, dev)
+    tracks = store.tracks
     poses = np.linalg.inv(np.reshape(np.asarray(veh_to_global, np.float64), [B, 4, 4])).reshape(B, 16)
     choice = None
     if sampler == "numpy":
@@ -139,11 +157,7 @@ def prepare_dynamic_batch(tracks, items, veh_to_global, n_per_frame=1024, r=2, s
             for j, i in enumerate(range(it - r, it + r + 1)):                     # dynamic_model.py:430-437
                 if 0 <= i < n_frames and len(tracks[t]["point"][i]) > 0:
                     choice[b, j] = np.random.choice(len(tracks[t]["point"][i]), n_per_frame, replace=True)
-    dev = torch.device(device)
-    d_pts = _dev(np.vstack(frame_pts) if frame_pts else np.zeros((0, 3)), dev, np.float64)
-    d_foff = _dev(np.array(frame_off), dev, np.int64)
-    d_boxes = _dev(np.stack(boxes), dev, np.float64)
-    d_first = _dev(np.array(track_first), dev, np.int64)
+    d_pts, d_foff, d_boxes, d_first = store.pts, store.frame_off, store.boxes, store.track_first
     d_it = _dev(np.array([t for t, _ in items]), dev, np.int32)
     d_if = _dev(np.array([i for _, i in items]), dev, np.int32)
     d_pose = _dev(poses, dev, np.float64)

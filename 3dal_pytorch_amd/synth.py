@@ -274,6 +274,49 @@ def gt_box_in_vehicle(box_global, veh_to_global):
     return np.concatenate([c, 0.9 * np.asarray(box_global[3:6]), [0.0, 0.0], [yaw]]).astype(np.float32)
 
 
+def segment_files(root, seed, n_frames=12, n_tracks=5, max_pts=300, scene_name="synth0001"):
+    """One synthetic segment written in the reference's on-disk formats under `root`:
+    annos/<token>.pkl, infos.pkl (list of info dicts), det_annos.pkl (list, deliberately NOT in frame order),
+    trackStatic.pkl and trackDynamic.pkl (the same tracks: {track id: per-frame lists}). Tracks come from scene()
+    with points added around each box (every 5th frame of odd tracks empty); the frames where scene() says the
+    matched annotation is missing have no such object in their annos file. Returns the paths and the pieces."""
+    import os
+    import pickle
+    tracks, poses, dets, has_gt = scene(seed, n_frames, n_tracks)
+    for k, tr in enumerate(tracks):
+        for j, b in enumerate(tr["bbox"]):
+            n = 0 if (k % 2 == 1 and j % 5 == 4) else int(40 + uniform(seed, f"sf{k}_{j}k", (1,))[0] * (max_pts - 40))
+            local = uniform(seed, f"sf{k}_{j}p", (n, 3), -1.0, 1.0) * (b[3:6] / 2 * 1.2)
+            cy, sy = np.cos(b[6]), np.sin(b[6])
+            rot = np.array([[cy, -sy, 0.0], [sy, cy, 0.0], [0.0, 0.0, 1.0]])
+            tr["point"][j] = local @ rot.T + b[:3]
+    os.makedirs(os.path.join(root, "annos"), exist_ok=True)
+    infos = []
+    for f in range(n_frames):
+        tok = f"fr_{f}"
+        objs = [{"id": k, "name": tr["match"][0], "label": tr["type"][0], "num_points": 10,
+                 "box": gt_box_in_vehicle(tr["bbox"][tr["token"].index(tok)], poses[tok])}
+                for k, tr in enumerate(tracks) if tok in tr["token"] and has_gt[(k, tok)]]
+        path = os.path.join(root, "annos", tok + ".pkl")
+        with open(path, "wb") as fh:
+            pickle.dump({"scene_name": scene_name, "frame_name": f"{scene_name}_{f}", "frame_id": f,
+                         "veh_to_global": poses[tok], "objects": objs}, fh)
+        infos.append({"path": os.path.join(root, "lidar", tok + ".pkl"), "anno_path": path, "token": tok,
+                      "timestamp": 0.1 * f, "sweeps": []})
+    order = np.argsort(uniform(seed, "sf_order", (n_frames,)))
+    det_annos = [{"name": np.array(["VEHICLE"] * len(dets[f"fr_{f}"])), "score": np.full(len(dets[f"fr_{f}"]), 0.5),
+                  "boxes_lidar": dets[f"fr_{f}"].copy(),
+                  "frame_id": f"segment-{scene_name}_with_camera_labels_{f:03d}", "metadata": {"token": f"fr_{f}"}}
+                 for f in order]
+    track = {f"id{k:02d}": tr for k, tr in enumerate(tracks)}
+    paths = {"infos": os.path.join(root, "infos.pkl"), "det_annos": os.path.join(root, "det_annos.pkl"),
+             "static": os.path.join(root, "trackStatic.pkl"), "dynamic": os.path.join(root, "trackDynamic.pkl")}
+    for key, obj in (("infos", infos), ("det_annos", det_annos), ("static", track), ("dynamic", track)):
+        with open(paths[key], "wb") as fh:
+            pickle.dump(obj, fh)
+    return paths, tracks, poses, dets, has_gt
+
+
 def loss_case(seed, two_stage=False, batch=6, n_pts=64):
     """Synthetic model outputs + labels for the loss modules (tools/static_model.py:348-517): returns
     (output dict of float32 arrays, labels tuple in the criterion's argument order)."""
