@@ -219,9 +219,10 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16"],
                     help="arithmetic of the shared-MLP kernels (fp32 = the reference's; bf16/fp16 = configs C3/C5)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / maxpool / cpu_baseline legs")
-    ap.add_argument("--config", default=None, choices=["C2", "C3", "C5"],
+    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5"],
                     help="BASELINE.json configs by name: C2 = the default (static, 4096 x 1024, fp32); C3 = dynamic head, "
-                         "1024 items x 5 x 1024 pts, bf16; C5 = static, N=4096, 2048 crops per GPU, fp16 MFMA")
+                         "1024 items x 5 x 1024 pts, bf16; C4 = one segment (64 static crops x 4096 pts + 40 dynamic tracks), sharded "
+                         "over the GPUs (strong scaling); C5 = static, N=4096, 2048 crops per GPU, fp16 MFMA")
     args = ap.parse_args()
     if args.config == "C3":
         args.head, args.precision, args.batch, args.points = "dynamic", "bf16", 1024, 1024
@@ -249,26 +250,49 @@ def main():
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     static = args.head == "static"
-    B = args.batch or (4096 if static else 1024)
-    N = args.points if static else 5 * args.points
-    first = rank * B                                            # weak scaling: B items per GPU
-    if static:
-        model, inputs, host = make_static(B, N, dev, first)
-        step_fn = lambda: model.refine(*inputs)                 # noqa: E731
-        flop_item = arch.static_one_flop(N)
+    mixed = args.config == "C4"
+    if mixed:
+        # 198 frames; 64 static tracks -> 64 crops at N=4096; 40 dynamic tracks with lengths
+        # rng.integers(20,199) -> one item per track-frame; contiguous index sharding, static and dynamic batches
+        # back to back, one all-gather per head. The segment is fixed: strong scaling.
+        lens = np.random.default_rng(10922081).integers(20, 199, size=40)
+        n_static, n_dyn = 64, int(lens.sum())
+        s_lo, s_hi = dal3_dist.shard_range(n_static, rank, world)
+        d_lo, d_hi = dal3_dist.shard_range(n_dyn, rank, world)
+        smodel, sin, _ = make_static(max(s_hi - s_lo, 1), 4096, dev, s_lo)
+        dmodel, din = make_dynamic(max(d_hi - d_lo, 1), dev, d_lo)
+        smodel.precision = dmodel.precision = args.precision
+        B, N, static, host, model = (s_hi - s_lo) + (d_hi - d_lo), 0, False, None, smodel
+        flop_item = (n_static * arch.static_one_flop(4096) + n_dyn * arch.dynamic_flop(5120)) / (n_static + n_dyn)
+        n_total = n_static + n_dyn
+
+        def step_fn():
+            a = smodel.refine(*sin)[:s_hi - s_lo]
+            a = dal3_dist.all_gather_boxes(a, n_static) if use_dist else a
+            b = dmodel.refine(*din)[:d_hi - d_lo]
+            b = dal3_dist.all_gather_boxes(b, n_dyn) if use_dist else b
+            return torch.cat([a, b])
     else:
-        model, inputs = make_dynamic(B, dev, first)
-        step_fn = lambda: model.refine(*inputs)                 # noqa: E731
-        flop_item = arch.dynamic_flop(N)
-        host = None
-    n_total = B * world
-    model.precision = args.precision
+        B = args.batch or (4096 if static else 1024)
+        N = args.points if static else 5 * args.points
+        first = rank * B                                            # weak scaling: B items per GPU
+        if static:
+            model, inputs, host = make_static(B, N, dev, first)
+            step_fn = lambda: model.refine(*inputs)                 # noqa: E731
+            flop_item = arch.static_one_flop(N)
+        else:
+            model, inputs = make_dynamic(B, dev, first)
+            step_fn = lambda: model.refine(*inputs)                 # noqa: E731
+            flop_item = arch.dynamic_flop(N)
+            host = None
+        n_total = B * world
+        model.precision = args.precision
     peak = MFMA_PEAK_TFLOPS[args.precision]
     dname = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.precision]
 
     def step():
         boxes = step_fn()
-        return dal3_dist.all_gather_boxes(boxes, n_total) if use_dist else boxes
+        return dal3_dist.all_gather_boxes(boxes, n_total) if (use_dist and not mixed) else boxes
 
     def fence():
         if use_dist:
@@ -303,18 +327,22 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "ms_per_step_median": round(per_step[len(per_step) // 2], 3), "ms_per_step_min": round(per_step[0], 3),
         "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
-        "config": {"workload": (f"StaticModelOneBoxEst forward+decode, {B} crops x {N} pts per GPU, {args.precision}"
+        "scaling": "strong" if mixed else "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
+        "config": {"workload": (f"one synthetic segment: {n_total - 64} dynamic items (40 tracks) x 5120 pts + 64 static "
+                                f"crops x 4096 pts, {args.precision}, both heads back to back "
+                                "(BASELINE.json configs[3])") if mixed else
+                               (f"StaticModelOneBoxEst forward+decode, {B} crops x {N} pts per GPU, {args.precision}"
                                 + (" (BASELINE.json configs[1])" if (B, N) == (4096, 1024) else "")) if static else
                                (f"DynamicModel forward+decode, {B} items x {N} pts + 101 boxes per GPU, {args.precision} "
                                 "arithmetic (BASELINE.json configs[2] shape)"),
                    "items_per_gpu": B, "points_per_item": N, "sampler": model.sampler,
-                   "parallelism": f"object-sharded x{world}, one all-gather of (B,7) boxes" if world > 1 else "single GPU",
+                   "parallelism": (f"object-sharded x{world}, one all-gather of (B,7) boxes" + (" per head" if mixed else ""))
+                   if world > 1 else "single GPU",
                    "algorithmic_gflop_per_item": round(flop_item / 1e9, 4)},
         "whole_path_tflops": round(value * flop_item / 1e12, 2),
         "whole_path_mfma_frac": round(value / world * flop_item / 1e12 / peak, 4),
     }
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not mixed:
         kr = kernel_rooflines(model, inputs[0], 3 if static else 4, B, N, iters=max(3, min(args.steps, 10)))
         dom = max(kr, key=lambda k: kr[k]["ms"])
         traffic = None
