@@ -146,13 +146,13 @@ def maxpool_roofline(dev, iters):
             "exact": ok}
 
 
-def cpu_baseline(host, budget_s=20.0):
+def cpu_baseline(host, budget_s=20.0, threads=None):
     """the oracle (reference formulation) on the host cores, B=64 sample of the same crops"""
     R = importlib.import_module("oracle.ref_heads")
     pts_np, init_np, sd = host
-    # tools/cpu_threads.py on the GPU box (256 logical cores): 8 thr 64, 16 thr 76, 32 thr 80, 64 thr 53,
-    # 128 thr 27 crops/s -> the port saturates at 32 threads; more only adds contention
-    n = min(len(os.sched_getaffinity(0)), 32)
+    # `bench.py --cpu-sweep 8 16 32 64 128` on the GPU box (256 logical cores): 8 thr 64, 16 thr 76, 32 thr 80,
+    # 64 thr 53, 128 thr 27 crops/s -> the port saturates at 32 threads; more only adds contention
+    n = threads or min(len(os.sched_getaffinity(0)), 32)
     torch.set_num_threads(n)
     sample = 64
     tsd = R.as_torch_sd(sd)
@@ -223,7 +223,15 @@ def main():
                     help="BASELINE.json configs by name: C2 = the default (static, 4096 x 1024, fp32); C3 = dynamic head, "
                          "1024 items x 5 x 1024 pts, bf16; C4 = one segment (64 static crops x 4096 pts + 40 dynamic tracks), sharded "
                          "over the GPUs (strong scaling); C5 = static, N=4096, 2048 crops per GPU, fp16 MFMA")
+    ap.add_argument("--cpu-sweep", type=int, nargs="+", default=None, metavar="THREADS",
+                    help="run only the cpu_baseline leg at these torch thread counts (no GPU work) and print one JSON line")
     args = ap.parse_args()
+    if args.cpu_sweep:
+        pts_np, init_np, _ = synth.static_crops(64, args.points)
+        host = (pts_np, init_np, synth.state_dict("static_one"))
+        print(json.dumps({"cpu_baseline_sweep": [cpu_baseline(host, budget_s=6.0, threads=t) for t in args.cpu_sweep],
+                          "affinity": len(os.sched_getaffinity(0))}))
+        return
     if args.config == "C3":
         args.head, args.precision, args.batch, args.points = "dynamic", "bf16", 1024, 1024
     elif args.config == "C5":
