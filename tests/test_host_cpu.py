@@ -143,3 +143,38 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         hip.lib()
     with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
         hip.lib().dal3_last_error()
+
+
+def test_oracle_is_test_infrastructure_only():
+    """nothing shipped or measured routes through oracle/: the package, the tools and the examples never name it in
+    code; bench.py imports it in its cpu_baseline leg only, __graft_entry__ in build() (import check) and smoke()"""
+    import ast
+    import glob
+    pat = re.compile(r"\boracle\b")
+
+    def code_mentions(path):
+        """names of the top-level functions (None = module level) whose code imports the oracle package"""
+        tree = ast.parse(open(path).read())
+        hits = []
+
+        def visit(node, owner):
+            for n in ast.iter_child_nodes(node):
+                here = n.name if (isinstance(n, ast.FunctionDef) and owner is None) else owner
+                names = []
+                if isinstance(n, ast.Import):
+                    names = [a.name for a in n.names]
+                elif isinstance(n, ast.ImportFrom):
+                    names = [n.module or ""]
+                elif isinstance(n, ast.Call) and n.args and isinstance(n.args[0], ast.Constant) \
+                        and isinstance(n.args[0].value, str) and getattr(n.func, "attr", "") == "import_module":
+                    names = [n.args[0].value]
+                if any(pat.match(x.split(".")[0]) for x in names):
+                    hits.append(here)
+                visit(n, here)
+        visit(tree, None)
+        return hits
+    for path in glob.glob(os.path.join(ROOT, "3dal_pytorch_amd", "**", "*.py"), recursive=True) + \
+            glob.glob(os.path.join(ROOT, "tools", "*.py")):
+        assert not code_mentions(path), path
+    assert set(code_mentions(os.path.join(ROOT, "bench.py"))) == {"cpu_baseline"}
+    assert set(code_mentions(os.path.join(ROOT, "__graft_entry__.py"))) <= {"build", "smoke"}
