@@ -118,11 +118,14 @@ struct LdsRing {
     const char* stream;                                   // global: this kernel's fragment stream
     char* lds;                                            // LDS: LP_SLOTS * SLOT_BYTES
     int n_segs, seg_issue, slot_issue, slot_use, wave, lane;
+    bool cyclic;                                          // persistent kernels: past the stream's end comes its start
 
-    __device__ __forceinline__ void init(const void* stream_, char* lds_, int n_segs_, int wave_, int lane_) {
+    __device__ __forceinline__ void init(const void* stream_, char* lds_, int n_segs_, int wave_, int lane_,
+                                         bool cyclic_ = false) {
         stream = static_cast<const char*>(stream_);
         lds = lds_;
         n_segs = n_segs_;
+        cyclic = cyclic_;
         wave = __builtin_amdgcn_readfirstlane(wave_);
         lane = lane_;
         seg_issue = 0;
@@ -143,19 +146,42 @@ struct LdsRing {
                                              (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
         }
         ++seg_issue;
+        if (cyclic && seg_issue == n_segs) seg_issue = 0;
         slot_issue = slot_issue + 1 == LP_SLOTS ? 0 : slot_issue + 1;
     }
     // make the next segment readable: my share landed (the following segment's MY_LOADS loads may stay in
     // flight), everyone's share landed and everyone is done with the slot about to be refilled (barrier)
     __device__ __forceinline__ void acquire() {
+        acquire_wait();
+        issue();
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MY_LOADS) : "memory");
+    }
+    // The two halves of acquire() for callers that hide the refill's instructions under MFMAs: acquire_wait() as soon as
+    // every fragment of the current segment is in registers (it also waits for this wave's outstanding LDS reads:
+    // the barrier tells the others the slot may be overwritten), then issue_part(0..MY_LOADS-1) one at a time
+    // between MFMAs, then issue_done().
+    __device__ __forceinline__ void acquire_wait() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MY_LOADS) : "memory");
+#ifndef DAL3_ABL_BAR                                      // timing experiment only
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         slot_use = slot_use + 1 == LP_SLOTS ? 0 : slot_use + 1;
-        issue();
-        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void issue_part(int k) {
+        const int seg = seg_issue < n_segs ? seg_issue : n_segs - 1;
+        const int f = wave + 4 * k;
+        const char* src = stream + (size_t)seg * SLOT_BYTES + lane * 16 + f * 1024;
+        char* dst = lds + slot_issue * SLOT_BYTES + f * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+    __device__ __forceinline__ void issue_done() {
+        ++seg_issue;
+        if (cyclic && seg_issue == n_segs) seg_issue = 0;
+        slot_issue = slot_issue + 1 == LP_SLOTS ? 0 : slot_issue + 1;
     }
     template <class DT>
     __device__ __forceinline__ typename DT::v8 frag(int f) const {

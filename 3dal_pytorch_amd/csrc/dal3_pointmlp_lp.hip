@@ -8,6 +8,27 @@
 #define LP_WAVES 4
 
 // ------------------------------------------------------------------------------------------------
+#ifndef LP_PART
+#define LP_PART 3
+#endif
+// Diagnostic build only (-DDAL3_STAMP): s_memtime stamps of the decode kernel's phases (tools/stamps_lp.py).
+#if defined(DAL3_STAMP) && (LP_PART & 2)
+__device__ long long* g_stamps_lp = nullptr;
+extern "C" int dal3_debug_set_stamps_lp(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_lp), &p, sizeof(p));
+}
+#define LP_STAMP(k)                                                                               \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (lane == 0 && grp < 4096) g_stamps_lp[(grp * 4 + wave) * 8 + (k)] = t_;                \
+    } while (0)
+#else
+#define LP_STAMP(k)
+#endif
+
 template <class DT, int T>
 __global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN pts, int c_in, int n_pts,
                                                                 int tiles_per_item, float* __restrict__ g) {
@@ -54,46 +75,96 @@ __global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN
     }
 }
 
+// timing experiments only (tools/stamps_lp.py): what the main loop costs without its pack / init VALU work
+#ifdef DAL3_ABL_PACK
+template <class DT>
+__device__ __forceinline__ ActTile<DT> abl_pack(const f32x16& a) {
+    ActTile<DT> t;
+    typedef int int4v __attribute__((ext_vector_type(4)));
+    int4v u = {__float_as_int(a[0]), __float_as_int(a[1]), __float_as_int(a[2]), __float_as_int(a[3])};
+    int4v v = {__float_as_int(a[4]), __float_as_int(a[5]), __float_as_int(a[6]), __float_as_int(a[7])};
+    t.k[0] = __builtin_bit_cast(typename DT::v8, u);
+    t.k[1] = __builtin_bit_cast(typename DT::v8, v);
+    return t;
+}
+#define LP_PACK(x) abl_pack<DT>(x)
+#else
+#define LP_PACK(x) pack_relu<DT>(x)
+#endif
 // ------------------------------------------------------------------------------------------------
+// Persistent: 256 workgroups (one per CU: the ring takes 120 of the 160 KiB of LDS) each walk the 256-point groups
+// g = blockIdx.x, blockIdx.x + gridDim.x, ... The weight stream is the same for every group, so the ring simply
+// runs on cyclically: while a group's last segments are consumed the next group's first two are already on their
+// way, and only the first group of a workgroup pays the cold start of the ring (with one workgroup per group it was
+// paid 64 times per CU at 4096 x 1024, behind nothing: one wave per SIMD leaves no one to hide it).
 template <class DT, int T>
 __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN pts, int c_in, int n_pts,
-                                                                int tiles_per_item, const float* __restrict__ gbias,
+                                                                int tiles_per_item, int n_groups,
+                                                                const float* __restrict__ gbias,
                                                                 float* __restrict__ logits, uint8_t* __restrict__ mask) {
     constexpr int SEG = LP_DEC_SEG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // b2 64 | db2 256 | db3 128 | db4 128 | dw5 256 | db5 32  (= 864 floats), then the crop's dconv1 term (512)
     float* s_bias = reinterpret_cast<float*>(smem + LP_SLOTS * SEG * 1024);
     float* s_gb = s_bias + 864;
+    float* s_b1 = s_gb + 512;                              // conv1's bias (64): read per group, so not from global
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
-    const int64_t b = blockIdx.x / tiles_per_item;
-    const int n0 = ((blockIdx.x % tiles_per_item) * LP_WAVES + wave) * (32 * T);
 
     for (int i = threadIdx.x; i < 864; i += 256) s_bias[i] = w.bias_dec[i];
-    for (int i = threadIdx.x; i < 512; i += 256) s_gb[i] = gbias[b * 512 + i];
-    __syncthreads();
+    if (threadIdx.x < 64) s_b1[threadIdx.x] = w.b1[threadIdx.x];
+    float w1r[2][2];                                       // conv1's four A fragments (K = 2 x 2 raw channels)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w1r[i >> 1][i & 1] = w.w1[i * 64 + lane];
     const float* s_db2 = s_bias + 64;
     const float* s_db3 = s_bias + 320;
     const float* s_db4 = s_bias + 448;
     const float* s_dw5 = s_bias + 576;
     const float* s_db5 = s_bias + 832;
     LdsRing<SEG> ring;
-    ring.init(w.dec_stream, smem, LP_DEC_SEGS, wave, lane);
+    ring.init(w.dec_stream, smem, LP_DEC_SEGS, wave, lane, true);
+
+    // the NEXT group's points and dconv1 term are fetched into registers in the middle of the current group (after
+    // its main loop), a good 15 us before they are needed: read at the top of a group they cost an exposed HBM round
+    // trip per group (stamps: 15 % of the kernel sat in front of the first MFMA)
+    float in_nx[T][2], gb_nx[2];
+    auto prefetch = [&](int g) {
+        const int64_t bb = g / tiles_per_item;
+        load_points<2, T>(pts, bb, ((g % tiles_per_item) * LP_WAVES + wave) * (32 * T), n_pts, c_in, in_nx, lane);
+        gb_nx[0] = gbias[bb * 512 + threadIdx.x];
+        gb_nx[1] = gbias[bb * 512 + 256 + threadIdx.x];
+    };
+    prefetch(blockIdx.x);
+
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int64_t b = grp / tiles_per_item;
+    const int n0 = ((grp % tiles_per_item) * LP_WAVES + wave) * (32 * T);
+    // this crop's dconv1 term. Nobody still reads the previous group's: its last reader sits before the three
+    // barriers of dconv3/dconv4. The group's first acquire() (a barrier) publishes it — and s_bias, the first time.
+    s_gb[threadIdx.x] = gb_nx[0];
+    s_gb[256 + threadIdx.x] = gb_nx[1];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    LP_STAMP(0);
 
     ActTile<DT> x1[T][2], x2[T][2];
     {
-        float in[T][2];
-        load_points<2, T>(pts, b, n0, n_pts, c_in, in, lane);
-        f32x16 x1f[T][2];
-        first_layer<2, 2, T>(w.w1, w.b1, in, x1f, lane);
+        // conv1 in fp32 (first_layer of dal3_device.h with the weights in registers and the bias in LDS). s_b1 was
+        // written before this workgroup's first barrier... which the first group has not passed yet: it reads
+        // the bias after its first acquire() instead, so conv1 sits behind that barrier for every group.
+        ring.acquire();                                    // segment 0: conv2 (0..7) | dconv1a chunk 0 (8..11)
 #pragma unroll
-        for (int j = 0; j < T; ++j) {
-            x1[j][0] = pack_relu<DT>(x1f[j][0]);
-            x1[j][1] = pack_relu<DT>(x1f[j][1]);
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x16 bv = tile_from_channels(s_b1 + 32 * mt, h);
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                f32x16 acc = bv;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) acc = mfma32(w1r[mt][k], in_nx[j][k], acc);
+                x1[j][mt] = pack_relu<DT>(acc);
+            }
         }
     }
-    ring.acquire();                                        // segment 0: conv2 (0..7) | dconv1a chunk 0 (8..11)
     lp_layer<DT, 2, 2, T, SEG, 0, 2>(ring, 0, s_bias, x1, x2, lane);
 
     f32x16 a2[T][8];
@@ -111,10 +182,15 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
 #pragma unroll
         for (int i = 0; i < 4; ++i) d[i] = ring.template frag<DT>(f0 + i);
     };
-    auto dconv1_chunk = [&](f32x16 (&t)[T], int chunk, const frag_t (&q)[4]) {
-        const f32x16 init = tile_from_channels(s_gb + 32 * (chunk & 15), h);
+    // t <- the crop's dconv1 term of a chunk (the accumulators' initial value), read from LDS straight into both
+    // tiles' registers a half-iteration before the chunk's MFMAs
+    auto init_chunk = [&](f32x16 (&t)[T], int chunk) {
+#ifndef DAL3_ABL_INIT
 #pragma unroll
-        for (int j = 0; j < T; ++j) t[j] = init;
+        for (int j = 0; j < T; ++j) t[j] = tile_from_channels(s_gb + 32 * (chunk & 15), h);
+#endif
+    };
+    auto dconv1_chunk = [&](f32x16 (&t)[T], const frag_t (&q)[4]) {
         static_assert(T == 2, "MfmaAsm::block4x2 is written for two point tiles");
         MfmaAsm<DT>::block4x2(t[0], t[1], q[0], q[1], q[2], q[3], x2[0][0].k[0], x2[0][0].k[1], x2[0][1].k[0],
                               x2[0][1].k[1], x2[1][0].k[0], x2[1][0].k[1], x2[1][1].k[0], x2[1][1].k[1]);
@@ -126,21 +202,54 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
             for (int j = 0; j < T; ++j) a2[j][mt0 + (i >> 1)] = DT::mfma(a[i], p[j].k[i & 1], a2[j][mt0 + (i >> 1)]);
         }
     };
-    {
-        frag_t q[4];
-        load4(q, 8);
-        dconv1_chunk(tA, 0, q);
-    }
-    for (int i = 0; i < 8; ++i) {                          // segment 1+i: 1a(2i+1) | 2(2i) | 1a(2i+2) | 2(2i+1)
-        ring.acquire();
-        frag_t q[4], ga[4], gb[4];
-        ActTile<DT> p[T];
-        load4(q, 0);
-        load4(ga, 4);
-        DAL3_SCHED_FENCE();
-        dconv1_chunk(tB, 2 * i + 1, q);
+    // the same eight MFMAs with the ring's refill (10 LDS-DMA instructions and their address arithmetic) dealt out
+    // between them: issued in one piece after the barrier they cost ~650 cycles per segment with the matrix pipe idle
+    // The next segment's first eight fragments are read in the first gap (unconditionally: after the last round they
+    // are dconv3's, unused — a branch would cost the compiler its exact lgkmcnt) — behind the first MFMA, because
+    // hipcc cannot see acquire_wait()'s s_waitcnt and waits for `a` again: before the reads that wait is free.
+    auto mma4_refill = [&](const frag_t (&a)[4], const ActTile<DT> (&p)[T], int mt0, frag_t (&nq)[4], frag_t (&na)[4]) {
+        constexpr int ML = LdsRing<SEG>::MY_LOADS;
 #pragma unroll
-        for (int j = 0; j < T; ++j) p[j] = pack_relu<DT>(tA[j]);
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                a2[j][mt0 + (i >> 1)] = DT::mfma(a[i], p[j].k[i & 1], a2[j][mt0 + (i >> 1)]);
+                DAL3_SCHED_FENCE();
+                const int g = 2 * i + j;                   // gap 0..7: parts g, and 8 + g for g < ML - 8
+                if (g == 0) {
+                    load4(nq, 0);
+                    load4(na, 4);
+                }
+                if (g < ML) ring.issue_part(g);
+                if (8 + g < ML) ring.issue_part(8 + g);
+                DAL3_SCHED_FENCE();
+            }
+        }
+        static_assert(ML <= 16, "two parts per gap at most");
+        ring.issue_done();
+    };
+    frag_t q[4], ga[4], gb[4];
+    {
+        load4(q, 8);
+        init_chunk(tA, 0);
+        DAL3_SCHED_FENCE();
+        dconv1_chunk(tA, q);
+        init_chunk(tB, 1);
+    }
+    ring.acquire();                                        // segment 1
+    load4(q, 0);
+    load4(ga, 4);
+    LP_STAMP(1);
+    // Segment 1+i: 1a(2i+1) | 2(2i) | 1a(2i+2) | 2(2i+1). At the top of an iteration the segment's first eight
+    // fragments are already in registers: the barrier that opens the NEXT segment is taken as soon as the current
+    // one's last fragments have been read, its refill and the next segment's first reads go under the last eight MFMAs.
+    for (int i = 0; i < 8; ++i) {
+        ActTile<DT> p[T];
+        DAL3_SCHED_FENCE();
+        dconv1_chunk(tB, q);
+#pragma unroll
+        for (int j = 0; j < T; ++j) p[j] = LP_PACK(tA[j]);
+        init_chunk(tA, 2 * i + 2);                         // chunk 16 = zero filler weights, result unused
         load4(gb, 8);
         DAL3_SCHED_FENCE();
         mma4(ga, p, 0);
@@ -158,9 +267,10 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         DAL3_SCHED_FENCE();
         mma4(gb, p, 6);
         DAL3_SCHED_FENCE();
-        dconv1_chunk(tA, 2 * i + 2, q);                    // chunk 16 = zero filler, result unused
+        dconv1_chunk(tA, q);
 #pragma unroll
-        for (int j = 0; j < T; ++j) p[j] = pack_relu<DT>(tB[j]);
+        for (int j = 0; j < T; ++j) p[j] = LP_PACK(tB[j]);
+        init_chunk(tB, 2 * i + 3);
         load4(gb, 28);
         DAL3_SCHED_FENCE();
         mma4(ga, p, 0);
@@ -173,8 +283,15 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         DAL3_SCHED_FENCE();
         mma4(ga, p, 4);
         DAL3_SCHED_FENCE();
-        mma4(gb, p, 6);
+        ring.acquire_wait();                               // segment 2+i (after the loop: dconv3's first)
+        mma4_refill(gb, p, 6, q, ga);
         DAL3_SCHED_FENCE();
+    }
+    LP_STAMP(2);
+    {
+        const int nx = grp + (int)gridDim.x;
+        prefetch(nx < n_groups ? nx : grp);               // (the last group re-reads itself: uniform control flow)
+        __builtin_amdgcn_sched_barrier(0);                 // pinned here: left alone hipcc sinks loads to their first use
     }
     ActTile<DT> xd[T][8], y3[T][4];
 #pragma unroll
@@ -182,10 +299,11 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) xd[j][mt] = pack_relu<DT>(a2[j][mt]);
     }
-    ring.acquire();                                        // dconv3 out-tiles 0,1
+    LP_STAMP(3);
     lp_layer<DT, 8, 4, T, SEG, 0, 2>(ring, 0, s_db3, xd, y3, lane);
     ring.acquire();                                        // dconv3 out-tiles 2,3
     lp_layer<DT, 8, 4, T, SEG, 2, 2>(ring, 0, s_db3, xd, y3, lane);
+    LP_STAMP(4);
     ring.acquire();                                        // dconv4
     f32x16 y4[T][4];
 #pragma unroll
@@ -199,6 +317,7 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         for (int j = 0; j < T; ++j) y4[j][m] = relu16(acc[j]);
     }
 
+    LP_STAMP(5);
     float l0[T], l1[T];
 #pragma unroll
     for (int j = 0; j < T; ++j) l0[j] = l1[j] = 0.0f;
@@ -232,6 +351,8 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
             mask[b * n_pts + n] = s0 < s1 ? 1 : 0;
         }
     }
+    LP_STAMP(6);
+  }   // groups
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -312,16 +433,29 @@ static hipError_t enc_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, fl
     if (pad8 * 8 <= pad4 * 9) return enc_lp_t<DT, 8>(w, pts, c_in, B, N, g, s);
     return enc_lp_t<DT, 4>(w, pts, c_in, B, N, g, s);
 }
+static int lp_cu_count() {                                  // one persistent workgroup per CU
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        n = v;
+    }
+    return n;
+}
 template <class DT>
 static hipError_t dec_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, const float* gbias, float* logits,
                          uint8_t* mask, hipStream_t s) {
     constexpr int T = DAL3_LP_DEC_T;
-    const size_t lds = LP_SLOTS * LP_DEC_SEG * 1024 + (864 + 512) * 4;
+    const size_t lds = LP_SLOTS * LP_DEC_SEG * 1024 + (864 + 512 + 64) * 4;
     auto k = ins_seg_decode_lp_kernel<DT, T>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int tpi = lp_tiles(N, T);
-    hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * tpi)), dim3(256), lds, s, w, pts, c_in, N, tpi, gbias, logits, mask);
+    const int64_t n_groups = (int64_t)B * tpi;
+    if (n_groups > 0x7fffffff) return hipErrorInvalidValue;
+    const int64_t grid = n_groups < lp_cu_count() ? n_groups : lp_cu_count();
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, s, w, pts, c_in, N, tpi, (int)n_groups, gbias, logits, mask);
     return hipGetLastError();
 }
 template <class DT, int KS, int C1, int C2, int C3>
@@ -341,9 +475,6 @@ static hipError_t head_lp(const PointHeadLpW& w, BCN x, int c_in, int B, int M, 
 // -amdgpu-mfma-vgpr-form` (accumulators in arch VGPRs: the pack/ReLU/max epilogues then need no
 // v_accvgpr_read; encode 1.18 -> 1.00 ms, heads 0.90 -> 0.86 ms), LP_PART=2 -> decode without it (its 256
 // accumulator registers only fit beside the rest in the AGPR half; with the flag it slows 1.92 -> 2.27 ms).
-#ifndef LP_PART
-#define LP_PART 3
-#endif
 #if LP_PART & 1
 hipError_t launch_ins_seg_encode_lp(int dtype, const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
     return dtype == DAL3_BF16 ? enc_lp<BF16>(w, pts, c_in, B, N, g, s) : enc_lp<FP16>(w, pts, c_in, B, N, g, s);
