@@ -107,6 +107,17 @@ __device__ __forceinline__ ActTile<DT> pack_relu(const f32x16& acc) {
     return t;
 }
 
+// one dword of pack_relu: two accumulator registers -> a ReLU'd 16-bit pair
+template <class DT>
+__device__ __forceinline__ int pack_relu_pair(float a, float b) {
+    const f32x2 p = {a, b};
+    const typename DT::v2 q = __builtin_convertvector(p, typename DT::v2);
+    short2_t s = __builtin_bit_cast(short2_t, q);
+    const short2_t zero = {0, 0};
+    s = __builtin_elementwise_max(s, zero);
+    return __builtin_bit_cast(int, s);
+}
+
 #define LP_SLOTS 3
 
 // LDS ring of weight segments. All state is wave-uniform.

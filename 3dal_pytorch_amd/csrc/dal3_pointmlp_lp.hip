@@ -75,22 +75,6 @@ __global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN
     }
 }
 
-// timing experiments only (tools/stamps_lp.py): what the main loop costs without its pack / init VALU work
-#ifdef DAL3_ABL_PACK
-template <class DT>
-__device__ __forceinline__ ActTile<DT> abl_pack(const f32x16& a) {
-    ActTile<DT> t;
-    typedef int int4v __attribute__((ext_vector_type(4)));
-    int4v u = {__float_as_int(a[0]), __float_as_int(a[1]), __float_as_int(a[2]), __float_as_int(a[3])};
-    int4v v = {__float_as_int(a[4]), __float_as_int(a[5]), __float_as_int(a[6]), __float_as_int(a[7])};
-    t.k[0] = __builtin_bit_cast(typename DT::v8, u);
-    t.k[1] = __builtin_bit_cast(typename DT::v8, v);
-    return t;
-}
-#define LP_PACK(x) abl_pack<DT>(x)
-#else
-#define LP_PACK(x) pack_relu<DT>(x)
-#endif
 // ------------------------------------------------------------------------------------------------
 // Persistent: 256 workgroups (one per CU: the ring takes 120 of the 160 KiB of LDS) each walk the 256-point groups
 // g = blockIdx.x, blockIdx.x + gridDim.x, ... The weight stream is the same for every group, so the ring simply
@@ -185,10 +169,12 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     // t <- the crop's dconv1 term of a chunk (the accumulators' initial value), read from LDS straight into both
     // tiles' registers a half-iteration before the chunk's MFMAs
     auto init_chunk = [&](f32x16 (&t)[T], int chunk) {
-#ifndef DAL3_ABL_INIT
 #pragma unroll
-        for (int j = 0; j < T; ++j) t[j] = tile_from_channels(s_gb + 32 * (chunk & 15), h);
-#endif
+        for (int j = 0; j < T; ++j) {
+            int off = 32 * (chunk & 15);
+            asm volatile("" : "+v"(off));                  // one read per tile: hipcc would read once and copy 16 registers
+            t[j] = tile_from_channels(s_gb + off, h);      // (the offset, not the pointer: that would lose its address space)
+        }
     };
     auto dconv1_chunk = [&](f32x16 (&t)[T], const frag_t (&q)[4]) {
         static_assert(T == 2, "MfmaAsm::block4x2 is written for two point tiles");
@@ -228,13 +214,42 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         static_assert(ML <= 16, "two parts per gap at most");
         ring.issue_done();
     };
+    // ... and with the 16-bit packing (ReLU, round) of a finished dconv1 chunk dealt out between them, two register
+    // pairs per gap: done in one piece (32 VALU) in front of the MFMAs that need it, the matrix pipe waited for it
+    auto mma4_pack = [&](const frag_t (&a)[4], const ActTile<DT> (&p)[T], int mt0, const f32x16 (&t)[T], ActTile<DT> (&pn)[T]) {
+        int4_t w[T][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                a2[j][mt0 + (i >> 1)] = DT::mfma(a[i], p[j].k[i & 1], a2[j][mt0 + (i >> 1)]);
+                DAL3_SCHED_FENCE();
+                const int g = 2 * i + j;                   // gap g packs register pairs 2g, 2g+1 of the 16 (T x 2 x 4)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int k = 2 * g + e, tj = k >> 3, ts = (k >> 2) & 1, ti = k & 3;
+                    w[tj][ts][ti] = pack_relu_pair<DT>(t[tj][8 * ts + 2 * ti], t[tj][8 * ts + 2 * ti + 1]);
+                }
+                DAL3_SCHED_FENCE();
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            pn[j].k[0] = __builtin_bit_cast(frag_t, w[j][0]);
+            pn[j].k[1] = __builtin_bit_cast(frag_t, w[j][1]);
+        }
+    };
     frag_t q[4], ga[4], gb[4];
+    ActTile<DT> pA[T], pB[T];
     {
         load4(q, 8);
         init_chunk(tA, 0);
         DAL3_SCHED_FENCE();
         dconv1_chunk(tA, q);
         init_chunk(tB, 1);
+#pragma unroll
+        for (int j = 0; j < T; ++j) pA[j] = pack_relu<DT>(tA[j]);
+        init_chunk(tA, 2);
     }
     ring.acquire();                                        // segment 1
     load4(q, 0);
@@ -243,48 +258,45 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     // Segment 1+i: 1a(2i+1) | 2(2i) | 1a(2i+2) | 2(2i+1). At the top of an iteration the segment's first eight
     // fragments are already in registers: the barrier that opens the NEXT segment is taken as soon as the current
     // one's last fragments have been read, its refill and the next segment's first reads go under the last eight MFMAs.
+    // pA / pB: the packed chunk the first / second half's dconv2 MFMAs consume; each is rewritten (from tA / tB, which
+    // is then re-initialised for the chunk after next) under the other half's MFMAs.
     for (int i = 0; i < 8; ++i) {
-        ActTile<DT> p[T];
         DAL3_SCHED_FENCE();
-        dconv1_chunk(tB, q);
-#pragma unroll
-        for (int j = 0; j < T; ++j) p[j] = LP_PACK(tA[j]);
-        init_chunk(tA, 2 * i + 2);                         // chunk 16 = zero filler weights, result unused
+        dconv1_chunk(tB, q);                               // chunk 2i+1
         load4(gb, 8);
         DAL3_SCHED_FENCE();
-        mma4(ga, p, 0);
+        mma4(ga, pA, 0);
         DAL3_SCHED_FENCE();
         load4(ga, 12);
         DAL3_SCHED_FENCE();
-        mma4(gb, p, 2);
+        mma4(gb, pA, 2);
         DAL3_SCHED_FENCE();
         load4(gb, 16);
         DAL3_SCHED_FENCE();
-        mma4(ga, p, 4);
+        mma4(ga, pA, 4);
         DAL3_SCHED_FENCE();
         load4(q, 20);
         load4(ga, 24);
         DAL3_SCHED_FENCE();
-        mma4(gb, p, 6);
-        DAL3_SCHED_FENCE();
-        dconv1_chunk(tA, q);
-#pragma unroll
-        for (int j = 0; j < T; ++j) p[j] = LP_PACK(tB[j]);
+        mma4_pack(gb, pA, 6, tB, pB);
         init_chunk(tB, 2 * i + 3);
+        DAL3_SCHED_FENCE();
+        dconv1_chunk(tA, q);                               // chunk 2i+2 (16 = zero filler weights, result unused)
         load4(gb, 28);
         DAL3_SCHED_FENCE();
-        mma4(ga, p, 0);
+        mma4(ga, pB, 0);
         DAL3_SCHED_FENCE();
         load4(ga, 32);
         DAL3_SCHED_FENCE();
-        mma4(gb, p, 2);
+        mma4(gb, pB, 2);
         DAL3_SCHED_FENCE();
         load4(gb, 36);
         DAL3_SCHED_FENCE();
-        mma4(ga, p, 4);
+        mma4_pack(ga, pB, 4, tA, pA);
+        init_chunk(tA, 2 * i + 4);
         DAL3_SCHED_FENCE();
         ring.acquire_wait();                               // segment 2+i (after the loop: dconv3's first)
-        mma4_refill(gb, p, 6, q, ga);
+        mma4_refill(gb, pB, 6, q, ga);
         DAL3_SCHED_FENCE();
     }
     LP_STAMP(2);
