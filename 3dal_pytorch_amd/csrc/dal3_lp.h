@@ -148,12 +148,14 @@ struct LdsRing {
     // this wave's quarter of the next segment -> slot_issue (past the stream's end: re-read the last one)
     __device__ __forceinline__ void issue() {
         const int seg = seg_issue < n_segs ? seg_issue : n_segs - 1;
-        const char* src = stream + (size_t)seg * SLOT_BYTES + lane * 16;
+        // uniform 64-bit base + unsigned 32-bit lane offset: the scalar-base form of the load (one VGPR of address per
+        // lane instead of a 64-bit pair that has to be built, kept or spilled)
+        const char* src = stream + (size_t)seg * SLOT_BYTES;
         char* dst = lds + slot_issue * SLOT_BYTES;
 #pragma unroll
         for (int k = 0; k < MY_LOADS; ++k) {
             const int f = wave + 4 * k;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024 + (uint32_t)(lane * 16)),
                                              (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
         }
         ++seg_issue;
@@ -184,9 +186,9 @@ struct LdsRing {
     __device__ __forceinline__ void issue_part(int k) {
         const int seg = seg_issue < n_segs ? seg_issue : n_segs - 1;
         const int f = wave + 4 * k;
-        const char* src = stream + (size_t)seg * SLOT_BYTES + lane * 16 + f * 1024;
+        const char* src = stream + (size_t)seg * SLOT_BYTES + f * 1024;
         char* dst = lds + slot_issue * SLOT_BYTES + f * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint32_t)(lane * 16)),
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
     __device__ __forceinline__ void issue_done() {

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN
     }
 }
 
+#define LP_DEC_SMALL_BYTES 7168                          // (864 + 512 + 64 + 256) floats, rounded up to 1 KiB
 // ------------------------------------------------------------------------------------------------
 // Persistent: 256 workgroups (one per CU: the ring takes 120 of the 160 KiB of LDS) each walk the 256-point groups
 // g = blockIdx.x, blockIdx.x + gridDim.x, ... The weight stream is the same for every group, so the ring simply
@@ -88,36 +89,45 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
                                                                 float* __restrict__ logits, uint8_t* __restrict__ mask) {
     constexpr int SEG = LP_DEC_SEG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: the small arrays FIRST, the ring behind them: every array is then reached from one per-lane register
+    // (16 h) plus an immediate offset (< 64 KiB); placed behind the 120-KiB ring each array needed an address
+    // register of its own, hipcc spilled them, and every reload sat behind an s_waitcnt vmcnt(0) that drained the
+    // ring's LDS-DMA right after it had been issued.
     // b2 64 | db2 256 | db3 128 | db4 128 | dw5 256 | db5 32  (= 864 floats), then the crop's dconv1 term (512)
-    float* s_bias = reinterpret_cast<float*>(smem + LP_SLOTS * SEG * 1024);
+    float* s_bias = reinterpret_cast<float*>(smem);
     float* s_gb = s_bias + 864;
-    float* s_b1 = s_gb + 512;                              // conv1's bias (64): read per group, so not from global
+    float* s_b1 = s_gb + 512;                              // conv1's bias (64) and its four A fragments (4 x 64): read
+    float* s_w1 = s_b1 + 64;                               // per group, so from LDS, not from global
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: everything derived from it too
     const int h = lane >> 5;
 
     for (int i = threadIdx.x; i < 864; i += 256) s_bias[i] = w.bias_dec[i];
     if (threadIdx.x < 64) s_b1[threadIdx.x] = w.b1[threadIdx.x];
-    float w1r[2][2];                                       // conv1's four A fragments (K = 2 x 2 raw channels)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w1r[i >> 1][i & 1] = w.w1[i * 64 + lane];
+    s_w1[threadIdx.x] = w.w1[threadIdx.x];
     const float* s_db2 = s_bias + 64;
     const float* s_db3 = s_bias + 320;
     const float* s_db4 = s_bias + 448;
     const float* s_dw5 = s_bias + 576;
     const float* s_db5 = s_bias + 832;
     LdsRing<SEG> ring;
-    ring.init(w.dec_stream, smem, LP_DEC_SEGS, wave, lane, true);
+    ring.init(w.dec_stream, smem + LP_DEC_SMALL_BYTES, LP_DEC_SEGS, wave, lane, true);
 
     // the NEXT group's points and dconv1 term are fetched into registers in the middle of the current group (after
     // its main loop), a good 15 us before they are needed: read at the top of a group they cost an exposed HBM round
     // trip per group (stamps: 15 % of the kernel sat in front of the first MFMA)
     float in_nx[T][2], gb_nx[2];
     auto prefetch = [&](int g) {
+        // the lane id goes through an opaque asm: hipcc otherwise computes the per-lane address parts once, keeps them
+        // (64-bit, per tile and channel) across the main loop where registers are scarcest, spills them, and each
+        // reload is a scratch read behind an s_waitcnt vmcnt(0) that drains the ring's LDS-DMA (2,400 ticks per group)
+        unsigned z = 0;                                    // (not `lane`, and not hoistable: either would be spilled too)
+        asm volatile("" : "+v"(z));
+        const int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
         const int64_t bb = g / tiles_per_item;
-        load_points<2, T>(pts, bb, ((g % tiles_per_item) * LP_WAVES + wave) * (32 * T), n_pts, c_in, in_nx, lane);
-        gb_nx[0] = gbias[bb * 512 + threadIdx.x];
-        gb_nx[1] = gbias[bb * 512 + 256 + threadIdx.x];
+        load_points<2, T>(pts, bb, ((g % tiles_per_item) * LP_WAVES + wave) * (32 * T), n_pts, c_in, in_nx, l);
+        gb_nx[0] = gbias[bb * 512 + wave * 64 + l];
+        gb_nx[1] = gbias[bb * 512 + 256 + wave * 64 + l];
     };
     prefetch(blockIdx.x);
 
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
             for (int j = 0; j < T; ++j) {
                 f32x16 acc = bv;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) acc = mfma32(w1r[mt][k], in_nx[j][k], acc);
+                for (int k = 0; k < 2; ++k) acc = mfma32(s_w1[(mt * 2 + k) * 64 + lane], in_nx[j][k], acc);
                 x1[j][mt] = pack_relu<DT>(acc);
             }
         }
@@ -459,7 +469,7 @@ template <class DT>
 static hipError_t dec_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, const float* gbias, float* logits,
                          uint8_t* mask, hipStream_t s) {
     constexpr int T = DAL3_LP_DEC_T;
-    const size_t lds = LP_SLOTS * LP_DEC_SEG * 1024 + (864 + 512 + 64) * 4;
+    const size_t lds = LP_SLOTS * LP_DEC_SEG * 1024 + LP_DEC_SMALL_BYTES;
     auto k = ins_seg_decode_lp_kernel<DT, T>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
