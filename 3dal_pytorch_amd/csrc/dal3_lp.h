@@ -329,35 +329,99 @@ __device__ __forceinline__ void lp_tile_max(const f32x16 (&acc)[T], const float*
 // The last layer of a stack with the max over points fused, for the TPS out-tiles of the current ring slot (their
 // fragments start at fragment 0): one fragment stream, groups of four read a group ahead — across tile boundaries
 // too, so that a tile's max epilogue (VALU + LDS atomics) runs while the next tile's first fragments are in flight.
-template <class DT, int KT, int T, int SEG, int TPS>
-__device__ __forceinline__ void lp_max_tiles(const LdsRing<SEG>& ring, const ActTile<DT> (&X)[T][KT], const float* bias,
-                                             int* smax, int lane) {
-    typedef typename DT::v8 frag_t;
-    constexpr int FPT = KT * 2, NG = TPS * FPT / 4;
-    static_assert(FPT % 4 == 0, "whole groups of four fragments per tile");
-    frag_t g[2][4];
-    f32x16 acc[T];
+// Max epilogue of a TRANSPOSED tile (points on the MFMA rows = the 16 registers, channels on the columns = the lanes):
+// the max over the points of the wave's T tiles is a max over registers — elementwise VALU, no lane exchange; the two
+// lane halves hold the same 32 channels and simply both take part in the LDS atomic (two lanes per address).
+template <int T>
+__device__ __forceinline__ void lp_tile_max_t(const f32x16 (&acc)[T], const float* bias, int* smax, int lane) {
+    float m = acc[0][0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) g[0][i] = ring.template frag<DT>(i);
+    for (int j = 0; j < T; ++j) {
+#pragma unroll
+        for (int r = (j == 0 ? 1 : 0); r < 16; ++r) m = __builtin_fmaxf(m, acc[j][r]);
+    }
+    const int ch = lane & 31;
+    int bits = __float_as_int(m + bias[ch]);
+    bits = bits > 0 ? bits : 0;
+    atomicMax(smax + ch, bits);
+}
+
+// The caller acquires the FIRST segment of the layer and passes first = true; every call then opens the next segment
+// itself, early: as soon as the slot's last fragments have been read the barrier is taken, and the refill's LDS-DMA
+// instructions and the next segment's first four fragment reads (into g, carried to the next call) go between the last
+// group's MFMAs. (Taken in one piece in front of a segment, wait + barrier + refill + first reads cost ~1,100 cycles
+// with the matrix pipe idle.) After the layer's last segment the ring is one segment ahead, which is what a following
+// layer's acquire() or the next group of a persistent kernel expects... so the caller must not acquire again.
+template <class DT, int KT, int T, int SEG, int TPS>
+__device__ __forceinline__ void lp_max_tiles(LdsRing<SEG>& ring, const ActTile<DT> (&X)[T][KT], const float* bias,
+                                             int* smax, int lane, typename DT::v8 (&g)[2][4], bool first) {
+    typedef typename DT::v8 frag_t;
+    constexpr int FPT = KT * 2, NG = TPS * FPT / 4, ML = LdsRing<SEG>::MY_LOADS;
+    static_assert(FPT % 4 == 0, "whole groups of four fragments per tile");
+    static_assert(NG % 2 == 0, "the carried group must be g[0]");
+    static_assert(ML <= 4 * T * 2, "two refill parts per MFMA gap at most");
+    // Up to four point tiles per wave there is room for TWO accumulator sets: a tile's max epilogue (about 50 + 16 T
+    // VALU / swizzle / LDS-atomic instructions) is then placed with the first 4 T MFMAs of the NEXT tile and dealt out
+    // between them (sched_group_barrier), instead of standing between the two tiles with the matrix pipe idle.
+    constexpr bool DB = T <= 4 && TPS > 1;
+    f32x16 acc[DB ? 2 : 1][T];
+    if (first) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[0][i] = ring.template frag<DT>(i);
+    }
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
-        if (gi + 1 < NG) {
+        const bool last = gi == NG - 1;
+        if (!last) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) g[(gi + 1) & 1][i] = ring.template frag<DT>(4 * (gi + 1) + i);
         }
         DAL3_SCHED_FENCE();
+        if (last) ring.acquire_wait();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = 4 * gi + i, k = f % FPT;
+            const int f = 4 * gi + i, k = f % FPT, c = DB ? (f / FPT) & 1 : 0;
             if (k == 0) {
 #pragma unroll
-                for (int j = 0; j < T; ++j) acc[j] = f32x16{};
+                for (int j = 0; j < T; ++j) acc[c][j] = f32x16{};
             }
 #pragma unroll
-            for (int j = 0; j < T; ++j) acc[j] = DT::mfma(g[gi & 1][i], X[j][k >> 1].k[k & 1], acc[j]);
-            if (k == FPT - 1) lp_tile_max<T>(acc, bias + 32 * (f / FPT), smax + 32 * (f / FPT), lane);
+            for (int j = 0; j < T; ++j) {
+                acc[c][j] = DT::mfma(X[j][k >> 1].k[k & 1], g[gi & 1][i], acc[c][j]);      // operands swapped: D^T
+                if (last) {
+                    const int n = i * T + j;               // gap n of the 4 T after the barrier
+                    DAL3_SCHED_FENCE();
+                    if (n == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) g[0][q] = ring.template frag<DT>(q);
+                    }
+                    if (4 * T >= ML) {
+                        if (n < ML) ring.issue_part(n);
+                    } else {
+                        if (2 * n < ML) ring.issue_part(2 * n);
+                        if (2 * n + 1 < ML) ring.issue_part(2 * n + 1);
+                    }
+                    DAL3_SCHED_FENCE();
+                }
+            }
+            if (!DB && k == FPT - 1) lp_tile_max_t<T>(acc[0], bias + 32 * (f / FPT), smax + 32 * (f / FPT), lane);
+        }
+        if (last) ring.issue_done();
+        if (DB && (4 * gi) % FPT == 0 && gi > 0 && !last) {
+            const int t = 4 * gi / FPT - 1;                // the tile that finished with the previous group
+            lp_tile_max_t<T>(acc[t & 1], bias + 32 * t, smax + 32 * t, lane);
+#pragma unroll
+            for (int n = 0; n < 4 * T; ++n) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // up to four VALU
+                __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);     // up to two DS (swizzles, the atomic)
+            }
         }
         DAL3_SCHED_FENCE();
+    }
+    if (DB) {
+        if (FPT == 4) lp_tile_max_t<T>(acc[(TPS - 2) & 1], bias + 32 * (TPS - 2), smax + 32 * (TPS - 2), lane);
+        lp_tile_max_t<T>(acc[(TPS - 1) & 1], bias + 32 * (TPS - 1), smax + 32 * (TPS - 1), lane);
     }
 }
 

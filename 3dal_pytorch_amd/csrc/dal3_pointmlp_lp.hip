@@ -12,9 +12,13 @@
 #define LP_PART 3
 #endif
 // Diagnostic build only (-DDAL3_STAMP): s_memtime stamps of the decode kernel's phases (tools/stamps_lp.py).
-#if defined(DAL3_STAMP) && (LP_PART & 2)
-__device__ long long* g_stamps_lp = nullptr;
+#if defined(DAL3_STAMP)
+__device__ long long* g_stamps_lp = nullptr;               // one per translation unit (LP_PART 1: encode, 2: decode)
+#if LP_PART & 2
 extern "C" int dal3_debug_set_stamps_lp(void* p) {
+#else
+extern "C" int dal3_debug_set_stamps_lp_enc(void* p) {
+#endif
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_lp), &p, sizeof(p));
 }
 #define LP_STAMP(k)                                                                               \
@@ -44,6 +48,10 @@ __global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN
     for (int i = threadIdx.x; i < 1280; i += 256) s_bias[i] = w.bias_enc[i];
     for (int i = threadIdx.x; i < 1024; i += 256) s_max[i] = 0;
     __syncthreads();
+#ifdef DAL3_STAMP
+    const int grp = blockIdx.x;
+#endif
+    LP_STAMP(0);
     LdsRing<SEG> ring;
     ring.init(w.enc_stream, smem, LP_ENC_SEGS, wave, lane);
 
@@ -59,20 +67,24 @@ __global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN
             x1[j][1] = pack_relu<DT>(x1f[j][1]);
         }
     }
+    LP_STAMP(1);
     ring.acquire();                                        // segment 0: conv2 | conv3 | conv4
     lp_layer<DT, 2, 2, T, SEG, 0, 2>(ring, 0, s_bias, x1, x2, lane);
     lp_layer<DT, 2, 2, T, SEG, 0, 2>(ring, 8, s_bias + 64, x2, x3, lane);
     lp_layer<DT, 2, 4, T, SEG, 0, 4>(ring, 16, s_bias + 128, x3, x4, lane);
-    for (int seg = 0; seg < 8; ++seg) {                    // conv5: 4 out-tiles (32 fragments) per segment
-        ring.acquire();
-        lp_max_tiles<DT, 4, T, SEG, 4>(ring, x4, s_bias + 256 + 128 * seg, s_max + 128 * seg, lane);
-    }
+    LP_STAMP(2);
+    typename DT::v8 g5[2][4];
+    ring.acquire();
+    for (int seg = 0; seg < 8; ++seg)                      // conv5: 4 out-tiles (32 fragments) per segment
+        lp_max_tiles<DT, 4, T, SEG, 4>(ring, x4, s_bias + 256 + 128 * seg, s_max + 128 * seg, lane, g5, seg == 0);
+    LP_STAMP(3);
     __syncthreads();
     int* gi = reinterpret_cast<int*>(g + b * 1024);
     for (int i = threadIdx.x; i < 1024; i += 256) {
         const int v = s_max[i];
         if (v > 0) atomicMax(gi + i, v);
     }
+    LP_STAMP(4);
 }
 
 #define LP_DEC_SMALL_BYTES 7168                          // (864 + 512 + 64 + 256) floats, rounded up to 1 KiB
@@ -422,10 +434,10 @@ __global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN 
     lp_seg_layers<DT, K2, M2, T, SEG, TPS2, 0>(ring, s_bias, x1, x2, lane);
     lp_seg_layers<DT, K3, M3, T, SEG, TPS3, 0>(ring, s_bias + C2, x2, x3, lane);
     const float* s_b4 = s_bias + C2 + C3;
-    for (int seg = 0; seg < M4 / TPS4; ++seg) {
-        ring.acquire();
-        lp_max_tiles<DT, K4, T, SEG, TPS4>(ring, x3, s_b4 + 32 * TPS4 * seg, s_max + 32 * TPS4 * seg, lane);
-    }
+    typename DT::v8 g4[2][4];
+    ring.acquire();
+    for (int seg = 0; seg < M4 / TPS4; ++seg)
+        lp_max_tiles<DT, K4, T, SEG, TPS4>(ring, x3, s_b4 + 32 * TPS4 * seg, s_max + 32 * TPS4 * seg, lane, g4, seg == 0);
     __syncthreads();
     int* fi = reinterpret_cast<int*>(feat + b * 512);
     for (int i = threadIdx.x; i < 512; i += 256) {
@@ -452,7 +464,9 @@ static hipError_t enc_lp_t(const InsSegLpW& w, BCN pts, int c_in, int B, int N, 
 template <class DT>
 static hipError_t enc_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
     const int64_t pad8 = (int64_t)lp_tiles(N, 8) * 1024, pad4 = (int64_t)lp_tiles(N, 4) * 512;
+#ifndef DAL3_LP_ENC_T4                                     // (A/B switch: always four tiles per wave)
     if (pad8 * 8 <= pad4 * 9) return enc_lp_t<DT, 8>(w, pts, c_in, B, N, g, s);
+#endif
     return enc_lp_t<DT, 4>(w, pts, c_in, B, N, g, s);
 }
 static int lp_cu_count() {                                  // one persistent workgroup per CU
