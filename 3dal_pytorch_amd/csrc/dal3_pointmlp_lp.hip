@@ -33,58 +33,83 @@ extern "C" int dal3_debug_set_stamps_lp_enc(void* p) {
 #define LP_STAMP(k)
 #endif
 
+#define LP_ENC_SMALL_BYTES 11264                         // (1280 + 1024 + 64 + 256) floats, rounded up to 1 KiB
+// Persistent like the decode kernel below (one workgroup per CU walking the 128 T-point groups, cyclic weight ring,
+// the next group's points fetched a layer ahead). T = 4: with eight tiles per wave conv4's output (256 registers) no
+// longer fits the arch VGPRs next to the accumulators and every conv5 MFMA paid v_accvgpr_read for its B operand
+// (54 against 40 cycles per MFMA); what made T = 4 slower before — twice the workgroups, each with its start-up, and
+// twice the ring refills per point — is gone with persistence and with the refills hidden under MFMAs.
 template <class DT, int T>
 __global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN pts, int c_in, int n_pts,
-                                                                int tiles_per_item, float* __restrict__ g) {
+                                                                int tiles_per_item, int n_groups, float* __restrict__ g) {
     constexpr int SEG = LP_ENC_SEG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_bias = reinterpret_cast<float*>(smem + LP_SLOTS * SEG * 1024);   // b2 64 | b3 64 | b4 128 | b5 1024
-    int* s_max = reinterpret_cast<int*>(s_bias + 1280);                       // 1024 channel maxima of this workgroup
+    // small arrays first (one address register + immediates, see the decode kernel), the ring behind them
+    float* s_bias = reinterpret_cast<float*>(smem);        // b2 64 | b3 64 | b4 128 | b5 1024
+    int* s_max = reinterpret_cast<int*>(s_bias + 1280);    // 1024 channel maxima of the current group
+    float* s_b1 = s_bias + 1280 + 1024;                    // conv1: bias (64) and its four A fragments (4 x 64)
+    float* s_w1 = s_b1 + 64;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int64_t b = blockIdx.x / tiles_per_item;
-    const int n0 = ((blockIdx.x % tiles_per_item) * LP_WAVES + wave) * (32 * T);   // past the end: duplicates of the last point
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5;
 
     for (int i = threadIdx.x; i < 1280; i += 256) s_bias[i] = w.bias_enc[i];
     for (int i = threadIdx.x; i < 1024; i += 256) s_max[i] = 0;
+    if (threadIdx.x < 64) s_b1[threadIdx.x] = w.b1[threadIdx.x];
+    s_w1[threadIdx.x] = w.w1[threadIdx.x];
     __syncthreads();
-#ifdef DAL3_STAMP
-    const int grp = blockIdx.x;
-#endif
-    LP_STAMP(0);
     LdsRing<SEG> ring;
-    ring.init(w.enc_stream, smem, LP_ENC_SEGS, wave, lane);
+    ring.init(w.enc_stream, smem + LP_ENC_SMALL_BYTES, LP_ENC_SEGS, wave, lane, true);
 
+    float in_nx[T][2];
+    auto prefetch = [&](int gq) {                          // (addresses rebuilt from a fresh lane id: see the decode kernel)
+        unsigned z = 0;
+        asm volatile("" : "+v"(z));
+        const int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+        load_points<2, T>(pts, gq / tiles_per_item, ((gq % tiles_per_item) * LP_WAVES + wave) * (32 * T), n_pts, c_in, in_nx, l);
+    };
+    prefetch(blockIdx.x);
+    ring.acquire();                                        // segment 0 of the first group: conv2 | conv3 | conv4
+
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int64_t b = grp / tiles_per_item;
+    LP_STAMP(0);
     ActTile<DT> x1[T][2], x2[T][2], x3[T][2], x4[T][4];
-    {
-        float in[T][2];
-        load_points<2, T>(pts, b, n0, n_pts, c_in, in, lane);
-        f32x16 x1f[T][2];
-        first_layer<2, 2, T>(w.w1, w.b1, in, x1f, lane);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {                       // conv1 in fp32 (first_layer of dal3_device.h, operands from LDS)
+        const f32x16 bv = tile_from_channels(s_b1 + 32 * mt, h);
 #pragma unroll
         for (int j = 0; j < T; ++j) {
-            x1[j][0] = pack_relu<DT>(x1f[j][0]);
-            x1[j][1] = pack_relu<DT>(x1f[j][1]);
+            f32x16 acc = bv;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) acc = mfma32(s_w1[(mt * 2 + k) * 64 + lane], in_nx[j][k], acc);
+            x1[j][mt] = pack_relu<DT>(acc);
         }
     }
     LP_STAMP(1);
-    ring.acquire();                                        // segment 0: conv2 | conv3 | conv4
     lp_layer<DT, 2, 2, T, SEG, 0, 2>(ring, 0, s_bias, x1, x2, lane);
     lp_layer<DT, 2, 2, T, SEG, 0, 2>(ring, 8, s_bias + 64, x2, x3, lane);
     lp_layer<DT, 2, 4, T, SEG, 0, 4>(ring, 16, s_bias + 128, x3, x4, lane);
+    {
+        const int nx = grp + (int)gridDim.x;
+        prefetch(nx < n_groups ? nx : grp);               // (the last group re-reads itself: uniform control flow)
+        __builtin_amdgcn_sched_barrier(0);
+    }
     LP_STAMP(2);
     typename DT::v8 g5[2][4];
     ring.acquire();
-    for (int seg = 0; seg < 8; ++seg)                      // conv5: 4 out-tiles (32 fragments) per segment
+    for (int seg = 0; seg < 8; ++seg)                      // conv5: 4 out-tiles (32 fragments) per segment; the last
         lp_max_tiles<DT, 4, T, SEG, 4>(ring, x4, s_bias + 256 + 128 * seg, s_max + 128 * seg, lane, g5, seg == 0);
-    LP_STAMP(3);
+    LP_STAMP(3);                                           // call has already opened the next group's segment 0
     __syncthreads();
     int* gi = reinterpret_cast<int*>(g + b * 1024);
     for (int i = threadIdx.x; i < 1024; i += 256) {
         const int v = s_max[i];
         if (v > 0) atomicMax(gi + i, v);
+        s_max[i] = 0;                                      // for the next group: its LDS atomics come after >= 1 barrier
     }
     LP_STAMP(4);
+  }
 }
 
 #define LP_DEC_SMALL_BYTES 7168                          // (864 + 512 + 64 + 256) floats, rounded up to 1 KiB
@@ -449,26 +474,6 @@ __global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN 
 // ------------------------------------------------------------------------------------------------
 static inline int lp_tiles(int n_pts, int T) { return (n_pts + 32 * LP_WAVES * T - 1) / (32 * LP_WAVES * T); }
 
-template <class DT, int T>
-static hipError_t enc_lp_t(const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
-    const size_t lds = LP_SLOTS * LP_ENC_SEG * 1024 + (1280 + 1024) * 4;
-    auto k = ins_seg_encode_lp_kernel<DT, T>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    const int tpi = lp_tiles(N, T);
-    hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * tpi)), dim3(256), lds, s, w, pts, c_in, N, tpi, g);
-    return hipGetLastError();
-}
-// points per workgroup = 128*T: T = 8 (one workgroup per 1024 points, fewest flushes of the channel maxima)
-// unless the padding to a multiple of 1024 points would waste more than 1/8 of the work; then T = 4
-template <class DT>
-static hipError_t enc_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
-    const int64_t pad8 = (int64_t)lp_tiles(N, 8) * 1024, pad4 = (int64_t)lp_tiles(N, 4) * 512;
-#ifndef DAL3_LP_ENC_T4                                     // (A/B switch: always four tiles per wave)
-    if (pad8 * 8 <= pad4 * 9) return enc_lp_t<DT, 8>(w, pts, c_in, B, N, g, s);
-#endif
-    return enc_lp_t<DT, 4>(w, pts, c_in, B, N, g, s);
-}
 static int lp_cu_count() {                                  // one persistent workgroup per CU
     static int n = 0;
     if (n == 0) {
@@ -478,6 +483,20 @@ static int lp_cu_count() {                                  // one persistent wo
         n = v;
     }
     return n;
+}
+template <class DT>
+static hipError_t enc_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
+    constexpr int T = 4;
+    const size_t lds = LP_SLOTS * LP_ENC_SEG * 1024 + LP_ENC_SMALL_BYTES;
+    auto k = ins_seg_encode_lp_kernel<DT, T>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int tpi = lp_tiles(N, T);
+    const int64_t n_groups = (int64_t)B * tpi;
+    if (n_groups > 0x7fffffff) return hipErrorInvalidValue;
+    const int64_t grid = n_groups < lp_cu_count() ? n_groups : lp_cu_count();
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, s, w, pts, c_in, N, tpi, (int)n_groups, g);
+    return hipGetLastError();
 }
 template <class DT>
 static hipError_t dec_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, const float* gbias, float* logits,

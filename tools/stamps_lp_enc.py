@@ -39,3 +39,7 @@ print("waves sampled", len(s), " ticks per workgroup (stamp 0 -> 4)", tot)
 for i, n in enumerate(names):
     print(f"{n:40s} mean {d[:, i].mean():9.0f}  p10 {np.percentile(d[:, i], 10):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}"
           f"  share {d[:, i].mean() / tot:6.1%}  ticks/MFMA {d[:, i].mean() / mf[i] if mf[i] else 0:6.1f}")
+g = stamps.cpu().numpy().reshape(-1, 4, 8)
+seam = (g[256:4096, :, 0] - g[:4096 - 256, :, 4]).astype(np.float64)
+seam = seam[(g[256:4096, :, 0] > 0) & (g[:4096 - 256, :, 4] > 0)]
+print("seam between consecutive groups of a workgroup: mean", seam.mean(), "p10", np.percentile(seam, 10), "p90", np.percentile(seam, 90))
