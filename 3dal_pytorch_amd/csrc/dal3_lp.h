@@ -279,13 +279,14 @@ __host__ __device__ constexpr int lp_tiles_per_seg(int kt, int mt) {
 }
 
 // a whole layer, one ring segment per TPS out-tiles
-template <class DT, int KT, int MT, int T, int SEG, int TPS, int M0>
+// (ACQ0 = false: the layer's first segment has been acquired already, e.g. by the early acquire of lp_max_tiles)
+template <class DT, int KT, int MT, int T, int SEG, int TPS, int M0, bool ACQ0 = true>
 __device__ __forceinline__ void lp_seg_layers(LdsRing<SEG>& ring, const float* bias, const ActTile<DT> (&X)[T][KT],
                                               ActTile<DT> (&Y)[T][MT], int lane) {
     if constexpr (M0 < MT) {
-        ring.acquire();
+        if (M0 > 0 || ACQ0) ring.acquire();
         lp_layer<DT, KT, MT, T, SEG, M0, TPS>(ring, 0, bias, X, Y, lane);
-        lp_seg_layers<DT, KT, MT, T, SEG, TPS, M0 + TPS>(ring, bias, X, Y, lane);
+        lp_seg_layers<DT, KT, MT, T, SEG, TPS, M0 + TPS, ACQ0>(ring, bias, X, Y, lane);
     }
 }
 

@@ -33,6 +33,10 @@ extern "C" int dal3_debug_set_stamps_lp_enc(void* p) {
 #define LP_STAMP(k)
 #endif
 
+// bytes of the point heads' small LDS arrays (biases, maxima, first layer), rounded up to 1 KiB
+__host__ __device__ constexpr int lp_head_small_bytes(int c1, int c2, int c3, int ks) {
+    return ((c2 + c3 + 512 + 512 + c1 + (c1 / 32) * ks * 64) * 4 + 1023) / 1024 * 1024;
+}
 #define LP_ENC_SMALL_BYTES 11264                         // (1280 + 1024 + 64 + 256) floats, rounded up to 1 KiB
 // Persistent like the decode kernel below (one workgroup per CU walking the 128 T-point groups, cyclic weight ring,
 // the next group's points fetched a layer ahead). T = 4: with eight tiles per wave conv4's output (256 registers) no
@@ -416,59 +420,89 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
 
 // ------------------------------------------------------------------------------------------------
 // conv1..4 + max over the points. Per layer the out-tiles are grouped into segments of <= 32 fragments.
+// Persistent like the two kernels above: one workgroup per CU walks the (point tile, item) pairs in item-minor order
+// (XCD balance: see point_head_kernel), skipping the tiles that hold only duplicates.
 template <class DT, int KS, int C1, int C2, int C3, int T>
-__global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN x, int c_in, int n_pts,
-                                                            int tiles_per_item, float* __restrict__ feat,
+__global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN x, int c_in, int n_pts_all,
+                                                            int n_items, int n_groups, float* __restrict__ feat,
                                                             const int32_t* __restrict__ distinct) {
     constexpr int SEG = LP_HEAD_SEG;
     constexpr int K2 = C1 / 32, M2 = C2 / 32, K3 = C2 / 32, M3 = C3 / 32, K4 = C3 / 32, M4 = 16;
     constexpr int TPS2 = lp_tiles_per_seg(K2, M2), TPS3 = lp_tiles_per_seg(K3, M3), TPS4 = lp_tiles_per_seg(K4, M4);
+    constexpr int NB = C2 + C3 + 512, NW1 = K2 * KS * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_bias = reinterpret_cast<float*>(smem + LP_SLOTS * SEG * 1024);   // b2 C2 | b3 C3 | b4 512
-    int* s_max = reinterpret_cast<int*>(s_bias + C2 + C3 + 512);
+    float* s_bias = reinterpret_cast<float*>(smem);        // b2 C2 | b3 C3 | b4 512 ; small arrays first, ring behind
+    int* s_max = reinterpret_cast<int*>(s_bias + NB);      // 512 channel maxima of the current group
+    float* s_b1 = s_bias + NB + 512;                       // first layer: bias (C1) and A fragments [K2][KS][64]
+    float* s_w1 = s_b1 + C1;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int n_items = gridDim.x / tiles_per_item;        // item-minor block order (XCD balance): see point_head_kernel
-    const int64_t b = blockIdx.x % n_items;
-    const int wg_tile = blockIdx.x / n_items;
-    const int n0 = (wg_tile * LP_WAVES + wave) * (32 * T);
-    if (distinct) {                                        // duplicates beyond the first distinct[b] points: see point_head_kernel
-        const int d = distinct[b];
-        n_pts = d <= 0 ? 1 : (d < n_pts ? d : n_pts);
-        if (wg_tile * LP_WAVES * 32 * T >= n_pts) return;  // whole workgroup: uniform exit
-    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5;
 
-    for (int i = threadIdx.x; i < C2 + C3 + 512; i += 256) s_bias[i] = w.bias[i];
+    for (int i = threadIdx.x; i < NB; i += 256) s_bias[i] = w.bias[i];
     for (int i = threadIdx.x; i < 512; i += 256) s_max[i] = 0;
+    for (int i = threadIdx.x; i < C1; i += 256) s_b1[i] = w.b1[i];
+    for (int i = threadIdx.x; i < NW1; i += 256) s_w1[i] = w.w1[i];
     __syncthreads();
     LdsRing<SEG> ring;
-    ring.init(w.stream, smem, M2 / TPS2 + M3 / TPS3 + M4 / TPS4, wave, lane);
+    ring.init(w.stream, smem + lp_head_small_bytes(C1, C2, C3, KS), M2 / TPS2 + M3 / TPS3 + M4 / TPS4, wave, lane, true);
 
+    // the next group's points and its item's count of distinct points, fetched a layer ahead (see the decode kernel)
+    float in_nx[T][KS];
+    int np_nx;
+    auto prefetch = [&](int id) {
+        unsigned z = 0;
+        asm volatile("" : "+v"(z));
+        const int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+        const int bb = id % n_items;
+        int np = n_pts_all;
+        if (distinct) {                                    // duplicates beyond the first distinct[b] points: see point_head_kernel
+            const int d = distinct[bb];
+            np = d <= 0 ? 1 : (d < np ? d : np);
+        }
+        np_nx = np;
+        load_points<KS, T>(x, bb, ((id / n_items) * LP_WAVES + wave) * (32 * T), np, c_in, in_nx, l);
+    };
+    prefetch(blockIdx.x);
+    ring.acquire();                                        // the first segment of the first group's conv2
+
+  for (int id = blockIdx.x; id < n_groups; id += gridDim.x) {
+    const int64_t b = id % n_items;
+    const int wg_tile = id / n_items;
+    const int nx = id + (int)gridDim.x < n_groups ? id + (int)gridDim.x : id;
+    if (wg_tile * LP_WAVES * 32 * T >= np_nx) {            // only duplicates in this tile: uniform skip (the ring stays put)
+        prefetch(nx);
+        continue;
+    }
     ActTile<DT> x1[T][K2], x2[T][M2], x3[T][M3];
-    {
-        float in[T][KS];
-        load_points<KS, T>(x, b, n0, n_pts, c_in, in, lane);
-        f32x16 x1f[T][K2];
-        first_layer<KS, K2, T>(w.w1, w.b1, in, x1f, lane);
+#pragma unroll
+    for (int mt = 0; mt < K2; ++mt) {                      // first layer in fp32 (first_layer of dal3_device.h, operands from LDS)
+        const f32x16 bv = tile_from_channels(s_b1 + 32 * mt, h);
 #pragma unroll
         for (int j = 0; j < T; ++j) {
+            f32x16 acc = bv;
 #pragma unroll
-            for (int m = 0; m < K2; ++m) x1[j][m] = pack_relu<DT>(x1f[j][m]);
+            for (int k = 0; k < KS; ++k) acc = mfma32(s_w1[(mt * KS + k) * 64 + lane], in_nx[j][k], acc);
+            x1[j][mt] = pack_relu<DT>(acc);
         }
     }
-    lp_seg_layers<DT, K2, M2, T, SEG, TPS2, 0>(ring, s_bias, x1, x2, lane);
+    lp_seg_layers<DT, K2, M2, T, SEG, TPS2, 0, false>(ring, s_bias, x1, x2, lane);
+    prefetch(nx);
+    __builtin_amdgcn_sched_barrier(0);
     lp_seg_layers<DT, K3, M3, T, SEG, TPS3, 0>(ring, s_bias + C2, x2, x3, lane);
     const float* s_b4 = s_bias + C2 + C3;
     typename DT::v8 g4[2][4];
     ring.acquire();
-    for (int seg = 0; seg < M4 / TPS4; ++seg)
+    for (int seg = 0; seg < M4 / TPS4; ++seg)              // (the last call opens the next group's first segment)
         lp_max_tiles<DT, K4, T, SEG, TPS4>(ring, x3, s_b4 + 32 * TPS4 * seg, s_max + 32 * TPS4 * seg, lane, g4, seg == 0);
     __syncthreads();
     int* fi = reinterpret_cast<int*>(feat + b * 512);
     for (int i = threadIdx.x; i < 512; i += 256) {
         const int v = s_max[i];
         if (v > 0) atomicMax(fi + i, v);
+        s_max[i] = 0;                                      // for the next group: its LDS atomics come after >= 1 barrier
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -517,12 +551,14 @@ template <class DT, int KS, int C1, int C2, int C3>
 static hipError_t head_lp(const PointHeadLpW& w, BCN x, int c_in, int B, int M, float* feat, const int32_t* distinct,
                           hipStream_t s) {
     constexpr int T = DAL3_LP_HEAD_T;
-    const size_t lds = LP_SLOTS * LP_HEAD_SEG * 1024 + (C2 + C3 + 512 + 512) * 4;
+    const size_t lds = LP_SLOTS * LP_HEAD_SEG * 1024 + lp_head_small_bytes(C1, C2, C3, KS);
     auto k = point_head_lp_kernel<DT, KS, C1, C2, C3, T>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const int tpi = lp_tiles(M, T);
-    hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * tpi)), dim3(256), lds, s, w, x, c_in, M, tpi, feat, distinct);
+    const int64_t n_groups = (int64_t)B * lp_tiles(M, T);
+    if (n_groups > 0x7fffffff) return hipErrorInvalidValue;
+    const int64_t grid = n_groups < lp_cu_count() ? n_groups : lp_cu_count();
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, s, w, x, c_in, M, B, (int)n_groups, feat, distinct);
     return hipGetLastError();
 }
 
