@@ -204,8 +204,21 @@ struct LdsRing {
 
 // acc[j] += W'(32 x 32*KT) . X[j] with the block's KT*2 fragments starting at fragment f0 of the slot; the
 // fragments are read in groups of four, a group ahead of their MFMAs (see lp_layer)
-template <class DT, int KT, int T, int SEG>
-__device__ __forceinline__ void lp_block(const LdsRing<SEG>& ring, int f0, const ActTile<DT> (&X)[T][KT],
+// EARLY: the block's last four fragments are the last reads of the slot — the next segment is opened before their
+// MFMAs (acquire_wait) and its refill dealt out between them; whoever uses the ring next must not acquire again.
+template <int SEG, int GAPS>
+__device__ __forceinline__ void lp_refill_gap(LdsRing<SEG>& ring, int n) {
+    constexpr int ML = LdsRing<SEG>::MY_LOADS;
+    static_assert(ML <= 2 * GAPS, "two refill parts per MFMA gap at most");
+    if (GAPS >= ML) {
+        if (n < ML) ring.issue_part(n);
+    } else {
+        if (2 * n < ML) ring.issue_part(2 * n);
+        if (2 * n + 1 < ML) ring.issue_part(2 * n + 1);
+    }
+}
+template <class DT, int KT, int T, int SEG, bool EARLY = false>
+__device__ __forceinline__ void lp_block(LdsRing<SEG>& ring, int f0, const ActTile<DT> (&X)[T][KT],
                                          f32x16 (&acc)[T]) {
     typedef typename DT::v8 frag_t;
     constexpr int NG = KT * 2 / 4;
@@ -215,17 +228,27 @@ __device__ __forceinline__ void lp_block(const LdsRing<SEG>& ring, int f0, const
     for (int i = 0; i < 4; ++i) g[0][i] = ring.template frag<DT>(f0 + i);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
+        const bool last = EARLY && gi == NG - 1;
         if (gi + 1 < NG) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) g[(gi + 1) & 1][i] = ring.template frag<DT>(f0 + 4 * (gi + 1) + i);
         }
         DAL3_SCHED_FENCE();
+        if (last) ring.acquire_wait();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = 4 * gi + i;
 #pragma unroll
-            for (int j = 0; j < T; ++j) acc[j] = DT::mfma(g[gi & 1][i], X[j][k >> 1].k[k & 1], acc[j]);
+            for (int j = 0; j < T; ++j) {
+                acc[j] = DT::mfma(g[gi & 1][i], X[j][k >> 1].k[k & 1], acc[j]);
+                if (last) {
+                    DAL3_SCHED_FENCE();
+                    lp_refill_gap<SEG, 4 * T>(ring, i * T + j);
+                    DAL3_SCHED_FENCE();
+                }
+            }
         }
+        if (last) ring.issue_done();
         DAL3_SCHED_FENCE();
     }
 }
@@ -235,8 +258,8 @@ __device__ __forceinline__ void lp_block(const LdsRing<SEG>& ring, int f0, const
 // The MTN*KT*2 fragments are walked as ONE stream in groups of four, each group's ds_reads issued before the
 // previous group's MFMAs (also across out-tile boundaries): left to itself hipcc puts every read right in front
 // of its MFMAs and each fragment exposes the LDS latency (T = 2: only 64 MFMA cycles per fragment to hide it).
-template <class DT, int KT, int MT, int T, int SEG, int MT0, int MTN>
-__device__ __forceinline__ void lp_layer(const LdsRing<SEG>& ring, int f0, const float* bias,
+template <class DT, int KT, int MT, int T, int SEG, int MT0, int MTN, bool EARLY = false>
+__device__ __forceinline__ void lp_layer(LdsRing<SEG>& ring, int f0, const float* bias,
                                          const ActTile<DT> (&X)[T][KT], ActTile<DT> (&Y)[T][MT], int lane) {
     typedef typename DT::v8 frag_t;
     constexpr int FPT = KT * 2;                            // fragments per out-tile
@@ -249,11 +272,13 @@ __device__ __forceinline__ void lp_layer(const LdsRing<SEG>& ring, int f0, const
     for (int i = 0; i < 4; ++i) g[0][i] = ring.template frag<DT>(f0 + i);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
+        const bool last = EARLY && gi == NG - 1;           // (EARLY: see lp_block)
         if (gi + 1 < NG) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) g[(gi + 1) & 1][i] = ring.template frag<DT>(f0 + 4 * (gi + 1) + i);
         }
         DAL3_SCHED_FENCE();
+        if (last) ring.acquire_wait();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = 4 * gi + i, m = MT0 + f / FPT, k = f % FPT;
@@ -263,12 +288,20 @@ __device__ __forceinline__ void lp_layer(const LdsRing<SEG>& ring, int f0, const
                 for (int j = 0; j < T; ++j) acc[j] = b;
             }
 #pragma unroll
-            for (int j = 0; j < T; ++j) acc[j] = DT::mfma(g[gi & 1][i], X[j][k >> 1].k[k & 1], acc[j]);
+            for (int j = 0; j < T; ++j) {
+                acc[j] = DT::mfma(g[gi & 1][i], X[j][k >> 1].k[k & 1], acc[j]);
+                if (last) {
+                    DAL3_SCHED_FENCE();
+                    lp_refill_gap<SEG, 4 * T>(ring, i * T + j);
+                    DAL3_SCHED_FENCE();
+                }
+            }
             if (k == FPT - 1) {
 #pragma unroll
                 for (int j = 0; j < T; ++j) Y[j][m] = pack_relu<DT>(acc[j]);
             }
         }
+        if (last) ring.issue_done();
         DAL3_SCHED_FENCE();
     }
 }

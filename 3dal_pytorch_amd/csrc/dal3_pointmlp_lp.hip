@@ -171,23 +171,25 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         gb_nx[1] = gbias[bb * 512 + 256 + wave * 64 + l];
     };
     prefetch(blockIdx.x);
+    // The crop's dconv1 term goes to LDS one group ahead: here for the first group, in front of dconv4 for the others
+    // (nobody reads the old one after the main loop; dconv4's barrier, here acquire(), publishes the new one).
+    auto publish_gb = [&]() {
+        s_gb[threadIdx.x] = gb_nx[0];
+        s_gb[256 + threadIdx.x] = gb_nx[1];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    publish_gb();
+    ring.acquire();                                        // segment 0 of the first group (publishes s_bias ... too)
 
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const int64_t b = grp / tiles_per_item;
     const int n0 = ((grp % tiles_per_item) * LP_WAVES + wave) * (32 * T);
-    // this crop's dconv1 term. Nobody still reads the previous group's: its last reader sits before the three
-    // barriers of dconv3/dconv4. The group's first acquire() (a barrier) publishes it — and s_bias, the first time.
-    s_gb[threadIdx.x] = gb_nx[0];
-    s_gb[256 + threadIdx.x] = gb_nx[1];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     LP_STAMP(0);
 
     ActTile<DT> x1[T][2], x2[T][2];
     {
-        // conv1 in fp32 (first_layer of dal3_device.h with the weights in registers and the bias in LDS). s_b1 was
-        // written before this workgroup's first barrier... which the first group has not passed yet: it reads
-        // the bias after its first acquire() instead, so conv1 sits behind that barrier for every group.
-        ring.acquire();                                    // segment 0: conv2 (0..7) | dconv1a chunk 0 (8..11)
+        // conv1 in fp32 (first_layer of dal3_device.h, operands from LDS). Segment 0 (conv2 | dconv1a chunk 0) is open:
+        // by the acquire in front of the loop for the first group, by the previous group's dconv4 for the others.
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const f32x16 bv = tile_from_channels(s_b1 + 32 * mt, h);
@@ -363,11 +365,11 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         for (int mt = 0; mt < 8; ++mt) xd[j][mt] = pack_relu<DT>(a2[j][mt]);
     }
     LP_STAMP(3);
-    lp_layer<DT, 8, 4, T, SEG, 0, 2>(ring, 0, s_db3, xd, y3, lane);
-    ring.acquire();                                        // dconv3 out-tiles 2,3
-    lp_layer<DT, 8, 4, T, SEG, 2, 2>(ring, 0, s_db3, xd, y3, lane);
+    // dconv3 (two segments) and dconv4 (one): each opens the next segment itself, under its last eight MFMAs
+    lp_layer<DT, 8, 4, T, SEG, 0, 2, true>(ring, 0, s_db3, xd, y3, lane);
+    lp_layer<DT, 8, 4, T, SEG, 2, 2, true>(ring, 0, s_db3, xd, y3, lane);
+    publish_gb();                                          // the next group's (fetched after the main loop)
     LP_STAMP(4);
-    ring.acquire();                                        // dconv4
     f32x16 y4[T][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -375,7 +377,10 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         const f32x16 bv = tile_from_channels(s_db4 + 32 * m, h);
 #pragma unroll
         for (int j = 0; j < T; ++j) acc[j] = bv;
-        lp_block<DT, 4, T, SEG>(ring, m * 8, y3, acc);
+        if (m < 3)
+            lp_block<DT, 4, T, SEG>(ring, m * 8, y3, acc);
+        else
+            lp_block<DT, 4, T, SEG, true>(ring, m * 8, y3, acc);   // ... the next group's segment 0 (conv2 | dconv1a chunk 0)
 #pragma unroll
         for (int j = 0; j < T; ++j) y4[j][m] = relu16(acc[j]);
     }
