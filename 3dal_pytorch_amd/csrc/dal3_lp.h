@@ -217,11 +217,17 @@ __device__ __forceinline__ void lp_refill_gap(LdsRing<SEG>& ring, int n) {
         if (2 * n + 1 < ML) ring.issue_part(2 * n + 1);
     }
 }
-template <class DT, int KT, int T, int SEG, bool EARLY = false>
+// gap(n): work placed (between scheduling fences) after MFMA n = k T + j of the block — a few VALU instructions per
+// gap ride in the shadow of the 32-cycle MFMAs (the previous tile's packing, say); n is a constant after unrolling.
+struct LpNoGap {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <class DT, int KT, int T, int SEG, bool EARLY = false, class Gap = LpNoGap>
 __device__ __forceinline__ void lp_block(LdsRing<SEG>& ring, int f0, const ActTile<DT> (&X)[T][KT],
-                                         f32x16 (&acc)[T]) {
+                                         f32x16 (&acc)[T], Gap gap = Gap()) {
     typedef typename DT::v8 frag_t;
     constexpr int NG = KT * 2 / 4;
+    constexpr bool GAPS = !__is_same(Gap, LpNoGap);
     static_assert((KT * 2) % 4 == 0, "whole groups of four fragments");
     frag_t g[2][4];
 #pragma unroll
@@ -241,9 +247,10 @@ __device__ __forceinline__ void lp_block(LdsRing<SEG>& ring, int f0, const ActTi
 #pragma unroll
             for (int j = 0; j < T; ++j) {
                 acc[j] = DT::mfma(g[gi & 1][i], X[j][k >> 1].k[k & 1], acc[j]);
-                if (last) {
+                if (last || GAPS) {
                     DAL3_SCHED_FENCE();
-                    lp_refill_gap<SEG, 4 * T>(ring, i * T + j);
+                    if (last) lp_refill_gap<SEG, 4 * T>(ring, i * T + j);
+                    gap(k * T + j);
                     DAL3_SCHED_FENCE();
                 }
             }

@@ -365,25 +365,72 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         for (int mt = 0; mt < 8; ++mt) xd[j][mt] = pack_relu<DT>(a2[j][mt]);
     }
     LP_STAMP(3);
-    // dconv3 (two segments) and dconv4 (one): each opens the next segment itself, under its last eight MFMAs
-    lp_layer<DT, 8, 4, T, SEG, 0, 2, true>(ring, 0, s_db3, xd, y3, lane);
-    lp_layer<DT, 8, 4, T, SEG, 2, 2, true>(ring, 0, s_db3, xd, y3, lane);
+    // dconv3 (two segments of two out-tiles) and dconv4 (one segment): each segment's last block opens the next
+    // segment itself, under its last eight MFMAs. Two accumulator sets alternate: a finished tile is read out of its
+    // AGPRs, ReLU'd and (dconv3) rounded in pieces of a few instructions between the MFMAs of the NEXT tile — taken in
+    // one piece after each tile (64 VALU per 32 MFMAs) these layers ran at 64 / 71 cycles per MFMA.
+    static_assert(T == 2, "gap schedules below are written for two point tiles");
+    f32x16 accA[T], accB[T];
+    int4_t pw[T][2];
+    auto bias_tile = [&](f32x16 (&acc)[T], const float* bias) {
+        const f32x16 bv = tile_from_channels(bias, h);
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = bv;
+    };
+    auto pack_piece = [&](const f32x16 (&acc)[T], int p) {       // register pair p of the 16 (T x 2 x 4) of a tile
+        const int tj = p >> 3, ts = (p >> 2) & 1, ti = p & 3;
+        pw[tj][ts][ti] = pack_relu_pair<DT>(acc[tj][8 * ts + 2 * ti], acc[tj][8 * ts + 2 * ti + 1]);
+    };
+    auto packed_to = [&](int m) {
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            y3[j][m].k[0] = __builtin_bit_cast(frag_t, pw[j][0]);
+            y3[j][m].k[1] = __builtin_bit_cast(frag_t, pw[j][1]);
+        }
+    };
+    bias_tile(accA, s_db3);
+    lp_block<DT, 8, T, SEG>(ring, 0, xd, accA);                                          // dconv3 tile 0
+    bias_tile(accB, s_db3 + 32);
+    lp_block<DT, 8, T, SEG, true>(ring, 16, xd, accB, [&](int n) {                       // tile 1 | pack tile 0
+        if (n % 2 == 0) pack_piece(accA, n / 2);
+    });
+    packed_to(0);
+    bias_tile(accA, s_db3 + 64);
+    lp_block<DT, 8, T, SEG>(ring, 0, xd, accA, [&](int n) {                              // tile 2 | pack tile 1
+        if (n % 2 == 0) pack_piece(accB, n / 2);
+    });
+    packed_to(1);
+    bias_tile(accB, s_db3 + 96);
+    lp_block<DT, 8, T, SEG, true>(ring, 16, xd, accB, [&](int n) {                       // tile 3 | pack tile 2
+        if (n % 2 == 0) pack_piece(accA, n / 2);
+    });
+    packed_to(2);
     publish_gb();                                          // the next group's (fetched after the main loop)
     LP_STAMP(4);
     f32x16 y4[T][4];
+    auto relu_piece = [&](const f32x16 (&acc)[T], int m, int n) {    // two of the 32 accumulator registers of a tile
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        f32x16 acc[T];
-        const f32x16 bv = tile_from_channels(s_db4 + 32 * m, h);
-#pragma unroll
-        for (int j = 0; j < T; ++j) acc[j] = bv;
-        if (m < 3)
-            lp_block<DT, 4, T, SEG>(ring, m * 8, y3, acc);
-        else
-            lp_block<DT, 4, T, SEG, true>(ring, m * 8, y3, acc);   // ... the next group's segment 0 (conv2 | dconv1a chunk 0)
-#pragma unroll
-        for (int j = 0; j < T; ++j) y4[j][m] = relu16(acc[j]);
-    }
+        for (int e = 0; e < 2; ++e) {
+            const int idx = 2 * n + e, tj = idx >> 4, r = idx & 15;
+            y4[tj][m][r] = relu1(acc[tj][r]);
+        }
+    };
+    bias_tile(accA, s_db4);
+    lp_block<DT, 4, T, SEG>(ring, 0, y3, accA, [&](int n) {                              // dconv4 tile 0 | pack dconv3 tile 3:
+        if (n < 8) {                                                                     // its k-steps 6, 7 (n >= 12) are
+            pack_piece(accB, 2 * n);                                                     // the first to need it
+            pack_piece(accB, 2 * n + 1);
+        }
+        if (n == 7) packed_to(3);
+    });
+    bias_tile(accB, s_db4 + 32);
+    lp_block<DT, 4, T, SEG>(ring, 8, y3, accB, [&](int n) { relu_piece(accA, 0, n); });   // tile 1 | ReLU tile 0
+    bias_tile(accA, s_db4 + 64);
+    lp_block<DT, 4, T, SEG>(ring, 16, y3, accA, [&](int n) { relu_piece(accB, 1, n); });  // tile 2 | ReLU tile 1
+    bias_tile(accB, s_db4 + 96);
+    lp_block<DT, 4, T, SEG, true>(ring, 24, y3, accB, [&](int n) { relu_piece(accA, 2, n); });   // tile 3 | ReLU tile 2,
+#pragma unroll                                                                                  // opens the next group's segment 0
+    for (int j = 0; j < T; ++j) y4[j][3] = relu16(accB[j]);
 
     LP_STAMP(5);
     float l0[T], l1[T];
