@@ -129,6 +129,9 @@ struct LdsRing {
     const char* stream;                                   // global: this kernel's fragment stream
     char* lds;                                            // LDS: LP_SLOTS * SLOT_BYTES
     int n_segs, seg_issue, slot_issue, slot_use, wave, lane;
+#ifdef DAL3_STAMP
+    long long bar_ticks = 0, wait_ticks = 0;              // diagnostic: time spent in the counted wait / in s_barrier
+#endif
     bool cyclic;                                          // persistent kernels: past the stream's end comes its start
 
     __device__ __forceinline__ void init(const void* stream_, char* lds_, int n_segs_, int wave_, int lane_,
@@ -175,9 +178,21 @@ struct LdsRing {
     // between MFMAs, then issue_done().
     __device__ __forceinline__ void acquire_wait() {
         __builtin_amdgcn_sched_barrier(0);
+#ifdef DAL3_STAMP
+        unsigned long long t0_, t1_, t2_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory");
+#endif
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MY_LOADS) : "memory");
+#ifdef DAL3_STAMP
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_)::"memory");
+#endif
 #ifndef DAL3_ABL_BAR                                      // timing experiment only
         __builtin_amdgcn_s_barrier();
+#endif
+#ifdef DAL3_STAMP
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_)::"memory");
+        wait_ticks += (long long)(t1_ - t0_);
+        bar_ticks += (long long)(t2_ - t1_);
 #endif
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);

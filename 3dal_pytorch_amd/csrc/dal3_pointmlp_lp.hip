@@ -467,6 +467,12 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         }
     }
     LP_STAMP(6);
+#if defined(DAL3_STAMP)
+    if (lane == 0 && grp < 4096) {                         // slot 7: ticks inside s_barrier (low 32 bits) and inside the
+        g_stamps_lp[(grp * 4 + wave) * 8 + 7] = (ring.bar_ticks & 0xffffffffll) | (ring.wait_ticks << 32);   // counted wait
+    }
+    ring.bar_ticks = ring.wait_ticks = 0;
+#endif
   }   // groups
 }
 

@@ -45,3 +45,8 @@ g = stamps.cpu().numpy().reshape(-1, 4, 8)
 seam = (g[256:4096, :, 0] - g[:4096 - 256, :, 6]).astype(np.float64)
 seam = seam[(g[256:4096, :, 0] > 0) & (g[:4096 - 256, :, 6] > 0)]
 print("seam between consecutive groups of a workgroup: mean", seam.mean(), "p90", np.percentile(seam, 90))
+# slot 7: per group, ticks each wave spent inside s_barrier (low 32 bits) and inside the counted vmcnt/lgkmcnt wait
+raw = stamps.cpu().numpy().reshape(-1, 4, 8)[:, :, 7]
+raw = raw[(stamps.cpu().numpy().reshape(-1, 4, 8)[:, :, 6] > 0)]
+bar, wt = (raw & 0xffffffff).astype(np.float64), (raw >> 32).astype(np.float64)
+print("per group: ticks in s_barrier, by wave", bar.reshape(-1, 4).mean(0).round(0), " in the counted wait", wt.reshape(-1, 4).mean(0).round(0))
