@@ -13,6 +13,8 @@ __device__ __forceinline__ f32x16 mf(float a, float b, f32x16 c) { return __buil
 // MODE 3: no load, but two VALU per group
 // MODE 4: as 0 with two independent accumulators alternating per MFMA (T=2 shape, 8 MFMAs per load)
 // MODE 5: as 0 but the accumulator alternates per GROUP between two tiles (dependency across the load is broken)
+// MODE 11: as 0 but the fragments come from LDS (ds_read_b128, ring of D), no global loads in the loop
+// MODE 12: as 11 with the read issued after the 2nd MFMA of the group
 template <int MODE, int D = 8>
 __global__ __launch_bounds__(256) void k(const f32x4* __restrict__ w, float* __restrict__ out, long long* __restrict__ cyc, int iters) {
     const int lane = threadIdx.x & 63;
@@ -23,6 +25,12 @@ __global__ __launch_bounds__(256) void k(const f32x4* __restrict__ w, float* __r
     const f32x4* next = w + lane;
     for (int i = 0; i < D; ++i) { ring[i] = *next; next += 64; }
     const f32x4 cst = {0.5f, 0.25f, 0.125f, 1.0f};
+    __shared__ f32x4 lds[64 * 64];                                  // 64 KiB: 64 fragments
+    if (MODE == 11 || MODE == 12) {
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) lds[i] = w[i];
+        __syncthreads();
+    }
+    int lf = D;
     float junk = 0;
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
@@ -31,6 +39,7 @@ __global__ __launch_bounds__(256) void k(const f32x4* __restrict__ w, float* __r
             if (MODE == 7 && i % 4 == 0) asm volatile("" : "+v"(ring[(i + 3) % D][0]));
             f32x4 a = (MODE == 2 || MODE == 3) ? cst : ring[i % D];
             if (MODE == 0 || MODE == 4 || MODE == 5 || MODE == 7 || MODE == 10) { ring[i % D] = *next; next += 64; }
+            if (MODE == 11) { ring[i % D] = lds[(lf & 63) * 64 + lane]; ++lf; }
             if (MODE == 8) { asm volatile("s_nop 0"); }
             if (MODE == 9) { asm volatile("s_waitcnt vmcnt(0)"); }
             if (MODE == 2) { ring[i % D] = *next; next += 64; }
@@ -41,6 +50,7 @@ __global__ __launch_bounds__(256) void k(const f32x4* __restrict__ w, float* __r
                 else if (MODE == 5) { if (i & 1) acc1 = mf(a[e], t[4 * (i % 4) + e], acc1); else acc0 = mf(a[e], t[4 * (i % 4) + e], acc0); }
                 else acc0 = mf(a[e], t[4 * (i % 4) + e], acc0);
                 if (MODE == 1 && e == 1) { FENCE(); ring[i % D] = *next; next += 64; FENCE(); }
+                if (MODE == 12 && e == 1) { FENCE(); ring[i % D] = lds[(lf & 63) * 64 + lane]; ++lf; FENCE(); }
             }
             FENCE();
         }
@@ -86,5 +96,8 @@ int main() {
     run<7>("7: as 0 with one s_waitcnt per 4 groups", w, out, cyc);
     run<8>("8: as 6 plus one s_nop 0 per group", w, out, cyc);
     run<9>("9: as 6 plus one (trivially satisfied) s_waitcnt vmcnt(0) per group", w, out, cyc);
+    run<11>("11: fragments from LDS (ds_read_b128 ring of 8)", w, out, cyc);
+    run<12>("12: as 11, read issued after the 2nd MFMA", w, out, cyc);
+    run<11, 4>("11/D4: LDS ring of 4", w, out, cyc);
     return 0;
 }
