@@ -334,14 +334,16 @@ __host__ __device__ constexpr int lp_tiles_per_seg(int kt, int mt) {
 }
 
 // a whole layer, one ring segment per TPS out-tiles
-// (ACQ0 = false: the layer's first segment has been acquired already, e.g. by the early acquire of lp_max_tiles)
-template <class DT, int KT, int MT, int T, int SEG, int TPS, int M0, bool ACQ0 = true>
+// CHAIN = false: every segment is acquired in front of its out-tiles. CHAIN = true: the layer's first segment is open
+// already (by whoever used the ring before) and every segment opens the next one itself under its last MFMAs (lp_layer
+// EARLY) — after the layer the following layer's (or group's) first segment is open.
+template <class DT, int KT, int MT, int T, int SEG, int TPS, int M0, bool CHAIN = false>
 __device__ __forceinline__ void lp_seg_layers(LdsRing<SEG>& ring, const float* bias, const ActTile<DT> (&X)[T][KT],
                                               ActTile<DT> (&Y)[T][MT], int lane) {
     if constexpr (M0 < MT) {
-        if (M0 > 0 || ACQ0) ring.acquire();
-        lp_layer<DT, KT, MT, T, SEG, M0, TPS>(ring, 0, bias, X, Y, lane);
-        lp_seg_layers<DT, KT, MT, T, SEG, TPS, M0 + TPS, ACQ0>(ring, bias, X, Y, lane);
+        if (!CHAIN) ring.acquire();
+        lp_layer<DT, KT, MT, T, SEG, M0, TPS, CHAIN>(ring, 0, bias, X, Y, lane);
+        lp_seg_layers<DT, KT, MT, T, SEG, TPS, M0 + TPS, CHAIN>(ring, bias, X, Y, lane);
     }
 }
 

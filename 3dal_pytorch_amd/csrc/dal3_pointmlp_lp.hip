@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN
     LP_STAMP(1);
     lp_layer<DT, 2, 2, T, SEG, 0, 2>(ring, 0, s_bias, x1, x2, lane);
     lp_layer<DT, 2, 2, T, SEG, 0, 2>(ring, 8, s_bias + 64, x2, x3, lane);
-    lp_layer<DT, 2, 4, T, SEG, 0, 4>(ring, 16, s_bias + 128, x3, x4, lane);
+    lp_layer<DT, 2, 4, T, SEG, 0, 4, true>(ring, 16, s_bias + 128, x3, x4, lane);    // opens conv5's first segment
     {
         const int nx = grp + (int)gridDim.x;
         prefetch(nx < n_groups ? nx : grp);               // (the last group re-reads itself: uniform control flow)
@@ -101,7 +101,6 @@ __global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN
     }
     LP_STAMP(2);
     typename DT::v8 g5[2][4];
-    ring.acquire();
     for (int seg = 0; seg < 8; ++seg)                      // conv5: 4 out-tiles (32 fragments) per segment; the last
         lp_max_tiles<DT, 4, T, SEG, 4>(ring, x4, s_bias + 256 + 128 * seg, s_max + 128 * seg, lane, g5, seg == 0);
     LP_STAMP(3);                                           // call has already opened the next group's segment 0
@@ -544,13 +543,12 @@ __global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN 
             x1[j][mt] = pack_relu<DT>(acc);
         }
     }
-    lp_seg_layers<DT, K2, M2, T, SEG, TPS2, 0, false>(ring, s_bias, x1, x2, lane);
+    lp_seg_layers<DT, K2, M2, T, SEG, TPS2, 0, true>(ring, s_bias, x1, x2, lane);     // every segment opens the next
     prefetch(nx);
     __builtin_amdgcn_sched_barrier(0);
-    lp_seg_layers<DT, K3, M3, T, SEG, TPS3, 0>(ring, s_bias + C2, x2, x3, lane);
+    lp_seg_layers<DT, K3, M3, T, SEG, TPS3, 0, true>(ring, s_bias + C2, x2, x3, lane);
     const float* s_b4 = s_bias + C2 + C3;
     typename DT::v8 g4[2][4];
-    ring.acquire();
     for (int seg = 0; seg < M4 / TPS4; ++seg)              // (the last call opens the next group's first segment)
         lp_max_tiles<DT, K4, T, SEG, TPS4>(ring, x3, s_b4 + 32 * TPS4 * seg, s_max + 32 * TPS4 * seg, lane, g4, seg == 0);
     __syncthreads();
