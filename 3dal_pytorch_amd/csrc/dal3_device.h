@@ -238,93 +238,14 @@ __device__ __forceinline__ void load_points(const BCN& x, int64_t b, int n0, int
     }
 }
 
-// xor-exchange inside each 32-lane half without an address register (ds_swizzle bit-mask mode)
-template <int XOR>
-__device__ __forceinline__ float swz_xor(float v) {
-    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (XOR << 10) | 0x1F));
-}
-
-// Channel-wise max over the 32 points of a tile (and the T tiles of the wave), post-ReLU, combined
-// across waves / workgroups by an integer atomic max on the bit pattern (values are >= +0, so the
-// order of the bit patterns is the order of the floats; dst is zero-filled before the launch).
-// Transposing butterfly: each exchange halves the live registers (16 swizzles instead of 80).
-// The folded bias is added AFTER the max (x -> fl(x + b) is monotone, so max_p fl(acc_p + b) ==
-// fl(max_p acc_p + b)): accumulators start at zero and no load sits in front of a chunk's MFMAs.
+// Channel-wise max over the points of a tile (and the T tiles of the wave), post-ReLU, combined across waves /
+// workgroups by an integer atomic max on the bit pattern (values are >= +0, so the order of the bit patterns is the
+// order of the floats; dst is zero-filled before the launch). The folded bias is added AFTER the max (x -> fl(x + b)
+// is monotone, so max_p fl(acc_p + b) == fl(max_p acc_p + b)): accumulators start at zero and no load sits in front
+// of a chunk's MFMAs. The work is cut into 10 micro-steps; step k is issued right after fragment group k of the NEXT
+// tile (mma_block_ring's side job), i.e. in the shadow of that group's last 64-cycle MFMA.
 //
-// The work is cut into 10 micro-steps of <= ~12 VALU instructions; step k is issued right after
-// fragment group k of the NEXT tile (mma_block_ring's side job), i.e. in the shadow of that group's
-// last 64-cycle MFMA, so the matrix pipe never waits for the epilogue. Every ds_swizzle is consumed one
-// step after it is issued: its latency passes under a whole group of MFMAs.
-template <int T>
-struct MaxEpilogue {
-    static constexpr int STEPS = 10;
-    float keep[8], recv[8], bias_v;
-
-    __device__ __forceinline__ static float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
-
-    __device__ __forceinline__ void step(int k, const f32x16 (&acc)[T], const float* __restrict__ bias,
-                                         float* __restrict__ dst, int lane) {
-        if (k < 4) {                                   // max over the wave's tiles + first exchange, 2 pairs per step
-            const bool up = lane & 1;
-#pragma unroll
-            for (int i = 2 * k; i < 2 * k + 2; ++i) {
-                float lo = acc[0][i], hi = acc[0][i + 8];
-#pragma unroll
-                for (int j = 1; j < T; ++j) {
-                    lo = vmax(lo, acc[j][i]);
-                    hi = vmax(hi, acc[j][i + 8]);
-                }
-                keep[i] = up ? hi : lo;
-                recv[i] = swz_xor<1>(up ? lo : hi);
-            }
-            if (k == 0) {                              // bias: LDS copy (an lgkmcnt wait, never a vmcnt drain of the ring)
-                const int r = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-                bias_v = bias[tile_chan(r, lane >> 5)];
-            }
-        } else if (k == 4) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) keep[i] = vmax(keep[i], recv[i]);
-        } else if (k == 5) {
-            const bool up = lane & 2;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float lo = keep[i], hi = keep[i + 4];
-                keep[i] = up ? hi : lo;
-                recv[i] = swz_xor<2>(up ? lo : hi);
-            }
-        } else if (k == 6) {
-            const bool up = lane & 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) keep[i] = vmax(keep[i], recv[i]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float lo = keep[i], hi = keep[i + 2];
-                keep[i] = up ? hi : lo;
-                recv[i] = swz_xor<4>(up ? lo : hi);
-            }
-        } else if (k == 7) {
-            const bool up = lane & 8;
-            const float v0 = vmax(keep[0], recv[0]), v1 = vmax(keep[1], recv[1]);
-            keep[0] = up ? v1 : v0;
-            recv[0] = swz_xor<8>(up ? v0 : v1);
-        } else if (k == 8) {
-            keep[0] = vmax(keep[0], recv[0]);
-            recv[0] = swz_xor<16>(keep[0]);
-        } else if (k == 9) {
-            // lane bits 0..3 selected register bits 3..0; lane bit 4 holds a replica
-            const int r = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-            int bits = __float_as_int(vmax(keep[0], recv[0]) + bias_v);
-            bits = bits > 0 ? bits : 0;                  // ReLU on the bit pattern (-0.0 and negatives -> +0)
-            if ((lane & 16) == 0) atomicMax(reinterpret_cast<int*>(dst) + tile_chan(r, lane >> 5), bits);
-        }
-    }
-    __device__ __forceinline__ void all(const f32x16 (&acc)[T], const float* bias, float* dst, int lane) {
-#pragma unroll
-        for (int k = 0; k < STEPS; ++k) step(k, acc, bias, dst, lane);
-    }
-};
-
-// The same for a TRANSPOSED tile (conv_max_layer computes the max-pooled layer with the MFMA operands swapped):
+// The tile is TRANSPOSED (conv_max_layer computes the max-pooled layer with the MFMA operands swapped):
 // the 32 points of a tile are the 16 registers of the two lane halves, the 32 channels are the lanes, so the max over
 // the wave's points is a v_max3 chain over registers (8 T instructions instead of ~110 plus 16 swizzles) and one
 // exchange between the halves. On this chip every VALU instruction between two f32 MFMAs costs matrix-pipe time

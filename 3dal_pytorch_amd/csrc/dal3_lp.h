@@ -347,46 +347,7 @@ __device__ __forceinline__ void lp_seg_layers(LdsRing<SEG>& ring, const float* b
     }
 }
 
-// max epilogue into an LDS int array (zero-initialised, flushed to global once per workgroup)
-template <int T>
-__device__ __forceinline__ void lp_tile_max(const f32x16 (&acc)[T], const float* bias, int* smax, int lane) {
-    f32x16 m = acc[0];
-#pragma unroll
-    for (int j = 1; j < T; ++j) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m[r] = __builtin_fmaxf(m[r], acc[j][r]);
-    }
-    float v8[8], v4[4], v2[2], v1;
-    {
-        const bool up = lane & 1;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v8[i] = __builtin_fmaxf(up ? m[i + 8] : m[i], swz_xor<1>(up ? m[i] : m[i + 8]));
-    }
-    {
-        const bool up = lane & 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v4[i] = __builtin_fmaxf(up ? v8[i + 4] : v8[i], swz_xor<2>(up ? v8[i] : v8[i + 4]));
-    }
-    {
-        const bool up = lane & 4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) v2[i] = __builtin_fmaxf(up ? v4[i + 2] : v4[i], swz_xor<4>(up ? v4[i] : v4[i + 2]));
-    }
-    {
-        const bool up = lane & 8;
-        v1 = __builtin_fmaxf(up ? v2[1] : v2[0], swz_xor<8>(up ? v2[0] : v2[1]));
-    }
-    v1 = __builtin_fmaxf(v1, swz_xor<16>(v1));
-    const int r = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-    const int ch = tile_chan(r, lane >> 5);
-    int bits = __float_as_int(v1 + bias[ch]);
-    bits = bits > 0 ? bits : 0;
-    if ((lane & 16) == 0) atomicMax(smax + ch, bits);
-}
-
-// The last layer of a stack with the max over points fused, for the TPS out-tiles of the current ring slot (their
-// fragments start at fragment 0): one fragment stream, groups of four read a group ahead — across tile boundaries
-// too, so that a tile's max epilogue (VALU + LDS atomics) runs while the next tile's first fragments are in flight.
+// (the maxima go into an LDS int array, zero-initialised, flushed to global once per group)
 // Max epilogue of a TRANSPOSED tile (points on the MFMA rows = the 16 registers, channels on the columns = the lanes):
 // the max over the points of the wave's T tiles is a max over registers — elementwise VALU, no lane exchange; the two
 // lane halves hold the same 32 channels and simply both take part in the LDS atomic (two lanes per address).
