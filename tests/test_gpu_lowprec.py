@@ -121,3 +121,34 @@ def test_lowprec_kernels_are_bitwise_repeatable(prec):
         out = model._run(pts, init, None)
         for k, v in ref.items():
             assert torch.equal(out[k], v), k
+
+
+@pytest.mark.parametrize("kind,n", [("static_one", 700), ("static_two", 1024), ("dynamic", 0)])
+def test_persistent_groups_equal_single_group_launches(kind, n):
+    """The 16-bit kernels are persistent: a workgroup walks many groups of points with state carried across them
+    (cyclic weight ring, the next group's points and per-crop term prefetched, ring segments opened a layer early,
+    tiles of duplicates skipped). A big launch (several groups per workgroup, ragged point counts, crops with few
+    segmented points) must give, crop for crop, the bits of launches so small that every workgroup sees one group."""
+    B = 640
+    if kind == "dynamic":
+        pts_np, box_np, init_np, _ = synth.dynamic_items(B // 8, seed=13)                  # 80 items x 5120 points
+        B = B // 8
+        model = build_model("dynamic", synth.state_dict("dynamic", seed=13))
+        args = (dev(pts_np).transpose(2, 1), dev(box_np).transpose(2, 1), dev(init_np))
+    else:
+        model, sd, pts_np, _, init, gt = _static(kind, B, n, seed=13)                     # about half the points segmented
+        pts_np[::7] *= 40.0                                                               # ... and crops with hardly any
+        args = (dev(pts_np).transpose(2, 1), init, gt)
+    model.precision = "bf16"
+    whole = model._run(*args)
+    keys = ("logits", "mask", "counts", "bp" if kind == "dynamic" else "bp1", "boxes7")
+    step = 4 if kind == "dynamic" else 16
+    for a in range(0, B, step * 5):                                                       # every fifth small batch
+        model.item_offset = a
+        part = model._run(*[t[a:a + step] for t in args])
+        for k in keys:
+            assert torch.equal(part[k], whole[k][a:a + step]), (k, a)
+    model.item_offset = 0
+    if kind != "dynamic":
+        counts = whole["counts"].cpu().numpy()
+        assert (counts < 256).any() and (counts > 256).any()                              # both head paths: tile skipped / not
