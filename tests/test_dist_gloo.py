@@ -90,3 +90,92 @@ def test_sharded_refine_equals_per_shard_concat(world, n_items):
     lo, hi = dal3_dist.shard_range(n_items, world - 1, world)
     if hi > lo:
         assert np.array_equal(whole[lo:hi], synth.static_crops(hi - lo, 128, first=lo)[0])
+
+
+# ------------------------------------------------------------------ the file-level drivers (eval.py) on two ranks
+def _eval_worker(rank, world, port, root, head, ret):
+    """refine_static_tracks / refine_dynamic_tracks with the device stages stood in on CPU: crop preparation by a
+    deterministic function of the GLOBAL item index (what the device sampler guarantees), the heads by a cheap
+    function of the prepared crop. Under test: contiguous sharding of tracks / track-frames, per-batch item offsets,
+    the ragged all-gather, and that every rank ends up with the whole result."""
+    import pickle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ev = importlib.import_module("3dal_pytorch_amd.eval")
+        infos = ev.reorganize_info(pickle.load(open(os.path.join(root, "infos.pkl"), "rb")))
+        annos = ev.Annos(infos)
+        track = pickle.load(open(os.path.join(root, "trackStatic.pkl" if head == "static" else "trackDynamic.pkl"), "rb"))
+
+        def fake_static(tracks, poses, n_points, sampler, seed, item_offset, device):
+            assert sampler == "device"
+            pts = torch.stack([torch.full((3, 8), float(item_offset + b) + 0.25 * len(t["token"])) for b, t in enumerate(tracks)])
+            init = torch.stack([torch.as_tensor(np.asarray(t["bbox"][0], np.float32)) for t in tracks])
+            return pts, init
+
+        class _Store:
+            def __init__(self, tracks, dev):
+                self.tracks = tracks
+
+        def fake_dynamic(store, items, poses, n_per_frame, r, s, sampler, seed, item_offset, device):
+            assert sampler == "device"
+            B = len(items)
+            pts = torch.stack([torch.full((4, 8), float(item_offset + b) + 0.5 * t + 0.01 * i) for b, (t, i) in enumerate(items)])
+            init = torch.stack([torch.as_tensor(np.append(np.asarray(store.tracks[t]["bbox"][i], np.float32), 0.0)) for t, i in items])
+            return pts, torch.zeros((B, 8, 101)), init
+
+        class _Model(torch.nn.Module):
+            r, s = 2, 50
+
+            def __init__(self):
+                super().__init__()
+                self.p = torch.nn.Parameter(torch.zeros(1))
+                self.item_offset = 0
+
+            def refine(self, pts, *rest):
+                init = rest[-1]
+                return torch.cat([init[:, :6], pts[:, 0, :1] + self.item_offset * 0.0], 1).float()
+
+        ev.prep.prepare_static_batch = fake_static
+        ev.prep.prepare_dynamic_batch = fake_dynamic
+        ev.prep.TrackStore = _Store
+        model = _Model()
+        if head == "static":
+            track = ev.preprocessing(track, annos)
+            out = ev.refine_static_tracks(model, track, annos, batch_size=2, n_points=8, sampler="device")
+        else:
+            out = ev.refine_dynamic_tracks(model, track, annos, batch_size=5, sampler="device")
+        if world > 1:
+            with pytest.raises(ValueError, match="cannot be sharded"):
+                ev.refine_static_tracks(model, track, annos, sampler="numpy")
+        if rank == world - 1:                              # the LAST rank reports: it holds the ragged tail
+            ret.put(out)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("head", ["static", "dynamic"])
+def test_eval_drivers_shard_and_gather(tmp_path, head):
+    synth.segment_files(str(tmp_path), 77, n_frames=12, n_tracks=7)
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world in (1, 2, 3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ret = ctx.Queue()
+        procs = [ctx.Process(target=_eval_worker, args=(r, world, port, str(tmp_path), head, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results[world] = ret.get(timeout=240)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    n = results[1].shape[0]
+    assert n == (5 if head == "static" else 70) and results[1].shape == (n, 7)      # 7 tracks, 2 dropped / 70 track-frames
+    assert len(np.unique(results[1][:, 6])) == n                   # the stand-in encodes the global item index
+    for world in (2, 3):
+        assert np.array_equal(results[world], results[1]), world
