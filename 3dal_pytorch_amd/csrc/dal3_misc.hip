@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void segment_counts_kernel(const uint8_t* __re
 //     count < M -> every segmented point plus duplicates (the reference tops up with random
 //     duplicates; every consumer is a max over points, so which duplicates is immaterial);
 //     count >= M -> the M smallest 32-bit hash keys (uniform subset without replacement), found by
-//     a 32-step bisection on the key value, ties taken in index order.
+//     a radix select on the key value, ties taken in index order.
 //  3. gather obj_pts[b,k,:C] = pts[b,:C,idx[k]]
 __global__ __launch_bounds__(256) void compact_sample_kernel(const uint8_t* __restrict__ mask, BCN pts, int N, int C,
                                                              int M, int sampler, const int32_t* __restrict__ choice,
@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256) void compact_sample_kernel(const uint8_t* __re
                                                              int32_t* __restrict__ counts, int32_t* __restrict__ pos,
                                                              int32_t* __restrict__ obj_idx, float* __restrict__ obj_pts) {
     __shared__ int lds_wave[8];
+    __shared__ int lds_hist[256];
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x;
     int32_t* pos_b = pos + b * N;
@@ -337,16 +338,44 @@ __global__ __launch_bounds__(256) void compact_sample_kernel(const uint8_t* __re
         for (int k = tid; k < M; k += 256) idx_b[k] = pos_b[k % count];
     } else {
         const uint64_t item = (uint64_t)(item_offset + b);
-        // smallest thr with #{key <= thr} >= M
-        uint32_t lo = 0, hi = 0xFFFFFFFFu;
-        while (lo < hi) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            int c = 0;
-            for (int i = tid; i < count; i += 256) c += hash_key(seed, item, (uint32_t)i) <= mid ? 1 : 0;
-            c = block_sum(c, lds_wave);
-            if (c >= M) hi = mid; else lo = mid + 1;
+        // thr = the M-th smallest key, by a radix select: four rounds of one byte each (a histogram of the byte over the
+        // keys that match the prefix found so far, then the bin holding the M-th) instead of 32 bisection steps with a
+        // block-wide count each
+        uint32_t prefix = 0;
+        int remaining = M;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            __syncthreads();                                // lds_hist / lds_wave reuse
+            lds_hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < count; i += 256) {
+                const uint32_t key = hash_key(seed, item, (uint32_t)i);
+                if (shift == 24 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&lds_hist[(key >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            // inclusive prefix sum of the 256 bins (bin = thread); the wanted bin is the first with cum >= remaining
+            const int lane = tid & 63, wave = tid >> 6;
+            int cum = lds_hist[tid];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(cum, off);
+                if (lane >= off) cum += up;
+            }
+            if (lane == 63) lds_wave[wave] = cum;
+            __syncthreads();
+            int base = 0;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) base += wv < wave ? lds_wave[wv] : 0;
+            cum += base;
+            const int before = cum - lds_hist[tid];
+            if (before < remaining && cum >= remaining) {   // exactly one thread
+                lds_wave[4] = tid;
+                lds_wave[5] = before;
+            }
+            __syncthreads();
+            prefix |= (uint32_t)lds_wave[4] << shift;
+            remaining -= lds_wave[5];
         }
-        const uint32_t thr = lo;
+        const uint32_t thr = prefix;
         int n_less = 0;
         for (int i = tid; i < count; i += 256) n_less += hash_key(seed, item, (uint32_t)i) < thr ? 1 : 0;
         n_less = block_sum(n_less, lds_wave);

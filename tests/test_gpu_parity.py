@@ -187,6 +187,35 @@ def test_gather_device_sampler_properties():
     assert np.array_equal(idx[4:], idx4)
 
 
+def _hash_key(seed, item, i):
+    """csrc/dal3_misc.hip hash_key (a splitmix64 finaliser of seed, global item index and rank), top 32 bits"""
+    m = (1 << 64) - 1
+    z = (seed ^ (item * 0x9E3779B97F4A7C15) ^ ((i << 32) | i)) & m
+    z = (z + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return ((z ^ (z >> 31)) & m) >> 32
+
+
+def test_gather_device_sampler_takes_the_smallest_keys():
+    """count >= M: exactly the M segmented points with the smallest hash keys (keyed on seed, GLOBAL item index and
+    the point's rank among the segmented ones) — restated on the host, for two point counts, with
+    an item offset, and with M = 2560 of 5120 (the dynamic head's shape)"""
+    for B, N, M, seed, off in ((6, 1024, 512, 42, 0), (3, 5120, 2560, 10922081, 17)):
+        mask = synth.uniform(8, f"dsk{N}", (B, N)) < 0.8
+        mask[0] = True
+        pts = dev(synth.static_crops(1, N, seed=5)[0]).expand(B, N, 3).transpose(2, 1)
+        counts, idx, _ = _gather(mask, pts, M, hip.SAMPLER_DEVICE, seed=seed, item_offset=off)
+        for b in range(B):
+            pos = np.nonzero(mask[b])[0]
+            assert counts[b] == len(pos) >= M
+            keys = np.array([_hash_key(seed, off + b, i) for i in range(len(pos))], dtype=np.uint64)
+            assert len(np.unique(keys)) == len(keys)                     # no ties in these draws
+            order = np.argsort(keys, kind="stable")[:M]
+            want = np.concatenate([pos[np.sort(order[:-1])], pos[order[-1:]]])    # keys below the M-th in index order,
+            assert np.array_equal(idx[b], want), (N, b)                         # then the M-th itself (the "ties")
+
+
 def test_gather_device_sampler_is_uniform():
     """count = 1024, M = 512: every point is kept with probability 1/2 over many items"""
     B, N = 512, 1024
