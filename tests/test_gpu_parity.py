@@ -333,15 +333,16 @@ def test_static_one_b64_teacher_forced_vs_oracle():
     assert rel_err(o["boxes7"].cpu().numpy(), R.decode_static(want, torch.from_numpy(init_np), False)) < TOL
 
 
-def test_shard_equals_whole_job_bitwise():
-    """object crops are independent: rows [a,b) run alone (item_offset=a) == the same rows of the full run"""
-    B, N = 48, 1024
+@pytest.mark.parametrize("B,N,cuts", [(48, 1024, (0, 16, 48)), (1070, 96, (0, 130, 1000, 1070))])
+def test_shard_equals_whole_job_bitwise(B, N, cuts):
+    """object crops are independent: rows [a,b) run alone (item_offset=a) == the same rows of the full run, at a
+    small and at a four-digit, ragged batch size"""
     pts_np, init_np, gt_np = synth.static_crops(B, N, seed=12)
     sd = synth.state_dict("static_two", seed=12)
     model = build_model("static_two", sd)
     full = model.refine(dev(pts_np).transpose(2, 1), dev(init_np), dev(gt_np)).cpu().numpy()
     parts = []
-    for a, b in ((0, 16), (16, 48)):
+    for a, b in zip(cuts, cuts[1:]):
         model.item_offset = a
         parts.append(model.refine(dev(pts_np[a:b]).transpose(2, 1), dev(init_np[a:b]), dev(gt_np[a:b])).cpu().numpy())
     model.item_offset = 0
