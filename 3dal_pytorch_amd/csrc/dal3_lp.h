@@ -365,26 +365,27 @@ __device__ __forceinline__ void lp_tile_max_t(const f32x16 (&acc)[T], const floa
     atomicMax(smax + ch, bits);
 }
 
-// The caller acquires the FIRST segment of the layer and passes first = true; every call then opens the next segment
+// The caller acquires the first segment of the layer and instantiates its first call with FIRST; every call then opens the next segment
 // itself, early: as soon as the slot's last fragments have been read the barrier is taken, and the refill's LDS-DMA
 // instructions and the next segment's first four fragment reads (into g, carried to the next call) go between the last
 // group's MFMAs. (Taken in one piece in front of a segment, wait + barrier + refill + first reads cost ~1,100 cycles
 // with the matrix pipe idle.) After the layer's last segment the ring is one segment ahead, which is what a following
 // layer's acquire() or the next group of a persistent kernel expects... so the caller must not acquire again.
-template <class DT, int KT, int T, int SEG, int TPS>
+template <class DT, int KT, int T, int SEG, int TPS, bool FIRST>
 __device__ __forceinline__ void lp_max_tiles(LdsRing<SEG>& ring, const ActTile<DT> (&X)[T][KT], const float* bias,
-                                             int* smax, int lane, typename DT::v8 (&g)[2][4], bool first) {
+                                             int* smax, int lane, typename DT::v8 (&g)[2][4], f32x16 (&acc)[2][T]) {
     typedef typename DT::v8 frag_t;
     constexpr int FPT = KT * 2, NG = TPS * FPT / 4, ML = LdsRing<SEG>::MY_LOADS;
-    static_assert(FPT % 4 == 0, "whole groups of four fragments per tile");
-    static_assert(NG % 2 == 0, "the carried group must be g[0]");
+    static_assert(FPT % 8 == 0, "at least two groups of four fragments per tile");
+    static_assert(NG % 2 == 0 && TPS % 2 == 0, "the carried group must be g[0], the carried tile acc[1]");
     static_assert(ML <= 4 * T * 2, "two refill parts per MFMA gap at most");
-    // Up to four point tiles per wave there is room for TWO accumulator sets: a tile's max epilogue (about 50 + 16 T
-    // VALU / swizzle / LDS-atomic instructions) is then placed with the first 4 T MFMAs of the NEXT tile and dealt out
-    // between them (sched_group_barrier), instead of standing between the two tiles with the matrix pipe idle.
-    constexpr bool DB = T <= 4 && TPS > 1;
-    f32x16 acc[DB ? 2 : 1][T];
-    if (first) {
+    static_assert(T <= 4, "two accumulator sets");
+    // TWO accumulator sets (acc, the caller's: they live across the calls of a layer): a tile's max epilogue is placed
+    // with the first 4 T MFMAs of the NEXT tile and dealt out between them (sched_group_barrier) instead of standing
+    // between two tiles with the matrix pipe idle — also across segments: a segment's last tile is finished under the
+    // next call's first MFMAs (bias / smax of consecutive segments are contiguous), the layer's very last tile by
+    // lp_max_tiles_finish().
+    if (FIRST) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[0][i] = ring.template frag<DT>(i);
     }
@@ -399,7 +400,7 @@ __device__ __forceinline__ void lp_max_tiles(LdsRing<SEG>& ring, const ActTile<D
         if (last) ring.acquire_wait();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = 4 * gi + i, k = f % FPT, c = DB ? (f / FPT) & 1 : 0;
+            const int f = 4 * gi + i, k = f % FPT, c = (f / FPT) & 1;
             if (k == 0) {
 #pragma unroll
                 for (int j = 0; j < T; ++j) acc[c][j] = f32x16{};
@@ -414,33 +415,28 @@ __device__ __forceinline__ void lp_max_tiles(LdsRing<SEG>& ring, const ActTile<D
 #pragma unroll
                         for (int q = 0; q < 4; ++q) g[0][q] = ring.template frag<DT>(q);
                     }
-                    if (4 * T >= ML) {
-                        if (n < ML) ring.issue_part(n);
-                    } else {
-                        if (2 * n < ML) ring.issue_part(2 * n);
-                        if (2 * n + 1 < ML) ring.issue_part(2 * n + 1);
-                    }
+                    lp_refill_gap<SEG, 4 * T>(ring, n);
                     DAL3_SCHED_FENCE();
                 }
             }
-            if (!DB && k == FPT - 1) lp_tile_max_t<T>(acc[0], bias + 32 * (f / FPT), smax + 32 * (f / FPT), lane);
         }
         if (last) ring.issue_done();
-        if (DB && (4 * gi) % FPT == 0 && gi > 0 && !last) {
-            const int t = 4 * gi / FPT - 1;                // the tile that finished with the previous group
-            lp_tile_max_t<T>(acc[t & 1], bias + 32 * t, smax + 32 * t, lane);
+        if ((4 * gi) % FPT == 0 && !last && (gi > 0 || !FIRST)) {
+            const int t = 4 * gi / FPT - 1;                // the tile that finished with the previous group (-1: the
+            lp_tile_max_t<T>(acc[t & 1], bias + 32 * t, smax + 32 * t, lane);              // previous segment's last)
 #pragma unroll
             for (int n = 0; n < 4 * T; ++n) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // up to four VALU
-                __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);     // up to two DS (swizzles, the atomic)
+                __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);     // up to two DS (the bias read, the atomic)
             }
         }
         DAL3_SCHED_FENCE();
     }
-    if (DB) {
-        if (FPT == 4) lp_tile_max_t<T>(acc[(TPS - 2) & 1], bias + 32 * (TPS - 2), smax + 32 * (TPS - 2), lane);
-        lp_tile_max_t<T>(acc[(TPS - 1) & 1], bias + 32 * (TPS - 1), smax + 32 * (TPS - 1), lane);
-    }
+}
+// the epilogue of the layer's very last tile (bias / smax: that tile's 32 channels)
+template <int T>
+__device__ __forceinline__ void lp_max_tiles_finish(const f32x16 (&acc)[2][T], const float* bias, int* smax, int lane) {
+    lp_tile_max_t<T>(acc[1], bias, smax, lane);
 }
 

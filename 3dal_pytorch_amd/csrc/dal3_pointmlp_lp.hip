@@ -101,9 +101,12 @@ __global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN
     }
     LP_STAMP(2);
     typename DT::v8 g5[2][4];
-    for (int seg = 0; seg < 8; ++seg)                      // conv5: 4 out-tiles (32 fragments) per segment; the last
-        lp_max_tiles<DT, 4, T, SEG, 4>(ring, x4, s_bias + 256 + 128 * seg, s_max + 128 * seg, lane, g5, seg == 0);
-    LP_STAMP(3);                                           // call has already opened the next group's segment 0
+    f32x16 acc5[2][T];                                     // conv5: 4 out-tiles (32 fragments) per segment; the last
+    lp_max_tiles<DT, 4, T, SEG, 4, true>(ring, x4, s_bias + 256, s_max, lane, g5, acc5);
+    for (int seg = 1; seg < 8; ++seg)                      // call has already opened the next group's segment 0
+        lp_max_tiles<DT, 4, T, SEG, 4, false>(ring, x4, s_bias + 256 + 128 * seg, s_max + 128 * seg, lane, g5, acc5);
+    lp_max_tiles_finish<T>(acc5, s_bias + 256 + 1024 - 32, s_max + 1024 - 32, lane);
+    LP_STAMP(3);
     __syncthreads();
     int* gi = reinterpret_cast<int*>(g + b * 1024);
     for (int i = threadIdx.x; i < 1024; i += 256) {
@@ -549,8 +552,11 @@ __global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN 
     lp_seg_layers<DT, K3, M3, T, SEG, TPS3, 0, true>(ring, s_bias + C2, x2, x3, lane);
     const float* s_b4 = s_bias + C2 + C3;
     typename DT::v8 g4[2][4];
-    for (int seg = 0; seg < M4 / TPS4; ++seg)              // (the last call opens the next group's first segment)
-        lp_max_tiles<DT, K4, T, SEG, TPS4>(ring, x3, s_b4 + 32 * TPS4 * seg, s_max + 32 * TPS4 * seg, lane, g4, seg == 0);
+    f32x16 acc4[2][T];                                     // (the last call opens the next group's first segment)
+    lp_max_tiles<DT, K4, T, SEG, TPS4, true>(ring, x3, s_b4, s_max, lane, g4, acc4);
+    for (int seg = 1; seg < M4 / TPS4; ++seg)
+        lp_max_tiles<DT, K4, T, SEG, TPS4, false>(ring, x3, s_b4 + 32 * TPS4 * seg, s_max + 32 * TPS4 * seg, lane, g4, acc4);
+    lp_max_tiles_finish<T>(acc4, s_b4 + 512 - 32, s_max + 512 - 32, lane);
     __syncthreads();
     int* fi = reinterpret_cast<int*>(feat + b * 512);
     for (int i = threadIdx.x; i < 512; i += 256) {
