@@ -121,13 +121,14 @@ __device__ __forceinline__ int pack_relu_pair(float a, float b) {
 #define LP_SLOTS 3
 
 // LDS ring of weight segments. All state is wave-uniform.
-template <int SEG>
+template <int SEG, int SLOTS = LP_SLOTS>
 struct LdsRing {
+    static_assert(SLOTS == 2 || SLOTS == 3, "SLOTS - 1 segments are in flight ahead of the one in use");
     static constexpr int SLOT_BYTES = SEG * 1024;
     static constexpr int MY_LOADS = SEG / 4;              // LDS-DMA instructions per wave per segment (4 waves)
     static_assert(SEG % 4 == 0, "segment must split evenly over the 4 waves");
     const char* stream;                                   // global: this kernel's fragment stream
-    char* lds;                                            // LDS: LP_SLOTS * SLOT_BYTES
+    char* lds;                                            // LDS: SLOTS * SLOT_BYTES
     int n_segs, seg_issue, slot_issue, slot_use, wave, lane;
 #ifdef DAL3_STAMP
     long long bar_ticks = 0, wait_ticks = 0;              // diagnostic: time spent in the counted wait / in s_barrier
@@ -144,9 +145,9 @@ struct LdsRing {
         lane = lane_;
         seg_issue = 0;
         slot_issue = 0;
-        slot_use = LP_SLOTS - 1;
-        issue();                                          // segments 0 and 1 in flight before the first acquire
-        issue();
+        slot_use = SLOTS - 1;
+        issue();                                          // segments 0 and (three slots) 1 in flight before the first acquire
+        if (SLOTS == 3) issue();
     }
     // this wave's quarter of the next segment -> slot_issue (past the stream's end: re-read the last one)
     __device__ __forceinline__ void issue() {
@@ -163,7 +164,7 @@ struct LdsRing {
         }
         ++seg_issue;
         if (cyclic && seg_issue == n_segs) seg_issue = 0;
-        slot_issue = slot_issue + 1 == LP_SLOTS ? 0 : slot_issue + 1;
+        slot_issue = slot_issue + 1 == SLOTS ? 0 : slot_issue + 1;
     }
     // make the next segment readable: my share landed (the following segment's MY_LOADS loads may stay in
     // flight), everyone's share landed and everyone is done with the slot about to be refilled (barrier)
@@ -182,7 +183,7 @@ struct LdsRing {
         unsigned long long t0_, t1_, t2_;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory");
 #endif
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MY_LOADS) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SLOTS == 3 ? MY_LOADS : 0) : "memory");   // (two slots: no younger segment in flight)
 #ifdef DAL3_STAMP
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_)::"memory");
 #endif
@@ -196,7 +197,7 @@ struct LdsRing {
 #endif
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        slot_use = slot_use + 1 == LP_SLOTS ? 0 : slot_use + 1;
+        slot_use = slot_use + 1 == SLOTS ? 0 : slot_use + 1;
     }
     __device__ __forceinline__ void issue_part(int k) {
         const int seg = seg_issue < n_segs ? seg_issue : n_segs - 1;
@@ -209,7 +210,7 @@ struct LdsRing {
     __device__ __forceinline__ void issue_done() {
         ++seg_issue;
         if (cyclic && seg_issue == n_segs) seg_issue = 0;
-        slot_issue = slot_issue + 1 == LP_SLOTS ? 0 : slot_issue + 1;
+        slot_issue = slot_issue + 1 == SLOTS ? 0 : slot_issue + 1;
     }
     template <class DT>
     __device__ __forceinline__ typename DT::v8 frag(int f) const {
@@ -221,9 +222,9 @@ struct LdsRing {
 // fragments are read in groups of four, a group ahead of their MFMAs (see lp_layer)
 // EARLY: the block's last four fragments are the last reads of the slot — the next segment is opened before their
 // MFMAs (acquire_wait) and its refill dealt out between them; whoever uses the ring next must not acquire again.
-template <int SEG, int GAPS>
-__device__ __forceinline__ void lp_refill_gap(LdsRing<SEG>& ring, int n) {
-    constexpr int ML = LdsRing<SEG>::MY_LOADS;
+template <int SEG, int GAPS, class Ring>
+__device__ __forceinline__ void lp_refill_gap(Ring& ring, int n) {
+    constexpr int ML = Ring::MY_LOADS;
     static_assert(ML <= 2 * GAPS, "two refill parts per MFMA gap at most");
     if (GAPS >= ML) {
         if (n < ML) ring.issue_part(n);
@@ -237,8 +238,8 @@ __device__ __forceinline__ void lp_refill_gap(LdsRing<SEG>& ring, int n) {
 struct LpNoGap {
     __device__ __forceinline__ void operator()(int) const {}
 };
-template <class DT, int KT, int T, int SEG, bool EARLY = false, class Gap = LpNoGap>
-__device__ __forceinline__ void lp_block(LdsRing<SEG>& ring, int f0, const ActTile<DT> (&X)[T][KT],
+template <class DT, int KT, int T, int SEG, bool EARLY = false, class Gap = LpNoGap, class Ring>
+__device__ __forceinline__ void lp_block(Ring& ring, int f0, const ActTile<DT> (&X)[T][KT],
                                          f32x16 (&acc)[T], Gap gap = Gap()) {
     typedef typename DT::v8 frag_t;
     constexpr int NG = KT * 2 / 4;
@@ -280,8 +281,8 @@ __device__ __forceinline__ void lp_block(LdsRing<SEG>& ring, int f0, const ActTi
 // The MTN*KT*2 fragments are walked as ONE stream in groups of four, each group's ds_reads issued before the
 // previous group's MFMAs (also across out-tile boundaries): left to itself hipcc puts every read right in front
 // of its MFMAs and each fragment exposes the LDS latency (T = 2: only 64 MFMA cycles per fragment to hide it).
-template <class DT, int KT, int MT, int T, int SEG, int MT0, int MTN, bool EARLY = false>
-__device__ __forceinline__ void lp_layer(LdsRing<SEG>& ring, int f0, const float* bias,
+template <class DT, int KT, int MT, int T, int SEG, int MT0, int MTN, bool EARLY = false, class Ring>
+__device__ __forceinline__ void lp_layer(Ring& ring, int f0, const float* bias,
                                          const ActTile<DT> (&X)[T][KT], ActTile<DT> (&Y)[T][MT], int lane) {
     typedef typename DT::v8 frag_t;
     constexpr int FPT = KT * 2;                            // fragments per out-tile
@@ -337,8 +338,8 @@ __host__ __device__ constexpr int lp_tiles_per_seg(int kt, int mt) {
 // CHAIN = false: every segment is acquired in front of its out-tiles. CHAIN = true: the layer's first segment is open
 // already (by whoever used the ring before) and every segment opens the next one itself under its last MFMAs (lp_layer
 // EARLY) — after the layer the following layer's (or group's) first segment is open.
-template <class DT, int KT, int MT, int T, int SEG, int TPS, int M0, bool CHAIN = false>
-__device__ __forceinline__ void lp_seg_layers(LdsRing<SEG>& ring, const float* bias, const ActTile<DT> (&X)[T][KT],
+template <class DT, int KT, int MT, int T, int SEG, int TPS, int M0, bool CHAIN = false, class Ring>
+__device__ __forceinline__ void lp_seg_layers(Ring& ring, const float* bias, const ActTile<DT> (&X)[T][KT],
                                               ActTile<DT> (&Y)[T][MT], int lane) {
     if constexpr (M0 < MT) {
         if (!CHAIN) ring.acquire();
@@ -371,11 +372,11 @@ __device__ __forceinline__ void lp_tile_max_t(const f32x16 (&acc)[T], const floa
 // group's MFMAs. (Taken in one piece in front of a segment, wait + barrier + refill + first reads cost ~1,100 cycles
 // with the matrix pipe idle.) After the layer's last segment the ring is one segment ahead, which is what a following
 // layer's acquire() or the next group of a persistent kernel expects... so the caller must not acquire again.
-template <class DT, int KT, int T, int SEG, int TPS, bool FIRST>
-__device__ __forceinline__ void lp_max_tiles(LdsRing<SEG>& ring, const ActTile<DT> (&X)[T][KT], const float* bias,
+template <class DT, int KT, int T, int SEG, int TPS, bool FIRST, class Ring>
+__device__ __forceinline__ void lp_max_tiles(Ring& ring, const ActTile<DT> (&X)[T][KT], const float* bias,
                                              int* smax, int lane, typename DT::v8 (&g)[2][4], f32x16 (&acc)[2][T]) {
     typedef typename DT::v8 frag_t;
-    constexpr int FPT = KT * 2, NG = TPS * FPT / 4, ML = LdsRing<SEG>::MY_LOADS;
+    constexpr int FPT = KT * 2, NG = TPS * FPT / 4, ML = Ring::MY_LOADS;
     static_assert(FPT % 8 == 0, "at least two groups of four fragments per tile");
     static_assert(NG % 2 == 0 && TPS % 2 == 0, "the carried group must be g[0], the carried tile acc[1]");
     static_assert(ML <= 4 * T * 2, "two refill parts per MFMA gap at most");

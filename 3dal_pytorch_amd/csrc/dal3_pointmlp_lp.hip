@@ -482,8 +482,14 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
 // conv1..4 + max over the points. Per layer the out-tiles are grouped into segments of <= 32 fragments.
 // Persistent like the two kernels above: one workgroup per CU walks the (point tile, item) pairs in item-minor order
 // (XCD balance: see point_head_kernel), skipping the tiles that hold only duplicates.
+// The point heads fit 256 registers per wave, so with a TWO-slot ring (64 + 8 KiB of LDS) two workgroups share a CU:
+// two waves per SIMD, one computing while the other sits at a barrier or in an epilogue (heads 0.63 -> 0.61 ms; with
+// two slots one segment is in flight ahead of the one in use instead of two). 3 restores one workgroup per CU.
+#ifndef DAL3_LP_HEAD_SLOTS
+#define DAL3_LP_HEAD_SLOTS 2
+#endif
 template <class DT, int KS, int C1, int C2, int C3, int T>
-__global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN x, int c_in, int n_pts_all,
+__global__ __launch_bounds__(256, DAL3_LP_HEAD_SLOTS == 2 ? 2 : 1) void point_head_lp_kernel(PointHeadLpW w, BCN x, int c_in, int n_pts_all,
                                                             int n_items, int n_groups, float* __restrict__ feat,
                                                             const int32_t* __restrict__ distinct) {
     constexpr int SEG = LP_HEAD_SEG;
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256) void point_head_lp_kernel(PointHeadLpW w, BCN 
     for (int i = threadIdx.x; i < C1; i += 256) s_b1[i] = w.b1[i];
     for (int i = threadIdx.x; i < NW1; i += 256) s_w1[i] = w.w1[i];
     __syncthreads();
-    LdsRing<SEG> ring;
+    LdsRing<SEG, DAL3_LP_HEAD_SLOTS> ring;
     ring.init(w.stream, smem + lp_head_small_bytes(C1, C2, C3, KS), M2 / TPS2 + M3 / TPS3 + M4 / TPS4, wave, lane, true);
 
     // the next group's points and its item's count of distinct points, fetched a layer ahead (see the decode kernel)
@@ -613,13 +619,14 @@ template <class DT, int KS, int C1, int C2, int C3>
 static hipError_t head_lp(const PointHeadLpW& w, BCN x, int c_in, int B, int M, float* feat, const int32_t* distinct,
                           hipStream_t s) {
     constexpr int T = DAL3_LP_HEAD_T;
-    const size_t lds = LP_SLOTS * LP_HEAD_SEG * 1024 + lp_head_small_bytes(C1, C2, C3, KS);
+    const size_t lds = DAL3_LP_HEAD_SLOTS * LP_HEAD_SEG * 1024 + lp_head_small_bytes(C1, C2, C3, KS);
     auto k = point_head_lp_kernel<DT, KS, C1, C2, C3, T>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int64_t n_groups = (int64_t)B * lp_tiles(M, T);
     if (n_groups > 0x7fffffff) return hipErrorInvalidValue;
-    const int64_t grid = n_groups < lp_cu_count() ? n_groups : lp_cu_count();
+    const int64_t wgs = (int64_t)lp_cu_count() * (DAL3_LP_HEAD_SLOTS == 2 ? 2 : 1);
+    const int64_t grid = n_groups < wgs ? n_groups : wgs;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, s, w, x, c_in, M, B, (int)n_groups, feat, distinct);
     return hipGetLastError();
 }
