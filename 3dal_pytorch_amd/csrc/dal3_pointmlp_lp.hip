@@ -43,8 +43,14 @@ __host__ __device__ constexpr int lp_head_small_bytes(int c1, int c2, int c3, in
 // longer fits the arch VGPRs next to the accumulators and every conv5 MFMA paid v_accvgpr_read for its B operand
 // (54 against 40 cycles per MFMA); what made T = 4 slower before — twice the workgroups, each with its start-up, and
 // twice the ring refills per point — is gone with persistence and with the refills hidden under MFMAs.
+#ifndef DAL3_LP_ENC_T
+#define DAL3_LP_ENC_T 4
+#endif
+#ifndef DAL3_LP_ENC_SLOTS
+#define DAL3_LP_ENC_SLOTS 3                               // 2 (with T = 2): two workgroups per CU (A/B switch)
+#endif
 template <class DT, int T>
-__global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN pts, int c_in, int n_pts,
+__global__ __launch_bounds__(256, DAL3_LP_ENC_SLOTS == 2 ? 2 : 1) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN pts, int c_in, int n_pts,
                                                                 int tiles_per_item, int n_groups, float* __restrict__ g) {
     constexpr int SEG = LP_ENC_SEG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void ins_seg_encode_lp_kernel(InsSegLpW w, BCN
     if (threadIdx.x < 64) s_b1[threadIdx.x] = w.b1[threadIdx.x];
     s_w1[threadIdx.x] = w.w1[threadIdx.x];
     __syncthreads();
-    LdsRing<SEG> ring;
+    LdsRing<SEG, DAL3_LP_ENC_SLOTS> ring;
     ring.init(w.enc_stream, smem + LP_ENC_SMALL_BYTES, LP_ENC_SEGS, wave, lane, true);
 
     float in_nx[T][2];
@@ -588,15 +594,16 @@ static int lp_cu_count() {                                  // one persistent wo
 }
 template <class DT>
 static hipError_t enc_lp(const InsSegLpW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
-    constexpr int T = 4;
-    const size_t lds = LP_SLOTS * LP_ENC_SEG * 1024 + LP_ENC_SMALL_BYTES;
+    constexpr int T = DAL3_LP_ENC_T;
+    const size_t lds = DAL3_LP_ENC_SLOTS * LP_ENC_SEG * 1024 + LP_ENC_SMALL_BYTES;
     auto k = ins_seg_encode_lp_kernel<DT, T>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int tpi = lp_tiles(N, T);
     const int64_t n_groups = (int64_t)B * tpi;
     if (n_groups > 0x7fffffff) return hipErrorInvalidValue;
-    const int64_t grid = n_groups < lp_cu_count() ? n_groups : lp_cu_count();
+    const int64_t wgs = (int64_t)lp_cu_count() * (DAL3_LP_ENC_SLOTS == 2 ? 2 : 1);
+    const int64_t grid = n_groups < wgs ? n_groups : wgs;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, s, w, pts, c_in, N, tpi, (int)n_groups, g);
     return hipGetLastError();
 }
