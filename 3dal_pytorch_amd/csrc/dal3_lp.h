@@ -120,6 +120,19 @@ __device__ __forceinline__ int pack_relu_pair(float a, float b) {
 
 #define LP_SLOTS 3
 
+// One LDS-DMA instruction: 16 B per lane from gbase + lane_off (uniform 64-bit base, 32-bit per-lane offset) to the
+// LDS address dst + 16 * lane. Written as inline asm on purpose: with __builtin_amdgcn_global_load_lds anywhere in
+// a loop hipcc's waitcnt pass degrades EVERY wait on an LDS read in that loop to `s_waitcnt lgkmcnt(0)` (LDS written
+// by a VMEM instruction: it gives up counting), so each group of fragment reads issued a group ahead was waited for
+// right away, together with the group actually needed — the LDS latency the read-ahead was there to hide. Hidden in
+// asm, the compiler counts LDS reads exactly again (lgkmcnt(4) etc.). Its own vmcnt waits stay safe: loads it does
+// not know of only make the real count higher than its model, and loads return in order. m0 is not used otherwise
+// in these kernels (it cannot be declared as a clobber: reserved).
+__device__ __forceinline__ void lds_dma16(const char* gbase, uint32_t lane_off, char* dst) {
+    const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dst;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(gbase), "s"(lds_addr) : "memory");
+}
+
 // LDS ring of weight segments. All state is wave-uniform.
 template <int SEG, int SLOTS = LP_SLOTS>
 struct LdsRing {
@@ -159,8 +172,7 @@ struct LdsRing {
 #pragma unroll
         for (int k = 0; k < MY_LOADS; ++k) {
             const int f = wave + 4 * k;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024 + (uint32_t)(lane * 16)),
-                                             (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+            lds_dma16(src + f * 1024, (uint32_t)(lane * 16), dst + f * 1024);
         }
         ++seg_issue;
         if (cyclic && seg_issue == n_segs) seg_issue = 0;
@@ -204,8 +216,7 @@ struct LdsRing {
         const int f = wave + 4 * k;
         const char* src = stream + (size_t)seg * SLOT_BYTES + f * 1024;
         char* dst = lds + slot_issue * SLOT_BYTES + f * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint32_t)(lane * 16)),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        lds_dma16(src, (uint32_t)(lane * 16), dst);
     }
     __device__ __forceinline__ void issue_done() {
         ++seg_issue;
