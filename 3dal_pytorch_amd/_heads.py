@@ -7,6 +7,8 @@ the stream (plumbing). The train-mode `forward_train` methods run stock torch op
 training needs batch-statistics BN, live dropout and autograd (SURVEY.md 8(a) note T); they are
 never used when `self.training` is False.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -117,28 +119,80 @@ class DynamicPointNetEstimation(_PointHead):
 
 
 class PackedCache:
-    """Folded + fragment-ordered device weights are a derived cache of the nn.Parameters: rebuilt
-    when any tensor's version counter, storage or device changes (load_state_dict, .cuda(),
-    optimizer steps)."""
+    """Folded + fragment-ordered device weights are a derived cache of the nn.Parameters. A blob is rebuilt when
+    any tensor of its module changed identity — (data_ptr, version counter, shape, device) per tensor, compared as
+    a tuple — which covers load_state_dict, .cuda()/.to(), optimizer steps and every in-place op on the tensor
+    itself. It does NOT see writes that bypass the version counter: `p.data.copy_()`, `p.data.mul_()`, EMA updates
+    through `.data`, writes through raw pointers. After such an update call `model.invalidate_packed()`; the model
+    classes also call it from load_state_dict and _apply. DAL3_CHECK_PACKED=1 (debug) additionally checksums every
+    tensor on the device at each use and rebuilds on a mismatch (one device->host sync per forward)."""
 
     def __init__(self):
         self._stamp = {}
         self._blob = {}
+        self._src = {}
+        self._check = os.environ.get("DAL3_CHECK_PACKED") == "1"
 
     @staticmethod
-    def _stamp_of(module):
-        s = 0
-        for t in list(module.parameters()) + list(module.buffers()):
-            s = (s * 1000003 + t._version * 31 + t.data_ptr()) & 0xFFFFFFFFFFFF
-        return s
+    def _tensors(module):
+        return list(module.parameters()) + list(module.buffers())
+
+    def _stamp_of(self, module, dtype):
+        ts = self._tensors(module)
+        stamp = tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in ts) + (dtype,)
+        if self._check:
+            with torch.no_grad():
+                stamp += (tuple(float(t.detach().double().sum()) for t in ts),)
+        return stamp
 
     def get(self, key, module, head_kind, dtype=_hip.F32):
-        stamp = (self._stamp_of(module), dtype)
+        stamp = self._stamp_of(module, dtype)
         if self._stamp.get(key) != stamp:
             dev = next(module.parameters()).device
             self._blob[key] = _hip.pack(head_kind, module.pairs(), dev, dtype)
             self._stamp[key] = stamp
+            self._src[key] = (module, dtype)
         return self._blob[key]
+
+    def current(self):
+        """True when every packed blob still matches the tensors it was built from"""
+        return all(self._stamp_of(mod, dt) == self._stamp[key] for key, (mod, dt) in self._src.items())
+
+    def invalidate(self):
+        """forget every packed blob: the next forward re-folds and re-packs from the current parameters"""
+        self._stamp.clear()
+        self._blob.clear()
+        self._src.clear()
+
+    def snapshot(self):
+        """(stamps, blobs) as they are now: what a captured hipGraph must keep alive and compare against"""
+        return dict(self._stamp), dict(self._blob)
+
+
+class PackedModelMixin:
+    """invalidate_packed() + the hooks that call it; mixed into the three model classes"""
+
+    def invalidate_packed(self):
+        self._cache.invalidate()
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._cache.invalidate()
+        return out
+
+    def train(self, mode=True):
+        # the HIP training kernels update running statistics through raw pointers (no version bump): whatever was
+        # packed before a train/eval switch is not trusted after it
+        out = super().train(mode)
+        if hasattr(self, "_cache"):
+            self._cache.invalidate()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if hasattr(self, "_cache"):
+            self._cache.invalidate()
+        return out
 
 
 def dtype_of(precision):

@@ -138,3 +138,41 @@ def static_two_flop(n_pts, m=NUM_OBJECT_POINT):
 def dynamic_flop(n_pts=NUM_FRAME * 1024, m=NUM_FRAME * NUM_OBJECT_POINT, n_box=101):
     return 2 * (ins_seg_mac(4, n_pts) + head_mac(POINT_EMB, m) + head_mac(BOX_EMB, n_box)
                 + head_mac(DYNAMIC_BOX_EST, 0))
+
+
+# Executed work (what the kernels really issue), reported NEXT to the algorithmic figures above and never in their
+# place: the first layer's K is padded to the MFMA's k-step (3 -> 4), the decode kernel recomputes
+# conv1-conv2 instead of reading a 1 GB activation back, ragged N is padded to the wave's tile — and the point heads
+# SKIP object points that are copies (device sampler: only the first min(count, M) sampled points are distinct).
+def _pad(n, g):
+    return (n + g - 1) // g * g
+
+
+def ins_seg_encode_mac(n_channel, executed=False):
+    c = _pad(n_channel, 2) if executed else n_channel
+    return c * 64 + 64 * 64 + 64 * 64 + 64 * 128 + 128 * 1024
+
+
+def ins_seg_decode_mac(n_channel, executed=False):
+    mac = 64 * 512 + 512 * 256 + 256 * 128 + 128 * 128 + 128 * 2
+    if executed:
+        mac += _pad(n_channel, 2) * 64 + 64 * 64
+    return mac
+
+
+def head_point_mac(table, executed=False):
+    convs = table["convs"]
+    mac = sum(ci * co for _, _, ci, co in convs[1:])
+    c0 = convs[0][2]
+    return mac + (_pad(c0, 2) if executed else c0) * convs[0][3]
+
+
+def head_executed_points(counts, m, granule):
+    """object points a point head really processes given each item's number of segmented points: the first
+    min(count, m) (at least one) rounded up to the skip granule (32 points per wave in the fp32 kernel, 256 per
+    workgroup in the 16-bit one), never more than the padded m"""
+    total = 0
+    for c in counts:
+        d = min(max(int(c), 1), m)
+        total += min(_pad(d, granule), _pad(m, granule))
+    return total

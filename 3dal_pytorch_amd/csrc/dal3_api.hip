@@ -572,6 +572,29 @@ extern "C" int dal3_point_head_forward(int head_kind, const void* packed, int dt
     return point_head_run(head_kind, packed, dtype, x, B, M, out, out_stride, ws, static_cast<hipStream_t>(stream));
 }
 
+/* the per-point stack + max of a point head alone (no FC tail): feat (B,512). n_distinct: see dal3.h */
+extern "C" int dal3_point_head_pool(int head_kind, const void* packed, int dtype, dal3_bcn x, int B, int M,
+                                    const int32_t* n_distinct, float* feat, dal3_stream stream) {
+    TRY(check_dtype(dtype));
+    if (head_kind != DAL3_HEAD_STATIC_BOX_EST && head_kind != DAL3_HEAD_POINT_EMB && head_kind != DAL3_HEAD_BOX_EMB)
+        return fail(DAL3_EINVAL, "point_head_pool: head_kind %d is not a point head", head_kind);
+    if (!packed || !feat) return fail(DAL3_EINVAL, "point_head_pool: null pointer");
+    if (B <= 0 || M <= 0) return fail(DAL3_EINVAL, "point_head_pool: B and M must be positive");
+    TRY(check_bcn(x, "x"));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int c_in, ks, c[4], n_fc, fi[3], fo[3];
+    point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
+    HIP_TRY(hipMemsetAsync(feat, 0, (size_t)B * 512 * sizeof(float), s));
+    if (dtype != DAL3_F32) {
+        const PointHeadLpW w = point_head_lp_view(packed, head_kind);
+        HIP_TRY(launch_point_head_lp(dtype, head_kind, w, to_bcn(x), c_in, B, M, feat, n_distinct, s));
+        return 0;
+    }
+    const PointHeadW w = point_head_view(static_cast<const float*>(packed), head_kind);
+    HIP_TRY(launch_point_head(head_kind, w, to_bcn(x), c_in, B, M, feat, n_distinct, s));
+    return 0;
+}
+
 extern "C" int dal3_dynamic_box_est_forward(const void* packed, const float* embedding, int B, float* box_pred,
                                             void* workspace, size_t workspace_bytes, dal3_stream stream) {
     if (!packed || !embedding || !box_pred || !workspace || B <= 0) return fail(DAL3_EINVAL, "dynamic_box_est: bad argument");

@@ -14,9 +14,9 @@
 
 #define DAL3_PLANE_DOUBLES 24            // 6 faces x [nx, ny, nz, d]
 
-// `v >= 0` on the bit pattern: the library is compiled with -fno-honor-nans (dal3_pointmlp.hip wants it), under
-// which a floating-point compare may be rewritten as if NaN did not exist; the reference's NaN behaviour is part
-// of the contract here, so the compare is done in integers.
+// `v >= 0` on the bit pattern: the reference's NaN behaviour is part of the contract here (a NaN point is inside
+// every box), so the compare is done in integers and does not depend on the floating-point flags of the build
+// (only dal3_pointmlp*.hip are compiled with -fno-honor-nans; this header's users keep IEEE NaN semantics).
 __device__ __forceinline__ bool ge_zero(float v) {
     const uint32_t b = __float_as_uint(v);
     return (b & 0x7fffffffu) <= 0x7f800000u && ((b >> 31) == 0 || (b << 1) == 0);

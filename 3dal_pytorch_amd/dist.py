@@ -40,6 +40,64 @@ def all_gather_boxes(local_boxes, n_items, group=None):
     return out[:n_items]
 
 
+class BoxGatherer:
+    """The same all-gather, taken off the critical path: persistent send / receive buffers in two slots and an
+    asynchronous all_gather_into_tensor per batch whose result is collected one batch later, so that the collective
+    (tens of microseconds of RCCL latency, more when a peer is late) runs beside the next batch's kernels instead
+    of between two batches. A 16-bit step of a few milliseconds cannot afford a gather in series with it.
+
+        g = BoxGatherer(n_items, device)
+        for batch in batches:
+            g.submit(model.refine(*batch))        # enqueue only
+            done = g.collect(keep=1)              # (n_items,7) boxes of the PREVIOUS batch, or None
+        last = g.collect(keep=0)
+
+    Without an initialised process group it degenerates to passing the local boxes through."""
+
+    def __init__(self, n_items, device, width=7, group=None, slots=2):
+        self.n_items, self.width, self.group = n_items, width, group
+        self.active = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or os.environ.get("DAL3_FORCE_DIST") == "1")
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.per = (n_items + self.world - 1) // self.world
+        self.send = [torch.zeros((self.per, width), dtype=torch.float32, device=device) for _ in range(slots)]
+        self.recv = [torch.empty((self.world * self.per, width), dtype=torch.float32, device=device)
+                     for _ in range(slots)] if self.active else None
+        self.pending = []                        # [(slot, work)] oldest first
+        self.turn = 0
+
+    def submit(self, local_boxes):
+        if len(self.pending) == len(self.send):
+            raise RuntimeError("BoxGatherer: collect() before submitting more batches than there are slots")
+        slot = self.turn
+        self.turn = (self.turn + 1) % len(self.send)
+        self.send[slot][: local_boxes.shape[0]].copy_(local_boxes)
+        work = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True) \
+            if self.active else None
+        self.pending.append((slot, work))
+
+    def collect(self, keep=0):
+        """Result of the oldest outstanding batch once more than `keep` are in flight, else None."""
+        if len(self.pending) <= keep:
+            return None
+        slot, work = self.pending.pop(0)
+        if work is None:
+            return self.send[slot][: self.n_items]
+        work.wait()                              # orders the current stream behind the collective; no host sync
+        return self.recv[slot][: self.n_items]
+
+
+def world_census(device, group=None):
+    """What the communicator itself reports: backend, world size, and the sum of one 1 per rank through an
+    all-reduce (= the number of ranks that really took part)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world_size": 1, "ranks_counted": 1}
+    one = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(one, group=group)
+    return {"backend": dist.get_backend(group), "world_size": dist.get_world_size(group),
+            "ranks_counted": int(round(float(one.item())))}
+
+
 def refine_sharded(model, n_items, make_shard, group=None):
     """Run `model.refine` on this rank's shard and gather. make_shard(lo, hi) returns the refine()
     arguments for items [lo, hi) already resident on this rank's GPU. The device sampler is keyed
@@ -48,8 +106,12 @@ def refine_sharded(model, n_items, make_shard, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     lo, hi = shard_range(n_items, rank, world)
     if hi > lo:
+        saved = model.item_offset
         model.item_offset = lo
-        local = model.refine(*make_shard(lo, hi))
+        try:
+            local = model.refine(*make_shard(lo, hi))
+        finally:
+            model.item_offset = saved          # the model leaves as it came (a later eager call keys on ITS offset)
     else:
         dev = next(model.parameters()).device
         local = torch.zeros((0, 7), dtype=torch.float32, device=dev)

@@ -14,7 +14,7 @@ import torch.nn as nn
 from . import _hip, arch
 from .datasets import DYNAMICTRACK                                  # noqa: F401  (the drivers import it from here)
 from .losses import DynamicModelLoss, huber_loss                    # noqa: F401
-from ._heads import (BoxEmbedding, DynamicPointNetEstimation as PointNetEstimation, PackedCache,
+from ._heads import (BoxEmbedding, DynamicPointNetEstimation as PointNetEstimation, PackedCache, PackedModelMixin,
                      PointEmbedding, PointNetInstanceSeg, Workspace, as_f32, dtype_of, numpy_choice, rows_contiguous)
 from .static_model import _box_pred, _mask_and_gather, _parse, _seg_logits
 
@@ -27,7 +27,7 @@ MEAN_SIZE_ARR = np.array(arch.MEAN_SIZE)
 _M = NUM_FRAME * NUM_OBJECT_POINT
 
 
-class DynamicModel(nn.Module):
+class DynamicModel(PackedModelMixin, nn.Module):
     def __init__(self, n_classes=3, n_channel=4):
         super().__init__()
         if n_channel != 4:

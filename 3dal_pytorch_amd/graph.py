@@ -9,8 +9,17 @@ sampler (the NumPy sampler needs a host round trip in the middle), fixed (B, N).
 """
 import torch
 
+from ._heads import Workspace
+
 
 class CapturedRefine:
+    """The recorded graph holds RAW pointers to the model's workspace and to its packed-weight blobs. Both are kept
+    alive here for as long as the graph exists: the capture runs on a workspace of its own (an eager call with a
+    larger batch may re-allocate the model's, never this one), and the blobs are referenced together with the
+    PackedCache stamps they were built from. Every call compares the stamps first; if the weights changed
+    (load_state_dict, an optimizer step, invalidate_packed()) the graph is recorded again instead of replaying the
+    stale weights. `recaptures` counts how often that happened."""
+
     def __init__(self, model, *example_inputs):
         if model.training:
             raise RuntimeError("capture the eval-mode path: call model.eval() first")
@@ -20,16 +29,37 @@ class CapturedRefine:
         # static input buffers in the callers' layout (same strides as the examples, e.g. point-major pts)
         self.inputs = [None if t is None else torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
                        .copy_(t) for t in example_inputs]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                       # warm-up outside the capture: packs weights, sizes workspace
-            model.refine(*self.inputs)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.boxes = model.refine(*self.inputs)
+        self._ws = Workspace()                              # the captured launches' own workspace
+        self.recaptures = -1
+        self._capture()
+
+    def _capture(self):
+        model = self.model
+        saved_ws = model._ws
+        model._ws = self._ws
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                   # warm-up outside the capture: packs weights, sizes workspace
+                model.refine(*self.inputs)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.boxes = model.refine(*self.inputs)
+        finally:
+            model._ws = saved_ws
+        self._stamps, self._blobs = model._cache.snapshot()     # the blobs the graph points into stay referenced
+        self._ws_buf = self._ws.buf
+        self._settings = (model.precision, model.seed, model.item_offset)
         self._keep = dict(model.last) if hasattr(model, "last") else None
+        self.recaptures += 1
+
+    def _stale(self):
+        m = self.model
+        if (m.precision, m.seed, m.item_offset) != self._settings:
+            return True
+        return m._cache._stamp != self._stamps or not m._cache.current()
 
     def __call__(self, *inputs):
         """copies the inputs into the captured buffers, replays, returns the (B,7) boxes (a buffer that the next
@@ -37,6 +67,8 @@ class CapturedRefine:
         for dst, src in zip(self.inputs, inputs):
             if dst is not None:
                 dst.copy_(src)
+        if self._stale():
+            self._capture()
         self.graph.replay()
         return self.boxes
 

@@ -22,7 +22,7 @@ from . import _hip, arch
 from . import train as _train
 from .datasets import STATICTRACK                                   # noqa: F401  (the drivers import it from here)
 from .losses import FrustumPointNetLossOneBoxEst, FrustumPointNetLossTwoBoxEst, huber_loss   # noqa: F401
-from ._heads import (PackedCache, PointNetInstanceSeg, StaticPointNetEstimation as PointNetEstimation,
+from ._heads import (PackedCache, PackedModelMixin, PointNetInstanceSeg, StaticPointNetEstimation as PointNetEstimation,
                      Workspace, as_f32, dtype_of, numpy_choice, rows_contiguous)
 
 NUM_HEADING_BIN = arch.NUM_HEADING_BIN
@@ -32,7 +32,7 @@ NUM_POINT = 4096                                   # static_model.py:15
 MEAN_SIZE_ARR = np.array(arch.MEAN_SIZE)
 
 
-class _StaticBase(nn.Module):
+class _StaticBase(PackedModelMixin, nn.Module):
     two_stage = False
 
     def __init__(self, n_classes=3, n_channel=3):

@@ -88,6 +88,21 @@ def recentre_seg_bias(sd, margin_mean):
     return sd
 
 
+def widest_gap_centre(margin, window=0.1):
+    """(threshold, half_gap): a decision threshold for the segmentation margin logit1 - logit0 that sits in the
+    middle of the WIDEST gap between consecutive sorted margins among the central `window` quantiles. Re-centring
+    the bias there (recentre_seg_bias(sd, threshold)) still segments about half the points, and leaves every point
+    at least half_gap away from the tie — so that a last-bit difference between two fp32 implementations cannot
+    flip a mask bit and the free-running comparisons of the parity tests are unconditional."""
+    m = np.sort(np.asarray(margin, np.float64).ravel())
+    n = len(m)
+    lo, hi = int(n * (0.5 - window / 2)), max(int(n * (0.5 + window / 2)), int(n * (0.5 - window / 2)) + 2)
+    hi = min(hi, n)
+    gaps = np.diff(m[lo:hi])
+    i = int(np.argmax(gaps))
+    return float(0.5 * (m[lo + i] + m[lo + i + 1])), float(0.5 * gaps[i])
+
+
 # --------------------------------------------------------------------------- inputs
 def static_crops(batch, n_pts, seed=SEED, first=0):
     """pts (batch, n_pts, 3) fp32 point-major, init_box (batch, 7), bbox_gt (batch, 7).

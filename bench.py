@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — object-crops/sec through the refinement heads on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--head static|dynamic]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5] [--precision fp32|bf16|fp16]
+
+With --gpus N > 1 and no launcher in the environment, the process starts the N ranks itself
+(3dal_pytorch_amd/launch.py: `python -m torch.distributed.run ... bench.py ...` as a child, before
+this process has made any HIP call) and relays rank 0's JSON line; started under
+`python -m torch.distributed.run` it is a rank. Either way: one process per GPU over RCCL.
 
 Workload (config.workload): BASELINE.json configs[1] — StaticModelOneBoxEst, 4096 crops x 1024
 points, fp32, per GPU, synthetic crops and random-init weights from 3dal_pytorch_amd/synth.py
 (no dataset / checkpoint is reachable). One step = one pass of the hot path over the batch:
 ins_seg -> mask -> object-point sampling -> box estimator -> decode to (B,7) boxes, inputs
 already resident in HBM; with N > 1 every rank refines its own 4096 crops (weak scaling, crops
-are independent) and one RCCL all-gather of the (N*4096, 7) boxes closes the step.
+are independent) and ONE RCCL all-gather of the (N*4096, 7) boxes closes the step. The gather is
+asynchronous and collected one step later (dist.BoxGatherer), so it runs beside the next batch's
+kernels; every gather is finished inside the timed region.
 
 The JSON line also carries
-  roofline      the dominant kernel (an fp32-MFMA shared-MLP kernel) timed live with HIP events
-                on the launch stream: algorithmic FLOP per launch / average duration vs the
-                157.3 TFLOP/s f32 MFMA peak of gfx950
+  roofline      the dominant kernel (an MFMA shared-MLP kernel) timed live with HIP events on the
+                launch stream: algorithmic FLOP per launch / average duration vs the MFMA peak of
+                the arithmetic type (157.3 TFLOP/s f32, 2.5 PFLOP/s bf16/f16 dense)
+  kernels       every kernel of the step with algorithmic AND executed GFLOP per launch
   maxpool       the standalone N-axis max-pool kernel on (4096,1024,1024) fp32 vs 8 TB/s HBM
+  configs       BASELINE.json's other configurations on this GPU (C3 dynamic bf16, C5 static N=4096 fp16 MFMA,
+                C4 the mixed segment), each a whole-path rate
+  rccl          what the communicator reports (world size, ranks counted by an all-reduce) and the
+                all-gather's own latency
   cpu_baseline  the oracle (reference-formulation torch-CPU port) on this box's host cores, on
                 a bounded sample of the same workload
 """
@@ -40,11 +51,13 @@ synth = importlib.import_module("3dal_pytorch_amd.synth")
 sm = importlib.import_module("3dal_pytorch_amd.static_model")
 dm = importlib.import_module("3dal_pytorch_amd.dynamic_model")
 dal3_dist = importlib.import_module("3dal_pytorch_amd.dist")
+launch = importlib.import_module("3dal_pytorch_amd.launch")
 
-F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
-# dense peaks per arithmetic dtype (MI355X_MICROARCH.md "Chip-level parameters"; bf16/fp16 ~2.5 PF dense)
+# dense peaks per arithmetic dtype (MI355X_MICROARCH.md "Chip-level parameters": f32 MFMA = v_mfma_f32_32x32x2_f32,
+# exact f32; bf16/fp16 ~2.5 PF dense)
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
+DNAME = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}
 
 
 def events_ms(fn, iters, warmup=2):
@@ -60,7 +73,17 @@ def events_ms(fn, iters, warmup=2):
     return a.elapsed_time(b) / iters
 
 
-def make_static(B, N, dev, first):
+def recentre(model, fwd):
+    """shift the segmentation bias so that about half the points are segmented (synth.py); done with one full-size
+    pass so that every profiled launch of a kernel has the same shape"""
+    with torch.no_grad():
+        lg = fwd()["logits"]
+        model.ins_seg.dconv5.bias[1] -= (lg[:, :, 1] - lg[:, :, 0]).mean()
+        del lg
+    model.invalidate_packed()
+
+
+def make_static(B, N, dev, first, precision="fp32"):
     pts_np, init_np, gt_np = synth.static_crops(B, N, first=first)
     model = sm.StaticModelOneBoxEst()
     sd = synth.state_dict("static_one")
@@ -68,62 +91,105 @@ def make_static(B, N, dev, first):
     model = model.to(dev).eval()
     pts = torch.from_numpy(pts_np).to(dev).transpose(2, 1)          # the callers' layout (static_eval.py:265)
     init, gt = torch.from_numpy(init_np).to(dev), torch.from_numpy(gt_np).to(dev)
-    # re-centre the segmentation bias so that about half the points are segmented (synth.py);
-    # done with one full-size pass so that every profiled launch of a kernel has the same shape
-    with torch.no_grad():
-        lg = model(pts, init, gt)["logits"]
-        model.ins_seg.dconv5.bias[1] -= (lg[:, :, 1] - lg[:, :, 0]).mean()
-        del lg
+    recentre(model, lambda: model(pts, init, gt))
     model.item_offset = first
+    model.precision = precision
     return model, (pts, init, gt), (pts_np, init_np, sd)
 
 
-def make_dynamic(B, dev, first):
-    pts_np, box_np, init8_np, gt_np = synth.dynamic_items(B, first=first)
+def make_dynamic(B, dev, first, precision="fp32", n_per_frame=1024):
+    pts_np, box_np, init8_np, gt_np = synth.dynamic_items(B, n_per_frame=n_per_frame, first=first)
     model = dm.DynamicModel()
     model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict("dynamic").items()})
     model = model.to(dev).eval()
     pts = torch.from_numpy(pts_np).to(dev).transpose(2, 1)
     box = torch.from_numpy(box_np).to(dev).transpose(2, 1)
     init8 = torch.from_numpy(init8_np).to(dev)
-    with torch.no_grad():
-        lg = model(pts, box, None)["logits"]
-        model.ins_seg.dconv5.bias[1] -= (lg[:, :, 1] - lg[:, :, 0]).mean()
-        del lg
+    recentre(model, lambda: model(pts, box, None))
     model.item_offset = first
+    model.precision = precision
     return model, (pts, box, init8)
 
 
-def kernel_rooflines(model, pts, c_in, B, N, iters):
-    """per-kernel HIP-event timing of the two shared-MLP kernels of ins_seg (per-kernel C-ABI entries)"""
+# ---------------------------------------------------------------------------------------- per-kernel accounting
+def kernel_table(model, inputs, static, B, N, iters):
+    """Every kernel of one step through its own C-ABI entry, HIP events on the launch stream. Per launch:
+    algorithmic GFLOP (what `frac` is computed from) and executed GFLOP (padding, the decode
+    kernel's recompute of conv1-2, and — the other way — the object points the point head skips as copies)."""
     lib = hip.lib()
-    dt = hip.DTYPES[model.precision]
-    peak = MFMA_PEAK_TFLOPS[model.precision]
-    w = model._cache.get("ins_seg", model.ins_seg, hip.HEAD_INS_SEG, dt)
-    g = torch.zeros((B, 1024), device=pts.device)
-    gb = torch.empty((B, 512), device=pts.device)
-    logits = torch.empty((B, N, 2), device=pts.device)
-    mask = torch.empty((B, N), dtype=torch.uint8, device=pts.device)
+    prec = model.precision
+    dt = hip.DTYPES[prec]
+    peak = MFMA_PEAK_TFLOPS[prec]
+    dev = inputs[0].device
+    c_in = 3 if static else 4
+    M = arch.NUM_OBJECT_POINT * (1 if static else arch.NUM_FRAME)
+    pts = inputs[0]
     x = hip.bcn(pts)
+    w = model._cache.get("ins_seg", model.ins_seg, hip.HEAD_INS_SEG, dt)
+    g = torch.zeros((B, 1024), device=dev)
+    gb = torch.empty((B, 512), device=dev)
+    logits = torch.empty((B, N, 2), device=dev)
+    mask = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    idx = torch.empty((B, M), dtype=torch.int32, device=dev)
+    obj = torch.empty((B, M, c_in), device=dev)
+    feat = torch.empty((B, 512), device=dev)
+    gws = torch.empty(max(int(lib.dal3_gather_workspace_bytes(B, N)), 8), dtype=torch.uint8, device=dev)
+    st = hip.stream
 
     def enc():
-        hip.check(lib.dal3_ins_seg_encode(hip.ptr(w), dt, c_in, x, B, N, hip.ptr(g), hip.stream()))
+        hip.check(lib.dal3_ins_seg_encode(hip.ptr(w), dt, c_in, x, B, N, hip.ptr(g), st()))
+
+    def fc():
+        hip.check(lib.dal3_ins_seg_global_bias(hip.ptr(w), dt, hip.ptr(g), B, hip.ptr(gb), st()))
 
     def dec():
-        hip.check(lib.dal3_ins_seg_decode(hip.ptr(w), dt, c_in, x, B, N, hip.ptr(gb), hip.ptr(logits), hip.ptr(mask),
-                                          hip.stream()))
-    enc()
-    hip.check(lib.dal3_ins_seg_global_bias(hip.ptr(w), dt, hip.ptr(g), B, hip.ptr(gb), hip.stream()))
-    t_enc = events_ms(enc, iters)
-    t_dec = events_ms(dec, iters)
-    mac_enc = c_in * 64 + 64 * 64 * 2 + 64 * 128 + 128 * 1024
-    mac_dec = 64 * 512 + 512 * 256 + 256 * 128 + 128 * 128 + 128 * 2
+        hip.check(lib.dal3_ins_seg_decode(hip.ptr(w), dt, c_in, x, B, N, hip.ptr(gb), hip.ptr(logits), hip.ptr(mask), st()))
+
+    def samp():
+        hip.check(lib.dal3_mask_compact_sample(hip.ptr(mask), x, B, N, c_in, M, hip.SAMPLER_DEVICE, None, model.seed,
+                                               model.item_offset, hip.ptr(counts), hip.ptr(idx), hip.ptr(obj),
+                                               hip.ptr(gws), gws.numel(), st()))
+    heads = [("box_est", "one", model.box_est, arch.STATIC_BOX_EST, obj.transpose(2, 1), M, counts)] if static else \
+            [("point_emb", "pe", model.point_emb, arch.POINT_EMB, obj.transpose(2, 1), M, counts),
+             ("box_emb", "be", model.box_emb, arch.BOX_EMB, inputs[1], inputs[1].shape[2], None)]
+    enc(), fc(), dec(), samp()
+    torch.cuda.synchronize()
+    cnt = counts.cpu().numpy()
     out = {}
-    for name, t, mac in (("ins_seg_encode_kernel", t_enc, mac_enc), ("ins_seg_decode_kernel", t_dec, mac_dec)):
-        tf = 2.0 * mac * B * N / (t * 1e-3) / 1e12
-        out[name] = {"ms": round(t, 4), "algorithmic_gflop": round(2.0 * mac * B * N / 1e9, 2),
-                     "tflops": round(tf, 2), "frac": round(tf / peak, 4)}
-    return out
+
+    def row(name, t, alg_mac, exe_mac, note=None):
+        tf = 2.0 * alg_mac / (t * 1e-3) / 1e12
+        r = {"ms": round(t, 4), "algorithmic_gflop": round(2.0 * alg_mac / 1e9, 2),
+             "executed_gflop": round(2.0 * exe_mac / 1e9, 2), "tflops": round(tf, 2), "frac": round(tf / peak, 4),
+             "tflops_executed": round(2.0 * exe_mac / (t * 1e-3) / 1e12, 2)}
+        if note:
+            r["note"] = note
+        out[name] = r
+    lp = prec != "fp32"
+    sfx = "_lp_kernel" if lp else "_kernel"
+    row("ins_seg_encode" + sfx, events_ms(enc, iters), arch.ins_seg_encode_mac(c_in) * B * N,
+        arch.ins_seg_encode_mac(c_in, True) * B * N)
+    row("fc_kernel[dconv1 global term]", events_ms(fc, iters), 1024 * 512 * B, 1024 * 512 * arch._pad(B, 32))
+    row("ins_seg_decode" + sfx, events_ms(dec, iters), arch.ins_seg_decode_mac(c_in) * B * N,
+        arch.ins_seg_decode_mac(c_in, True) * B * N)
+    t = events_ms(samp, iters)
+    out["compact_sample_kernel"] = {"ms": round(t, 4), "algorithmic_gflop": 0.0, "executed_gflop": 0.0,
+                                    "bytes": int(B * N + B * M * (4 + 4 * c_in)),
+                                    "note": "mask -> ordered positives -> M sampled points; integer work"}
+    for name, key, mod, table, hx, m, distinct in heads:
+        hw = model._cache.get(key, mod, mod.HEAD_KIND, dt)
+        hxb = hip.bcn(hx)
+
+        def pool(hw=hw, hxb=hxb, m=m, distinct=distinct, kind=mod.HEAD_KIND):
+            hip.check(lib.dal3_point_head_pool(kind, hip.ptr(hw), dt, hxb, B, m, hip.ptr(distinct), hip.ptr(feat), st()))
+        t = events_ms(pool, iters)
+        granule = 256 if lp else 32
+        exe_pts = arch.head_executed_points(cnt, m, granule) if distinct is not None else B * arch._pad(m, granule)
+        row(f"point_head{sfx}[{name}]", t, arch.head_point_mac(table) * B * m, arch.head_point_mac(table, True) * exe_pts,
+            note=f"{exe_pts / (B * m):.3f} of the {m} object points per item are computed"
+                 + (" (copies skipped)" if distinct is not None else " (padding)"))
+    return out, float(cnt.mean())
 
 
 def maxpool_roofline(dev, iters):
@@ -143,7 +209,7 @@ def maxpool_roofline(dev, iters):
     del x
     return {"kernel": "maxpool_rows_kernel", "shape": [rows // 1024, 1024, n], "bound": "hbm", "ms": round(t, 4),
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "exact": ok}
+            "algorithmic_bytes": nbytes, "exact": ok}
 
 
 def cpu_baseline(host, budget_s=20.0, threads=None):
@@ -152,7 +218,8 @@ def cpu_baseline(host, budget_s=20.0, threads=None):
     pts_np, init_np, sd = host
     # `bench.py --cpu-sweep 8 16 32 64 128` on the GPU box (256 logical cores): 8 thr 64, 16 thr 76, 32 thr 80,
     # 64 thr 53, 128 thr 27 crops/s -> the port saturates at 32 threads; more only adds contention
-    n = threads or min(len(os.sched_getaffinity(0)), 32)
+    avail = len(os.sched_getaffinity(0))
+    n = threads or min(avail, 32)
     torch.set_num_threads(n)
     sample = 64
     tsd = R.as_torch_sd(sd)
@@ -167,9 +234,10 @@ def cpu_baseline(host, budget_s=20.0, threads=None):
             R.decode_static(R.static_one_forward(tsd, pts, init), init, False)
             it += 1
         dt = (time.perf_counter() - t0) / it
-    return {"value": round(sample / dt, 2), "unit": "object-crops/s", "cores": n, "kind": "port",
+    return {"value": round(sample / dt, 2), "unit": "object-crops/s", "cores": n, "cores_available": avail,
+            "kind": "port",
             "sample": f"oracle/ref_heads.py static_one_forward+decode, {it} x (B={sample}, N={pts.shape[2]}) fp32, "
-                      f"torch {torch.__version__} CPU kernels, {n} threads"}
+                      f"torch {torch.__version__} CPU kernels, {n} of {avail} host threads (the port saturates there)"}
 
 
 def torch_gpu_baseline(model, inputs, sample=256, iters=3):
@@ -208,6 +276,195 @@ def torch_gpu_baseline(model, inputs, sample=256, iters=3):
                       f"loop, {iters} x (B={pts.shape[0]}, N={pts.shape[2]}) fp32 on the same GPU"}
 
 
+def committed_profile(kernel, precision, B, N):
+    """HBM bytes per launch and PMC ratios from the COMMITTED rocprofv3 passes (profiles/*.json, written by
+    tools/prof_summary.py on an earlier run of this very command) — only when that profile was taken at this
+    precision and shape; always labelled with its file, never presented as measured in this run."""
+    out = {"traffic": None, "pmc": None}
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        t = json.load(open(tfile))
+        shape = t.get("_shape", {"precision": "fp32", "B": 4096, "N": 1024})
+        if (shape.get("precision"), shape.get("B"), shape.get("N")) == (precision, B, N) and kernel in t:
+            out["traffic"] = t[kernel]
+            out["traffic_source"] = {"file": "profiles/traffic.json", "taken": t.get("_taken", "round 1"),
+                                     "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                                            "FETCH_SIZE x 2 per MI355X_MICROARCH.md, per launch; not measured in this run"}
+    pfile = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    if precision == "fp32" and (B, N) == (4096, 1024) and os.path.exists(pfile):
+        d = json.load(open(pfile)).get(kernel, {})
+        if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+            cyc = d["GRBM_GUI_ACTIVE"] / 8.0                        # the counter sums the 8 XCDs
+            out["pmc"] = {"source": "profiles/r01_pmc.json (rocprofv3 --pmc, separate passes, round 1; not measured in this run)",
+                          "mfma_busy": round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), 4),
+                          "clock_ghz": round(cyc / d["avg_ns_under_GRBM_GUI_ACTIVE"], 3)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------- workloads
+class Workload:
+    """what one rank does per step: `parts` = [(refine closure -> local (n,7) boxes, n_local, n_total)], one per head"""
+
+    def __init__(self):
+        self.parts = []
+        self.gatherers = None
+
+
+def build_workload(args, dev, rank, world):
+    wl = Workload()
+    prec = args.precision
+    if args.config == "C4":
+        # SURVEY 8(d) C4: 198 frames; 64 static tracks -> 64 crops at N=4096; 40 dynamic tracks with lengths
+        # rng.integers(20,199) -> one item per track-frame; contiguous index sharding, static and dynamic batches
+        # back to back, one all-gather per head. The segment is fixed: strong scaling.
+        lens = np.random.default_rng(10922081).integers(20, 199, size=40)
+        n_static, n_dyn = 64, int(lens.sum())
+        s_lo, s_hi = dal3_dist.shard_range(n_static, rank, world)
+        d_lo, d_hi = dal3_dist.shard_range(n_dyn, rank, world)
+        smodel, sin, _ = make_static(max(s_hi - s_lo, 1), 4096, dev, s_lo, prec)
+        dmodel, din = make_dynamic(max(d_hi - d_lo, 1), dev, d_lo, prec)
+        wl.parts = [(lambda: smodel.refine(*sin)[:s_hi - s_lo], s_hi - s_lo, n_static),
+                    (lambda: dmodel.refine(*din)[:d_hi - d_lo], d_hi - d_lo, n_dyn)]
+        wl.model, wl.inputs, wl.host, wl.static = smodel, None, None, False
+        wl.B, wl.N = (s_hi - s_lo) + (d_hi - d_lo), 0
+        wl.n_total = n_static + n_dyn
+        wl.flop_item = (n_static * arch.static_one_flop(4096) + n_dyn * arch.dynamic_flop(5120)) / wl.n_total
+        wl.scaling = "strong"
+        wl.desc = (f"one synthetic segment: {n_dyn} dynamic items (40 tracks) x 5120 pts + 64 static crops x 4096 pts, "
+                   f"{prec}, both heads back to back (BASELINE.json configs[3])")
+        return wl
+    static = args.head == "static"
+    B = args.batch or (4096 if static else 1024)
+    N = args.points if static else 5 * args.points
+    first = rank * B                                            # weak scaling: B items per GPU
+    if static:
+        model, inputs, host = make_static(B, N, dev, first, prec)
+        flop_item = arch.static_one_flop(N)
+        desc = f"StaticModelOneBoxEst forward+decode, {B} crops x {N} pts per GPU, {prec}" + \
+            (" (BASELINE.json configs[1])" if (B, N, prec) == (4096, 1024, "fp32") else
+             " (BASELINE.json configs[4] shape)" if (N, prec) == (4096, "fp16") else "")
+    else:
+        model, inputs = make_dynamic(B, dev, first, prec, args.points)
+        host = None
+        flop_item = arch.dynamic_flop(N)
+        desc = (f"DynamicModel forward+decode, {B} items x {N} pts + 101 boxes per GPU, {prec} arithmetic"
+                + (" (BASELINE.json configs[2])" if (B, N, prec) == (1024, 5120, "bf16") else ""))
+    wl.parts = [(lambda: model.refine(*inputs), B, B * world)]
+    wl.model, wl.inputs, wl.host, wl.static = model, inputs, host, static
+    wl.B, wl.N, wl.n_total, wl.flop_item, wl.scaling, wl.desc = B, N, B * world, flop_item, "weak", desc
+    return wl
+
+
+def time_steps(wl, dev, steps, warmup, use_dist, overlap=True):
+    """W untimed + exactly K timed steps between two fences (barrier + device synchronize); returns (seconds,
+    per-step event times, last complete result). With a process group every step ends in one all-gather per head;
+    with `overlap` it is collected one step later, and the last one before the closing fence."""
+    if wl.gatherers is None:
+        wl.gatherers = [dal3_dist.BoxGatherer(n_total, dev) for _, _, n_total in wl.parts]
+
+    def fence():
+        if use_dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    last = [None] * len(wl.parts)
+
+    def step(final=False):
+        for i, (fn, _, _) in enumerate(wl.parts):
+            wl.gatherers[i].submit(fn())
+            got = wl.gatherers[i].collect(keep=1 if (overlap and not final) else 0)
+            if got is not None:
+                last[i] = got
+    for _ in range(warmup):
+        step(final=True)
+    fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        step(final=(i == steps - 1))
+        marks[i + 1].record()
+    fence()
+    dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    boxes = torch.cat(last)
+    assert boxes.shape == (wl.n_total, 7) and bool(torch.isfinite(boxes).all())
+    if use_dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, per_step, boxes
+
+
+def gather_latency(wl, dev, iters=50):
+    """the all-gather on its own: HIP events around `iters` synchronous gathers of this rank's boxes (per head)"""
+    outs = []
+    for (fn, n_local, n_total) in wl.parts:
+        local = torch.zeros((n_local, 7), device=dev)
+        outs.append(events_ms(lambda: dal3_dist.all_gather_boxes(local, n_total), iters, warmup=5))
+    return [round(t * 1e3, 1) for t in outs]
+
+
+def other_config(name, dev, steps):
+    """one of BASELINE.json's other configurations on this GPU: whole-path rate (same step definition)"""
+    ns = argparse.Namespace(config=name, head="static", precision="fp32", batch=0, points=1024)
+    apply_config(ns)
+    wl = build_workload(ns, dev, 0, 1)
+    dt, per_step, _ = time_steps(wl, dev, steps, 2, False)
+    value = wl.n_total * steps / dt
+    peak = MFMA_PEAK_TFLOPS[ns.precision]
+    r = {"workload": wl.desc, "value": round(value, 1), "unit": "items/s", "ms_per_step": round(dt / steps * 1e3, 3),
+         "ms_per_step_min": round(per_step[0], 3), "steps": steps, "dtype": DNAME[ns.precision],
+         "algorithmic_gflop_per_item": round(wl.flop_item / 1e9, 4),
+         "whole_path_tflops": round(value * wl.flop_item / 1e12, 1),
+         "whole_path_mfma_frac": round(value * wl.flop_item / 1e12 / peak, 4)}
+    if name != "C4":
+        kr, _ = kernel_table(wl.model, wl.inputs, wl.static, wl.B, wl.N, iters=max(3, min(steps, 5)))
+        dom = max((k for k in kr if "frac" in kr[k]), key=lambda k: kr[k]["ms"])
+        r["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kr[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
+                         "frac": kr[dom]["frac"], "ms_per_launch": kr[dom]["ms"]}
+    del wl
+    torch.cuda.empty_cache()
+    return r
+
+
+def apply_config(args):
+    if args.config == "C3":
+        args.head, args.precision, args.batch, args.points = "dynamic", "bf16", 1024, 1024
+    elif args.config == "C5":
+        args.head, args.precision, args.batch, args.points = "static", "fp16", 2048, 4096
+    elif args.config == "C2":
+        args.head, args.precision, args.batch, args.points = "static", "fp32", 4096, 1024
+
+
+def plumbing_only(args, rank, world):
+    """No GPU work: every rank makes the boxes a refine() of its shard would return (a function of the global item
+    index), the launcher / process-group / gather path runs on DAL3_BENCH_BACKEND (gloo on CPU), and rank 0 prints a
+    line whose `value` is null. What tests/test_launch_cpu.py drives at world size 2."""
+    backend = os.environ.get("DAL3_BENCH_BACKEND", "gloo")
+    torch.distributed.init_process_group(backend, rank=rank, world_size=world)
+    n_total = 37
+    lo, hi = dal3_dist.shard_range(n_total, rank, world)
+    local = (torch.arange(lo, hi, dtype=torch.float32)[:, None] * 10 + torch.arange(7, dtype=torch.float32)[None])
+    g = dal3_dist.BoxGatherer(n_total, torch.device("cpu"))
+    got = None
+    for _ in range(3):
+        g.submit(local)
+        r = g.collect(keep=1)
+        got = r if r is not None else got
+    got = g.collect(keep=0)
+    want = torch.arange(n_total, dtype=torch.float32)[:, None] * 10 + torch.arange(7, dtype=torch.float32)[None]
+    ok = bool(torch.equal(got, want)) and bool(torch.equal(dal3_dist.all_gather_boxes(local, n_total), want))
+    census = dal3_dist.world_census(torch.device("cpu"))
+    if os.environ.get("DAL3_BENCH_FAIL_RANK") == str(rank):          # the launcher's failure path, for its test
+        sys.exit(3)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "object-crops/sec through static+dynamic refinement heads", "value": None,
+                          "plumbing_only": True, "n_gpus": world, "gathered_ok": ok, "rccl": census}), flush=True)
+    sys.exit(0 if ok else 4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,11 +475,15 @@ def main():
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16"],
                     help="arithmetic of the shared-MLP kernels (fp32 = the reference's; bf16/fp16 = configs C3/C5)")
-    ap.add_argument("--no-extras", action="store_true", help="skip roofline / maxpool / cpu_baseline legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / maxpool / configs / cpu_baseline legs")
+    ap.add_argument("--only-maxpool", action="store_true", help="run only the standalone max-pool kernel (profiling)")
+    ap.add_argument("--serial-gather", action="store_true", help="wait for each step's all-gather inside the step")
     ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5"],
                     help="BASELINE.json configs by name: C2 = the default (static, 4096 x 1024, fp32); C3 = dynamic head, "
                          "1024 items x 5 x 1024 pts, bf16; C4 = one segment (64 static crops x 4096 pts + 40 dynamic tracks), sharded "
                          "over the GPUs (strong scaling); C5 = static, N=4096, 2048 crops per GPU, fp16 MFMA")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="launcher + process group + gather only, no GPU work (CPU test of the N > 1 start-up path)")
     ap.add_argument("--cpu-sweep", type=int, nargs="+", default=None, metavar="THREADS",
                     help="run only the cpu_baseline leg at these torch thread counts (no GPU work) and print one JSON line")
     args = ap.parse_args()
@@ -232,17 +493,27 @@ def main():
         print(json.dumps({"cpu_baseline_sweep": [cpu_baseline(host, budget_s=6.0, threads=t) for t in args.cpu_sweep],
                           "affinity": len(os.sched_getaffinity(0))}))
         return
-    if args.config == "C3":
-        args.head, args.precision, args.batch, args.points = "dynamic", "bf16", 1024, 1024
-    elif args.config == "C5":
-        args.head, args.precision, args.batch, args.points = "static", "fp16", 2048, 4096
+
+    # ---- N > 1 without a launcher: start the ranks as children; this process never touches the GPU
+    if args.gpus > 1 and not launch.under_launcher():
+        rc, out = launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, need_gpus=not args.plumbing_only)
+        line = launch.relay_json_line(out)
+        if line:
+            print(line, flush=True)
+        sys.exit(rc if rc else (0 if line else 1))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
+    if args.plumbing_only:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        plumbing_only(args, rank, world)
+    apply_config(args)
+    if torch.cuda.device_count() <= local:
+        sys.exit(f"bench.py: needs {max(args.gpus, local + 1)} GPUs, this machine shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # DAL3_FORCE_DIST=1 runs the RCCL path even with one rank (exercises init + all-gather on a 1-GPU box)
@@ -257,150 +528,94 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    static = args.head == "static"
-    mixed = args.config == "C4"
-    if mixed:
-        # 198 frames; 64 static tracks -> 64 crops at N=4096; 40 dynamic tracks with lengths
-        # rng.integers(20,199) -> one item per track-frame; contiguous index sharding, static and dynamic batches
-        # back to back, one all-gather per head. The segment is fixed: strong scaling.
-        lens = np.random.default_rng(10922081).integers(20, 199, size=40)
-        n_static, n_dyn = 64, int(lens.sum())
-        s_lo, s_hi = dal3_dist.shard_range(n_static, rank, world)
-        d_lo, d_hi = dal3_dist.shard_range(n_dyn, rank, world)
-        smodel, sin, _ = make_static(max(s_hi - s_lo, 1), 4096, dev, s_lo)
-        dmodel, din = make_dynamic(max(d_hi - d_lo, 1), dev, d_lo)
-        smodel.precision = dmodel.precision = args.precision
-        B, N, static, host, model = (s_hi - s_lo) + (d_hi - d_lo), 0, False, None, smodel
-        flop_item = (n_static * arch.static_one_flop(4096) + n_dyn * arch.dynamic_flop(5120)) / (n_static + n_dyn)
-        n_total = n_static + n_dyn
+    if args.only_maxpool:
+        rec = {"maxpool": maxpool_roofline(dev, iters=args.steps)}
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+        return
 
-        def step_fn():
-            a = smodel.refine(*sin)[:s_hi - s_lo]
-            a = dal3_dist.all_gather_boxes(a, n_static) if use_dist else a
-            b = dmodel.refine(*din)[:d_hi - d_lo]
-            b = dal3_dist.all_gather_boxes(b, n_dyn) if use_dist else b
-            return torch.cat([a, b])
-    else:
-        B = args.batch or (4096 if static else 1024)
-        N = args.points if static else 5 * args.points
-        first = rank * B                                            # weak scaling: B items per GPU
-        if static:
-            model, inputs, host = make_static(B, N, dev, first)
-            step_fn = lambda: model.refine(*inputs)                 # noqa: E731
-            flop_item = arch.static_one_flop(N)
-        else:
-            model, inputs = make_dynamic(B, dev, first)
-            step_fn = lambda: model.refine(*inputs)                 # noqa: E731
-            flop_item = arch.dynamic_flop(N)
-            host = None
-        n_total = B * world
-        model.precision = args.precision
+    wl = build_workload(args, dev, rank, world)
     peak = MFMA_PEAK_TFLOPS[args.precision]
-    dname = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.precision]
-
-    def step():
-        boxes = step_fn()
-        return dal3_dist.all_gather_boxes(boxes, n_total) if (use_dist and not mixed) else boxes
-
-    def fence():
-        if use_dist:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # per-step HIP events on the launch stream ride along (median / min); `value` comes from the
-    # wall clock around all K steps, fenced on both sides
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        boxes = step()
-        marks[i + 1].record()
-    fence()
-    dt = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    assert boxes.shape == (n_total, 7) and bool(torch.isfinite(boxes).all())
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-
+    dt, per_step, _ = time_steps(wl, dev, args.steps, args.warmup, use_dist, overlap=not args.serial_gather)
     ms_per_step = dt / args.steps * 1e3
-    value = n_total * args.steps / dt
+    value = wl.n_total * args.steps / dt
+    mixed = args.config == "C4"
     rec = {
         "metric": "object-crops/sec through static+dynamic refinement heads",
         "value": round(value, 1), "unit": "object-crops/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "ms_per_step_median": round(per_step[len(per_step) // 2], 3), "ms_per_step_min": round(per_step[0], 3),
         "higher_is_better": True,
-        "scaling": "strong" if mixed else "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
-        "config": {"workload": (f"one synthetic segment: {n_total - 64} dynamic items (40 tracks) x 5120 pts + 64 static "
-                                f"crops x 4096 pts, {args.precision}, both heads back to back "
-                                "(BASELINE.json configs[3])") if mixed else
-                               (f"StaticModelOneBoxEst forward+decode, {B} crops x {N} pts per GPU, {args.precision}"
-                                + (" (BASELINE.json configs[1])" if (B, N) == (4096, 1024) else "")) if static else
-                               (f"DynamicModel forward+decode, {B} items x {N} pts + 101 boxes per GPU, {args.precision} "
-                                "arithmetic (BASELINE.json configs[2] shape)"),
-                   "items_per_gpu": B, "points_per_item": N, "sampler": model.sampler,
-                   "parallelism": (f"object-sharded x{world}, one all-gather of (B,7) boxes" + (" per head" if mixed else ""))
-                   if world > 1 else "single GPU",
-                   "algorithmic_gflop_per_item": round(flop_item / 1e9, 4)},
-        "whole_path_tflops": round(value * flop_item / 1e12, 2),
-        "whole_path_mfma_frac": round(value / world * flop_item / 1e12 / peak, 4),
+        "scaling": wl.scaling, "vs_baseline": None, "dtype": DNAME[args.precision], "data": "synthetic",
+        "config": {"workload": wl.desc, "items_per_gpu": wl.B, "points_per_item": wl.N, "sampler": wl.model.sampler,
+                   "parallelism": (f"object-sharded x{world}, one all-gather of (B,7) boxes" + (" per head" if mixed else "")
+                                   + (", collected one step later (overlapped)" if not args.serial_gather else ", serial"))
+                   if use_dist else "single GPU",
+                   "algorithmic_gflop_per_item": round(wl.flop_item / 1e9, 4)},
+        "whole_path_tflops": round(value * wl.flop_item / 1e12, 2),
+        "whole_path_mfma_frac": round(value / world * wl.flop_item / 1e12 / peak, 4),
     }
+    if use_dist:
+        census = dal3_dist.world_census(dev)
+        rec["rccl"] = dict(census, allgather_us=gather_latency(wl, dev),
+                           message_bytes_per_rank=[((n_total + world - 1) // world) * 28 for _, _, n_total in wl.parts],
+                           rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()))
+        rec["rccl_world_size"] = census["world_size"]
+        if not args.no_extras:
+            # the same steps with the gather waited for inside each step: what the overlap is worth
+            dt2, _, _ = time_steps(wl, dev, args.steps, 1, use_dist, overlap=args.serial_gather)
+            rec["rccl"]["ms_per_step_" + ("overlapped" if args.serial_gather else "serial_gather")] = round(dt2 / args.steps * 1e3, 3)
     if rank == 0 and world == 1 and not args.no_extras and not mixed:
-        kr = kernel_rooflines(model, inputs[0], 3 if static else 4, B, N, iters=max(3, min(args.steps, 10)))
-        dom = max(kr, key=lambda k: kr[k]["ms"])
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")          # HBM bytes per launch from rocprofv3 --pmc
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(dom)
-        pmc = None                                                      # MFMA-busy and clock from the committed PMC passes
-        pfile = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if args.precision == "fp32" and os.path.exists(pfile):
-            d = json.load(open(pfile)).get(dom, {})
-            if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
-                cyc = d["GRBM_GUI_ACTIVE"] / 8.0                        # the counter sums the 8 XCDs
-                pmc = {"source": "profiles/r01_pmc.json (rocprofv3 --pmc, separate passes)",
-                       "mfma_busy": round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), 4),
-                       "clock_ghz": round(cyc / d["avg_ns_under_GRBM_GUI_ACTIVE"], 3)}
-        rec["roofline"] = {"kernel": dom + ("" if args.precision == "fp32" else "_lp"), "bound": "mfma",
-                           "achieved": kr[dom]["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kr[dom]["frac"],
-                           "traffic": traffic, "ms_per_launch": kr[dom]["ms"],
-                           "algorithmic_gflop_per_launch": kr[dom]["algorithmic_gflop"], "pmc": pmc}
+        B, N, model, inputs, static = wl.B, wl.N, wl.model, wl.inputs, wl.static
+        kr, mean_count = kernel_table(model, inputs, static, B, N, iters=max(3, min(args.steps, 10)))
+        mf = [k for k in kr if "frac" in kr[k]]
+        dom = max(mf, key=lambda k: kr[k]["ms"])
+        prof = committed_profile(dom, args.precision, B, N)
+        rec["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kr[dom]["tflops"], "peak": peak,
+                           "unit": "TFLOP/s", "frac": kr[dom]["frac"], "traffic": prof["traffic"],
+                           "ms_per_launch": kr[dom]["ms"], "algorithmic_gflop_per_launch": kr[dom]["algorithmic_gflop"],
+                           "executed_gflop_per_launch": kr[dom]["executed_gflop"], "pmc": prof["pmc"]}
+        if "traffic_source" in prof:
+            rec["roofline"]["traffic_source"] = prof["traffic_source"]
         rec["kernels"] = kr
+        rec["mean_segmented_points_per_item"] = round(mean_count, 1)
+        exe = sum(kr[k]["executed_gflop"] for k in kr) + 2.0 * B * sum(
+            ci * co for t in ([arch.STATIC_BOX_EST] if static else [arch.POINT_EMB, arch.BOX_EMB, arch.DYNAMIC_BOX_EST])
+            for _, _, ci, co in t["fcs"]) / 1e9
+        rec["executed_gflop_per_step"] = round(exe, 1)
+        rec["algorithmic_gflop_per_step"] = round(B * wl.flop_item / 1e9, 1)
+        rec["whole_path_mfma_frac_executed"] = round(exe / ms_per_step / peak, 4)      # GFLOP/ms = TFLOP/s
         if static and args.precision == "fp32":
             # the same workload on the 16-bit MFMA path (BASELINE.json configs C3/C5 arithmetic): reported beside
             # the fp32 headline, never as `value`
             rec["lowprec"] = {}
             for prec in ("bf16", "fp16"):
                 model.precision = prec
-                for _ in range(2):
-                    step_fn()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    step_fn()
-                torch.cuda.synchronize()
-                d = (time.perf_counter() - t1) / args.steps
-                k2 = kernel_rooflines(model, inputs[0], 3, B, N, iters=max(3, min(args.steps, 10)))
-                d2 = max(k2, key=lambda k: k2[k]["ms"])
+                d, _, _ = time_steps(wl, dev, args.steps, 2, False)
+                d /= args.steps
+                k2, _ = kernel_table(model, inputs, static, B, N, iters=max(3, min(args.steps, 10)))
+                d2 = max((k for k in k2 if "frac" in k2[k]), key=lambda k: k2[k]["ms"])
                 rec["lowprec"][prec] = {"value": round(B / d, 1), "unit": "object-crops/s", "ms_per_step": round(d * 1e3, 3),
-                                        "whole_path_tflops": round(B / d * flop_item / 1e12, 1),
-                                        "roofline": {"kernel": d2 + "_lp", "bound": "mfma", "achieved": k2[d2]["tflops"],
+                                        "whole_path_tflops": round(B / d * wl.flop_item / 1e12, 1),
+                                        "roofline": {"kernel": d2, "bound": "mfma", "achieved": k2[d2]["tflops"],
                                                      "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s",
                                                      "frac": k2[d2]["frac"], "ms_per_launch": k2[d2]["ms"]},
                                         "kernels": k2}
             model.precision = args.precision
         rec["maxpool"] = maxpool_roofline(dev, iters=5)
-        if static:
-            if args.precision == "fp32":
-                rec["torch_gpu_baseline"] = torch_gpu_baseline(model, inputs)
-            rec["cpu_baseline"] = cpu_baseline(host)
+        if static and args.precision == "fp32" and (B, N) == (4096, 1024):
+            rec["torch_gpu_baseline"] = torch_gpu_baseline(model, inputs)
+            rec["cpu_baseline"] = cpu_baseline(wl.host)
+            del wl, model, inputs
+            torch.cuda.empty_cache()
+            # BASELINE.json's other configurations, driver-timed in the same run (the metric is "static+dynamic heads")
+            rec["configs"] = {"C2": "this line's `value`"}
+            for name, st in (("C3", 10), ("C5", 10), ("C4", 3)):
+                rec["configs"][name] = other_config(name, dev, st)
+        elif static:
+            rec["cpu_baseline"] = cpu_baseline(wl.host)
     if use_dist:
-        fence()
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
     sys.stdout.flush()
     C.CDLL(None).fflush(None)                                   # whatever C stdio still holds goes to stderr too

@@ -136,6 +136,15 @@ int dal3_point_head_forward(int head_kind, const void* packed, int dtype, dal3_b
                             float* out, int64_t out_stride,
                             void* workspace, size_t workspace_bytes, dal3_stream stream);
 
+/* The per-point stack + max of the same heads as its own launch (conv1..4 + BN + ReLU, torch.max(x, 2)[0]:
+ * static_model.py:329-334, dynamic_model.py:240-245, :277-282) -> feat (B,512), no FC tail; per-kernel timing and
+ * tests. n_distinct (B) i32 device or NULL: only the first n_distinct[b] points of item b differ, the others repeat
+ * one of them (what dal3_mask_compact_sample's device sampler writes when fewer than M points are segmented);
+ * repeated points cannot change a max over points, so the kernel skips them. The whole-model sequencers pass
+ * `counts` here. */
+int dal3_point_head_pool(int head_kind, const void* packed, int dtype, dal3_bcn x, int B, int M,
+                         const int32_t* n_distinct, float* feat, dal3_stream stream);
+
 /* ---- dynamic PointNetEstimation.forward (dynamic_model.py:300-312): (B,384) -> (B,39). */
 int dal3_dynamic_box_est_forward(const void* packed, const float* embedding, int B, float* box_pred,
                                  void* workspace, size_t workspace_bytes, dal3_stream stream);

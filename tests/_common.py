@@ -41,6 +41,15 @@ def dynamic_case(batch, g):
             torch.from_numpy(init8_np), torch.from_numpy(gt_np))
 
 
+def recentred_sd(kind, sample_pts_np, seed):
+    """synth weights of `kind` with the segmentation bias re-centred (oracle logits of a small sample of the
+    inputs) so that about half the points are segmented; with the raw random init every point lands in one class"""
+    from oracle import ref_heads as R
+    sd = synth.state_dict(kind, seed=seed)
+    lg = R.ins_seg(R.as_torch_sd(sd), torch.from_numpy(np.ascontiguousarray(sample_pts_np)).transpose(2, 1))
+    return synth.recentre_seg_bias(sd, float((lg[:, :, 1] - lg[:, :, 0]).mean()))
+
+
 def rel_err(a, b):
     """max |a-b| / max|b| : the '<= 1e-4 relative' measure of BASELINE.json's north_star."""
     a = np.asarray(a, np.float64)

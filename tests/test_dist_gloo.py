@@ -92,6 +92,62 @@ def test_sharded_refine_equals_per_shard_concat(world, n_items):
         assert np.array_equal(whole[lo:hi], synth.static_crops(hi - lo, 128, first=lo)[0])
 
 
+def _gatherer_worker(rank, world, port, n_items, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = dal3_dist.shard_range(n_items, rank, world)
+        g = dal3_dist.BoxGatherer(n_items, torch.device("cpu"))
+        got = []
+        for step in range(5):                                   # submit step k, collect step k-1: the overlapped form
+            local = torch.arange(lo, hi, dtype=torch.float32)[:, None] * 100 + step + torch.arange(7)[None] * 0.125
+            g.submit(local)
+            r = g.collect(keep=1)
+            if r is not None:
+                got.append(r.clone())
+        got.append(g.collect(keep=0).clone())
+        assert g.collect(keep=0) is None
+        with pytest.raises(RuntimeError):
+            for _ in range(3):
+                g.submit(local)
+        census = dal3_dist.world_census(torch.device("cpu"))
+        if rank == world - 1:
+            ret.put((torch.stack(got).numpy(), census))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_items", [(2, 9), (3, 4)])
+def test_box_gatherer_pipelines_steps_in_order(world, n_items):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_gatherer_worker, args=(r, world, port, n_items, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, census = ret.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert census == {"backend": "gloo", "world_size": world, "ranks_counted": world}
+    assert got.shape == (5, n_items, 7)
+    for step in range(5):
+        want = np.arange(n_items, dtype=np.float32)[:, None] * 100 + step + np.arange(7, dtype=np.float32)[None] * 0.125
+        assert np.array_equal(got[step], want), step
+
+
+def test_box_gatherer_without_a_process_group_passes_boxes_through():
+    g = dal3_dist.BoxGatherer(5, torch.device("cpu"))
+    x = torch.arange(35, dtype=torch.float32).reshape(5, 7)
+    g.submit(x)
+    assert g.collect(keep=1) is None
+    assert torch.equal(g.collect(keep=0), x)
+    assert dal3_dist.world_census(torch.device("cpu")) == {"backend": None, "world_size": 1, "ranks_counted": 1}
+
+
 # ------------------------------------------------------------------ the file-level drivers (eval.py) on two ranks
 def _eval_worker(rank, world, port, root, head, ret):
     """refine_static_tracks / refine_dynamic_tracks with the device stages stood in on CPU: crop preparation by a

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from _common import build_model, synth
+from _common import build_model, recentred_sd, synth
 
 hip = importlib.import_module("3dal_pytorch_amd._hip")
 pytestmark = pytest.mark.gpu
@@ -51,6 +51,61 @@ def test_dynamic_c3_shape_properties():
     # the box window is max-pooled: reversing the 101 boxes cannot change the box embedding
     rev = model._run(dp.transpose(2, 1), db.flip(1).transpose(2, 1), init_box8=di)
     assert torch.equal(rev["embedding"][:, 256:], full["embedding"][:, 256:])
+
+
+def test_dynamic_c3_full_size_bf16():
+    """BASELINE.json configs[2] at its full size: 1024 items x 5120 points + 101 boxes, bf16. Finite; a shard run on
+    its own (with its item offset) equals the same rows of the whole job bit for bit; a launch so small that every
+    persistent workgroup sees a single group gives the same bits as the 1024-item launch."""
+    B = 1024
+    p, bx, i8, _ = synth.dynamic_items(B, seed=31)
+    model = build_model("dynamic", recentred_sd("dynamic", p[:2], 31))
+    model.precision = "bf16"
+    dp, db, di = torch.from_numpy(p).cuda(), torch.from_numpy(bx).cuda(), torch.from_numpy(i8).cuda()
+    full = model._run(dp.transpose(2, 1), db.transpose(2, 1), init_box8=di)
+    assert full["logits"].shape == (B, 5120, 2)
+    for k in ("logits", "embedding", "bp", "boxes7"):
+        assert bool(torch.isfinite(full[k]).all()), k
+    counts = full["counts"].cpu().numpy()
+    assert counts.min() >= 0 and counts.max() <= 5120 and 0.2 < (full["mask"].float().mean().item()) < 0.8
+    for lo, hi in ((0, 128), (384, 512), (1000, 1024), (517, 521)):      # ranks 0 and 3 of 8, a ragged tail, 4 items
+        model.item_offset = lo
+        part = model._run(dp[lo:hi].transpose(2, 1), db[lo:hi].transpose(2, 1), init_box8=di[lo:hi])
+        for k in ("logits", "mask", "counts", "obj_idx", "embedding", "bp", "boxes7"):
+            assert torch.equal(part[k], full[k][lo:hi]), (k, lo)
+    model.item_offset = 0
+    again = model._run(dp.transpose(2, 1), db.transpose(2, 1), init_box8=di)
+    assert torch.equal(again["boxes7"], full["boxes7"]) and torch.equal(again["logits"], full["logits"])
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_static_c5_full_size_lowprec(prec):
+    """BASELINE.json configs[4] per-GPU size: 2048 crops x 4096 points through the 16-bit MFMA kernels. Finite; shard
+    == whole bit for bit; single-group launches == the persistent launch; logits invariant under a permutation of
+    a crop's points."""
+    B, N = 2048, 4096
+    base, init_np, gt_np = synth.static_crops(128, N, seed=32)
+    pts_np = np.tile(base, (16, 1, 1))
+    pts_np[128:] += synth.normal(32, "jit", (1, 1, 3), 0.0, 0.01).astype(np.float32)
+    pts_np[::9] *= 30.0                                                    # crops with hardly any segmented point
+    init_np, gt_np = np.tile(init_np, (16, 1)), np.tile(gt_np, (16, 1))
+    model = build_model("static_one", recentred_sd("static_one", base[:4], 32))
+    model.precision = prec
+    pts, init, gt = (torch.from_numpy(a).cuda() for a in (pts_np, init_np, gt_np))
+    full = model._run(pts.transpose(2, 1), init, gt)
+    for k in ("logits", "bp1", "boxes7"):
+        assert bool(torch.isfinite(full[k]).all()), k
+    counts = full["counts"].cpu().numpy()
+    assert (counts < 256).any() and (counts > 512).any()
+    for lo, hi in ((0, 256), (1792, 2048), (1001, 1003)):
+        model.item_offset = lo
+        part = model._run(pts[lo:hi].transpose(2, 1), init[lo:hi], gt[lo:hi])
+        for k in ("logits", "mask", "counts", "obj_idx", "bp1", "boxes7"):
+            assert torch.equal(part[k], full[k][lo:hi]), (k, lo)
+    model.item_offset = 0
+    perm = torch.from_numpy(np.argsort(synth.uniform(32, "perm", (N,)))).cuda()
+    permuted = model._run(pts[:32][:, perm].transpose(2, 1), init[:32], gt[:32])
+    assert torch.equal(permuted["logits"], full["logits"][:32][:, perm])
 
 
 def test_fused_max_equals_standalone_maxpool():

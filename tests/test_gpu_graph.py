@@ -33,6 +33,57 @@ def test_captured_dynamic_refine_equals_eager():
         assert torch.equal(cap(dp, db, di), model.refine(dp, db, di))
 
 
+def test_captured_graph_survives_workspace_growth_and_follows_weight_updates():
+    """The graph bakes in raw pointers: (1) an eager call with a larger batch re-allocates the model's workspace —
+    the capture runs on its own and must be unaffected; (2) new weights (load_state_dict, an in-place update, or a
+    `.data` write followed by invalidate_packed()) must not be answered with the stale packed blobs."""
+    B, N = 8, 512
+    model = build_model("static_one", synth.state_dict("static_one", seed=3))
+    p, i, g = (torch.from_numpy(a).cuda() for a in synth.static_crops(B, N, seed=3))
+    cap = graph.CapturedRefine(model, p.transpose(2, 1), i, g)
+    first = cap(p.transpose(2, 1), i, g).clone()
+    big = [torch.from_numpy(a).cuda() for a in synth.static_crops(512, 2048, seed=5)]
+    model.refine(big[0].transpose(2, 1), big[1], big[2])          # grows model._ws: a new buffer
+    junk = torch.full((64 << 20,), 7, dtype=torch.uint8, device="cuda")   # whatever was freed is likely reused here
+    assert torch.equal(cap(p.transpose(2, 1), i, g), first)
+    del junk
+    assert cap.recaptures == 0
+    # (2a) load_state_dict
+    sd2 = synth.state_dict("static_one", seed=4)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd2.items()})
+    want = model.refine(p.transpose(2, 1), i, g).clone()
+    assert not torch.equal(want, first)
+    assert torch.equal(cap(p.transpose(2, 1), i, g), want) and cap.recaptures == 1
+    # (2b) a write through .data does not bump the version counter: invalidate_packed() is the documented hook
+    with torch.no_grad():
+        model.box_est.fc3.bias.data.add_(0.25)
+    model.invalidate_packed()
+    want = model.refine(p.transpose(2, 1), i, g).clone()
+    assert torch.equal(cap(p.transpose(2, 1), i, g), want) and cap.recaptures == 2
+    # (2c) an ordinary in-place update (what an optimizer step is) is seen without any call
+    with torch.no_grad():
+        model.box_est.fc3.bias.add_(0.25)
+    want2 = model.refine(p.transpose(2, 1), i, g).clone()
+    assert not torch.equal(want2, want)
+    assert torch.equal(cap(p.transpose(2, 1), i, g), want2) and cap.recaptures == 3
+
+
+def test_data_writes_need_invalidate_packed_and_debug_mode_finds_them(monkeypatch):
+    model = build_model("static_one", synth.state_dict("static_one", seed=3))
+    p, i, g = (torch.from_numpy(a).cuda() for a in synth.static_crops(4, 512, seed=3))
+    a = model.refine(p.transpose(2, 1), i, g).clone()
+    model.box_est.fc3.bias.data.add_(0.5)                        # invisible to the version counter
+    model.invalidate_packed()
+    b = model.refine(p.transpose(2, 1), i, g).clone()
+    assert not torch.equal(a, b) and float((b[:, :3] - a[:, :3] - 0.5).abs().max()) < 1e-5
+    # DAL3_CHECK_PACKED=1: the cache checksums the tensors on the device and repacks by itself
+    monkeypatch.setenv("DAL3_CHECK_PACKED", "1")
+    m2 = build_model("static_one", synth.state_dict("static_one", seed=3))
+    assert torch.equal(m2.refine(p.transpose(2, 1), i, g), a)
+    m2.box_est.fc3.bias.data.add_(0.5)
+    assert torch.equal(m2.refine(p.transpose(2, 1), i, g), b)
+
+
 def test_capture_refuses_the_numpy_sampler_and_train_mode():
     model = build_model("static_one", synth.state_dict("static_one"))
     p, i, g = (torch.from_numpy(a).cuda() for a in synth.static_crops(2, 256))

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from _common import build_model, rel_err, synth
+from _common import build_model, positions_from_indices, rel_err, synth
 from oracle import ref_heads as R
 
 hip = importlib.import_module("3dal_pytorch_amd._hip")
@@ -87,6 +87,77 @@ def test_dynamic_lowprec_vs_fp32_path(prec):
     assert rel_err(o["logits"].cpu().numpy(), ref["logits"].cpu().numpy()) < TOL_LOGITS[prec]
     assert rel_err(o["embedding"].cpu().numpy(), ref["embedding"].cpu().numpy()) < TOL_BOX[prec]
     assert rel_err(o["bp"].cpu().numpy(), ref["bp"].cpu().numpy()) < 2 * TOL_BOX[prec]
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_dynamic_lowprec_vs_oracle_teacher_forced(prec):
+    """A5-A7 in 16 bits against the ORACLE (not against this package's fp32 kernels): logits free-running; then the
+    oracle's mask and its NumPy draws are forced, so that both sides embed the same 2560 object points, and the
+    point / box embeddings and the 39 box parameters are compared with the oracle's."""
+    B = 4
+    p, bx, i8, _ = synth.dynamic_items(B, seed=21)
+    sd = synth.state_dict("dynamic", seed=21)
+    p_t, b_t = torch.from_numpy(p).transpose(2, 1), torch.from_numpy(bx).transpose(2, 1)
+    lg = R.ins_seg(R.as_torch_sd(sd), p_t)
+    sd = synth.recentre_seg_bias(sd, float((lg[:, :, 1] - lg[:, :, 0]).mean()))
+    np.random.seed(22)
+    want = R.dynamic_forward(R.as_torch_sd(sd), p_t, b_t)
+    wmask = want["mask"].numpy()
+    assert (wmask.sum(1) > 0).all()
+    model = build_model("dynamic", sd)
+    model.precision = prec
+    dp, dbx, di8 = dev(p).transpose(2, 1), dev(bx).transpose(2, 1), dev(i8)
+    free = model._run(dp, dbx, init_box8=di8)
+    wl = want["logits"].numpy()
+    assert rel_err(free["logits"].cpu().numpy(), wl) < TOL_LOGITS[prec]
+    margin = wl[:, :, 1] - wl[:, :, 0]
+    sure = np.abs(margin) > 2 * TOL_LOGITS[prec] * np.abs(wl).max()
+    assert np.array_equal(free["mask"].cpu().numpy()[sure], (margin > 0)[sure])          # only near-ties may flip
+    choice = np.stack([positions_from_indices(wmask[i], want["_indices"][i].numpy()) for i in range(B)])
+    o = model._run(dp, dbx, init_box8=di8, choice=torch.from_numpy(choice), mask_override=want["mask"])
+    assert np.array_equal(o["obj_idx"].cpu().numpy(), want["_indices"].numpy())
+    emb = o["embedding"].cpu().numpy()
+    assert rel_err(emb[:, :256], want["_point_e"].numpy()) < TOL_BOX[prec]
+    assert rel_err(emb[:, 256:], want["_box_e"].numpy()) < TOL_BOX[prec]
+    bp = o["bp"].cpu().numpy()
+    wbp = np.concatenate([want["center"].numpy(), want["heading_scores"].numpy(),
+                          want["heading_residuals_normalized"].numpy(), want["size_scores"].numpy(),
+                          want["size_residuals_normalized"].numpy().reshape(B, 9)], 1)
+    assert rel_err(bp, wbp) < 2 * TOL_BOX[prec]
+    # decoded boxes wherever the 16-bit argmaxes agree with the oracle's (a near-tie class may flip)
+    same = (bp[:, 3:15].argmax(1) == wbp[:, 3:15].argmax(1)) & (bp[:, 27:30].argmax(1) == wbp[:, 27:30].argmax(1))
+    assert same.any()
+    wb7 = R.decode_dynamic(want, torch.from_numpy(i8))
+    d = np.abs(o["boxes7"].cpu().numpy()[same] - wb7[same])
+    assert d.max() < 2 * TOL_BOX[prec] * np.abs(wb7).max()
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_c5_static_n4096_lowprec_vs_oracle(prec):
+    """BASELINE.json configs[4] shape (dense N=4096 crops, 16-bit MFMA shared MLP): ins_seg against the oracle at
+    B=8, and the whole static head with the oracle's segmentation and draws forced."""
+    B, N = 8, 4096
+    model, sd, pts_np, pts, init, gt = _static("static_one", B, N, seed=23)
+    tsd = R.as_torch_sd(sd)
+    pts_t = torch.from_numpy(pts_np).transpose(2, 1)
+    np.random.seed(24)
+    want = R.static_one_forward(tsd, pts_t, init.cpu())
+    wl = want["logits"].numpy()
+    model.precision = prec
+    free = model._run(pts, init, gt)
+    assert rel_err(free["logits"].cpu().numpy(), wl) < TOL_LOGITS[prec]
+    margin = wl[:, :, 1] - wl[:, :, 0]
+    sure = np.abs(margin) > 2 * TOL_LOGITS[prec] * np.abs(wl).max()
+    assert np.array_equal(free["mask"].cpu().numpy()[sure], (margin > 0)[sure])
+    wmask = want["mask"].numpy()
+    counts = wmask.sum(1)
+    choice = np.stack([positions_from_indices(wmask[i], want["_indices"][i].numpy()) if counts[i] else
+                       np.zeros(512, np.int64) for i in range(B)])
+    o = model._run(pts, init, gt, choice=torch.from_numpy(choice), mask_override=want["mask"])
+    wbp = np.concatenate([want["center_boxnet"].numpy(), want["heading_scores"].numpy(),
+                          want["heading_residuals_normalized"].numpy(), want["size_scores"].numpy(),
+                          want["size_residuals_normalized"].numpy().reshape(B, 9)], 1)
+    assert rel_err(o["bp1"].cpu().numpy(), wbp) < TOL_BOX[prec]
 
 
 def test_lowprec_api_errors():

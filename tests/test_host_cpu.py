@@ -178,3 +178,35 @@ def test_oracle_is_test_infrastructure_only():
         assert not code_mentions(path), path
     assert set(code_mentions(os.path.join(ROOT, "bench.py"))) == {"cpu_baseline"}
     assert set(code_mentions(os.path.join(ROOT, "__graft_entry__.py"))) <= {"build", "smoke"}
+
+
+def test_packed_cache_stamps_follow_parameter_identity():
+    """host logic of the derived weight cache: the stamp is a per-tensor tuple (pointer, version, shape, device);
+    in-place ops and load_state_dict change it, a write through .data does not (hence invalidate_packed())"""
+    heads = importlib.import_module("3dal_pytorch_amd._heads")
+    sm = importlib.import_module("3dal_pytorch_amd.static_model")
+    m = sm.StaticModelOneBoxEst()
+    cache = heads.PackedCache()
+    s0 = cache._stamp_of(m.box_est, 0)
+    assert s0 == cache._stamp_of(m.box_est, 0) and s0 != cache._stamp_of(m.box_est, 1)
+    with torch.no_grad():
+        m.box_est.fc3.bias.add_(1.0)
+    s1 = cache._stamp_of(m.box_est, 0)
+    assert s1 != s0
+    m.box_est.fc3.bias.data.add_(1.0)
+    assert cache._stamp_of(m.box_est, 0) == s1            # invisible: the documented case for invalidate_packed()
+    m.load_state_dict(m.state_dict())
+    assert cache._stamp_of(m.box_est, 0) != s1
+    # the hooks empty the model's own cache
+    m._cache._stamp["x"], m._cache._blob["x"], m._cache._src["x"] = (1,), None, (m.box_est, 0)
+    m.load_state_dict(m.state_dict())
+    assert not m._cache._stamp and not m._cache._blob
+    m._cache._stamp["x"] = (1,)
+    m.eval()
+    assert not m._cache._stamp
+    m._cache._stamp["x"] = (1,)
+    m.float()
+    assert not m._cache._stamp
+    m._cache._stamp["x"] = (1,)
+    m.invalidate_packed()
+    assert not m._cache._stamp

@@ -1,0 +1,61 @@
+"""The N > 1 start-up path of bench.py on CPU: `python bench.py --gpus 2` with no launcher in the environment must
+spawn its ranks itself (3dal_pytorch_amd/launch.py) from a parent that never touches a GPU, relay rank 0's one JSON
+line and pass the ranks' exit code on. The hot path cannot run here, so the ranks run `--plumbing-only`: launcher,
+process group (gloo), BoxGatherer / all_gather_boxes and the census, no kernels."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+from _common import ROOT
+
+launch = importlib.import_module("3dal_pytorch_amd.launch")
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DAL3_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2", **extra)
+    return env
+
+
+def test_bench_without_enough_gpus_fails_cleanly():
+    """no GPU here: a plain `bench.py --gpus 2` says what it needs and exits non-zero without starting anything"""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                         text=True, env=_env(), timeout=300)
+    assert out.returncode != 0
+    assert "needs 2 GPUs" in out.stderr, out.stderr[-1000:]
+    assert out.stdout.strip() == ""
+
+
+def test_bench_self_launches_two_ranks_and_relays_one_line():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--plumbing-only"], capture_output=True, text=True,
+                         env=_env(), timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["plumbing_only"] and rec["gathered_ok"]
+    assert rec["rccl"] == {"backend": "gloo", "world_size": 2, "ranks_counted": 2}
+
+
+def test_a_failing_rank_fails_the_launcher():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--plumbing-only"], capture_output=True, text=True,
+                         env=_env(DAL3_BENCH_FAIL_RANK="1"), timeout=600)
+    assert out.returncode != 0
+
+
+def test_under_a_launcher_the_process_is_a_rank():
+    """what the driver does for N > 1: torch.distributed.run starts bench.py; it must not spawn again"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(launch.free_port()), BENCH, "--gpus", "2", "--plumbing-only"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=_env(), timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads(launch.relay_json_line(out.stdout))
+    assert rec["rccl"]["ranks_counted"] == 2
+
+
+def test_relay_picks_the_json_line():
+    assert launch.relay_json_line("NCCL version 2.x\n{\"a\": 1}\ntrailing\n") == '{"a": 1}'
+    assert launch.relay_json_line("nothing here\n") is None

@@ -4,10 +4,13 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p variants/obj_$1
-CC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-honor-nans"
-for f in dal3_api dal3_pointmlp dal3_misc dal3_prep dal3_crops dal3_train; do
+CC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function"
+NONAN=-fno-honor-nans          # the shared-MLP kernels only, as in the Makefile
+for f in dal3_api dal3_misc dal3_prep dal3_crops dal3_train; do
   $CC $2 -c 3dal_pytorch_amd/csrc/$f.hip -o variants/obj_$1/$f.o &
 done
+CC="$CC $NONAN"
+$CC $2 -c 3dal_pytorch_amd/csrc/dal3_pointmlp.hip -o variants/obj_$1/dal3_pointmlp.o &
 $CC $2 -DLP_PART=1 -mllvm -amdgpu-mfma-vgpr-form -c 3dal_pytorch_amd/csrc/dal3_pointmlp_lp.hip -o variants/obj_$1/lp_enc.o &
 $CC $2 -DLP_PART=2 -c 3dal_pytorch_amd/csrc/dal3_pointmlp_lp.hip -o variants/obj_$1/lp_dec.o &
 wait
