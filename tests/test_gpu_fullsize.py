@@ -87,16 +87,20 @@ def test_static_c5_full_size_lowprec(prec):
     base, init_np, gt_np = synth.static_crops(128, N, seed=32)
     pts_np = np.tile(base, (16, 1, 1))
     pts_np[128:] += synth.normal(32, "jit", (1, 1, 3), 0.0, 0.01).astype(np.float32)
-    pts_np[::9] *= 30.0                                                    # crops with hardly any segmented point
+    sd = recentred_sd("static_one", base[:4], 32)
+    # every ninth crop is shrunk so that only a few dozen of its points are segmented (the head then skips whole
+    # tiles of copies; factor found with the oracle: 0.85 leaves 10..170 points of these crops), some to none at all
+    pts_np[::9] *= np.float32(0.85)
+    pts_np[4::27] *= np.float32(0.02)
     init_np, gt_np = np.tile(init_np, (16, 1)), np.tile(gt_np, (16, 1))
-    model = build_model("static_one", recentred_sd("static_one", base[:4], 32))
+    model = build_model("static_one", sd)
     model.precision = prec
     pts, init, gt = (torch.from_numpy(a).cuda() for a in (pts_np, init_np, gt_np))
     full = model._run(pts.transpose(2, 1), init, gt)
     for k in ("logits", "bp1", "boxes7"):
         assert bool(torch.isfinite(full[k]).all()), k
     counts = full["counts"].cpu().numpy()
-    assert (counts < 256).any() and (counts > 512).any()
+    assert ((counts > 0) & (counts < 256)).any() and (counts == 0).any() and (counts > 512).any()
     for lo, hi in ((0, 256), (1792, 2048), (1001, 1003)):
         model.item_offset = lo
         part = model._run(pts[lo:hi].transpose(2, 1), init[lo:hi], gt[lo:hi])
