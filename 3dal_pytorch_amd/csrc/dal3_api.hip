@@ -405,7 +405,7 @@ static int ins_seg_run(const void* packed, int dtype, int c_in, const dal3_bcn& 
     if (c_in != 3 && c_in != 4) return fail(DAL3_EINVAL, "ins_seg: c_in must be 3 or 4");
     TRY(check_bcn(pts, "pts"));
     const BCN x = to_bcn(pts);
-    HIP_TRY(hipMemsetAsync(ws.g, 0, (size_t)B * 1024 * sizeof(float), s));
+    HIP_TRY(launch_fill_words(ws.g, (size_t)B * 1024, 0u, s));
     if (dtype == DAL3_F32) {
         const InsSegW w = ins_seg_view(static_cast<const float*>(packed), c_in);
         HIP_TRY(launch_ins_seg_encode(w, x, c_in, B, N, ws.g, s));
@@ -551,7 +551,7 @@ static int point_head_run(int head_kind, const void* packed, int dtype, const da
     TRY(check_bcn(x, "x"));
     int c_in, ks, c[4], n_fc, fi[3], fo[3];
     point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
-    HIP_TRY(hipMemsetAsync(ws.feat, 0, (size_t)B * 512 * sizeof(float), s));
+    HIP_TRY(launch_fill_words(ws.feat, (size_t)B * 512, 0u, s));
     if (dtype != DAL3_F32) {
         const PointHeadLpW w = point_head_lp_view(packed, head_kind);
         HIP_TRY(launch_point_head_lp(dtype, head_kind, w, to_bcn(x), c_in, B, M, ws.feat, distinct, s));
@@ -584,7 +584,7 @@ extern "C" int dal3_point_head_pool(int head_kind, const void* packed, int dtype
     hipStream_t s = static_cast<hipStream_t>(stream);
     int c_in, ks, c[4], n_fc, fi[3], fo[3];
     point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
-    HIP_TRY(hipMemsetAsync(feat, 0, (size_t)B * 512 * sizeof(float), s));
+    HIP_TRY(launch_fill_words(feat, (size_t)B * 512, 0u, s));
     if (dtype != DAL3_F32) {
         const PointHeadLpW w = point_head_lp_view(packed, head_kind);
         HIP_TRY(launch_point_head_lp(dtype, head_kind, w, to_bcn(x), c_in, B, M, feat, n_distinct, s));

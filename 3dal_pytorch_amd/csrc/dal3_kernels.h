@@ -191,6 +191,9 @@ hipError_t launch_writeback(const double* final_boxes, const int32_t* final_idx,
                             int32_t* owner, hipStream_t s);
 hipError_t launch_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, hipStream_t s);
 hipError_t launch_segment_counts(const uint8_t* mask, int B, int N, int32_t* counts, hipStream_t s);
+// p[0..n_words) = value (32-bit words) as a kernel launch; used instead of hipMemsetAsync wherever the call may be
+// captured into a hipGraph (see dal3_misc.hip)
+hipError_t launch_fill_words(void* p, size_t n_words, uint32_t value, hipStream_t s);
 hipError_t launch_compact_sample(const uint8_t* mask, BCN pts, int B, int N, int C, int M, int sampler,
                                  const int32_t* choice, uint64_t seed, int64_t item_offset, int32_t* counts,
                                  int32_t* pos, int32_t* obj_idx, float* obj_pts, hipStream_t s);

@@ -404,6 +404,32 @@ __global__ __launch_bounds__(256) void compact_sample_kernel(const uint8_t* __re
     }
 }
 
+// Zero-fill as a KERNEL, not hipMemsetAsync: on ROCm 7.0 a memset node of a captured hipGraph does not keep its
+// fill value reliably — after other work on the process (a larger eager launch, a big allocation) replays of the graph
+// filled the max-pool accumulators with an arbitrary 32-bit pattern instead of 0 (tools/dbg_graph.py: about half of
+// the processes, persistent until the graph is recorded again; torch-only graphs and eager calls were never affected).
+// A kernel node carries its arguments by value. n_words 32-bit words, 16-byte aligned pointers take the wide path.
+__global__ __launch_bounds__(256) void fill_words_kernel(uint32_t* __restrict__ p, size_t n_words, uint32_t value) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        const size_t n4 = n_words / 4;
+        uint4 v;
+        v.x = v.y = v.z = v.w = value;
+        for (size_t k = i; k < n4; k += stride) reinterpret_cast<uint4*>(p)[k] = v;
+        for (size_t k = 4 * n4 + i; k < n_words; k += stride) p[k] = value;
+    } else {
+        for (size_t k = i; k < n_words; k += stride) p[k] = value;
+    }
+}
+hipError_t launch_fill_words(void* p, size_t n_words, uint32_t value, hipStream_t s) {
+    if (n_words == 0) return hipSuccess;
+    const size_t want = (n_words / 4 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    hipLaunchKernelGGL(fill_words_kernel, dim3(grid), dim3(256), 0, s, static_cast<uint32_t*>(p), n_words, value);
+    return hipGetLastError();
+}
+
 hipError_t launch_segment_counts(const uint8_t* mask, int B, int N, int32_t* counts, hipStream_t s) {
     hipLaunchKernelGGL(segment_counts_kernel, dim3(B), dim3(256), 0, s, mask, N, counts);
     return hipGetLastError();

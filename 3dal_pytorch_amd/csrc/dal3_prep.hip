@@ -306,7 +306,7 @@ hipError_t launch_writeback(const double* final_boxes, const int32_t* final_idx,
                             const double* pose_inv, const double* track_box, float* det, const int64_t* det_start,
                             const int32_t* det_count, const uint8_t* active, int P, int64_t n_det, int32_t* match,
                             int32_t* owner, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(owner, 0xFF, (size_t)n_det * sizeof(int32_t), s);     // -1
+    hipError_t e = launch_fill_words(owner, (size_t)n_det, 0xFFFFFFFFu, s);             // -1
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(writeback_match_kernel, dim3((P + 127) / 128), dim3(128), 0, s, track_box, pose_inv, det, det_start,
                        det_count, active, P, match, owner);

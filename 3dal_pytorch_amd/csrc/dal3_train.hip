@@ -799,7 +799,7 @@ __global__ void tr_segmax_unpack_kernel(const unsigned long long* __restrict__ p
 
 hipError_t launch_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float* scale, const float* shift,
                             float* g, int32_t* arg, int64_t n_seg, unsigned long long* packed, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(packed, 0, (size_t)n_seg * C * sizeof(unsigned long long), s);
+    hipError_t e = launch_fill_words(packed, (size_t)n_seg * C * 2, 0u, s);     // (a kernel: captured into hipGraphs, see dal3_misc.hip)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tr_segmax_kernel, dim3((C + 63) / 64, (unsigned)(n_seg * SEG_CHUNKS)), dim3(256), 0, s, z, ldz, seg, C,
                        scale, shift, packed);

@@ -59,6 +59,10 @@ class CapturedRefine:
         m = self.model
         if (m.precision, m.seed, m.item_offset) != self._settings:
             return True
+        # the blobs themselves must be the ones the graph points into: after invalidate_packed() the cache re-packs
+        # into NEW tensors whose stamps can equal the old ones (a .data write leaves pointer and version untouched)
+        if any(m._cache._blob.get(k) is not v for k, v in self._blobs.items()):
+            return True
         return m._cache._stamp != self._stamps or not m._cache.current()
 
     def __call__(self, *inputs):

@@ -284,8 +284,8 @@ def committed_profile(kernel, precision, B, N):
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         t = json.load(open(tfile))
-        shape = t.get("_shape", {"precision": "fp32", "B": 4096, "N": 1024})
-        if (shape.get("precision"), shape.get("B"), shape.get("N")) == (precision, B, N) and kernel in t:
+        shape = t.get("_shape", {"precisions": ["fp32"], "B": 4096, "N": 1024})
+        if precision in shape.get("precisions", []) and (shape.get("B"), shape.get("N")) == (B, N) and kernel in t:
             out["traffic"] = t[kernel]
             out["traffic_source"] = {"file": "profiles/traffic.json", "taken": t.get("_taken", "round 1"),
                                      "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "

@@ -26,10 +26,13 @@ def short(name):
     return name.split("(")[0].replace("void ", "").split("<")[0]
 
 
-stats = glob.glob(os.path.join(src, "prof_kt", "**", "*kernel_stats.csv"), recursive=True)
-if stats:
+for sub, sfx in (("prof_kt", ""), ("prof_kt_bf16", "_bf16"), ("prof_kt_c3", "_c3"), ("prof_kt_c5", "_c5"),
+                 ("prof_kt_maxpool", "_maxpool")):
+    stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if not stats:
+        continue
     rows = list(csv.DictReader(open(stats[0])))
-    with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
+    with open(os.path.join(out_dir, f"{tag}_kernel_stats{sfx}.csv"), "w") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows:
@@ -38,12 +41,15 @@ if stats:
                             r["MinNs"], r["MaxNs"], r["StdDev"]])
 
 pmc = defaultdict(lambda: defaultdict(list))
-for d in ("prof_fetch", "prof_write", "prof_mfma"):
+for d in ("prof_fetch", "prof_write", "prof_mfma", "prof_fetch_bf16", "prof_write_bf16", "prof_mfma_bf16",
+          "prof_fetch_maxpool", "prof_write_maxpool"):
     for fn in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(fn)):
             k = short(r["Kernel_Name"])
             if not any(o in k for o in OURS):
                 continue
+            if d.endswith("_bf16") and "_lp_" not in k:
+                continue                                          # the fp32 passes already hold the shared small kernels
             pmc[k][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"]),
                                               int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 summary, traffic = {}, {}
@@ -62,5 +68,8 @@ for k, ctrs in pmc.items():
         traffic[k] = round(s["hbm_read_bytes_corrected"] + s["hbm_write_bytes"])
     summary[k] = s
 json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+import datetime                                              # noqa: E402
+traffic["_shape"] = {"precisions": ["fp32", "bf16"], "B": 4096, "N": 1024}   # what the PMC passes ran (`_lp_` rows: bf16)
+traffic["_taken"] = f"{tag}, {datetime.date.today().isoformat()}, tools/profile_round.sh"
 json.dump(traffic, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1, sort_keys=True))

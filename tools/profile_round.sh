@@ -1,16 +1,30 @@
 #!/bin/bash
-# tools/profile_round.sh — run ON the GPU box (gpurun -- 'bash tools/profile_round.sh'): the bench line plus the
-# rocprofv3 passes whose summaries tools/prof_summary.py condenses into profiles/. Counters are collected in their
-# own passes (never together with a trace domain), as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
+# tools/profile_round.sh [TAG] — run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r02'): the bench line plus
+# the rocprofv3 passes whose summaries tools/prof_summary.py condenses into profiles/. Counters are collected in their
+# own passes (never together with a trace domain), as /opt/skills/guides/MI355X_MICROARCH.md prescribes. The program
+# after `--` is python3 itself (no env / bash -c hop: the profiler's preload has initialised the GPU by then).
 set -u
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -o kt -- python3 $R/bench.py --no-extras --steps 10 --warmup 2 > $O/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt_bf16 -o kt -- python3 $R/bench.py --no-extras --precision bf16 --steps 10 --warmup 2 > $O/bench_bf16_under_rocprof.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -o c -- python3 $R/bench.py --no-extras --steps 3 --warmup 1 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -o c -- python3 $R/bench.py --no-extras --steps 3 --warmup 1 > /dev/null 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_mfma -o c -- python3 $R/bench.py --no-extras --steps 3 --warmup 1 > /dev/null 2>&1
+KT="--kernel-trace --stats --output-format csv"
+rocprofv3 $KT -d $O/prof_kt -o kt -- python3 $R/bench.py --no-extras --steps 10 --warmup 2 > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 $KT -d $O/prof_kt_bf16 -o kt -- python3 $R/bench.py --no-extras --precision bf16 --steps 10 --warmup 2 > $O/bench_bf16_under_rocprof.json 2>/dev/null
+rocprofv3 $KT -d $O/prof_kt_c3 -o kt -- python3 $R/bench.py --no-extras --config C3 --steps 10 --warmup 2 > $O/bench_c3_under_rocprof.json 2>/dev/null
+rocprofv3 $KT -d $O/prof_kt_c5 -o kt -- python3 $R/bench.py --no-extras --config C5 --steps 10 --warmup 2 > $O/bench_c5_under_rocprof.json 2>/dev/null
+# the HBM-roofline kernel on its own: kernel trace, then FETCH_SIZE and WRITE_SIZE in separate passes
+rocprofv3 $KT -d $O/prof_kt_maxpool -o kt -- python3 $R/bench.py --only-maxpool --steps 10 > $O/bench_maxpool_under_rocprof.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch_maxpool -o c -- python3 $R/bench.py --only-maxpool --steps 3 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write_maxpool -o c -- python3 $R/bench.py --only-maxpool --steps 3 > /dev/null 2>&1
+for P in fp32 bf16; do
+  S=""; [ $P = bf16 ] && S="_bf16"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch$S -o c -- python3 $R/bench.py --no-extras --precision $P --steps 3 --warmup 1 > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write$S -o c -- python3 $R/bench.py --no-extras --precision $P --steps 3 --warmup 1 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_mfma$S -o c -- python3 $R/bench.py --no-extras --precision $P --steps 3 --warmup 1 > /dev/null 2>&1
+done
+python3 $R/tools/prof_summary.py $TAG $O > $O/prof_summary.log 2>&1
+cp $R/profiles/${TAG}_* $R/profiles/traffic.json $O/ 2>/dev/null
 ls $O
