@@ -264,7 +264,10 @@ def _hip_training(m, pts):
 
 def _seg_logits(m, pts):
     if _hip_training(m, pts):
-        return _train.ins_seg_train_forward(m.ins_seg, pts.float(), p_drop=m.ins_seg.dropout.p)
+        # m.drop_mask: optional (B*N,128) multiplier that replaces the random Dropout draw of this forward (parity
+        # tests replay the reference's own draw with it); None = draw on the device
+        return _train.ins_seg_train_forward(m.ins_seg, pts.float(), p_drop=m.ins_seg.dropout.p,
+                                            drop_mask=getattr(m, "drop_mask", None))
     return m.ins_seg(pts)
 
 

@@ -103,6 +103,16 @@ def widest_gap_centre(margin, window=0.1):
     return float(0.5 * (m[lo + i] + m[lo + i + 1])), float(0.5 * gaps[i])
 
 
+def fixture_sample(a, limit=16384, keep=8192):
+    """what a fixture stores of a large tensor: all of it up to `limit` elements, else `keep` elements at fixed
+    pseudo-random flat positions (a function of the size only) — the generator and the test apply the same map"""
+    a = np.asarray(a)
+    if a.size <= limit:
+        return a.reshape(-1)
+    idx = np.sort(np.random.default_rng(a.size).choice(a.size, keep, replace=False))
+    return a.reshape(-1)[idx]
+
+
 # --------------------------------------------------------------------------- inputs
 def static_crops(batch, n_pts, seed=SEED, first=0):
     """pts (batch, n_pts, 3) fp32 point-major, init_box (batch, 7), bbox_gt (batch, 7).

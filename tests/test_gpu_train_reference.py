@@ -1,0 +1,106 @@
+"""N4 pinned to the REFERENCE's training step: tests/golden/train_step_*.npz hold one step of the real
+StaticModelOneBoxEst / DynamicModel in train mode — forward, the reference's criterion, total_loss.backward(),
+Adam — run by tests/golden/gen_train_step.py from the imported reference code (in float64, with the float32 run's
+Dropout draw and NumPy draws recorded). Here the drop-in modules take the same step on the MI355X with the HIP
+training kernels (train_backend "hip"): same weights, same inputs, the recorded Dropout multiplier and NumPy seed.
+Bar: every compared tensor within 1e-4 of that tensor's largest entry (the reference's OWN float32 run is 3e-3 ..
+2e-2 away from its float64 run on these gradients: `f32_noise` in the fixture)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from _common import build_model, golden, synth
+
+losses = importlib.import_module("3dal_pytorch_amd.losses")
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _case(kind, g):
+    if kind == "static_one":
+        B, N = 8, 256
+        pts, init, gt = synth.static_crops(B, N, seed=41)
+        labels = synth.loss_case(41, batch=B, n_pts=N)[1]
+        inp = dict(pts=pts, init=init, gt=gt)
+    else:
+        B, n_per = 4, 64
+        pts, box, init8, gt = synth.dynamic_items(B, n_per_frame=n_per, seed=42)
+        labels = synth.loss_case(42, batch=B, n_pts=5 * n_per)[1]
+        inp = dict(pts=pts, box=box, gt=gt)
+    s = sum(np.asarray(v, np.float64).sum() for v in inp.values())
+    assert abs(s - float(g["in_sum"])) < 1e-9, "synthetic input generator drifted from the fixture"
+    sd = synth.recentre_seg_bias(synth.state_dict(kind, seed=43), float(g["margin_shift"]))
+    return inp, labels, sd
+
+
+def _rel(a, ref, ref_max):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return float(np.abs(a - ref).max() / max(ref_max, 1e-30))
+
+
+@pytest.mark.parametrize("kind", ["static_one", "dynamic"])
+def test_one_training_step_matches_the_reference(kind):
+    g = golden("train_step_" + kind)
+    inp, labels, sd = _case(kind, g)
+    model = build_model(kind, sd).train()
+    assert model.train_backend == "hip"
+    model.sampler = "numpy"                                              # the reference's draws, in its order
+    keep = np.unpackbits(g["drop_keep"], axis=1).astype(np.float32)
+    model.drop_mask = torch.from_numpy(keep / (1.0 - model.ins_seg.dropout.p)).cuda()
+    crit = (losses.FrustumPointNetLossOneBoxEst() if kind == "static_one" else losses.DynamicModelLoss())
+    opt = torch.optim.Adam(model.parameters(), lr=float(g["lr"]))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()     # noqa: E731
+    np.random.seed(int(g["np_seed"]))
+    if kind == "static_one":
+        out = model(dev(inp["pts"]).transpose(2, 1), dev(inp["init"]), dev(inp["gt"]))
+    else:
+        out = model(dev(inp["pts"]).transpose(2, 1), dev(inp["box"]).transpose(2, 1), dev(inp["gt"]))
+    # forward: logits, the mask (hence the draws), the box parameters
+    lg = out["logits"].detach().cpu().numpy()
+    err = np.abs(lg - g["ref_logits"]).max()
+    assert err / np.abs(g["ref_logits"]).max() < TOL
+    assert float(g["min_abs_margin"]) > 20 * err
+    assert np.array_equal(out["mask"].cpu().numpy(), g["mask"])
+    for k in ("center", "heading_scores", "size_scores", "heading_residuals_normalized", "size_residuals_normalized"):
+        ref = g["ref_out_" + k]
+        assert _rel(out[k].detach().cpu().numpy(), ref, np.abs(ref).max()) < TOL, k
+    # criterion: every entry of the reference's loss dict
+    ls = crit(out, *[dev(a) for a in labels])
+    for k in ls:
+        assert abs(float(ls[k]) - float(g["ref_loss_" + k])) <= TOL * max(abs(float(g["ref_loss_" + k])), 1.0), k
+    opt.zero_grad()
+    ls["total_loss"].backward()
+    params = dict(model.named_parameters())
+    names = [k[len("ref_grad_"):] for k in g if k.startswith("ref_grad_")]
+    assert len(names) >= 18
+    worst = {}
+    for name in names:
+        got = synth.fixture_sample(params[name].grad.detach().cpu().numpy())
+        ref, ref_max = g["ref_grad_" + name], float(g["refmax_grad_" + name])
+        if ref_max < 1e-9:                                             # analytically zero (a shift that a BN removes)
+            assert np.abs(got).max() < 1e-5, name
+            continue
+        worst[name] = _rel(got, ref, ref_max)
+    bad = {k: v for k, v in worst.items() if v >= TOL}
+    assert not bad, bad
+    # BatchNorm running statistics after the forward
+    sdm = model.state_dict()
+    for k in g:
+        if k.startswith("ref_rm_") or k.startswith("ref_rv_"):
+            key = k[7:] + (".running_mean" if k.startswith("ref_rm_") else ".running_var")
+            ref = g[k]
+            assert _rel(sdm[key].cpu().numpy(), ref, np.abs(ref).max()) < TOL, key
+    # Adam's first step moves every weight by lr * g / (|g| + eps): sign-like, so an entry whose gradient is within
+    # rounding of zero can land on either side. Compare where the reference's gradient is clear of zero.
+    opt.step()
+    for name in names:
+        ref_g, ref_max = g["ref_grad_" + name], float(g["refmax_grad_" + name])
+        if ref_max < 1e-9:
+            continue
+        clear = np.abs(ref_g) > 1e-3 * ref_max
+        new = synth.fixture_sample(dict(model.named_parameters())[name].detach().cpu().numpy())
+        ref_new = g["ref_new_" + name]
+        assert clear.mean() > 0.5, name
+        assert np.abs(new - ref_new)[clear].max() < 2e-2 * float(g["lr"]) + 1e-6 * float(g["refmax_new_" + name]), name
