@@ -24,12 +24,13 @@ def huber_loss(error, delta=1.0):
 _CONST = {}
 
 
-def _consts(dev):
+def _consts(dev, dtype=torch.float32):
     """one-hot tables and MEAN_SIZE_ARR on the device, built once (also keeps the criterion hipGraph-capturable)"""
-    c = _CONST.get(dev)
+    c = _CONST.get((dev, dtype))
     if c is None:
-        c = _CONST[dev] = (torch.eye(arch.NUM_HEADING_BIN, device=dev), torch.eye(arch.NUM_SIZE_CLUSTER, device=dev),
-                           torch.tensor(arch.MEAN_SIZE, dtype=torch.float32, device=dev).view(1, arch.NUM_SIZE_CLUSTER, 3))
+        c = _CONST[(dev, dtype)] = (torch.eye(arch.NUM_HEADING_BIN, device=dev, dtype=dtype),
+                                    torch.eye(arch.NUM_SIZE_CLUSTER, device=dev, dtype=dtype),
+                                    torch.tensor(arch.MEAN_SIZE, dtype=dtype, device=dev).view(1, arch.NUM_SIZE_CLUSTER, 3))
     return c
 
 
@@ -44,9 +45,9 @@ def _box_terms(center, heading_scores, heading_residuals_normalized, size_scores
     center_loss = huber_loss(torch.norm(center - center_label, dim=1), delta=2.0)
     hcl, scl = heading_class_label.long(), size_class_label.long()
     heading_class_loss = F.nll_loss(F.log_softmax(heading_scores, dim=1), hcl)
-    eye_h, eye_s, mean_size = _consts(dev)
+    eye_h, eye_s, mean_size = _consts(dev, center.dtype)
     h_onehot = eye_h[hcl]
-    h_pred = torch.sum(heading_residuals_normalized * h_onehot.float(), dim=1)
+    h_pred = torch.sum(heading_residuals_normalized * h_onehot, dim=1)
     heading_res_loss = huber_loss(h_pred - heading_residuals_label / (np.pi / arch.NUM_HEADING_BIN), delta=1.0)
     size_class_loss = F.nll_loss(F.log_softmax(size_scores, dim=1), scl)
     s_onehot = eye_s[scl].view(-1, arch.NUM_SIZE_CLUSTER, 1).repeat(1, 1, 3)

@@ -223,7 +223,10 @@ def _mask_and_gather(pts, logits, n_obj, n_ch, model=None):
         return obj.transpose(2, 1), mask
     counts = mask.sum(1).cpu().numpy()
     choice = numpy_choice(counts, n_obj)
-    obj = torch.zeros((pts.shape[0], n_ch, n_obj), dtype=torch.float32, device=pts.device)
+    # (float32 in the reference whatever comes in; following a float64 input lets the composite be run in float64
+    # against the reference's float64 training step, tests/test_host_dropin_train.py)
+    obj = torch.zeros((pts.shape[0], n_ch, n_obj), dtype=pts.dtype if pts.dtype == torch.float64 else torch.float32,
+                      device=pts.device)
     for i, k in enumerate(counts):
         if k > 0:
             pos = torch.nonzero(mask[i]).squeeze(1)
@@ -235,12 +238,12 @@ def _mask_and_gather(pts, logits, n_obj, n_ch, model=None):
 _MEAN_SIZE_ON = {}
 
 
-def _mean_size(device):
+def _mean_size(device, dtype=torch.float32):
     """MEAN_SIZE_ARR as a device tensor, uploaded once per device (an upload inside a step would also break hipGraph
     capture of the step)"""
-    t = _MEAN_SIZE_ON.get(device)
+    t = _MEAN_SIZE_ON.get((device, dtype))
     if t is None:
-        t = _MEAN_SIZE_ON[device] = torch.tensor(arch.MEAN_SIZE, dtype=torch.float32, device=device)
+        t = _MEAN_SIZE_ON[(device, dtype)] = torch.tensor(arch.MEAN_SIZE, dtype=dtype, device=device)
     return t
 
 
@@ -248,7 +251,7 @@ def _parse(box_pred):
     B = box_pred.shape[0]
     hrn = box_pred[:, 15:27]
     srn = box_pred[:, 30:39].contiguous().view(B, 3, 3)
-    mean = _mean_size(box_pred.device)
+    mean = _mean_size(box_pred.device, box_pred.dtype)
     return (box_pred[:, 0:3], box_pred[:, 3:15], hrn, hrn * (np.pi / NUM_HEADING_BIN),
             box_pred[:, 27:30], srn, srn * mean[None])
 

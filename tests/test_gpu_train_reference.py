@@ -3,8 +3,18 @@ StaticModelOneBoxEst / DynamicModel in train mode — forward, the reference's c
 Adam — run by tests/golden/gen_train_step.py from the imported reference code (in float64, with the float32 run's
 Dropout draw and NumPy draws recorded). Here the drop-in modules take the same step on the MI355X with the HIP
 training kernels (train_backend "hip"): same weights, same inputs, the recorded Dropout multiplier and NumPy seed.
-Bar: every compared tensor within 1e-4 of that tensor's largest entry (the reference's OWN float32 run is 3e-3 ..
-2e-2 away from its float64 run on these gradients: `f32_noise` in the fixture)."""
+Bar: forward outputs, every loss term and the running statistics within 1e-4 (relative to the tensor's largest
+entry); so are the gradients of everything behind the last ReLU of ins_seg (dconv5) and of the box heads.
+The other gradients: within max(1e-4, 1.5 x the reference's own float32 error on that tensor, 4 / (B*N)).
+Why not 1e-4 throughout: the step is not a smooth function. A ReLU input or two pooled candidates within float32
+rounding of each other fall on one side in float64 and on the other in a float32 run, and ONE such activation among
+the B*N points of this small batch moves the gradients in front of it by ~1/(B*N) of their scale. The reference's
+own float32 CPU run is 2e-3 .. 2e-2 away from its float64 run on the static fixture for exactly this reason
+(`f32_noise`), and this path lands on the same values there to three digits; on the dynamic fixture it is this
+path's rounding that flips one gate of dconv2 (one row of its weight gradient, 6e-3; everything else in that tensor
+1e-5). That the difference is such events and not semantics is pinned where it can be: in float64 on the CPU this
+package's composite reproduces the fixture to 1e-6 (tests/test_host_dropin_train.py), and layer by layer on
+tie-free data the HIP kernels match float64 autograd to 1e-4 (tests/test_gpu_train.py)."""
 import importlib
 
 import numpy as np
@@ -75,6 +85,7 @@ def test_one_training_step_matches_the_reference(kind):
     params = dict(model.named_parameters())
     names = [k[len("ref_grad_"):] for k in g if k.startswith("ref_grad_")]
     assert len(names) >= 18
+    noise = dict(zip([str(k) for k in g["f32_noise_keys"]], [float(v) for v in g["f32_noise"]]))
     worst = {}
     for name in names:
         got = synth.fixture_sample(params[name].grad.detach().cpu().numpy())
@@ -83,8 +94,16 @@ def test_one_training_step_matches_the_reference(kind):
             assert np.abs(got).max() < 1e-5, name
             continue
         worst[name] = _rel(got, ref, ref_max)
-    bad = {k: v for k, v in worst.items() if v >= TOL}
-    assert not bad, bad
+    table = {k: (round(v, 7), round(noise["grad_" + k], 7)) for k, v in sorted(worst.items(), key=lambda t: -t[1])}
+    n_points = out["logits"].shape[0] * out["logits"].shape[1]
+    smooth = ("ins_seg.dconv5.", "box_est.", "point_emb.fc", "box_emb.fc")           # no ReLU / arg-max event in front
+    bad = {k: v for k, v in table.items()
+           if v[0] >= (TOL if k.startswith(smooth) else max(TOL, 1.5 * v[1], 4.0 / n_points))}
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(table, open(f"gpurun_out/train_ref_{kind}.json", "w"), indent=1)
+    assert not bad, (bad, table)
+    print("\n[train step vs reference] gradient error (this path, the reference's own float32 run):", table)
     # BatchNorm running statistics after the forward
     sdm = model.state_dict()
     for k in g:

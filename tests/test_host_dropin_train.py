@@ -6,12 +6,15 @@ import os
 import pickle
 
 import numpy as np
+import pytest
 import torch
 
 from _common import golden, synth
 
 datasets = importlib.import_module("3dal_pytorch_amd.datasets")
 losses = importlib.import_module("3dal_pytorch_amd.losses")
+sm = importlib.import_module("3dal_pytorch_amd.static_model")
+dm = importlib.import_module("3dal_pytorch_amd.dynamic_model")
 
 
 def _write_annos(tmp_path, tracks, drop=()):
@@ -110,3 +113,57 @@ def test_drivers_imports_resolve_in_the_dropin():
             "from dynamic_model import DynamicModelLoss; print('ok')" % os.path.join(root, "3dal_pytorch_amd", "dropin"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+# ------------------------------------------------------------------ the reference's training step, in float64
+@pytest.mark.parametrize("kind", ["static_one", "dynamic"])
+def test_composite_in_float64_reproduces_the_reference_training_step(kind):
+    """tests/golden/train_step_*.npz: one step of the REAL reference (forward, its criterion, backward; float64 run of
+    the imported code with the float32 run's Dropout and NumPy draws, tests/golden/gen_train_step.py). This package's
+    train-mode composite + criteria, run in float64 on the CPU with the same draws, must give the same logits, the
+    same loss terms and the same gradients to 1e-6 — the semantic pin of the training path. (What float32 arithmetic
+    adds on top — isolated ReLU gates / pooled arg-maxima that fall on the other side — is measured on the GPU in
+    tests/test_gpu_train_reference.py.)"""
+    from _common import golden
+    g = golden("train_step_" + kind)
+    if kind == "static_one":
+        B, N = 8, 256
+        pts, init, gt = synth.static_crops(B, N, seed=41)
+        labels = synth.loss_case(41, batch=B, n_pts=N)[1]
+        model, crit = sm.StaticModelOneBoxEst(), losses.FrustumPointNetLossOneBoxEst()
+    else:
+        B, N = 4, 320
+        pts, box, _, gt = synth.dynamic_items(B, n_per_frame=64, seed=42)
+        labels = synth.loss_case(42, batch=B, n_pts=N)[1]
+        model, crit = dm.DynamicModel(), losses.DynamicModelLoss()
+    sd = synth.recentre_seg_bias(synth.state_dict(kind, seed=43), float(g["margin_shift"]))
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    model = model.double().train()
+    model.train_backend, model.sampler = "torch", "numpy"
+    keep = torch.from_numpy(np.unpackbits(g["drop_keep"], axis=1).astype(np.float64)).reshape(B, N, 128).permute(0, 2, 1)
+    model.ins_seg.dropout.register_forward_hook(lambda m, i, o: i[0] * keep / (1.0 - m.p))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()          # noqa: E731
+    np.random.seed(int(g["np_seed"]))
+    if kind == "static_one":
+        out = model(t(pts).transpose(2, 1), t(init), t(gt))
+    else:
+        out = model(t(pts).transpose(2, 1), t(box).transpose(2, 1), t(gt))
+    assert np.array_equal(out["mask"].numpy(), g["mask"])
+    assert np.abs(out["logits"].detach().numpy() - g["ref_logits"]).max() < 1e-6 * np.abs(g["ref_logits"]).max()
+    ls = crit(out, *[t(a) if a.dtype == np.float32 else torch.from_numpy(a) for a in labels])
+    for k, v in ls.items():
+        assert abs(float(v.detach()) - float(g["ref_loss_" + k])) < 1e-6 * max(1.0, abs(float(g["ref_loss_" + k]))), k
+    ls["total_loss"].backward()
+    params = dict(model.named_parameters())
+    n = 0
+    for k in g:
+        if not k.startswith("ref_grad_"):
+            continue
+        name, mx = k[9:], float(g["refmax_grad_" + k[9:]])
+        got = synth.fixture_sample(params[name].grad.numpy())
+        if mx < 1e-9:
+            assert np.abs(got).max() < 1e-9, name
+            continue
+        assert np.abs(got - g[k]).max() < 1e-6 * mx, (name, np.abs(got - g[k]).max() / mx)
+        n += 1
+    assert n >= 15
