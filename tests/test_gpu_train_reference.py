@@ -100,8 +100,8 @@ def test_one_training_step_matches_the_reference(kind):
     bad = {k: v for k, v in table.items()
            if v[0] >= (TOL if k.startswith(smooth) else max(TOL, 1.5 * v[1], 4.0 / n_points))}
     import json, os
-    os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(table, open(f"gpurun_out/train_ref_{kind}.json", "w"), indent=1)
+    if os.path.isdir("gpurun_out"):                                    # on the GPU box: keep the table for DESIGN.md
+        json.dump(table, open(f"gpurun_out/train_ref_{kind}.json", "w"), indent=1)
     assert not bad, (bad, table)
     print("\n[train step vs reference] gradient error (this path, the reference's own float32 run):", table)
     # BatchNorm running statistics after the forward
@@ -112,14 +112,16 @@ def test_one_training_step_matches_the_reference(kind):
             ref = g[k]
             assert _rel(sdm[key].cpu().numpy(), ref, np.abs(ref).max()) < TOL, key
     # Adam's first step moves every weight by lr * g / (|g| + eps): sign-like, so an entry whose gradient is within
-    # rounding of zero can land on either side. Compare where the reference's gradient is clear of zero.
+    # the gradient's own error band of zero can land on either side. Compare where the reference's gradient is clear
+    # of that band.
     opt.step()
+    after = dict(model.named_parameters())
     for name in names:
         ref_g, ref_max = g["ref_grad_" + name], float(g["refmax_grad_" + name])
         if ref_max < 1e-9:
             continue
-        clear = np.abs(ref_g) > 1e-3 * ref_max
-        new = synth.fixture_sample(dict(model.named_parameters())[name].detach().cpu().numpy())
-        ref_new = g["ref_new_" + name]
-        assert clear.mean() > 0.5, name
-        assert np.abs(new - ref_new)[clear].max() < 2e-2 * float(g["lr"]) + 1e-6 * float(g["refmax_new_" + name]), name
+        band = TOL if name.startswith(smooth) else max(TOL, 1.5 * noise["grad_" + name], 4.0 / n_points)
+        clear = np.abs(ref_g) > 3 * band * ref_max
+        new = synth.fixture_sample(after[name].detach().cpu().numpy())
+        assert clear.mean() > 0.25, (name, clear.mean())
+        assert np.abs(new - g["ref_new_" + name])[clear].max() < 2e-2 * float(g["lr"]) + 1e-6 * float(g["refmax_new_" + name]), name
