@@ -96,6 +96,9 @@ SIGNATURES = {
     "dal3_tr_wgrad_workspace_bytes": (_sz, [_i64, _i, _i]),
     "dal3_tr_wgrad": (_i, [vp, _i64, vp, _i64, vp, vp, _i, _i64, _i, _i, vp, _sz, vp, vp]),
     "dal3_tr_segmax": (_i, [vp, _i64, _i64, _i, vp, vp, vp, vp, _i64, vp, _sz, vp]),
+    "dal3_tr_act_dropout": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _u64, vp, C.c_float, vp, _i64, vp]),
+    "dal3_tr_linear_pool_workspace_bytes": (_sz, [_i, _i, _i64]),
+    "dal3_tr_linear_pool": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, vp, vp, vp, _i64, _i, vp, vp, vp, _sz, vp]),
     "dal3_tr_segsum": (_i, [vp, _i64, _i64, _i, vp, _i64, vp]),
     "dal3_maxpool_n": (_i, [vp, _i64, _i64, vp, vp]),
     "dal3_shared_mlp_layer": (_i, [C.POINTER(Layer), _i, BCN, _i, _i, vp, vp, _sz, vp]),

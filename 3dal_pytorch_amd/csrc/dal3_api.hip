@@ -844,6 +844,40 @@ extern "C" int dal3_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, c
     return 0;
 }
 
+extern "C" int dal3_tr_act_dropout(const float* x, int64_t M, int C, int64_t ldx, const float* scale, const float* shift,
+                                   int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop,
+                                   float* out, int64_t ldo, dal3_stream stream) {
+    if (!x || !out || M <= 0 || C <= 0 || (C & 3) || ldx < C || ldo < C || (ldx & 3) || (ldo & 3) || (scale && !shift) ||
+        (mult && (ldm < C || (ldm & 3))) || !(p_drop >= 0.0f && p_drop <= 1.0f))
+        return fail(DAL3_EINVAL, "tr_act_dropout: bad argument (C and the row strides multiples of 4, 0 <= p <= 1)");
+    HIP_TRY(launch_tr_act_dropout(x, M, C, ldx, scale, shift, relu, mult, ldm, seed, step, p_drop, out, ldo,
+                                  static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" size_t dal3_tr_linear_pool_workspace_bytes(int c_in, int c_out, int64_t n_seg) {
+    return tr_linear_workspace_bytes(c_in, c_out) + (size_t)n_seg * c_out * 8;
+}
+
+extern "C" int dal3_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                                   int relu_in, const float* W, int64_t ldw, const float* bias, const float* out_scale,
+                                   const float* out_shift, int64_t seg, int c_out, float* g, int32_t* arg, void* workspace,
+                                   size_t workspace_bytes, dal3_stream stream) {
+    if (!a || !W || !out_scale || !out_shift || !g || !arg || !mult32(M) || !mult32(c_in) || c_out <= 0 || c_out % 128 != 0 ||
+        lda < c_in || (lda & 3) || ldw < c_in || (ldw & 3) || (scale && !shift) || (scale && c_in > 1024) || seg <= 0 ||
+        seg % 32 != 0 || M % seg != 0)
+        return fail(DAL3_EINVAL, "tr_linear_pool: bad argument (M, c_in multiples of 32; c_out of 128; seg a multiple of 32 "
+                                 "that divides M; strides multiples of 4)");
+    const size_t wbytes = tr_linear_workspace_bytes(c_in, c_out), need = wbytes + (size_t)(M / seg) * c_out * 8;
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) || (wbytes & 7))
+        return fail(DAL3_EWORKSPACE, "tr_linear_pool: workspace smaller than dal3_tr_linear_pool_workspace_bytes() or not 16-byte aligned");
+    char* base = static_cast<char*>(workspace);
+    HIP_TRY(launch_tr_linear_pool(a, M, c_in, lda, scale, shift, relu_in, W, ldw, bias, out_scale, out_shift, seg, c_out, g, arg,
+                                  reinterpret_cast<float*>(base), reinterpret_cast<unsigned long long*>(base + wbytes),
+                                  static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_tr_segsum(const float* x, int64_t ldx, int64_t seg, int C, float* out, int64_t n_seg,
                               dal3_stream stream) {
     if (!x || !out || seg <= 0 || C <= 0 || n_seg <= 0 || ldx < C) return fail(DAL3_EINVAL, "tr_segsum: bad argument");

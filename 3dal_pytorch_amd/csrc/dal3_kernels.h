@@ -226,6 +226,13 @@ size_t tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in);
 hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale,
                            const float* shift, int relu_in, int64_t M, int c_out, int c_in, float* part, float* dW,
                            hipStream_t s);
+hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                                 int relu_in, const float* W, int64_t ldw, const float* bias, const float* out_scale,
+                                 const float* out_shift, int64_t seg, int c_out, float* g, int32_t* arg, float* ws,
+                                 unsigned long long* packed, hipStream_t s);
+hipError_t launch_tr_act_dropout(const float* x, int64_t M, int C, int64_t ldx, const float* scale, const float* shift, int relu,
+                                 const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, float* out,
+                                 int64_t ldo, hipStream_t s);
 hipError_t launch_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float* scale, const float* shift,
                             float* g, int32_t* arg, int64_t n_seg, unsigned long long* packed, hipStream_t s);
 hipError_t launch_tr_segsum(const float* x, int64_t ldx, int64_t seg, int C, float* out, int64_t n_seg, hipStream_t s);

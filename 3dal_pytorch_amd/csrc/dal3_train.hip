@@ -328,6 +328,134 @@ __global__ __launch_bounds__(256, 2) void tr_linear_ring_kernel(const float* __r
     }
 }
 
+__global__ void tr_segmax_unpack_kernel(const unsigned long long* __restrict__ packed, int64_t n, float* __restrict__ g,
+                                        int32_t* __restrict__ arg);
+// ---- the pooled layer's forward without its output tensor: conv (W, b) -> BN -> ReLU -> max over the points of each
+// segment, for layers whose batch statistics are known BEFORE the layer runs (train.py obtains them from the second
+// moments of the layer's input). Same ring / ping-pong structure as tr_linear_ring_kernel, but the MFMA operands are
+// SWAPPED (D^T = act(a) . W^T: points on the accumulator's registers, channels on its lanes — the idiom of the eval
+// kernels' max-pooled layers), so the max over a tile's 32 points is a compare chain over 16 registers plus one
+// exchange between the lane halves, each carrying the point index (first maximum wins, like torch.max). The MFMA
+// computes the same k-ordered FMA chain per output element whichever operand is which, so z — and with it g and
+// arg — are bit-identical to tr_linear + tr_segmax. Candidates of different tiles / waves meet in the packed 64-bit
+// atomicMax of tr_segmax_kernel (high word: bits of y >= +0, low word: ~index). z itself (1 GB for ins_seg's conv5 at
+// 64 x 4096 points) is never written. seg must be a multiple of 32 (a tile lies in one segment).
+__global__ __launch_bounds__(256, 2) void tr_linear_pool_kernel(const float* __restrict__ a, int64_t M, int c_in, int64_t lda,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int relu_in,
+                                                                const f32x4* __restrict__ wpk, const float* __restrict__ bias,
+                                                                const float* __restrict__ out_scale,
+                                                                const float* __restrict__ out_shift, int64_t seg, int c_out,
+                                                                unsigned long long* __restrict__ packed, int n_mblk) {
+    __shared__ float s_sc[TR_MAX_ACT_CIN], s_sh[TR_MAX_ACT_CIN];
+    const bool act = scale != nullptr;
+    if (act) {
+        for (int i = threadIdx.x; i < c_in; i += 256) {
+            s_sc[i] = scale[i];
+            s_sh[i] = shift[i];
+        }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int mblk = (int)(unit % n_mblk);
+    const int64_t pt0 = (unit / n_mblk) * (32 * TR_T);
+    if (pt0 >= M) return;
+    const int mt0 = mblk * TR_MTB;
+    const int KT = c_in / 32;
+    int64_t prow[TR_T];
+#pragma unroll
+    for (int j = 0; j < TR_T; ++j) prow[j] = min(pt0 + 32 * j, M - 32) + m;
+    WRing<DAL3_PF> ring;
+    ring.init(wpk + (int64_t)mblk * KT * 16 * 64, lane);
+    f32x16 acc[TR_T][TR_MTB];
+#pragma unroll
+    for (int t = 0; t < TR_MTB; ++t) {
+        const float bv = bias ? bias[32 * (mt0 + t) + m] : 0.0f;     // this lane's CHANNEL; the same for all 16 point rows
+#pragma unroll
+        for (int j = 0; j < TR_T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][t][r] = bv;
+    }
+    TrX xa, xb;
+    tr_load_x(xa, 0, a, lda, prow, h);
+    auto block = [&](const f32x16 (&X)[TR_T]) {                     // tr_ring_block with the operands swapped
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ring_batch_wait<DAL3_PF>(ring, i);
+            const f32x4 w = ring.slot[i % DAL3_PF];
+            ring.slot[i % DAL3_PF] = ring.fetch();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int j = 0; j < TR_T; ++j) acc[j][i / 4] = mfma32(X[j][4 * (i % 4) + e], w[e], acc[j][i / 4]);
+            }
+            DAL3_SCHED_FENCE();
+        }
+    };
+    for (int kt = 0; kt < KT; kt += 2) {
+        tr_load_x(xb, min(kt + 1, KT - 1), a, lda, prow, h);
+        DAL3_SCHED_FENCE();
+        if (act) tr_act_lds(xa.X, s_sc, s_sh, kt, h, relu_in);
+        block(xa.X);
+        tr_load_x(xa, min(kt + 2, KT - 1), a, lda, prow, h);
+        DAL3_SCHED_FENCE();
+        if (kt + 1 < KT) {
+            if (act) tr_act_lds(xb.X, s_sc, s_sh, kt + 1, h, relu_in);
+            block(xb.X);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TR_MTB; ++t) {
+        const int c = 32 * (mt0 + t) + m;
+        const float sc = out_scale[c], sh = out_shift[c];
+#pragma unroll
+        for (int j = 0; j < TR_T; ++j) {
+            if (pt0 + 32 * j >= M) break;
+            const int64_t p0 = pt0 + 32 * j;                           // the tile's first point; rows (r&3) + 8 (r>>2) + 4 h
+            float bv = -1.0f;
+            int bi = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                             // increasing point index: '>' keeps the first maximum
+                const float y = fmaxf(__builtin_fmaf(acc[j][t][r], sc, sh), 0.0f);
+                if (y > bv) {
+                    bv = y;
+                    bi = (r & 3) + 8 * (r >> 2) + 4 * h;
+                }
+            }
+            const float ov = __shfl_xor(bv, 32);
+            const int oi = __shfl_xor(bi, 32);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+            if (h == 0) {
+                const int64_t s_idx = p0 / seg;
+                const uint32_t in_seg = (uint32_t)(p0 - s_idx * seg) + (uint32_t)bi;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(bv) << 32) | (0xffffffffu - in_seg);
+                atomicMax(packed + s_idx * c_out + c, key);
+            }
+        }
+    }
+}
+
+hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                                 int relu_in, const float* W, int64_t ldw, const float* bias, const float* out_scale,
+                                 const float* out_shift, int64_t seg, int c_out, float* g, int32_t* arg, float* ws,
+                                 unsigned long long* packed, hipStream_t s) {
+    const int n_mblk = c_out / 128;
+    const int64_t units = ((M + 32 * TR_T - 1) / (32 * TR_T)) * n_mblk;
+    const int64_t n = (int64_t)c_out * c_in, n_seg = M / seg;
+    hipError_t e = launch_fill_words(packed, (size_t)n_seg * c_out * 2, 0u, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, 0, c_out, c_in, ws);
+    hipLaunchKernelGGL(tr_linear_pool_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda, scale, shift,
+                       relu_in, reinterpret_cast<const f32x4*>(ws), bias, out_scale, out_shift, seg, c_out, packed, n_mblk);
+    const int64_t total = n_seg * c_out;
+    hipLaunchKernelGGL(tr_segmax_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, packed, total, g, arg);
+    return hipGetLastError();
+}
+
 size_t tr_linear_workspace_bytes(int c_in, int c_out) {
     return c_out % 128 == 0 ? (size_t)c_out * c_in * sizeof(float) + DAL3_PF * 1024 : 0;
 }
@@ -745,6 +873,64 @@ hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_
                        relu_in, M, c_out, c_in, part, n_mb, n_kb, pts);
     const int64_t n = (int64_t)c_out * c_in;
     hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, (int)n_slices, n, dW);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- activation + Dropout
+// out[p][c] = act(x[p][c]) * m[p][c],  m = mult[p][c] when given, else (keep ? 1/(1-p) : 0) with keep drawn by a
+// counter-based generator keyed on (seed + step, p*C + c): the backward pass re-creates the same multiplier from the
+// same key instead of reading a stored (M x C) mask (128 MB at 64 x 4096 points for ins_seg's Dropout), and `step`
+// is read from DEVICE memory so that a step captured into a hipGraph draws afresh on every replay (the host bumps
+// that scalar with an ordinary captured op). 16 bytes per lane, rows of C floats (C a multiple of 4).
+__device__ __forceinline__ uint32_t tr_hash32(uint64_t key, uint64_t idx) {
+    uint64_t z = key + idx * 0x9E3779B97F4A7C15ull;                     // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+__global__ __launch_bounds__(256) void tr_act_dropout_kernel(const float* __restrict__ x, int64_t M, int C, int64_t ldx,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             int relu, const float* __restrict__ mult, int64_t ldm,
+                                                             uint64_t seed, const int64_t* __restrict__ step, uint32_t thresh,
+                                                             float keep_scale, float* __restrict__ out, int64_t ldo) {
+    const int c4 = C / 4;
+    const int64_t n = M * c4, stride = (int64_t)gridDim.x * blockDim.x;
+    const uint64_t key = seed + (step ? (uint64_t)(*step) * 0xD1B54A32D192ED03ull : 0ull);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t p = i / c4;
+        const int c = (int)(i - p * c4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + p * ldx + c);
+        if (scale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        }
+        if (mult) {
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(mult + p * ldm + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= mv[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tr_hash32(key, (uint64_t)(p * C + c + e)) >= thresh ? v[e] * keep_scale : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(out + p * ldo + c) = v;
+    }
+}
+hipError_t launch_tr_act_dropout(const float* x, int64_t M, int C, int64_t ldx, const float* scale, const float* shift, int relu,
+                                 const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, float* out,
+                                 int64_t ldo, hipStream_t s) {
+    const int64_t n = M * (C / 4);
+    const int64_t want = (n + 255) / 256;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+    const double t = (double)p_drop * 4294967296.0;
+    const uint32_t thresh = p_drop <= 0.0f ? 0u : (t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t);
+    const float keep_scale = p_drop < 1.0f ? 1.0f / (1.0f - p_drop) : 0.0f;
+    hipLaunchKernelGGL(tr_act_dropout_kernel, dim3(grid), dim3(256), 0, s, x, M, C, ldx, scale, shift, relu, mult, ldm, seed, step,
+                       thresh, keep_scale, out, ldo);
     return hipGetLastError();
 }
 

@@ -138,7 +138,7 @@ def _train_forward(m, pts, box):
     logits = _seg_logits(m, pts)
     obj, mask = _mask_and_gather(pts, logits, _M, 4, m)
     emb = torch.cat([_box_pred(m, m.point_emb, obj), _box_pred(m, m.box_emb, box if box.dtype == torch.float64 else box.float())], dim=1)
-    c, hs, hrn, hr, ss, srn, sr = _parse(m.box_est(emb))
+    c, hs, hrn, hr, ss, srn, sr = _parse(_box_pred(m, m.box_est, emb))
     return {"logits": logits, "mask": mask, "center": c, "heading_scores": hs,
             "heading_residuals_normalized": hrn, "heading_residuals": hr, "size_scores": ss,
             "size_residuals_normalized": srn, "size_residuals": sr}

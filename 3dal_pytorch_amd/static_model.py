@@ -274,9 +274,19 @@ def _seg_logits(m, pts):
     return m.ins_seg(pts)
 
 
+def _tail(m, head, x):
+    """the per-item FC layers of a head: on the HIP training kernels when the batch is a multiple of 32 (rows = items),
+    else stock torch ops"""
+    if getattr(m, "train_backend", "hip") == "hip" and _train.fc_tail_supported(x):
+        return _train.fc_tail_train_forward(head, x)
+    return head.tail(x)
+
+
 def _box_pred(m, head, obj):
+    if not head.TABLE["convs"]:                        # the dynamic box estimator: FC layers only
+        return _tail(m, head, obj)
     if _hip_training(m, obj):
-        return head.tail(_train.point_stack_train_forward(head, obj))
+        return _tail(m, head, _train.point_stack_train_forward(head, obj))
     return head(obj)
 
 

@@ -84,11 +84,12 @@ class _BN:
     """batch statistics of one layer's pre-BN output and everything derived from them"""
 
     def __init__(self, z, gamma, beta, running_mean, running_var, sums=None):
-        """sums: optional float64 (2*C,) [sum z, sum z^2] obtained without a pass over z (see _moments_through)"""
-        M, C = z.shape
+        """z: the layer's pre-BN output (M,C), or just its shape (M, C) when `sums` is given.
+        sums: optional float64 (2*C,) [sum z, sum z^2] obtained without a pass over z (see _moments_through)"""
+        M, C = z if isinstance(z, tuple) else z.shape
         if sums is None:
             sums = _colred(z, 0)
-        st = torch.empty((4, C), dtype=torch.float32, device=z.device)
+        st = torch.empty((4, C), dtype=torch.float32, device=sums.device)
         self.mu, self.rstd, self.scale, self.shift = st[0], st[1], st[2], st[3]
         self.gamma = gamma.contiguous()
         _hip.check(_hip.lib().dal3_tr_bn_finalize(_hip.ptr(sums), C, M, _hip.ptr(self.gamma), _hip.ptr(beta.contiguous()),
@@ -126,6 +127,51 @@ def _segmax(z, bn, seg):
     _hip.check(_hip.lib().dal3_tr_segmax(_hip.ptr(z), z.stride(0), seg, C, _hip.ptr(bn.scale), _hip.ptr(bn.shift), _hip.ptr(g),
                                          _hip.ptr(arg), n_seg, _hip.ptr(ws), ws.numel() * 8, _hip.stream()))
     return g, arg
+
+
+def _linear_pool(a, act, W, b, bn, seg):
+    """g, arg of  max over each segment of relu(bn(act(a) @ W^T + b))  without the layer's output (dal3_tr_linear_pool)"""
+    M, c_in = a.shape
+    c_out = W.shape[0]
+    n_seg = M // seg
+    lib = _hip.lib()
+    need = lib.dal3_tr_linear_pool_workspace_bytes(c_in, c_out, n_seg)
+    ws = _ws(need, a.device)
+    g = torch.empty((n_seg, c_out), dtype=torch.float32, device=a.device)
+    arg = torch.empty((n_seg, c_out), dtype=torch.int32, device=a.device)
+    sc, sh, relu = act
+    _hip.check(lib.dal3_tr_linear_pool(_hip.ptr(a), M, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu), _hip.ptr(W),
+                                       W.stride(0), _hip.ptr(b), _hip.ptr(bn.scale), _hip.ptr(bn.shift), seg, c_out,
+                                       _hip.ptr(g), _hip.ptr(arg), _hip.ptr(ws), need, _hip.stream()))
+    return g, arg
+
+
+_DROP_STEP = {}
+
+
+def _drop_step(dev):
+    """device-resident draw counter, bumped once per training forward by an ordinary (graph-capturable) op"""
+    t = _DROP_STEP.get(dev)
+    if t is None:
+        t = _DROP_STEP[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
+    return t
+
+
+def _act_dropout(x, act, drop):
+    """act(x) * Dropout multiplier in one pass (dal3_tr_act_dropout). drop: None | a (M,C) multiplier tensor |
+    (seed, step tensor, p): multiplier re-created from the key, nothing stored"""
+    M, C = x.shape
+    out = torch.empty((M, C), dtype=torch.float32, device=x.device)
+    sc, sh, relu = act if act is not None else (None, None, False)
+    mult, seed, step, p = None, 0, None, 0.0
+    if torch.is_tensor(drop):
+        mult = drop
+    elif drop is not None:
+        seed, step, p = drop
+    _hip.check(_hip.lib().dal3_tr_act_dropout(_hip.ptr(x), M, C, x.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu),
+                                              _hip.ptr(mult), mult.stride(0) if mult is not None else 0, seed, _hip.ptr(step),
+                                              float(p), _hip.ptr(out), out.stride(0), _hip.stream()))
+    return out
 
 
 def _gather_at(z, arg, seg):
@@ -290,7 +336,8 @@ class _PointStack(torch.autograd.Function):
 
 class _InsSeg(torch.autograd.Function):
     """PointNetInstanceSeg in train mode: (B,C,N) -> logits (B,N,2). params: conv1..5 then dconv1..4 as
-    (W, b, gamma, beta) each, then dconv5 (W, b); drop: (B*N,128) multiplier (0 or 1/(1-p)) or None."""
+    (W, b, gamma, beta) each, then dconv5 (W, b); drop: None, a (B*N,128) multiplier (0 or 1/(1-p)), or the key
+    (seed, device step counter, p) of the on-device draw."""
 
     @staticmethod
     def forward(ctx, pts, drop, stats, *params):
@@ -301,22 +348,37 @@ class _InsSeg(torch.autograd.Function):
         a0 = _points_major(pts.detach())
         Ws, bns, zs = [], [], []
         a, act = a0, None
-        for k in range(5):                                              # conv1..5
+        for k in range(4):                                              # conv1..4
             W, b, gamma, beta = P[4 * k:4 * k + 4]
             W2 = W.reshape(W.shape[0], -1)
             W2 = _pad_cols(W2, 32) if k == 0 else W2.contiguous()
             z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous())
-            sums = None
-            if k == 4:                                                  # conv5: moments through its 128-channel input
-                sums, a4c, S4, m14 = _moments_through(zs[3], bns[3], W2, b)
-            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), sums=sums)
+            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)))
             Ws.append(W2)
             bns.append(bn)
             zs.append(z)
             a, act = z, bn.act
-        g, arg = _segmax(zs[4], bns[4], N)                              # (B,1024)
-        zarg = _gather_at(zs[4], arg, N)
-        zs[4] = None                                                    # 1 GB at 64 x 4096: not needed again
+        # conv5 -> bn5 -> ReLU -> max over the crop's points. Its batch statistics come from the 128 x 128 second
+        # moments of its INPUT (no pass over the 1024-channel output), so bn5's affine is known before the layer runs
+        # and the layer + pooling are ONE kernel: the (B*N, 1024) output — 1 GB at 64 x 4096 points — is never
+        # written. (N not a multiple of 32: the unfused pair, a tile must lie inside one crop.)
+        W5c, b5c, gamma5, beta5 = P[16:20]
+        W5c = W5c.reshape(W5c.shape[0], -1).contiguous()
+        b5c = b5c.contiguous()
+        sums, a4c, S4, m14 = _moments_through(zs[3], bns[3], W5c, b5c)
+        bn5 = _BN((M, W5c.shape[0]), gamma5, beta5, *(stats[4] if stats is not None else (None, None)), sums=sums)
+        if N % 32 == 0:
+            g, arg = _linear_pool(zs[3], bns[3].act, W5c, b5c, bn5, N)
+            rows = arg.long() + torch.arange(B, device=arg.device)[:, None] * N
+            zarg = torch.einsum("bck,ck->bc", a4c[rows.reshape(-1)].view(B, W5c.shape[0], -1), W5c) + b5c    # pre-BN value there
+        else:
+            z5 = _linear(zs[3], W5c, W5c.shape[1], W5c.shape[1], W5c.shape[0], act=bns[3].act, bias=b5c)
+            g, arg = _segmax(z5, bn5, N)
+            zarg = _gather_at(z5, arg, N)
+            del z5
+        Ws.append(W5c)
+        bns.append(bn5)
+        zs.append(None)
         # dconv1 on cat([out2, g.expand]): per-point part W[:, :64] out2, per-crop part W[:, 64:] g + b
         Wd1 = P[20].reshape(P[20].shape[0], -1).contiguous()            # (512, 1088)
         gb = torch.addmm(P[21], g, Wd1[:, 64:].t())                     # (B,512)
@@ -335,9 +397,7 @@ class _InsSeg(torch.autograd.Function):
             bns.append(bn)
             zs.append(z)
             a, act = z, bn.act
-        a4 = torch.relu(zs[8] * bns[8].scale + bns[8].shift)           # Dropout sits between dbn4's ReLU and dconv5
-        if drop is not None:
-            a4 = a4 * drop
+        a4 = _act_dropout(zs[8], bns[8].act, drop)                      # Dropout sits between dbn4's ReLU and dconv5
         W5 = torch.zeros((32, 128), dtype=torch.float32, device=pts.device)
         W5[:2] = P[36].reshape(2, 128)
         b5 = torch.zeros(32, dtype=torch.float32, device=pts.device)
@@ -359,7 +419,7 @@ class _InsSeg(torch.autograd.Function):
         grads[37] = dzl[:, :2].sum(0)
         da = _linear(dzl, W5, 128, 32, 128, transpose=True)
         if drop is not None:
-            da = da * drop
+            da = _act_dropout(da, None, drop)                           # the same multiplier, re-created from its key
         for k in (8, 7, 6):                                             # dconv4..2
             dz, dgam, dbet = bns[k].backward(zs[k], da=da)
             grads[4 * k] = _wgrad(dz, zs[k - 1], Ws[k].shape[0], Ws[k].shape[1], bns[k - 1].act).reshape(shapes[4 * k])
@@ -401,7 +461,92 @@ class _InsSeg(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
-def _bn_stats(mod, names):
+class _FcTail(torch.autograd.Function):
+    """The per-item tail of a head in train mode — Linear -> BatchNorm1d (batch statistics over the B items) -> ReLU,
+    n_bn times, then an optional last Linear without BN (fc3) — on the same training kernels as the per-point stacks,
+    with rows = items: (B, c_in) -> (B, c_out). B must be a multiple of 32 (the drivers' batches are; otherwise the
+    stock composite runs). params: (W, b, gamma, beta) per BN layer, then (W, b) of the last layer if there is one.
+    Reference: static_model.py:336-338, dynamic_model.py:247-248, :284-285, :306-311."""
+
+    @staticmethod
+    def forward(ctx, x, stats, n_bn, *params):
+        P = [p.detach() for p in params]
+        a, act = x.detach().contiguous(), None
+        a_in = a
+        Ws, bns, zs = [], [], []
+        for k in range(n_bn):
+            W, b, gamma, beta = P[4 * k:4 * k + 4]
+            W = W.contiguous()
+            z = _linear(a, W, W.shape[1], W.shape[1], W.shape[0], act=act, bias=b.contiguous())
+            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)))
+            Ws.append(W)
+            bns.append(bn)
+            zs.append(z)
+            a, act = z, bn.act
+        last = None
+        if len(P) > 4 * n_bn:
+            W, b = P[4 * n_bn], P[4 * n_bn + 1]
+            c_out = W.shape[0]
+            cp = (c_out + 31) // 32 * 32
+            Wp = torch.zeros((cp, W.shape[1]), dtype=torch.float32, device=W.device)
+            Wp[:c_out] = W
+            bp = torch.zeros(cp, dtype=torch.float32, device=W.device)
+            bp[:c_out] = b
+            out = _linear(a, Wp, Wp.shape[1], Wp.shape[1], cp, act=act, bias=bp)[:, :c_out]
+            last = (Wp, c_out)
+        else:
+            out = _act_dropout(a, act, None)                      # relu(bn(z)) of the last BN layer
+        ctx.saved = (a_in, Ws, bns, zs, last, n_bn, [tuple(p.shape) for p in params])
+        return out.contiguous()
+
+    @staticmethod
+    def backward(ctx, dout):
+        a_in, Ws, bns, zs, last, n_bn, shapes = ctx.saved
+        grads = [None] * len(shapes)
+        dev = dout.device
+        if last is not None:
+            Wp, c_out = last
+            dz = torch.zeros((dout.shape[0], Wp.shape[0]), dtype=torch.float32, device=dev)
+            dz[:, :c_out] = dout
+            src, act = (zs[-1], bns[-1].act) if n_bn else (a_in, None)
+            grads[4 * n_bn] = _wgrad(dz, src, Wp.shape[0], Wp.shape[1], act)[:c_out].reshape(shapes[4 * n_bn])
+            grads[4 * n_bn + 1] = dout.sum(0)
+            da = _linear(dz, Wp, Wp.shape[1], Wp.shape[0], Wp.shape[1], transpose=True)
+        else:
+            da = dout.contiguous()
+        for k in range(n_bn - 1, -1, -1):
+            dz, dgam, dbet = bns[k].backward(zs[k], da=da)
+            src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a_in, None)
+            grads[4 * k] = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act).reshape(shapes[4 * k])
+            grads[4 * k + 1] = torch.zeros(shapes[4 * k + 1], device=dev)      # a bias in front of a train-mode BN
+            grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
+            da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
+        return (da, None, None, *grads)
+
+
+def fc_tail_supported(x):
+    return x.is_cuda and x.dim() == 2 and x.shape[0] % 32 == 0 and x.shape[1] % 32 == 0
+
+
+def fc_tail_train_forward(head, x):
+    """`_PointHead.tail(x)` in train mode on the HIP training kernels (B a multiple of 32); updates the BatchNorm running
+    statistics like torch does"""
+    fcs = head.TABLE["fcs"]
+    params, bn_names = [], []
+    for name, bn, _, _ in fcs:
+        lin = getattr(head, name)
+        params += [lin.weight, lin.bias]
+        if bn:
+            b = getattr(head, bn)
+            params += [b.weight, b.bias]
+            bn_names.append(bn)
+    if any(bn is None for _, bn, _, _ in fcs[:-1]):
+        raise RuntimeError("fc tail: only the last layer may come without a BatchNorm")
+    stats = _bn_stats(head, bn_names)
+    return _FcTail.apply(x, stats, len(bn_names), *params)
+
+
+def _bn_stats(mod, names):def _bn_stats(mod, names):
     out = []
     for n in names:
         bn = getattr(mod, n)
@@ -415,14 +560,19 @@ def ins_seg_train_forward(ins_seg, pts, p_drop=0.5, drop_mask=None):
     """train-mode PointNetInstanceSeg.forward on the HIP training kernels: logits (B,N,2), autograd-connected to the
     module's parameters; updates the BatchNorm running statistics like torch does. drop_mask: optional (B*N,128)
     multiplier replacing the random Dropout draw (tests)."""
-    B, _, N = pts.shape
-    if drop_mask is None and p_drop > 0:
-        drop_mask = (torch.rand((B * N, 128), device=pts.device) >= p_drop).float() / (1.0 - p_drop)
+    drop = drop_mask
+    if drop is None and p_drop > 0:
+        # the draw happens inside dal3_tr_act_dropout, keyed on a seed taken from torch's CPU generator (so
+        # torch.manual_seed() makes runs repeatable) and a device-side step counter (so a captured step draws afresh
+        # on every hipGraph replay); the backward re-creates the multiplier from the same key
+        step = _drop_step(pts.device)
+        step.add_(1)
+        drop = (int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF, step, float(p_drop))
     params = []
     for conv, bn in ins_seg.pairs():
         params += [conv.weight, conv.bias] + ([bn.weight, bn.bias] if bn is not None else [])
     stats = _bn_stats(ins_seg, ["bn1", "bn2", "bn3", "bn4", "bn5", "dbn1", "dbn2", "dbn3", "dbn4"])
-    return _InsSeg.apply(pts, drop_mask, stats, *params)
+    return _InsSeg.apply(pts, drop, stats, *params)
 
 
 def point_stack_train_forward(head, pts):

@@ -312,6 +312,29 @@ int dal3_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, co
 int dal3_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float* scale, const float* shift, float* g,
                    int32_t* arg, int64_t n_seg, void* workspace /* n_seg*C*8 bytes, 8-byte aligned */,
                    size_t workspace_bytes, dal3_stream stream);
+/* dal3_tr_act_dropout: out = act(x) * m, one pass. act as in dal3_tr_linear (scale == NULL: identity; relu applied after the
+ * affine when relu != 0). m = mult[p][c] (row stride ldm) when mult != NULL — a caller-supplied multiplier, e.g. the
+ * reference's own draw in a parity test — else m = keep / (1 - p_drop) with keep ~ Bernoulli(1 - p_drop) drawn by a
+ * counter-based generator keyed on (seed, *step, p * C + c): forward and backward pass the same (seed, step) and get the
+ * same multiplier without storing it; step (device int64, may be NULL = 0) lets a hipGraph replay draw afresh.
+ * Replaces: self.dropout = nn.Dropout(p=0.5) applied to relu(dbn4(dconv4(x))) (static_model.py:268,292-293) and its
+ * backward. */
+int dal3_tr_act_dropout(const float* x, int64_t M, int C, int64_t ldx, const float* scale, const float* shift, int relu,
+                        const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, float* out,
+                        int64_t ldo, dal3_stream stream);
+
+/* dal3_tr_linear_pool: a layer followed by BN + ReLU + max over the points of each segment, WITHOUT materialising the
+ * layer's output: g[s][co] = max_p relu(z[p][co] * out_scale[co] + out_shift[co]), arg = index (within the segment) of
+ * the first maximum, with z = act(a) . W^T + bias as in dal3_tr_linear (forward orientation, per-channel bias).
+ * For layers whose BN affine is known before the layer runs (ins_seg's conv5, the point heads' conv4: train.py gets
+ * their batch statistics from the second moments of the layer's INPUT). Bit-identical to dal3_tr_linear followed by
+ * dal3_tr_segmax. c_out a multiple of 128, seg a multiple of 32 dividing M.
+ * Replaces: F.relu(self.bn5(self.conv5(out4))) + torch.max(out5, 2) (static_model.py:283-284, :333-334). */
+size_t dal3_tr_linear_pool_workspace_bytes(int c_in, int c_out, int64_t n_seg);
+int dal3_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift, int relu_in,
+                        const float* W, int64_t ldw, const float* bias, const float* out_scale, const float* out_shift,
+                        int64_t seg, int c_out, float* g, int32_t* arg, void* workspace, size_t workspace_bytes,
+                        dal3_stream stream);
 int dal3_tr_segsum(const float* x, int64_t ldx, int64_t seg, int C, float* out, int64_t n_seg, dal3_stream stream);
 
 /* ---- one fused shared-MLP layer, for layer-wise tests: y = relu?(W' x + b') with BN folded,

@@ -309,3 +309,99 @@ def test_train_mode_with_the_device_sampler_needs_no_host_round_trip():
     ref.sampler, ref.ins_seg.dropout.p = "numpy", 0.0
     np.random.seed(1)
     assert torch.equal(ref(*args)["mask"], runs[0][2])
+
+
+# ------------------------------------------------------------------ round 2: fused pooling, Dropout kernel, FC tails
+@pytest.mark.parametrize("B,N,c_in,c_out", [(4, 256, 128, 1024), (3, 96, 64, 128), (2, 4096, 128, 1024)])
+def test_fused_linear_pool_equals_linear_then_segmax_bitwise(B, N, c_in, c_out):
+    """dal3_tr_linear_pool (conv -> BN -> ReLU -> max over each crop's points without writing the layer's output) must
+    give the bits of dal3_tr_linear + dal3_tr_segmax: same g, same arg-max (first maximum), ties included"""
+    M = B * N
+    gen = torch.Generator(device="cuda").manual_seed(B * 1000 + N)
+    a = torch.randn((M, c_in), device="cuda", generator=gen)
+    a[: 2 * N: 2] = a[1: 2 * N: 2]                                   # exact ties between neighbouring points
+    W = torch.randn((c_out, c_in), device="cuda", generator=gen) / c_in ** 0.5
+    b = torch.randn(c_out, device="cuda", generator=gen)
+    sc_in = torch.rand(c_in, device="cuda", generator=gen) + 0.5
+    sh_in = torch.randn(c_in, device="cuda", generator=gen) * 0.3
+
+    class BN:                                                        # just the affine the kernels read
+        scale = torch.rand(c_out, device="cuda", generator=gen) - 0.3    # some negative scales too
+        shift = torch.randn(c_out, device="cuda", generator=gen) * 0.2
+    act = (sc_in, sh_in, True)
+    z = train._linear(a, W, c_in, c_in, c_out, act=act, bias=b)
+    g0, arg0 = train._segmax(z, BN, N)
+    g1, arg1 = train._linear_pool(a, act, W, b, BN, N)
+    assert torch.equal(g0, g1)
+    assert torch.equal(arg0, arg1)
+    assert int((arg0 % 2 == 0).sum()) > 0                            # (ties resolved towards the first point)
+    y = torch.relu(z * BN.scale + BN.shift).view(B, N, c_out)
+    assert torch.allclose(y.max(1).values, g1, rtol=0, atol=1e-6)
+
+
+def test_dropout_kernel_statistics_key_and_backward():
+    M, C, p = 4096, 128, 0.5
+    x = torch.randn((M, C), device="cuda")
+    sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    key = (1234567, step, p)
+    y1 = train._act_dropout(x, (sc, sh, True), key)
+    y2 = train._act_dropout(x, (sc, sh, True), key)
+    assert torch.equal(y1, y2)                                       # the multiplier is a function of the key
+    a = torch.relu(x * sc + sh)
+    kept = (y1 != 0) | (a == 0)
+    assert torch.allclose(y1[kept], a[kept] * 2.0, rtol=1e-6, atol=0)
+    frac = float(((y1 != 0) & (a != 0)).sum()) / float((a != 0).sum())
+    assert abs(frac - 0.5) < 0.01                                    # Bernoulli(1 - p) over 260k draws
+    cols = ((y1 != 0) & (a != 0)).float().mean(0) / (a != 0).float().mean(0)
+    assert float(cols.min()) > 0.4 and float(cols.max()) < 0.6       # no channel pattern
+    # the backward pass re-creates the same multiplier from the key: d/dx of (y * w).sum() through the dropout
+    w = torch.randn((M, C), device="cuda")
+    back = train._act_dropout(w, None, key)
+    mult = torch.where(kept & (a != 0), torch.full_like(a, 2.0), torch.zeros_like(a))
+    assert torch.equal(back[a != 0], (w * mult)[a != 0])
+    step.add_(1)                                                     # a new step: a new draw
+    y3 = train._act_dropout(x, (sc, sh, True), key)
+    assert not torch.equal(y3, y1)
+    agree = float(((y3 != 0) == (y1 != 0))[a != 0].float().mean())
+    assert 0.45 < agree < 0.55                                       # independent of the previous one
+    # a caller-supplied multiplier (the parity tests' path) is applied as is
+    forced = (torch.rand((M, C), device="cuda") > 0.3).float() * 1.25
+    assert torch.allclose(train._act_dropout(x, (sc, sh, True), forced), a * forced, rtol=1e-6, atol=0)
+    # p = 0 keeps everything
+    assert torch.allclose(train._act_dropout(x, (sc, sh, True), (5, None, 0.0)), a, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("kind,head_name,c_in", [("static_one", "box_est", 512), ("dynamic", "point_emb", 512),
+                                                 ("dynamic", "box_emb", 512), ("dynamic", "box_est", 384)])
+def test_fc_tail_on_hip_kernels_matches_float64_autograd(kind, head_name, c_in):
+    """the per-item Linear -> BatchNorm1d -> ReLU tails (rows = items) on the training kernels: output, input
+    gradient, every parameter gradient and the running statistics against float64 autograd of `_PointHead.tail`"""
+    B = 64
+    model = build_model(kind, synth.state_dict(kind, seed=27)).train()
+    head = getattr(model, head_name)
+    ref = copy.deepcopy(head).double()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((B, c_in), device="cuda", generator=gen).abs()           # pooled features are >= 0
+    x.requires_grad_(True)
+    xd = x.detach().double().requires_grad_(True)
+    want = ref.tail(xd)
+    w = torch.randn(want.shape, device="cuda", generator=gen)
+    (want * w.double()).sum().backward()
+    assert train.fc_tail_supported(x)
+    got = train.fc_tail_train_forward(head, x)
+    (got * w).sum().backward()
+    assert got.shape == want.shape and _close(got.detach(), want.detach())
+    assert _close(x.grad, xd.grad)
+    names = [n for n, _ in head.named_parameters() if n.startswith("fc")]
+    gmax = max(float(dict(ref.named_parameters())[n].grad.abs().max()) for n in names)
+    for n in names:
+        p, q = dict(head.named_parameters())[n], dict(ref.named_parameters())[n]
+        assert p.grad is not None and _close(p.grad, q.grad, gmax), n
+    for (n, b1), (_, b2) in zip(head.named_buffers(), ref.named_buffers()):
+        if n.startswith("fcbn") and not n.endswith("num_batches_tracked"):
+            assert _close(b1, b2), n
+        if n.startswith("fcbn") and n.endswith("num_batches_tracked"):
+            assert int(b1) == int(b2) == 1
+    # a batch that is not a multiple of 32 goes through the stock composite (model-level dispatch)
+    assert not train.fc_tail_supported(x[:40])
