@@ -546,7 +546,7 @@ def fc_tail_train_forward(head, x):
     return _FcTail.apply(x, stats, len(bn_names), *params)
 
 
-def _bn_stats(mod, names):def _bn_stats(mod, names):
+def _bn_stats(mod, names):
     out = []
     for n in names:
         bn = getattr(mod, n)
