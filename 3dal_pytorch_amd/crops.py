@@ -28,13 +28,54 @@ def transform_box(box, pose):
     return np.concatenate([center, box[..., 3:6], heading[..., np.newaxis]], axis=-1)
 
 
+class RaggedRows:
+    """The rows [start[k], start[k+1]) of one flat device tensor, for k in [k0, k1): behaves like the list of per-
+    detection arrays the reference builds (len, indexing, iteration, slicing), but a view object is made only when
+    an element is asked for. Materialising the 11,520 views of one segment eagerly (torch.tensor_split) cost 64 ms
+    of host time — ten times the three kernels that computed them."""
+
+    def __init__(self, flat, start, k0, k1):
+        self.flat, self.start, self.k0, self.k1 = flat, start, k0, k1
+
+    def __len__(self):
+        return self.k1 - self.k0
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            lo, hi, step = i.indices(len(self))
+            if step != 1:
+                return [self[j] for j in range(lo, hi, step)]
+            return RaggedRows(self.flat, self.start, self.k0 + lo, self.k0 + max(lo, hi))
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        k = self.k0 + i
+        return self.flat[int(self.start[k]):int(self.start[k + 1])]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def counts(self):
+        """rows per element, as a NumPy array (no device access)"""
+        return np.diff(self.start[self.k0:self.k1 + 1])
+
+    def numpy_list(self):
+        """what the trackData pickles hold: a Python list of NumPy arrays (one device->host copy for all of them)"""
+        lo, hi = int(self.start[self.k0]), int(self.start[self.k1])
+        host = self.flat[lo:hi].cpu().numpy()
+        cuts = (self.start[self.k0 + 1:self.k1] - lo).astype(np.int64)
+        return np.split(host, cuts) if len(self) else []
+
+
 def extract_crops(sweeps, detections, veh_to_global, device="cuda", return_index=False):
     """sweeps: list of (P_f,3) float32 arrays or CUDA tensors; detections: list of (K_f,7|9) float32 detector
     boxes; veh_to_global: list of flat-16 poses. Returns a list (one entry per frame) of dicts
       'boxes_lidar' (K_f,7) float32 NumPy — Waymo-convention boxes, vehicle frame (det_annos rows)
       'bbox'        (K_f,7) float64 NumPy — the same boxes in the global frame (trackData 'bbox')
-      'point'       list of K_f CUDA float64 tensors (k,3), global frame, in sweep order (trackData 'point')
-      'index'       (return_index) list of K_f CUDA int32 tensors: which sweep points they are
+      'point'       K_f CUDA float64 tensors (k,3), global frame, in sweep order (trackData 'point'): a RaggedRows
+                    sequence over ONE flat tensor (index / iterate / slice it like a list; .numpy_list() for pickles)
+      'index'       (return_index) likewise K_f CUDA int32 tensors: which sweep points they are
     """
     dev = torch.device(device)
     if dev.type != "cuda":
@@ -70,15 +111,12 @@ def extract_crops(sweeps, detections, veh_to_global, device="cuda", return_index
     _hip.check(lib.dal3_crop_fill(_hip.ptr(d_pts), _hip.ptr(d_poff), _hip.ptr(d_planes), _hip.ptr(d_sph), _hip.ptr(d_boff), F,
                                   K, max_pts, _hip.ptr(d_pose), _hip.ptr(counts), _hip.ptr(start), _hip.ptr(out),
                                   _hip.ptr(idx), _hip.ptr(ws), ws.numel(), _hip.stream()))
-    # one C++ split instead of a Python slice per detection (thousands of them per segment)
-    cuts = torch.from_numpy(h_start[1:-1].astype(np.int64))
-    views = torch.tensor_split(out[:total], cuts) if K > 0 else ()
-    iviews = torch.tensor_split(idx[:total], cuts) if (return_index and K > 0) else ()
     frames, k = [], 0
     for f in range(F):
-        rec = {"boxes_lidar": boxes[f], "bbox": transform_box(boxes[f], poses[f]), "point": list(views[k:k + n_box[f]])}
+        rec = {"boxes_lidar": boxes[f], "bbox": transform_box(boxes[f], poses[f]),
+               "point": RaggedRows(out, h_start, k, k + n_box[f])}
         if return_index:
-            rec["index"] = list(iviews[k:k + n_box[f]])
+            rec["index"] = RaggedRows(idx, h_start, k, k + n_box[f])
         frames.append(rec)
         k += n_box[f]
     return frames

@@ -65,33 +65,84 @@ def _dev(a, device, dtype):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(device)
 
 
+def _transform_boxes(box, pose):
+    """_transform_box for (B,7) boxes with one pose EACH, (B,4,4): vectorised, same float64 operations per box"""
+    heading = box[:, -1] + np.arctan2(pose[:, 1, 0], pose[:, 0, 0])
+    center = np.einsum("bij,bj->bi", pose[:, 0:3, 0:3], box[:, 0:3]) + pose[:, 0:3, 3]
+    return np.concatenate([center, box[:, 3:6], heading[:, None]], axis=-1)
+
+
+def _upload(arr, dev):
+    """host array -> device through a pinned staging buffer (one copy into it, one asynchronous DMA out of it)"""
+    arr = np.ascontiguousarray(arr)
+    if dev.type != "cuda" or arr.nbytes < (1 << 20):
+        return torch.from_numpy(arr).to(dev)
+    stage = torch.empty(arr.shape, dtype=torch.from_numpy(arr[:0]).dtype, pin_memory=True)
+    stage.numpy()[...] = arr
+    return stage.to(dev, non_blocking=True)
+
+
+class StaticTrackStore:
+    """Every static track of a segment resident on the device, flattened ONCE: the global-frame points of all frames
+    of all tracks in one float64 array (one concatenate over the frames, no per-track intermediate), the per-track
+    offsets into it, and each track's best-score frame with its box. `prepare_static_batch(store, poses, first=k)`
+    then prepares tracks [k, k+B) with O(B) host arithmetic and no upload (the drivers walk a segment's tracks in
+    order, static_eval.py:256-267 through the DataLoader). What the reference does per ITEM instead: stack the
+    track's frames, `np.argmax` the scores, invert the pose, move the box (static_model.py:530-544)."""
+
+    def __init__(self, tracks, device="cuda"):
+        dev = torch.device(device)
+        frames, counts = [], []
+        for tr in tracks:
+            n = 0
+            for p in tr["point"]:
+                p = np.asarray(p, np.float64).reshape(-1, 3)
+                frames.append(p)
+                n += p.shape[0]
+            counts.append(n)
+        self.tracks = tracks
+        self.offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        self.n_points = np.asarray(counts, np.int64)
+        self.best = np.array([int(np.argmax(np.stack(tr["score"]))) for tr in tracks], np.int64)
+        self.best_box = (np.stack([np.asarray(tr["bbox"][b], np.float64).reshape(7) for tr, b in zip(tracks, self.best)])
+                         if tracks else np.zeros((0, 7)))
+        flat = np.concatenate(frames) if frames else np.zeros((0, 3))
+        self.pts = _upload(flat, dev)
+        self.d_offsets = torch.from_numpy(self.offsets).to(dev)
+        self.device = dev
+
+    def __len__(self):
+        return len(self.tracks)
+
+
 def prepare_static_batch(tracks, veh_to_global, n_points=4096, sampler="numpy", seed=10922081, item_offset=0,
-                         device="cuda", gt_boxes=None):
-    """tracks: list of track dicts; veh_to_global: list of flat-16 poses of each track's BEST-score frame
+                         device="cuda", gt_boxes=None, first=0):
+    """tracks: list of track dicts, or a StaticTrackStore (then tracks [first, first + len(veh_to_global)) of it are
+    prepared and nothing is uploaded); veh_to_global: list of flat-16 poses of each track's BEST-score frame
     (annos['veh_to_global'], static_model.py:538). Returns (pts (B,3,N) fp32 view of point-major storage,
     init_box (B,7) fp32) — exactly what static_eval.py:265-266 feeds forward().
     gt_boxes: optional list of the matched annotation's float32 (9,) `box` of that frame (static_model.py:550-553);
     then a third value is returned, the labels of static_model.py:548-566 as a dict of device tensors:
     bbox_gt (B,7), mask_label (B,N) u8, center_label, heading_class_label, heading_residuals_label,
     size_class_label, size_residual_label."""
-    B = len(tracks)
-    pts_list, boxes, poses, offsets = [], [], [], [0]
-    choice = np.empty((B, n_points), np.int32) if sampler == "numpy" else None
-    for b, tr in enumerate(tracks):
-        p = np.vstack(tr["point"])
-        best = int(np.argmax(np.stack(tr["score"])))
-        pose = np.linalg.inv(np.reshape(veh_to_global[b], [4, 4]))
-        boxes.append(_transform_box(np.asarray(tr["bbox"][best], np.float64)[None, :], pose)[0])
-        poses.append(pose.reshape(16))
-        pts_list.append(p)
-        offsets.append(offsets[-1] + p.shape[0])
-        if choice is not None:
-            choice[b] = np.random.choice(p.shape[0], n_points, replace=True)     # static_model.py:546
-    dev = torch.device(device)
-    d_pts = _dev(np.vstack(pts_list), dev, np.float64)
-    d_off = _dev(np.array(offsets), dev, np.int64)
-    d_pose = _dev(np.stack(poses), dev, np.float64)
-    d_box = _dev(np.stack(boxes), dev, np.float64)
+    store = tracks if isinstance(tracks, StaticTrackStore) else StaticTrackStore(tracks, device)
+    if not isinstance(tracks, StaticTrackStore):
+        first = 0
+    B = len(veh_to_global)
+    if first < 0 or first + B > len(store):
+        raise ValueError(f"prepare_static_batch: tracks [{first}, {first + B}) are not in the store of {len(store)}")
+    dev = store.device
+    pose = np.linalg.inv(np.reshape(np.asarray(veh_to_global, np.float64), [B, 4, 4]))          # one batched inverse
+    boxes = _transform_boxes(store.best_box[first:first + B], pose)
+    choice = None
+    if sampler == "numpy":                                                      # static_model.py:546, track by track
+        choice = np.empty((B, n_points), np.int32)
+        for b in range(B):
+            choice[b] = np.random.choice(int(store.n_points[first + b]), n_points, replace=True)
+    d_pts = store.pts
+    d_off = store.d_offsets[first:first + B + 1]
+    d_pose = _dev(pose.reshape(B, 16), dev, np.float64)
+    d_box = _dev(boxes, dev, np.float64)
     d_choice = _dev(choice, dev, np.int32) if choice is not None else None
     out = torch.empty((B, n_points, 3), dtype=torch.float32, device=dev)
     init = torch.empty((B, 7), dtype=torch.float32, device=dev)

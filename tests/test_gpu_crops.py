@@ -70,7 +70,7 @@ def test_crop_extraction_vs_reference_create_pd_detection():
         assert np.array_equal(rec["boxes_lidar"], g[f"boxes_lidar{f}"])
         assert np.array_equal(rec["bbox"], g[f"bbox{f}"])
         assert [int(p.shape[0]) for p in rec["point"]] == g[f"count{f}"].tolist()
-        got = torch.cat(rec["point"]).cpu().numpy()
+        got = torch.cat(list(rec["point"])).cpu().numpy()
         assert got.dtype == np.float64 and np.abs(got - g[f"point{f}"]).max() < 1e-9
         # sweep order inside every detection, and the indices are the members
         inside = G.points_in_rbbox(sweeps[f], rec["boxes_lidar"])
@@ -142,4 +142,5 @@ def test_crop_extraction_keeps_the_reference_treatment_of_non_finite_points():
 def test_crop_extraction_without_any_detection():
     pts, box9, _, _, pose = synth.sweep(48, "none", n_points=2000, n_boxes=3)
     frames = crops.extract_crops([pts, pts[:100]], [box9[:0], box9[:0]], [pose, pose], return_index=True)
-    assert len(frames) == 2 and all(f["point"] == [] and f["index"] == [] and f["bbox"].shape == (0, 7) for f in frames)
+    assert len(frames) == 2 and all(len(f["point"]) == 0 and len(f["index"]) == 0 and list(f["point"]) == [] and
+                                    f["point"].numpy_list() == [] and f["bbox"].shape == (0, 7) for f in frames)

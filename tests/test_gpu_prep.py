@@ -173,3 +173,24 @@ def test_labels_with_device_sampler_follow_the_points(monkeypatch):
     two = prep.prepare_static_batch([tr, tr], [pose, pose], n_points=2048, sampler="device", gt_boxes=[gt9, gt9], seed=5)
     one = prep.prepare_static_batch([tr], [pose], n_points=2048, sampler="device", gt_boxes=[gt9], seed=5, item_offset=1)
     assert torch.equal(two[2]["mask_label"][1:], one[2]["mask_label"]) and torch.equal(two[0][1:], one[0])
+
+
+def test_static_track_store_batches_equal_the_one_shot_call():
+    """N1 with the host taken out of the per-batch path: the segment's tracks are flattened and uploaded once
+    (StaticTrackStore); batches [first, first+B) prepared from it equal the same tracks prepared from their dicts,
+    bit for bit, for both samplers (the NumPy sampler consumes the global stream track by track either way)."""
+    tracks = [synth.track(33, t, n_frames=5 + t % 4) for t in range(10)]
+    poses = [synth.pose_veh_to_global(33, tr["token"][int(np.argmax(tr["score"]))]) for tr in tracks]
+    store = prep.StaticTrackStore(tracks)
+    assert len(store) == 10 and store.pts.shape[0] == sum(sum(len(p) for p in tr["point"]) for tr in tracks)
+    whole_p, whole_i = prep.prepare_static_batch(tracks, poses, n_points=512, sampler="device", seed=9)
+    parts = [prep.prepare_static_batch(store, poses[k:k + 4], n_points=512, sampler="device", seed=9, first=k, item_offset=k)
+             for k in range(0, 10, 4)]
+    assert torch.equal(torch.cat([p for p, _ in parts]), whole_p) and torch.equal(torch.cat([i for _, i in parts]), whole_i)
+    np.random.seed(5)
+    a_p, a_i = prep.prepare_static_batch(tracks[3:7], poses[3:7], n_points=300, sampler="numpy")
+    np.random.seed(5)
+    b_p, b_i = prep.prepare_static_batch(store, poses[3:7], n_points=300, sampler="numpy", first=3)
+    assert torch.equal(a_p, b_p) and torch.equal(a_i, b_i)
+    with pytest.raises(ValueError):
+        prep.prepare_static_batch(store, poses[:4], first=8)

@@ -50,7 +50,7 @@ def main():
     frames = crops.extract_crops(sweeps, dets, poses, return_index=True)
     torch.cuda.synchronize()
     t_call = time.perf_counter() - t0
-    members = sum(int(p.shape[0]) for fr in frames for p in fr["point"])
+    members = int(sum(fr["point"].counts().sum() for fr in frames))
 
     # device part alone, through the C ABI
     F, K = args.frames, args.frames * args.boxes

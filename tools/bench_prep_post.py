@@ -40,6 +40,23 @@ def main():
         dt = time.perf_counter() - t0
         out[f"prepare_static_batch[{sampler}]"] = {"tracks": B, "points_out": B * 4096, "call_ms": round(dt * 1e3, 1),
                                                    "crops_per_s": round(B / dt, 1)}
+    # the segment's tracks flattened and uploaded once (StaticTrackStore), then prepared in the drivers' batches of 64
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    store = prep.StaticTrackStore(tracks)
+    torch.cuda.synchronize()
+    t_store = time.perf_counter() - t0
+    prep.prepare_static_batch(store, poses[:64], n_points=4096, sampler="device", first=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(0, B, 64):
+        prep.prepare_static_batch(store, poses[k:k + 64], n_points=4096, sampler="device", first=k, item_offset=k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["prepare_static_batch[device, StaticTrackStore, batches of 64]"] = {
+        "tracks": B, "store_build_ms": round(t_store * 1e3, 1), "all_batches_ms": round(dt * 1e3, 2),
+        "ms_per_batch_of_64": round(dt * 1e3 / max(B // 64, 1), 3), "crops_per_s_excluding_the_build": round(B / dt, 1),
+        "crops_per_s_including_the_build": round(B / (dt + t_store), 1)}
     items = [(i % 64, j) for i in range(64) for j in range(len(base[i]["token"]))][:B]
     dposes = [synth.pose_veh_to_global(80, base[t]["token"][j]) for t, j in items]
     prep.prepare_dynamic_batch(base, items[:4], dposes[:4], sampler="device")
