@@ -56,6 +56,7 @@ static InsSegW ins_seg_walk(Cursor& c) {
     w.db5 = c.take(32);
     w.enc_stream = c.take4((size_t)ENC_FRAGS * 256);
     w.dec_stream = c.take4((size_t)DEC_FRAGS * 256);
+    w.lat_stream = c.take4((size_t)LAT_FRAGS * 256);
     return w;
 }
 
@@ -313,6 +314,9 @@ extern "C" int dal3_pack_weights(int head_kind, const dal3_layer* L, int n_layer
                       16 * 256, 56 * 256, 40 * 256));
         TRY(pack_frag(L[7], PACK_FRAG_MT_MAJOR, 0, 256, w.dec_stream, DEC_W3, w.db3, s));
         TRY(pack_frag(L[8], PACK_FRAG_MT_MAJOR, 0, 128, w.dec_stream, DEC_W4, w.db4, s));
+        // the same dconv1a / dconv2 out-tile major, for the latency kernels
+        TRY(pack_frag(L[5], PACK_FRAG_MT_MAJOR, 0, 64, w.lat_stream, LAT_W1A, nullptr, s));
+        TRY(pack_frag(L[6], PACK_FRAG_MT_MAJOR, 0, 512, w.lat_stream, LAT_W2, nullptr, s));
         HIP_TRY(launch_pack_weight(L[9], PACK_ROWMAJOR, 0, 128, 0, 0, mut(w.dw5), s));
         HIP_TRY(launch_pack_bias(L[9], mut(w.db5), s));
         return 0;

@@ -54,11 +54,13 @@ struct InsSegW {
     const float* db5;         // 2
     const f32x4* enc_stream;
     const f32x4* dec_stream;
-};
+    const f32x4* lat_stream;  // dconv1a (16 out-tiles x 2 k-tiles) | dconv2 (8 x 16), OUT-TILE major: the latency kernels
+};                            // (dal3_latency.hip) give each wave whole output tiles; dec_stream interleaves them K-major
 enum {                        // stream geometry in fragments of 256 floats
     ENC_W2 = 0, ENC_W3 = 16, ENC_W4 = 32, ENC_W5 = 64, ENC_FRAGS = 64 + 512,
     DEC_W2 = 0, DEC_MIX = 16, DEC_MIX_FRAGS = 8 + 16 * 40, DEC_W3 = 16 + 648, DEC_W4 = 16 + 648 + 128,
-    DEC_FRAGS = 16 + 648 + 128 + 64
+    DEC_FRAGS = 16 + 648 + 128 + 64,
+    LAT_W1A = 0, LAT_W2 = 128, LAT_FRAGS = 128 + 512
 };
 
 struct FcW {
@@ -230,6 +232,13 @@ hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t ld
                                  int relu_in, const float* W, int64_t ldw, const float* bias, const float* out_scale,
                                  const float* out_shift, int64_t seg, int c_out, float* g, int32_t* arg, float* ws,
                                  unsigned long long* packed, hipStream_t s);
+// small jobs: one 16-wave workgroup per 32-point tile, activations through LDS (dal3_latency.hip); bit-identical results
+hipError_t launch_ins_seg_encode_lat(const InsSegW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s);
+hipError_t launch_ins_seg_decode_lat(const InsSegW& w, BCN pts, int c_in, int B, int N, const float* gbias, float* logits,
+                                     uint8_t* mask, hipStream_t s);
+hipError_t launch_point_head_lat(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat,
+                                 const int32_t* distinct, hipStream_t s);
+bool lat_use(int64_t tiles);    // the dispatch rule (dal3_pointmlp.hip)
 hipError_t launch_tr_act_dropout(const float* x, int64_t M, int C, int64_t ldx, const float* scale, const float* shift, int relu,
                                  const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, float* out,
                                  int64_t ldo, hipStream_t s);

@@ -12,6 +12,8 @@
 // One wave owns T tiles of 32 points; waves never talk to each other (no LDS, no barrier): the
 // cross-wave max is an atomic on g / feat. Weights stream from L2 as 1-KiB coalesced dwordx4
 // fragments shared by all waves of the chip.
+#include <stdlib.h>
+
 #include "dal3_device.h"
 #include "dal3_kernels.h"
 
@@ -303,7 +305,20 @@ static inline int tiles_per_item(int n_pts, int T) {
     return (n_pts + 32 * DAL3_WG_WAVES * T - 1) / (32 * DAL3_WG_WAVES * T);
 }
 
+// Which family runs: the latency kernels (dal3_latency.hip: a 16-wave workgroup per tile, one per CU) while the job has
+// at most DAL3_LAT_MAX_TILES tiles (default 512 = two rounds of workgroups on the 256 CUs), the throughput kernels
+// above that. Both give the same bits. DAL3_LAT_MAX_TILES=0 turns the latency family off (A/B measurements).
+bool lat_use(int64_t tiles) {
+    static int64_t limit = -1;
+    if (limit < 0) {
+        const char* e = getenv("DAL3_LAT_MAX_TILES");
+        limit = e ? atoll(e) : 512;
+    }
+    return tiles <= limit;
+}
+
 hipError_t launch_ins_seg_encode(const InsSegW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
+    if (lat_use((int64_t)B * ((N + 31) / 32))) return launch_ins_seg_encode_lat(w, pts, c_in, B, N, g, s);
     constexpr int T = DAL3_ENC_T;
     // A wave runs its T tiles through the whole encoder one after the other (~150 us per tile at 2.4 GHz). When the
     // job cannot fill the chip's 1024 SIMDs anyway (small eval batches), one tile per wave halves that serial
@@ -320,6 +335,7 @@ hipError_t launch_ins_seg_encode(const InsSegW& w, BCN pts, int c_in, int B, int
 
 hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int N, const float* gbias,
                                  float* logits, uint8_t* mask, hipStream_t s) {
+    if (lat_use((int64_t)B * ((N + 31) / 32))) return launch_ins_seg_decode_lat(w, pts, c_in, B, N, gbias, logits, mask, s);
     constexpr int T = DAL3_DEC_T;
     const int tpi = tiles_per_item(N, T);
     hipLaunchKernelGGL(ins_seg_decode_kernel<T>, dim3((unsigned)((int64_t)B * tpi)), dim3(64 * DAL3_WG_WAVES), 0, s, w, pts, c_in, N, tpi,
@@ -329,6 +345,7 @@ hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int
 
 hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat,
                              const int32_t* distinct, hipStream_t s) {
+    if (lat_use((int64_t)B * ((M + 31) / 32))) return launch_point_head_lat(head_kind, w, x, c_in, B, M, feat, distinct, s);
     constexpr int T = DAL3_HEAD_T;
     const int tpi = (M + 32 * T - 1) / (32 * T);       // one-wave workgroups
     const dim3 grid((unsigned)((int64_t)B * tpi)), block(64);

@@ -1,0 +1,82 @@
+"""The latency kernels (csrc/dal3_latency.hip: small jobs, one 16-wave workgroup per 32-point tile, activations
+through LDS) against the throughput kernels (one wave per tile, activations in registers): the dispatch between the
+two families must be invisible — bit-identical logits, masks, counts, drawn indices, box parameters and refined boxes.
+The throughput family's outputs are computed in a child process with DAL3_LAT_MAX_TILES=0 (the dispatch rule is read
+once per process); both are pinned to the oracle elsewhere (tests/test_gpu_parity.py runs the small fixtures through
+the latency family now, the large ones through the throughput family)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from _common import ROOT, build_model, synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("static_one", 1, 1024), ("static_one", 3, 700), ("static_two", 2, 33), ("static_one", 16, 1024),
+         ("dynamic", 2, 0), ("static_one", 5, 4096)]
+
+
+def _run(kind, B, N):
+    """every output of one forward + decode, as NumPy arrays"""
+    model = build_model(kind, synth.state_dict(kind, seed=51))
+    if kind == "dynamic":
+        p, bx, i8, _ = synth.dynamic_items(B, n_per_frame=256, seed=52)
+        o = model._run(torch.from_numpy(p).cuda().transpose(2, 1), torch.from_numpy(bx).cuda().transpose(2, 1),
+                       init_box8=torch.from_numpy(i8).cuda())
+    else:
+        p, i, g = synth.static_crops(B, N, seed=52)
+        p[0, : max(N // 3, 1)] *= 0.85                       # a crop with few segmented points (tiles of copies are skipped)
+        o = model._run(torch.from_numpy(p).cuda().transpose(2, 1), torch.from_numpy(i).cuda(), torch.from_numpy(g).cuda())
+    return {k: v.cpu().numpy() for k, v in o.items() if torch.is_tensor(v)}
+
+
+CHILD = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import test_gpu_latency as T
+out = {}
+for kind, B, N in T.CASES:
+    for k, v in T._run(kind, B, N).items():
+        out[f"{kind}_{B}_{N}_{k}"] = v
+np.savez(%(path)r, **out)
+"""
+
+
+def test_latency_family_equals_throughput_family_bitwise(tmp_path):
+    path = str(tmp_path / "throughput.npz")
+    env = dict(os.environ, DAL3_LAT_MAX_TILES="0")
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "path": path}], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    want = np.load(path)
+    assert os.environ.get("DAL3_LAT_MAX_TILES") is None, "this process must run the default dispatch"
+    n = 0
+    for kind, B, N in CASES:
+        got = _run(kind, B, N)
+        for k, v in got.items():
+            w = want[f"{kind}_{B}_{N}_{k}"]
+            assert v.shape == w.shape and v.dtype == w.dtype, (kind, B, N, k)
+            assert np.array_equal(v, w, equal_nan=True), (kind, B, N, k, float(np.abs(v.astype(np.float64) - w).max()))
+            n += 1
+    assert n >= 50
+
+
+def test_small_job_latency_is_below_the_single_wave_chain():
+    """B = 1 crop of 1024 points: the stream time of one refine() (HIP events over 100 calls) with the latency family;
+    the single-wave chains alone took 258 us (encode 72 + decode 102 + point head 84 at 2.4 GHz)"""
+    model = build_model("static_one", synth.state_dict("static_one", seed=51))
+    p, i, g = (torch.from_numpy(a).cuda() for a in synth.static_crops(1, 1024, seed=52))
+    for _ in range(10):
+        model.refine(p.transpose(2, 1), i, g)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(100):
+        model.refine(p.transpose(2, 1), i, g)
+    b.record()
+    b.synchronize()
+    us = a.elapsed_time(b) * 10.0
+    assert us < 260.0, us

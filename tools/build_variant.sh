@@ -11,6 +11,7 @@ for f in dal3_api dal3_misc dal3_prep dal3_crops dal3_train; do
 done
 CC="$CC $NONAN"
 $CC $2 -c 3dal_pytorch_amd/csrc/dal3_pointmlp.hip -o variants/obj_$1/dal3_pointmlp.o &
+$CC $2 -c 3dal_pytorch_amd/csrc/dal3_latency.hip -o variants/obj_$1/dal3_latency.o &
 $CC $2 -DLP_PART=1 -mllvm -amdgpu-mfma-vgpr-form -c 3dal_pytorch_amd/csrc/dal3_pointmlp_lp.hip -o variants/obj_$1/lp_enc.o &
 $CC $2 -DLP_PART=2 -c 3dal_pytorch_amd/csrc/dal3_pointmlp_lp.hip -o variants/obj_$1/lp_dec.o &
 wait
