@@ -956,7 +956,8 @@ extern "C" int dal3_static_forward(const dal3_static_args* a, int phases, dal3_s
 
     if (phases & DAL3_PHASE_SEG) {
         TRY(ins_seg_run(a->w_ins_seg, a->dtype, 3, a->pts, B, N, a->logits, a->mask, nullptr, ws.seg, s));
-        if (a->counts) HIP_TRY(launch_segment_counts(a->mask, B, N, a->counts, s));
+        // (when the box phase follows in this call, its compaction kernel writes the same counts)
+        if (a->counts && !(phases & DAL3_PHASE_BOX)) HIP_TRY(launch_segment_counts(a->mask, B, N, a->counts, s));
     }
     if (!(phases & DAL3_PHASE_BOX)) return 0;
 
@@ -1019,7 +1020,8 @@ extern "C" int dal3_dynamic_forward(const dal3_dynamic_args* a, int phases, dal3
 
     if (phases & DAL3_PHASE_SEG) {
         TRY(ins_seg_run(a->w_ins_seg, a->dtype, 4, a->pts, B, N, a->logits, a->mask, nullptr, ws.seg, s));
-        if (a->counts) HIP_TRY(launch_segment_counts(a->mask, B, N, a->counts, s));
+        // (when the box phase follows in this call, its compaction kernel writes the same counts)
+        if (a->counts && !(phases & DAL3_PHASE_BOX)) HIP_TRY(launch_segment_counts(a->mask, B, N, a->counts, s));
     }
     if (!(phases & DAL3_PHASE_BOX)) return 0;
 
