@@ -124,6 +124,9 @@ __global__ __launch_bounds__(256, DAL3_LP_ENC_SLOTS == 2 ? 2 : 1) void ins_seg_e
   }
 }
 
+#ifndef DAL3_LP_SPREAD
+#define DAL3_LP_SPREAD 1                                 // main-loop placement of refill pieces and packing: see the kernel
+#endif
 #define LP_DEC_SMALL_BYTES 7168                          // (864 + 512 + 64 + 256) floats, rounded up to 1 KiB
 // ------------------------------------------------------------------------------------------------
 // Persistent: 256 workgroups (one per CU: the ring takes 120 of the 160 KiB of LDS) each walk the 256-point groups
@@ -316,6 +319,102 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     load4(q, 0);
     load4(ga, 4);
     LP_STAMP(1);
+#if DAL3_LP_SPREAD
+    // Segment 1+i: 1a(2i+1) | 2(2i) | 1a(2i+2) | 2(2i+1), as above. What differs from the schedule kept below
+    // (DAL3_LP_SPREAD=0) is WHERE the non-MFMA work sits. tools/ubench/lp_loop.hip prices it: four VALU in one MFMA
+    // gap stretch that gap by ~13 cycles, two by ~2.5; ten LDS-DMA pieces dealt out one per gap in consecutive gaps
+    // (plus the counted wait and barrier behind them) cost ~330 cycles per 80 MFMAs, one piece every eighth gap ~110.
+    // So: the ring refill that the barrier at the end of iteration i-1 made room for is issued one piece after every
+    // eighth MFMA of iteration i (it has until the barrier at the end of iteration i+1 to land: the ring's third slot
+    // gives that distance for free), and a chunk's 16-bit packing takes ONE register pair per gap over the sixteen
+    // gaps of the two MFMA groups in front of its consumer instead of two pairs in each of eight gaps. Same
+    // instructions, same operands, same results.
+    constexpr int ML = LdsRing<SEG>::MY_LOADS;
+    static_assert(ML == 10, "ten refill points per iteration below");
+    auto mma4_gap = [&](const frag_t (&a)[4], const ActTile<DT> (&p)[T], int mt0, auto&& gap) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                a2[j][mt0 + (i >> 1)] = DT::mfma(a[i], p[j].k[i & 1], a2[j][mt0 + (i >> 1)]);
+                DAL3_SCHED_FENCE();
+                gap(2 * i + j);
+                DAL3_SCHED_FENCE();
+            }
+        }
+    };
+    auto pack_pair = [&](int4_t (&w)[T][2], const f32x16 (&t)[T], int k) {   // register pair k of the 16 (T x 2 x 4) of a chunk
+        const int tj = k >> 3, ts = (k >> 2) & 1, ti = k & 3;
+        w[tj][ts][ti] = pack_relu_pair<DT>(t[tj][8 * ts + 2 * ti], t[tj][8 * ts + 2 * ti + 1]);
+    };
+    auto packed_into = [&](ActTile<DT> (&pn)[T], const int4_t (&w)[T][2]) {
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            pn[j].k[0] = __builtin_bit_cast(frag_t, w[j][0]);
+            pn[j].k[1] = __builtin_bit_cast(frag_t, w[j][1]);
+        }
+    };
+    for (int i = 0; i < 8; ++i) {
+        const bool refill = i > 0;                         // (iteration 0's slot was refilled by the acquire() above)
+        auto part = [&](int k) {
+            if (refill) ring.issue_part(k);
+        };
+        DAL3_SCHED_FENCE();
+        dconv1_chunk(tB, q);                               // chunk 2i+1
+        load4(gb, 8);
+        part(0);
+        DAL3_SCHED_FENCE();
+        mma4_gap(ga, pA, 0, [&](int g) { if (g == 7) part(1); });
+        DAL3_SCHED_FENCE();
+        load4(ga, 12);
+        DAL3_SCHED_FENCE();
+        mma4_gap(gb, pA, 2, [&](int g) { if (g == 7) part(2); });
+        DAL3_SCHED_FENCE();
+        load4(gb, 16);
+        DAL3_SCHED_FENCE();
+        int4_t wB[T][2];
+        mma4_gap(ga, pA, 4, [&](int g) { pack_pair(wB, tB, g); if (g == 7) part(3); });
+        DAL3_SCHED_FENCE();
+        load4(q, 20);
+        load4(ga, 24);
+        DAL3_SCHED_FENCE();
+        mma4_gap(gb, pA, 6, [&](int g) { pack_pair(wB, tB, 8 + g); if (g == 7) part(4); });
+        packed_into(pB, wB);
+        init_chunk(tB, 2 * i + 3);
+        DAL3_SCHED_FENCE();
+        dconv1_chunk(tA, q);                               // chunk 2i+2 (16 = zero filler weights, result unused)
+        load4(gb, 28);
+        part(5);
+        DAL3_SCHED_FENCE();
+        mma4_gap(ga, pB, 0, [&](int g) { if (g == 7) part(6); });
+        DAL3_SCHED_FENCE();
+        load4(ga, 32);
+        DAL3_SCHED_FENCE();
+        int4_t wA[T][2];
+        mma4_gap(gb, pB, 2, [&](int g) { pack_pair(wA, tA, g); if (g == 7) part(7); });
+        DAL3_SCHED_FENCE();
+        load4(gb, 36);
+        DAL3_SCHED_FENCE();
+        mma4_gap(ga, pB, 4, [&](int g) { pack_pair(wA, tA, 8 + g); if (g == 3) part(8); if (g == 7) part(9); });
+        packed_into(pA, wA);
+        init_chunk(tA, 2 * i + 4);
+        if (refill) ring.issue_done();
+        DAL3_SCHED_FENCE();
+        ring.acquire_wait();                               // segment 2+i (after the loop: dconv3's first)
+        mma4_gap(gb, pB, 6, [&](int g) {                   // (the slot's refill: dealt out over the next iteration)
+            if (g == 0) {
+                load4(q, 0);
+                load4(ga, 4);
+            }
+        });
+        DAL3_SCHED_FENCE();
+    }
+    // the refill the loop's last barrier made room for has no next iteration to ride on: in one piece, once per group
+#pragma unroll
+    for (int k = 0; k < ML; ++k) ring.issue_part(k);
+    ring.issue_done();
+    DAL3_SCHED_FENCE();
+#else
     // Segment 1+i: 1a(2i+1) | 2(2i) | 1a(2i+2) | 2(2i+1). At the top of an iteration the segment's first eight
     // fragments are already in registers: the barrier that opens the NEXT segment is taken as soon as the current
     // one's last fragments have been read, its refill and the next segment's first reads go under the last eight MFMAs.
@@ -360,6 +459,7 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         mma4_refill(gb, pB, 6, q, ga);
         DAL3_SCHED_FENCE();
     }
+#endif
     LP_STAMP(2);
     {
         const int nx = grp + (int)gridDim.x;
