@@ -71,6 +71,7 @@ SIGNATURES = {
     "dal3_gather_workspace_bytes": (_sz, [_i, _i]),
     "dal3_segment_counts": (_i, [vp, _i, _i, vp, vp]),
     "dal3_mask_compact_sample": (_i, [vp, BCN, _i, _i, _i, _i, _i, vp, _u64, _i64, vp, vp, vp, vp, _sz, vp]),
+    "dal3_mask_compact_sample_step": (_i, [vp, BCN, _i, _i, _i, _i, _u64, vp, _i64, vp, vp, vp, vp, _sz, vp]),
     "dal3_point_head_workspace_bytes": (_sz, [_i]),
     "dal3_point_head_forward": (_i, [_i, vp, _i, BCN, _i, _i, vp, _i64, vp, _sz, vp]),
     "dal3_point_head_pool": (_i, [_i, vp, _i, BCN, _i, _i, vp, vp, vp]),

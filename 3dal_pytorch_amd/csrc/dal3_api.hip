@@ -492,14 +492,14 @@ extern "C" int dal3_segment_counts(const uint8_t* mask, int B, int N, int32_t* c
 
 static int gather_run(const uint8_t* mask, const dal3_bcn& pts, int B, int N, int C, int M, int sampler,
                       const int32_t* choice, uint64_t seed, int64_t item_offset, int32_t* counts, int32_t* obj_idx,
-                      float* obj_pts, int32_t* pos, hipStream_t s) {
+                      float* obj_pts, int32_t* pos, hipStream_t s, const int64_t* step = nullptr) {
     if (!mask || !counts || !obj_idx || !obj_pts) return fail(DAL3_EINVAL, "gather: null pointer");
     if (B <= 0 || N <= 0 || M <= 0 || C <= 0 || C > 8) return fail(DAL3_EINVAL, "gather: bad shape");
     if (sampler == DAL3_SAMPLER_CHOICE && !choice) return fail(DAL3_EINVAL, "gather: DAL3_SAMPLER_CHOICE needs choice");
     if (sampler != DAL3_SAMPLER_CHOICE && sampler != DAL3_SAMPLER_DEVICE) return fail(DAL3_EINVAL, "gather: bad sampler");
     TRY(check_bcn(pts, "pts"));
     HIP_TRY(launch_compact_sample(mask, to_bcn(pts), B, N, C, M, sampler, choice, seed, item_offset, counts, pos,
-                                  obj_idx, obj_pts, s));
+                                  obj_idx, obj_pts, s, step));
     return 0;
 }
 
@@ -513,6 +513,17 @@ extern "C" int dal3_mask_compact_sample(const uint8_t* mask, dal3_bcn pts, int B
     if (!c.ok) return fail(DAL3_EWORKSPACE, "gather: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
     return gather_run(mask, pts, B, N, C, M, sampler, choice, seed, item_offset, counts, obj_idx, obj_pts, pos,
                       static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dal3_mask_compact_sample_step(const uint8_t* mask, dal3_bcn pts, int B, int N, int C, int M, uint64_t seed,
+                                             const int64_t* step, int64_t item_offset, int32_t* counts, int32_t* obj_idx,
+                                             float* obj_pts, void* workspace, size_t workspace_bytes, dal3_stream stream) {
+    if (!workspace) return fail(DAL3_EINVAL, "gather: workspace is NULL");
+    Carver c(workspace, workspace_bytes);
+    int32_t* pos = c.take<int32_t>((size_t)B * N);
+    if (!c.ok) return fail(DAL3_EWORKSPACE, "gather: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
+    return gather_run(mask, pts, B, N, C, M, DAL3_SAMPLER_DEVICE, nullptr, seed, item_offset, counts, obj_idx, obj_pts, pos,
+                      static_cast<hipStream_t>(stream), step);
 }
 
 // ---------------------------------------------------------------------------------- point heads

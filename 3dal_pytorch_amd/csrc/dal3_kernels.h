@@ -198,7 +198,7 @@ hipError_t launch_segment_counts(const uint8_t* mask, int B, int N, int32_t* cou
 hipError_t launch_fill_words(void* p, size_t n_words, uint32_t value, hipStream_t s);
 hipError_t launch_compact_sample(const uint8_t* mask, BCN pts, int B, int N, int C, int M, int sampler,
                                  const int32_t* choice, uint64_t seed, int64_t item_offset, int32_t* counts,
-                                 int32_t* pos, int32_t* obj_idx, float* obj_pts, hipStream_t s);
+                                 int32_t* pos, int32_t* obj_idx, float* obj_pts, hipStream_t s, const int64_t* step = nullptr);
 hipError_t launch_decode_boxes(float* box_pred, int B, const float* center_add, int64_t center_add_stride,
                                int center_inplace, const float* boxes_center_add, int64_t boxes_center_add_stride,
                                const float* yaw_base, int64_t yaw_stride, float* heading_residuals,

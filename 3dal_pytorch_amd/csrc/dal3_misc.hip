@@ -301,9 +301,12 @@ __global__ __launch_bounds__(256) void segment_counts_kernel(const uint8_t* __re
 //  3. gather obj_pts[b,k,:C] = pts[b,:C,idx[k]]
 __global__ __launch_bounds__(256) void compact_sample_kernel(const uint8_t* __restrict__ mask, BCN pts, int N, int C,
                                                              int M, int sampler, const int32_t* __restrict__ choice,
-                                                             uint64_t seed, int64_t item_offset,
+                                                             uint64_t seed, int64_t item_offset, const int64_t* __restrict__ step,
                                                              int32_t* __restrict__ counts, int32_t* __restrict__ pos,
                                                              int32_t* __restrict__ obj_idx, float* __restrict__ obj_pts) {
+    // `step` (device, optional): a draw counter kept in device memory, so that a training step captured into a hipGraph
+    // draws fresh object points on every replay (a kernel ARGUMENT would be frozen in the graph)
+    if (step) seed += (uint64_t)(*step) * 0xD6E8FEB86659FD93ull;
     __shared__ int lds_wave[8];
     __shared__ int lds_hist[256];
     const int64_t b = blockIdx.x;
@@ -437,9 +440,9 @@ hipError_t launch_segment_counts(const uint8_t* mask, int B, int N, int32_t* cou
 
 hipError_t launch_compact_sample(const uint8_t* mask, BCN pts, int B, int N, int C, int M, int sampler,
                                  const int32_t* choice, uint64_t seed, int64_t item_offset, int32_t* counts,
-                                 int32_t* pos, int32_t* obj_idx, float* obj_pts, hipStream_t s) {
+                                 int32_t* pos, int32_t* obj_idx, float* obj_pts, hipStream_t s, const int64_t* step) {
     hipLaunchKernelGGL(compact_sample_kernel, dim3(B), dim3(256), 0, s, mask, pts, N, C, M, sampler, choice, seed,
-                       item_offset, counts, pos, obj_idx, obj_pts);
+                       item_offset, step, counts, pos, obj_idx, obj_pts);
     return hipGetLastError();
 }
 

@@ -212,14 +212,15 @@ def _mask_and_gather(pts, logits, n_obj, n_ch, model=None):
         obj = torch.empty((B, n_obj, n_ch), dtype=torch.float32, device=pts.device)
         need = lib.dal3_gather_workspace_bytes(B, N)
         ws = torch.empty(max(int(need), 8), dtype=torch.uint8, device=pts.device)
-        # a fresh draw per training step, as the reference's np.random gives: the key advances with a per-model counter
+        # a fresh draw per training step, as the reference's np.random gives: the key carries a draw counter that
+        # lives in DEVICE memory and is bumped by an ordinary op — captured into a hipGraph (graph.CapturedTrainStep)
+        # it still advances on every replay, where a host-computed seed would be frozen into the kernel's arguments
         # (eval keeps the fixed key so that shards of a job reproduce the whole job)
-        step = getattr(model, "_train_draws", 0)
-        model._train_draws = step + 1
-        seed = (model.seed + 0x9E3779B97F4A7C15 * (step + 1)) & 0xFFFFFFFFFFFFFFFF
-        _hip.check(lib.dal3_mask_compact_sample(_hip.ptr(m8), _hip.bcn(p32), B, N, n_ch, n_obj, _hip.SAMPLER_DEVICE, None,
-                                                seed, model.item_offset, _hip.ptr(counts), _hip.ptr(idx),
-                                                _hip.ptr(obj), _hip.ptr(ws), ws.numel(), _hip.stream()))
+        step = _train.draw_step(model, pts.device)
+        step.add_(1)
+        _hip.check(lib.dal3_mask_compact_sample_step(_hip.ptr(m8), _hip.bcn(p32), B, N, n_ch, n_obj, model.seed, _hip.ptr(step),
+                                                     model.item_offset, _hip.ptr(counts), _hip.ptr(idx), _hip.ptr(obj),
+                                                     _hip.ptr(ws), ws.numel(), _hip.stream()))
         return obj.transpose(2, 1), mask
     counts = mask.sum(1).cpu().numpy()
     choice = numpy_choice(counts, n_obj)

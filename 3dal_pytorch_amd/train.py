@@ -146,14 +146,14 @@ def _linear_pool(a, act, W, b, bn, seg):
     return g, arg
 
 
-_DROP_STEP = {}
-
-
-def _drop_step(dev):
-    """device-resident draw counter, bumped once per training forward by an ordinary (graph-capturable) op"""
-    t = _DROP_STEP.get(dev)
-    if t is None:
-        t = _DROP_STEP[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
+def draw_step(module, dev):
+    """the module's device-resident draw counter (starts at 0 with the module, so runs are repeatable), bumped once
+    per random draw of a training forward by an ordinary, graph-capturable op. Not a buffer: it is no part of the
+    reference's state_dict."""
+    t = module.__dict__.get("_draw_step")
+    if t is None or t.device != dev:
+        t = torch.zeros(1, dtype=torch.int64, device=dev)
+        module.__dict__["_draw_step"] = t
     return t
 
 
@@ -565,7 +565,7 @@ def ins_seg_train_forward(ins_seg, pts, p_drop=0.5, drop_mask=None):
         # the draw happens inside dal3_tr_act_dropout, keyed on a seed taken from torch's CPU generator (so
         # torch.manual_seed() makes runs repeatable) and a device-side step counter (so a captured step draws afresh
         # on every hipGraph replay); the backward re-creates the multiplier from the same key
-        step = _drop_step(pts.device)
+        step = draw_step(ins_seg, pts.device)
         step.add_(1)
         drop = (int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF, step, float(p_drop))
     params = []

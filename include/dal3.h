@@ -125,6 +125,14 @@ int dal3_mask_compact_sample(const uint8_t* mask, dal3_bcn pts, int B, int N, in
                              int32_t* counts, int32_t* obj_idx, float* obj_pts,
                              void* workspace, size_t workspace_bytes, dal3_stream stream);
 
+/* The device sampler with its draw counter in DEVICE memory: key = (seed, *step, global item index, rank). Training
+ * draws fresh object points every step (the reference's np.random stream moves on, static_model.py:36-47); a step
+ * captured into a hipGraph must not freeze that, so the counter is a device scalar the caller bumps with a captured op
+ * (step == NULL: as dal3_mask_compact_sample with DAL3_SAMPLER_DEVICE). */
+int dal3_mask_compact_sample_step(const uint8_t* mask, dal3_bcn pts, int B, int N, int C, int M, uint64_t seed,
+                                  const int64_t* step, int64_t item_offset, int32_t* counts, int32_t* obj_idx,
+                                  float* obj_pts, void* workspace, size_t workspace_bytes, dal3_stream stream);
+
 /* ---- shared MLP (4 x Conv1d k=1 + BN + ReLU) + channel-wise max over the point axis + the FC
  * stack of the head: static PointNetEstimation.forward (static_model.py:320-339) -> (B,39);
  * PointEmbedding.forward (dynamic_model.py:234-249) -> (B,256); BoxEmbedding.forward

@@ -130,3 +130,39 @@ def test_captured_train_step_matches_eager_steps():
     assert abs(runs["graph"][0] - runs["eager"][0]) <= 1e-5 * abs(runs["eager"][0])
     for k, v in runs["eager"][1].items():
         assert torch.allclose(runs["graph"][1][k], v, rtol=1e-5, atol=1e-6), k
+
+
+def test_a_captured_training_draw_advances_on_every_replay():
+    """The device sampler's key and the Dropout key carry a draw counter that lives in device memory and is bumped by a
+    captured op: a hipGraph replay of a training forward draws fresh object points / a fresh Dropout pattern each
+    time (a host-computed seed would be frozen into the kernel arguments at capture)."""
+    sm = importlib.import_module("3dal_pytorch_amd.static_model")
+    train = importlib.import_module("3dal_pytorch_amd.train")
+    model = build_model("static_one", synth.state_dict("static_one", seed=3)).train()
+    B, N = 4, 2048
+    pts = torch.from_numpy(synth.static_crops(B, N, seed=3)[0]).cuda().transpose(2, 1)
+    logits = torch.zeros((B, N, 2), device="cuda")
+    logits[:, : N // 2 + 300, 1] = 1.0                                  # 1324 segmented points per crop: a real subset draw
+    x = torch.randn((B * N, 128), device="cuda")
+
+    def draw():
+        obj, _ = sm._mask_and_gather(pts, logits, 512, 3, model)
+        key = (99, train.draw_step(model.ins_seg, pts.device), 0.5)
+        train.draw_step(model.ins_seg, pts.device).add_(1)
+        return obj.clone(), train._act_dropout(x, None, key)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        draw()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        obj, dropped = draw()
+    outs = []
+    for _ in range(3):
+        g.replay()
+        outs.append((obj.clone(), dropped.clone(), int(train.draw_step(model, pts.device)), int(train.draw_step(model.ins_seg, pts.device))))
+    assert outs[1][2] == outs[0][2] + 1 and outs[2][3] == outs[1][3] + 1
+    assert not torch.equal(outs[0][0], outs[1][0]) and not torch.equal(outs[1][0], outs[2][0])       # new object points
+    assert not torch.equal(outs[0][1], outs[1][1]) and not torch.equal(outs[1][1], outs[2][1])       # new Dropout pattern
