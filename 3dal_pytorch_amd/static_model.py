@@ -314,7 +314,7 @@ def _train_forward_two(m, pts, init_box, bbox_gt):
         size = mean[sc] + sr1[ar, sc].double()
         ang = hc.double() * (2 * np.pi / NUM_HEADING_BIN) + hr1[ar, hc].double()
         ang = torch.where(ang > np.pi, ang - 2 * np.pi, ang) + init_box[:, -1].double()
-        box_one = torch.cat([c1.double(), size, ang[:, None]], 1).float()
+        box_one = torch.cat([c1.double(), size, ang[:, None]], 1).to(c1.dtype)        # (.float() in the reference)
         y0, y1 = init_box[:, -1], -box_one[:, -1]
         x, y, z = obj[:, 0], obj[:, 1], obj[:, 2]
         px = torch.cos(y0)[:, None] * x - torch.sin(y0)[:, None] * y + init_box[:, 0:1] - box_one[:, 0:1]
@@ -326,7 +326,7 @@ def _train_forward_two(m, pts, init_box, bbox_gt):
         per = two_pi / NUM_HEADING_BIN
         shifted = torch.remainder(torch.remainder(bbox_gt[:, -1] - box_one[:, -1], two_pi) + per / 2, two_pi)
         hcl = (shifted / per).long()
-        hrl = shifted - (hcl.float() * per + per / 2)
+        hrl = shifted - (hcl.to(shifted.dtype) * per + per / 2)
     c2, hs2, hrn2, hr2, ss2, srn2, sr2 = _parse(_box_pred(m, m.box_est_two, obj2))
     c2 = c2 + c1
     return {"logits": logits, "mask": mask, "heading_scores_one": hs1,

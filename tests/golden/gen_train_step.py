@@ -37,13 +37,20 @@ PICK = {                                                      # parameters whose
                    "ins_seg.dconv5.weight", "ins_seg.dconv5.bias", "box_est.conv1.weight", "box_est.conv4.weight",
                    "box_est.bn4.weight", "box_est.fc1.weight", "box_est.fcbn1.weight", "box_est.fc2.weight",
                    "box_est.fc3.weight", "box_est.fc3.bias"],
+    "static_two": ["ins_seg.conv2.weight", "ins_seg.conv5.weight", "ins_seg.dconv1.weight", "ins_seg.dconv5.weight",
+                   "ins_seg.dconv5.bias", "box_est_one.conv1.weight", "box_est_one.conv4.weight", "box_est_one.fc1.weight",
+                   "box_est_one.fc3.weight", "box_est_one.fc3.bias", "box_est_two.conv1.weight", "box_est_two.conv3.weight",
+                   "box_est_two.bn4.bias", "box_est_two.fc2.weight", "box_est_two.fcbn2.weight", "box_est_two.fc3.weight",
+                   "box_est_two.fc3.bias"],
     "dynamic": ["ins_seg.conv1.weight", "ins_seg.conv5.weight", "ins_seg.bn5.bias", "ins_seg.dconv1.weight",
                 "ins_seg.dconv3.weight", "ins_seg.dconv5.weight", "ins_seg.dconv5.bias", "point_emb.conv1.weight",
                 "point_emb.conv4.weight", "point_emb.fc1.weight", "point_emb.fcbn2.bias", "box_emb.conv1.weight",
                 "box_emb.conv4.weight", "box_emb.fc2.weight", "box_est.fc1.weight", "box_est.fcbn1.weight",
                 "box_est.fc3.weight", "box_est.fc3.bias"],
 }
-STATS = {"static_one": ["ins_seg.bn1", "ins_seg.bn5", "ins_seg.dbn2", "ins_seg.dbn4", "box_est.bn2", "box_est.bn4",
+STATS = {"static_two": ["ins_seg.bn3", "ins_seg.dbn1", "box_est_one.bn1", "box_est_one.fcbn1", "box_est_two.bn4",
+                        "box_est_two.fcbn2"],
+         "static_one": ["ins_seg.bn1", "ins_seg.bn5", "ins_seg.dbn2", "ins_seg.dbn4", "box_est.bn2", "box_est.bn4",
                         "box_est.fcbn1", "box_est.fcbn2"],
          "dynamic": ["ins_seg.bn2", "ins_seg.bn5", "ins_seg.dbn4", "point_emb.bn4", "point_emb.fcbn1", "box_emb.bn3",
                      "box_emb.fcbn2", "box_est.fcbn2"]}
@@ -51,10 +58,11 @@ STATS = {"static_one": ["ins_seg.bn1", "ins_seg.bn5", "ins_seg.dbn2", "ins_seg.d
 
 def case(kind):
     """inputs (numpy, float32) and labels of the step"""
-    if kind == "static_one":
+    if kind in ("static_one", "static_two"):
         B, N = 8, 256
-        pts, init, gt = synth.static_crops(B, N, seed=41)
-        labels = synth.loss_case(41, batch=B, n_pts=N)[1]
+        seed = 41 if kind == "static_one" else 44
+        pts, init, gt = synth.static_crops(B, N, seed=seed)
+        labels = synth.loss_case(seed, batch=B, n_pts=N)[1]
         return dict(pts=pts, init=init, gt=gt), labels
     B, n_per = 4, 64
     pts, box, init8, gt = synth.dynamic_items(B, n_per_frame=n_per, seed=42)
@@ -72,10 +80,12 @@ def one_step(kind, mods, sd_np, inp, labels, dtype, torch_seed, np_seed, force_k
         torch.set_default_dtype(torch.float64)
         torch.Tensor.float = lambda self, *a, **k: self.double()
     try:
-        model = (sm.StaticModelOneBoxEst(3, 3) if kind == "static_one" else dm.DynamicModel(3, 4))
+        model = (sm.StaticModelOneBoxEst(3, 3) if kind == "static_one" else
+                 sm.StaticModelTwoBoxEst(3, 3) if kind == "static_two" else dm.DynamicModel(3, 4))
         model.load_state_dict({k: torch.as_tensor(v) for k, v in sd_np.items()}, strict=True)
         model = model.to(dtype).train()
-        crit = (sm.FrustumPointNetLossOneBoxEst() if kind == "static_one" else dm.DynamicModelLoss())
+        crit = (sm.FrustumPointNetLossOneBoxEst() if kind == "static_one" else
+                sm.FrustumPointNetLossTwoBoxEst() if kind == "static_two" else dm.DynamicModelLoss())
         opt = torch.optim.Adam(model.parameters(), lr=LR)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dtype)          # noqa: E731
         drop = {}
@@ -89,7 +99,7 @@ def one_step(kind, mods, sd_np, inp, labels, dtype, torch_seed, np_seed, force_k
         h = model.ins_seg.dropout.register_forward_hook(hook)
         torch.manual_seed(torch_seed)
         np.random.seed(np_seed)
-        if kind == "static_one":
+        if kind != "dynamic":
             out = model(t(inp["pts"]).transpose(2, 1), t(inp["init"]), t(inp["gt"]))
         else:
             out = model(t(inp["pts"]).transpose(2, 1), t(inp["box"]).transpose(2, 1), t(inp["gt"]))
@@ -102,7 +112,11 @@ def one_step(kind, mods, sd_np, inp, labels, dtype, torch_seed, np_seed, force_k
         res = {"logits": out["logits"].detach().numpy(), "mask": out["mask"].numpy()}
         for k, v in losses.items():
             res["loss_" + k] = np.float64(v.detach())
-        for k in ("center", "heading_scores", "size_scores", "heading_residuals_normalized", "size_residuals_normalized"):
+        for k in (("center", "heading_scores", "size_scores", "heading_residuals_normalized", "size_residuals_normalized")
+                  if kind != "static_two" else
+                  ("center_one", "box_one", "heading_scores_one", "size_residuals_normalized_one", "center_two",
+                   "heading_scores_two", "size_scores_two", "heading_residuals_normalized_two",
+                   "size_residuals_normalized_two", "heading_class_label_two", "heading_residuals_label_two")):
             res["out_" + k] = out[k].detach().numpy()
         for name in PICK[kind]:
             res["grad_" + name] = params[name].grad.numpy().copy()
@@ -131,7 +145,7 @@ def replay_indices(kind, mods, pts_np, mask, np_seed):
     sm, dm = mods
     np.random.seed(np_seed)
     pts = torch.from_numpy(pts_np).transpose(2, 1)
-    if kind == "static_one":
+    if kind != "dynamic":
         return sm.gather_object_pts(pts[:, :3, :], torch.from_numpy(mask), sm.NUM_OBJECT_POINT)[1].numpy()
     return dm.gather_object_pts(pts[:, :4, :], torch.from_numpy(mask), dm.NUM_FRAME * dm.NUM_OBJECT_POINT)[1].numpy()
 
@@ -140,7 +154,7 @@ def main():
     sm, dm, _, _, _ = G.import_reference()
     torch.set_grad_enabled(True)
     torch.set_num_threads(4)
-    for kind, torch_seed, np_seed in (("static_one", 101, 202), ("dynamic", 103, 204)):
+    for kind, torch_seed, np_seed in (("static_one", 101, 202), ("dynamic", 103, 204), ("static_two", 105, 206)):
         inp, labels = case(kind)
         sd = synth.state_dict(kind, seed=43)
         # pass 0 (float32, as the reference runs): its Dropout draw is THE draw of this step.

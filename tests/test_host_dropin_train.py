@@ -116,7 +116,7 @@ def test_drivers_imports_resolve_in_the_dropin():
 
 
 # ------------------------------------------------------------------ the reference's training step, in float64
-@pytest.mark.parametrize("kind", ["static_one", "dynamic"])
+@pytest.mark.parametrize("kind", ["static_one", "static_two", "dynamic"])
 def test_composite_in_float64_reproduces_the_reference_training_step(kind):
     """tests/golden/train_step_*.npz: one step of the REAL reference (forward, its criterion, backward; float64 run of
     the imported code with the float32 run's Dropout and NumPy draws, tests/golden/gen_train_step.py). This package's
@@ -126,11 +126,13 @@ def test_composite_in_float64_reproduces_the_reference_training_step(kind):
     tests/test_gpu_train_reference.py.)"""
     from _common import golden
     g = golden("train_step_" + kind)
-    if kind == "static_one":
+    if kind in ("static_one", "static_two"):
         B, N = 8, 256
-        pts, init, gt = synth.static_crops(B, N, seed=41)
-        labels = synth.loss_case(41, batch=B, n_pts=N)[1]
-        model, crit = sm.StaticModelOneBoxEst(), losses.FrustumPointNetLossOneBoxEst()
+        seed = 41 if kind == "static_one" else 44
+        pts, init, gt = synth.static_crops(B, N, seed=seed)
+        labels = synth.loss_case(seed, batch=B, n_pts=N)[1]
+        model, crit = ((sm.StaticModelOneBoxEst(), losses.FrustumPointNetLossOneBoxEst()) if kind == "static_one" else
+                       (sm.StaticModelTwoBoxEst(), losses.FrustumPointNetLossTwoBoxEst()))
     else:
         B, N = 4, 320
         pts, box, _, gt = synth.dynamic_items(B, n_per_frame=64, seed=42)
@@ -144,11 +146,18 @@ def test_composite_in_float64_reproduces_the_reference_training_step(kind):
     model.ins_seg.dropout.register_forward_hook(lambda m, i, o: i[0] * keep / (1.0 - m.p))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()          # noqa: E731
     np.random.seed(int(g["np_seed"]))
-    if kind == "static_one":
+    if kind != "dynamic":
         out = model(t(pts).transpose(2, 1), t(init), t(gt))
     else:
         out = model(t(pts).transpose(2, 1), t(box).transpose(2, 1), t(gt))
     assert np.array_equal(out["mask"].numpy(), g["mask"])
+    for k in g:
+        if k.startswith("ref_out_"):
+            v, ref = out[k[8:]].detach().numpy(), g[k]
+            if ref.dtype == np.int64:
+                assert np.array_equal(v, ref), k
+            else:
+                assert np.abs(v - ref).max() < 1e-6 * max(np.abs(ref).max(), 1.0), k
     assert np.abs(out["logits"].detach().numpy() - g["ref_logits"]).max() < 1e-6 * np.abs(g["ref_logits"]).max()
     ls = crit(out, *[t(a) if a.dtype == np.float32 else torch.from_numpy(a) for a in labels])
     for k, v in ls.items():
