@@ -133,8 +133,7 @@ class DynamicModel(PackedModelMixin, nn.Module):
 
 
 def _train_forward(m, pts, box):
-    # the stacks (ins_seg, point_emb, and box_emb when B*101 is a multiple of 32, e.g. the train drivers' batch of
-    # 64) on the HIP training kernels when train_backend == "hip"; the FC heads are stock torch ops
+    # the stacks (ins_seg, point_emb, box_emb) and the FC tails on the HIP training kernels when train_backend == "hip"
     logits = _seg_logits(m, pts)
     obj, mask = _mask_and_gather(pts, logits, _M, 4, m)
     emb = torch.cat([_box_pred(m, m.point_emb, obj), _box_pred(m, m.box_emb, box if box.dtype == torch.float64 else box.float())], dim=1)

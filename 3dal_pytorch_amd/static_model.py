@@ -259,7 +259,7 @@ def _parse(box_pred):
 
 def _hip_training(m, pts):
     """train_backend "hip" (default): the per-point stacks run on lib3dal_hip.so's training kernels (train.py);
-    "torch": the stock composite. The HIP kernels need CUDA tensors and B*N a multiple of 32."""
+    "torch": the stock composite. The HIP kernels need CUDA tensors; any B and N."""
     backend = getattr(m, "train_backend", "hip")
     if backend not in ("hip", "torch"):
         raise ValueError(f"unknown train_backend {backend!r}")
@@ -276,8 +276,8 @@ def _seg_logits(m, pts):
 
 
 def _tail(m, head, x):
-    """the per-item FC layers of a head: on the HIP training kernels when the batch is a multiple of 32 (rows = items),
-    else stock torch ops"""
+    """the per-item FC layers of a head: on the HIP training kernels (rows = items), stock torch ops for the "torch"
+    backend or on the CPU"""
     if getattr(m, "train_backend", "hip") == "hip" and _train.fc_tail_supported(x):
         return _train.fc_tail_train_forward(head, x)
     return head.tail(x)

@@ -54,9 +54,14 @@ def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False,
     return z
 
 
-def _colred(z, mode, da=None, dg=None, arg=None, seg=0, bn=None):
-    """float64 column sums (2*C,) on the device: see dal3_tr_colred"""
+def _pad32(n):
+    return (n + 31) // 32 * 32
+
+
+def _colred(z, mode, da=None, dg=None, arg=None, seg=0, bn=None, rows=None):
+    """float64 column sums (2*C,) on the device over the first `rows` rows of z: see dal3_tr_colred"""
     M, C = z.shape
+    M = rows if rows is not None else M
     lib = _hip.lib()
     need = lib.dal3_tr_colred_workspace_bytes(M, C)
     ws = _ws(need, z.device)
@@ -83,12 +88,14 @@ def _wgrad(dz, a, c_out, c_in, act=None):
 class _BN:
     """batch statistics of one layer's pre-BN output and everything derived from them"""
 
-    def __init__(self, z, gamma, beta, running_mean, running_var, sums=None):
-        """z: the layer's pre-BN output (M,C), or just its shape (M, C) when `sums` is given.
+    def __init__(self, z, gamma, beta, running_mean, running_var, sums=None, rows=None):
+        """z: the layer's pre-BN output (M,C), or just its shape (M, C) when `sums` is given. rows: how many of z's
+        rows are real (the buffers are padded to a multiple of 32 rows; the padding takes no part in the statistics).
         sums: optional float64 (2*C,) [sum z, sum z^2] obtained without a pass over z (see _moments_through)"""
         M, C = z if isinstance(z, tuple) else z.shape
+        M = rows if rows is not None else M
         if sums is None:
-            sums = _colred(z, 0)
+            sums = _colred(z, 0, rows=M)
         st = torch.empty((4, C), dtype=torch.float32, device=sums.device)
         self.mu, self.rstd, self.scale, self.shift = st[0], st[1], st[2], st[3]
         self.gamma = gamma.contiguous()
@@ -104,9 +111,10 @@ class _BN:
 
     def backward(self, z, da=None, dg=None, arg=None, seg=0):
         """(dz, dgamma, dbeta) from the gradient w.r.t. relu(bn(z))"""
-        M, C = z.shape
+        C = z.shape[1]
+        M = self.M                                                          # the real rows; padding rows get dz = 0
         lib = _hip.lib()
-        sums = _colred(z, 1, da=da, dg=dg, arg=arg, seg=seg, bn=(self.scale, self.shift, self.mu, self.rstd))
+        sums = _colred(z, 1, da=da, dg=dg, arg=arg, seg=seg, bn=(self.scale, self.shift, self.mu, self.rstd), rows=M)
         co = torch.empty((5, C), dtype=torch.float32, device=z.device)      # dgamma, dbeta, k1, k2, k3
         _hip.check(lib.dal3_tr_bnbwd_coef(_hip.ptr(sums), C, M, _hip.ptr(self.gamma), _hip.ptr(self.rstd), _hip.ptr(co[0]),
                                           _hip.ptr(co[1]), _hip.ptr(co[2]), _hip.ptr(co[3]), _hip.ptr(co[4]), _hip.stream()))
@@ -115,12 +123,14 @@ class _BN:
                                            _hip.ptr(dg), _hip.ptr(arg), seg, _hip.ptr(self.scale), _hip.ptr(self.shift),
                                            _hip.ptr(self.mu), _hip.ptr(self.rstd), _hip.ptr(co[2]), _hip.ptr(co[3]),
                                            _hip.ptr(co[4]), _hip.ptr(dz), dz.stride(0), _hip.stream()))
+        if z.shape[0] > M:
+            dz[M:].zero_()                                                  # (wgrad sums over every row it is given)
         return dz, co[0], co[1]
 
 
 def _segmax(z, bn, seg):
-    M, C = z.shape
-    n_seg = M // seg
+    C = z.shape[1]
+    n_seg = bn.M // seg
     g = torch.empty((n_seg, C), dtype=torch.float32, device=z.device)
     arg = torch.empty((n_seg, C), dtype=torch.int32, device=z.device)
     ws = torch.empty(n_seg * C, dtype=torch.int64, device=z.device)
@@ -181,10 +191,10 @@ def _gather_at(z, arg, seg):
     return z[rows, torch.arange(C, device=z.device)[None, :]]
 
 
-def _segsum(x, seg):
-    M, C = x.shape
-    out = torch.empty((M // seg, C), dtype=torch.float32, device=x.device)
-    _hip.check(_hip.lib().dal3_tr_segsum(_hip.ptr(x), x.stride(0), seg, C, _hip.ptr(out), M // seg, _hip.stream()))
+def _segsum(x, seg, n_seg):
+    C = x.shape[1]
+    out = torch.empty((n_seg, C), dtype=torch.float32, device=x.device)
+    _hip.check(_hip.lib().dal3_tr_segsum(_hip.ptr(x), x.stride(0), seg, C, _hip.ptr(out), n_seg, _hip.stream()))
     return out
 
 
@@ -196,16 +206,17 @@ def _pad_cols(w, n):
 
 
 def _points_major(pts, c_pad=32):
-    """(B,C,N) logical -> (B*N, c_pad) row-major, zero-padded channels"""
+    """(B,C,N) logical -> (pad32(B*N), c_pad) row-major, zero-padded channels and rows"""
     B, C, N = pts.shape
-    a0 = torch.zeros((B * N, c_pad), dtype=torch.float32, device=pts.device)
-    a0[:, :C] = pts.transpose(2, 1).reshape(B * N, C)
+    a0 = torch.zeros((_pad32(B * N), c_pad), dtype=torch.float32, device=pts.device)
+    a0[:B * N, :C] = pts.transpose(2, 1).reshape(B * N, C)
     return a0
 
 
 def supported(pts):
-    """the training kernels tile the flattened point axis: B*N must be a multiple of 32 (N itself need not be)"""
-    return pts.is_cuda and (pts.shape[0] * pts.shape[2]) % 32 == 0
+    """CUDA tensors of any (B, N): the kernels tile the flattened point axis in 32s, the host pads the row buffers to
+    a multiple of 32 and keeps the padding out of every sum (statistics over the real rows, dz = 0 on the rest)"""
+    return pts.is_cuda
 
 
 def _check(pts, what):
@@ -213,8 +224,6 @@ def _check(pts, what):
     if pts.requires_grad:
         raise NotImplementedError(f"{what}: the HIP training path does not produce a gradient for the input points "
                                   "(the reference never asks for one); use train_backend='torch' for that")
-    if not supported(pts):
-        raise RuntimeError(f"{what}: the training kernels need B*N to be a multiple of 32, got {pts.shape[0]} x {pts.shape[2]}")
 
 
 def _moments_through(z_prev, bn_prev, W, b):
@@ -223,11 +232,16 @@ def _moments_through(z_prev, bn_prev, W, b):
         mean(z) = W mean(a) + b,    var(z)_c = w_c^T Cov(a) w_c.
     Cov(a) is accumulated on CENTRED activations by the MFMA wgrad kernel (no mean^2 to cancel) and the small
     products are float64. Returns (sums, a, S, m1) with S = sum a a^T and m1 = sum a for the backward shortcut."""
-    M, K = z_prev.shape
+    K = z_prev.shape[1]
+    M = bn_prev.M                                                          # real rows (z_prev is padded to 32s)
     a = torch.relu(z_prev * bn_prev.scale + bn_prev.shift)
+    if a.shape[0] > M:
+        a[M:].zero_()
     m1 = a.sum(0, dtype=torch.float64)
     mean_a = m1 / M
     ac = a - mean_a.float()
+    if a.shape[0] > M:
+        ac[M:].zero_()
     Sc = _wgrad(ac, ac, K, K).double()
     del ac
     W64 = W.double()
@@ -252,13 +266,16 @@ def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N, cache
     with S = sum_p a[p] a[p]^T (a K x K Gram matrix: the wgrad of a K->K layer) and m1 = sum_p a[p]. The K x K
     products are float64 torch matmuls (tiny); the per-point work stays on the MFMA kernels.
     Returns (da (M,K), dW (C,K), dgamma, dbeta)."""
-    M, K = z_prev.shape
+    K = z_prev.shape[1]
+    M = bn_prev.M                                                          # real rows
     C = W.shape[0]
     dev = z_prev.device
     if cached is not None:
         a, S, m1 = cached                                                   # from _moments_through in the forward
     else:
         a = torch.relu(z_prev * bn_prev.scale + bn_prev.shift)             # (M,K), materialised once (K << C)
+        if a.shape[0] > M:
+            a[M:].zero_()
         S = m1 = None
     D = (dg * (g > 0)).double()                                            # ReLU gate at the pooled point
     xhat = (zarg.double() - bn.mu.double()) * bn.rstd.double()             # (B,C) at the arg-max points
@@ -298,7 +315,7 @@ class _PointStack(torch.autograd.Function):
             W2 = W.reshape(W.shape[0], -1)
             W2 = _pad_cols(W2, 32) if k == 0 else W2.contiguous()
             z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous())
-            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)))
+            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), rows=B * N)
             Ws.append(W2)
             bns.append(bn)
             zs.append(z)
@@ -353,7 +370,7 @@ class _InsSeg(torch.autograd.Function):
             W2 = W.reshape(W.shape[0], -1)
             W2 = _pad_cols(W2, 32) if k == 0 else W2.contiguous()
             z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous())
-            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)))
+            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), rows=M)
             Ws.append(W2)
             bns.append(bn)
             zs.append(z)
@@ -381,9 +398,10 @@ class _InsSeg(torch.autograd.Function):
         zs.append(None)
         # dconv1 on cat([out2, g.expand]): per-point part W[:, :64] out2, per-crop part W[:, 64:] g + b
         Wd1 = P[20].reshape(P[20].shape[0], -1).contiguous()            # (512, 1088)
-        gb = torch.addmm(P[21], g, Wd1[:, 64:].t())                     # (B,512)
-        z = _linear(zs[1], Wd1, Wd1.shape[1], 64, 512, act=bns[1].act, bias=gb.contiguous(), seg=N)
-        bn = _BN(z, P[22], P[23], *(stats[5] if stats is not None else (None, None)))
+        gb = torch.zeros(((a0.shape[0] - 1) // N + 1, 512), dtype=torch.float32, device=g.device)  # (padding rows index past B)
+        torch.addmm(P[21], g, Wd1[:, 64:].t(), out=gb[:B])             # (B,512)
+        z = _linear(zs[1], Wd1, Wd1.shape[1], 64, 512, act=bns[1].act, bias=gb, seg=N)
+        bn = _BN(z, P[22], P[23], *(stats[5] if stats is not None else (None, None)), rows=M)
         Ws.append(Wd1)
         bns.append(bn)
         zs.append(z)
@@ -392,11 +410,13 @@ class _InsSeg(torch.autograd.Function):
             W, b, gamma, beta = P[4 * k:4 * k + 4]
             W2 = W.reshape(W.shape[0], -1).contiguous()
             z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous())
-            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)))
+            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), rows=M)
             Ws.append(W2)
             bns.append(bn)
             zs.append(z)
             a, act = z, bn.act
+        if torch.is_tensor(drop) and drop.shape[0] < zs[8].shape[0]:     # a supplied multiplier: pad its rows too
+            drop = torch.cat([drop, drop.new_zeros((zs[8].shape[0] - drop.shape[0], drop.shape[1]))])
         a4 = _act_dropout(zs[8], bns[8].act, drop)                      # Dropout sits between dbn4's ReLU and dconv5
         W5 = torch.zeros((32, 128), dtype=torch.float32, device=pts.device)
         W5[:2] = P[36].reshape(2, 128)
@@ -405,16 +425,17 @@ class _InsSeg(torch.autograd.Function):
         zl = _linear(a4, W5, 128, 128, 32, bias=b5)
         ctx.saved = (a0, Ws, bns, zs, g, arg, a4, drop, W5, N, [tuple(p.shape) for p in params], zarg, P[17].contiguous(),
                      (a4c, S4, m14))
-        return zl[:, :2].reshape(B, N, 2).contiguous()
+        return zl[:M, :2].reshape(B, N, 2).contiguous()
 
     @staticmethod
     def backward(ctx, dlogits):
         a0, Ws, bns, zs, g, arg, a4, drop, W5, N, shapes, zarg, b_conv5, conv5_cache = ctx.saved
-        M = a0.shape[0]
+        Mp = a0.shape[0]
+        M = dlogits.shape[0] * dlogits.shape[1]
         dev = a0.device
         grads = [None] * 38
-        dzl = torch.zeros((M, 32), dtype=torch.float32, device=dev)
-        dzl[:, :2] = dlogits.reshape(M, 2)
+        dzl = torch.zeros((Mp, 32), dtype=torch.float32, device=dev)
+        dzl[:M, :2] = dlogits.reshape(M, 2)
         grads[36] = _wgrad(dzl, a4, 32, 128)[:2].reshape(shapes[36])
         grads[37] = dzl[:, :2].sum(0)
         da = _linear(dzl, W5, 128, 32, 128, transpose=True)
@@ -430,7 +451,7 @@ class _InsSeg(torch.autograd.Function):
         dz, dgam, dbet = bns[5].backward(zs[5], da=da)
         Wd1 = Ws[5]
         dWa = _wgrad(dz, zs[1], 512, 64, bns[1].act)
-        dgb = _segsum(dz, N)                                            # (B,512)
+        dgb = _segsum(dz, N, g.shape[0])                                # (B,512)
         dW1 = torch.cat([dWa, dgb.t() @ g], 1)
         grads[20] = dW1.reshape(shapes[20])
         grads[21] = torch.zeros(shapes[21], device=dev)
@@ -464,21 +485,23 @@ class _InsSeg(torch.autograd.Function):
 class _FcTail(torch.autograd.Function):
     """The per-item tail of a head in train mode — Linear -> BatchNorm1d (batch statistics over the B items) -> ReLU,
     n_bn times, then an optional last Linear without BN (fc3) — on the same training kernels as the per-point stacks,
-    with rows = items: (B, c_in) -> (B, c_out). B must be a multiple of 32 (the drivers' batches are; otherwise the
-    stock composite runs). params: (W, b, gamma, beta) per BN layer, then (W, b) of the last layer if there is one.
+    with rows = items: (B, c_in) -> (B, c_out); any B (rows padded to 32s, statistics over the B real ones). params: (W, b, gamma, beta) per BN layer, then (W, b) of the last layer if there is one.
     Reference: static_model.py:336-338, dynamic_model.py:247-248, :284-285, :306-311."""
 
     @staticmethod
     def forward(ctx, x, stats, n_bn, *params):
         P = [p.detach() for p in params]
+        B = x.shape[0]
         a, act = x.detach().contiguous(), None
+        if B % 32:
+            a = torch.cat([a, a.new_zeros((_pad32(B) - B, a.shape[1]))])
         a_in = a
         Ws, bns, zs = [], [], []
         for k in range(n_bn):
             W, b, gamma, beta = P[4 * k:4 * k + 4]
             W = W.contiguous()
             z = _linear(a, W, W.shape[1], W.shape[1], W.shape[0], act=act, bias=b.contiguous())
-            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)))
+            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), rows=B)
             Ws.append(W)
             bns.append(bn)
             zs.append(z)
@@ -492,10 +515,10 @@ class _FcTail(torch.autograd.Function):
             Wp[:c_out] = W
             bp = torch.zeros(cp, dtype=torch.float32, device=W.device)
             bp[:c_out] = b
-            out = _linear(a, Wp, Wp.shape[1], Wp.shape[1], cp, act=act, bias=bp)[:, :c_out]
+            out = _linear(a, Wp, Wp.shape[1], Wp.shape[1], cp, act=act, bias=bp)[:B, :c_out]
             last = (Wp, c_out)
         else:
-            out = _act_dropout(a, act, None)                      # relu(bn(z)) of the last BN layer
+            out = _act_dropout(a, act, None)[:B]                  # relu(bn(z)) of the last BN layer
         ctx.saved = (a_in, Ws, bns, zs, last, n_bn, [tuple(p.shape) for p in params])
         return out.contiguous()
 
@@ -504,14 +527,17 @@ class _FcTail(torch.autograd.Function):
         a_in, Ws, bns, zs, last, n_bn, shapes = ctx.saved
         grads = [None] * len(shapes)
         dev = dout.device
+        B, Bp = dout.shape[0], a_in.shape[0]
         if last is not None:
             Wp, c_out = last
-            dz = torch.zeros((dout.shape[0], Wp.shape[0]), dtype=torch.float32, device=dev)
-            dz[:, :c_out] = dout
+            dz = torch.zeros((Bp, Wp.shape[0]), dtype=torch.float32, device=dev)
+            dz[:B, :c_out] = dout
             src, act = (zs[-1], bns[-1].act) if n_bn else (a_in, None)
             grads[4 * n_bn] = _wgrad(dz, src, Wp.shape[0], Wp.shape[1], act)[:c_out].reshape(shapes[4 * n_bn])
             grads[4 * n_bn + 1] = dout.sum(0)
             da = _linear(dz, Wp, Wp.shape[1], Wp.shape[0], Wp.shape[1], transpose=True)
+        elif Bp > B:
+            da = torch.cat([dout, dout.new_zeros((Bp - B, dout.shape[1]))])
         else:
             da = dout.contiguous()
         for k in range(n_bn - 1, -1, -1):
@@ -521,15 +547,15 @@ class _FcTail(torch.autograd.Function):
             grads[4 * k + 1] = torch.zeros(shapes[4 * k + 1], device=dev)      # a bias in front of a train-mode BN
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
             da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
-        return (da, None, None, *grads)
+        return (da[:B], None, None, *grads)
 
 
 def fc_tail_supported(x):
-    return x.is_cuda and x.dim() == 2 and x.shape[0] % 32 == 0 and x.shape[1] % 32 == 0
+    return x.is_cuda and x.dim() == 2 and x.shape[1] % 32 == 0
 
 
 def fc_tail_train_forward(head, x):
-    """`_PointHead.tail(x)` in train mode on the HIP training kernels (B a multiple of 32); updates the BatchNorm running
+    """`_PointHead.tail(x)` in train mode on the HIP training kernels; updates the BatchNorm running
     statistics like torch does"""
     fcs = head.TABLE["fcs"]
     params, bn_names = [], []

@@ -79,6 +79,42 @@ def test_ins_seg_training_step_matches_float64_autograd():
             assert _close(b1, b2), name
 
 
+@pytest.mark.parametrize("B,N", [(3, 100), (5, 77), (1, 1000)])
+def test_ins_seg_training_step_ragged_sizes_match_float64_autograd(B, N):
+    """B*N not a multiple of 32 (300, 385, 1000 points; N not a multiple of 32 either: conv5 and the pooling run as
+    two kernels): outputs, running statistics and every gradient against float64 autograd, as in the test above. The
+    yardstick for a gradient that a discrete decision rerouted is the stock fp32 composite's own distance."""
+    model = build_model("static_one", synth.state_dict("static_one", seed=21))
+    ours = model.ins_seg.train()
+    ref32, ref64 = copy.deepcopy(ours), copy.deepcopy(ours).double()
+    pts = torch.from_numpy(synth.static_crops(B, N, seed=21 + N)[0]).cuda().transpose(2, 1)
+    mul = (torch.from_numpy(synth.uniform(21, "drop", (B, N, 128))).cuda() >= 0.5).float() * 2.0
+    weight = torch.from_numpy(synth.normal(21, "lw", (B, N, 2)).astype(np.float32)).cuda()
+    w64 = _ref_ins_seg(ref64, pts.double(), mul.transpose(2, 1).double())
+    (w64 * weight.double()).sum().backward()
+    w32 = _ref_ins_seg(ref32, pts, mul.transpose(2, 1))
+    (w32 * weight).sum().backward()
+    got = train.ins_seg_train_forward(ours, pts, drop_mask=mul.reshape(B * N, 128))
+    (got * weight).sum().backward()
+    assert got.shape == (B, N, 2) and _close(got.detach(), w64.detach())
+    gmax = max(float(q.grad.abs().max()) for q in ref64.parameters())
+    for (name, p), (_, q), (_, r) in zip(ours.named_parameters(), ref32.named_parameters(), ref64.named_parameters()):
+        if _close(p.grad, r.grad, gmax):
+            continue
+        if float(r.grad.abs().max()) < 1e-6 * gmax:                    # analytically zero (B = 1: the pooled feature is
+            assert float(p.grad.abs().max()) < 1e-5 * gmax, name      # one row, dbn1 removes it, conv3..5 get nothing)
+            continue
+        mine, stock = _rel(p.grad.double(), r.grad), _rel(q.grad.double(), r.grad)
+        assert mine < 2e-2 and mine < 1.5 * stock + 1e-4, (name, mine, stock)
+    for (name, b1), (_, b2) in zip(ours.named_buffers(), ref64.named_buffers()):
+        if not name.endswith("num_batches_tracked"):
+            assert _close(b1, b2), name
+    # the random-Dropout path at a ragged size: runs, and the backward re-creates the forward's multiplier
+    out = train.ins_seg_train_forward(ours, pts)
+    out.sum().backward()
+    assert bool(torch.isfinite(out).all()) and all(bool(torch.isfinite(p.grad).all()) for p in ours.parameters())
+
+
 def test_ins_seg_training_step_larger_batch_is_as_close_to_float64_as_stock_fp32():
     """B*N = 3072 points (several wgrad slices, odd tile counts). Here one discrete decision differs from the
     float64 run, so the yardstick is the stock PyTorch-ROCm fp32 composite's own distance from float64."""
@@ -169,7 +205,7 @@ def test_batchnorm_relu_backward_and_pooling_kernels_vs_float64_autograd():
     (y64.reshape(3, seg, C).max(1)[0] * dg.double()).sum().backward()
     dz, dgam, dbet = bn.backward(z, dg=dg, arg=arg, seg=seg)
     assert _close(dz, z64.grad) and _close(dgam, g64.grad) and _close(dbet, b64.grad)
-    assert _close(train._segsum(da, seg), da.double().reshape(3, seg, C).sum(1))
+    assert _close(train._segsum(da, seg, 3), da.double().reshape(3, seg, C).sum(1))
 
 
 def test_ins_seg_random_dropout_and_eval_after_training_step():
@@ -191,9 +227,12 @@ def test_ins_seg_random_dropout_and_eval_after_training_step():
 
 
 @pytest.mark.parametrize("kind,attr,B,C,N", [("static_one", "box_est", 6, 3, 512), ("dynamic", "point_emb", 2, 4, 2560),
-                                              ("dynamic", "box_emb", 32, 8, 101)])
+                                              ("dynamic", "box_emb", 32, 8, 101), ("dynamic", "box_emb", 5, 8, 101),
+                                              ("static_one", "box_est", 3, 3, 90)])
 def test_point_stack_training_step_matches_float64_autograd(kind, attr, B, C, N):
-    """conv1..4 + max of the three point heads; box_emb's 101 boxes per item are not a multiple of 32, B*101 is"""
+    """conv1..4 + max of the three point heads; box_emb's 101 boxes per item are not a multiple of 32; the last two
+    cases have B*N not a multiple of 32 either (505 and 270 rows: the host pads the row buffers, the statistics and
+    every gradient sum run over the real rows only)"""
     model = build_model(kind, synth.state_dict(kind, seed=22))
     ours = getattr(model, attr).train()
     ref = copy.deepcopy(ours).double()
@@ -223,10 +262,10 @@ def test_training_kernels_reject_bad_shapes():
     z = torch.zeros((64, 32), device="cuda")
     assert lib.dal3_tr_linear(hip.ptr(a), 60, 32, 32, None, None, 0, hip.ptr(w), 32, 0, None, 0, 32, hip.ptr(z), 32, 0,
                               None, 0, hip.stream()) != 0
-    assert "multiples of 32" in lib.dal3_last_error().decode()
+    assert "multiples of 32" in lib.dal3_last_error().decode()      # (the host pads row buffers: see the ragged tests)
     with pytest.raises(RuntimeError):
         train.point_stack_train_forward(build_model("static_one", synth.state_dict("static_one")).box_est.train(),
-                                        torch.zeros((2, 3, 100), device="cuda"))        # B*N = 200 is not a multiple of 32
+                                        torch.zeros((2, 3, 100)))                       # CPU tensors: no silent fallback
 
 
 def _labels_for(B, N, seed, dev):
@@ -236,7 +275,8 @@ def _labels_for(B, N, seed, dev):
             (torch.from_numpy(synth.uniform(seed, "sc", (B,))).to(dev) * 3).long(), rnd("sr", (B, 3), 0.3))
 
 
-@pytest.mark.parametrize("kind,B", [("static_one", 4), ("static_two", 4), ("dynamic", 4), ("dynamic", 32)])
+@pytest.mark.parametrize("kind,B", [("static_one", 4), ("static_two", 4), ("dynamic", 4), ("dynamic", 32),
+                                    ("static_two", 3), ("dynamic", 3)])    # 3: FC tails / box_emb rows not in 32s
 def test_whole_train_step_hip_backend_vs_torch_backend(kind, B):
     """model.train(); forward; the reference's criterion; backward; Adam step — as static_train.py:76-86 does —
     with the per-point stacks on the HIP training kernels vs the stock-torch composite. Dropout off (its draw is
@@ -271,15 +311,17 @@ def test_whole_train_step_hip_backend_vs_torch_backend(kind, B):
                         o["mask"].clone())
     if not torch.equal(out["hip"][3], out["torch"][3]):
         # a logit pair within fp32 rounding of a tie flipped the segmentation of a point: the object points then
-        # differ and the runs are no longer comparable term by term (possible only in the large case)
-        assert B >= 32 and float((out["hip"][3] != out["torch"][3]).float().mean()) < 1e-4
+        # differ and the runs are no longer comparable term by term (dynamic B=32, and B=3 where the STOCK fp32 run is
+        # the one that leaves the float64 mask: one point with a logit gap of 8e-5, tools/dbg_mask_flip.py)
+        assert float((out["hip"][3] != out["torch"][3]).float().mean()) < (1e-4 if B >= 32 else 5e-4)
         assert abs(out["hip"][0] - out["torch"][0]) <= 2e-2 * abs(out["torch"][0])
         return
     assert abs(out["hip"][0] - out["torch"][0]) <= 1e-4 * abs(out["torch"][0])
     scale = max(float(g.norm()) for g in out["torch"][1].values())
     for k, gt in out["torch"][1].items():
         gh = out["hip"][1][k]                                # conv biases in front of a BN: exactly 0 vs autograd's noise
-        assert float((gh - gt).norm()) <= 2e-2 * float(gt.norm()) + 1e-6 * scale, k
+        # (B = 3: a BatchNorm over three items is ill-conditioned — gradients ~1e3, fp32 rounding of BOTH runs with them)
+        assert float((gh - gt).norm()) <= 2e-2 * float(gt.norm()) + (1e-6 if B > 3 else 1e-5) * scale, k
     for k, pt in out["torch"][2].items():
         assert float((out["hip"][2][k] - pt).abs().max()) <= 2.5e-3, k        # Adam moves every weight by <= lr (+ decay)
 
@@ -328,6 +370,7 @@ def test_fused_linear_pool_equals_linear_then_segmax_bitwise(B, N, c_in, c_out):
     class BN:                                                        # just the affine the kernels read
         scale = torch.rand(c_out, device="cuda", generator=gen) - 0.3    # some negative scales too
         shift = torch.randn(c_out, device="cuda", generator=gen) * 0.2
+    BN.M = M
     act = (sc_in, sh_in, True)
     z = train._linear(a, W, c_in, c_in, c_out, act=act, bias=b)
     g0, arg0 = train._segmax(z, BN, N)
@@ -373,12 +416,13 @@ def test_dropout_kernel_statistics_key_and_backward():
     assert torch.allclose(train._act_dropout(x, (sc, sh, True), (5, None, 0.0)), a, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("kind,head_name,c_in", [("static_one", "box_est", 512), ("dynamic", "point_emb", 512),
-                                                 ("dynamic", "box_emb", 512), ("dynamic", "box_est", 384)])
-def test_fc_tail_on_hip_kernels_matches_float64_autograd(kind, head_name, c_in):
+@pytest.mark.parametrize("kind,head_name,c_in,B", [("static_one", "box_est", 512, 64), ("dynamic", "point_emb", 512, 64),
+                                                   ("dynamic", "box_emb", 512, 64), ("dynamic", "box_est", 384, 64),
+                                                   ("static_one", "box_est", 512, 40), ("dynamic", "box_est", 384, 7)])
+def test_fc_tail_on_hip_kernels_matches_float64_autograd(kind, head_name, c_in, B):
     """the per-item Linear -> BatchNorm1d -> ReLU tails (rows = items) on the training kernels: output, input
-    gradient, every parameter gradient and the running statistics against float64 autograd of `_PointHead.tail`"""
-    B = 64
+    gradient, every parameter gradient and the running statistics against float64 autograd of `_PointHead.tail`
+    (B = 40 and 7: batches that are not a multiple of 32 — padded rows, statistics over the real ones)"""
     model = build_model(kind, synth.state_dict(kind, seed=27)).train()
     head = getattr(model, head_name)
     ref = copy.deepcopy(head).double()
@@ -404,5 +448,4 @@ def test_fc_tail_on_hip_kernels_matches_float64_autograd(kind, head_name, c_in):
             assert _close(b1, b2), n
         if n.startswith("fcbn") and n.endswith("num_batches_tracked"):
             assert int(b1) == int(b2)
-    # a batch that is not a multiple of 32 goes through the stock composite (model-level dispatch)
-    assert not train.fc_tail_supported(x[:40])
+    assert not train.fc_tail_supported(x.cpu())
