@@ -289,12 +289,13 @@ extern "C" int dal3_pack_weights(int head_kind, const dal3_layer* L, int n_layer
             HIP_TRY(launch_pack_weight_lp(L[2], dtype, 0, 0, 64, 2, 2, enc + 8 * F, s));
             HIP_TRY(launch_pack_weight_lp(L[3], dtype, 0, 0, 64, 4, 2, enc + 16 * F, s));
             HIP_TRY(launch_pack_weight_lp(L[4], dtype, 0, 0, 128, 32, 4, enc + 32 * F, s));
-            // decode stream, segments of 40: [conv2 @0, 1a(0) @8] ; 1a(c>=1) @40+20(c-1) ; 2(c) @44+20c ; dconv3 @360,@400 ; dconv4 @440
+            // decode stream, segments of 40: [conv2 @0, 1a(0) @8] ; 1a(c>=1) @40+20(c-1) ; 2(c) @44+20c ; dconv3 @360,@400 ; dconv4 @440, dconv5 @472
             HIP_TRY(launch_pack_weight_lp(L[1], dtype, 0, 0, 64, 2, 2, dec, s));
             HIP_TRY(launch_pack_weight_lp(L[5], dtype, 0, 0, 64, 16, 2, dec, s, 2, 8 * F, 40 * F, 20 * F));
             HIP_TRY(launch_pack_weight_lp(L[6], dtype, 1, 0, 512, 8, 16, dec, s, 8, 44 * F, 64 * F, 20 * F));
             HIP_TRY(launch_pack_weight_lp(L[7], dtype, 0, 0, 256, 4, 8, dec, s, 16, 360 * F, 400 * F, 40 * F));
             HIP_TRY(launch_pack_weight_lp(L[8], dtype, 0, 0, 128, 4, 4, dec + 440 * F, s));
+            HIP_TRY(launch_pack_weight_lp(L[9], dtype, 0, 0, 128, 1, 4, dec + 472 * F, s));   // dconv5: rows 0, 1 of one out-tile
             return 0;
         }
         InsSegW w = ins_seg_view(base, c_in);

@@ -85,7 +85,7 @@ struct PointHeadW {
 #define LP_ENC_SEG 32     // fragments per ring segment
 #define LP_ENC_SEGS 9     // conv2|conv3|conv4 , then conv5 four out-tiles per segment
 #define LP_DEC_SEG 40
-#define LP_DEC_SEGS 12    // [conv2, dconv1a(0)] , 8 x [1a(2i+1), 2(2i), 1a(2i+2), 2(2i+1)] , dconv3 x2 , dconv4
+#define LP_DEC_SEGS 12    // [conv2, dconv1a(0)] , 8 x [1a(2i+1), 2(2i), 1a(2i+2), 2(2i+1)] , dconv3 x2 , [dconv4, dconv5]
 #define LP_HEAD_SEG 32
 #ifndef DAL3_LP_ENC_T
 #define DAL3_LP_ENC_T 4

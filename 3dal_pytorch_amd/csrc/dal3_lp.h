@@ -50,11 +50,14 @@ struct FP16 {
 // write of an operand just before, `s_nop 11` the 8-pass XDL write -> any reader after the statement.
 template <class DT>
 struct MfmaAsm;
+// acc0 comes in holding the INITIAL value of both tiles (the crop's dconv1 term: the same for every point of a crop, so it
+// is read from LDS once, not once per tile); tile 1's first MFMA takes it as its C operand and goes first, before tile
+// 0's first MFMA overwrites it. Per tile the k order is unchanged.
 #define DAL3_LP_MFMA4X2(MN)                                                                                          \
-    asm volatile("s_nop 1\n\t" MN " %0, %2, %6, %0\n\t" MN " %1, %2, %10, %1\n\t" MN " %0, %3, %7, %0\n\t" MN           \
+    asm volatile("s_nop 1\n\t" MN " %1, %2, %10, %0\n\t" MN " %0, %2, %6, %0\n\t" MN " %0, %3, %7, %0\n\t" MN           \
                  " %1, %3, %11, %1\n\t" MN " %0, %4, %8, %0\n\t" MN " %1, %4, %12, %1\n\t" MN " %0, %5, %9, %0\n\t" MN  \
                  " %1, %5, %13, %1\n\ts_nop 11"                                                                       \
-                 : "+v"(acc0), "+v"(acc1)                                                                            \
+                 : "+v"(acc0), "=&v"(acc1)                                                                           \
                  : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b00), "v"(b01), "v"(b02), "v"(b03), "v"(b10), "v"(b11),      \
                    "v"(b12), "v"(b13))
 template <>
@@ -195,7 +198,9 @@ struct LdsRing {
         unsigned long long t0_, t1_, t2_;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory");
 #endif
+#ifndef DAL3_ABL_WAIT                                     // timing experiment only
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SLOTS == 3 ? MY_LOADS : 0) : "memory");   // (two slots: no younger segment in flight)
+#endif
 #ifdef DAL3_STAMP
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_)::"memory");
 #endif
@@ -249,40 +254,60 @@ __device__ __forceinline__ void lp_refill_gap(Ring& ring, int n) {
 struct LpNoGap {
     __device__ __forceinline__ void operator()(int) const {}
 };
-template <class DT, int KT, int T, int SEG, bool EARLY = false, class Gap = LpNoGap, class Ring>
-__device__ __forceinline__ void lp_block(Ring& ring, int f0, const ActTile<DT> (&X)[T][KT],
-                                         f32x16 (&acc)[T], Gap gap = Gap()) {
-    typedef typename DT::v8 frag_t;
+// On entry acc[0] holds the INITIAL value of every tile (the folded bias: one value per channel, the same for all the
+// wave's points, so it is read from LDS once): the first k-step runs the tiles in reverse order, tiles 1.. take acc[0]
+// as their C operand, tile 0 overwrites it last. Per tile the k order is what it always was.
+// g: the caller's two fragment groups. CARRY_IN: g[0] already holds this block's first four fragments (read by the block
+// before, under ITS MFMAs). F_NEXT >= 0: this block in turn reads the four fragments at F_NEXT for the block that follows —
+// of the same slot a group ahead as usual, or (EARLY) of the slot it opens, in the first gap behind the barrier — so no
+// block of a layer chain starts by waiting out an LDS round trip with the matrix pipe idle (stamps: 700-1,000 ticks
+// in front of the first MFMA of dconv3 and of dconv4, ~200 in front of every other block).
+template <class DT, int KT, int T, int SEG, bool EARLY = false, bool CARRY_IN = false, int F_NEXT = -1, class Gap = LpNoGap,
+          class Ring>
+__device__ __forceinline__ void lp_block(Ring& ring, int f0, const ActTile<DT> (&X)[T][KT], f32x16 (&acc)[T],
+                                         typename DT::v8 (&g)[2][4], Gap gap = Gap()) {
     constexpr int NG = KT * 2 / 4;
     constexpr bool GAPS = !__is_same(Gap, LpNoGap);
     static_assert((KT * 2) % 4 == 0, "whole groups of four fragments");
-    frag_t g[2][4];
+    static_assert(NG % 2 == 0, "the carried group is g[0] on the way in and on the way out");
+    if (!CARRY_IN) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) g[0][i] = ring.template frag<DT>(f0 + i);
+        for (int i = 0; i < 4; ++i) g[0][i] = ring.template frag<DT>(f0 + i);
+    }
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
-        const bool last = EARLY && gi == NG - 1;
-        if (gi + 1 < NG) {
+        const bool last = gi == NG - 1;
+        if (!last) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) g[(gi + 1) & 1][i] = ring.template frag<DT>(f0 + 4 * (gi + 1) + i);
+        } else if (F_NEXT >= 0 && !EARLY) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[0][i] = ring.template frag<DT>(F_NEXT + i);
         }
         DAL3_SCHED_FENCE();
-        if (last) ring.acquire_wait();
+        if (last && EARLY) ring.acquire_wait();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = 4 * gi + i;
 #pragma unroll
-            for (int j = 0; j < T; ++j) {
-                acc[j] = DT::mfma(g[gi & 1][i], X[j][k >> 1].k[k & 1], acc[j]);
-                if (last || GAPS) {
+            for (int jj = 0; jj < T; ++jj) {
+                const int j = k == 0 ? T - 1 - jj : jj;     // (first k-step: tile 0 last, it overwrites the shared initial value)
+                acc[j] = DT::mfma(g[gi & 1][i], X[j][k >> 1].k[k & 1], k == 0 ? acc[0] : acc[j]);
+                if ((last && EARLY) || GAPS) {
                     DAL3_SCHED_FENCE();
-                    if (last) lp_refill_gap<SEG, 4 * T>(ring, i * T + j);
-                    gap(k * T + j);
+                    if (last && EARLY) {
+                        if (F_NEXT >= 0 && i == 0 && jj == 0) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) g[0][q] = ring.template frag<DT>(F_NEXT + q);
+                        }
+                        lp_refill_gap<SEG, 4 * T>(ring, i * T + jj);
+                    }
+                    gap(k * T + jj);
                     DAL3_SCHED_FENCE();
                 }
             }
         }
-        if (last) ring.issue_done();
+        if (last && EARLY) ring.issue_done();
         DAL3_SCHED_FENCE();
     }
 }

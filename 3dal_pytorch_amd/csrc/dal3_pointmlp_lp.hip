@@ -29,8 +29,18 @@ extern "C" int dal3_debug_set_stamps_lp_enc(void* p) {
         __builtin_amdgcn_sched_barrier(0);                                                        \
         if (lane == 0 && grp < 4096) g_stamps_lp[(grp * 4 + wave) * 8 + (k)] = t_;                \
     } while (0)
+// sub-phase stamps (16 per wave and group) behind the 4096 x 4 x 8 phase stamps
+#define LP_SUB(k)                                                                                 \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (lane == 0 && grp < 4096) g_stamps_lp[4096 * 4 * 8 + (grp * 4 + wave) * 32 + (k)] = t_; \
+    } while (0)
 #else
 #define LP_STAMP(k)
+#define LP_SUB(k)
 #endif
 
 // bytes of the point heads' small LDS arrays (biases, maxima, first layer), rounded up to 1 KiB
@@ -160,11 +170,20 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     const float* s_db2 = s_bias + 64;
     const float* s_db3 = s_bias + 320;
     const float* s_db4 = s_bias + 448;
-    const float* s_dw5 = s_bias + 576;
     const float* s_db5 = s_bias + 832;
     LdsRing<SEG> ring;
     ring.init(w.dec_stream, smem + LP_DEC_SMALL_BYTES, LP_DEC_SEGS, wave, lane, true);
 
+    // A lane id the compiler cannot hoist out of the group loop: addresses derived from the kernel's `lane` are loop
+    // invariants, hipcc keeps them across the main loop where registers are scarcest and spills them, and every reload is
+    // a scratch read behind an `s_waitcnt vmcnt(0)` that also waits for whatever LDS-DMA the ring has in flight (stamps:
+    // 2,500 ticks per group in front of the logit stores, 700 in front of publish_gb). Rebuilt where it is used, the
+    // id costs two instructions and no register across the loop.
+    auto fresh_lane = [&]() {
+        unsigned z = 0;
+        asm volatile("" : "+v"(z));
+        return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+    };
     // the NEXT group's points and dconv1 term are fetched into registers in the middle of the current group (after
     // its main loop), a good 15 us before they are needed: read at the top of a group they cost an exposed HBM round
     // trip per group (stamps: 15 % of the kernel sat in front of the first MFMA)
@@ -173,9 +192,7 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         // the lane id goes through an opaque asm: hipcc otherwise computes the per-lane address parts once, keeps them
         // (64-bit, per tile and channel) across the main loop where registers are scarcest, spills them, and each
         // reload is a scratch read behind an s_waitcnt vmcnt(0) that drains the ring's LDS-DMA (2,400 ticks per group)
-        unsigned z = 0;                                    // (not `lane`, and not hoistable: either would be spilled too)
-        asm volatile("" : "+v"(z));
-        const int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+        const int l = fresh_lane();                        // (not `lane`, and not hoistable: either would be spilled too)
         const int64_t bb = g / tiles_per_item;
         load_points<2, T>(pts, bb, ((g % tiles_per_item) * LP_WAVES + wave) * (32 * T), n_pts, c_in, in_nx, l);
         gb_nx[0] = gbias[bb * 512 + wave * 64 + l];
@@ -184,9 +201,15 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     prefetch(blockIdx.x);
     // The crop's dconv1 term goes to LDS one group ahead: here for the first group, in front of dconv4 for the others
     // (nobody reads the old one after the main loop; dconv4's barrier, here acquire(), publishes the new one).
+    // (the compiler's wait for gb_nx is an `s_waitcnt vmcnt(0)`: it does not know of the ring's LDS-DMA, which it
+    // therefore also waits for — so this is called where the ring's last refill is oldest, and the points fetched with
+    // gb_nx are declared used here too, so that the same wait serves them)
     auto publish_gb = [&]() {
-        s_gb[threadIdx.x] = gb_nx[0];
-        s_gb[256 + threadIdx.x] = gb_nx[1];
+        const int t = wave * 64 + fresh_lane();
+        s_gb[t] = gb_nx[0];
+        s_gb[256 + t] = gb_nx[1];
+#pragma unroll
+        for (int j = 0; j < T; ++j) asm volatile("" : "+v"(in_nx[j][0]), "+v"(in_nx[j][1]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     publish_gb();
@@ -198,50 +221,63 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     LP_STAMP(0);
 
     ActTile<DT> x1[T][2], x2[T][2];
+    const int lnA = fresh_lane(), hA = lnA >> 5;          // for the prologue (see fresh_lane)
     {
         // conv1 in fp32 (first_layer of dal3_device.h, operands from LDS). Segment 0 (conv2 | dconv1a chunk 0) is open:
         // by the acquire in front of the loop for the first group, by the previous group's dconv4 for the others.
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const f32x16 bv = tile_from_channels(s_b1 + 32 * mt, h);
+            const f32x16 bv = tile_from_channels(s_b1 + 32 * mt, hA);
 #pragma unroll
             for (int j = 0; j < T; ++j) {
                 f32x16 acc = bv;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) acc = mfma32(s_w1[(mt * 2 + k) * 64 + lane], in_nx[j][k], acc);
+                for (int k = 0; k < 2; ++k) acc = mfma32(s_w1[(mt * 2 + k) * 64 + lnA], in_nx[j][k], acc);
                 x1[j][mt] = pack_relu<DT>(acc);
             }
         }
     }
-    lp_layer<DT, 2, 2, T, SEG, 0, 2>(ring, 0, s_bias, x1, x2, lane);
+    LP_SUB(8);
+    lp_layer<DT, 2, 2, T, SEG, 0, 2>(ring, 0, s_bias, x1, x2, lnA);
+    LP_SUB(9);
 
     f32x16 a2[T][8];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
-        const f32x16 bv = tile_from_channels(s_db2 + 32 * mt, h);
+        const f32x16 bv = tile_from_channels(s_db2 + 32 * mt, hA);
 #pragma unroll
         for (int j = 0; j < T; ++j) a2[j][mt] = bv;
     }
+    LP_SUB(10);
     f32x16 tA[T], tB[T];
     typedef typename DT::v8 frag_t;
     // LDS fragment reads are issued a whole group of four (= 8 MFMAs, 256 cycles) before their MFMAs: with the read
     // right in front of its MFMA (what the compiler does on its own) every fragment exposed the LDS latency
+#ifndef DAL3_ABL
+#define DAL3_ABL 0                                        // timing experiments only (tools/README.md): bit mask of main-loop parts left out
+#endif
     auto load4 = [&](frag_t (&d)[4], int f0) {
+        if (DAL3_ABL & 8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(d[i]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) d[i] = ring.template frag<DT>(f0 + i);
     };
     // t <- the crop's dconv1 term of a chunk (the accumulators' initial value), read from LDS straight into both
     // tiles' registers a half-iteration before the chunk's MFMAs
     auto init_chunk = [&](f32x16 (&t)[T], int chunk) {
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-            int off = 32 * (chunk & 15);
-            asm volatile("" : "+v"(off));                  // one read per tile: hipcc would read once and copy 16 registers
-            t[j] = tile_from_channels(s_gb + off, h);      // (the offset, not the pointer: that would lose its address space)
+        if (DAL3_ABL & 16) {
+            asm volatile("" : "+v"(t[0]));
+            return;
         }
+        // tile 0's registers only: the term is the same for both tiles (one crop), MfmaAsm::block4x2 feeds it to both
+        t[0] = tile_from_channels(s_gb + 32 * (chunk & 15), h);
     };
     auto dconv1_chunk = [&](f32x16 (&t)[T], const frag_t (&q)[4]) {
         static_assert(T == 2, "MfmaAsm::block4x2 is written for two point tiles");
+        if (DAL3_ABL & 64) return;
         MfmaAsm<DT>::block4x2(t[0], t[1], q[0], q[1], q[2], q[3], x2[0][0].k[0], x2[0][0].k[1], x2[0][1].k[0],
                               x2[0][1].k[1], x2[1][0].k[0], x2[1][0].k[1], x2[1][1].k[0], x2[1][1].k[1]);
     };
@@ -315,6 +351,7 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         for (int j = 0; j < T; ++j) pA[j] = pack_relu<DT>(tA[j]);
         init_chunk(tA, 2);
     }
+    LP_SUB(11);
     ring.acquire();                                        // segment 1
     load4(q, 0);
     load4(ga, 4);
@@ -345,6 +382,10 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     };
     auto pack_pair = [&](int4_t (&w)[T][2], const f32x16 (&t)[T], int k) {   // register pair k of the 16 (T x 2 x 4) of a chunk
         const int tj = k >> 3, ts = (k >> 2) & 1, ti = k & 3;
+        if (DAL3_ABL & 32) {
+            asm volatile("" : "=v"(w[tj][ts][ti]));
+            return;
+        }
         w[tj][ts][ti] = pack_relu_pair<DT>(t[tj][8 * ts + 2 * ti], t[tj][8 * ts + 2 * ti + 1]);
     };
     auto packed_into = [&](ActTile<DT> (&pn)[T], const int4_t (&w)[T][2]) {
@@ -357,7 +398,7 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     for (int i = 0; i < 8; ++i) {
         const bool refill = i > 0;                         // (iteration 0's slot was refilled by the acquire() above)
         auto part = [&](int k) {
-            if (refill) ring.issue_part(k);
+            if (refill && !(DAL3_ABL & 1)) ring.issue_part(k);
         };
         DAL3_SCHED_FENCE();
         dconv1_chunk(tB, q);                               // chunk 2i+1
@@ -408,10 +449,14 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
             }
         });
         DAL3_SCHED_FENCE();
+        if (i == 0) LP_SUB(12);
+        if (i == 1) LP_SUB(13);
     }
     // the refill the loop's last barrier made room for has no next iteration to ride on: in one piece, once per group
 #pragma unroll
-    for (int k = 0; k < ML; ++k) ring.issue_part(k);
+    for (int k = 0; k < ML; ++k) {
+        if (!(DAL3_ABL & 1)) ring.issue_part(k);
+    }
     ring.issue_done();
     DAL3_SCHED_FENCE();
 #else
@@ -466,12 +511,16 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         prefetch(nx < n_groups ? nx : grp);               // (the last group re-reads itself: uniform control flow)
         __builtin_amdgcn_sched_barrier(0);                 // pinned here: left alone hipcc sinks loads to their first use
     }
+    frag_t gq[2][4];                                        // dconv3's first four fragments: its segment has been open
+    load4(gq[0], 0);                                       // since the main loop's last barrier — read in front of the a2
+    DAL3_SCHED_FENCE();                                    // pack, not behind it with the matrix pipe waiting
     ActTile<DT> xd[T][8], y3[T][4];
 #pragma unroll
     for (int j = 0; j < T; ++j) {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) xd[j][mt] = pack_relu<DT>(a2[j][mt]);
     }
+    const int lnB = fresh_lane(), hB = lnB >> 5;         // for the rest of the group (see fresh_lane)
     LP_STAMP(3);
     // dconv3 (two segments of two out-tiles) and dconv4 (one segment): each segment's last block opens the next
     // segment itself, under its last eight MFMAs. Two accumulator sets alternate: a finished tile is read out of its
@@ -480,10 +529,8 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     static_assert(T == 2, "gap schedules below are written for two point tiles");
     f32x16 accA[T], accB[T];
     int4_t pw[T][2];
-    auto bias_tile = [&](f32x16 (&acc)[T], const float* bias) {
-        const f32x16 bv = tile_from_channels(bias, h);
-#pragma unroll
-        for (int j = 0; j < T; ++j) acc[j] = bv;
+    auto bias_tile = [&](f32x16 (&acc)[T], const float* bias) {  // tile 0's registers: lp_block feeds it to every tile
+        acc[0] = tile_from_channels(bias, hB);
     };
     auto pack_piece = [&](const f32x16 (&acc)[T], int p) {       // register pair p of the 16 (T x 2 x 4) of a tile
         const int tj = p >> 3, ts = (p >> 2) & 1, ti = p & 3;
@@ -496,77 +543,78 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
             y3[j][m].k[1] = __builtin_bit_cast(frag_t, pw[j][1]);
         }
     };
+    // dconv3 | dconv4 | dconv5 as ONE chain of blocks: every block reads the first four fragments of the next one under
+    // its own MFMAs (lp_block F_NEXT / CARRY_IN), the chain's first four were read in front of the a2 pack above.
     bias_tile(accA, s_db3);
-    lp_block<DT, 8, T, SEG>(ring, 0, xd, accA);                                          // dconv3 tile 0
+    lp_block<DT, 8, T, SEG, false, true, 16>(ring, 0, xd, accA, gq);                     // dconv3 tile 0
+    LP_SUB(0);
     bias_tile(accB, s_db3 + 32);
-    lp_block<DT, 8, T, SEG, true>(ring, 16, xd, accB, [&](int n) {                       // tile 1 | pack tile 0
+    lp_block<DT, 8, T, SEG, true, true, 0>(ring, 16, xd, accB, gq, [&](int n) {          // tile 1 | pack tile 0
         if (n % 2 == 0) pack_piece(accA, n / 2);
     });
     packed_to(0);
+    LP_SUB(1);
     bias_tile(accA, s_db3 + 64);
-    lp_block<DT, 8, T, SEG>(ring, 0, xd, accA, [&](int n) {                              // tile 2 | pack tile 1
+    lp_block<DT, 8, T, SEG, false, true, 16>(ring, 0, xd, accA, gq, [&](int n) {         // tile 2 | pack tile 1
         if (n % 2 == 0) pack_piece(accB, n / 2);
     });
     packed_to(1);
-    bias_tile(accB, s_db3 + 96);
-    lp_block<DT, 8, T, SEG, true>(ring, 16, xd, accB, [&](int n) {                       // tile 3 | pack tile 2
+    LP_SUB(2);
+    publish_gb();                                          // the next group's (fetched after the main loop); nobody reads
+    bias_tile(accB, s_db3 + 96);                           // s_gb between the main loop's last barrier and the next group
+    lp_block<DT, 8, T, SEG, true, true, 0>(ring, 16, xd, accB, gq, [&](int n) {          // tile 3 | pack tile 2
         if (n % 2 == 0) pack_piece(accA, n / 2);
     });
     packed_to(2);
-    publish_gb();                                          // the next group's (fetched after the main loop)
+    LP_SUB(3);
     LP_STAMP(4);
-    f32x16 y4[T][4];
-    auto relu_piece = [&](const f32x16 (&acc)[T], int m, int n) {    // two of the 32 accumulator registers of a tile
+    // dconv4's output is rounded to 16 bits like every other hidden layer: dconv5 (128 -> 2) then is ONE more out-tile
+    // on the matrix pipe — eight fragments at the end of dconv4's ring segment, rows 0 and 1 real, the rest zero; 16
+    // MFMAs per wave and group — instead of 256 fp32 FMAs per lane on the VALU with the matrix pipe idle (stamps: 3,800
+    // ticks per group, 7 % of the kernel). Rows 0 / 1 of the result are registers 0 / 1 of lanes 0..31: no lane exchange.
+    ActTile<DT> y4p[T][4];
+    auto packed_to4 = [&](int m) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int idx = 2 * n + e, tj = idx >> 4, r = idx & 15;
-            y4[tj][m][r] = relu1(acc[tj][r]);
+        for (int j = 0; j < T; ++j) {
+            y4p[j][m].k[0] = __builtin_bit_cast(frag_t, pw[j][0]);
+            y4p[j][m].k[1] = __builtin_bit_cast(frag_t, pw[j][1]);
         }
     };
     bias_tile(accA, s_db4);
-    lp_block<DT, 4, T, SEG>(ring, 0, y3, accA, [&](int n) {                              // dconv4 tile 0 | pack dconv3 tile 3:
+    lp_block<DT, 4, T, SEG, false, true, 8>(ring, 0, y3, accA, gq, [&](int n) {          // dconv4 tile 0 | pack dconv3 tile 3:
         if (n < 8) {                                                                     // its k-steps 6, 7 (n >= 12) are
             pack_piece(accB, 2 * n);                                                     // the first to need it
             pack_piece(accB, 2 * n + 1);
         }
         if (n == 7) packed_to(3);
     });
+    LP_SUB(4);
     bias_tile(accB, s_db4 + 32);
-    lp_block<DT, 4, T, SEG>(ring, 8, y3, accB, [&](int n) { relu_piece(accA, 0, n); });   // tile 1 | ReLU tile 0
+    lp_block<DT, 4, T, SEG, false, true, 16>(ring, 8, y3, accB, gq, [&](int n) { pack_piece(accA, n); });    // tile 1 | pack tile 0
+    packed_to4(0);
+    LP_SUB(5);
     bias_tile(accA, s_db4 + 64);
-    lp_block<DT, 4, T, SEG>(ring, 16, y3, accA, [&](int n) { relu_piece(accB, 1, n); });  // tile 2 | ReLU tile 1
+    lp_block<DT, 4, T, SEG, false, true, 24>(ring, 16, y3, accA, gq, [&](int n) { pack_piece(accB, n); });   // tile 2 | pack tile 1
+    packed_to4(1);
+    LP_SUB(6);
     bias_tile(accB, s_db4 + 96);
-    lp_block<DT, 4, T, SEG, true>(ring, 24, y3, accB, [&](int n) { relu_piece(accA, 2, n); });   // tile 3 | ReLU tile 2,
-#pragma unroll                                                                                  // opens the next group's segment 0
-    for (int j = 0; j < T; ++j) y4[j][3] = relu16(accB[j]);
-
+    lp_block<DT, 4, T, SEG, false, true, 32>(ring, 24, y3, accB, gq, [&](int n) { pack_piece(accA, n); });   // tile 3 | pack tile 2
+    packed_to4(2);
     LP_STAMP(5);
-    float l0[T], l1[T];
-#pragma unroll
-    for (int j = 0; j < T; ++j) l0[j] = l1[j] = 0.0f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 wa = *reinterpret_cast<const f32x4*>(s_dw5 + 32 * kt + 8 * q + 4 * h);
-            const f32x4 wb = *reinterpret_cast<const f32x4*>(s_dw5 + 128 + 32 * kt + 8 * q + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int j = 0; j < T; ++j) {
-                    l0[j] = fmaf(wa[e], y4[j][kt][4 * q + e], l0[j]);
-                    l1[j] = fmaf(wb[e], y4[j][kt][4 * q + e], l1[j]);
-                }
-            }
+    bias_tile(accA, s_db5);                                                              // (db5 padded to 32 rows)
+    lp_block<DT, 4, T, SEG, true, true>(ring, 32, y4p, accA, gq, [&](int n) {            // dconv5 | pack dconv4 tile 3 (its
+        if (n < 8) {                                                                     // k-steps 6, 7 need it); the second
+            pack_piece(accB, 2 * n);                                                     // half opens the next group's
+            pack_piece(accB, 2 * n + 1);                                                 // segment 0
         }
-    }
-    const float bias0 = s_db5[0], bias1 = s_db5[1];
+        if (n == 7) packed_to4(3);
+    });
+    LP_SUB(7);
 #pragma unroll
     for (int j = 0; j < T; ++j) {
-        const float s0 = l0[j] + __shfl_xor(l0[j], 32) + bias0;
-        const float s1 = l1[j] + __shfl_xor(l1[j], 32) + bias1;
-        const int n = n0 + 32 * j + (lane & 31);
-        if (h == 0 && n < n_pts) {
+        const float s0 = accA[j][0], s1 = accA[j][1];      // rows 0, 1 of the tile: lanes 0..31, one point each
+        const int n = n0 + 32 * j + (lnB & 31);
+        if (hB == 0 && n < n_pts) {
             f32x2 o;
             o[0] = s0;
             o[1] = s1;

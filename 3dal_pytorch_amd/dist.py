@@ -60,20 +60,24 @@ class BoxGatherer:
             dist.get_world_size(group) > 1 or os.environ.get("DAL3_FORCE_DIST") == "1")
         self.world = dist.get_world_size(group) if self.active else 1
         self.per = (n_items + self.world - 1) // self.world
-        self.send = [torch.zeros((self.per, width), dtype=torch.float32, device=device) for _ in range(slots)]
+        self.slots = slots
+        self.send = [torch.zeros((self.per, width), dtype=torch.float32, device=device) for _ in range(slots)] \
+            if self.active else None
         self.recv = [torch.empty((self.world * self.per, width), dtype=torch.float32, device=device)
                      for _ in range(slots)] if self.active else None
-        self.pending = []                        # [(slot, work)] oldest first
+        self.pending = []                        # [(slot | local boxes, work)] oldest first
         self.turn = 0
 
     def submit(self, local_boxes):
-        if len(self.pending) == len(self.send):
+        if len(self.pending) == self.slots:
             raise RuntimeError("BoxGatherer: collect() before submitting more batches than there are slots")
+        if not self.active:                      # one rank: the boxes themselves, no staging copy
+            self.pending.append((local_boxes, None))
+            return
         slot = self.turn
-        self.turn = (self.turn + 1) % len(self.send)
+        self.turn = (self.turn + 1) % self.slots
         self.send[slot][: local_boxes.shape[0]].copy_(local_boxes)
-        work = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True) \
-            if self.active else None
+        work = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
         self.pending.append((slot, work))
 
     def collect(self, keep=0):
@@ -82,7 +86,7 @@ class BoxGatherer:
             return None
         slot, work = self.pending.pop(0)
         if work is None:
-            return self.send[slot][: self.n_items]
+            return slot[: self.n_items]
         work.wait()                              # orders the current stream behind the collective; no host sync
         return self.recv[slot][: self.n_items]
 

@@ -7,6 +7,8 @@ hipStreamBeginCapture on ROCm; lib3dal_hip.so only ever enqueues on the stream i
 nothing, so its launches are captured as they are) and replays it per call. Requirements: eval mode, the device
 sampler (the NumPy sampler needs a host round trip in the middle), fixed (B, N).
 """
+import collections
+
 import torch
 
 from ._heads import Workspace
@@ -75,6 +77,66 @@ class CapturedRefine:
             self._capture()
         self.graph.replay()
         return self.boxes
+
+
+class StreamPipe:
+    """Consecutive `model.refine()` calls on `depth` HIP streams, each with a workspace of its own.
+
+    At the eval drivers' batch (64 crops x 4096 points, static_eval.py:299) one call is two big kernels and ten
+    small ones (the per-crop FC layers, the sampler, the fills, the box decode: 4-27 us each, 86 us of a 1.55 ms
+    call) during which most of the chip idles, and the big kernels' last wave of workgroups leaves CUs empty too.
+    Batches are independent, so the next call can fill those holes: `submit()` enqueues a call on the next stream
+    (it waits for what the caller's stream has produced so far: the inputs), `collect(keep)` hands back finished
+    boxes in submission order after making the caller's stream wait for them, leaving `keep` calls in flight.
+
+        pipe = StreamPipe(model)                      # eval mode; any sampler that needs no host round trip
+        for batch in batches:
+            pipe.submit(*batch)
+            for boxes in pipe.collect(keep=1): ...
+        for boxes in pipe.collect(): ...
+    """
+
+    def __init__(self, model, depth=2):
+        if model.training:
+            raise RuntimeError("StreamPipe runs the eval-mode path: call model.eval() first")
+        if getattr(model, "sampler", "device") != "device":
+            raise RuntimeError("StreamPipe needs sampler='device' (the NumPy sampler synchronises with the host)")
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.model = model
+        self.streams = [torch.cuda.Stream() for _ in range(depth)]
+        self.workspaces = [Workspace() for _ in range(depth)]
+        self.pending = collections.deque()
+        self.submitted = 0
+
+    def submit(self, *inputs):
+        k = self.submitted % len(self.streams)
+        stream, model = self.streams[k], self.model
+        stream.wait_stream(torch.cuda.current_stream())
+        saved = model._ws
+        model._ws = self.workspaces[k]                      # (a call still running on the other stream uses the other one)
+        try:
+            with torch.cuda.stream(stream):
+                boxes = model.refine(*inputs)
+                done = torch.cuda.Event()
+                done.record(stream)
+        finally:
+            model._ws = saved
+        for t in inputs:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)                     # the caller may free them while the call is in flight
+        self.pending.append((boxes, done))
+        self.submitted += 1
+
+    def collect(self, keep=0):
+        out = []
+        cur = torch.cuda.current_stream()
+        while len(self.pending) > keep:
+            boxes, done = self.pending.popleft()
+            cur.wait_event(done)
+            boxes.record_stream(cur)
+            out.append(boxes)
+        return out
 
 
 class CapturedTrainStep:

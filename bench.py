@@ -52,6 +52,7 @@ sm = importlib.import_module("3dal_pytorch_amd.static_model")
 dm = importlib.import_module("3dal_pytorch_amd.dynamic_model")
 dal3_dist = importlib.import_module("3dal_pytorch_amd.dist")
 launch = importlib.import_module("3dal_pytorch_amd.launch")
+dal3_graph = importlib.import_module("3dal_pytorch_amd.graph")
 
 # dense peaks per arithmetic dtype (MI355X_MICROARCH.md "Chip-level parameters": f32 MFMA = v_mfma_f32_32x32x2_f32,
 # exact f32; bf16/fp16 ~2.5 PF dense)
@@ -367,8 +368,14 @@ def time_steps(wl, dev, steps, warmup, use_dist, overlap=True):
             torch.distributed.barrier()
         torch.cuda.synchronize()
     last = [None] * len(wl.parts)
+    pipe = getattr(wl, "pipe", None)
 
     def step(final=False):
+        if pipe is not None:                                # consecutive steps on alternating streams (one head, no ranks)
+            pipe.submit(*wl.inputs)
+            for got in pipe.collect(keep=0 if final else len(pipe.streams) - 1):
+                last[0] = got
+            return
         for i, (fn, _, _) in enumerate(wl.parts):
             wl.gatherers[i].submit(fn())
             got = wl.gatherers[i].collect(keep=1 if (overlap and not final) else 0)
@@ -478,6 +485,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / maxpool / configs / cpu_baseline legs")
     ap.add_argument("--only-maxpool", action="store_true", help="run only the standalone max-pool kernel (profiling)")
     ap.add_argument("--serial-gather", action="store_true", help="wait for each step's all-gather inside the step")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="run consecutive steps on this many HIP streams (graph.StreamPipe): small batches, one GPU")
     ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5"],
                     help="BASELINE.json configs by name: C2 = the default (static, 4096 x 1024, fp32); C3 = dynamic head, "
                          "1024 items x 5 x 1024 pts, bf16; C4 = one segment (64 static crops x 4096 pts + 40 dynamic tracks), sharded "
@@ -534,6 +543,11 @@ def main():
         return
 
     wl = build_workload(args, dev, rank, world)
+    if args.streams > 1:
+        if use_dist or args.config == "C4":
+            sys.exit("bench.py: --streams is for single-GPU, single-head runs")
+        wl.pipe = dal3_graph.StreamPipe(wl.model, depth=args.streams)
+        wl.desc += f", consecutive steps on {args.streams} HIP streams"
     peak = MFMA_PEAK_TFLOPS[args.precision]
     dt, per_step, _ = time_steps(wl, dev, args.steps, args.warmup, use_dist, overlap=not args.serial_gather)
     ms_per_step = dt / args.steps * 1e3

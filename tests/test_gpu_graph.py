@@ -166,3 +166,30 @@ def test_a_captured_training_draw_advances_on_every_replay():
     assert outs[1][2] == outs[0][2] + 1 and outs[2][3] == outs[1][3] + 1
     assert not torch.equal(outs[0][0], outs[1][0]) and not torch.equal(outs[1][0], outs[2][0])       # new object points
     assert not torch.equal(outs[0][1], outs[1][1]) and not torch.equal(outs[1][1], outs[2][1])       # new Dropout pattern
+
+
+def test_stream_pipe_returns_what_sequential_calls_return():
+    """graph.StreamPipe: consecutive refine() calls on two streams with a workspace each; the boxes come back in
+    submission order and are bitwise what the same calls give one after the other (different batches, different
+    item offsets, a batch size that changes in between)"""
+    model = build_model("static_one", synth.state_dict("static_one", seed=33))
+    batches = []
+    for k, (B, N) in enumerate([(8, 1024), (8, 1024), (5, 512), (8, 1024), (16, 2048), (8, 1024)]):
+        p, i, _ = synth.static_crops(B, N, seed=40 + k)
+        batches.append((torch.from_numpy(p).cuda().transpose(2, 1), torch.from_numpy(i).cuda()))
+    want = []
+    for k, b in enumerate(batches):
+        model.item_offset = 100 * k
+        want.append(model.refine(*b).clone())
+    pipe = graph.StreamPipe(model, depth=2)
+    got = []
+    for k, b in enumerate(batches):
+        model.item_offset = 100 * k
+        pipe.submit(*b)
+        got += pipe.collect(keep=1)
+    got += pipe.collect()
+    torch.cuda.synchronize()
+    assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+    model.train()
+    with pytest.raises(RuntimeError):
+        graph.StreamPipe(model)
