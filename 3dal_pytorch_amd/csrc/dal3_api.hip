@@ -802,6 +802,34 @@ extern "C" int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int
     return 0;
 }
 
+extern "C" int dal3_tr_bn_stats(const float* z, int64_t M, int C, int64_t ldz, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
+                                float* scale, float* shift, void* workspace, size_t workspace_bytes, dal3_stream stream) {
+    if (!z || M < 2 || C <= 0 || C % 4 || ldz < C || ldz % 4 || !gamma || !beta || !mu || !rstd || !scale || !shift ||
+        (!running_mean != !running_var))
+        return fail(DAL3_EINVAL, "tr_bn_stats: bad argument (C and the row stride must be multiples of 4, M >= 2)");
+    if (!workspace || workspace_bytes < tr_colred_workspace_bytes(M, C))
+        return fail(DAL3_EWORKSPACE, "tr_bn_stats: workspace smaller than dal3_tr_colred_workspace_bytes()");
+    HIP_TRY(launch_tr_bn_stats(z, M, C, ldz, gamma, beta, running_mean, running_var, momentum, eps, mu, rstd, scale, shift,
+                               static_cast<double*>(workspace), static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_bnbwd_sums(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda,
+                                  const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
+                                  const float* mu, const float* rstd, const float* gamma, float* dgamma, float* dbeta,
+                                  float* k1, float* k2, float* k3, void* workspace, size_t workspace_bytes,
+                                  dal3_stream stream) {
+    if (!z || M <= 0 || C <= 0 || C % 4 || ldz < C || ldz % 4 || (da && ldda % 4) || !scale || !shift || !mu || !rstd ||
+        (!da && (!dg || !arg || seg <= 0)) || !gamma || !dgamma || !dbeta || !k1 || !k2 || !k3)
+        return fail(DAL3_EINVAL, "tr_bnbwd_sums: bad argument (C and the row strides must be multiples of 4)");
+    if (!workspace || workspace_bytes < tr_colred_workspace_bytes(M, C))
+        return fail(DAL3_EWORKSPACE, "tr_bnbwd_sums: workspace smaller than dal3_tr_colred_workspace_bytes()");
+    HIP_TRY(launch_tr_bnbwd_sums(z, M, C, ldz, da, ldda, dg, arg, seg, scale, shift, mu, rstd, gamma, dgamma, dbeta, k1, k2,
+                                 k3, static_cast<double*>(workspace), static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_tr_bn_finalize(const double* sums, int C, int64_t M, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, float eps, float* mu,
                                    float* rstd, float* scale, float* shift, dal3_stream stream) {

@@ -411,7 +411,6 @@ __device__ __forceinline__ void lp_tile_max_t(const f32x16 (&acc)[T], const floa
 template <class DT, int KT, int T, int SEG, int TPS, bool FIRST, class Ring>
 __device__ __forceinline__ void lp_max_tiles(Ring& ring, const ActTile<DT> (&X)[T][KT], const float* bias,
                                              int* smax, int lane, typename DT::v8 (&g)[2][4], f32x16 (&acc)[2][T]) {
-    typedef typename DT::v8 frag_t;
     constexpr int FPT = KT * 2, NG = TPS * FPT / 4, ML = Ring::MY_LOADS;
     static_assert(FPT % 8 == 0, "at least two groups of four fragments per tile");
     static_assert(NG % 2 == 0 && TPS % 2 == 0, "the carried group must be g[0], the carried tile acc[1]");

@@ -134,9 +134,6 @@ __global__ __launch_bounds__(256, DAL3_LP_ENC_SLOTS == 2 ? 2 : 1) void ins_seg_e
   }
 }
 
-#ifndef DAL3_LP_SPREAD
-#define DAL3_LP_SPREAD 1                                 // main-loop placement of refill pieces and packing: see the kernel
-#endif
 #define LP_DEC_SMALL_BYTES 7168                          // (864 + 512 + 64 + 256) floats, rounded up to 1 KiB
 // ------------------------------------------------------------------------------------------------
 // Persistent: 256 workgroups (one per CU: the ring takes 120 of the 160 KiB of LDS) each walk the 256-point groups
@@ -281,64 +278,6 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         MfmaAsm<DT>::block4x2(t[0], t[1], q[0], q[1], q[2], q[3], x2[0][0].k[0], x2[0][0].k[1], x2[0][1].k[0],
                               x2[0][1].k[1], x2[1][0].k[0], x2[1][0].k[1], x2[1][1].k[0], x2[1][1].k[1]);
     };
-    auto mma4 = [&](const frag_t (&a)[4], const ActTile<DT> (&p)[T], int mt0) {   // out-tiles mt0, mt0+1 x two k-steps
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < T; ++j) a2[j][mt0 + (i >> 1)] = DT::mfma(a[i], p[j].k[i & 1], a2[j][mt0 + (i >> 1)]);
-        }
-    };
-    // the same eight MFMAs with the ring's refill (10 LDS-DMA instructions and their address arithmetic) dealt out
-    // between them: issued in one piece after the barrier they cost ~650 cycles per segment with the matrix pipe idle
-    // The next segment's first eight fragments are read in the first gap (unconditionally: after the last round they
-    // are dconv3's, unused — a branch would cost the compiler its exact lgkmcnt) — behind the first MFMA, because
-    // hipcc cannot see acquire_wait()'s s_waitcnt and waits for `a` again: before the reads that wait is free.
-    auto mma4_refill = [&](const frag_t (&a)[4], const ActTile<DT> (&p)[T], int mt0, frag_t (&nq)[4], frag_t (&na)[4]) {
-        constexpr int ML = LdsRing<SEG>::MY_LOADS;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < T; ++j) {
-                a2[j][mt0 + (i >> 1)] = DT::mfma(a[i], p[j].k[i & 1], a2[j][mt0 + (i >> 1)]);
-                DAL3_SCHED_FENCE();
-                const int g = 2 * i + j;                   // gap 0..7: parts g, and 8 + g for g < ML - 8
-                if (g == 0) {
-                    load4(nq, 0);
-                    load4(na, 4);
-                }
-                if (g < ML) ring.issue_part(g);
-                if (8 + g < ML) ring.issue_part(8 + g);
-                DAL3_SCHED_FENCE();
-            }
-        }
-        static_assert(ML <= 16, "two parts per gap at most");
-        ring.issue_done();
-    };
-    // ... and with the 16-bit packing (ReLU, round) of a finished dconv1 chunk dealt out between them, two register
-    // pairs per gap: done in one piece (32 VALU) in front of the MFMAs that need it, the matrix pipe waited for it
-    auto mma4_pack = [&](const frag_t (&a)[4], const ActTile<DT> (&p)[T], int mt0, const f32x16 (&t)[T], ActTile<DT> (&pn)[T]) {
-        int4_t w[T][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < T; ++j) {
-                a2[j][mt0 + (i >> 1)] = DT::mfma(a[i], p[j].k[i & 1], a2[j][mt0 + (i >> 1)]);
-                DAL3_SCHED_FENCE();
-                const int g = 2 * i + j;                   // gap g packs register pairs 2g, 2g+1 of the 16 (T x 2 x 4)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int k = 2 * g + e, tj = k >> 3, ts = (k >> 2) & 1, ti = k & 3;
-                    w[tj][ts][ti] = pack_relu_pair<DT>(t[tj][8 * ts + 2 * ti], t[tj][8 * ts + 2 * ti + 1]);
-                }
-                DAL3_SCHED_FENCE();
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-            pn[j].k[0] = __builtin_bit_cast(frag_t, w[j][0]);
-            pn[j].k[1] = __builtin_bit_cast(frag_t, w[j][1]);
-        }
-    };
     frag_t q[4], ga[4], gb[4];
     ActTile<DT> pA[T], pB[T];
     {
@@ -356,9 +295,12 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     load4(q, 0);
     load4(ga, 4);
     LP_STAMP(1);
-#if DAL3_LP_SPREAD
-    // Segment 1+i: 1a(2i+1) | 2(2i) | 1a(2i+2) | 2(2i+1), as above. What differs from the schedule kept below
-    // (DAL3_LP_SPREAD=0) is WHERE the non-MFMA work sits. tools/ubench/lp_loop.hip prices it: four VALU in one MFMA
+    // Segment 1+i: 1a(2i+1) | 2(2i) | 1a(2i+2) | 2(2i+1). At the top of an iteration the segment's first eight fragments
+    // are already in registers; the barrier that opens the NEXT segment is taken as soon as the current one's last
+    // fragments have been read. pA / pB: the packed chunk the first / second half's dconv2 MFMAs consume; each is
+    // rewritten (from tA / tB, which is then re-initialised for the chunk after next) under the other half's MFMAs.
+    // WHERE the non-MFMA work sits (round 1 had the refill's ten pieces in the last eight gaps and the packing two
+    // pairs per gap): tools/ubench/lp_loop.hip prices it: four VALU in one MFMA
     // gap stretch that gap by ~13 cycles, two by ~2.5; ten LDS-DMA pieces dealt out one per gap in consecutive gaps
     // (plus the counted wait and barrier behind them) cost ~330 cycles per 80 MFMAs, one piece every eighth gap ~110.
     // So: the ring refill that the barrier at the end of iteration i-1 made room for is issued one piece after every
@@ -459,52 +401,6 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     }
     ring.issue_done();
     DAL3_SCHED_FENCE();
-#else
-    // Segment 1+i: 1a(2i+1) | 2(2i) | 1a(2i+2) | 2(2i+1). At the top of an iteration the segment's first eight
-    // fragments are already in registers: the barrier that opens the NEXT segment is taken as soon as the current
-    // one's last fragments have been read, its refill and the next segment's first reads go under the last eight MFMAs.
-    // pA / pB: the packed chunk the first / second half's dconv2 MFMAs consume; each is rewritten (from tA / tB, which
-    // is then re-initialised for the chunk after next) under the other half's MFMAs.
-    for (int i = 0; i < 8; ++i) {
-        DAL3_SCHED_FENCE();
-        dconv1_chunk(tB, q);                               // chunk 2i+1
-        load4(gb, 8);
-        DAL3_SCHED_FENCE();
-        mma4(ga, pA, 0);
-        DAL3_SCHED_FENCE();
-        load4(ga, 12);
-        DAL3_SCHED_FENCE();
-        mma4(gb, pA, 2);
-        DAL3_SCHED_FENCE();
-        load4(gb, 16);
-        DAL3_SCHED_FENCE();
-        mma4(ga, pA, 4);
-        DAL3_SCHED_FENCE();
-        load4(q, 20);
-        load4(ga, 24);
-        DAL3_SCHED_FENCE();
-        mma4_pack(gb, pA, 6, tB, pB);
-        init_chunk(tB, 2 * i + 3);
-        DAL3_SCHED_FENCE();
-        dconv1_chunk(tA, q);                               // chunk 2i+2 (16 = zero filler weights, result unused)
-        load4(gb, 28);
-        DAL3_SCHED_FENCE();
-        mma4(ga, pB, 0);
-        DAL3_SCHED_FENCE();
-        load4(ga, 32);
-        DAL3_SCHED_FENCE();
-        mma4(gb, pB, 2);
-        DAL3_SCHED_FENCE();
-        load4(gb, 36);
-        DAL3_SCHED_FENCE();
-        mma4_pack(ga, pB, 4, tA, pA);
-        init_chunk(tA, 2 * i + 4);
-        DAL3_SCHED_FENCE();
-        ring.acquire_wait();                               // segment 2+i (after the loop: dconv3's first)
-        mma4_refill(gb, pB, 6, q, ga);
-        DAL3_SCHED_FENCE();
-    }
-#endif
     LP_STAMP(2);
     {
         const int nx = grp + (int)gridDim.x;

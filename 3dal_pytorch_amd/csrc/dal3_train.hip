@@ -518,28 +518,42 @@ __global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict_
             rs = *reinterpret_cast<const f32x4*>(rstd + c);
         }
         const int64_t r1 = min(M, r0 + TR_RED_ROWS);
-        for (int64_t p = r0 + rl; p < r1; p += 16) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(z + p * ldz + c);
-            if (mode == 0) {
+        // four rows per trip, their loads issued together; rows past the end are clamped and masked, the order of the
+        // adds is unchanged
+        for (int64_t p0 = r0 + rl; p0 < r1; p0 += 64) {
+            f32x4 v4[4], d4[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s0[e] += v[e];
-                    s1[e] += (double)v[e] * v[e];
+            for (int u = 0; u < 4; ++u) {
+                const int64_t p = min(p0 + 16 * u, M - 1);
+                v4[u] = *reinterpret_cast<const f32x4*>(z + p * ldz + c);
+                if (mode == 1) {
+                    if (src.da) {
+                        d4[u] = *reinterpret_cast<const f32x4*>(src.da + p * src.ldda + c);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d4[u][e] = src.at(p, c + e, C);
+                    }
                 }
-            } else {
-                f32x4 d;
-                if (src.da) {
-                    d = *reinterpret_cast<const f32x4*>(src.da + p * src.ldda + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p0 + 16 * u >= r1) break;
+                const f32x4 v = v4[u];
+                if (mode == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s0[e] += v[e];
+                        s1[e] += (double)v[e] * v[e];
+                    }
                 } else {
+                    const f32x4 d = d4[u];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) d[e] = src.at(p, c + e, C);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float y = v[e] * sc[e] + sh[e];
-                    const float dy = y > 0.0f ? d[e] : 0.0f;
-                    s0[e] += dy;
-                    s1[e] += (double)dy * ((v[e] - mean[e]) * rs[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = v[e] * sc[e] + sh[e];
+                        const float dy = y > 0.0f ? d[e] : 0.0f;
+                        s0[e] += dy;
+                        s1[e] += (double)dy * ((v[e] - mean[e]) * rs[e]);
+                    }
                 }
             }
         }
@@ -566,9 +580,33 @@ __global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict_
 }
 
 // 16 channels x 16 partial-lanes per block: lane l adds the partials l, l+16, l+32, ... in that order, then the 16
-// lane sums are added in lane order — a fixed association, so the result is reproducible.
+// lane sums are added in lane order — a fixed association, so the result is reproducible. What follows the sums is
+// folded in (EPI): nothing (0: the sums themselves), the forward BatchNorm epilogue (1: batch mean / biased variance ->
+// mu, rstd, the folded affine scale = gamma*rstd, shift = beta - mean*scale, and the running statistics' update with
+// momentum and unbiased variance exactly as torch's BatchNorm1d does it), or the backward one (2: dbeta = sum dy,
+// dgamma = sum dy*xhat, and the coefficients of dz = k1*(dy - k2 - xhat*k3)) — a layer's statistics are two launches,
+// not three (the third was 15 us of launch latency for a few hundred bytes, 22 times per training step).
+struct BnEpi {
+    int64_t M;
+    const float* gamma;
+    const float* beta;          // forward
+    float* running_mean;
+    float* running_var;
+    float momentum, eps;
+    float* mu;                  // forward: out
+    float* rstd;                // forward: out; backward: in
+    float* scale;               // forward: out
+    float* shift;
+    float* dgamma;              // backward: out
+    float* dbeta;
+    float* k1;
+    float* k2;
+    float* k3;
+};
+
+template <int EPI>
 __global__ __launch_bounds__(256) void tr_colred_final_kernel(const double* __restrict__ part, int n_blocks, int C,
-                                                              double* __restrict__ out) {
+                                                              double* __restrict__ out, BnEpi e) {
     __shared__ double sm[2][16][16];
     const int cl = threadIdx.x & 15, l = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -588,8 +626,31 @@ __global__ __launch_bounds__(256) void tr_colred_final_kernel(const double* __re
             t0 += sm[0][i][cl];
             t1 += sm[1][i][cl];
         }
-        out[c] = t0;
-        out[C + c] = t1;
+        if (EPI == 0) {
+            out[c] = t0;
+            out[C + c] = t1;
+        } else if (EPI == 1) {
+            const double mean = t0 / (double)e.M;
+            double var = t1 / (double)e.M - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double rs = 1.0 / sqrt(var + (double)e.eps);
+            const double sc = (double)e.gamma[c] * rs;
+            e.mu[c] = (float)mean;
+            e.rstd[c] = (float)rs;
+            e.scale[c] = (float)sc;
+            e.shift[c] = (float)((double)e.beta[c] - mean * sc);
+            if (e.running_mean) {
+                e.running_mean[c] = (1.0f - e.momentum) * e.running_mean[c] + e.momentum * (float)mean;
+                e.running_var[c] = (1.0f - e.momentum) * e.running_var[c] +
+                                   e.momentum * (float)(var * ((double)e.M / (double)(e.M - 1)));
+            }
+        } else {
+            e.dbeta[c] = (float)t0;
+            e.dgamma[c] = (float)t1;
+            e.k1[c] = e.gamma[c] * e.rstd[c];
+            e.k2[c] = (float)(t0 / (double)e.M);
+            e.k3[c] = (float)(t1 / (double)e.M);
+        }
     }
 }
 
@@ -597,14 +658,45 @@ size_t tr_colred_workspace_bytes(int64_t M, int C) {
     return (size_t)((M + TR_RED_ROWS - 1) / TR_RED_ROWS) * C * 2 * sizeof(double);
 }
 
+static void colred_partials(const float* z, int64_t M, int C, int64_t ldz, int mode, const DaSrc& src, const float* scale,
+                            const float* shift, const float* mu, const float* rstd, double* part, hipStream_t s) {
+    const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
+    hipLaunchKernelGGL(tr_colred_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, s, z, M, C, ldz, mode, src, scale, shift, mu,
+                       rstd, part);
+}
+
 hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                             const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                             const float* mu, const float* rstd, double* part, double* out, hipStream_t s) {
     const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
-    DaSrc src{da, ldda, dg, arg, seg};
-    hipLaunchKernelGGL(tr_colred_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, s, z, M, C, ldz, mode, src, scale, shift, mu,
-                       rstd, part);
-    hipLaunchKernelGGL(tr_colred_final_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, nb, C, out);
+    colred_partials(z, M, C, ldz, mode, DaSrc{da, ldda, dg, arg, seg}, scale, shift, mu, rstd, part, s);
+    hipLaunchKernelGGL(tr_colred_final_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, s, part, nb, C, out, BnEpi{});
+    return hipGetLastError();
+}
+
+// batch statistics of z and everything the forward derives from them (see BnEpi)
+hipError_t launch_tr_bn_stats(const float* z, int64_t M, int C, int64_t ldz, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
+                              float* scale, float* shift, double* part, hipStream_t s) {
+    const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
+    colred_partials(z, M, C, ldz, 0, DaSrc{nullptr, 0, nullptr, nullptr, 0}, nullptr, nullptr, nullptr, nullptr, part, s);
+    BnEpi e{};
+    e.M = M, e.gamma = gamma, e.beta = beta, e.running_mean = running_mean, e.running_var = running_var;
+    e.momentum = momentum, e.eps = eps, e.mu = mu, e.rstd = rstd, e.scale = scale, e.shift = shift;
+    hipLaunchKernelGGL(tr_colred_final_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, s, part, nb, C, nullptr, e);
+    return hipGetLastError();
+}
+
+// the two sums of the BatchNorm/ReLU backward and its per-channel coefficients
+hipError_t launch_tr_bnbwd_sums(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda, const float* dg,
+                                const int32_t* arg, int64_t seg, const float* scale, const float* shift, const float* mu,
+                                const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* k1, float* k2,
+                                float* k3, double* part, hipStream_t s) {
+    const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
+    colred_partials(z, M, C, ldz, 1, DaSrc{da, ldda, dg, arg, seg}, scale, shift, mu, rstd, part, s);
+    BnEpi e{};
+    e.M = M, e.gamma = gamma, e.rstd = const_cast<float*>(rstd), e.dgamma = dgamma, e.dbeta = dbeta, e.k1 = k1, e.k2 = k2, e.k3 = k3;
+    hipLaunchKernelGGL(tr_colred_final_kernel<2>, dim3((C + 15) / 16), dim3(256), 0, s, part, nb, C, nullptr, e);
     return hipGetLastError();
 }
 
@@ -717,35 +809,37 @@ hipError_t launch_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, 
 #define WG_MT 4
 #define WG_KT 2
 #define WG_MIN_SLICE 128                 // fewest points per wave
-
 #define WG_KS 8                           // k-steps (pairs of points) per operand block
 
+template <int MT, int KT>
 struct WgBlock {
-    float av[WG_KS][WG_MT], bv[WG_KS][WG_KT];
+    float av[WG_KS][MT], bv[WG_KS][KT];
 };
 
 // pa / pb point at this lane's element of the block's first point row: dz[(p0 + h)][32*mt0 + m], a[(p0 + h)][32*kt0 + m];
 // the tiles of the block are 32 floats apart (an immediate offset), successive k-steps two rows apart.
-__device__ __forceinline__ void wg_load(WgBlock& bk, const float* __restrict__ pa, int64_t lddz, const float* __restrict__ pb,
-                                        int64_t lda, int n_mt, int n_kt) {
+template <int MT, int KT>
+__device__ __forceinline__ void wg_load(WgBlock<MT, KT>& bk, const float* __restrict__ pa, int64_t lddz,
+                                        const float* __restrict__ pb, int64_t lda, int n_mt, int n_kt) {
 #pragma unroll
     for (int s = 0; s < WG_KS; ++s) {
         const float* ra = pa + 2 * s * lddz;
         const float* rb = pb + 2 * s * lda;
 #pragma unroll
-        for (int t = 0; t < WG_MT; ++t) bk.av[s][t] = t < n_mt ? ra[32 * t] : 0.0f;
+        for (int t = 0; t < MT; ++t) bk.av[s][t] = t < n_mt ? ra[32 * t] : 0.0f;
 #pragma unroll
-        for (int k = 0; k < WG_KT; ++k) bk.bv[s][k] = k < n_kt ? rb[32 * k] : 0.0f;   // raw; activation at use
+        for (int k = 0; k < KT; ++k) bk.bv[s][k] = k < n_kt ? rb[32 * k] : 0.0f;   // raw; activation at use
     }
 }
 
-__device__ __forceinline__ void wg_compute(WgBlock& bk, f32x16 (&acc)[WG_MT][WG_KT], const float (&sc)[WG_KT],
-                                           const float (&sh)[WG_KT], bool act, int relu_in, int n_kt) {
+template <int MT, int KT>
+__device__ __forceinline__ void wg_compute(WgBlock<MT, KT>& bk, f32x16 (&acc)[MT][KT], const float (&sc)[KT],
+                                           const float (&sh)[KT], bool act, int relu_in, int n_kt) {
     if (act) {
 #pragma unroll
         for (int s = 0; s < WG_KS; ++s)
 #pragma unroll
-            for (int k = 0; k < WG_KT; ++k) {
+            for (int k = 0; k < KT; ++k) {
                 const float v = bk.bv[s][k] * sc[k] + sh[k];
                 bk.bv[s][k] = k < n_kt ? (relu_in ? fmaxf(v, 0.0f) : v) : 0.0f;
             }
@@ -753,11 +847,16 @@ __device__ __forceinline__ void wg_compute(WgBlock& bk, f32x16 (&acc)[WG_MT][WG_
 #pragma unroll
     for (int s = 0; s < WG_KS; ++s)
 #pragma unroll
-        for (int t = 0; t < WG_MT; ++t)
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int k = 0; k < WG_KT; ++k) acc[t][k] = mfma32(bk.av[s][t], bk.bv[s][k], acc[t][k]);
+            for (int k = 0; k < KT; ++k) acc[t][k] = mfma32(bk.av[s][t], bk.bv[s][k], acc[t][k]);
 }
 
+// MT x KT: the block of tiles a wave owns; NB: operand blocks (16 points each) in its ring — NB - 1 are in flight while
+// one is consumed. The big layers run <4, 2, 2> (128 accumulator registers, 96 of operands); layers with at most 64
+// output channels would leave most of that idle and are bound by the latency of their loads instead (one 16-point block
+// in flight per wave: 93 us for 134 MB), so they run <2, 2, 4>: three blocks in flight in the same registers (55 us).
+template <int MT, int KT, int NB>
 __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ a,
                                                        int64_t lda, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int relu_in, int64_t M, int c_out,
@@ -769,52 +868,73 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
     const int64_t slice = unit / (n_mb * n_kb);
     const int64_t p_begin = slice * slice_pts;
     if (p_begin >= M) return;
-    const int64_t p_end = min(M, p_begin + slice_pts);         // M, slice_pts % 32 == 0: whole blocks of 2*WG_KS = 16 points
-    const int mt0 = (blk / n_kb) * WG_MT, kt0 = (blk % n_kb) * WG_KT;
-    const int n_mt = min(WG_MT, c_out / 32 - mt0), n_kt = min(WG_KT, c_in / 32 - kt0);
-    float sc[WG_KT], sh[WG_KT];
+    const int64_t p_end = min(M, p_begin + slice_pts);         // M % 32 == 0, slice_pts % 64 == 0: whole 16-point blocks
+    const int mt0 = (blk / n_kb) * MT, kt0 = (blk % n_kb) * KT;
+    const int n_mt = min(MT, c_out / 32 - mt0), n_kt = min(KT, c_in / 32 - kt0);
+    float sc[KT], sh[KT];
 #pragma unroll
-    for (int k = 0; k < WG_KT; ++k) {
+    for (int k = 0; k < KT; ++k) {
         sc[k] = (scale && k < n_kt) ? scale[32 * (kt0 + k) + m] : 1.0f;
         sh[k] = (scale && k < n_kt) ? shift[32 * (kt0 + k) + m] : 0.0f;
     }
-    f32x16 acc[WG_MT][WG_KT];
+    f32x16 acc[MT][KT];
 #pragma unroll
-    for (int t = 0; t < WG_MT; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int k = 0; k < WG_KT; ++k) acc[t][k] = f32x16{};
+        for (int k = 0; k < KT; ++k) acc[t][k] = f32x16{};
     const bool act = scale != nullptr;
-    WgBlock b0, b1;                                            // ping-pong: loads of the next 16 points before these MFMAs
-    const float* pa = dz + (p_begin + h) * lddz + 32 * mt0 + m;
-    const float* pb = a + (p_begin + h) * lda + 32 * kt0 + m;
+    WgBlock<MT, KT> ring[NB];
+    const float* const pa0 = dz + (p_begin + h) * lddz + 32 * mt0 + m;
+    const float* const pb0 = a + (p_begin + h) * lda + 32 * kt0 + m;
     const int64_t sa = 2 * WG_KS * lddz, sb = 2 * WG_KS * lda;
-    // steady state without data-dependent branches around the loads: the slice is an even number of 16-point blocks
-    // (slice_pts % 32 == 0); the load issued during the LAST compute re-reads the slice's first block (valid memory,
-    // values unused) instead of being skipped.
+    // steady state without data-dependent branches around the loads: a load past the slice's end re-reads the slice's
+    // first block (valid memory, values unused) instead of being skipped
     const int64_t n_blk = (p_end - p_begin) / (2 * WG_KS);
-    const float* const pa0 = pa;
-    const float* const pb0 = pb;
-    wg_load(b0, pa, lddz, pb, lda, n_mt, n_kt);
-    for (int64_t i = 0; i < n_blk; i += 2) {
-        wg_load(b1, pa + sa, lddz, pb + sb, lda, n_mt, n_kt);
-        DAL3_SCHED_FENCE();
-        wg_compute(b0, acc, sc, sh, act, relu_in, n_kt);
-        DAL3_SCHED_FENCE();
-        const bool more = i + 2 < n_blk;
-        pa = more ? pa + 2 * sa : pa0;
-        pb = more ? pb + 2 * sb : pb0;
-        wg_load(b0, pa, lddz, pb, lda, n_mt, n_kt);
-        DAL3_SCHED_FENCE();
-        wg_compute(b1, acc, sc, sh, act, relu_in, n_kt);
-        DAL3_SCHED_FENCE();
+    if constexpr (NB == 2) {
+        // ping-pong with running pointers (n_blk is even: M and the slices are multiples of 32 points)
+        const float* pa = pa0;
+        const float* pb = pb0;
+        wg_load(ring[0], pa, lddz, pb, lda, n_mt, n_kt);
+        for (int64_t i = 0; i < n_blk; i += 2) {
+            wg_load(ring[1], pa + sa, lddz, pb + sb, lda, n_mt, n_kt);
+            DAL3_SCHED_FENCE();
+            wg_compute(ring[0], acc, sc, sh, act, relu_in, n_kt);
+            DAL3_SCHED_FENCE();
+            const bool more = i + 2 < n_blk;
+            pa = more ? pa + 2 * sa : pa0;
+            pb = more ? pb + 2 * sb : pb0;
+            wg_load(ring[0], pa, lddz, pb, lda, n_mt, n_kt);
+            DAL3_SCHED_FENCE();
+            wg_compute(ring[1], acc, sc, sh, act, relu_in, n_kt);
+            DAL3_SCHED_FENCE();
+        }
+    } else {
+        // NB blocks: the slice is padded to a multiple of NB blocks by the same re-read, the surplus computes are
+        // skipped (wave-uniform)
+#pragma unroll
+        for (int b = 0; b < NB - 1; ++b) {
+            const int64_t i = b < n_blk ? b : 0;
+            wg_load(ring[b], pa0 + i * sa, lddz, pb0 + i * sb, lda, n_mt, n_kt);
+        }
+        for (int64_t i0 = 0; i0 < n_blk; i0 += NB) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int64_t nx = i0 + u + NB - 1;
+                const int64_t j = nx < n_blk ? nx : 0;
+                wg_load(ring[(u + NB - 1) % NB], pa0 + j * sa, lddz, pb0 + j * sb, lda, n_mt, n_kt);
+                DAL3_SCHED_FENCE();
+                if (i0 + u < n_blk) wg_compute(ring[u], acc, sc, sh, act, relu_in, n_kt);
+                DAL3_SCHED_FENCE();
+            }
+        }
     }
     // D tile: row (co) = tile_chan(r, h), col (ci) = lane & 31
     float* out = part + slice * (int64_t)c_out * c_in;
 #pragma unroll
-    for (int t = 0; t < WG_MT; ++t) {
+    for (int t = 0; t < MT; ++t) {
         if (t >= n_mt) break;
 #pragma unroll
-        for (int k = 0; k < WG_KT; ++k) {
+        for (int k = 0; k < KT; ++k) {
             if (k >= n_kt) break;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -847,13 +967,22 @@ __global__ __launch_bounds__(256) void tr_wgrad_final_kernel(const float* __rest
     if (l == 0 && i < n) dW[i] = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
 }
 
-// slice length: enough (tile block, slice) units to occupy the chip (>= ~2048 waves) without going below
-// WG_MIN_SLICE points per wave; a multiple of 32
+// slice length: enough (tile block, slice) units to occupy the chip (~1024 waves: with 2048 the partial sums of the
+// small layers — one (c_out x c_in) tile block per 128 points — were a quarter of the traffic, and every shape ran 5-20 %
+// slower) without going below WG_MIN_SLICE points per wave; a multiple of 64
+static bool wgrad_small(int c_out) { return c_out <= 64; }    // at most two out-tiles: the <2, 2, 4> instantiation
+static void wgrad_blocks(int c_out, int c_in, int* n_mb, int* n_kb) {
+    const int mt = wgrad_small(c_out) ? 2 : WG_MT;
+    *n_mb = (c_out / 32 + mt - 1) / mt;
+    *n_kb = (c_in / 32 + WG_KT - 1) / WG_KT;
+}
 static int64_t wgrad_slice_pts(int64_t M, int c_out, int c_in) {
-    const int64_t blocks = (int64_t)((c_out / 32 + WG_MT - 1) / WG_MT) * ((c_in / 32 + WG_KT - 1) / WG_KT);
-    const int64_t want_slices = (2048 + blocks - 1) / blocks;
+    int n_mb, n_kb;
+    wgrad_blocks(c_out, c_in, &n_mb, &n_kb);
+    const int64_t blocks = (int64_t)n_mb * n_kb;
+    const int64_t want_slices = (1024 + blocks - 1) / blocks;
     int64_t pts = (M + want_slices - 1) / want_slices;
-    pts = (pts + 31) / 32 * 32;
+    pts = (pts + 63) / 64 * 64;
     return pts < WG_MIN_SLICE ? WG_MIN_SLICE : pts;
 }
 
@@ -865,12 +994,18 @@ size_t tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in) {
 hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale,
                            const float* shift, int relu_in, int64_t M, int c_out, int c_in, float* part, float* dW,
                            hipStream_t s) {
-    const int n_mb = (c_out / 32 + WG_MT - 1) / WG_MT, n_kb = (c_in / 32 + WG_KT - 1) / WG_KT;
+    int n_mb, n_kb;
+    wgrad_blocks(c_out, c_in, &n_mb, &n_kb);
     const int64_t pts = wgrad_slice_pts(M, c_out, c_in);
     const int64_t n_slices = (M + pts - 1) / pts;
     const int64_t units = n_slices * n_mb * n_kb;
-    hipLaunchKernelGGL(tr_wgrad_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, dz, lddz, a, lda, scale, shift,
-                       relu_in, M, c_out, c_in, part, n_mb, n_kb, pts);
+    const dim3 grid((unsigned)((units + 3) / 4));
+    if (wgrad_small(c_out))
+        hipLaunchKernelGGL((tr_wgrad_kernel<2, WG_KT, 4>), grid, dim3(256), 0, s, dz, lddz, a, lda, scale, shift, relu_in, M,
+                           c_out, c_in, part, n_mb, n_kb, pts);
+    else
+        hipLaunchKernelGGL((tr_wgrad_kernel<WG_MT, WG_KT, 2>), grid, dim3(256), 0, s, dz, lddz, a, lda, scale, shift, relu_in,
+                           M, c_out, c_in, part, n_mb, n_kb, pts);
     const int64_t n = (int64_t)c_out * c_in;
     hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, (int)n_slices, n, dW);
     return hipGetLastError();

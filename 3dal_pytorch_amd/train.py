@@ -94,15 +94,23 @@ class _BN:
         sums: optional float64 (2*C,) [sum z, sum z^2] obtained without a pass over z (see _moments_through)"""
         M, C = z if isinstance(z, tuple) else z.shape
         M = rows if rows is not None else M
-        if sums is None:
-            sums = _colred(z, 0, rows=M)
-        st = torch.empty((4, C), dtype=torch.float32, device=sums.device)
+        dev = sums.device if sums is not None else z.device
+        st = torch.empty((4, C), dtype=torch.float32, device=dev)
         self.mu, self.rstd, self.scale, self.shift = st[0], st[1], st[2], st[3]
         self.gamma = gamma.contiguous()
-        _hip.check(_hip.lib().dal3_tr_bn_finalize(_hip.ptr(sums), C, M, _hip.ptr(self.gamma), _hip.ptr(beta.contiguous()),
-                                                  _hip.ptr(running_mean), _hip.ptr(running_var), _MOM, _EPS, _hip.ptr(self.mu),
-                                                  _hip.ptr(self.rstd), _hip.ptr(self.scale), _hip.ptr(self.shift),
-                                                  _hip.stream()))
+        lib = _hip.lib()
+        if sums is None:                                    # reduction + epilogue: two launches
+            need = lib.dal3_tr_colred_workspace_bytes(M, C)
+            ws = _ws(need, dev)
+            _hip.check(lib.dal3_tr_bn_stats(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(self.gamma), _hip.ptr(beta.contiguous()),
+                                            _hip.ptr(running_mean), _hip.ptr(running_var), _MOM, _EPS, _hip.ptr(self.mu),
+                                            _hip.ptr(self.rstd), _hip.ptr(self.scale), _hip.ptr(self.shift), _hip.ptr(ws),
+                                            need, _hip.stream()))
+        else:
+            _hip.check(lib.dal3_tr_bn_finalize(_hip.ptr(sums), C, M, _hip.ptr(self.gamma), _hip.ptr(beta.contiguous()),
+                                               _hip.ptr(running_mean), _hip.ptr(running_var), _MOM, _EPS, _hip.ptr(self.mu),
+                                               _hip.ptr(self.rstd), _hip.ptr(self.scale), _hip.ptr(self.shift),
+                                               _hip.stream()))
         self.M = M
 
     @property
@@ -114,10 +122,14 @@ class _BN:
         C = z.shape[1]
         M = self.M                                                          # the real rows; padding rows get dz = 0
         lib = _hip.lib()
-        sums = _colred(z, 1, da=da, dg=dg, arg=arg, seg=seg, bn=(self.scale, self.shift, self.mu, self.rstd), rows=M)
         co = torch.empty((5, C), dtype=torch.float32, device=z.device)      # dgamma, dbeta, k1, k2, k3
-        _hip.check(lib.dal3_tr_bnbwd_coef(_hip.ptr(sums), C, M, _hip.ptr(self.gamma), _hip.ptr(self.rstd), _hip.ptr(co[0]),
-                                          _hip.ptr(co[1]), _hip.ptr(co[2]), _hip.ptr(co[3]), _hip.ptr(co[4]), _hip.stream()))
+        need = lib.dal3_tr_colred_workspace_bytes(M, C)
+        ws = _ws(need, z.device)
+        _hip.check(lib.dal3_tr_bnbwd_sums(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(da), da.stride(0) if da is not None else 0,
+                                          _hip.ptr(dg), _hip.ptr(arg), seg, _hip.ptr(self.scale), _hip.ptr(self.shift),
+                                          _hip.ptr(self.mu), _hip.ptr(self.rstd), _hip.ptr(self.gamma), _hip.ptr(co[0]),
+                                          _hip.ptr(co[1]), _hip.ptr(co[2]), _hip.ptr(co[3]), _hip.ptr(co[4]), _hip.ptr(ws),
+                                          need, _hip.stream()))
         dz = torch.empty_like(z)
         _hip.check(lib.dal3_tr_bnbwd_apply(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(da), da.stride(0) if da is not None else 0,
                                            _hip.ptr(dg), _hip.ptr(arg), seg, _hip.ptr(self.scale), _hip.ptr(self.shift),

@@ -301,6 +301,17 @@ int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, cons
                    const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                    const float* mu, const float* rstd, void* workspace, size_t workspace_bytes, double* out,
                    dal3_stream stream);
+/* The two reductions WITH their per-channel epilogues (what a training step calls: the second stage of the reduction
+ * carries the epilogue, a layer's statistics are two launches): dal3_tr_bn_stats = dal3_tr_colred mode 0 followed by
+ * dal3_tr_bn_finalize, dal3_tr_bnbwd_sums = mode 1 followed by dal3_tr_bnbwd_coef — same sums, same results.
+ * workspace: dal3_tr_colred_workspace_bytes(M, C). */
+int dal3_tr_bn_stats(const float* z, int64_t M, int C, int64_t ldz, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
+                     float* scale, float* shift, void* workspace, size_t workspace_bytes, dal3_stream stream);
+int dal3_tr_bnbwd_sums(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda, const float* dg,
+                       const int32_t* arg, int64_t seg, const float* scale, const float* shift, const float* mu,
+                       const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
+                       void* workspace, size_t workspace_bytes, dal3_stream stream);
 /* per-channel epilogues of the two reductions, one launch each: batch mean / biased variance -> mu, rstd, the folded
  * affine scale = gamma*rstd, shift = beta - mu*scale, and torch's running-statistics update (unbiased variance,
  * `momentum`; running_* may both be NULL); backward sums -> dgamma, dbeta and k1..k3 of dal3_tr_bnbwd_apply. */

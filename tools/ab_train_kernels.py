@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""A/B timing of the training GEMM kernels of library builds in ONE process (boxes differ by several per cent):
+  python tools/ab_train_kernels.py build_a.so build_b.so [--M 262144] [--rounds 5]
+interleaved rounds of dal3_tr_linear (forward, dgrad) and dal3_tr_wgrad at the static train step's layer shapes."""
+import argparse
+import ctypes as C
+import importlib
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+hip = importlib.import_module("3dal_pytorch_amd._hip")
+ap = argparse.ArgumentParser()
+ap.add_argument("libs", nargs="+")
+ap.add_argument("--M", type=int, default=64 * 4096)
+ap.add_argument("--rounds", type=int, default=5)
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+M = args.M
+
+
+def load(path):
+    h = C.CDLL(os.path.abspath(path))
+    for name, (res, a) in hip.SIGNATURES.items():
+        if hasattr(h, name):
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, a
+    return h
+
+
+libs = [(os.path.basename(p), load(p)) for p in args.libs]
+st = hip.stream()
+shapes = [(32, 64), (64, 64), (64, 128), (64, 512), (512, 256), (256, 128), (128, 128), (128, 32)]
+ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+
+
+def timed(fn, iters=5):
+    fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+for ci, co in shapes:
+    a = torch.randn((M, ci), device=dev)
+    W = torch.randn((co, ci), device=dev) * 0.1
+    b = torch.randn(co, device=dev)
+    sc, sh = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1
+    dz = torch.randn((M, co), device=dev)
+    z = torch.empty((M, co), device=dev)
+    da = torch.empty((M, ci), device=dev)
+    dW = [torch.empty((co, ci), device=dev) for _ in libs]
+    res = {(n, k): [] for n, _ in libs for k in ("fwd", "dgrad", "wgrad")}
+    for r in range(args.rounds):
+        for i, (n, lib) in enumerate(libs):
+            res[(n, "fwd")].append(timed(lambda: lib.dal3_tr_linear(hip.ptr(a), M, ci, ci, hip.ptr(sc), hip.ptr(sh), 1, hip.ptr(W), ci, 0,
+                                                                    hip.ptr(b), 0, co, hip.ptr(z), co, 0, hip.ptr(ws), ws.numel(), st)))
+            res[(n, "dgrad")].append(timed(lambda: lib.dal3_tr_linear(hip.ptr(dz), M, co, co, None, None, 0, hip.ptr(W), ci, 1, None, 0, ci,
+                                                                      hip.ptr(da), ci, 0, hip.ptr(ws), ws.numel(), st)))
+            res[(n, "wgrad")].append(timed(lambda: lib.dal3_tr_wgrad(hip.ptr(dz), co, hip.ptr(a), ci, hip.ptr(sc), hip.ptr(sh), 1, M, co, ci,
+                                                                     hip.ptr(ws), ws.numel(), hip.ptr(dW[i]), st)))
+    torch.cuda.synchronize()
+    ref = dz.double().t() @ torch.relu(a.double() * sc.double() + sh.double())
+    line = f"{ci:4d} -> {co:4d}: "
+    for i, (n, _) in enumerate(libs):
+        err = float((dW[i].double() - ref).abs().max() / ref.abs().max())
+        line += f"[{n}] fwd {statistics.median(res[(n, 'fwd')]):7.1f} dgrad {statistics.median(res[(n, 'dgrad')]):7.1f} " \
+                f"wgrad {statistics.median(res[(n, 'wgrad')]):7.1f} us (dW err {err:.1e})  "
+    print(line)
