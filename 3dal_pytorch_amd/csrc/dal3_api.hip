@@ -802,6 +802,20 @@ extern "C" int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int
     return 0;
 }
 
+extern "C" size_t dal3_tr_seg_ce_workspace_bytes(int64_t M) { return M > 0 ? tr_seg_ce_workspace_bytes(M) : 0; }
+
+extern "C" int dal3_tr_seg_ce(const float* logits, const void* labels, int labels_are_int64, int64_t M, float* loss,
+                              float* dlogits, void* workspace, size_t workspace_bytes, dal3_stream stream) {
+    if (!logits || !labels || M <= 0 || !loss || !dlogits) return fail(DAL3_EINVAL, "tr_seg_ce: bad argument");
+    if ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 7)
+        return fail(DAL3_EINVAL, "tr_seg_ce: logits and dlogits must be 8-byte aligned");
+    if (!workspace || workspace_bytes < tr_seg_ce_workspace_bytes(M) || (reinterpret_cast<uintptr_t>(workspace) & 7))
+        return fail(DAL3_EWORKSPACE, "tr_seg_ce: workspace smaller than dal3_tr_seg_ce_workspace_bytes() or misaligned");
+    HIP_TRY(launch_tr_seg_ce(logits, labels, labels_are_int64, M, loss, dlogits, static_cast<double*>(workspace),
+                             static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_tr_bn_stats(const float* z, int64_t M, int C, int64_t ldz, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
                                 float* scale, float* shift, void* workspace, size_t workspace_bytes, dal3_stream stream) {

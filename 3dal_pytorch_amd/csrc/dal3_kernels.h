@@ -215,6 +215,9 @@ size_t tr_colred_workspace_bytes(int64_t M, int C);
 hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                             const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                             const float* mu, const float* rstd, double* part, double* out, hipStream_t s);
+size_t tr_seg_ce_workspace_bytes(int64_t M);
+hipError_t launch_tr_seg_ce(const float* logits, const void* labels, int labels_i64, int64_t M, float* loss, float* dlogits,
+                            double* part, hipStream_t s);
 hipError_t launch_tr_bn_stats(const float* z, int64_t M, int C, int64_t ldz, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
                               float* scale, float* shift, double* part, hipStream_t s);

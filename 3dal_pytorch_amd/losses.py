@@ -4,7 +4,8 @@ with `huber_loss` (:341-346). Same call signature, same keys in the returned dic
 (mask + w_box * (10 center + heading class + size class + 20 heading residual + 20 size residual), per stage).
 
 Stock torch ops on whatever device the outputs live on (the reference hard-codes `.cuda()` on its one-hot
-tables): next to the per-point stacks this is O(B) work plus one log-softmax over the (B*N, 2) logits.
+tables): next to the per-point stacks this is O(B) work — plus the mask term over the (B*N, 2) logits, which on the
+GPU is one pass of lib3dal_hip.so (`_SegCE`: loss and gradient together) instead of six stock kernels.
 """
 import numpy as np
 import torch
@@ -34,7 +35,36 @@ def _consts(dev, dtype=torch.float32):
     return c
 
 
+class _SegCE(torch.autograd.Function):
+    """the mask term on lib3dal_hip.so (dal3_tr_seg_ce): loss and softmax - onehot in one pass over the logits"""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        from . import _hip
+        lib = _hip.lib()
+        lg = logits.detach().reshape(-1, 2).contiguous()
+        lab = labels.reshape(-1).contiguous()
+        M = lg.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=lg.device)
+        d = torch.empty_like(lg)
+        need = lib.dal3_tr_seg_ce_workspace_bytes(M)
+        ws = torch.empty(need, dtype=torch.uint8, device=lg.device)
+        _hip.check(lib.dal3_tr_seg_ce(_hip.ptr(lg), _hip.ptr(lab), int(lab.dtype == torch.int64), M, _hip.ptr(loss),
+                                      _hip.ptr(d), _hip.ptr(ws), need, _hip.stream()))
+        ctx.save_for_backward(d)
+        ctx.shape, ctx.M = logits.shape, M
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return (d * (g / ctx.M)).view(ctx.shape), None
+
+
 def _mask_loss(logits, mask_label):
+    if logits.is_cuda and logits.dtype == torch.float32 and mask_label.is_cuda and mask_label.dtype in (torch.float32,
+                                                                                                      torch.int64):
+        return _SegCE.apply(logits, mask_label)
     return F.nll_loss(F.log_softmax(logits.view(-1, 2), dim=1), mask_label.view(-1).long())
 
 

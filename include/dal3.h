@@ -301,6 +301,14 @@ int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, cons
                    const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                    const float* mu, const float* rstd, void* workspace, size_t workspace_bytes, double* out,
                    dal3_stream stream);
+/* The segmentation term of the reference's three criteria (tools/static_model.py:378-380, tools/dynamic_model.py:337-339:
+ * F.nll_loss(F.log_softmax(logits.view(-1, 2), dim=1), mask_label.view(-1).long())) in one pass: loss[0] = mean over the
+ * M points of -log_softmax(logits[p])[label[p]], and dlogits[p] = softmax(logits[p]) - onehot(label[p]) (the gradient
+ * of M * loss; the caller scales it). logits, dlogits: (M, 2) fp32 contiguous; labels: (M,) float32 or int64 (0 / 1).
+ * Sums in float64, blocks added in index order (reproducible). workspace: dal3_tr_seg_ce_workspace_bytes(M). */
+size_t dal3_tr_seg_ce_workspace_bytes(int64_t M);
+int dal3_tr_seg_ce(const float* logits, const void* labels, int labels_are_int64, int64_t M, float* loss, float* dlogits,
+                   void* workspace, size_t workspace_bytes, dal3_stream stream);
 /* The two reductions WITH their per-channel epilogues (what a training step calls: the second stage of the reduction
  * carries the epilogue, a layer's statistics are two launches): dal3_tr_bn_stats = dal3_tr_colred mode 0 followed by
  * dal3_tr_bn_finalize, dal3_tr_bnbwd_sums = mode 1 followed by dal3_tr_bnbwd_coef — same sums, same results.

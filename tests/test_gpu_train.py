@@ -449,3 +449,28 @@ def test_fc_tail_on_hip_kernels_matches_float64_autograd(kind, head_name, c_in, 
         if n.startswith("fcbn") and n.endswith("num_batches_tracked"):
             assert int(b1) == int(b2)
     assert not train.fc_tail_supported(x.cpu())
+
+
+@pytest.mark.parametrize("B,N,int_labels", [(4, 1024, False), (3, 1000, True), (64, 4096, False)])
+def test_fused_mask_loss_matches_float64_log_softmax_nll(B, N, int_labels):
+    """losses._mask_loss on CUDA tensors is dal3_tr_seg_ce: the value and the gradient against the reference's
+    F.nll_loss(F.log_softmax(...)) in float64, float and int64 labels, a point count that is no multiple of the
+    kernel's block, logits up to +-60 (no overflow), and bitwise repeatability"""
+    losses = importlib.import_module("3dal_pytorch_amd.losses")
+    gen = torch.Generator(device="cuda").manual_seed(B * N)
+    logits = (torch.randn((B, N, 2), device="cuda", generator=gen) * 4.0)
+    logits[0, :8] = torch.tensor([[60.0, -60.0], [-60.0, 60.0], [0.0, 0.0], [1e-3, -1e-3]] * 2, device="cuda")
+    lab = (torch.rand((B, N), device="cuda", generator=gen) > 0.6)
+    labels = lab.long() if int_labels else lab.float()
+    x = logits.clone().requires_grad_(True)
+    got = losses._mask_loss(x, labels)
+    (got * 3.0).backward()
+    x64 = logits.double().requires_grad_(True)
+    want = F.nll_loss(F.log_softmax(x64.view(-1, 2), dim=1), lab.view(-1).long())
+    (want * 3.0).backward()
+    assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
+    assert float((x.grad.double() - x64.grad).abs().max()) <= 1e-6 * float(x64.grad.abs().max())
+    y = logits.clone().requires_grad_(True)
+    again = losses._mask_loss(y, labels)
+    (again * 3.0).backward()
+    assert float(again) == float(got) and torch.equal(y.grad, x.grad)
