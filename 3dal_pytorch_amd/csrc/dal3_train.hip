@@ -579,8 +579,8 @@ __global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict_
     }
 }
 
-// 16 channels x 16 partial-lanes per block: lane l adds the partials l, l+16, l+32, ... in that order, then the 16
-// lane sums are added in lane order — a fixed association, so the result is reproducible. What follows the sums is
+// 16 channels x 16 partial-lanes per block: lane l adds the partials l, l+16, l+32, ... (in four interleaved chains),
+// then the 16 lane sums are added in lane order — a fixed association, so the result is reproducible. What follows the sums is
 // folded in (EPI): nothing (0: the sums themselves), the forward BatchNorm epilogue (1: batch mean / biased variance ->
 // mu, rstd, the folded affine scale = gamma*rstd, shift = beta - mean*scale, and the running statistics' update with
 // momentum and unbiased variance exactly as torch's BatchNorm1d does it), or the backward one (2: dbeta = sum dy,
@@ -612,10 +612,23 @@ __global__ __launch_bounds__(256) void tr_colred_final_kernel(const double* __re
     const int c = blockIdx.x * 16 + cl;
     double s0 = 0.0, s1 = 0.0;
     if (c < C) {
-        for (int b = l; b < n_blocks; b += 16) {
-            s0 += part[((int64_t)b * C + c) * 2];
-            s1 += part[((int64_t)b * C + c) * 2 + 1];
+        // four independent chains (the loop is a chain of dependent L2 round trips otherwise: 16 us for 1024 partials),
+        // combined in a fixed order
+        double u0[4] = {0, 0, 0, 0}, u1[4] = {0, 0, 0, 0};
+        int b = l;
+        for (; b + 48 < n_blocks; b += 64) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u0[k] += part[((int64_t)(b + 16 * k) * C + c) * 2];
+                u1[k] += part[((int64_t)(b + 16 * k) * C + c) * 2 + 1];
+            }
         }
+        for (; b < n_blocks; b += 16) {
+            u0[0] += part[((int64_t)b * C + c) * 2];
+            u1[0] += part[((int64_t)b * C + c) * 2 + 1];
+        }
+        s0 = (u0[0] + u0[1]) + (u0[2] + u0[3]);
+        s1 = (u1[0] + u1[1]) + (u1[2] + u1[3]);
     }
     sm[0][l][cl] = s0;
     sm[1][l][cl] = s1;

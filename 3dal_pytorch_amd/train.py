@@ -58,6 +58,18 @@ def _pad32(n):
     return (n + 31) // 32 * 32
 
 
+def _zero_grads(shapes, idx, dev):
+    """gradients that are analytically zero (a conv / fc bias in front of a train-mode BatchNorm): views of ONE zeroed
+    buffer instead of a fill kernel per parameter (twenty of them per step)"""
+    sizes = [int(torch.Size(shapes[i]).numel()) for i in idx]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    out, o = {}, 0
+    for i, n in zip(idx, sizes):
+        out[i] = flat[o:o + n].view(shapes[i])
+        o += n
+    return out
+
+
 def _colred(z, mode, da=None, dg=None, arg=None, seg=0, bn=None, rows=None):
     """float64 column sums (2*C,) on the device over the first `rows` rows of z: see dal3_tr_colred"""
     M, C = z.shape
@@ -343,20 +355,21 @@ class _PointStack(torch.autograd.Function):
     def backward(ctx, dg):
         a0, Ws, bns, zs, arg, N, shapes, zarg, g, biases = ctx.saved
         grads = [None] * 16
+        zero = _zero_grads(shapes, [1, 5, 9, 13], a0.device)
         da = None
         for k in (3, 2, 1, 0):
             if k == 3:
                 da, dW, dgam, dbet = _pooled_layer_backward(zs[2], bns[2], Ws[3], biases[3], bns[3], zarg, g, arg,
                                                             dg, N)
                 grads[12] = dW.reshape(shapes[12])
-                grads[13] = torch.zeros(shapes[13], device=dW.device)
+                grads[13] = zero[13]
                 grads[14], grads[15] = dgam, dbet
                 continue
             dz, dgam, dbet = bns[k].backward(zs[k], da=da)
             src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a0, None)
             dW = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
             grads[4 * k] = dW[:, :shapes[4 * k][1]].reshape(shapes[4 * k])
-            grads[4 * k + 1] = torch.zeros(shapes[4 * k + 1], device=dz.device)
+            grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
             if k > 0:
                 da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
@@ -446,6 +459,7 @@ class _InsSeg(torch.autograd.Function):
         M = dlogits.shape[0] * dlogits.shape[1]
         dev = a0.device
         grads = [None] * 38
+        zero = _zero_grads(shapes, [4 * k + 1 for k in range(9)], dev)
         dzl = torch.zeros((Mp, 32), dtype=torch.float32, device=dev)
         dzl[:M, :2] = dlogits.reshape(M, 2)
         grads[36] = _wgrad(dzl, a4, 32, 128)[:2].reshape(shapes[36])
@@ -456,7 +470,7 @@ class _InsSeg(torch.autograd.Function):
         for k in (8, 7, 6):                                             # dconv4..2
             dz, dgam, dbet = bns[k].backward(zs[k], da=da)
             grads[4 * k] = _wgrad(dz, zs[k - 1], Ws[k].shape[0], Ws[k].shape[1], bns[k - 1].act).reshape(shapes[4 * k])
-            grads[4 * k + 1] = torch.zeros(shapes[4 * k + 1], device=dev)
+            grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
             da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
         # dconv1: per-point part against out2, per-crop part against g
@@ -466,7 +480,7 @@ class _InsSeg(torch.autograd.Function):
         dgb = _segsum(dz, N, g.shape[0])                                # (B,512)
         dW1 = torch.cat([dWa, dgb.t() @ g], 1)
         grads[20] = dW1.reshape(shapes[20])
-        grads[21] = torch.zeros(shapes[21], device=dev)
+        grads[21] = zero[21]
         grads[22], grads[23] = dgam, dbet
         dg = dgb @ Wd1[:, 64:]                                          # (B,1024)
         da2_dec = _linear(dz, Wd1, Wd1.shape[1], 512, 64, transpose=True)
@@ -477,14 +491,14 @@ class _InsSeg(torch.autograd.Function):
                 da, dW, dgam, dbet = _pooled_layer_backward(zs[3], bns[3], Ws[4], b_conv5, bns[4], zarg, g, arg, dg, N,
                                                             cached=conv5_cache)
                 grads[16] = dW.reshape(shapes[16])
-                grads[17] = torch.zeros(shapes[17], device=dev)
+                grads[17] = zero[17]
                 grads[18], grads[19] = dgam, dbet
                 continue
             dz, dgam, dbet = bns[k].backward(zs[k], da=da)
             src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a0, None)
             dW = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
             grads[4 * k] = dW[:, :shapes[4 * k][1]].reshape(shapes[4 * k])
-            grads[4 * k + 1] = torch.zeros(shapes[4 * k + 1], device=dev)
+            grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
             if k == 2:                                                  # out2 also feeds the decoder
                 da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, out=da2_dec,
@@ -540,6 +554,7 @@ class _FcTail(torch.autograd.Function):
         grads = [None] * len(shapes)
         dev = dout.device
         B, Bp = dout.shape[0], a_in.shape[0]
+        zero = _zero_grads(shapes, [4 * k + 1 for k in range(n_bn)], dev)
         if last is not None:
             Wp, c_out = last
             dz = torch.zeros((Bp, Wp.shape[0]), dtype=torch.float32, device=dev)
@@ -556,7 +571,7 @@ class _FcTail(torch.autograd.Function):
             dz, dgam, dbet = bns[k].backward(zs[k], da=da)
             src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a_in, None)
             grads[4 * k] = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act).reshape(shapes[4 * k])
-            grads[4 * k + 1] = torch.zeros(shapes[4 * k + 1], device=dev)      # a bias in front of a train-mode BN
+            grads[4 * k + 1] = zero[4 * k + 1]                                 # a bias in front of a train-mode BN
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
             da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
         return (da[:B], None, None, *grads)

@@ -24,7 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--points", type=int, default=4096)
-    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--backends", default="hip,torch")
     ap.add_argument("--graph", action="store_true", help="also time the step captured into a hipGraph (device sampler)")
     ap.add_argument("--sampler", default="numpy", choices=["numpy", "device"],
@@ -63,14 +63,19 @@ def main():
             opt.step()
             return loss
         np.random.seed(0)
-        for _ in range(2):
+        for _ in range(5):
             step()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.iters):
+        # median of per-step times (HIP events around each step): a fresh box's first seconds run slower, and a mean
+        # over five steps moved by 20 % between two runs of the same binary
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.iters + 1)]
+        marks[0].record()
+        for i in range(args.iters):
             loss = step()
+            marks[i + 1].record()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / args.iters * 1e3
+        per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.iters))
+        ms = per[len(per) // 2]
         g_ms = None
         if args.graph and args.sampler == "device":
             # a FRESH model: a parameter that has already taken part in an eager backward keeps a gradient accumulator
