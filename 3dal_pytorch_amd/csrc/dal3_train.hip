@@ -184,27 +184,31 @@ __global__ __launch_bounds__(256) void tr_linear_kernel(const float* __restrict_
 // 1-KiB load, and they are streamed through the 8-deep prefetch ring of the eval kernels (dal3_device.h) instead of
 // being double-buffered per k-tile: 128 accumulator + 64 activation + 32 ring registers leave room for two waves per
 // SIMD, so one wave's prologue/epilogue hides under the other's MFMAs.
-__global__ void tr_pack_kernel(const float* __restrict__ W, int64_t ldw, int transpose_w, int c_out, int c_in,
+__global__ void tr_pack_kernel(const float* __restrict__ W, int64_t ldw, int transpose_w, int c_out, int c_in, int mtb,
                                float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)c_out * c_in) return;
     const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
     int64_t f = i >> 8;                                       // fragment index
-    const int q = (int)(f & 3), t = (int)((f >> 2) & 3);
-    f >>= 4;
+    const int q = (int)(f & 3);
+    f >>= 2;
+    const int t = (int)(f % mtb);
+    f /= mtb;
     const int KT = c_in / 32;
     const int kt = (int)(f % KT), mblk = (int)(f / KT);
-    const int row = 32 * (4 * mblk + t) + (lane & 31), col = 32 * kt + 8 * q + 4 * (lane >> 5) + e;
+    const int row = 32 * (mtb * mblk + t) + (lane & 31), col = 32 * kt + 8 * q + 4 * (lane >> 5) + e;
     out[i] = transpose_w ? W[(int64_t)col * ldw + row] : W[(int64_t)row * ldw + col];
 }
 
+template <int T>
 struct TrX {
-    f32x16 X[TR_T];
+    f32x16 X[T];
 };
 
 // y = max(x*scale + shift, 0) with the per-channel affine read from LDS (copied there once per workgroup): keeping
 // it in registers from load to use costs 32 VGPRs per stage and pushed the kernel into scratch
-__device__ __forceinline__ void tr_act_lds(f32x16 (&X)[TR_T], const float* __restrict__ s_sc, const float* __restrict__ s_sh,
+template <int T>
+__device__ __forceinline__ void tr_act_lds(f32x16 (&X)[T], const float* __restrict__ s_sc, const float* __restrict__ s_sh,
                                            int kt, int h, int relu_in) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -213,17 +217,18 @@ __device__ __forceinline__ void tr_act_lds(f32x16 (&X)[TR_T], const float* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int j = 0; j < TR_T; ++j) {
+            for (int j = 0; j < T; ++j) {
                 const float v = X[j][4 * q + e] * sc[e] + sh[e];
                 X[j][4 * q + e] = relu_in ? fmaxf(v, 0.0f) : v;
             }
     }
 }
 
-__device__ __forceinline__ void tr_load_x(TrX& st, int kt, const float* __restrict__ a, int64_t lda,
-                                          const int64_t (&prow)[TR_T], int h) {
+template <int T>
+__device__ __forceinline__ void tr_load_x(TrX<T>& st, int kt, const float* __restrict__ a, int64_t lda,
+                                          const int64_t (&prow)[T], int h) {
 #pragma unroll
-    for (int j = 0; j < TR_T; ++j) {
+    for (int j = 0; j < T; ++j) {
         const float* ap = a + prow[j] * lda + 32 * kt + 4 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -234,29 +239,36 @@ __device__ __forceinline__ void tr_load_x(TrX& st, int kt, const float* __restri
     }
 }
 
-// the 16 fragments (4 output tiles x 4 q) of one k-tile, taken from the ring
-__device__ __forceinline__ void tr_ring_block(WRing<DAL3_PF>& ring, const f32x16 (&X)[TR_T], f32x16 (&acc)[TR_T][TR_MTB]) {
+// the 4 MTB fragments (MTB output tiles x 4 q) of one k-tile, taken from the ring; BASE: the ring slot of the first
+// (0, or 4 for the second k-tile of a pair when a k-tile is only four fragments)
+template <int T, int MTB, int BASE>
+__device__ __forceinline__ void tr_ring_block(WRing<DAL3_PF>& ring, const f32x16 (&X)[T], f32x16 (&acc)[T][MTB]) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        ring_batch_wait<DAL3_PF>(ring, i);
-        const f32x4 w = ring.slot[i % DAL3_PF];
-        ring.slot[i % DAL3_PF] = ring.fetch();
+    for (int i = 0; i < 4 * MTB; ++i) {
+        ring_batch_wait<DAL3_PF>(ring, BASE + i);
+        const f32x4 w = ring.slot[(BASE + i) % DAL3_PF];
+        ring.slot[(BASE + i) % DAL3_PF] = ring.fetch();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int j = 0; j < TR_T; ++j) acc[j][i / 4] = mfma32(w[e], X[j][4 * (i % 4) + e], acc[j][i / 4]);
+            for (int j = 0; j < T; ++j) acc[j][i / 4] = mfma32(w[e], X[j][4 * (i % 4) + e], acc[j][i / 4]);
         }
         DAL3_SCHED_FENCE();
     }
 }
 
+// T point tiles x MTB output tiles per wave. <2, 4>: the big layers (c_out % 128 == 0). <2, 2>: c_out % 64 == 0 (the
+// 64-channel layers and their gradients; through the strided-weight kernel above the 512 -> 64 dgrad of dconv1 ran at
+// 65 TFLOP/s). <1, 1>: few rows (the per-item FC tails: 64 rows x 512 channels as <2, 4> is FOUR waves walking K = 512
+// one after the other, 83 us; as 32 waves of one tile each, a fraction of that).
+template <int T, int MTB>
 __global__ __launch_bounds__(256, 2) void tr_linear_ring_kernel(const float* __restrict__ a, int64_t M, int c_in, int64_t lda,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, int relu_in,
                                                                 const f32x4* __restrict__ wpk, const float* __restrict__ bias,
                                                                 int64_t seg, int c_out, float* __restrict__ z, int64_t ldz,
                                                                 int accumulate, int n_mblk) {
-    static_assert(TR_MTB == 4 && DAL3_PF == 8, "fragment order of tr_pack_kernel");
+    static_assert(DAL3_PF == 8 && (MTB == 1 || MTB == 2 || MTB == 4), "fragment order of tr_pack_kernel, ring slots");
     __shared__ float s_sc[TR_MAX_ACT_CIN], s_sh[TR_MAX_ACT_CIN];
     const bool act = scale != nullptr;
     if (act) {
@@ -269,20 +281,20 @@ __global__ __launch_bounds__(256, 2) void tr_linear_ring_kernel(const float* __r
     const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
     const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int mblk = (int)(unit % n_mblk);
-    const int64_t pt0 = (unit / n_mblk) * (32 * TR_T);
+    const int64_t pt0 = (unit / n_mblk) * (32 * T);
     if (pt0 >= M) return;
-    const int mt0 = mblk * TR_MTB;
+    const int mt0 = mblk * MTB;
     const int KT = c_in / 32;
-    int64_t prow[TR_T];
+    int64_t prow[T];
 #pragma unroll
-    for (int j = 0; j < TR_T; ++j) prow[j] = min(pt0 + 32 * j, M - 32) + m;
+    for (int j = 0; j < T; ++j) prow[j] = min(pt0 + 32 * j, M - 32) + m;
     WRing<DAL3_PF> ring;
-    ring.init(wpk + (int64_t)mblk * KT * 16 * 64, lane);
-    f32x16 acc[TR_T][TR_MTB];
+    ring.init(wpk + (int64_t)mblk * KT * (4 * MTB) * 64, lane);
+    f32x16 acc[T][MTB];
 #pragma unroll
-    for (int j = 0; j < TR_T; ++j) {
+    for (int j = 0; j < T; ++j) {
 #pragma unroll
-        for (int t = 0; t < TR_MTB; ++t) {
+        for (int t = 0; t < MTB; ++t) {
             if (bias) {
                 const float* bp = bias + (seg > 0 ? (prow[j] / seg) * c_out : 0) + 32 * (mt0 + t);
                 acc[j][t] = tile_from_channels(bp, h);
@@ -291,26 +303,27 @@ __global__ __launch_bounds__(256, 2) void tr_linear_ring_kernel(const float* __r
             }
         }
     }
-    TrX xa, xb;                                              // raw loads one k-tile ahead; activation applied at use
-    tr_load_x(xa, 0, a, lda, prow, h);
+    constexpr int BASE2 = (4 * MTB) % DAL3_PF;               // ring slot of the second k-tile's first fragment
+    TrX<T> xa, xb;                                           // raw loads one k-tile ahead; activation applied at use
+    tr_load_x<T>(xa, 0, a, lda, prow, h);
     for (int kt = 0; kt < KT; kt += 2) {
-        tr_load_x(xb, min(kt + 1, KT - 1), a, lda, prow, h);
+        tr_load_x<T>(xb, min(kt + 1, KT - 1), a, lda, prow, h);
         DAL3_SCHED_FENCE();
-        if (act) tr_act_lds(xa.X, s_sc, s_sh, kt, h, relu_in);
-        tr_ring_block(ring, xa.X, acc);
-        tr_load_x(xa, min(kt + 2, KT - 1), a, lda, prow, h);
+        if (act) tr_act_lds<T>(xa.X, s_sc, s_sh, kt, h, relu_in);
+        tr_ring_block<T, MTB, 0>(ring, xa.X, acc);
+        tr_load_x<T>(xa, min(kt + 2, KT - 1), a, lda, prow, h);
         DAL3_SCHED_FENCE();
         if (kt + 1 < KT) {
-            if (act) tr_act_lds(xb.X, s_sc, s_sh, kt + 1, h, relu_in);
-            tr_ring_block(ring, xb.X, acc);
+            if (act) tr_act_lds<T>(xb.X, s_sc, s_sh, kt + 1, h, relu_in);
+            tr_ring_block<T, MTB, BASE2>(ring, xb.X, acc);
         }
     }
 #pragma unroll
-    for (int j = 0; j < TR_T; ++j) {
+    for (int j = 0; j < T; ++j) {
         if (pt0 + 32 * j >= M) break;
         float* zp = z + (pt0 + 32 * j + m) * ldz + 4 * h;
 #pragma unroll
-        for (int t = 0; t < TR_MTB; ++t) {
+        for (int t = 0; t < MTB; ++t) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4* dst = reinterpret_cast<f32x4*>(zp + 32 * (mt0 + t) + 8 * q);
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void tr_linear_pool_kernel(const float* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][t][r] = bv;
     }
-    TrX xa, xb;
+    TrX<TR_T> xa, xb;
     tr_load_x(xa, 0, a, lda, prow, h);
     auto block = [&](const f32x16 (&X)[TR_T]) {                     // tr_ring_block with the operands swapped
 #pragma unroll
@@ -448,7 +461,7 @@ hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t ld
     const int64_t n = (int64_t)c_out * c_in, n_seg = M / seg;
     hipError_t e = launch_fill_words(packed, (size_t)n_seg * c_out * 2, 0u, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, 0, c_out, c_in, ws);
+    hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, 0, c_out, c_in, TR_MTB, ws);
     hipLaunchKernelGGL(tr_linear_pool_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda, scale, shift,
                        relu_in, reinterpret_cast<const f32x4*>(ws), bias, out_scale, out_shift, seg, c_out, packed, n_mblk);
     const int64_t total = n_seg * c_out;
@@ -456,25 +469,46 @@ hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t ld
     return hipGetLastError();
 }
 
+// every layer with whole 32-channel tiles can take a ring path (which one depends on M: see launch_tr_linear)
 size_t tr_linear_workspace_bytes(int c_in, int c_out) {
-    return c_out % 128 == 0 ? (size_t)c_out * c_in * sizeof(float) + DAL3_PF * 1024 : 0;
+    return c_out % 32 == 0 ? (size_t)c_out * c_in * sizeof(float) + DAL3_PF * 1024 : 0;
+}
+
+#define TR_SMALL_M 256                   // at most this many rows: one 32 x 32 output tile per wave (<1, 1>)
+
+template <int T, int MTB>
+static void tr_linear_ring_launch(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                                  int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
+                                  int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s) {
+    const int n_mblk = c_out / (32 * MTB);
+    const int64_t units = ((M + 32 * T - 1) / (32 * T)) * n_mblk;
+    const int64_t n = (int64_t)c_out * c_in;
+    hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, transpose_w, c_out, c_in,
+                       MTB, ws);
+    hipLaunchKernelGGL((tr_linear_ring_kernel<T, MTB>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda,
+                       scale, shift, relu_in, reinterpret_cast<const f32x4*>(ws), bias, seg, c_out, z, ldz, accumulate,
+                       n_mblk);
 }
 
 hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                             int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
                             int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s) {
-    const int n_mblk = (c_out / 32 + TR_MTB - 1) / TR_MTB;
-    const int64_t units = ((M + 32 * TR_T - 1) / (32 * TR_T)) * n_mblk;
-    if (ws && c_out % 128 == 0 && (!scale || c_in <= TR_MAX_ACT_CIN)) {
-        const int64_t n = (int64_t)c_out * c_in;
-        hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, transpose_w, c_out, c_in,
-                           ws);
-        hipLaunchKernelGGL(tr_linear_ring_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda, scale,
-                           shift, relu_in, reinterpret_cast<const f32x4*>(ws), bias, seg, c_out, z, ldz, accumulate, n_mblk);
-        return hipGetLastError();
+    const bool ring_ok = ws && (!scale || c_in <= TR_MAX_ACT_CIN);
+    if (ring_ok && M <= TR_SMALL_M) {
+        tr_linear_ring_launch<1, 1>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
+                                    accumulate, ws, s);
+    } else if (ring_ok && c_out % 128 == 0) {
+        tr_linear_ring_launch<TR_T, TR_MTB>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z,
+                                            ldz, accumulate, ws, s);
+    } else if (ring_ok && c_out % 64 == 0) {
+        tr_linear_ring_launch<TR_T, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
+                                       accumulate, ws, s);
+    } else {
+        const int n_mblk = (c_out / 32 + TR_MTB - 1) / TR_MTB;
+        const int64_t units = ((M + 32 * TR_T - 1) / (32 * TR_T)) * n_mblk;
+        hipLaunchKernelGGL(tr_linear_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda, scale, shift,
+                           relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz, accumulate, n_mblk);
     }
-    hipLaunchKernelGGL(tr_linear_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda, scale, shift,
-                       relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz, accumulate, n_mblk);
     return hipGetLastError();
 }
 

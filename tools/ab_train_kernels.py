@@ -34,6 +34,8 @@ def load(path):
 libs = [(os.path.basename(p), load(p)) for p in args.libs]
 st = hip.stream()
 shapes = [(32, 64), (64, 64), (64, 128), (64, 512), (512, 256), (256, 128), (128, 128), (128, 32)]
+if M <= 1024:                                               # the per-item FC tails (rows = items)
+    shapes = [(512, 512), (512, 256), (256, 64), (384, 512)]
 ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 
 
@@ -68,7 +70,10 @@ for ci, co in shapes:
                                                                      hip.ptr(ws), ws.numel(), hip.ptr(dW[i]), st)))
     torch.cuda.synchronize()
     ref = dz.double().t() @ torch.relu(a.double() * sc.double() + sh.double())
-    line = f"{ci:4d} -> {co:4d}: "
+    zref = torch.relu(a.double() * sc.double() + sh.double()) @ W.double().t() + b.double()
+    zerr = float((z.double() - zref).abs().max() / zref.abs().max())      # (z: the LAST library's forward)
+    daerr = float((da.double() - dz.double() @ W.double()).abs().max() / (dz.double() @ W.double()).abs().max())
+    line = f"{ci:4d} -> {co:4d} (z err {zerr:.0e}, da err {daerr:.0e}): "
     for i, (n, _) in enumerate(libs):
         err = float((dW[i].double() - ref).abs().max() / ref.abs().max())
         line += f"[{n}] fwd {statistics.median(res[(n, 'fwd')]):7.1f} dgrad {statistics.median(res[(n, 'dgrad')]):7.1f} " \
