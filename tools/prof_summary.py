@@ -19,7 +19,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(root, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 OURS = ("ins_seg_", "point_head_kernel", "maxpool_rows", "fc_kernel", "compact_sample", "decode_boxes",
-        "segment_counts", "recenter_kernel", "pack_", "generic_layer")
+        "segment_counts", "recenter_kernel", "pack_", "generic_layer", "tr_", "fill_words", "lat_kernel")
 
 
 def short(name):
@@ -27,12 +27,13 @@ def short(name):
 
 
 for sub, sfx in (("prof_kt", ""), ("prof_kt_bf16", "_bf16"), ("prof_kt_c3", "_c3"), ("prof_kt_c5", "_c5"),
-                 ("prof_kt_maxpool", "_maxpool")):
+                 ("prof_kt_maxpool", "_maxpool"), ("prof_kt_train", "_train")):
     stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
     if not stats:
         continue
     rows = list(csv.DictReader(open(stats[0])))
-    with open(os.path.join(out_dir, f"{tag}_kernel_stats{sfx}.csv"), "w") as f:
+    name = f"{tag}_train_kernel_stats.csv" if sfx == "_train" else f"{tag}_kernel_stats{sfx}.csv"
+    with open(os.path.join(out_dir, name), "w") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows:
