@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void tr_linear_kernel(const float* __restrict_
                                                         int c_out, float* __restrict__ z, int64_t ldz, int accumulate,
                                                         int n_mblk) {
     const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t unit = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: so is everything derived from it)
     const int mblk = (int)(unit % n_mblk);
     const int64_t pt0 = (unit / n_mblk) * (32 * TR_T);
     if (pt0 >= M) return;
@@ -261,8 +261,11 @@ __device__ __forceinline__ void tr_ring_block(WRing<DAL3_PF>& ring, const f32x16
 // 64-channel layers and their gradients; through the strided-weight kernel above the 512 -> 64 dgrad of dconv1 ran at
 // 65 TFLOP/s). <1, 1>: few rows (the per-item FC tails: 64 rows x 512 channels as <2, 4> is FOUR waves walking K = 512
 // one after the other, 83 us; as 32 waves of one tile each, a fraction of that).
+#ifndef TR_RING_OCC
+#define TR_RING_OCC 1                   // waves per SIMD the kernel is compiled for: at 2 (256 registers) <2, 4> spilled and ran 5 % slower
+#endif
 template <int T, int MTB>
-__global__ __launch_bounds__(256, 2) void tr_linear_ring_kernel(const float* __restrict__ a, int64_t M, int c_in, int64_t lda,
+__global__ __launch_bounds__(256, TR_RING_OCC) void tr_linear_ring_kernel(const float* __restrict__ a, int64_t M, int c_in, int64_t lda,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, int relu_in,
                                                                 const f32x4* __restrict__ wpk, const float* __restrict__ bias,
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void tr_linear_ring_kernel(const float* __r
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t unit = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the ring's buffer descriptor stays in SGPRs — from a per-lane value hipcc builds a waterfall loop around EVERY fragment fetch)
     const int mblk = (int)(unit % n_mblk);
     const int64_t pt0 = (unit / n_mblk) * (32 * T);
     if (pt0 >= M) return;
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void tr_linear_pool_kernel(const float* __r
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t unit = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: see tr_linear_ring_kernel)
     const int mblk = (int)(unit % n_mblk);
     const int64_t pt0 = (unit / n_mblk) * (32 * TR_T);
     if (pt0 >= M) return;
@@ -910,7 +913,7 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
                                                        int c_in, float* __restrict__ part, int n_mb, int n_kb,
                                                        int64_t slice_pts) {
     const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t unit = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int blk = (int)(unit % (n_mb * n_kb));
     const int64_t slice = unit / (n_mb * n_kb);
     const int64_t p_begin = slice * slice_pts;
