@@ -474,3 +474,30 @@ def test_fused_mask_loss_matches_float64_log_softmax_nll(B, N, int_labels):
     again = losses._mask_loss(y, labels)
     (again * 3.0).backward()
     assert float(again) == float(got) and torch.equal(y.grad, x.grad)
+
+
+@pytest.mark.parametrize("M,C", [(4128, 96), (300, 64), (64 * 4096, 128)])
+def test_fused_statistics_entries_equal_the_two_step_ones_bitwise(M, C):
+    """dal3_tr_bn_stats = dal3_tr_colred(mode 0) + dal3_tr_bn_finalize and dal3_tr_bnbwd_sums = dal3_tr_colred(mode 1) +
+    dal3_tr_bnbwd_coef: the second stage of the reduction carries the epilogue, the numbers are the same bits"""
+    lib = hip.lib()
+    gen = torch.Generator(device="cuda").manual_seed(M + C)
+    z = torch.randn((M, C), device="cuda", generator=gen) * 2.0 + 0.5
+    da = torch.randn((M, C), device="cuda", generator=gen)
+    gamma = torch.rand(C, device="cuda", generator=gen) + 0.5
+    beta = torch.randn(C, device="cuda", generator=gen) * 0.3
+    rm1, rv1 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    bn = train._BN(z, gamma, beta, rm1, rv1)                                   # fused
+    sums = train._colred(z, 0)
+    st = torch.empty((4, C), device="cuda")
+    hip.check(lib.dal3_tr_bn_finalize(hip.ptr(sums), C, M, hip.ptr(gamma), hip.ptr(beta), hip.ptr(rm2), hip.ptr(rv2), 0.1,
+                                      1e-5, hip.ptr(st[0]), hip.ptr(st[1]), hip.ptr(st[2]), hip.ptr(st[3]), hip.stream()))
+    for a, b in ((bn.mu, st[0]), (bn.rstd, st[1]), (bn.scale, st[2]), (bn.shift, st[3]), (rm1, rm2), (rv1, rv2)):
+        assert torch.equal(a, b)
+    dz, dgam, dbet = bn.backward(z, da=da)                                      # fused sums + coefficients
+    sums1 = train._colred(z, 1, da=da, bn=(bn.scale, bn.shift, bn.mu, bn.rstd))
+    co = torch.empty((5, C), device="cuda")
+    hip.check(lib.dal3_tr_bnbwd_coef(hip.ptr(sums1), C, M, hip.ptr(bn.gamma), hip.ptr(bn.rstd), hip.ptr(co[0]), hip.ptr(co[1]),
+                                     hip.ptr(co[2]), hip.ptr(co[3]), hip.ptr(co[4]), hip.stream()))
+    assert torch.equal(dgam, co[0]) and torch.equal(dbet, co[1])
