@@ -27,29 +27,50 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--backends", default="hip,torch")
     ap.add_argument("--graph", action="store_true", help="also time the step captured into a hipGraph (device sampler)")
+    ap.add_argument("--kind", default="static_one", choices=["static_one", "dynamic"],
+                    help="static_train.py's StaticModelOneBoxEst (64 x 4096) or dynamic_train.py's DynamicModel (5 x 1024 points "
+                         "+ 101 boxes per item)")
     ap.add_argument("--sampler", default="numpy", choices=["numpy", "device"],
                     help="object-point sampling in the train-mode forward: the reference's host loop or the GPU kernel")
     args = ap.parse_args()
     B, N = args.batch, args.points
     dev = torch.device("cuda", 0)
-    p, i, g = synth.static_crops(min(B, 64), N, seed=3)
-    reps = (B + p.shape[0] - 1) // p.shape[0]
-    pts = torch.from_numpy(np.tile(p, (reps, 1, 1))[:B]).to(dev).transpose(2, 1)
-    init = torch.from_numpy(np.tile(i, (reps, 1))[:B]).to(dev)
-    gt = torch.from_numpy(np.tile(g, (reps, 1))[:B]).to(dev)
+    dynamic = args.kind == "dynamic"
+    if dynamic:
+        dm = importlib.import_module("3dal_pytorch_amd.dynamic_model")
+        if args.points == 4096:
+            args.points = 1024                                  # per frame: 5 x 1024 points per item
+        p, bx, _, g = synth.dynamic_items(min(B, 16), n_per_frame=args.points, seed=3)
+        reps = (B + p.shape[0] - 1) // p.shape[0]
+        N = p.shape[1]
+        pts = torch.from_numpy(np.tile(p, (reps, 1, 1))[:B]).to(dev).transpose(2, 1)
+        init = torch.from_numpy(np.tile(bx, (reps, 1, 1))[:B]).to(dev).transpose(2, 1)      # the box sequence
+        gt = torch.from_numpy(np.tile(g, (reps, 1))[:B]).to(dev)
+    else:
+        p, i, g = synth.static_crops(min(B, 64), N, seed=3)
+        reps = (B + p.shape[0] - 1) // p.shape[0]
+        pts = torch.from_numpy(np.tile(p, (reps, 1, 1))[:B]).to(dev).transpose(2, 1)
+        init = torch.from_numpy(np.tile(i, (reps, 1))[:B]).to(dev)
+        gt = torch.from_numpy(np.tile(g, (reps, 1))[:B]).to(dev)
     labels = ((torch.rand((B, N), device=dev) > 0.6).float(), torch.randn((B, 3), device=dev),
               torch.randint(0, 12, (B,), device=dev), 0.1 * torch.randn((B,), device=dev),
               torch.randint(0, 3, (B,), device=dev), 0.3 * torch.randn((B, 3), device=dev))
-    crit = losses.FrustumPointNetLossOneBoxEst()
-    out = {"workload": f"StaticModelOneBoxEst train step, {B} crops x {N} pts, fp32, Adam, {args.sampler} sampler",
+    crit = losses.DynamicModelLoss() if dynamic else losses.FrustumPointNetLossOneBoxEst()
+    out = {"workload": (f"DynamicModel train step, {B} items x {N} pts + 101 boxes" if dynamic else
+                        f"StaticModelOneBoxEst train step, {B} crops x {N} pts") + f", fp32, Adam, {args.sampler} sampler",
            "unit": "ms per step"}
     # algorithmic FLOP of the per-point stacks: forward + dgrad + wgrad = 3x forward (nominal formulation)
-    mac_pt = sum(ci * co for _, _, ci, co in arch.ins_seg_layers(3)) - 1024 * 512      # per-crop part of dconv1 excluded
-    mac_obj = sum(ci * co for _, _, ci, co in arch.STATIC_BOX_EST["convs"])
-    flop = 3 * 2.0 * (B * N * mac_pt + B * 512 * mac_obj)
+    mac_pt = sum(ci * co for _, _, ci, co in arch.ins_seg_layers(4 if dynamic else 3)) - 1024 * 512   # per-crop part of dconv1 excluded
+    if dynamic:
+        mac_obj = sum(ci * co for _, _, ci, co in arch.POINT_EMB["convs"])
+        mac_box = sum(ci * co for _, _, ci, co in arch.BOX_EMB["convs"])
+        flop = 3 * 2.0 * (B * N * mac_pt + B * 2560 * mac_obj + B * 101 * mac_box)
+    else:
+        mac_obj = sum(ci * co for _, _, ci, co in arch.STATIC_BOX_EST["convs"])
+        flop = 3 * 2.0 * (B * N * mac_pt + B * 512 * mac_obj)
     for backend in args.backends.split(","):
-        model = sm.StaticModelOneBoxEst()
-        model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict("static_one").items()})
+        model = dm.DynamicModel() if dynamic else sm.StaticModelOneBoxEst()
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict(args.kind).items()})
         model = model.to(dev).train()
         model.train_backend = backend
         model.sampler = args.sampler
@@ -82,8 +103,8 @@ def main():
             # bound to that stream, which a capture on another stream cannot use
             graph = importlib.import_module("3dal_pytorch_amd.graph")
             del model, opt
-            gm = sm.StaticModelOneBoxEst()
-            gm.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict("static_one").items()})
+            gm = dm.DynamicModel() if dynamic else sm.StaticModelOneBoxEst()
+            gm.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict(args.kind).items()})
             gm = gm.to(dev).train()
             gm.train_backend, gm.sampler = backend, "device"
             gopt = torch.optim.Adam(gm.parameters(), lr=1e-3, weight_decay=1e-4, capturable=True)

@@ -18,6 +18,7 @@ rocprofv3 $KT -d $O/prof_kt_c5 -o kt -- python3 $R/bench.py --no-extras --config
 # one training step (64 x 4096, fp32, Adam, device sampler): kernel trace of tools/bench_train.py
 rocprofv3 $KT -d $O/prof_kt_train -o kt -- python3 $R/tools/bench_train.py --backends hip --sampler device --iters 10 > $O/bench_train_under_rocprof.json 2>/dev/null
 python3 $R/tools/bench_train.py --sampler device > $O/bench_train.json 2>/dev/null
+python3 $R/tools/bench_train.py --kind dynamic --sampler device > $O/bench_train_dynamic.json 2>/dev/null
 python3 $R/tools/bench_latency.py > $O/bench_latency.json 2>/dev/null
 # the HBM-roofline kernel on its own: kernel trace, then FETCH_SIZE and WRITE_SIZE in separate passes
 rocprofv3 $KT -d $O/prof_kt_maxpool -o kt -- python3 $R/bench.py --only-maxpool --steps 10 > $O/bench_maxpool_under_rocprof.json 2>/dev/null
