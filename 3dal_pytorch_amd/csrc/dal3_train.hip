@@ -264,8 +264,8 @@ __device__ __forceinline__ void tr_ring_block(WRing<DAL3_PF>& ring, const f32x16
 #ifndef TR_RING_OCC
 #define TR_RING_OCC 1                   // waves per SIMD the kernel is compiled for: at 2 (256 registers) <2, 4> spilled and ran 5 % slower
 #endif
-template <int T, int MTB>
-__global__ __launch_bounds__(256, TR_RING_OCC) void tr_linear_ring_kernel(const float* __restrict__ a, int64_t M, int c_in, int64_t lda,
+template <int T, int MTB, int OCC>
+__global__ __launch_bounds__(256, OCC) void tr_linear_ring_kernel(const float* __restrict__ a, int64_t M, int c_in, int64_t lda,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, int relu_in,
                                                                 const f32x4* __restrict__ wpk, const float* __restrict__ bias,
@@ -479,7 +479,7 @@ size_t tr_linear_workspace_bytes(int c_in, int c_out) {
 
 #define TR_SMALL_M 256                   // at most this many rows: one 32 x 32 output tile per wave (<1, 1>)
 
-template <int T, int MTB>
+template <int T, int MTB, int OCC>
 static void tr_linear_ring_launch(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                                   int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
                                   int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s) {
@@ -488,7 +488,7 @@ static void tr_linear_ring_launch(const float* a, int64_t M, int c_in, int64_t l
     const int64_t n = (int64_t)c_out * c_in;
     hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, transpose_w, c_out, c_in,
                        MTB, ws);
-    hipLaunchKernelGGL((tr_linear_ring_kernel<T, MTB>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda,
+    hipLaunchKernelGGL((tr_linear_ring_kernel<T, MTB, OCC>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda,
                        scale, shift, relu_in, reinterpret_cast<const f32x4*>(ws), bias, seg, c_out, z, ldz, accumulate,
                        n_mblk);
 }
@@ -497,15 +497,18 @@ hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, co
                             int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
                             int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s) {
     const bool ring_ok = ws && (!scale || c_in <= TR_MAX_ACT_CIN);
+    // K <= 128: a wave's whole K loop is a few microseconds, about as long as its prologue and its stores; the smaller
+    // <2, 2> tile fits two waves per SIMD, so one wave's ends run under the other's MFMAs (64 -> 512: 282 -> 258 us)
+    const int small_k = 128;
     if (ring_ok && M <= TR_SMALL_M) {
-        tr_linear_ring_launch<1, 1>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
-                                    accumulate, ws, s);
-    } else if (ring_ok && c_out % 128 == 0) {
-        tr_linear_ring_launch<TR_T, TR_MTB>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z,
-                                            ldz, accumulate, ws, s);
-    } else if (ring_ok && c_out % 64 == 0) {
-        tr_linear_ring_launch<TR_T, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
+        tr_linear_ring_launch<1, 1, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
                                        accumulate, ws, s);
+    } else if (ring_ok && c_out % 128 == 0 && c_in > small_k) {
+        tr_linear_ring_launch<TR_T, TR_MTB, TR_RING_OCC>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg,
+                                                         c_out, z, ldz, accumulate, ws, s);
+    } else if (ring_ok && c_out % 64 == 0) {
+        tr_linear_ring_launch<TR_T, 2, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
+                                          accumulate, ws, s);
     } else {
         const int n_mblk = (c_out / 32 + TR_MTB - 1) / TR_MTB;
         const int64_t units = ((M + 32 * TR_T - 1) / (32 * TR_T)) * n_mblk;
