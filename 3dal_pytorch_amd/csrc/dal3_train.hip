@@ -509,6 +509,9 @@ hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, co
     } else if (ring_ok && c_out % 64 == 0) {
         tr_linear_ring_launch<TR_T, 2, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
                                           accumulate, ws, s);
+    } else if (ring_ok) {                                   // c_out = 32, 96, ...: one output tile per wave
+        tr_linear_ring_launch<TR_T, 1, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
+                                          accumulate, ws, s);
     } else {
         const int n_mblk = (c_out / 32 + TR_MTB - 1) / TR_MTB;
         const int64_t units = ((M + 32 * TR_T - 1) / (32 * TR_T)) * n_mblk;
@@ -870,31 +873,35 @@ struct WgBlock {
 };
 
 // pa / pb point at this lane's element of the block's first point row: dz[(p0 + h)][32*mt0 + m], a[(p0 + h)][32*kt0 + m];
-// the tiles of the block are 32 floats apart (an immediate offset), successive k-steps two rows apart.
+// the tiles of the block are 32 floats apart, successive k-steps two rows apart. A tile past the layer's edge (t >= n_mt,
+// k >= n_kt) re-reads the last real one — oa / ob hold the clamped offsets — and its accumulator is simply never stored:
+// a conditional load (`t < n_mt ? p[..] : 0`) is a BRANCH per load to hipcc, 50-120 of them per 16-point block, and
+// with them every load, its address arithmetic and the activation sat in one blob between two bursts of MFMAs (the big
+// layers ran at 58 % of peak for it).
 template <int MT, int KT>
 __device__ __forceinline__ void wg_load(WgBlock<MT, KT>& bk, const float* __restrict__ pa, int64_t lddz,
-                                        const float* __restrict__ pb, int64_t lda, int n_mt, int n_kt) {
+                                        const float* __restrict__ pb, int64_t lda, const int (&oa)[MT], const int (&ob)[KT]) {
 #pragma unroll
     for (int s = 0; s < WG_KS; ++s) {
         const float* ra = pa + 2 * s * lddz;
         const float* rb = pb + 2 * s * lda;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) bk.av[s][t] = t < n_mt ? ra[32 * t] : 0.0f;
+        for (int t = 0; t < MT; ++t) bk.av[s][t] = ra[oa[t]];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) bk.bv[s][k] = k < n_kt ? rb[32 * k] : 0.0f;   // raw; activation at use
+        for (int k = 0; k < KT; ++k) bk.bv[s][k] = rb[ob[k]];                        // raw; activation at use
     }
 }
 
 template <int MT, int KT>
 __device__ __forceinline__ void wg_compute(WgBlock<MT, KT>& bk, f32x16 (&acc)[MT][KT], const float (&sc)[KT],
-                                           const float (&sh)[KT], bool act, int relu_in, int n_kt) {
+                                           const float (&sh)[KT], bool act, int relu_in) {
     if (act) {
 #pragma unroll
         for (int s = 0; s < WG_KS; ++s)
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const float v = bk.bv[s][k] * sc[k] + sh[k];
-                bk.bv[s][k] = k < n_kt ? (relu_in ? fmaxf(v, 0.0f) : v) : 0.0f;
+                bk.bv[s][k] = relu_in ? fmaxf(v, 0.0f) : v;
             }
     }
 #pragma unroll
@@ -924,11 +931,16 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
     const int64_t p_end = min(M, p_begin + slice_pts);         // M % 32 == 0, slice_pts % 64 == 0: whole 16-point blocks
     const int mt0 = (blk / n_kb) * MT, kt0 = (blk % n_kb) * KT;
     const int n_mt = min(MT, c_out / 32 - mt0), n_kt = min(KT, c_in / 32 - kt0);
+    int oa[MT], ob[KT];                                        // tile offsets, clamped to the last real tile (see wg_load)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) oa[t] = 32 * min(t, n_mt - 1);
+#pragma unroll
+    for (int k = 0; k < KT; ++k) ob[k] = 32 * min(k, n_kt - 1);
     float sc[KT], sh[KT];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-        sc[k] = (scale && k < n_kt) ? scale[32 * (kt0 + k) + m] : 1.0f;
-        sh[k] = (scale && k < n_kt) ? shift[32 * (kt0 + k) + m] : 0.0f;
+        sc[k] = scale ? scale[32 * kt0 + ob[k] + m] : 1.0f;
+        sh[k] = scale ? shift[32 * kt0 + ob[k] + m] : 0.0f;
     }
     f32x16 acc[MT][KT];
 #pragma unroll
@@ -947,18 +959,18 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
         // ping-pong with running pointers (n_blk is even: M and the slices are multiples of 32 points)
         const float* pa = pa0;
         const float* pb = pb0;
-        wg_load(ring[0], pa, lddz, pb, lda, n_mt, n_kt);
+        wg_load(ring[0], pa, lddz, pb, lda, oa, ob);
         for (int64_t i = 0; i < n_blk; i += 2) {
-            wg_load(ring[1], pa + sa, lddz, pb + sb, lda, n_mt, n_kt);
+            wg_load(ring[1], pa + sa, lddz, pb + sb, lda, oa, ob);
             DAL3_SCHED_FENCE();
-            wg_compute(ring[0], acc, sc, sh, act, relu_in, n_kt);
+            wg_compute(ring[0], acc, sc, sh, act, relu_in);
             DAL3_SCHED_FENCE();
             const bool more = i + 2 < n_blk;
             pa = more ? pa + 2 * sa : pa0;
             pb = more ? pb + 2 * sb : pb0;
-            wg_load(ring[0], pa, lddz, pb, lda, n_mt, n_kt);
+            wg_load(ring[0], pa, lddz, pb, lda, oa, ob);
             DAL3_SCHED_FENCE();
-            wg_compute(ring[1], acc, sc, sh, act, relu_in, n_kt);
+            wg_compute(ring[1], acc, sc, sh, act, relu_in);
             DAL3_SCHED_FENCE();
         }
     } else {
@@ -967,16 +979,16 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
 #pragma unroll
         for (int b = 0; b < NB - 1; ++b) {
             const int64_t i = b < n_blk ? b : 0;
-            wg_load(ring[b], pa0 + i * sa, lddz, pb0 + i * sb, lda, n_mt, n_kt);
+            wg_load(ring[b], pa0 + i * sa, lddz, pb0 + i * sb, lda, oa, ob);
         }
         for (int64_t i0 = 0; i0 < n_blk; i0 += NB) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int64_t nx = i0 + u + NB - 1;
                 const int64_t j = nx < n_blk ? nx : 0;
-                wg_load(ring[(u + NB - 1) % NB], pa0 + j * sa, lddz, pb0 + j * sb, lda, n_mt, n_kt);
+                wg_load(ring[(u + NB - 1) % NB], pa0 + j * sa, lddz, pb0 + j * sb, lda, oa, ob);
                 DAL3_SCHED_FENCE();
-                if (i0 + u < n_blk) wg_compute(ring[u], acc, sc, sh, act, relu_in, n_kt);
+                if (i0 + u < n_blk) wg_compute(ring[u], acc, sc, sh, act, relu_in);
                 DAL3_SCHED_FENCE();
             }
         }
