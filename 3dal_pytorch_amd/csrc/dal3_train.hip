@@ -15,6 +15,8 @@
 // materialised once; normalisation + ReLU are applied on load by the consumer ("act": y = max(z*scale+shift, 0)).
 // All channel counts are multiples of 32 here (the host pads 3 -> 32 input channels and 2 -> 32 logits; that is
 // < 1 % of the work) and M is a multiple of 32.
+#include <type_traits>
+
 #include "dal3_device.h"
 #include "dal3_kernels.h"
 
@@ -282,9 +284,11 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_ring_kernel(const float* _
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the ring's buffer descriptor stays in SGPRs — from a per-lane value hipcc builds a waterfall loop around EVERY fragment fetch)
-    const int mblk = (int)(unit % n_mblk);
-    const int64_t pt0 = (unit / n_mblk) * (32 * T);
+    // scalar (the ring's buffer descriptor stays in SGPRs: from a per-lane value hipcc builds a waterfall loop around every
+    // fragment fetch) and 32-bit (a 64-bit division is ~200 instructions; the host keeps the unit count below 2^32)
+    const uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mblk = (int)(unit % (uint32_t)n_mblk);
+    const int64_t pt0 = (int64_t)(unit / (uint32_t)n_mblk) * (32 * T);
     if (pt0 >= M) return;
     const int mt0 = mblk * MTB;
     const int KT = c_in / 32;
@@ -294,17 +298,27 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_ring_kernel(const float* _
     WRing<DAL3_PF> ring;
     ring.init(wpk + (int64_t)mblk * KT * (4 * MTB) * 64, lane);
     f32x16 acc[T][MTB];
+    if (bias) {
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
-#pragma unroll
-        for (int t = 0; t < MTB; ++t) {
-            if (bias) {
-                const float* bp = bias + (seg > 0 ? (prow[j] / seg) * c_out : 0) + 32 * (mt0 + t);
-                acc[j][t] = tile_from_channels(bp, h);
-            } else {
-                acc[j][t] = f32x16{};
+        for (int j = 0; j < T; ++j) {
+            // the per-segment term's row: ONE division per point tile, scalar when a tile cannot straddle two segments
+            // (seg % 32 == 0: every caller with N % 32 == 0), 32-bit per lane otherwise — `prow[j] / seg` as written, a
+            // 64-bit division per lane and output tile, was ~1,000 of the 1,400 vector instructions in front of the
+            // first MFMA (4 us per wave against 7 us of MFMAs for a K = 64 layer)
+            int64_t row = 0;
+            if (seg > 0) {
+                const int64_t first = min(pt0 + 32 * j, M - 32);
+                row = (seg % 32 == 0) ? (int64_t)((uint32_t)first / (uint32_t)seg) : (int64_t)((uint32_t)prow[j] / (uint32_t)seg);
             }
+            const float* bp = bias + row * c_out + 32 * mt0;
+#pragma unroll
+            for (int t = 0; t < MTB; ++t) acc[j][t] = tile_from_channels(bp + 32 * t, h);
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int t = 0; t < MTB; ++t) acc[j][t] = f32x16{};
     }
     constexpr int BASE2 = (4 * MTB) % DAL3_PF;               // ring slot of the second k-tile's first fragment
     TrX<T> xa, xb;                                           // raw loads one k-tile ahead; activation applied at use
@@ -321,27 +335,34 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_ring_kernel(const float* _
             tr_ring_block<T, MTB, BASE2>(ring, xb.X, acc);
         }
     }
+    // (the branch on `accumulate` OUTSIDE the store loops: inside, it is a branch per store — 64 per wave)
+    auto store_tiles = [&](auto acc_flag) {
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
-        if (pt0 + 32 * j >= M) break;
-        float* zp = z + (pt0 + 32 * j + m) * ldz + 4 * h;
+        for (int j = 0; j < T; ++j) {
+            if (pt0 + 32 * j >= M) break;
+            float* zp = z + (pt0 + 32 * j + m) * ldz + 4 * h;
 #pragma unroll
-        for (int t = 0; t < MTB; ++t) {
+            for (int t = 0; t < MTB; ++t) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4* dst = reinterpret_cast<f32x4*>(zp + 32 * (mt0 + t) + 8 * q);
-                f32x4 o = {acc[j][t][4 * q], acc[j][t][4 * q + 1], acc[j][t][4 * q + 2], acc[j][t][4 * q + 3]};
-                if (accumulate) {
-                    const f32x4 old = *dst;
-                    o[0] += old[0];
-                    o[1] += old[1];
-                    o[2] += old[2];
-                    o[3] += old[3];
+                for (int q = 0; q < 4; ++q) {
+                    f32x4* dst = reinterpret_cast<f32x4*>(zp + 32 * (mt0 + t) + 8 * q);
+                    f32x4 o = {acc[j][t][4 * q], acc[j][t][4 * q + 1], acc[j][t][4 * q + 2], acc[j][t][4 * q + 3]};
+                    if (decltype(acc_flag)::value) {
+                        const f32x4 old = *dst;
+                        o[0] += old[0];
+                        o[1] += old[1];
+                        o[2] += old[2];
+                        o[3] += old[3];
+                    }
+                    *dst = o;
                 }
-                *dst = o;
             }
         }
-    }
+    };
+    if (accumulate)
+        store_tiles(std::true_type{});
+    else
+        store_tiles(std::false_type{});
 }
 
 __global__ void tr_segmax_unpack_kernel(const unsigned long long* __restrict__ packed, int64_t n, float* __restrict__ g,
