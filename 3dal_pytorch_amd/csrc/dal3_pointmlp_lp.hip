@@ -615,10 +615,20 @@ __global__ __launch_bounds__(256, DAL3_LP_HEAD_SLOTS == 2 ? 2 : 1) void point_he
     lp_max_tiles_finish<T>(acc4, s_b4 + 512 - 32, s_max + 512 - 32, lane);
     __syncthreads();
     int* fi = reinterpret_cast<int*>(feat + b * 512);
-    for (int i = threadIdx.x; i < 512; i += 256) {
-        const int v = s_max[i];
-        if (v > 0) atomicMax(fi + i, v);
-        s_max[i] = 0;                                      // for the next group: its LDS atomics come after >= 1 barrier
+    {
+        // the thread index rebuilt from an opaque lane id: derived from threadIdx.x the per-lane address is a loop
+        // invariant that hipcc hoists, spills, and reloads here behind an s_waitcnt vmcnt(0) — which also waits for the
+        // ring refill issued a moment ago (see the decode kernel's fresh_lane)
+        unsigned z = 0;
+        asm volatile("" : "+v"(z));
+        const int tix = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = tix + 256 * r;
+            const int v = s_max[i];
+            if (v > 0) atomicMax(fi + i, v);
+            s_max[i] = 0;                                  // for the next group: its LDS atomics come after >= 1 barrier
+        }
     }
   }
 }
