@@ -802,6 +802,25 @@ extern "C" int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int
     return 0;
 }
 
+extern "C" int dal3_tr_box_loss(const float* center, const float* center_label, const float* heading_scores,
+                                const float* heading_residuals_normalized, const int64_t* heading_class_label,
+                                const float* heading_residuals_label, const float* size_scores,
+                                const float* size_residuals_normalized, const int64_t* size_class_label,
+                                const float* size_residuals_label, int B, float* losses, float* g_center,
+                                float* g_heading_scores, float* g_heading_residuals_normalized, float* g_size_scores,
+                                float* g_size_residuals_normalized, dal3_stream stream) {
+    if (!center || !center_label || !heading_scores || !heading_residuals_normalized || !heading_class_label ||
+        !heading_residuals_label || !size_scores || !size_residuals_normalized || !size_class_label ||
+        !size_residuals_label || B <= 0 || !losses || !g_center || !g_heading_scores || !g_heading_residuals_normalized ||
+        !g_size_scores || !g_size_residuals_normalized)
+        return fail(DAL3_EINVAL, "tr_box_loss: bad argument");
+    HIP_TRY(launch_tr_box_loss(center, center_label, heading_scores, heading_residuals_normalized, heading_class_label,
+                               heading_residuals_label, size_scores, size_residuals_normalized, size_class_label,
+                               size_residuals_label, B, losses, g_center, g_heading_scores, g_heading_residuals_normalized,
+                               g_size_scores, g_size_residuals_normalized, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" size_t dal3_tr_seg_ce_workspace_bytes(int64_t M) { return M > 0 ? tr_seg_ce_workspace_bytes(M) : 0; }
 
 extern "C" int dal3_tr_seg_ce(const float* logits, const void* labels, int labels_are_int64, int64_t M, float* loss,

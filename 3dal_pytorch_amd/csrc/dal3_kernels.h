@@ -215,6 +215,10 @@ size_t tr_colred_workspace_bytes(int64_t M, int C);
 hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                             const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                             const float* mu, const float* rstd, double* part, double* out, hipStream_t s);
+hipError_t launch_tr_box_loss(const float* center, const float* center_label, const float* hs, const float* hrn,
+                              const int64_t* hcl, const float* hrl, const float* ss, const float* srn, const int64_t* scl,
+                              const float* srl, int B, float* losses, float* g_center, float* g_hs, float* g_hrn, float* g_ss,
+                              float* g_srn, hipStream_t s);
 size_t tr_seg_ce_workspace_bytes(int64_t M);
 hipError_t launch_tr_seg_ce(const float* logits, const void* labels, int labels_i64, int64_t M, float* loss, float* dlogits,
                             double* part, hipStream_t s);

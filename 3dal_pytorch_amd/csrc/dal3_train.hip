@@ -1309,3 +1309,116 @@ hipError_t launch_tr_seg_ce(const float* logits, const void* labels, int labels_
     hipLaunchKernelGGL(tr_seg_ce_final_kernel, dim3(1), dim3(256), 0, s, part, nb, M, loss);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------- box loss terms
+// The five box terms of the criteria (static_model.py:382-424 per estimate, dynamic_model.py:341-383): centre (Huber of
+// the L2 distance, delta 2), heading class (cross-entropy over 12 bins), heading residual (Huber, delta 1, of the
+// predicted normalised residual of the LABEL's bin against label / (pi/12)), size class (cross-entropy over 3) and size
+// residual (Huber, delta 1, of || label / mean_size[class] - predicted normalised residual of the label's class ||), each
+// the mean over the B items — and the gradient of every mean w.r.t. its inputs, in the same pass. O(B) work that stock
+// ops spread over ~60 launches per estimate and step. One workgroup; per-thread float64 sums over items tid, tid+256, ...,
+// added in thread order (reproducible).
+__constant__ float c_tr_mean_size[9] = {4.8f, 1.8f, 1.5f, 10.0f, 2.6f, 3.2f, 2.0f, 1.0f, 1.6f};
+
+struct BoxLossArgs {
+    const float* center;        // (B,3)
+    const float* center_label;  // (B,3)
+    const float* hs;            // (B,12) heading scores
+    const float* hrn;           // (B,12) normalised heading residuals
+    const int64_t* hcl;         // (B,)
+    const float* hrl;           // (B,)
+    const float* ss;            // (B,3)  size scores
+    const float* srn;           // (B,3,3) normalised size residuals
+    const int64_t* scl;         // (B,)
+    const float* srl;           // (B,3)
+    float* losses;              // (5,): centre, heading class, heading residual, size class, size residual
+    float* g_center;            // (B,3)   d losses[0] / d center
+    float* g_hs;                // (B,12)  d losses[1] / d hs
+    float* g_hrn;               // (B,12)  d losses[2] / d hrn
+    float* g_ss;                // (B,3)   d losses[3] / d ss
+    float* g_srn;               // (B,9)   d losses[4] / d srn
+};
+
+__global__ __launch_bounds__(256) void tr_box_loss_kernel(BoxLossArgs a, int B) {
+    __shared__ double sm[5][256];
+    const float inv_b = 1.0f / (float)B;
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < B; b += 256) {
+        // centre
+        float d[3], n2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            d[k] = a.center[b * 3 + k] - a.center_label[b * 3 + k];
+            n2 += d[k] * d[k];
+        }
+        const float dist = sqrtf(n2);
+        float q = fminf(dist, 2.0f);
+        acc[0] += (double)(0.5f * q * q + 2.0f * (dist - q));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.g_center[b * 3 + k] = dist > 0.0f ? q * d[k] / dist * inv_b : 0.0f;
+        // heading class
+        const int hc = (int)a.hcl[b];
+        float mx = a.hs[b * 12];
+#pragma unroll
+        for (int k = 1; k < 12; ++k) mx = fmaxf(mx, a.hs[b * 12 + k]);
+        float e[12], sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            e[k] = expf(a.hs[b * 12 + k] - mx);
+            sum += e[k];
+        }
+        acc[1] += (double)(mx + logf(sum) - a.hs[b * 12 + hc]);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) a.g_hs[b * 12 + k] = (e[k] / sum - (k == hc ? 1.0f : 0.0f)) * inv_b;
+        // heading residual of the label's bin
+        const float er = a.hrn[b * 12 + hc] - a.hrl[b] / (float)(3.14159265358979323846 / 12.0);
+        const float ae = fabsf(er);
+        q = fminf(ae, 1.0f);
+        acc[2] += (double)(0.5f * q * q + (ae - q));
+#pragma unroll
+        for (int k = 0; k < 12; ++k) a.g_hrn[b * 12 + k] = k == hc ? (er > 0.0f ? q : (er < 0.0f ? -q : 0.0f)) * inv_b : 0.0f;
+        // size class
+        const int sc = (int)a.scl[b];
+        const float s0 = a.ss[b * 3], s1 = a.ss[b * 3 + 1], s2 = a.ss[b * 3 + 2];
+        const float smx = fmaxf(s0, fmaxf(s1, s2));
+        const float f0 = expf(s0 - smx), f1 = expf(s1 - smx), f2 = expf(s2 - smx);
+        const float fs = f0 + f1 + f2;
+        acc[3] += (double)(smx + logf(fs) - a.ss[b * 3 + sc]);
+        a.g_ss[b * 3 + 0] = (f0 / fs - (sc == 0 ? 1.0f : 0.0f)) * inv_b;
+        a.g_ss[b * 3 + 1] = (f1 / fs - (sc == 1 ? 1.0f : 0.0f)) * inv_b;
+        a.g_ss[b * 3 + 2] = (f2 / fs - (sc == 2 ? 1.0f : 0.0f)) * inv_b;
+        // size residual of the label's class
+        float v[3];
+        n2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            v[k] = a.srl[b * 3 + k] / c_tr_mean_size[sc * 3 + k] - a.srn[b * 9 + sc * 3 + k];
+            n2 += v[k] * v[k];
+        }
+        const float sd = sqrtf(n2);
+        q = fminf(sd, 1.0f);
+        acc[4] += (double)(0.5f * q * q + (sd - q));
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int cls = k / 3, kk = k % 3;
+            a.g_srn[b * 9 + k] = (cls == sc && sd > 0.0f) ? -q * v[kk] / sd * inv_b : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) sm[t][threadIdx.x] = acc[t];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double s = 0.0;
+        for (int i = 0; i < 256; ++i) s += sm[threadIdx.x][i];
+        a.losses[threadIdx.x] = (float)(s / (double)B);
+    }
+}
+
+hipError_t launch_tr_box_loss(const float* center, const float* center_label, const float* hs, const float* hrn,
+                              const int64_t* hcl, const float* hrl, const float* ss, const float* srn, const int64_t* scl,
+                              const float* srl, int B, float* losses, float* g_center, float* g_hs, float* g_hrn, float* g_ss,
+                              float* g_srn, hipStream_t s) {
+    BoxLossArgs a{center, center_label, hs, hrn, hcl, hrl, ss, srn, scl, srl, losses, g_center, g_hs, g_hrn, g_ss, g_srn};
+    hipLaunchKernelGGL(tr_box_loss_kernel, dim3(1), dim3(256), 0, s, a, B);
+    return hipGetLastError();
+}

@@ -5,7 +5,8 @@ with `huber_loss` (:341-346). Same call signature, same keys in the returned dic
 
 Stock torch ops on whatever device the outputs live on (the reference hard-codes `.cuda()` on its one-hot
 tables): next to the per-point stacks this is O(B) work — plus the mask term over the (B*N, 2) logits, which on the
-GPU is one pass of lib3dal_hip.so (`_SegCE`: loss and gradient together) instead of six stock kernels.
+GPU is one pass of lib3dal_hip.so (`_SegCE`: loss and gradient together) instead of six stock kernels, and the five
+box terms of an estimate with their gradients are one launch (`_BoxTerms`) instead of ~60.
 """
 import numpy as np
 import torch
@@ -68,10 +69,39 @@ def _mask_loss(logits, mask_label):
     return F.nll_loss(F.log_softmax(logits.view(-1, 2), dim=1), mask_label.view(-1).long())
 
 
+class _BoxTerms(torch.autograd.Function):
+    """the five box terms of one estimate and their gradients in one launch of lib3dal_hip.so (dal3_tr_box_loss)"""
+
+    @staticmethod
+    def forward(ctx, center, hs, hrn, ss, srn, center_label, hcl, hrl, scl, srl):
+        from . import _hip
+        f = lambda t: t.detach().contiguous().float()                       # noqa: E731
+        B, dev = center.shape[0], center.device
+        ins = (f(center), f(center_label), f(hs), f(hrn), hcl.long().contiguous(), f(hrl), f(ss), f(srn),
+               scl.long().contiguous(), f(srl))
+        losses = torch.empty(5, dtype=torch.float32, device=dev)
+        g = [torch.empty(s, dtype=torch.float32, device=dev) for s in ((B, 3), (B, 12), (B, 12), (B, 3), (B, 3, 3))]
+        _hip.check(_hip.lib().dal3_tr_box_loss(*[_hip.ptr(t) for t in ins], B, _hip.ptr(losses), *[_hip.ptr(t) for t in g],
+                                               _hip.stream()))
+        ctx.save_for_backward(*g)
+        return losses[0], losses[1], losses[2], losses[3], losses[4]
+
+    @staticmethod
+    def backward(ctx, gc, ghc, ghr, gsc, gsr):
+        g = ctx.saved_tensors
+        return (g[0] * gc, g[1] * ghc, g[2] * ghr, g[3] * gsc, g[4] * gsr, None, None, None, None, None)
+
+
 def _box_terms(center, heading_scores, heading_residuals_normalized, size_scores, size_residuals_normalized, center_label,
                heading_class_label, heading_residuals_label, size_class_label, size_residuals_label):
     """(center, heading class, heading residual, size class, size residual) losses of ONE box estimate"""
     dev = center.device
+    if center.is_cuda and center.dtype == torch.float32 and all(
+            t.is_cuda for t in (heading_scores, center_label, heading_class_label, heading_residuals_label,
+                                size_class_label, size_residuals_label)):
+        return _BoxTerms.apply(center, heading_scores, heading_residuals_normalized, size_scores, size_residuals_normalized,
+                               center_label, heading_class_label, heading_residuals_label, size_class_label,
+                               size_residuals_label)
     center_loss = huber_loss(torch.norm(center - center_label, dim=1), delta=2.0)
     hcl, scl = heading_class_label.long(), size_class_label.long()
     heading_class_loss = F.nll_loss(F.log_softmax(heading_scores, dim=1), hcl)

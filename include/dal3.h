@@ -307,6 +307,19 @@ int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, cons
  * of M * loss; the caller scales it). logits, dlogits: (M, 2) fp32 contiguous; labels: (M,) float32 or int64 (0 / 1).
  * Sums in float64, blocks added in index order (reproducible). workspace: dal3_tr_seg_ce_workspace_bytes(M). */
 size_t dal3_tr_seg_ce_workspace_bytes(int64_t M);
+/* The five box terms of one box estimate (tools/static_model.py:382-424, tools/dynamic_model.py:341-383), each the mean
+ * over the B items: losses[0..4] = centre (Huber, delta 2, of ||center - label||), heading class (cross-entropy, 12
+ * bins), heading residual (Huber, delta 1, of the label bin's normalised residual against label / (pi/12)), size class
+ * (cross-entropy, 3), size residual (Huber, delta 1, of ||label / mean_size[class] - the label class's normalised
+ * residual||) — unweighted; and g_* = the gradient of the matching loss w.r.t. that input (the other entries 0).
+ * All inputs contiguous fp32 except the two int64 class labels (values in range). One launch. */
+int dal3_tr_box_loss(const float* center, const float* center_label, const float* heading_scores,
+                     const float* heading_residuals_normalized, const int64_t* heading_class_label,
+                     const float* heading_residuals_label, const float* size_scores,
+                     const float* size_residuals_normalized, const int64_t* size_class_label,
+                     const float* size_residuals_label, int B, float* losses, float* g_center, float* g_heading_scores,
+                     float* g_heading_residuals_normalized, float* g_size_scores, float* g_size_residuals_normalized,
+                     dal3_stream stream);
 int dal3_tr_seg_ce(const float* logits, const void* labels, int labels_are_int64, int64_t M, float* loss, float* dlogits,
                    void* workspace, size_t workspace_bytes, dal3_stream stream);
 /* The two reductions WITH their per-channel epilogues (what a training step calls: the second stage of the reduction

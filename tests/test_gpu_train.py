@@ -501,3 +501,35 @@ def test_fused_statistics_entries_equal_the_two_step_ones_bitwise(M, C):
     hip.check(lib.dal3_tr_bnbwd_coef(hip.ptr(sums1), C, M, hip.ptr(bn.gamma), hip.ptr(bn.rstd), hip.ptr(co[0]), hip.ptr(co[1]),
                                      hip.ptr(co[2]), hip.ptr(co[3]), hip.ptr(co[4]), hip.stream()))
     assert torch.equal(dgam, co[0]) and torch.equal(dbet, co[1])
+
+
+@pytest.mark.parametrize("tag", ["one", "two", "dyn"])
+def test_criteria_on_the_gpu_match_the_stock_float64_formulation(tag):
+    """The three loss modules on CUDA tensors (mask term: dal3_tr_seg_ce, box terms: dal3_tr_box_loss, one launch per
+    estimate) against the same modules on CPU float64 tensors (stock torch ops, pinned to the reference's criteria by
+    tests/test_host_dropin_train.py): every entry of the loss dict and the gradient of the total w.r.t. every output that
+    takes part, two values of w_box, a batch that needs more than one pass of the kernel's 256 threads."""
+    losses = importlib.import_module("3dal_pytorch_amd.losses")
+    crit = {"one": losses.FrustumPointNetLossOneBoxEst, "two": losses.FrustumPointNetLossTwoBoxEst,
+            "dyn": losses.DynamicModelLoss}[tag]()
+    for B, w_box in ((8, 1.0), (300, 0.3)):
+        out_np, labels_np = synth.loss_case(50 + B, batch=B, n_pts=64, two_stage=(tag == "two"))
+        labels_np = list(labels_np)
+        labels_np[1] = labels_np[1] + np.float32(3.0) * (np.arange(B)[:, None] % 2).astype(np.float32)   # some centres beyond delta
+        grad_keys = [k for k, v in out_np.items() if v.dtype == np.float32 and not k.endswith("label_two")]
+        res = {}
+        for dev, dt in (("cuda", torch.float32), ("cpu", torch.float64)):
+            o = {k: (torch.from_numpy(v).to(dev).to(dt) if v.dtype == np.float32 else torch.from_numpy(v).to(dev))
+                 for k, v in out_np.items()}
+            for k in grad_keys:
+                o[k].requires_grad_(True)
+            lab = [torch.from_numpy(a).to(dev).to(dt) if a.dtype == np.float32 else torch.from_numpy(a).to(dev) for a in labels_np]
+            ls = crit(o, *lab, w_box=w_box)
+            ls["total_loss"].backward()
+            res[dev] = ({k: float(v.detach()) for k, v in ls.items()},
+                        {k: o[k].grad.detach().cpu().double() for k in grad_keys if o[k].grad is not None})
+        assert set(res["cuda"][0]) == set(res["cpu"][0]) and set(res["cuda"][1]) == set(res["cpu"][1])
+        for k, v in res["cpu"][0].items():
+            assert abs(res["cuda"][0][k] - v) <= 2e-6 * max(abs(v), 1e-3), (k, res["cuda"][0][k], v)
+        for k, g in res["cpu"][1].items():
+            assert float((res["cuda"][1][k] - g).abs().max()) <= 2e-6 * max(float(g.abs().max()), 1e-6), k
