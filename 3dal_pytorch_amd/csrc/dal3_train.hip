@@ -1422,3 +1422,115 @@ hipError_t launch_tr_box_loss(const float* center, const float* center_label, co
     hipLaunchKernelGGL(tr_box_loss_kernel, dim3(1), dim3(256), 0, s, a, B);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------- pooled layer, sparse terms
+// The two B*C-sparse terms of the backward of  conv -> BN -> ReLU -> max over an item's points  (train.py
+// _pooled_layer_backward): with row(b,c) = b*N + arg[b][c] the pooled point of channel c in item b and kd = k1 * dy there,
+//     da[row(b,c)][:] += kd[b][c] * W[c][:]                  (scatter: several channels of an item can share a point)
+//     dWs[c][:]        = sum_b kd[b][c] * a[row(b,c)][:]     (gather)
+// Stock ops did the first as a 33 MB outer product + index_put_(accumulate=True) (a sort of the 65,536 row indices and two
+// passes) and the second as a 33 MB gather + product + sum: 0.4 ms of a 9.6 ms step.
+// Scatter, one workgroup per item, DETERMINISTIC without a global sort: the item's channels are bucketed by point in LDS
+// (count, prefix sum, fill by atomic slot, then each point's short list is put in channel order), and each touched row is
+// owned by one group of K/4 lanes that adds its channels' terms in that order and updates the row once.
+// LDS: (2 N + C + 1) ints per item, at most 64 KiB (N = 5120 points and C = 1024 channels: 45 KiB)
+__global__ __launch_bounds__(256) void tr_pool_scatter_kernel(const int32_t* __restrict__ arg, const float* __restrict__ kd,
+                                                              const float* __restrict__ W, int64_t ldw, int C, int K, int N,
+                                                              float* __restrict__ da, int64_t ldda) {
+    extern __shared__ int s_pool[];
+    int* cnt = s_pool;                                     // [N + 1] counts, then start offsets (exclusive prefix)
+    int* fill = s_pool + N + 1;                            // [N] slots handed out
+    int* list = fill + N;                                  // [C] channels grouped by point
+    __shared__ int s_part[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int p = tid; p <= N; p += 256) cnt[p] = 0;
+    for (int p = tid; p < N; p += 256) fill[p] = 0;
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) atomicAdd(&cnt[arg[(int64_t)b * C + c]], 1);
+    __syncthreads();
+    // exclusive prefix sum over cnt[0..N): a contiguous chunk per thread, then the 256 chunk totals
+    const int chunk = (N + 255) / 256, p0 = tid * chunk, p1 = min(N, p0 + chunk);
+    int loc = 0;
+    for (int p = p0; p < p1; ++p) loc += cnt[p];
+    s_part[tid] = loc;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int v = s_part[i];
+            s_part[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    int run = s_part[tid];
+    for (int p = p0; p < p1; ++p) {
+        const int v = cnt[p];
+        cnt[p] = run;
+        run += v;
+    }
+    if (tid == 255) cnt[N] = C;
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int p = arg[(int64_t)b * C + c];
+        list[cnt[p] + atomicAdd(&fill[p], 1)] = c;
+    }
+    __syncthreads();
+    for (int p = tid; p < N; p += 256) {                   // channel order inside each point's list (insertion sort: the
+        const int s0 = cnt[p], n = fill[p];                // lists are a handful of entries)
+        for (int i = 1; i < n; ++i) {
+            const int v = list[s0 + i];
+            int j = i - 1;
+            while (j >= 0 && list[s0 + j] > v) {
+                list[s0 + j + 1] = list[s0 + j];
+                --j;
+            }
+            list[s0 + j + 1] = v;
+        }
+    }
+    __syncthreads();
+    const int lanes = K / 4;                               // lanes per row: 32 (K = 128) or 64 (K = 256)
+    const int grp = tid / lanes, n_grp = 256 / lanes, l = tid % lanes;
+    for (int p = grp; p < N; p += n_grp) {
+        const int n = fill[p];
+        if (n == 0) continue;
+        const int s0 = cnt[p];
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < n; ++i) {
+            const int c = list[s0 + i];
+            const float w = kd[(int64_t)b * C + c];
+            const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)c * ldw + 4 * l);
+            acc[0] += w * v[0];
+            acc[1] += w * v[1];
+            acc[2] += w * v[2];
+            acc[3] += w * v[3];
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(da + ((int64_t)b * N + p) * ldda + 4 * l);
+        f32x4 o = *dst;
+        o[0] += acc[0];
+        o[1] += acc[1];
+        o[2] += acc[2];
+        o[3] += acc[3];
+        *dst = o;
+    }
+}
+
+// gather: one workgroup of K threads per channel, the items in order (a fixed association)
+__global__ void tr_pool_gather_kernel(const int32_t* __restrict__ arg, const float* __restrict__ kd, const float* __restrict__ a,
+                                      int64_t lda, int B, int C, int K, int N, float* __restrict__ dWs) {
+    const int c = blockIdx.x, k = threadIdx.x;
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const int64_t row = (int64_t)b * N + arg[(int64_t)b * C + c];
+        acc += kd[(int64_t)b * C + c] * a[row * lda + k];
+    }
+    dWs[(int64_t)c * K + k] = acc;
+}
+
+hipError_t launch_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a, int64_t lda,
+                                 int B, int C, int K, int N, float* da, int64_t ldda, float* dWs, hipStream_t s) {
+    const size_t lds = (size_t)(2 * N + 1 + C) * sizeof(int);
+    hipLaunchKernelGGL(tr_pool_scatter_kernel, dim3(B), dim3(256), lds, s, arg, kd, W, ldw, C, K, N, da, ldda);
+    hipLaunchKernelGGL(tr_pool_gather_kernel, dim3(C), dim3(K), 0, s, arg, kd, a, lda, B, C, K, N, dWs);
+    return hipGetLastError();
+}

@@ -258,10 +258,10 @@ def _moments_through(z_prev, bn_prev, W, b):
     products are float64. Returns (sums, a, S, m1) with S = sum a a^T and m1 = sum a for the backward shortcut."""
     K = z_prev.shape[1]
     M = bn_prev.M                                                          # real rows (z_prev is padded to 32s)
-    a = torch.relu(z_prev * bn_prev.scale + bn_prev.shift)
+    a = _act_dropout(z_prev, bn_prev.act, None)                            # relu(bn(z_prev)) in one pass
     if a.shape[0] > M:
         a[M:].zero_()
-    m1 = a.sum(0, dtype=torch.float64)
+    m1 = _colred(a, 0, rows=M)[:K]                                          # float64 column sums, fixed order
     mean_a = m1 / M
     ac = a - mean_a.float()
     if a.shape[0] > M:
@@ -297,7 +297,7 @@ def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N, cache
     if cached is not None:
         a, S, m1 = cached                                                   # from _moments_through in the forward
     else:
-        a = torch.relu(z_prev * bn_prev.scale + bn_prev.shift)             # (M,K), materialised once (K << C)
+        a = _act_dropout(z_prev, bn_prev.act, None)                        # (M,K), materialised once (K << C)
         if a.shape[0] > M:
             a[M:].zero_()
         S = m1 = None
@@ -313,14 +313,23 @@ def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N, cache
     G = W64.t() @ (Bc[:, None] * W64)                                       # (K,K)
     v = (A + Bc * b64) @ W64                                                # (K,)
     da = _linear(a, G.float().contiguous(), K, K, K, transpose=True, bias=v.float().contiguous())
-    rows = (arg.long() + torch.arange(arg.shape[0], device=dev)[:, None] * N).reshape(-1)      # global point index
-    kd = (k1 * D).float()                                                   # (B,C)
-    da.index_put_((rows,), (kd[:, :, None] * W[None]).reshape(-1, K), accumulate=True)        # sorted: deterministic
+    kd = (k1 * D).float().contiguous()                                      # (B,C)
     if S is None:
         S = _wgrad(a, a, K, K).double()                                     # Gram matrix on the MFMA wgrad kernel
-        m1 = a.sum(0, dtype=torch.float64)
+        m1 = _colred(a, 0, rows=M)[:K]
     dW = A[:, None] * m1[None] + Bc[:, None] * (W64 @ S + b64[:, None] * m1[None])
-    dW = dW + (kd.double()[:, :, None] * a[rows].reshape(arg.shape[0], C, K).double()).sum(0)
+    # the two sparse terms (one pooled point per item and channel): scatter into da, gather for dW
+    if 2 * N + C + 1 <= 16384 and K in (64, 128, 256):                      # one call of the library (LDS buckets per item)
+        dWs = torch.empty((C, K), dtype=torch.float32, device=dev)
+        Wc = W.contiguous()
+        _hip.check(_hip.lib().dal3_tr_pool_sparse(_hip.ptr(arg), _hip.ptr(kd), _hip.ptr(Wc), Wc.stride(0), _hip.ptr(a),
+                                                  a.stride(0), arg.shape[0], C, K, N, _hip.ptr(da), da.stride(0), _hip.ptr(dWs),
+                                                  _hip.stream()))
+    else:                                                                   # very long items: stock ops (sorted: deterministic)
+        rows = (arg.long() + torch.arange(arg.shape[0], device=dev)[:, None] * N).reshape(-1)
+        da.index_put_((rows,), (kd[:, :, None] * W[None]).reshape(-1, K), accumulate=True)
+        dWs = (kd[:, :, None] * a[rows].reshape(arg.shape[0], C, K)).sum(0)
+    dW = dW + dWs.double()
     return da, dW.float(), dgamma.float(), dbeta.float()
 
 

@@ -307,6 +307,13 @@ int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, cons
  * of M * loss; the caller scales it). logits, dlogits: (M, 2) fp32 contiguous; labels: (M,) float32 or int64 (0 / 1).
  * Sums in float64, blocks added in index order (reproducible). workspace: dal3_tr_seg_ce_workspace_bytes(M). */
 size_t dal3_tr_seg_ce_workspace_bytes(int64_t M);
+/* The two sparse terms of the backward of conv -> BN -> ReLU -> max over an item's N points (one pooled point per item
+ * and channel: arg (B,C) int32, as dal3_tr_segmax / dal3_tr_linear_pool return it; kd (B,C) = k1 * dy at those points):
+ *   da[b*N + arg[b][c]][0..K) += kd[b][c] * W[c][0..K)     in place, deterministic (channels of a point added in channel order)
+ *   dWs[c][0..K) = sum over b (in order) of kd[b][c] * a[b*N + arg[b][c]][0..K)
+ * K = 64, 128 or 256; 2 N + C + 1 <= 16384 (the buckets of an item live in LDS). */
+int dal3_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a, int64_t lda, int B,
+                        int C, int K, int N, float* da, int64_t ldda, float* dWs, dal3_stream stream);
 /* The five box terms of one box estimate (tools/static_model.py:382-424, tools/dynamic_model.py:341-383), each the mean
  * over the B items: losses[0..4] = centre (Huber, delta 2, of ||center - label||), heading class (cross-entropy, 12
  * bins), heading residual (Huber, delta 1, of the label bin's normalised residual against label / (pi/12)), size class

@@ -533,3 +533,29 @@ def test_criteria_on_the_gpu_match_the_stock_float64_formulation(tag):
             assert abs(res["cuda"][0][k] - v) <= 2e-6 * max(abs(v), 1e-3), (k, res["cuda"][0][k], v)
         for k, g in res["cpu"][1].items():
             assert float((res["cuda"][1][k] - g).abs().max()) <= 2e-6 * max(float(g.abs().max()), 1e-6), k
+
+
+@pytest.mark.parametrize("B,C,K,N", [(4, 1024, 128, 4096), (3, 512, 256, 512), (5, 512, 128, 101), (2, 1024, 128, 5120)])
+def test_pooled_layer_sparse_terms_match_stock_index_put_and_gather(B, C, K, N):
+    """dal3_tr_pool_sparse against index_put_(accumulate=True) / gather-multiply-sum in float64, with many channels
+    sharing a pooled point (the kernel adds them in channel order: bitwise repeatable)"""
+    gen = torch.Generator(device="cuda").manual_seed(B * C + N)
+    arg = torch.randint(0, max(N // 8, 1), (B, C), device="cuda", generator=gen, dtype=torch.int32)     # heavy sharing
+    arg[:, ::7] = torch.randint(0, N, (B, (C + 6) // 7), device="cuda", generator=gen, dtype=torch.int32)
+    kd = torch.randn((B, C), device="cuda", generator=gen)
+    W = torch.randn((C, K), device="cuda", generator=gen)
+    a = torch.randn((B * N, K), device="cuda", generator=gen)
+    da0 = torch.randn((B * N, K), device="cuda", generator=gen)
+    rows = (arg.long() + torch.arange(B, device="cuda")[:, None] * N).reshape(-1)
+    want_da = da0.double().index_put((rows,), (kd.double()[:, :, None] * W.double()[None]).reshape(-1, K), accumulate=True)
+    want_dw = (kd.double()[:, :, None] * a.double()[rows].reshape(B, C, K)).sum(0)
+    outs = []
+    for _ in range(2):
+        da, dws = da0.clone(), torch.empty((C, K), device="cuda")
+        hip.check(hip.lib().dal3_tr_pool_sparse(hip.ptr(arg), hip.ptr(kd), hip.ptr(W), K, hip.ptr(a), K, B, C, K, N, hip.ptr(da), K,
+                                                hip.ptr(dws), hip.stream()))
+        outs.append((da, dws))
+    assert _close(outs[0][0], want_da) and _close(outs[0][1], want_dw)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert hip.lib().dal3_tr_pool_sparse(hip.ptr(arg), hip.ptr(kd), hip.ptr(W), K, hip.ptr(a), K, B, C, K, 9000, hip.ptr(da), K,
+                                         hip.ptr(dws), hip.stream()) != 0          # 2 N + C + 1 > 16384: refused
