@@ -1433,23 +1433,31 @@ hipError_t launch_tr_box_loss(const float* center, const float* center_label, co
 // Scatter, one workgroup per item, DETERMINISTIC without a global sort: the item's channels are bucketed by point in LDS
 // (count, prefix sum, fill by atomic slot, then each point's short list is put in channel order), and each touched row is
 // owned by one group of K/4 lanes that adds its channels' terms in that order and updates the row once.
-// LDS: (2 N + C + 1) ints per item, at most 64 KiB (N = 5120 points and C = 1024 channels: 45 KiB)
+// LDS: (2 N + C + 1) ints per item, at most 64 KiB (N = 5120 points and C = 1024 channels: 45 KiB).
+// POOL_SLICES workgroups share an item: each buckets only the channels whose point falls into its slice of the point axis
+// and owns those rows (one workgroup per item was a chain of dependent L2 / HBM round trips: 100-180 us).
+#define POOL_SLICES 16
 __global__ __launch_bounds__(256) void tr_pool_scatter_kernel(const int32_t* __restrict__ arg, const float* __restrict__ kd,
                                                               const float* __restrict__ W, int64_t ldw, int C, int K, int N,
                                                               float* __restrict__ da, int64_t ldda) {
     extern __shared__ int s_pool[];
-    int* cnt = s_pool;                                     // [N + 1] counts, then start offsets (exclusive prefix)
-    int* fill = s_pool + N + 1;                            // [N] slots handed out
-    int* list = fill + N;                                  // [C] channels grouped by point
-    __shared__ int s_part[256];
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int p = tid; p <= N; p += 256) cnt[p] = 0;
-    for (int p = tid; p < N; p += 256) fill[p] = 0;
+    const int per = (N + POOL_SLICES - 1) / POOL_SLICES;
+    const int lo = blockIdx.y * per, hi = min(N, lo + per), n_loc = max(hi - lo, 0);   // this workgroup's points [lo, hi)
+    int* cnt = s_pool;                                     // [n_loc + 1] counts, then start offsets (exclusive prefix)
+    int* fill = s_pool + per + 1;                          // [n_loc] slots handed out
+    int* list = fill + per;                                // [C] channels grouped by point
+    __shared__ int s_part[256];
+    for (int p = tid; p <= n_loc; p += 256) cnt[p] = 0;
+    for (int p = tid; p < n_loc; p += 256) fill[p] = 0;
     __syncthreads();
-    for (int c = tid; c < C; c += 256) atomicAdd(&cnt[arg[(int64_t)b * C + c]], 1);
+    for (int c = tid; c < C; c += 256) {
+        const int p = arg[(int64_t)b * C + c];
+        if (p >= lo && p < hi) atomicAdd(&cnt[p - lo], 1);
+    }
     __syncthreads();
-    // exclusive prefix sum over cnt[0..N): a contiguous chunk per thread, then the 256 chunk totals
-    const int chunk = (N + 255) / 256, p0 = tid * chunk, p1 = min(N, p0 + chunk);
+    // exclusive prefix sum over cnt[0..n_loc): a contiguous chunk per thread, then the 256 chunk totals
+    const int chunk = (n_loc + 255) / 256, p0 = min(n_loc, tid * chunk), p1 = min(n_loc, p0 + chunk);
     int loc = 0;
     for (int p = p0; p < p1; ++p) loc += cnt[p];
     s_part[tid] = loc;
@@ -1469,14 +1477,13 @@ __global__ __launch_bounds__(256) void tr_pool_scatter_kernel(const int32_t* __r
         cnt[p] = run;
         run += v;
     }
-    if (tid == 255) cnt[N] = C;
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         const int p = arg[(int64_t)b * C + c];
-        list[cnt[p] + atomicAdd(&fill[p], 1)] = c;
+        if (p >= lo && p < hi) list[cnt[p - lo] + atomicAdd(&fill[p - lo], 1)] = c;
     }
     __syncthreads();
-    for (int p = tid; p < N; p += 256) {                   // channel order inside each point's list (insertion sort: the
+    for (int p = tid; p < n_loc; p += 256) {               // channel order inside each point's list (insertion sort: the
         const int s0 = cnt[p], n = fill[p];                // lists are a handful of entries)
         for (int i = 1; i < n; ++i) {
             const int v = list[s0 + i];
@@ -1489,24 +1496,32 @@ __global__ __launch_bounds__(256) void tr_pool_scatter_kernel(const int32_t* __r
         }
     }
     __syncthreads();
-    const int lanes = K / 4;                               // lanes per row: 32 (K = 128) or 64 (K = 256)
+    const int lanes = K / 4;                               // lanes per row: 16, 32 or 64
     const int grp = tid / lanes, n_grp = 256 / lanes, l = tid % lanes;
-    for (int p = grp; p < N; p += n_grp) {
+    for (int p = grp; p < n_loc; p += n_grp) {
         const int n = fill[p];
         if (n == 0) continue;
         const int s0 = cnt[p];
+        f32x4* dst = reinterpret_cast<f32x4*>(da + ((int64_t)b * N + lo + p) * ldda + 4 * l);
+        f32x4 o = *dst;                                    // (issued first: its latency passes under the channel loop)
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int i = 0; i < n; ++i) {
-            const int c = list[s0 + i];
-            const float w = kd[(int64_t)b * C + c];
-            const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)c * ldw + 4 * l);
-            acc[0] += w * v[0];
-            acc[1] += w * v[1];
-            acc[2] += w * v[2];
-            acc[3] += w * v[3];
+        for (int i0 = 0; i0 < n; i0 += 4) {                // four channels' loads in flight, added in channel order
+            float w[4];
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = list[s0 + min(i0 + u, n - 1)];
+                w[u] = i0 + u < n ? kd[(int64_t)b * C + c] : 0.0f;
+                v[u] = *reinterpret_cast<const f32x4*>(W + (int64_t)c * ldw + 4 * l);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] += w[u] * v[u][0];
+                acc[1] += w[u] * v[u][1];
+                acc[2] += w[u] * v[u][2];
+                acc[3] += w[u] * v[u][3];
+            }
         }
-        f32x4* dst = reinterpret_cast<f32x4*>(da + ((int64_t)b * N + p) * ldda + 4 * l);
-        f32x4 o = *dst;
         o[0] += acc[0];
         o[1] += acc[1];
         o[2] += acc[2];
@@ -1520,17 +1535,26 @@ __global__ void tr_pool_gather_kernel(const int32_t* __restrict__ arg, const flo
                                       int64_t lda, int B, int C, int K, int N, float* __restrict__ dWs) {
     const int c = blockIdx.x, k = threadIdx.x;
     float acc = 0.0f;
-    for (int b = 0; b < B; ++b) {
-        const int64_t row = (int64_t)b * N + arg[(int64_t)b * C + c];
-        acc += kd[(int64_t)b * C + c] * a[row * lda + k];
+    for (int b0 = 0; b0 < B; b0 += 8) {                    // eight items' loads in flight, added in item order
+        float w[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = min(b0 + u, B - 1);
+            const int64_t row = (int64_t)b * N + arg[(int64_t)b * C + c];
+            w[u] = b0 + u < B ? kd[(int64_t)b * C + c] : 0.0f;
+            v[u] = a[row * lda + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += w[u] * v[u];
     }
     dWs[(int64_t)c * K + k] = acc;
 }
 
 hipError_t launch_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a, int64_t lda,
                                  int B, int C, int K, int N, float* da, int64_t ldda, float* dWs, hipStream_t s) {
-    const size_t lds = (size_t)(2 * N + 1 + C) * sizeof(int);
-    hipLaunchKernelGGL(tr_pool_scatter_kernel, dim3(B), dim3(256), lds, s, arg, kd, W, ldw, C, K, N, da, ldda);
+    const int per = (N + POOL_SLICES - 1) / POOL_SLICES;
+    const size_t lds = (size_t)(2 * per + 1 + C) * sizeof(int);
+    hipLaunchKernelGGL(tr_pool_scatter_kernel, dim3(B, POOL_SLICES), dim3(256), lds, s, arg, kd, W, ldw, C, K, N, da, ldda);
     hipLaunchKernelGGL(tr_pool_gather_kernel, dim3(C), dim3(K), 0, s, arg, kd, a, lda, B, C, K, N, dWs);
     return hipGetLastError();
 }
