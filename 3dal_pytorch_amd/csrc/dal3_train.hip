@@ -562,7 +562,8 @@ struct DaSrc {
     }
 };
 
-__global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict__ z, int64_t M, int C, int64_t ldz, int mode,
+template <int MODE, bool DENSE>
+__global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict__ z, int64_t M, int C, int64_t ldz,
                                                         DaSrc src, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ mu,
                                                         const float* __restrict__ rstd, double* __restrict__ part) {
@@ -574,6 +575,7 @@ __global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict_
     const int64_t r0 = (int64_t)blockIdx.y * TR_RED_ROWS;
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     if (c < C) {
+        constexpr int mode = MODE;                         // (compile time: a run-time mode is a branch per element to hipcc)
         f32x4 sc = {0, 0, 0, 0}, sh = sc, mean = sc, rs = sc;
         if (mode == 1) {
             sc = *reinterpret_cast<const f32x4*>(scale + c);
@@ -582,16 +584,17 @@ __global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict_
             rs = *reinterpret_cast<const f32x4*>(rstd + c);
         }
         const int64_t r1 = min(M, r0 + TR_RED_ROWS);
-        // four rows per trip, their loads issued together; rows past the end are clamped and masked, the order of the
-        // adds is unchanged
-        for (int64_t p0 = r0 + rl; p0 < r1; p0 += 64) {
-            f32x4 v4[4], d4[4];
+        // eight rows per trip, their loads issued together (a trip is one HBM round trip: with one row per trip the
+        // 64-channel layers ran at 2 TB/s); rows past the end are clamped and masked, the order of the adds is unchanged
+        constexpr int U = 8;
+        for (int64_t p0 = r0 + rl; p0 < r1; p0 += 16 * U) {
+            f32x4 v4[U], d4[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int64_t p = min(p0 + 16 * u, M - 1);
                 v4[u] = *reinterpret_cast<const f32x4*>(z + p * ldz + c);
                 if (mode == 1) {
-                    if (src.da) {
+                    if (DENSE) {
                         d4[u] = *reinterpret_cast<const f32x4*>(src.da + p * src.ldda + c);
                     } else {
 #pragma unroll
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict_
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 if (p0 + 16 * u >= r1) break;
                 const f32x4 v = v4[u];
                 if (mode == 0) {
@@ -738,8 +741,13 @@ size_t tr_colred_workspace_bytes(int64_t M, int C) {
 static void colred_partials(const float* z, int64_t M, int C, int64_t ldz, int mode, const DaSrc& src, const float* scale,
                             const float* shift, const float* mu, const float* rstd, double* part, hipStream_t s) {
     const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
-    hipLaunchKernelGGL(tr_colred_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, s, z, M, C, ldz, mode, src, scale, shift, mu,
-                       rstd, part);
+    const dim3 grid((C + 63) / 64, nb);
+    if (mode == 0)
+        hipLaunchKernelGGL((tr_colred_kernel<0, true>), grid, dim3(256), 0, s, z, M, C, ldz, src, scale, shift, mu, rstd, part);
+    else if (src.da)
+        hipLaunchKernelGGL((tr_colred_kernel<1, true>), grid, dim3(256), 0, s, z, M, C, ldz, src, scale, shift, mu, rstd, part);
+    else
+        hipLaunchKernelGGL((tr_colred_kernel<1, false>), grid, dim3(256), 0, s, z, M, C, ldz, src, scale, shift, mu, rstd, part);
 }
 
 hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
@@ -832,37 +840,45 @@ hipError_t launch_tr_bnbwd_coef(const double* sums, int C, int64_t M, const floa
 
 // ---------------------------------------------------------------------------------------------- BN backward, applied
 // dz = k1[c] * (dy - k2[c] - xhat * k3[c]),  k1 = gamma*rstd, k2 = mean(dy), k3 = mean(dy*xhat)
+template <bool DENSE>
 __global__ __launch_bounds__(256) void tr_bnbwd_apply_kernel(const float* __restrict__ z, int64_t M, int C, int64_t ldz,
                                                              DaSrc src, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* __restrict__ mu,
                                                              const float* __restrict__ rstd, const float* __restrict__ k1,
                                                              const float* __restrict__ k2, const float* __restrict__ k3,
                                                              float* __restrict__ dz, int64_t lddz) {
-    // block: 16 groups of 4 channels x 16 rows; grid (C/64, M/64): a thread walks 4 rows
+    // block: 16 groups of 4 channels x 16 rows; grid (C/64, M/128): a thread walks 8 rows, all their loads issued before
+    // the first is used (rows past the end are clamped for the loads and skipped for the stores)
+    constexpr int U = 8;
     const int c = (blockIdx.x * 16 + (threadIdx.x & 15)) * 4;
     if (c >= C) return;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
     const f32x4 mean = *reinterpret_cast<const f32x4*>(mu + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
     const f32x4 a1 = *reinterpret_cast<const f32x4*>(k1 + c), a2 = *reinterpret_cast<const f32x4*>(k2 + c);
     const f32x4 a3 = *reinterpret_cast<const f32x4*>(k3 + c);
+    const int64_t p0 = (int64_t)blockIdx.y * (16 * U) + (threadIdx.x >> 4);
+    f32x4 v[U], d[U];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t p = (int64_t)blockIdx.y * 64 + i * 16 + (threadIdx.x >> 4);
-        if (p >= M) return;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(z + p * ldz + c);
-        f32x4 d;
-        if (src.da) {
-            d = *reinterpret_cast<const f32x4*>(src.da + p * src.ldda + c);
+    for (int i = 0; i < U; ++i) {
+        const int64_t p = min(p0 + 16 * i, M - 1);
+        v[i] = *reinterpret_cast<const f32x4*>(z + p * ldz + c);
+        if (DENSE) {
+            d[i] = *reinterpret_cast<const f32x4*>(src.da + p * src.ldda + c);
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = src.at(p, c + e, C);
+            for (int e = 0; e < 4; ++e) d[i][e] = src.at(p, c + e, C);
         }
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t p = p0 + 16 * i;
+        if (p >= M) break;
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float y = v[e] * sc[e] + sh[e];
-            const float dy = y > 0.0f ? d[e] : 0.0f;
-            o[e] = a1[e] * (dy - a2[e] - (v[e] - mean[e]) * rs[e] * a3[e]);
+            const float y = v[i][e] * sc[e] + sh[e];
+            const float dy = y > 0.0f ? d[i][e] : 0.0f;
+            o[e] = a1[e] * (dy - a2[e] - (v[i][e] - mean[e]) * rs[e] * a3[e]);
         }
         *reinterpret_cast<f32x4*>(dz + p * lddz + c) = o;
     }
@@ -873,8 +889,13 @@ hipError_t launch_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, 
                                  const float* mu, const float* rstd, const float* k1, const float* k2, const float* k3,
                                  float* dz, int64_t lddz, hipStream_t s) {
     DaSrc src{da, ldda, dg, arg, seg};
-    hipLaunchKernelGGL(tr_bnbwd_apply_kernel, dim3((C + 63) / 64, (unsigned)((M + 63) / 64)), dim3(256), 0, s, z, M, C, ldz,
-                       src, scale, shift, mu, rstd, k1, k2, k3, dz, lddz);
+    const dim3 grid((C + 63) / 64, (unsigned)((M + 127) / 128));
+    if (da)
+        hipLaunchKernelGGL((tr_bnbwd_apply_kernel<true>), grid, dim3(256), 0, s, z, M, C, ldz, src, scale, shift, mu, rstd, k1,
+                           k2, k3, dz, lddz);
+    else
+        hipLaunchKernelGGL((tr_bnbwd_apply_kernel<false>), grid, dim3(256), 0, s, z, M, C, ldz, src, scale, shift, mu, rstd, k1,
+                           k2, k3, dz, lddz);
     return hipGetLastError();
 }
 
