@@ -31,6 +31,7 @@ The JSON line also carries
                 a bounded sample of the same workload
 """
 import argparse
+import gc
 import ctypes as C
 import importlib
 import json
@@ -381,17 +382,36 @@ def time_steps(wl, dev, steps, warmup, use_dist, overlap=True):
             got = wl.gatherers[i].collect(keep=1 if (overlap and not final) else 0)
             if got is not None:
                 last[i] = got
+    gc_was = gc.isenabled()
+    if os.environ.get("DAL3_BENCH_GC") != "1":              # (=1: leave the collector on, to reproduce the stall)
+        # As timeit does: no cyclic-GC pass inside the timed region. A generation-2 pass over the process's objects is a
+        # 40 ms host stall; where it falls depends on allocation counts (even on the script's path), and when it falls on
+        # the first timed step — the queue is empty right behind the fence — the GPU waits for it: 20 steps read 28.7 ms
+        # per step instead of 26.3 (median and minimum unaffected). Collected BEFORE the warm-up: 40 ms of idling is
+        # enough for the chip to drop its clocks, and the 16-bit steps take five steps to get them back.
+        # DAL3_BENCH_DEBUG=1 prints the host/event timeline.
+        gc.collect()
+        gc.disable()
     for _ in range(warmup):
         step(final=True)
     fence()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
+    host = []
     for i in range(steps):
         step(final=(i == steps - 1))
         marks[i + 1].record()
+        host.append(time.perf_counter() - t0)
+    t_issued = time.perf_counter() - t0
     fence()
     dt = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
+    if os.environ.get("DAL3_BENCH_DEBUG") == "1":
+        ev = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+        sys.stderr.write(f"[time_steps] issued by {t_issued * 1e3:.1f} ms, fence returned at {dt * 1e3:.1f} ms, events sum "
+                         f"{sum(ev):.1f} ms, host per step (ms) {[round(h * 1e3, 1) for h in host]}, events {[round(e, 1) for e in ev]}\n")
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     boxes = torch.cat(last)
     assert boxes.shape == (wl.n_total, 7) and bool(torch.isfinite(boxes).all())
@@ -416,7 +436,7 @@ def other_config(name, dev, steps):
     ns = argparse.Namespace(config=name, head="static", precision="fp32", batch=0, points=1024)
     apply_config(ns)
     wl = build_workload(ns, dev, 0, 1)
-    dt, per_step, _ = time_steps(wl, dev, steps, 2, False)
+    dt, per_step, _ = time_steps(wl, dev, steps, 5, False)
     value = wl.n_total * steps / dt
     peak = MFMA_PEAK_TFLOPS[ns.precision]
     r = {"workload": wl.desc, "value": round(value, 1), "unit": "items/s", "ms_per_step": round(dt / steps * 1e3, 3),
@@ -558,6 +578,7 @@ def main():
         "value": round(value, 1), "unit": "object-crops/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "ms_per_step_median": round(per_step[len(per_step) // 2], 3), "ms_per_step_min": round(per_step[0], 3),
+        "ms_per_step_max": round(per_step[-1], 3),
         "higher_is_better": True,
         "scaling": wl.scaling, "vs_baseline": None, "dtype": DNAME[args.precision], "data": "synthetic",
         "config": {"workload": wl.desc, "items_per_gpu": wl.B, "points_per_item": wl.N, "sampler": wl.model.sampler,
@@ -604,7 +625,7 @@ def main():
             rec["lowprec"] = {}
             for prec in ("bf16", "fp16"):
                 model.precision = prec
-                d, _, _ = time_steps(wl, dev, args.steps, 2, False)
+                d, _, _ = time_steps(wl, dev, args.steps, 5, False)
                 d /= args.steps
                 k2, _ = kernel_table(model, inputs, static, B, N, iters=max(3, min(args.steps, 10)))
                 d2 = max((k for k in k2 if "frac" in k2[k]), key=lambda k: k2[k]["ms"])
