@@ -134,23 +134,24 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ W, co
         const int ch = 32 * mt + tile_chan(r, h);
         acc[r] = (wave == 0 && ch < c_out) ? bias[ch] : 0.0f;
     }
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // (rows past c_out and items past B read row 0 / item 0 — wp and xp are clamped above — and are never stored: a
+    // conditional load is a branch per load to hipcc, four per trip of this loop)
     const int chunk = ((c_in + 31) / 32) * 8;              // per-wave share of K, a multiple of 8
     const int k_end = min(c_in, (wave + 1) * chunk);
     int k0 = wave * chunk;
     for (; k0 + 16 <= k_end; k0 += 16) {
-        const f32x4 a0 = row_ok ? *reinterpret_cast<const f32x4*>(wp + k0) : zero;
-        const f32x4 a1 = row_ok ? *reinterpret_cast<const f32x4*>(wp + k0 + 8) : zero;
-        const f32x4 b0 = item_ok ? *reinterpret_cast<const f32x4*>(xp + k0) : zero;
-        const f32x4 b1 = item_ok ? *reinterpret_cast<const f32x4*>(xp + k0 + 8) : zero;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(wp + k0);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(wp + k0 + 8);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(xp + k0);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(xp + k0 + 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = mfma32(a0[e], b0[e], acc);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = mfma32(a1[e], b1[e], acc);
     }
     for (; k0 < k_end; k0 += 8) {
-        const f32x4 a = row_ok ? *reinterpret_cast<const f32x4*>(wp + k0) : zero;
-        const f32x4 bv = item_ok ? *reinterpret_cast<const f32x4*>(xp + k0) : zero;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wp + k0);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(xp + k0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = mfma32(a[e], bv[e], acc);
     }
