@@ -210,3 +210,22 @@ def test_packed_cache_stamps_follow_parameter_identity():
     m._cache._stamp["x"] = (1,)
     m.invalidate_packed()
     assert not m._cache._stamp
+
+
+def test_box_gatherer_without_a_process_group_passes_the_boxes_through():
+    """one rank, no torch.distributed: submit/collect hand back the very tensors, in order, `keep` in flight, and a
+    third submit without a collect is refused (two slots)"""
+    import importlib
+    dist = importlib.import_module("3dal_pytorch_amd.dist")
+    g = dist.BoxGatherer(5, torch.device("cpu"))
+    assert not g.active
+    a, b = torch.arange(35.0).view(5, 7), torch.arange(35.0, 70.0).view(5, 7)
+    g.submit(a)
+    assert g.collect(keep=1) is None
+    g.submit(b)
+    got = g.collect(keep=1)
+    assert got.data_ptr() == a.data_ptr() and torch.equal(got, a)
+    g.submit(a)
+    with pytest.raises(RuntimeError):
+        g.submit(b)
+    assert torch.equal(g.collect(keep=0), b) and torch.equal(g.collect(keep=0), a) and g.collect(keep=0) is None
