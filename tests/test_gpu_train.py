@@ -79,10 +79,11 @@ def test_ins_seg_training_step_matches_float64_autograd():
             assert _close(b1, b2), name
 
 
-@pytest.mark.parametrize("B,N", [(3, 100), (5, 77), (1, 1000)])
+@pytest.mark.parametrize("B,N", [(3, 100), (5, 77), (1, 1000), (2, 8192)])
 def test_ins_seg_training_step_ragged_sizes_match_float64_autograd(B, N):
     """B*N not a multiple of 32 (300, 385, 1000 points; N not a multiple of 32 either: conv5 and the pooling run as
-    two kernels): outputs, running statistics and every gradient against float64 autograd, as in the test above. The
+    two kernels), and 8192 points per crop (the pooled layer's sparse terms no longer fit the library's per-item LDS
+    buckets: the stock-op path): outputs, running statistics and every gradient against float64 autograd, as in the test above. The
     yardstick for a gradient that a discrete decision rerouted is the stock fp32 composite's own distance."""
     model = build_model("static_one", synth.state_dict("static_one", seed=21))
     ours = model.ins_seg.train()
