@@ -394,9 +394,9 @@ __global__ __launch_bounds__(256, 2) void tr_linear_pool_kernel(const float* __r
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: see tr_linear_ring_kernel)
-    const int mblk = (int)(unit % n_mblk);
-    const int64_t pt0 = (unit / n_mblk) * (32 * TR_T);
+    const uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar, 32-bit: see tr_linear_ring_kernel)
+    const int mblk = (int)(unit % (uint32_t)n_mblk);
+    const int64_t pt0 = (int64_t)(unit / (uint32_t)n_mblk) * (32 * TR_T);
     if (pt0 >= M) return;
     const int mt0 = mblk * TR_MTB;
     const int KT = c_in / 32;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void tr_linear_pool_kernel(const float* __r
                 bi = oi;
             }
             if (h == 0) {
-                const int64_t s_idx = p0 / seg;
+                const int64_t s_idx = (int64_t)((uint32_t)p0 / (uint32_t)seg);   // (32-bit: M < 2^31 rows)
                 const uint32_t in_seg = (uint32_t)(p0 - s_idx * seg) + (uint32_t)bi;
                 const unsigned long long key = ((unsigned long long)__float_as_uint(bv) << 32) | (0xffffffffu - in_seg);
                 atomicMax(packed + s_idx * c_out + c, key);

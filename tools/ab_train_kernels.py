@@ -50,6 +50,34 @@ def timed(fn, iters=5):
     return a.elapsed_time(b) / iters * 1e3
 
 
+def pool_case():
+    """dal3_tr_linear_pool at conv5's shape (128 -> 1024, 64 x 4096 points)"""
+    ci, co, seg = 128, 1024, 4096
+    a = torch.randn((M, ci), device=dev)
+    W = torch.randn((co, ci), device=dev) * 0.1
+    b = torch.randn(co, device=dev)
+    sc, sh = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1
+    osc, osh = torch.rand(co, device=dev) + 0.5, torch.randn(co, device=dev) * 0.1
+    n_seg = M // seg
+    out = []
+    res = {n: [] for n, _ in libs}
+    for r in range(args.rounds):
+        for n, lib in libs:
+            g = torch.empty((n_seg, co), device=dev)
+            arg = torch.empty((n_seg, co), dtype=torch.int32, device=dev)
+            need = lib.dal3_tr_linear_pool_workspace_bytes(ci, co, n_seg)
+            w2 = torch.empty(need, dtype=torch.uint8, device=dev)
+            f = lambda: lib.dal3_tr_linear_pool(hip.ptr(a), M, ci, ci, hip.ptr(sc), hip.ptr(sh), 1, hip.ptr(W), ci, hip.ptr(b),
+                                                hip.ptr(osc), hip.ptr(osh), seg, co, hip.ptr(g), hip.ptr(arg), hip.ptr(w2), need, st)
+            res[n].append(timed(f))
+            if r == 0:
+                out.append((g.clone(), arg.clone()))
+    same = all(torch.equal(out[0][0], o[0]) and torch.equal(out[0][1], o[1]) for o in out)
+    print("linear_pool 128 -> 1024 + max: " + "  ".join(f"[{n}] {statistics.median(v):7.1f} us" for n, v in res.items()) + f"  (same bits: {same})")
+
+
+if M % 4096 == 0 and M >= 8192:
+    pool_case()
 for ci, co in shapes:
     a = torch.randn((M, ci), device=dev)
     W = torch.randn((co, ci), device=dev) * 0.1
