@@ -1,7 +1,8 @@
 // dal3_pointmlp_lp.hip — bf16 / fp16 MFMA versions of the three shared-MLP kernels (configs C3 / C5 of
 // BASELINE.json). Same math and fusion as dal3_pointmlp.hip; see dal3_lp.h for the operand layout and
 // the LDS-DMA weight ring. The K=3/4/8 first layer stays on the fp32 MFMA (raw coordinates are not
-// rounded to 16 bits); accumulation is fp32 throughout; dconv5 and the mask stay fp32 on the VALU.
+// rounded to 16 bits); accumulation is fp32 throughout; dconv5 is a 17th 16-bit out-tile of the decode kernel (rows 0, 1);
+// logits, mask and all I/O are fp32.
 #include "dal3_kernels.h"
 #include "dal3_lp.h"
 
