@@ -236,8 +236,12 @@ __global__ __launch_bounds__(256) void maxpool_rows_scalar_kernel(const float* _
 
 hipError_t launch_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, hipStream_t s) {
     if (rows <= 0 || n <= 0) return hipErrorInvalidValue;
+    // one wave per row, as many workgroups as that takes: with the grid capped at 16 workgroups per CU (waves walking
+    // 256 rows each) the same kernel read 6.5 TB/s, uncapped 7.1 (one box, (4096, 1024, 1024) fp32) — a wave's next row
+    // starts behind its butterfly and store, a fresh wave's loads do not. (Two rows per wave: 6.9 in the same process;
+    // plain instead of non-temporal loads: 6.5. tools/ab_maxpool.py)
     int64_t blocks = (rows + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 0x7fffffff) blocks = 0x7fffffff;
     const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     if (vec) hipLaunchKernelGGL(maxpool_rows_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, x, rows, n, out);
     else hipLaunchKernelGGL(maxpool_rows_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, rows, n, out);
