@@ -802,6 +802,14 @@ extern "C" int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int
     return 0;
 }
 
+extern "C" int dal3_tr_pool_coef(const float* dg, const float* g, const float* zarg, const float* mu, const float* rstd,
+                                 const float* gamma, int B, int C, int64_t M, double* coef, float* kd, dal3_stream stream) {
+    if (!dg || !g || !zarg || !mu || !rstd || !gamma || B <= 0 || C <= 0 || M <= 0 || !coef || !kd)
+        return fail(DAL3_EINVAL, "tr_pool_coef: bad argument");
+    HIP_TRY(launch_tr_pool_coef(dg, g, zarg, mu, rstd, gamma, B, C, M, coef, kd, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a,
                                    int64_t lda, int B, int C, int K, int N, float* da, int64_t ldda, float* dWs,
                                    dal3_stream stream) {

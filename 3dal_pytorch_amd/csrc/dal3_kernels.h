@@ -215,6 +215,8 @@ size_t tr_colred_workspace_bytes(int64_t M, int C);
 hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                             const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                             const float* mu, const float* rstd, double* part, double* out, hipStream_t s);
+hipError_t launch_tr_pool_coef(const float* dg, const float* g, const float* zarg, const float* mu, const float* rstd,
+                               const float* gamma, int B, int C, int64_t M, double* coef, float* kd, hipStream_t s);
 hipError_t launch_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a, int64_t lda,
                                  int B, int C, int K, int N, float* da, int64_t ldda, float* dWs, hipStream_t s);
 hipError_t launch_tr_box_loss(const float* center, const float* center_label, const float* hs, const float* hrn,

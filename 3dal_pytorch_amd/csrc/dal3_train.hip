@@ -1579,3 +1579,41 @@ hipError_t launch_tr_pool_sparse(const int32_t* arg, const float* kd, const floa
     hipLaunchKernelGGL(tr_pool_gather_kernel, dim3(C), dim3(K), 0, s, arg, kd, a, lda, B, C, K, N, dWs);
     return hipGetLastError();
 }
+
+// per-channel coefficients of the pooled layer's backward (train.py _pooled_layer_backward), one thread per channel, the B
+// items in order: D = dg * [g > 0] (the ReLU gate at the pooled point), xhat = (zarg - mu) * rstd,
+//   dbeta = sum_b D, dgamma = sum_b D * xhat, k1 = gamma * rstd, k2 = dbeta / M, k3 = dgamma / M,
+//   A = -k1 k2 + k1 k3 rstd mu, Bc = -k1 k3 rstd, kd[b][c] = k1 * D[b][c]            (float64 except kd)
+// — two dozen stock launches on (C,) and (B, C) tensors otherwise. coef: (4, C) float64 = dbeta | dgamma | A | Bc.
+__global__ __launch_bounds__(256) void tr_pool_coef_kernel(const float* __restrict__ dg, const float* __restrict__ g,
+                                                           const float* __restrict__ zarg, const float* __restrict__ mu,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           int B, int C, int64_t M, double* __restrict__ coef,
+                                                           float* __restrict__ kd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = (double)mu[c], rs = (double)rstd[c];
+    double dbeta = 0.0, dgamma = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t i = (int64_t)b * C + c;
+        const double D = g[i] > 0.0f ? (double)dg[i] : 0.0;
+        dbeta += D;
+        dgamma += D * (((double)zarg[i] - m) * rs);
+    }
+    const double k1 = (double)gamma[c] * rs, k2 = dbeta / (double)M, k3 = dgamma / (double)M;
+    coef[c] = dbeta;
+    coef[C + c] = dgamma;
+    coef[2 * C + c] = -k1 * k2 + k1 * k3 * rs * m;
+    coef[3 * C + c] = -k1 * k3 * rs;
+    for (int b = 0; b < B; ++b) {
+        const int64_t i = (int64_t)b * C + c;
+        kd[i] = (float)(k1 * (g[i] > 0.0f ? (double)dg[i] : 0.0));
+    }
+}
+
+hipError_t launch_tr_pool_coef(const float* dg, const float* g, const float* zarg, const float* mu, const float* rstd,
+                               const float* gamma, int B, int C, int64_t M, double* coef, float* kd, hipStream_t s) {
+    hipLaunchKernelGGL(tr_pool_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dg, g, zarg, mu, rstd, gamma, B, C, M, coef,
+                       kd);
+    return hipGetLastError();
+}

@@ -301,19 +301,18 @@ def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N, cache
         if a.shape[0] > M:
             a[M:].zero_()
         S = m1 = None
-    D = (dg * (g > 0)).double()                                            # ReLU gate at the pooled point
-    xhat = (zarg.double() - bn.mu.double()) * bn.rstd.double()             # (B,C) at the arg-max points
-    dbeta = D.sum(0)
-    dgamma = (D * xhat).sum(0)
-    k1 = bn.gamma.double() * bn.rstd.double()
-    k2, k3 = dbeta / M, dgamma / M
-    A = -k1 * k2 + k1 * k3 * bn.rstd.double() * bn.mu.double()
-    Bc = -k1 * k3 * bn.rstd.double()
+    # the per-channel coefficients and kd = k1 * D in one launch (float64; the items added in order)
+    nB = arg.shape[0]
+    coef = torch.empty((4, C), dtype=torch.float64, device=dev)
+    kd = torch.empty((nB, C), dtype=torch.float32, device=dev)
+    _hip.check(_hip.lib().dal3_tr_pool_coef(_hip.ptr(dg.contiguous()), _hip.ptr(g.contiguous()), _hip.ptr(zarg.contiguous()),
+                                            _hip.ptr(bn.mu), _hip.ptr(bn.rstd), _hip.ptr(bn.gamma), nB, C, M, _hip.ptr(coef),
+                                            _hip.ptr(kd), _hip.stream()))
+    dbeta, dgamma, A, Bc = coef[0], coef[1], coef[2], coef[3]
     W64, b64 = W.double(), b.double()
     G = W64.t() @ (Bc[:, None] * W64)                                       # (K,K)
     v = (A + Bc * b64) @ W64                                                # (K,)
     da = _linear(a, G.float().contiguous(), K, K, K, transpose=True, bias=v.float().contiguous())
-    kd = (k1 * D).float().contiguous()                                      # (B,C)
     if S is None:
         S = _wgrad(a, a, K, K).double()                                     # Gram matrix on the MFMA wgrad kernel
         m1 = _colred(a, 0, rows=M)[:K]

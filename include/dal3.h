@@ -307,6 +307,12 @@ int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, cons
  * of M * loss; the caller scales it). logits, dlogits: (M, 2) fp32 contiguous; labels: (M,) float32 or int64 (0 / 1).
  * Sums in float64, blocks added in index order (reproducible). workspace: dal3_tr_seg_ce_workspace_bytes(M). */
 size_t dal3_tr_seg_ce_workspace_bytes(int64_t M);
+/* Per-channel coefficients of that backward, items added in order: with D = dg * [g > 0] and xhat = (zarg - mu) * rstd
+ * (dg, g, zarg: (B, C) fp32 — upstream gradient, pooled value, pre-BN value at the pooled point), coef (4, C) float64 =
+ * dbeta = sum_b D | dgamma = sum_b D xhat | A = -k1 k2 + k1 k3 rstd mu | Bc = -k1 k3 rstd  (k1 = gamma rstd, k2 = dbeta / M,
+ * k3 = dgamma / M), and kd (B, C) fp32 = k1 * D. */
+int dal3_tr_pool_coef(const float* dg, const float* g, const float* zarg, const float* mu, const float* rstd,
+                      const float* gamma, int B, int C, int64_t M, double* coef, float* kd, dal3_stream stream);
 /* The two sparse terms of the backward of conv -> BN -> ReLU -> max over an item's N points (one pooled point per item
  * and channel: arg (B,C) int32, as dal3_tr_segmax / dal3_tr_linear_pool return it; kd (B,C) = k1 * dy at those points):
  *   da[b*N + arg[b][c]][0..K) += kd[b][c] * W[c][0..K)     in place, deterministic (channels of a point added in channel order)
