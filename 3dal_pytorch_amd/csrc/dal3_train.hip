@@ -234,7 +234,11 @@ __device__ __forceinline__ void tr_load_x(TrX<T>& st, int kt, const float* __res
         const float* ap = a + prow[j] * lda + 32 * kt + 4 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+#ifdef TR_ABL_NOLOADX
+            const f32x4 v = {(float)kt, (float)h, (float)q, (float)lda};
+#else
             const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 8 * q);
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) st.X[j][4 * q + e] = v[e];
         }
@@ -243,11 +247,13 @@ __device__ __forceinline__ void tr_load_x(TrX<T>& st, int kt, const float* __res
 
 // the 4 MTB fragments (MTB output tiles x 4 q) of one k-tile, taken from the ring; BASE: the ring slot of the first
 // (0, or 4 for the second k-tile of a pair when a k-tile is only four fragments)
-template <int T, int MTB, int BASE>
-__device__ __forceinline__ void tr_ring_block(WRing<DAL3_PF>& ring, const f32x16 (&X)[T], f32x16 (&acc)[T][MTB]) {
+struct TrNoSide {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int T, int MTB, int BASE, class Ring, class Side = TrNoSide>
+__device__ __forceinline__ void tr_ring_block(Ring& ring, const f32x16 (&X)[T], f32x16 (&acc)[T][MTB], Side side = Side()) {
 #pragma unroll
     for (int i = 0; i < 4 * MTB; ++i) {
-        ring_batch_wait<DAL3_PF>(ring, BASE + i);
         const f32x4 w = ring.slot[(BASE + i) % DAL3_PF];
         ring.slot[(BASE + i) % DAL3_PF] = ring.fetch();
 #pragma unroll
@@ -256,6 +262,7 @@ __device__ __forceinline__ void tr_ring_block(WRing<DAL3_PF>& ring, const f32x16
             for (int j = 0; j < T; ++j) acc[j][i / 4] = mfma32(w[e], X[j][4 * (i % 4) + e], acc[j][i / 4]);
         }
         DAL3_SCHED_FENCE();
+        side(i);
     }
 }
 
@@ -340,6 +347,9 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_ring_kernel(const float* _
 #pragma unroll
         for (int j = 0; j < T; ++j) {
             if (pt0 + 32 * j >= M) break;
+#ifdef TR_ABL_NOSTORE
+            if (acc[j][0][0] != 12345.678f) continue;
+#endif
             float* zp = z + (pt0 + 32 * j + m) * ldz + 4 * h;
 #pragma unroll
             for (int t = 0; t < MTB; ++t) {
@@ -363,6 +373,152 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_ring_kernel(const float* _
         store_tiles(std::true_type{});
     else
         store_tiles(std::false_type{});
+}
+
+// The same layer with PERSISTENT waves (one workgroup per wave slot of the chip, each wave walking units wave, wave +
+// n_waves, ...: a fixed output block, successive point tiles). Ablations of the kernel above (64 -> 512 at 262,144 rows:
+// 269 us; without its stores 195, without its activation loads 213, without both 151 = its MFMAs) showed the three
+// phases of a wave's life ADDING UP: workgroups that start together stay in step, so a CU loads, then multiplies, then
+// stores. Here the phases of consecutive units overlap inside one wave: the first k-tile (and the bias row) of unit
+// u + 1 are fetched BEFORE unit u's stores are issued (vmcnt counts loads and stores in issue order on gfx9: a load
+// issued behind the stores could only be waited for together with them), the stores drain under unit u + 1's MFMAs
+// (their data registers are read at issue), and the weight ring runs on cyclically (no refill bubble per unit).
+// Host-side conditions (launch_tr_linear): no accumulate, M % (32 T) == 0, seg == 0 or seg % (32 T) == 0 (one bias row per
+// unit), c_in % 64 == 0 (k-tiles in pairs; the ring's slot rotation is a compile-time pattern), n_waves % n_mblk == 0.
+struct WRingCyc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff, soff, len;
+    f32x4 slot[DAL3_PF];
+    __device__ __forceinline__ f32x4 fetch() {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        soff += 1024;
+        if (soff == len) soff = 0;
+        return __builtin_bit_cast(f32x4, v);
+    }
+    __device__ __forceinline__ void init(const f32x4* stream, uint32_t bytes, int lane) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(stream), 0, 0x7fffffff, 0x00020000);
+        voff = (uint32_t)lane * 16u;
+        soff = 0;
+        len = bytes;
+#pragma unroll
+        for (int i = 0; i < DAL3_PF; ++i) slot[i] = fetch();
+    }
+};
+
+template <int T, int MTB, int OCC, int KTC>                  // KTC: c_in / 32 when it is 2 or 4 (straight-line code per unit), else 0
+__global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* __restrict__ a, int64_t M, int c_in, int64_t lda,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int relu_in,
+                                                                const f32x4* __restrict__ wpk, const float* __restrict__ bias,
+                                                                int64_t seg, int c_out, float* __restrict__ z, int64_t ldz,
+                                                                int n_mblk, uint32_t n_units) {
+    static_assert(DAL3_PF == 8 && (MTB == 1 || MTB == 2 || MTB == 4), "fragment order of tr_pack_kernel, ring slots");
+    __shared__ float s_sc[TR_MAX_ACT_CIN], s_sh[TR_MAX_ACT_CIN];
+    const bool act = scale != nullptr;
+    if (act) {
+        for (int i = threadIdx.x; i < c_in; i += 256) {
+            s_sc[i] = scale[i];
+            s_sh[i] = shift[i];
+        }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
+    uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * 4u;
+    if (unit >= n_units) return;
+    const int mblk = (int)(unit % (uint32_t)n_mblk);          // the same for every unit of this wave
+    const int mt0 = mblk * MTB;
+    const int KT = KTC ? KTC : c_in / 32;
+    WRingCyc ring;
+    ring.init(wpk + (int64_t)mblk * KT * (4 * MTB) * 64, (uint32_t)(KT * 4 * MTB) * 1024u, lane);
+    auto bias_row = [&](int64_t pt0) {                        // scalar: one 32-bit division per unit
+        return seg > 0 ? bias + (int64_t)((uint32_t)pt0 / (uint32_t)seg) * c_out + 32 * mt0 : bias + 32 * mt0;
+    };
+    int64_t pt0 = (int64_t)(unit / (uint32_t)n_mblk) * (32 * T);
+    f32x16 bnext[MTB];
+#pragma unroll
+    for (int t = 0; t < MTB; ++t) bnext[t] = bias ? tile_from_channels(bias_row(pt0) + 32 * t, h) : f32x16{};
+    int64_t prow[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) prow[j] = pt0 + 32 * j + m;
+    constexpr int BASE2 = (4 * MTB) % DAL3_PF;
+    TrX<T> xa, xb;
+    tr_load_x<T>(xa, 0, a, lda, prow, h);
+    // everything fetched so far has landed before the loop is entered: hipcc's wait-count pass merges the state at the
+    // loop header from both edges, and with loads still pending on the entry edge it put an s_waitcnt vmcnt(8) at the top
+    // of EVERY unit — i.e. a wait for the stores the previous unit had just issued (269 -> 248 us instead of -> 190)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0) only (gfx9 encoding)
+    for (;;) {
+        f32x16 acc[T][MTB];
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int t = 0; t < MTB; ++t) acc[j][t] = bnext[t];
+        const uint32_t unit_n = unit + n_waves;
+        const bool more = unit_n < n_units;
+        const int64_t pt0_n = more ? (int64_t)(unit_n / (uint32_t)n_mblk) * (32 * T) : pt0;
+        int64_t prow_n[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) prow_n[j] = pt0_n + 32 * j + m;
+        if (bias && seg > 0) {                                  // the next unit's bias row: waited for at the next unit's top
+#pragma unroll
+            for (int t = 0; t < MTB; ++t) bnext[t] = tile_from_channels(bias_row(pt0_n) + 32 * t, h);
+        }
+        // an output tile's stores go out as soon as its last MFMA has been issued (tile t: after fragment 4 t + 3 of the
+        // LAST k-tile), between the MFMAs of the tiles behind it: issued in one burst at the end of the unit, the
+        // 16 * T * MTB KiB of the workgroup's four waves queue up in front of the CU's one path to L2 and every wave
+        // sits at its last store with the matrix pipe idle (ablation: 60 of the 215 us of 64 -> 512)
+        auto store_tile = [&](int t) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+#ifdef TR_ABL_NOSTORE
+                if (acc[j][0][0] != 12345.678f) continue;
+#endif
+                float* zp = z + (pt0 + 32 * j + m) * ldz + 4 * h + 32 * (mt0 + t);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 o = {acc[j][t][4 * q], acc[j][t][4 * q + 1], acc[j][t][4 * q + 2], acc[j][t][4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(zp + 8 * q) = o;
+                }
+            }
+        };
+        auto kstep = [&](int kt, auto last_c) {                 // k-tiles kt and kt + 1 (KT is even on this path)
+            constexpr bool LAST = decltype(last_c)::value;
+            tr_load_x<T>(xb, kt + 1, a, lda, prow, h);
+            DAL3_SCHED_FENCE();
+            if (act) tr_act_lds<T>(xa.X, s_sc, s_sh, kt, h, relu_in);
+            tr_ring_block<T, MTB, 0>(ring, xa.X, acc);
+            // k-tile kt + 2 of this unit, or — in the last round — the NEXT unit's first k-tile, ahead of the stores
+            tr_load_x<T>(xa, LAST ? 0 : kt + 2, a, lda, LAST ? prow_n : prow, h);
+            DAL3_SCHED_FENCE();
+            if (act) tr_act_lds<T>(xb.X, s_sc, s_sh, kt + 1, h, relu_in);
+            if (LAST)
+                tr_ring_block<T, MTB, BASE2>(ring, xb.X, acc, [&](int i) {
+                    if (i % 4 == 3) store_tile(i / 4);
+                });
+            else
+                tr_ring_block<T, MTB, BASE2>(ring, xb.X, acc);
+        };
+        // first and last round peeled (the same one when K = 64): hipcc's wait counts are per code location, and the
+        // waits of a unit's first fragments — fetched before the previous unit's stores — must count those stores as
+        // younger (vmcnt(39...63)); inside ONE loop body they get the steady-state count of the later rounds, which at
+        // the top of a unit is a wait for the stores
+        if constexpr (KTC == 2) {
+            kstep(0, std::true_type{});
+        } else if constexpr (KTC == 4) {
+            kstep(0, std::false_type{});
+            kstep(2, std::true_type{});
+        } else {                                               // KT >= 4
+            kstep(0, std::false_type{});
+            for (int kt = 2; kt + 2 < KT; kt += 2) kstep(kt, std::false_type{});
+            kstep(KT - 2, std::true_type{});
+        }
+        if (!more) break;
+        unit = unit_n;
+        pt0 = pt0_n;
+#pragma unroll
+        for (int j = 0; j < T; ++j) prow[j] = prow_n[j];
+    }
 }
 
 __global__ void tr_segmax_unpack_kernel(const unsigned long long* __restrict__ packed, int64_t n, float* __restrict__ g,
@@ -500,6 +656,19 @@ size_t tr_linear_workspace_bytes(int c_in, int c_out) {
 
 #define TR_SMALL_M 256                   // at most this many rows: one 32 x 32 output tile per wave (<1, 1>)
 
+#ifndef TR_PERS
+#define TR_PERS 1
+#endif
+template <int T, int MTB, int OCC>
+static bool tr_linear_pers_ok(int64_t M, int c_in, int64_t seg, int c_out, int accumulate) {
+    const int n_mblk = c_out / (32 * MTB);
+    const int64_t units = ((M + 32 * T - 1) / (32 * T)) * n_mblk;
+    const unsigned pers_grid = 256u * OCC;                  // one workgroup per wave slot: 4 * pers_grid waves
+    return TR_PERS && MTB >= 2 && c_out % (32 * MTB) == 0 && !accumulate && M % (32 * T) == 0 &&
+           (seg == 0 || seg % (32 * T) == 0) && c_in % 64 == 0 && (4 * pers_grid) % (unsigned)n_mblk == 0 &&
+           units >= 2 * 4 * (int64_t)pers_grid && units < (int64_t)1 << 31;
+}
+
 template <int T, int MTB, int OCC>
 static void tr_linear_ring_launch(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                                   int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
@@ -509,6 +678,23 @@ static void tr_linear_ring_launch(const float* a, int64_t M, int c_in, int64_t l
     const int64_t n = (int64_t)c_out * c_in;
     hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, transpose_w, c_out, c_in,
                        MTB, ws);
+    const int KT = c_in / 32;
+    const unsigned pers_grid = 256u * OCC;
+    if constexpr (MTB >= 2) {
+        if (tr_linear_pers_ok<T, MTB, OCC>(M, c_in, seg, c_out, accumulate)) {
+            const auto args = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(pers_grid), dim3(256), 0, s, a, M, c_in, lda, scale, shift, relu_in,
+                                   reinterpret_cast<const f32x4*>(ws), bias, seg, c_out, z, ldz, n_mblk, (uint32_t)units);
+            };
+            if (KT == 2)
+                args(tr_linear_pers_kernel<T, MTB, OCC, 2>);
+            else if (KT == 4 && MTB == 4)                      // (<2, 2, 2, 4> spills 64 registers; the generic one does not)
+                args(tr_linear_pers_kernel<T, MTB, OCC, 4>);
+            else
+                args(tr_linear_pers_kernel<T, MTB, OCC, 0>);
+            return;
+        }
+    }
     hipLaunchKernelGGL((tr_linear_ring_kernel<T, MTB, OCC>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda,
                        scale, shift, relu_in, reinterpret_cast<const f32x4*>(ws), bias, seg, c_out, z, ldz, accumulate,
                        n_mblk);
@@ -518,17 +704,27 @@ hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, co
                             int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
                             int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s) {
     const bool ring_ok = ws && (!scale || c_in <= TR_MAX_ACT_CIN);
-    // K <= 128: a wave's whole K loop is a few microseconds, about as long as its prologue and its stores; the smaller
-    // <2, 2> tile fits two waves per SIMD, so one wave's ends run under the other's MFMAs (64 -> 512: 282 -> 258 us)
-    const int small_k = 128;
+    // K <= 128 through the one-unit-per-wave kernel: a wave's whole K loop is a few microseconds, about as long as its
+    // prologue and its stores; the smaller <2, 2> tile fits two waves per SIMD, so one wave's ends run under the other's
+    // MFMAs (64 -> 512: 282 -> 258 us). Where the persistent kernel applies it overlaps the ends itself and the big tile
+    // wins again (64 -> 512: 185 us)
+#ifndef TR_SMALL_K
+#define TR_SMALL_K 128
+#endif
+    const int small_k = TR_SMALL_K;
     if (ring_ok && M <= TR_SMALL_M) {
         tr_linear_ring_launch<1, 1, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
                                        accumulate, ws, s);
-    } else if (ring_ok && c_out % 128 == 0 && c_in > small_k) {
+    } else if (ring_ok && c_out % 128 == 0 &&
+               (c_in > small_k || tr_linear_pers_ok<TR_T, TR_MTB, TR_RING_OCC>(M, c_in, seg, c_out, accumulate))) {
         tr_linear_ring_launch<TR_T, TR_MTB, TR_RING_OCC>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg,
                                                          c_out, z, ldz, accumulate, ws, s);
     } else if (ring_ok && c_out % 64 == 0) {
-        tr_linear_ring_launch<TR_T, 2, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
+#ifndef TR_SK_T
+#define TR_SK_T TR_T
+#define TR_SK_OCC 2
+#endif
+        tr_linear_ring_launch<TR_SK_T, 2, TR_SK_OCC>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
                                           accumulate, ws, s);
     } else if (ring_ok) {                                   // c_out = 32, 96, ...: one output tile per wave
         tr_linear_ring_launch<TR_T, 1, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
