@@ -385,6 +385,9 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_ring_kernel(const float* _
 // (their data registers are read at issue), and the weight ring runs on cyclically (no refill bubble per unit).
 // Host-side conditions (launch_tr_linear): no accumulate, M % (32 T) == 0, seg == 0 or seg % (32 T) == 0 (one bias row per
 // unit), c_in % 64 == 0 (k-tiles in pairs; the ring's slot rotation is a compile-time pattern), n_waves % n_mblk == 0.
+#ifndef TR_PERS
+#define TR_PERS 1                       // 0: every layer through the one-unit-per-wave kernels (A/B builds)
+#endif
 struct WRingCyc {
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff, soff, len;
@@ -632,6 +635,138 @@ __global__ __launch_bounds__(256, 2) void tr_linear_pool_kernel(const float* __r
     }
 }
 
+// tr_linear_pool_kernel with persistent waves, as tr_linear_pers_kernel: the next unit's first k-tile is fetched under
+// this unit's last MFMAs (a wave of the kernel above waits out one HBM round trip per unit with its matrix pipe idle:
+// 13 % of the 128 -> 1024 layer by ablation), the weight ring runs on cyclically, and an output tile's epilogue —
+// BN, ReLU, the max over its 32 points, the packed atomicMax — is placed behind the tile's last MFMA, under the MFMAs
+// of the tiles that follow. Same FMA chains, same candidates: g and arg are bit-identical to the kernel above.
+// Host-side conditions: M % (32 TR_T) == 0, c_in % 64 == 0, n_waves % n_mblk == 0, at least two units per wave.
+template <int OCC, int KTC>
+__global__ __launch_bounds__(256, OCC) void tr_linear_pool_pers_kernel(const float* __restrict__ a, int64_t M, int c_in, int64_t lda,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, int relu_in,
+                                                                     const f32x4* __restrict__ wpk, const float* __restrict__ bias,
+                                                                     const float* __restrict__ out_scale,
+                                                                     const float* __restrict__ out_shift, int64_t seg, int c_out,
+                                                                     unsigned long long* __restrict__ packed, int n_mblk,
+                                                                     uint32_t n_units) {
+    __shared__ float s_sc[TR_MAX_ACT_CIN], s_sh[TR_MAX_ACT_CIN];
+    const bool act = scale != nullptr;
+    if (act) {
+        for (int i = threadIdx.x; i < c_in; i += 256) {
+            s_sc[i] = scale[i];
+            s_sh[i] = shift[i];
+        }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
+    uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * 4u;
+    if (unit >= n_units) return;
+    const int mblk = (int)(unit % (uint32_t)n_mblk);
+    const int mt0 = mblk * TR_MTB;
+    const int KT = KTC ? KTC : c_in / 32;
+    WRingCyc ring;
+    ring.init(wpk + (int64_t)mblk * KT * 16 * 64, (uint32_t)(KT * 16) * 1024u, lane);
+    float bch[TR_MTB], osc[TR_MTB], osh[TR_MTB];               // this lane's channel of each output tile
+#pragma unroll
+    for (int t = 0; t < TR_MTB; ++t) {
+        const int c = 32 * (mt0 + t) + m;
+        bch[t] = bias ? bias[c] : 0.0f;
+        osc[t] = out_scale[c];
+        osh[t] = out_shift[c];
+    }
+    int64_t pt0 = (int64_t)(unit / (uint32_t)n_mblk) * (32 * TR_T);
+    int64_t prow[TR_T];
+#pragma unroll
+    for (int j = 0; j < TR_T; ++j) prow[j] = pt0 + 32 * j + m;
+    TrX<TR_T> xa, xb;
+    tr_load_x(xa, 0, a, lda, prow, h);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): see tr_linear_pers_kernel
+    for (;;) {
+        f32x16 acc[TR_T][TR_MTB];
+#pragma unroll
+        for (int t = 0; t < TR_MTB; ++t)
+#pragma unroll
+            for (int j = 0; j < TR_T; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][t][r] = bch[t];
+        const uint32_t unit_n = unit + n_waves;
+        const bool more = unit_n < n_units;
+        const int64_t pt0_n = more ? (int64_t)(unit_n / (uint32_t)n_mblk) * (32 * TR_T) : pt0;
+        int64_t prow_n[TR_T];
+#pragma unroll
+        for (int j = 0; j < TR_T; ++j) prow_n[j] = pt0_n + 32 * j + m;
+        auto finish_tile = [&](int t) {                         // the epilogue of tr_linear_pool_kernel for output tile t
+            const int c = 32 * (mt0 + t) + m;
+#pragma unroll
+            for (int j = 0; j < TR_T; ++j) {
+                const int64_t p0 = pt0 + 32 * j;
+                float bv = -1.0f;
+                int bi = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float y = fmaxf(__builtin_fmaf(acc[j][t][r], osc[t], osh[t]), 0.0f);
+                    if (y > bv) {
+                        bv = y;
+                        bi = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    }
+                }
+                const float ov = __shfl_xor(bv, 32);
+                const int oi = __shfl_xor(bi, 32);
+                if (ov > bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+                if (h == 0) {
+                    const int64_t s_idx = (int64_t)((uint32_t)p0 / (uint32_t)seg);
+                    const uint32_t in_seg = (uint32_t)(p0 - s_idx * seg) + (uint32_t)bi;
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(bv) << 32) | (0xffffffffu - in_seg);
+                    atomicMax(packed + s_idx * c_out + c, key);
+                }
+            }
+        };
+        auto block = [&](const f32x16 (&X)[TR_T], auto base_c, auto last_c) {
+            constexpr int BASE = decltype(base_c)::value;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 w = ring.slot[(BASE + i) % DAL3_PF];
+                ring.slot[(BASE + i) % DAL3_PF] = ring.fetch();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int j = 0; j < TR_T; ++j) acc[j][i / 4] = mfma32(X[j][4 * (i % 4) + e], w[e], acc[j][i / 4]);
+                }
+                DAL3_SCHED_FENCE();
+                if (decltype(last_c)::value && i % 4 == 3) finish_tile(i / 4);
+            }
+        };
+        auto kstep = [&](int kt, auto last_c) {
+            constexpr bool LAST = decltype(last_c)::value;
+            tr_load_x(xb, kt + 1, a, lda, prow, h);
+            DAL3_SCHED_FENCE();
+            if (act) tr_act_lds(xa.X, s_sc, s_sh, kt, h, relu_in);
+            block(xa.X, std::integral_constant<int, 0>{}, std::false_type{});
+            tr_load_x(xa, LAST ? 0 : kt + 2, a, lda, LAST ? prow_n : prow, h);
+            DAL3_SCHED_FENCE();
+            if (act) tr_act_lds(xb.X, s_sc, s_sh, kt + 1, h, relu_in);
+            block(xb.X, std::integral_constant<int, 0>{}, last_c);
+        };
+        if constexpr (KTC == 2) {
+            kstep(0, std::true_type{});
+        } else {                                               // KT >= 4
+            kstep(0, std::false_type{});
+            for (int kt = 2; kt + 2 < KT; kt += 2) kstep(kt, std::false_type{});
+            kstep(KT - 2, std::true_type{});
+        }
+        if (!more) break;
+        unit = unit_n;
+        pt0 = pt0_n;
+#pragma unroll
+        for (int j = 0; j < TR_T; ++j) prow[j] = prow_n[j];
+    }
+}
+
 hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                                  int relu_in, const float* W, int64_t ldw, const float* bias, const float* out_scale,
                                  const float* out_shift, int64_t seg, int c_out, float* g, int32_t* arg, float* ws,
@@ -642,8 +777,24 @@ hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t ld
     hipError_t e = launch_fill_words(packed, (size_t)n_seg * c_out * 2, 0u, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, 0, c_out, c_in, TR_MTB, ws);
-    hipLaunchKernelGGL(tr_linear_pool_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda, scale, shift,
-                       relu_in, reinterpret_cast<const f32x4*>(ws), bias, out_scale, out_shift, seg, c_out, packed, n_mblk);
+#ifndef TR_POOL_OCC
+#define TR_POOL_OCC 1                   // (at 2 the persistent kernel spills 120-170 registers)
+#endif
+    const unsigned pers_grid = 256u * TR_POOL_OCC;
+    if (TR_PERS && M % (32 * TR_T) == 0 && c_in % 64 == 0 && (4 * pers_grid) % (unsigned)n_mblk == 0 &&
+        units >= 2 * 4 * (int64_t)pers_grid && units < (int64_t)1 << 31) {
+        if (c_in == 64)
+            hipLaunchKernelGGL((tr_linear_pool_pers_kernel<TR_POOL_OCC, 2>), dim3(pers_grid), dim3(256), 0, s, a, M, c_in, lda, scale,
+                               shift, relu_in, reinterpret_cast<const f32x4*>(ws), bias, out_scale, out_shift, seg, c_out, packed,
+                               n_mblk, (uint32_t)units);
+        else
+            hipLaunchKernelGGL((tr_linear_pool_pers_kernel<TR_POOL_OCC, 0>), dim3(pers_grid), dim3(256), 0, s, a, M, c_in, lda, scale,
+                               shift, relu_in, reinterpret_cast<const f32x4*>(ws), bias, out_scale, out_shift, seg, c_out, packed,
+                               n_mblk, (uint32_t)units);
+    } else {
+        hipLaunchKernelGGL(tr_linear_pool_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda, scale, shift,
+                           relu_in, reinterpret_cast<const f32x4*>(ws), bias, out_scale, out_shift, seg, c_out, packed, n_mblk);
+    }
     const int64_t total = n_seg * c_out;
     hipLaunchKernelGGL(tr_segmax_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, packed, total, g, arg);
     return hipGetLastError();
@@ -656,9 +807,6 @@ size_t tr_linear_workspace_bytes(int c_in, int c_out) {
 
 #define TR_SMALL_M 256                   // at most this many rows: one 32 x 32 output tile per wave (<1, 1>)
 
-#ifndef TR_PERS
-#define TR_PERS 1
-#endif
 template <int T, int MTB, int OCC>
 static bool tr_linear_pers_ok(int64_t M, int c_in, int64_t seg, int c_out, int accumulate) {
     const int n_mblk = c_out / (32 * MTB);
