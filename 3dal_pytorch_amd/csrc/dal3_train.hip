@@ -1924,32 +1924,48 @@ hipError_t launch_tr_pool_sparse(const int32_t* arg, const float* kd, const floa
     return hipGetLastError();
 }
 
-// per-channel coefficients of the pooled layer's backward (train.py _pooled_layer_backward), one thread per channel, the B
-// items in order: D = dg * [g > 0] (the ReLU gate at the pooled point), xhat = (zarg - mu) * rstd,
+// per-channel coefficients of the pooled layer's backward (train.py _pooled_layer_backward): D = dg * [g > 0] (the ReLU
+// gate at the pooled point), xhat = (zarg - mu) * rstd,
 //   dbeta = sum_b D, dgamma = sum_b D * xhat, k1 = gamma * rstd, k2 = dbeta / M, k3 = dgamma / M,
 //   A = -k1 k2 + k1 k3 rstd mu, Bc = -k1 k3 rstd, kd[b][c] = k1 * D[b][c]            (float64 except kd)
 // — two dozen stock launches on (C,) and (B, C) tensors otherwise. coef: (4, C) float64 = dbeta | dgamma | A | Bc.
+// 64 channels x 4 item lanes per workgroup: lane l adds items l, l + 4, ... in order, the four lane sums are added in
+// lane order (deterministic; one thread per channel walking all B items was 74 us of dependent loads for B = 64).
 __global__ __launch_bounds__(256) void tr_pool_coef_kernel(const float* __restrict__ dg, const float* __restrict__ g,
                                                            const float* __restrict__ zarg, const float* __restrict__ mu,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            int B, int C, int64_t M, double* __restrict__ coef,
                                                            float* __restrict__ kd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double m = (double)mu[c], rs = (double)rstd[c];
+    __shared__ double sm[2][4][64];
+    const int el = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + el;
+    const bool live = c < C;
+    const double m = live ? (double)mu[c] : 0.0, rs = live ? (double)rstd[c] : 0.0;
     double dbeta = 0.0, dgamma = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const int64_t i = (int64_t)b * C + c;
-        const double D = g[i] > 0.0f ? (double)dg[i] : 0.0;
-        dbeta += D;
-        dgamma += D * (((double)zarg[i] - m) * rs);
+    if (live) {
+#pragma unroll 4
+        for (int b = l; b < B; b += 4) {
+            const int64_t i = (int64_t)b * C + c;
+            const double D = g[i] > 0.0f ? (double)dg[i] : 0.0;
+            dbeta += D;
+            dgamma += D * (((double)zarg[i] - m) * rs);
+        }
     }
+    sm[0][l][el] = dbeta;
+    sm[1][l][el] = dgamma;
+    __syncthreads();
+    if (!live) return;
+    dbeta = ((sm[0][0][el] + sm[0][1][el]) + sm[0][2][el]) + sm[0][3][el];
+    dgamma = ((sm[1][0][el] + sm[1][1][el]) + sm[1][2][el]) + sm[1][3][el];
     const double k1 = (double)gamma[c] * rs, k2 = dbeta / (double)M, k3 = dgamma / (double)M;
-    coef[c] = dbeta;
-    coef[C + c] = dgamma;
-    coef[2 * C + c] = -k1 * k2 + k1 * k3 * rs * m;
-    coef[3 * C + c] = -k1 * k3 * rs;
-    for (int b = 0; b < B; ++b) {
+    if (l == 0) {
+        coef[c] = dbeta;
+        coef[C + c] = dgamma;
+        coef[2 * C + c] = -k1 * k2 + k1 * k3 * rs * m;
+        coef[3 * C + c] = -k1 * k3 * rs;
+    }
+#pragma unroll 4
+    for (int b = l; b < B; b += 4) {
         const int64_t i = (int64_t)b * C + c;
         kd[i] = (float)(k1 * (g[i] > 0.0f ? (double)dg[i] : 0.0));
     }
@@ -1957,7 +1973,7 @@ __global__ __launch_bounds__(256) void tr_pool_coef_kernel(const float* __restri
 
 hipError_t launch_tr_pool_coef(const float* dg, const float* g, const float* zarg, const float* mu, const float* rstd,
                                const float* gamma, int B, int C, int64_t M, double* coef, float* kd, hipStream_t s) {
-    hipLaunchKernelGGL(tr_pool_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dg, g, zarg, mu, rstd, gamma, B, C, M, coef,
+    hipLaunchKernelGGL(tr_pool_coef_kernel, dim3((C + 63) / 64), dim3(256), 0, s, dg, g, zarg, mu, rstd, gamma, B, C, M, coef,
                        kd);
     return hipGetLastError();
 }

@@ -301,7 +301,7 @@ def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N, cache
         if a.shape[0] > M:
             a[M:].zero_()
         S = m1 = None
-    # the per-channel coefficients and kd = k1 * D in one launch (float64; the items added in order)
+    # the per-channel coefficients and kd = k1 * D in one launch (float64, fixed order of additions)
     nB = arg.shape[0]
     coef = torch.empty((4, C), dtype=torch.float64, device=dev)
     kd = torch.empty((nB, C), dtype=torch.float32, device=dev)

@@ -307,7 +307,7 @@ int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, cons
  * of M * loss; the caller scales it). logits, dlogits: (M, 2) fp32 contiguous; labels: (M,) float32 or int64 (0 / 1).
  * Sums in float64, blocks added in index order (reproducible). workspace: dal3_tr_seg_ce_workspace_bytes(M). */
 size_t dal3_tr_seg_ce_workspace_bytes(int64_t M);
-/* Per-channel coefficients of that backward, items added in order: with D = dg * [g > 0] and xhat = (zarg - mu) * rstd
+/* Per-channel coefficients of that backward (sums over the items in a fixed order: deterministic): with D = dg * [g > 0] and xhat = (zarg - mu) * rstd
  * (dg, g, zarg: (B, C) fp32 — upstream gradient, pooled value, pre-BN value at the pooled point), coef (4, C) float64 =
  * dbeta = sum_b D | dgamma = sum_b D xhat | A = -k1 k2 + k1 k3 rstd mu | Bc = -k1 k3 rstd  (k1 = gamma rstd, k2 = dbeta / M,
  * k3 = dgamma / M), and kd (B, C) fp32 = k1 * D. */
