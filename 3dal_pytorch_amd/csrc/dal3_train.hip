@@ -1422,10 +1422,18 @@ __global__ __launch_bounds__(256) void tr_wgrad_final_kernel(const float* __rest
 // small layers — one (c_out x c_in) tile block per 128 points — were a quarter of the traffic, and every shape ran 5-20 %
 // slower) without going below WG_MIN_SLICE points per wave; a multiple of 64
 static bool wgrad_small(int c_out) { return c_out <= 64; }    // at most two out-tiles: the <2, 2, 4> instantiation
+#ifndef WG_BIG_KT
+#define WG_BIG_KT 4
+#endif
+// in-tiles per wave: 4 x 4 tiles for the biggest layers (16 MFMAs per 8 operand loads instead of 8 per 6: without its
+// loads the 512 x 256 wgrad takes 483 us instead of 611, and what the loads cost is L2 -> CU traffic, every dz tile being
+// read once per block of in-tiles: 582 -> 555 us). Smaller layers have too few blocks for it (128 x 128: 101 -> 114 us).
+static int wgrad_kt(int c_out, int c_in) { return (c_out % 128 == 0 && c_in % 128 == 0 && c_out >= 256 && c_in >= 256) ? WG_BIG_KT : WG_KT; }
 static void wgrad_blocks(int c_out, int c_in, int* n_mb, int* n_kb) {
     const int mt = wgrad_small(c_out) ? 2 : WG_MT;
     *n_mb = (c_out / 32 + mt - 1) / mt;
-    *n_kb = (c_in / 32 + WG_KT - 1) / WG_KT;
+    const int kt = wgrad_kt(c_out, c_in);
+    *n_kb = (c_in / 32 + kt - 1) / kt;
 }
 static int64_t wgrad_slice_pts(int64_t M, int c_out, int c_in) {
     int n_mb, n_kb;
@@ -1454,6 +1462,9 @@ hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_
     if (wgrad_small(c_out))
         hipLaunchKernelGGL((tr_wgrad_kernel<2, WG_KT, 4>), grid, dim3(256), 0, s, dz, lddz, a, lda, scale, shift, relu_in, M,
                            c_out, c_in, part, n_mb, n_kb, pts);
+    else if (wgrad_kt(c_out, c_in) == 4)
+        hipLaunchKernelGGL((tr_wgrad_kernel<WG_MT, 4, 2>), grid, dim3(256), 0, s, dz, lddz, a, lda, scale, shift, relu_in,
+                           M, c_out, c_in, part, n_mb, n_kb, pts);
     else
         hipLaunchKernelGGL((tr_wgrad_kernel<WG_MT, WG_KT, 2>), grid, dim3(256), 0, s, dz, lddz, a, lda, scale, shift, relu_in,
                            M, c_out, c_in, part, n_mb, n_kb, pts);
