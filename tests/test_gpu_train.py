@@ -355,7 +355,42 @@ def test_train_mode_with_the_device_sampler_needs_no_host_round_trip():
 
 
 # ------------------------------------------------------------------ round 2: fused pooling, Dropout kernel, FC tails
-@pytest.mark.parametrize("B,N,c_in,c_out", [(4, 256, 128, 1024), (3, 96, 64, 128), (2, 4096, 128, 1024)])
+@pytest.mark.parametrize("c_in,c_out,seg", [(64, 512, 4096), (128, 128, 0), (512, 256, 0), (64, 64, 0), (192, 64, 0),
+                                            (256, 128, 0)])
+def test_persistent_linear_kernels_match_float64_and_the_one_unit_kernels_bitwise(c_in, c_out, seg):
+    """the software-pipelined persistent kernels (tr_linear_pers_kernel: K = 64 and K = 128 as straight-line code, K >= 128
+    generic, both tile shapes) at the step's size, 64 x 4096 rows: against float64, and against the one-unit-per-wave
+    kernels, which an accumulating call into a zeroed buffer still takes (0 + x is exact) — the same FMA chain per
+    element, so the same bits"""
+    M = 64 * 4096
+    gen = torch.Generator(device="cuda").manual_seed(c_in * 7 + c_out)
+    a = torch.randn((M, c_in), device="cuda", generator=gen)
+    W = torch.randn((c_out, c_in), device="cuda", generator=gen) / c_in ** 0.5
+    sc = torch.rand(c_in, device="cuda", generator=gen) + 0.5
+    sh = torch.randn(c_in, device="cuda", generator=gen) * 0.3
+    n_seg = M // seg if seg else 1
+    b = torch.randn((n_seg, c_out) if seg else (c_out,), device="cuda", generator=gen)
+    kw = dict(act=(sc, sh, True), bias=b)
+    if seg:
+        kw["seg"] = seg
+    z = train._linear(a, W, c_in, c_in, c_out, **kw)
+    ref = torch.zeros_like(z)
+    train._linear(a, W, c_in, c_in, c_out, out=ref, accumulate=True, **kw)
+    assert torch.equal(z, ref)
+    rows = torch.arange(0, M, 997, device="cuda")                       # a float64 check on a sample of the rows
+    act64 = torch.relu(a[rows].double() * sc.double() + sh.double())
+    bias64 = b.double()[rows // seg] if seg else b.double()
+    assert _close(z[rows], act64 @ W.double().t() + bias64)
+    dz = torch.randn((M, c_out), device="cuda", generator=gen)          # dgrad: the transposed weight, no bias
+    da = train._linear(dz, W, c_in, c_out, c_in, transpose=True)
+    ref = torch.zeros_like(da)
+    train._linear(dz, W, c_in, c_out, c_in, transpose=True, out=ref, accumulate=True)
+    assert torch.equal(da, ref)
+    assert _close(da[rows], dz[rows].double() @ W.double())
+
+
+@pytest.mark.parametrize("B,N,c_in,c_out", [(4, 256, 128, 1024), (3, 96, 64, 128), (2, 4096, 128, 1024),
+                                            (16, 4096, 128, 1024), (32, 2048, 64, 256)])
 def test_fused_linear_pool_equals_linear_then_segmax_bitwise(B, N, c_in, c_out):
     """dal3_tr_linear_pool (conv -> BN -> ReLU -> max over each crop's points without writing the layer's output) must
     give the bits of dal3_tr_linear + dal3_tr_segmax: same g, same arg-max (first maximum), ties included"""
