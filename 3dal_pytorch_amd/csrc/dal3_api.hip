@@ -816,8 +816,8 @@ extern "C" int dal3_tr_pool_sparse(const int32_t* arg, const float* kd, const fl
     if (!arg || !kd || !W || !a || !da || !dWs || B <= 0 || C <= 0 || N <= 0 || (K != 128 && K != 256 && K != 64) ||
         ldw < K || lda < K || ldda < K || ldw % 4 || ldda % 4)
         return fail(DAL3_EINVAL, "tr_pool_sparse: bad argument (K = 64, 128 or 256; row strides >= K, multiples of 4)");
-    if ((size_t)(2 * (size_t)N + 1 + (size_t)C) * sizeof(int) > 65536)
-        return fail(DAL3_EINVAL, "tr_pool_sparse: 2 N + C + 1 must not exceed 16384 (the item's buckets live in 64 KiB of LDS)");
+    if ((size_t)(2 * (size_t)N + 1 + (size_t)C) * sizeof(int) > 65536 || C > 4096)
+        return fail(DAL3_EINVAL, "tr_pool_sparse: 2 N + C + 1 must not exceed 16384 and C must not exceed 4096 (an item's buckets live in LDS)");
     HIP_TRY(launch_tr_pool_sparse(arg, kd, W, ldw, a, lda, B, C, K, N, da, ldda, dWs, static_cast<hipStream_t>(stream)));
     return 0;
 }

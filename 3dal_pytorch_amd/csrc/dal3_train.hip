@@ -1820,16 +1820,25 @@ __global__ __launch_bounds__(256) void tr_pool_scatter_kernel(const int32_t* __r
     const int b = blockIdx.x, tid = threadIdx.x;
     const int per = (N + POOL_SLICES - 1) / POOL_SLICES;
     const int lo = blockIdx.y * per, hi = min(N, lo + per), n_loc = max(hi - lo, 0);   // this workgroup's points [lo, hi)
-    int* cnt = s_pool;                                     // [n_loc + 1] counts, then start offsets (exclusive prefix)
-    int* fill = s_pool + per + 1;                          // [n_loc] slots handed out
-    int* list = fill + per;                                // [C] channels grouped by point
+    const int C4 = (C + 3) & ~3;
+    int* s_arg = s_pool;                                   // [C4] the item's pooled points (16-byte aligned: read as int4)
+    int* list = s_pool + C4;                               // [C] channels grouped by point, in channel order
+    int* pend = list + C;                                  // [C] the channels pooled inside [lo, hi), any order
+    int* cnt = pend + C;                                   // [n_loc + 1] counts, then start offsets (exclusive prefix)
+    int* fill = cnt + per + 1;                             // [n_loc] slots handed out
     __shared__ int s_part[256];
+    __shared__ int s_nin;
+    if (tid == 0) s_nin = 0;
     for (int p = tid; p <= n_loc; p += 256) cnt[p] = 0;
     for (int p = tid; p < n_loc; p += 256) fill[p] = 0;
+    for (int c = tid; c < C; c += 256) s_arg[c] = arg[(int64_t)b * C + c];
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
-        const int p = arg[(int64_t)b * C + c];
-        if (p >= lo && p < hi) atomicAdd(&cnt[p - lo], 1);
+        const int p = s_arg[c];
+        if (p >= lo && p < hi) {
+            atomicAdd(&cnt[p - lo], 1);
+            pend[atomicAdd(&s_nin, 1)] = c;
+        }
     }
     __syncthreads();
     // exclusive prefix sum over cnt[0..n_loc): a contiguous chunk per thread, then the 256 chunk totals
@@ -1853,14 +1862,43 @@ __global__ __launch_bounds__(256) void tr_pool_scatter_kernel(const int32_t* __r
         cnt[p] = run;
         run += v;
     }
+    if (p1 == n_loc) cnt[n_loc] = run;                     // the total (every thread that gets here holds the same value)
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        const int p = arg[(int64_t)b * C + c];
-        if (p >= lo && p < hi) list[cnt[p - lo] + atomicAdd(&fill[p - lo], 1)] = c;
+    // Channel order inside each point's list. Short lists (the usual case: a handful of channels per point): slots
+    // handed out by an atomic counter, then an insertion sort by the point's thread. That is quadratic in the list's
+    // length and run by ONE thread — with the tied maxima of zero-padded items (every channel of an item pooled at its
+    // first point) it took 300 us of a DynamicModel step, 8 ms at worst — so the channels of LONG lists are placed by
+    // rank instead: a channel's place = the number of lower channels pooled at the same point (a scan of the item's
+    // points in LDS, eight 16-byte reads in flight), over the compacted list of this workgroup's channels so that only
+    // as many waves scan as there are channels to place.
+    constexpr int POOL_SORT_MAX = 12;
+    const int n_in = s_nin;
+    for (int t = tid; t < n_in; t += 256) {
+        const int c = pend[t], p = s_arg[c] - lo;
+        const int s0 = cnt[p], n = cnt[p + 1] - s0;
+        if (n <= POOL_SORT_MAX) {
+            list[s0 + atomicAdd(&fill[p], 1)] = c;
+            continue;
+        }
+        const int pa = p + lo;
+        int r = 0;
+        const int4* v = reinterpret_cast<const int4*>(s_arg);
+        const int n4 = c >> 2;
+        int i = 0;
+        for (; i + 8 <= n4; i += 8) {
+            int4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = v[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r += (x[u].x == pa) + (x[u].y == pa) + (x[u].z == pa) + (x[u].w == pa);
+        }
+        for (int c2 = 4 * i; c2 < c; ++c2) r += s_arg[c2] == pa;
+        list[s0 + r] = c;
     }
     __syncthreads();
-    for (int p = tid; p < n_loc; p += 256) {               // channel order inside each point's list (insertion sort: the
-        const int s0 = cnt[p], n = fill[p];                // lists are a handful of entries)
+    for (int p = tid; p < n_loc; p += 256) {
+        const int s0 = cnt[p], n = cnt[p + 1] - s0;
+        if (n > POOL_SORT_MAX) continue;
         for (int i = 1; i < n; ++i) {
             const int v = list[s0 + i];
             int j = i - 1;
@@ -1875,9 +1913,8 @@ __global__ __launch_bounds__(256) void tr_pool_scatter_kernel(const int32_t* __r
     const int lanes = K / 4;                               // lanes per row: 16, 32 or 64
     const int grp = tid / lanes, n_grp = 256 / lanes, l = tid % lanes;
     for (int p = grp; p < n_loc; p += n_grp) {
-        const int n = fill[p];
+        const int s0 = cnt[p], n = cnt[p + 1] - s0;
         if (n == 0) continue;
-        const int s0 = cnt[p];
         f32x4* dst = reinterpret_cast<f32x4*>(da + ((int64_t)b * N + lo + p) * ldda + 4 * l);
         f32x4 o = *dst;                                    // (issued first: its latency passes under the channel loop)
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1929,7 +1966,7 @@ __global__ void tr_pool_gather_kernel(const int32_t* __restrict__ arg, const flo
 hipError_t launch_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a, int64_t lda,
                                  int B, int C, int K, int N, float* da, int64_t ldda, float* dWs, hipStream_t s) {
     const int per = (N + POOL_SLICES - 1) / POOL_SLICES;
-    const size_t lds = (size_t)(2 * per + 1 + C) * sizeof(int);
+    const size_t lds = (size_t)(2 * per + 1 + 3 * C + 4) * sizeof(int);
     hipLaunchKernelGGL(tr_pool_scatter_kernel, dim3(B, POOL_SLICES), dim3(256), lds, s, arg, kd, W, ldw, C, K, N, da, ldda);
     hipLaunchKernelGGL(tr_pool_gather_kernel, dim3(C), dim3(K), 0, s, arg, kd, a, lda, B, C, K, N, dWs);
     return hipGetLastError();

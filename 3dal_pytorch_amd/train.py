@@ -318,7 +318,7 @@ def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N, cache
         m1 = _colred(a, 0, rows=M)[:K]
     dW = A[:, None] * m1[None] + Bc[:, None] * (W64 @ S + b64[:, None] * m1[None])
     # the two sparse terms (one pooled point per item and channel): scatter into da, gather for dW
-    if 2 * N + C + 1 <= 16384 and K in (64, 128, 256):                      # one call of the library (LDS buckets per item)
+    if 2 * N + C + 1 <= 16384 and C <= 4096 and K in (64, 128, 256):                      # one call of the library (LDS buckets per item)
         dWs = torch.empty((C, K), dtype=torch.float32, device=dev)
         Wc = W.contiguous()
         _hip.check(_hip.lib().dal3_tr_pool_sparse(_hip.ptr(arg), _hip.ptr(kd), _hip.ptr(Wc), Wc.stride(0), _hip.ptr(a),

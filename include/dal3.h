@@ -317,7 +317,7 @@ int dal3_tr_pool_coef(const float* dg, const float* g, const float* zarg, const 
  * and channel: arg (B,C) int32, as dal3_tr_segmax / dal3_tr_linear_pool return it; kd (B,C) = k1 * dy at those points):
  *   da[b*N + arg[b][c]][0..K) += kd[b][c] * W[c][0..K)     in place, deterministic (channels of a point added in channel order)
  *   dWs[c][0..K) = sum over b (in order) of kd[b][c] * a[b*N + arg[b][c]][0..K)
- * K = 64, 128 or 256; 2 N + C + 1 <= 16384 (the buckets of an item live in LDS). */
+ * K = 64, 128 or 256; 2 N + C + 1 <= 16384 and C <= 4096 (the buckets of an item live in LDS). */
 int dal3_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a, int64_t lda, int B,
                         int C, int K, int N, float* da, int64_t ldda, float* dWs, dal3_stream stream);
 /* The five box terms of one box estimate (tools/static_model.py:382-424, tools/dynamic_model.py:341-383), each the mean

@@ -574,10 +574,14 @@ def test_criteria_on_the_gpu_match_the_stock_float64_formulation(tag):
 @pytest.mark.parametrize("B,C,K,N", [(4, 1024, 128, 4096), (3, 512, 256, 512), (5, 512, 128, 101), (2, 1024, 128, 5120)])
 def test_pooled_layer_sparse_terms_match_stock_index_put_and_gather(B, C, K, N):
     """dal3_tr_pool_sparse against index_put_(accumulate=True) / gather-multiply-sum in float64, with many channels
-    sharing a pooled point (the kernel adds them in channel order: bitwise repeatable)"""
+    sharing a pooled point (the kernel adds them in channel order: bitwise repeatable) — short lists (sorted) and
+    lists of hundreds of channels (placed by rank) in one call"""
     gen = torch.Generator(device="cuda").manual_seed(B * C + N)
     arg = torch.randint(0, max(N // 8, 1), (B, C), device="cuda", generator=gen, dtype=torch.int32)     # heavy sharing
     arg[:, ::7] = torch.randint(0, N, (B, (C + 6) // 7), device="cuda", generator=gen, dtype=torch.int32)
+    arg[0] = 0                                             # a zero-padded item: every channel pooled at its first point
+    if B > 1:
+        arg[1] = torch.randint(0, 3, (C,), device="cuda", generator=gen, dtype=torch.int32) * (N // 3)   # three long lists
     kd = torch.randn((B, C), device="cuda", generator=gen)
     W = torch.randn((C, K), device="cuda", generator=gen)
     a = torch.randn((B * N, K), device="cuda", generator=gen)
