@@ -868,11 +868,7 @@ hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, co
         tr_linear_ring_launch<TR_T, TR_MTB, TR_RING_OCC>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg,
                                                          c_out, z, ldz, accumulate, ws, s);
     } else if (ring_ok && c_out % 64 == 0) {
-#ifndef TR_SK_T
-#define TR_SK_T TR_T
-#define TR_SK_OCC 2
-#endif
-        tr_linear_ring_launch<TR_SK_T, 2, TR_SK_OCC>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
+        tr_linear_ring_launch<TR_T, 2, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
                                           accumulate, ws, s);
     } else if (ring_ok) {                                   // c_out = 32, 96, ...: one output tile per wave
         tr_linear_ring_launch<TR_T, 1, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
