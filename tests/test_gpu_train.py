@@ -599,3 +599,32 @@ def test_pooled_layer_sparse_terms_match_stock_index_put_and_gather(B, C, K, N):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert hip.lib().dal3_tr_pool_sparse(hip.ptr(arg), hip.ptr(kd), hip.ptr(W), K, hip.ptr(a), K, B, C, K, 9000, hip.ptr(da), K,
                                          hip.ptr(dws), hip.stream()) != 0          # 2 N + C + 1 > 16384: refused
+
+
+@pytest.mark.parametrize("B,C", [(64, 1024), (5, 96), (1, 32)])
+def test_pooled_layer_coefficients_match_the_float64_formulas(B, C):
+    """dal3_tr_pool_coef (the conv5 shortcut's per-channel algebra in one launch) against the stock float64 expressions it
+    replaced in train.py's _pooled_layer_backward"""
+    gen = torch.Generator(device="cuda").manual_seed(B * 31 + C)
+    dg = torch.randn((B, C), device="cuda", generator=gen)
+    g = torch.relu(torch.randn((B, C), device="cuda", generator=gen))        # about half of the gates closed
+    zarg = torch.randn((B, C), device="cuda", generator=gen) * 2 + 0.5
+    mu = torch.randn(C, device="cuda", generator=gen)
+    rstd = torch.rand(C, device="cuda", generator=gen) + 0.5
+    gamma = torch.randn(C, device="cuda", generator=gen)
+    M = B * 4096
+    coef = torch.empty((4, C), dtype=torch.float64, device="cuda")
+    kd = torch.empty((B, C), device="cuda")
+    hip.check(hip.lib().dal3_tr_pool_coef(hip.ptr(dg), hip.ptr(g), hip.ptr(zarg), hip.ptr(mu), hip.ptr(rstd), hip.ptr(gamma), B, C,
+                                          M, hip.ptr(coef), hip.ptr(kd), hip.stream()))
+    D = (dg * (g > 0)).double()
+    xhat = (zarg.double() - mu.double()) * rstd.double()
+    dbeta, dgamma = D.sum(0), (D * xhat).sum(0)
+    k1 = gamma.double() * rstd.double()
+    k2, k3 = dbeta / M, dgamma / M
+    want = torch.stack([dbeta, dgamma, -k1 * k2 + k1 * k3 * rstd.double() * mu.double(), -k1 * k3 * rstd.double()])
+    assert float((coef - want).abs().max()) <= 1e-12 * max(1.0, float(want.abs().max()))
+    assert torch.equal(kd, (k1 * D).float())
+    assert hip.lib().dal3_tr_pool_coef(hip.ptr(dg), hip.ptr(g), hip.ptr(zarg), hip.ptr(mu), hip.ptr(rstd), hip.ptr(gamma), 0, C, M,
+                                       hip.ptr(coef), hip.ptr(kd), hip.stream()) != 0
+
