@@ -306,22 +306,28 @@ __device__ __forceinline__ void conv_max_layer(WRing<D>& ring, const float* __re
 #pragma unroll
     for (int j = 0; j < T; ++j) accA[j] = f32x16{};
     mma_block_ring<KT, T, D, NoSide, true>(ring, X, accA);                // tile 0
-    for (int mt = 1; mt < n_tiles; mt += 2) {
+    // The loop body is two whole tiles and nothing else. With the last tile's un-hidden epilogue inside it (an
+    // `if (mt + 1 < n_tiles) ... else ep.all(...)`) the two paths left the ring's eight fragment registers and the two
+    // accumulator sets in different places, and hipcc reconciled them on the back edge: s_waitcnt vmcnt(7) ... vmcnt(0)
+    // around sixteen register copies — the ring drained, an L2 round trip with the matrix pipe idle, once per pair of tiles.
+    auto tile_b = [&](int mt) {                                            // tile mt, epilogue of tile mt-1
 #pragma unroll
         for (int j = 0; j < T; ++j) accB[j] = f32x16{};
-        auto epA = [&](int i) {                                            // tile mt, epilogue of tile mt-1
+        auto epA = [&](int i) {
             if (i < MaxEpilogueT<T>::STEPS) ep.step(i, accA, bias + 32 * (mt - 1), dst + 32 * (mt - 1), lane);
         };
         mma_block_ring<KT, T, D, decltype(epA), true>(ring, X, accB, epA);
-        if (mt + 1 < n_tiles) {
+    };
+    int mt = 1;
+    for (; mt + 1 < n_tiles; mt += 2) {
+        tile_b(mt);
 #pragma unroll
-            for (int j = 0; j < T; ++j) accA[j] = f32x16{};
-            auto epB = [&](int i) {                                        // tile mt+1, epilogue of tile mt
-                if (i < MaxEpilogueT<T>::STEPS) ep.step(i, accB, bias + 32 * mt, dst + 32 * mt, lane);
-            };
-            mma_block_ring<KT, T, D, decltype(epB), true>(ring, X, accA, epB);
-        } else {
-            ep.all(accB, bias + 32 * mt, dst + 32 * mt, lane);            // last tile: nothing left to hide under
-        }
+        for (int j = 0; j < T; ++j) accA[j] = f32x16{};
+        auto epB = [&](int i) {                                            // tile mt+1, epilogue of tile mt
+            if (i < MaxEpilogueT<T>::STEPS) ep.step(i, accB, bias + 32 * mt, dst + 32 * mt, lane);
+        };
+        mma_block_ring<KT, T, D, decltype(epB), true>(ring, X, accA, epB);
     }
+    tile_b(mt);                                                            // n_tiles is even: mt == n_tiles - 1
+    ep.all(accB, bias + 32 * mt, dst + 32 * mt, lane);                    // last tile: nothing left to hide under
 }
