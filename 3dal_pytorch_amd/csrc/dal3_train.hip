@@ -834,12 +834,13 @@ static void tr_linear_ring_launch(const float* a, int64_t M, int c_in, int64_t l
                 hipLaunchKernelGGL(kern, dim3(pers_grid), dim3(256), 0, s, a, M, c_in, lda, scale, shift, relu_in,
                                    reinterpret_cast<const f32x4*>(ws), bias, seg, c_out, z, ldz, n_mblk, (uint32_t)units);
             };
-            if (KT == 2)
+            if (KT == 2) {
                 args(tr_linear_pers_kernel<T, MTB, OCC, 2>);
-            else if (KT == 4 && MTB == 4)                      // (<2, 2, 2, 4> spills 64 registers; the generic one does not)
-                args(tr_linear_pers_kernel<T, MTB, OCC, 4>);
-            else
+            } else if (KT == 4 && MTB == 4) {                  // (<2, 2, 2, 4> spills 64 registers; the generic one does not)
+                if constexpr (MTB == 4) args(tr_linear_pers_kernel<T, MTB, OCC, 4>);
+            } else {
                 args(tr_linear_pers_kernel<T, MTB, OCC, 0>);
+            }
             return;
         }
     }
