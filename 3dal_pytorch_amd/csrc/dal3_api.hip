@@ -810,6 +810,32 @@ extern "C" int dal3_tr_pool_coef(const float* dg, const float* g, const float* z
     return 0;
 }
 
+static bool pool_k_ok(int K) { return K == 64 || K == 128 || K == 256; }
+
+extern "C" int dal3_tr_pool_moments(const float* W, int64_t ldw, const float* b, const double* m1, const float* Sc, int64_t M, int C,
+                                    int K, double* sums, dal3_stream stream) {
+    if (!W || !b || !m1 || !Sc || !sums || M <= 0 || C <= 0 || !pool_k_ok(K) || ldw < K)
+        return fail(DAL3_EINVAL, "tr_pool_moments: bad argument (K = 64, 128 or 256; ldw >= K)");
+    HIP_TRY(launch_tr_pool_moments(W, ldw, b, m1, Sc, M, C, K, sums, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_pool_gv(const double* coef, const float* W, int64_t ldw, const float* b, int C, int K, float* G, float* v,
+                               dal3_stream stream) {
+    if (!coef || !W || !b || !G || !v || C <= 0 || !pool_k_ok(K) || ldw < K)
+        return fail(DAL3_EINVAL, "tr_pool_gv: bad argument (K = 64, 128 or 256; ldw >= K)");
+    HIP_TRY(launch_tr_pool_gv(coef, W, ldw, b, C, K, G, v, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_pool_dw(const double* coef, const float* W, int64_t ldw, const float* b, const float* S, const double* m1,
+                               int64_t M, int centred, const float* dWs, int C, int K, float* dW, dal3_stream stream) {
+    if (!coef || !W || !b || !S || !m1 || !dWs || !dW || M <= 0 || C <= 0 || !pool_k_ok(K) || ldw < K)
+        return fail(DAL3_EINVAL, "tr_pool_dw: bad argument (K = 64, 128 or 256; ldw >= K)");
+    HIP_TRY(launch_tr_pool_dw(coef, W, ldw, b, S, m1, M, centred, dWs, C, K, dW, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a,
                                    int64_t lda, int B, int C, int K, int N, float* da, int64_t ldda, float* dWs,
                                    dal3_stream stream) {

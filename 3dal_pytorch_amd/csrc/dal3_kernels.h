@@ -217,6 +217,12 @@ hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int m
                             const float* mu, const float* rstd, double* part, double* out, hipStream_t s);
 hipError_t launch_tr_pool_coef(const float* dg, const float* g, const float* zarg, const float* mu, const float* rstd,
                                const float* gamma, int B, int C, int64_t M, double* coef, float* kd, hipStream_t s);
+hipError_t launch_tr_pool_moments(const float* W, int64_t ldw, const float* b, const double* m1, const float* Sc, int64_t M, int C,
+                                  int K, double* sums, hipStream_t s);
+hipError_t launch_tr_pool_gv(const double* coef, const float* W, int64_t ldw, const float* b, int C, int K, float* G, float* v,
+                             hipStream_t s);
+hipError_t launch_tr_pool_dw(const double* coef, const float* W, int64_t ldw, const float* b, const float* S, const double* m1,
+                             int64_t M, int centred, const float* dWs, int C, int K, float* dW, hipStream_t s);
 hipError_t launch_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a, int64_t lda,
                                  int B, int C, int K, int N, float* da, int64_t ldda, float* dWs, hipStream_t s);
 hipError_t launch_tr_box_loss(const float* center, const float* center_label, const float* hs, const float* hrn,

@@ -2022,3 +2022,101 @@ hipError_t launch_tr_pool_coef(const float* dg, const float* g, const float* zar
                        kd);
     return hipGetLastError();
 }
+
+// ---- the float64 algebra of the pooled layer's shortcut (train.py _moments_through / _pooled_layer_backward) as three
+// kernels instead of ~35 stock launches (W.double(), three rocBLAS dgemms of 16 MFLOP at 40 us each, products, sums,
+// casts): K = the layer's input channels (64, 128 or 256: one thread per input channel), C its output channels (one
+// workgroup each). All sums in float64 in a fixed order (loops in index order, LDS trees of a fixed shape).
+__device__ __forceinline__ double tr_block_sum(double v, double* red, int K) {   // K a power of two <= 256; all threads get the sum
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = K >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// forward: [sum z, sum z^2] over the M points of z = W a + b from the moments of a: m1 = sum a (K), Sc = sum of the
+// CENTRED a a^T (K x K, fp32 from the wgrad kernel):  mu_c = w_c . m1 / M + b_c,  var_c = max(w_c^T (Sc / M) w_c, 0),
+// sums = [mu M | (var + mu^2) M]
+__global__ __launch_bounds__(256) void tr_pool_moments_kernel(const float* __restrict__ W, int64_t ldw, const float* __restrict__ b,
+                                                              const double* __restrict__ m1, const float* __restrict__ Sc,
+                                                              int64_t M, int C, int K, double* __restrict__ sums) {
+    __shared__ double wrow[256], red[256];
+    const int c = blockIdx.x, k = threadIdx.x;
+    wrow[k] = (double)W[(int64_t)c * ldw + k];
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < K; ++j) t += wrow[j] * (double)Sc[(int64_t)j * K + k];
+    const double var = tr_block_sum(t * wrow[k] / (double)M, red, K);
+    const double mean = tr_block_sum(wrow[k] * (m1[k] / (double)M), red, K);
+    if (k == 0) {
+        const double mu = mean + (double)b[c], v = var > 0.0 ? var : 0.0;
+        sums[c] = mu * (double)M;
+        sums[C + c] = (v + mu * mu) * (double)M;
+    }
+}
+
+// backward, first half: G = W^T diag(Bc) W (K x K) and v = (A + Bc b)^T W (K), fp32 out (the operands of the linear
+// kernel that forms da). Workgroup k1 < K: row k1 of G; workgroup K: v. coef = dbeta | dgamma | A | Bc (tr_pool_coef).
+__global__ __launch_bounds__(256) void tr_pool_gv_kernel(const double* __restrict__ coef, const float* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ b, int C, int K, float* __restrict__ G,
+                                                         float* __restrict__ v) {
+    const int k1 = blockIdx.x, k2 = threadIdx.x;
+    const double* A = coef + 2 * (int64_t)C;
+    const double* Bc = coef + 3 * (int64_t)C;
+    double acc = 0.0;
+    if (k1 < K) {
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) acc += Bc[c] * (double)W[(int64_t)c * ldw + k1] * (double)W[(int64_t)c * ldw + k2];
+        G[(int64_t)k1 * K + k2] = (float)acc;
+    } else {
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) acc += (A[c] + Bc[c] * (double)b[c]) * (double)W[(int64_t)c * ldw + k2];
+        v[k2] = (float)acc;
+    }
+}
+
+// backward, second half: dW[c][k] = A_c m1_k + Bc_c ((W S)[c][k] + b_c m1_k) + dWs[c][k], with S = sum a a^T given either
+// directly (centred == 0) or as the centred Sc + m1 m1^T / M (centred != 0); fp32 out
+__global__ __launch_bounds__(256) void tr_pool_dw_kernel(const double* __restrict__ coef, const float* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ b, const float* __restrict__ S,
+                                                         const double* __restrict__ m1, int64_t M, int centred,
+                                                         const float* __restrict__ dWs, int C, int K, float* __restrict__ dW) {
+    __shared__ double wrow[256], red[256];
+    const int c = blockIdx.x, k = threadIdx.x;
+    wrow[k] = (double)W[(int64_t)c * ldw + k];
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < K; ++j) t += wrow[j] * (double)S[(int64_t)j * K + k];
+    const double m1k = m1[k];
+    if (centred) t += tr_block_sum(wrow[k] * m1k, red, K) * m1k / (double)M;   // (W m1) m1^T / M
+    const double A = coef[2 * (int64_t)C + c], Bc = coef[3 * (int64_t)C + c];
+    dW[(int64_t)c * K + k] = (float)(A * m1k + Bc * (t + (double)b[c] * m1k) + (double)dWs[(int64_t)c * K + k]);
+}
+
+static bool tr_pool_k_ok(int K) { return K == 64 || K == 128 || K == 256; }
+hipError_t launch_tr_pool_moments(const float* W, int64_t ldw, const float* b, const double* m1, const float* Sc, int64_t M, int C,
+                                  int K, double* sums, hipStream_t s) {
+    if (!tr_pool_k_ok(K)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tr_pool_moments_kernel, dim3(C), dim3(K), 0, s, W, ldw, b, m1, Sc, M, C, K, sums);
+    return hipGetLastError();
+}
+hipError_t launch_tr_pool_gv(const double* coef, const float* W, int64_t ldw, const float* b, int C, int K, float* G, float* v,
+                             hipStream_t s) {
+    if (!tr_pool_k_ok(K)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tr_pool_gv_kernel, dim3(K + 1), dim3(K), 0, s, coef, W, ldw, b, C, K, G, v);
+    return hipGetLastError();
+}
+hipError_t launch_tr_pool_dw(const double* coef, const float* W, int64_t ldw, const float* b, const float* S, const double* m1,
+                             int64_t M, int centred, const float* dWs, int C, int K, float* dW, hipStream_t s) {
+    if (!tr_pool_k_ok(K)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tr_pool_dw_kernel, dim3(C), dim3(K), 0, s, coef, W, ldw, b, S, m1, M, centred, dWs, C, K, dW);
+    return hipGetLastError();
+}
+

@@ -255,7 +255,8 @@ def _moments_through(z_prev, bn_prev, W, b):
     relu(bn(z_prev)) instead of a pass over the C-channel output (C = 1024, K = 128 for conv5: 1 GB not re-read):
         mean(z) = W mean(a) + b,    var(z)_c = w_c^T Cov(a) w_c.
     Cov(a) is accumulated on CENTRED activations by the MFMA wgrad kernel (no mean^2 to cancel) and the small
-    products are float64. Returns (sums, a, S, m1) with S = sum a a^T and m1 = sum a for the backward shortcut."""
+    products are float64 (dal3_tr_pool_moments). Returns (sums, a, (Sc, centred), m1): the centred second moments and m1 =
+    sum a for the backward shortcut (S = sum a a^T = Sc + m1 m1^T / M)."""
     K = z_prev.shape[1]
     M = bn_prev.M                                                          # real rows (z_prev is padded to 32s)
     a = _act_dropout(z_prev, bn_prev.act, None)                            # relu(bn(z_prev)) in one pass
@@ -266,14 +267,20 @@ def _moments_through(z_prev, bn_prev, W, b):
     ac = a - mean_a.float()
     if a.shape[0] > M:
         ac[M:].zero_()
-    Sc = _wgrad(ac, ac, K, K).double()
+    Sc = _wgrad(ac, ac, K, K)
     del ac
-    W64 = W.double()
-    mu = W64 @ mean_a + b.double()
-    var = ((W64 @ (Sc / M)) * W64).sum(1).clamp_(min=0.0)
-    sums = torch.cat([mu * M, (var + mu * mu) * M])
-    S = Sc + m1[:, None] * m1[None, :] / M
-    return sums, a, S, m1
+    C = W.shape[0]
+    if K in (64, 128, 256):                                                 # the float64 algebra in one launch
+        sums = torch.empty(2 * C, dtype=torch.float64, device=a.device)
+        Wc, bc = W.contiguous(), b.contiguous()
+        _hip.check(_hip.lib().dal3_tr_pool_moments(_hip.ptr(Wc), Wc.stride(0), _hip.ptr(bc), _hip.ptr(m1), _hip.ptr(Sc), M, C, K,
+                                                   _hip.ptr(sums), _hip.stream()))
+    else:
+        W64 = W.double()
+        mu = W64 @ mean_a + b.double()
+        var = ((W64 @ (Sc.double() / M)) * W64).sum(1).clamp_(min=0.0)
+        sums = torch.cat([mu * M, (var + mu * mu) * M])
+    return sums, a, (Sc, True), m1                                         # (Sc, True): S = Sc + m1 m1^T / M
 
 
 def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N, cached=None):
@@ -309,14 +316,22 @@ def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N, cache
                                             _hip.ptr(bn.mu), _hip.ptr(bn.rstd), _hip.ptr(bn.gamma), nB, C, M, _hip.ptr(coef),
                                             _hip.ptr(kd), _hip.stream()))
     dbeta, dgamma, A, Bc = coef[0], coef[1], coef[2], coef[3]
-    W64, b64 = W.double(), b.double()
-    G = W64.t() @ (Bc[:, None] * W64)                                       # (K,K)
-    v = (A + Bc * b64) @ W64                                                # (K,)
-    da = _linear(a, G.float().contiguous(), K, K, K, transpose=True, bias=v.float().contiguous())
+    fused = K in (64, 128, 256)                                             # the float64 algebra on lib3dal_hip.so
+    Wc, bc = W.contiguous(), b.contiguous()
+    if fused:
+        G = torch.empty((K, K), dtype=torch.float32, device=dev)
+        v = torch.empty(K, dtype=torch.float32, device=dev)
+        _hip.check(_hip.lib().dal3_tr_pool_gv(_hip.ptr(coef), _hip.ptr(Wc), Wc.stride(0), _hip.ptr(bc), C, K, _hip.ptr(G),
+                                              _hip.ptr(v), _hip.stream()))
+    else:
+        W64, b64 = W.double(), b.double()
+        G = (W64.t() @ (Bc[:, None] * W64)).float().contiguous()            # (K,K)
+        v = ((A + Bc * b64) @ W64).float().contiguous()                     # (K,)
+    da = _linear(a, G, K, K, K, transpose=True, bias=v)
     if S is None:
-        S = _wgrad(a, a, K, K).double()                                     # Gram matrix on the MFMA wgrad kernel
+        S = (_wgrad(a, a, K, K), False)                                     # Gram matrix on the MFMA wgrad kernel
         m1 = _colred(a, 0, rows=M)[:K]
-    dW = A[:, None] * m1[None] + Bc[:, None] * (W64 @ S + b64[:, None] * m1[None])
+    S, centred = S
     # the two sparse terms (one pooled point per item and channel): scatter into da, gather for dW
     if 2 * N + C + 1 <= 16384 and C <= 4096 and K in (64, 128, 256):                      # one call of the library (LDS buckets per item)
         dWs = torch.empty((C, K), dtype=torch.float32, device=dev)
@@ -328,8 +343,15 @@ def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N, cache
         rows = (arg.long() + torch.arange(arg.shape[0], device=dev)[:, None] * N).reshape(-1)
         da.index_put_((rows,), (kd[:, :, None] * W[None]).reshape(-1, K), accumulate=True)
         dWs = (kd[:, :, None] * a[rows].reshape(arg.shape[0], C, K)).sum(0)
-    dW = dW + dWs.double()
-    return da, dW.float(), dgamma.float(), dbeta.float()
+    if fused:
+        dW = torch.empty((C, K), dtype=torch.float32, device=dev)
+        m1c = m1.contiguous()
+        _hip.check(_hip.lib().dal3_tr_pool_dw(_hip.ptr(coef), _hip.ptr(Wc), Wc.stride(0), _hip.ptr(bc), _hip.ptr(S), _hip.ptr(m1c),
+                                              M, int(centred), _hip.ptr(dWs), C, K, _hip.ptr(dW), _hip.stream()))
+    else:
+        S64 = S.double() + (m1[:, None] * m1[None, :] / M if centred else 0.0)
+        dW = (A[:, None] * m1[None] + Bc[:, None] * (W64 @ S64 + b64[:, None] * m1[None]) + dWs.double()).float()
+    return da, dW, dgamma.float(), dbeta.float()
 
 
 class _PointStack(torch.autograd.Function):

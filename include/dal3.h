@@ -313,6 +313,21 @@ size_t dal3_tr_seg_ce_workspace_bytes(int64_t M);
  * k3 = dgamma / M), and kd (B, C) fp32 = k1 * D. */
 int dal3_tr_pool_coef(const float* dg, const float* g, const float* zarg, const float* mu, const float* rstd,
                       const float* gamma, int B, int C, int64_t M, double* coef, float* kd, dal3_stream stream);
+/* The float64 algebra around that layer, K = its input channels (64, 128 or 256), C its output channels, W (C, K) row-major
+ * with row stride ldw, b (C):
+ *   dal3_tr_pool_moments  forward: sums (2 C) float64 = [sum z | sum z^2] of z = W a + b over M points, from m1 = sum a
+ *                         (K, float64) and Sc = sum of the CENTRED a a^T (K x K fp32): mu = W m1 / M + b,
+ *                         var_c = max(w_c^T (Sc / M) w_c, 0), sums = [mu M | (var + mu^2) M];
+ *   dal3_tr_pool_gv       backward: G (K x K fp32) = W^T diag(Bc) W and v (K fp32) = (A + Bc b)^T W, with coef (4, C) from
+ *                         dal3_tr_pool_coef — the operands of the dense part of da = a G + v;
+ *   dal3_tr_pool_dw       backward: dW (C, K) fp32 = A m1^T + diag(Bc) (W S + b m1^T) + dWs, S = sum a a^T (K x K fp32)
+ *                         given directly (centred = 0) or as Sc + m1 m1^T / M (centred != 0); dWs (C, K): the sparse term. */
+int dal3_tr_pool_moments(const float* W, int64_t ldw, const float* b, const double* m1, const float* Sc, int64_t M, int C, int K,
+                         double* sums, dal3_stream stream);
+int dal3_tr_pool_gv(const double* coef, const float* W, int64_t ldw, const float* b, int C, int K, float* G, float* v,
+                    dal3_stream stream);
+int dal3_tr_pool_dw(const double* coef, const float* W, int64_t ldw, const float* b, const float* S, const double* m1, int64_t M,
+                    int centred, const float* dWs, int C, int K, float* dW, dal3_stream stream);
 /* The two sparse terms of the backward of conv -> BN -> ReLU -> max over an item's N points (one pooled point per item
  * and channel: arg (B,C) int32, as dal3_tr_segmax / dal3_tr_linear_pool return it; kd (B,C) = k1 * dy at those points):
  *   da[b*N + arg[b][c]][0..K) += kd[b][c] * W[c][0..K)     in place, deterministic (channels of a point added in channel order)

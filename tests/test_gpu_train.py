@@ -628,3 +628,42 @@ def test_pooled_layer_coefficients_match_the_float64_formulas(B, C):
     assert hip.lib().dal3_tr_pool_coef(hip.ptr(dg), hip.ptr(g), hip.ptr(zarg), hip.ptr(mu), hip.ptr(rstd), hip.ptr(gamma), 0, C, M,
                                        hip.ptr(coef), hip.ptr(kd), hip.stream()) != 0
 
+
+@pytest.mark.parametrize("C,K,M", [(1024, 128, 64 * 4096), (96, 64, 1000), (512, 256, 32768)])
+def test_pooled_layer_float64_algebra_kernels_match_the_stock_expressions(C, K, M):
+    """dal3_tr_pool_moments / _gv / _dw against the float64 torch expressions they replaced (train.py
+    _moments_through, _pooled_layer_backward): the same quantities to ~1e-12 in float64, to fp32 rounding where the
+    output is fp32"""
+    gen = torch.Generator(device="cuda").manual_seed(C + K)
+    W = torch.randn((C, K), device="cuda", generator=gen) / K ** 0.5
+    b = torch.randn(C, device="cuda", generator=gen)
+    x = torch.randn((4096, K), device="cuda", generator=gen).double() * 0.7 + 0.3
+    m1 = x.sum(0) * (M / 4096)
+    xc = x - x.mean(0)
+    Sc = ((xc.t() @ xc) * (M / 4096)).float().contiguous()
+    lib = hip.lib()
+    sums = torch.empty(2 * C, dtype=torch.float64, device="cuda")
+    hip.check(lib.dal3_tr_pool_moments(hip.ptr(W), K, hip.ptr(b), hip.ptr(m1), hip.ptr(Sc), M, C, K, hip.ptr(sums), hip.stream()))
+    W64 = W.double()
+    mu = W64 @ (m1 / M) + b.double()
+    var = ((W64 @ (Sc.double() / M)) * W64).sum(1).clamp_(min=0.0)
+    want = torch.cat([mu * M, (var + mu * mu) * M])
+    assert float((sums - want).abs().max()) <= 1e-11 * float(want.abs().max())
+    coef = torch.randn((4, C), device="cuda", generator=gen).double()
+    A, Bc = coef[2], coef[3]
+    G = torch.empty((K, K), device="cuda")
+    v = torch.empty(K, device="cuda")
+    hip.check(lib.dal3_tr_pool_gv(hip.ptr(coef), hip.ptr(W), K, hip.ptr(b), C, K, hip.ptr(G), hip.ptr(v), hip.stream()))
+    assert torch.equal(G, (W64.t() @ (Bc[:, None] * W64)).float()) or _close(G, W64.t() @ (Bc[:, None] * W64))
+    assert _close(v, (A + Bc * b.double()) @ W64)
+    dWs = torch.randn((C, K), device="cuda", generator=gen)
+    for centred in (1, 0):
+        S = Sc if centred else (Sc.double() + m1[:, None] * m1[None] / M).float().contiguous()
+        S64 = S.double() + (m1[:, None] * m1[None] / M if centred else 0.0)
+        dW = torch.empty((C, K), device="cuda")
+        hip.check(lib.dal3_tr_pool_dw(hip.ptr(coef), hip.ptr(W), K, hip.ptr(b), hip.ptr(S), hip.ptr(m1), M, centred, hip.ptr(dWs),
+                                      C, K, hip.ptr(dW), hip.stream()))
+        want = A[:, None] * m1[None] + Bc[:, None] * (W64 @ S64 + b.double()[:, None] * m1[None]) + dWs.double()
+        assert _close(dW, want)
+    assert lib.dal3_tr_pool_gv(hip.ptr(coef), hip.ptr(W), K, hip.ptr(b), C, 96, hip.ptr(G), hip.ptr(v), hip.stream()) != 0
+
