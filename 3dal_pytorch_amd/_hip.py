@@ -93,7 +93,8 @@ SIGNATURES = {
     "dal3_tr_colred": (_i, [vp, _i64, _i, _i64, _i, vp, _i64, vp, vp, _i64, vp, vp, vp, vp, vp, _sz, vp, vp]),
     "dal3_tr_pool_coef": (_i, [vp, vp, vp, vp, vp, vp, _i, _i, _i64, vp, vp, vp]),
     "dal3_tr_pool_moments": (_i, [vp, _i64, vp, vp, vp, _i64, _i, _i, vp, vp]),
-    "dal3_tr_pool_gv": (_i, [vp, vp, _i64, vp, _i, _i, vp, vp, vp]),
+    "dal3_tr_pool_gv_workspace_bytes": (_sz, [_i]),
+    "dal3_tr_pool_gv": (_i, [vp, vp, _i64, vp, _i, _i, vp, vp, vp, _sz, vp]),
     "dal3_tr_pool_dw": (_i, [vp, vp, _i64, vp, vp, vp, _i64, _i, vp, _i, _i, vp, vp]),
     "dal3_tr_pool_sparse": (_i, [vp, vp, vp, _i64, vp, _i64, _i, _i, _i, _i, vp, _i64, vp, vp]),
     "dal3_tr_box_loss": (_i, [vp] * 10 + [_i] + [vp] * 7),

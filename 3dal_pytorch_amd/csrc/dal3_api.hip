@@ -820,11 +820,15 @@ extern "C" int dal3_tr_pool_moments(const float* W, int64_t ldw, const float* b,
     return 0;
 }
 
+extern "C" size_t dal3_tr_pool_gv_workspace_bytes(int K) { return pool_k_ok(K) ? tr_pool_gv_workspace_bytes(K) : 0; }
+
 extern "C" int dal3_tr_pool_gv(const double* coef, const float* W, int64_t ldw, const float* b, int C, int K, float* G, float* v,
-                               dal3_stream stream) {
+                               void* workspace, size_t workspace_bytes, dal3_stream stream) {
     if (!coef || !W || !b || !G || !v || C <= 0 || !pool_k_ok(K) || ldw < K)
         return fail(DAL3_EINVAL, "tr_pool_gv: bad argument (K = 64, 128 or 256; ldw >= K)");
-    HIP_TRY(launch_tr_pool_gv(coef, W, ldw, b, C, K, G, v, static_cast<hipStream_t>(stream)));
+    if (!workspace || workspace_bytes < tr_pool_gv_workspace_bytes(K))
+        return fail(DAL3_EWORKSPACE, "tr_pool_gv: workspace too small (dal3_tr_pool_gv_workspace_bytes)");
+    HIP_TRY(launch_tr_pool_gv(coef, W, ldw, b, C, K, G, v, static_cast<double*>(workspace), static_cast<hipStream_t>(stream)));
     return 0;
 }
 

@@ -219,8 +219,9 @@ hipError_t launch_tr_pool_coef(const float* dg, const float* g, const float* zar
                                const float* gamma, int B, int C, int64_t M, double* coef, float* kd, hipStream_t s);
 hipError_t launch_tr_pool_moments(const float* W, int64_t ldw, const float* b, const double* m1, const float* Sc, int64_t M, int C,
                                   int K, double* sums, hipStream_t s);
+size_t tr_pool_gv_workspace_bytes(int K);
 hipError_t launch_tr_pool_gv(const double* coef, const float* W, int64_t ldw, const float* b, int C, int K, float* G, float* v,
-                             hipStream_t s);
+                             double* ws, hipStream_t s);
 hipError_t launch_tr_pool_dw(const double* coef, const float* W, int64_t ldw, const float* b, const float* S, const double* m1,
                              int64_t M, int centred, const float* dWs, int C, int K, float* dW, hipStream_t s);
 hipError_t launch_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a, int64_t lda,

@@ -2062,23 +2062,36 @@ __global__ __launch_bounds__(256) void tr_pool_moments_kernel(const float* __res
 }
 
 // backward, first half: G = W^T diag(Bc) W (K x K) and v = (A + Bc b)^T W (K), fp32 out (the operands of the linear
-// kernel that forms da). Workgroup k1 < K: row k1 of G; workgroup K: v. coef = dbeta | dgamma | A | Bc (tr_pool_coef).
+// kernel that forms da). coef = dbeta | dgamma | A | Bc (tr_pool_coef). The sums over the C channels are cut into
+// TR_GV_SPLIT parts (one workgroup per row k1 of G — or v — and part; a whole sum per thread was 1,024 dependent trips,
+// 51 us), float64 partials in ws, added in part order by the second kernel.
+#define TR_GV_SPLIT 8
 __global__ __launch_bounds__(256) void tr_pool_gv_kernel(const double* __restrict__ coef, const float* __restrict__ W, int64_t ldw,
-                                                         const float* __restrict__ b, int C, int K, float* __restrict__ G,
-                                                         float* __restrict__ v) {
-    const int k1 = blockIdx.x, k2 = threadIdx.x;
+                                                         const float* __restrict__ b, int C, int K, double* __restrict__ ws) {
+    const int k1 = blockIdx.x, k2 = threadIdx.x, part = blockIdx.y;
+    const int per = (C + TR_GV_SPLIT - 1) / TR_GV_SPLIT, c0 = part * per, c1 = min(C, c0 + per);
     const double* A = coef + 2 * (int64_t)C;
     const double* Bc = coef + 3 * (int64_t)C;
     double acc = 0.0;
     if (k1 < K) {
 #pragma unroll 8
-        for (int c = 0; c < C; ++c) acc += Bc[c] * (double)W[(int64_t)c * ldw + k1] * (double)W[(int64_t)c * ldw + k2];
-        G[(int64_t)k1 * K + k2] = (float)acc;
+        for (int c = c0; c < c1; ++c) acc += Bc[c] * (double)W[(int64_t)c * ldw + k1] * (double)W[(int64_t)c * ldw + k2];
     } else {
 #pragma unroll 8
-        for (int c = 0; c < C; ++c) acc += (A[c] + Bc[c] * (double)b[c]) * (double)W[(int64_t)c * ldw + k2];
-        v[k2] = (float)acc;
+        for (int c = c0; c < c1; ++c) acc += (A[c] + Bc[c] * (double)b[c]) * (double)W[(int64_t)c * ldw + k2];
     }
+    ws[((int64_t)part * (K + 1) + k1) * K + k2] = acc;
+}
+__global__ __launch_bounds__(256) void tr_pool_gv_final_kernel(const double* __restrict__ ws, int K, float* __restrict__ G,
+                                                               float* __restrict__ v) {
+    const int k1 = blockIdx.x, k2 = threadIdx.x;
+    double acc = 0.0;
+#pragma unroll
+    for (int p = 0; p < TR_GV_SPLIT; ++p) acc += ws[((int64_t)p * (K + 1) + k1) * K + k2];
+    if (k1 < K)
+        G[(int64_t)k1 * K + k2] = (float)acc;
+    else
+        v[k2] = (float)acc;
 }
 
 // backward, second half: dW[c][k] = A_c m1_k + Bc_c ((W S)[c][k] + b_c m1_k) + dWs[c][k], with S = sum a a^T given either
@@ -2107,10 +2120,12 @@ hipError_t launch_tr_pool_moments(const float* W, int64_t ldw, const float* b, c
     hipLaunchKernelGGL(tr_pool_moments_kernel, dim3(C), dim3(K), 0, s, W, ldw, b, m1, Sc, M, C, K, sums);
     return hipGetLastError();
 }
+size_t tr_pool_gv_workspace_bytes(int K) { return (size_t)TR_GV_SPLIT * (K + 1) * K * sizeof(double); }
 hipError_t launch_tr_pool_gv(const double* coef, const float* W, int64_t ldw, const float* b, int C, int K, float* G, float* v,
-                             hipStream_t s) {
+                             double* ws, hipStream_t s) {
     if (!tr_pool_k_ok(K)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(tr_pool_gv_kernel, dim3(K + 1), dim3(K), 0, s, coef, W, ldw, b, C, K, G, v);
+    hipLaunchKernelGGL(tr_pool_gv_kernel, dim3(K + 1, TR_GV_SPLIT), dim3(K), 0, s, coef, W, ldw, b, C, K, ws);
+    hipLaunchKernelGGL(tr_pool_gv_final_kernel, dim3(K + 1), dim3(K), 0, s, ws, K, G, v);
     return hipGetLastError();
 }
 hipError_t launch_tr_pool_dw(const double* coef, const float* W, int64_t ldw, const float* b, const float* S, const double* m1,

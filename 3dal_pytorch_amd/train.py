@@ -321,8 +321,10 @@ def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N, cache
     if fused:
         G = torch.empty((K, K), dtype=torch.float32, device=dev)
         v = torch.empty(K, dtype=torch.float32, device=dev)
+        need = _hip.lib().dal3_tr_pool_gv_workspace_bytes(K)
+        gws = _ws(need, dev)
         _hip.check(_hip.lib().dal3_tr_pool_gv(_hip.ptr(coef), _hip.ptr(Wc), Wc.stride(0), _hip.ptr(bc), C, K, _hip.ptr(G),
-                                              _hip.ptr(v), _hip.stream()))
+                                              _hip.ptr(v), _hip.ptr(gws), need, _hip.stream()))
     else:
         W64, b64 = W.double(), b.double()
         G = (W64.t() @ (Bc[:, None] * W64)).float().contiguous()            # (K,K)

@@ -324,8 +324,9 @@ int dal3_tr_pool_coef(const float* dg, const float* g, const float* zarg, const 
  *                         given directly (centred = 0) or as Sc + m1 m1^T / M (centred != 0); dWs (C, K): the sparse term. */
 int dal3_tr_pool_moments(const float* W, int64_t ldw, const float* b, const double* m1, const float* Sc, int64_t M, int C, int K,
                          double* sums, dal3_stream stream);
+size_t dal3_tr_pool_gv_workspace_bytes(int K);
 int dal3_tr_pool_gv(const double* coef, const float* W, int64_t ldw, const float* b, int C, int K, float* G, float* v,
-                    dal3_stream stream);
+                    void* workspace, size_t workspace_bytes, dal3_stream stream);
 int dal3_tr_pool_dw(const double* coef, const float* W, int64_t ldw, const float* b, const float* S, const double* m1, int64_t M,
                     int centred, const float* dWs, int C, int K, float* dW, dal3_stream stream);
 /* The two sparse terms of the backward of conv -> BN -> ReLU -> max over an item's N points (one pooled point per item

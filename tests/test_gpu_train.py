@@ -653,7 +653,10 @@ def test_pooled_layer_float64_algebra_kernels_match_the_stock_expressions(C, K, 
     A, Bc = coef[2], coef[3]
     G = torch.empty((K, K), device="cuda")
     v = torch.empty(K, device="cuda")
-    hip.check(lib.dal3_tr_pool_gv(hip.ptr(coef), hip.ptr(W), K, hip.ptr(b), C, K, hip.ptr(G), hip.ptr(v), hip.stream()))
+    need = lib.dal3_tr_pool_gv_workspace_bytes(K)
+    gws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    hip.check(lib.dal3_tr_pool_gv(hip.ptr(coef), hip.ptr(W), K, hip.ptr(b), C, K, hip.ptr(G), hip.ptr(v), hip.ptr(gws), need,
+                                  hip.stream()))
     assert torch.equal(G, (W64.t() @ (Bc[:, None] * W64)).float()) or _close(G, W64.t() @ (Bc[:, None] * W64))
     assert _close(v, (A + Bc * b.double()) @ W64)
     dWs = torch.randn((C, K), device="cuda", generator=gen)
@@ -665,5 +668,8 @@ def test_pooled_layer_float64_algebra_kernels_match_the_stock_expressions(C, K, 
                                       C, K, hip.ptr(dW), hip.stream()))
         want = A[:, None] * m1[None] + Bc[:, None] * (W64 @ S64 + b.double()[:, None] * m1[None]) + dWs.double()
         assert _close(dW, want)
-    assert lib.dal3_tr_pool_gv(hip.ptr(coef), hip.ptr(W), K, hip.ptr(b), C, 96, hip.ptr(G), hip.ptr(v), hip.stream()) != 0
+    assert lib.dal3_tr_pool_gv(hip.ptr(coef), hip.ptr(W), K, hip.ptr(b), C, 96, hip.ptr(G), hip.ptr(v), hip.ptr(gws), need,
+                               hip.stream()) != 0
+    assert lib.dal3_tr_pool_gv(hip.ptr(coef), hip.ptr(W), K, hip.ptr(b), C, K, hip.ptr(G), hip.ptr(v), hip.ptr(gws), 16,
+                               hip.stream()) != 0
 
