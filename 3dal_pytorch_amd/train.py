@@ -632,13 +632,11 @@ def fc_tail_train_forward(head, x):
 
 
 def _bn_stats(mod, names):
-    out = []
-    for n in names:
-        bn = getattr(mod, n)
-        out.append((bn.running_mean, bn.running_var))
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
-    return out
+    bns = [getattr(mod, n) for n in names]
+    if bns:
+        with torch.no_grad():                               # one launch for the module's counters instead of one each
+            torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+    return [(bn.running_mean, bn.running_var) for bn in bns]
 
 
 def ins_seg_train_forward(ins_seg, pts, p_drop=0.5, drop_mask=None):
