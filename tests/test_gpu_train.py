@@ -355,14 +355,15 @@ def test_train_mode_with_the_device_sampler_needs_no_host_round_trip():
 
 
 # ------------------------------------------------------------------ round 2: fused pooling, Dropout kernel, FC tails
-@pytest.mark.parametrize("c_in,c_out,seg", [(64, 512, 4096), (128, 128, 0), (512, 256, 0), (64, 64, 0), (192, 64, 0),
-                                            (256, 128, 0)])
-def test_persistent_linear_kernels_match_float64_and_the_one_unit_kernels_bitwise(c_in, c_out, seg):
+@pytest.mark.parametrize("c_in,c_out,seg,extra", [(64, 512, 4096, 0), (128, 128, 0, 0), (512, 256, 0, 0), (64, 64, 0, 0),
+                                                  (192, 64, 0, 0), (256, 128, 0, 0), (64, 512, 0, 37), (512, 256, 0, 1001),
+                                                  (128, 128, 0, 4095)])
+def test_persistent_linear_kernels_match_float64_and_the_one_unit_kernels_bitwise(c_in, c_out, seg, extra):
     """the software-pipelined persistent kernels (tr_linear_pers_kernel: K = 64 and K = 128 as straight-line code, K >= 128
     generic, both tile shapes) at the step's size, 64 x 4096 rows: against float64, and against the one-unit-per-wave
     kernels, which an accumulating call into a zeroed buffer still takes (0 + x is exact) — the same FMA chain per
-    element, so the same bits"""
-    M = 64 * 4096
+    element, so the same bits; `extra`: unit counts that are no multiple of the wave count"""
+    M = 64 * 4096 + 64 * extra                                          # extra: waves with one unit more than others
     gen = torch.Generator(device="cuda").manual_seed(c_in * 7 + c_out)
     a = torch.randn((M, c_in), device="cuda", generator=gen)
     W = torch.randn((c_out, c_in), device="cuda", generator=gen) / c_in ** 0.5
