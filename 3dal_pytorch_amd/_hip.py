@@ -106,6 +106,8 @@ SIGNATURES = {
     "dal3_tr_bn_finalize": (_i, [vp, _i, _i64, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp]),
     "dal3_tr_bnbwd_coef": (_i, [vp, _i, _i64, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dal3_tr_bnbwd_apply": (_i, [vp, _i64, _i, _i64, vp, _i64, vp, vp, _i64, vp, vp, vp, vp, vp, vp, vp, vp, _i64, vp]),
+    "dal3_tr_bnbwd_apply_segsum_workspace_bytes": (_sz, [_i64, _i]),
+    "dal3_tr_bnbwd_apply_segsum": (_i, [vp, _i64, _i, _i64, vp, _i64, vp, vp, vp, vp, vp, vp, vp, vp, _i64, _i64, vp, vp, _sz, vp]),
     "dal3_tr_wgrad_workspace_bytes": (_sz, [_i64, _i, _i]),
     "dal3_tr_wgrad": (_i, [vp, _i64, vp, _i64, vp, vp, _i, _i64, _i, _i, vp, _sz, vp, vp]),
     "dal3_tr_segmax": (_i, [vp, _i64, _i64, _i, vp, vp, vp, vp, _i64, vp, _sz, vp]),

@@ -943,6 +943,25 @@ extern "C" int dal3_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz
     return 0;
 }
 
+extern "C" size_t dal3_tr_bnbwd_apply_segsum_workspace_bytes(int64_t M, int C) {
+    return (M > 0 && C > 0) ? tr_bnbwd_apply_segsum_workspace_bytes(M, C) : 0;
+}
+
+extern "C" int dal3_tr_bnbwd_apply_segsum(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda,
+                                          const float* scale, const float* shift, const float* mu, const float* rstd,
+                                          const float* k1, const float* k2, const float* k3, float* dz, int64_t lddz,
+                                          int64_t sum_seg, float* seg_sums, void* workspace, size_t workspace_bytes,
+                                          dal3_stream stream) {
+    if (!z || !da || M <= 0 || C <= 0 || C % 64 || !scale || !shift || !mu || !rstd || !k1 || !k2 || !k3 || !dz || ldz < C ||
+        lddz < C || ldda < C || ldz % 4 || lddz % 4 || ldda % 4 || sum_seg <= 0 || sum_seg % 128 || M % sum_seg || !seg_sums)
+        return fail(DAL3_EINVAL, "tr_bnbwd_apply_segsum: bad argument (C % 64 == 0, sum_seg % 128 == 0, M % sum_seg == 0, dense da)");
+    if (!workspace || workspace_bytes < tr_bnbwd_apply_segsum_workspace_bytes(M, C))
+        return fail(DAL3_EWORKSPACE, "tr_bnbwd_apply_segsum: workspace too small");
+    HIP_TRY(launch_tr_bnbwd_apply_segsum(z, M, C, ldz, da, ldda, scale, shift, mu, rstd, k1, k2, k3, dz, lddz, sum_seg, seg_sums,
+                                         static_cast<double*>(workspace), static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" size_t dal3_tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in) {
     return (M > 0 && c_out > 0 && c_in > 0) ? tr_wgrad_workspace_bytes(M, c_out, c_in) : 0;
 }

@@ -249,6 +249,11 @@ hipError_t launch_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, 
                                  const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                                  const float* mu, const float* rstd, const float* k1, const float* k2, const float* k3,
                                  float* dz, int64_t lddz, hipStream_t s);
+size_t tr_bnbwd_apply_segsum_workspace_bytes(int64_t M, int C);
+hipError_t launch_tr_bnbwd_apply_segsum(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda,
+                                        const float* scale, const float* shift, const float* mu, const float* rstd,
+                                        const float* k1, const float* k2, const float* k3, float* dz, int64_t lddz,
+                                        int64_t sum_seg, float* seg_sums, double* ws, hipStream_t s);
 size_t tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in);
 hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale,
                            const float* shift, int relu_in, int64_t M, int c_out, int c_in, float* part, float* dW,

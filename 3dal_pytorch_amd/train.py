@@ -129,8 +129,9 @@ class _BN:
     def act(self):
         return (self.scale, self.shift, True)
 
-    def backward(self, z, da=None, dg=None, arg=None, seg=0):
-        """(dz, dgamma, dbeta) from the gradient w.r.t. relu(bn(z))"""
+    def backward(self, z, da=None, dg=None, arg=None, seg=0, sum_seg=0):
+        """(dz, dgamma, dbeta) from the gradient w.r.t. relu(bn(z)); with sum_seg also the column sums of dz over every
+        segment of sum_seg rows, (M / sum_seg, C), taken in the same pass (dal3_tr_bnbwd_apply_segsum)"""
         C = z.shape[1]
         M = self.M                                                          # the real rows; padding rows get dz = 0
         lib = _hip.lib()
@@ -143,12 +144,26 @@ class _BN:
                                           _hip.ptr(co[1]), _hip.ptr(co[2]), _hip.ptr(co[3]), _hip.ptr(co[4]), _hip.ptr(ws),
                                           need, _hip.stream()))
         dz = torch.empty_like(z)
+        if sum_seg:
+            fused = da is not None and C % 64 == 0 and sum_seg % 128 == 0 and M % sum_seg == 0 and M == z.shape[0]
+            if fused:
+                sums = torch.empty((M // sum_seg, C), dtype=torch.float32, device=z.device)
+                need2 = lib.dal3_tr_bnbwd_apply_segsum_workspace_bytes(M, C)
+                ws2 = _ws(need2, z.device)
+                _hip.check(lib.dal3_tr_bnbwd_apply_segsum(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(da), da.stride(0),
+                                                          _hip.ptr(self.scale), _hip.ptr(self.shift), _hip.ptr(self.mu),
+                                                          _hip.ptr(self.rstd), _hip.ptr(co[2]), _hip.ptr(co[3]), _hip.ptr(co[4]),
+                                                          _hip.ptr(dz), dz.stride(0), sum_seg, _hip.ptr(sums), _hip.ptr(ws2),
+                                                          need2, _hip.stream()))
+                return dz, co[0], co[1], sums
         _hip.check(lib.dal3_tr_bnbwd_apply(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(da), da.stride(0) if da is not None else 0,
                                            _hip.ptr(dg), _hip.ptr(arg), seg, _hip.ptr(self.scale), _hip.ptr(self.shift),
                                            _hip.ptr(self.mu), _hip.ptr(self.rstd), _hip.ptr(co[2]), _hip.ptr(co[3]),
                                            _hip.ptr(co[4]), _hip.ptr(dz), dz.stride(0), _hip.stream()))
         if z.shape[0] > M:
             dz[M:].zero_()                                                  # (wgrad sums over every row it is given)
+        if sum_seg:                                                         # (ragged sizes: the caller takes the separate pass)
+            return dz, co[0], co[1], None
         return dz, co[0], co[1]
 
 
@@ -506,10 +521,11 @@ class _InsSeg(torch.autograd.Function):
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
             da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
         # dconv1: per-point part against out2, per-crop part against g
-        dz, dgam, dbet = bns[5].backward(zs[5], da=da)
+        dz, dgam, dbet, dgb = bns[5].backward(zs[5], da=da, sum_seg=N)   # dgb (B,512): dz summed over each crop's points
         Wd1 = Ws[5]
         dWa = _wgrad(dz, zs[1], 512, 64, bns[1].act)
-        dgb = _segsum(dz, N, g.shape[0])                                # (B,512)
+        if dgb is None:
+            dgb = _segsum(dz, N, g.shape[0])
         dW1 = torch.cat([dWa, dgb.t() @ g], 1)
         grads[20] = dW1.reshape(shapes[20])
         grads[21] = zero[21]

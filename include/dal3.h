@@ -374,6 +374,14 @@ int dal3_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, const flo
                         const int32_t* arg, int64_t seg, const float* scale, const float* shift, const float* mu,
                         const float* rstd, const float* k1, const float* k2, const float* k3, float* dz, int64_t lddz,
                         dal3_stream stream);
+/* dal3_tr_bnbwd_apply (dense da) that also returns the column sums of dz over every segment of sum_seg rows — seg_sums
+ * (M / sum_seg, C) fp32, float64 inside, a fixed order — in the same pass: the per-crop gradient of dconv1's per-crop
+ * term. C % 64 == 0, sum_seg % 128 == 0, M % sum_seg == 0. */
+size_t dal3_tr_bnbwd_apply_segsum_workspace_bytes(int64_t M, int C);
+int dal3_tr_bnbwd_apply_segsum(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda,
+                               const float* scale, const float* shift, const float* mu, const float* rstd, const float* k1,
+                               const float* k2, const float* k3, float* dz, int64_t lddz, int64_t sum_seg, float* seg_sums,
+                               void* workspace, size_t workspace_bytes, dal3_stream stream);
 size_t dal3_tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in);
 int dal3_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale, const float* shift,
                   int relu_in, int64_t M, int c_out, int c_in, void* workspace, size_t workspace_bytes, float* dW,

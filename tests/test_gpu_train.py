@@ -674,3 +674,25 @@ def test_pooled_layer_float64_algebra_kernels_match_the_stock_expressions(C, K, 
     assert lib.dal3_tr_pool_gv(hip.ptr(coef), hip.ptr(W), K, hip.ptr(b), C, K, hip.ptr(G), hip.ptr(v), hip.ptr(gws), 16,
                                hip.stream()) != 0
 
+
+@pytest.mark.parametrize("B,N,C", [(8, 4096, 512), (3, 256, 64), (2, 128, 128)])
+def test_bn_backward_with_segment_sums_equals_the_two_pass_route(B, N, C):
+    """dal3_tr_bnbwd_apply_segsum: the same dz bits as dal3_tr_bnbwd_apply, and per-crop column sums equal to
+    dal3_tr_segsum's over that dz up to the order of the float64 additions"""
+    M = B * N
+    gen = torch.Generator(device="cuda").manual_seed(B * N + C)
+    z = torch.randn((M, C), device="cuda", generator=gen)
+    da = torch.randn((M, C), device="cuda", generator=gen)
+    gamma, beta = torch.rand(C, device="cuda", generator=gen) + 0.5, torch.randn(C, device="cuda", generator=gen) * 0.1
+    bn = train._BN(z, gamma, beta, None, None)
+    dz0, dgam0, dbet0 = bn.backward(z, da=da)
+    dz1, dgam1, dbet1, sums = bn.backward(z, da=da, sum_seg=N)
+    assert sums is not None and sums.shape == (B, C)
+    assert torch.equal(dz0, dz1) and torch.equal(dgam0, dgam1) and torch.equal(dbet0, dbet1)
+    ref = train._segsum(dz0, N, B)
+    want = dz0.double().view(B, N, C).sum(1)
+    scale = float(dz0.abs().sum(0).max())                                 # (the sums cancel: compare on the scale of what is added)
+    assert float((sums.double() - want).abs().max()) <= 1e-6 * scale
+    assert float((sums - ref).abs().max()) <= 1e-6 * scale
+    assert bn.backward(z[: M - 32], da=da[: M - 32], sum_seg=N)[3] is None    # ragged: left to the separate pass
+
