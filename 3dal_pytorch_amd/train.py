@@ -40,6 +40,19 @@ def _ws(nbytes, dev):
     return buf
 
 
+def _take_saved(ctx):
+    """the forward's buffers, handed over to this backward call: the ctx attribute is cleared, so a step's activations are
+    released when its backward returns — like torch's own saved tensors — and not when the caller's `loss` / output dict
+    go away, which in the usual loop is AFTER the next forward has allocated its own (2.5 GB held at DynamicModel's batch).
+    A second backward over the same graph (retain_graph=True) is therefore not available on this path."""
+    saved = ctx.saved
+    if saved is None:
+        raise RuntimeError("3dal_pytorch_amd.train: backward through the HIP training path a second time (its buffers are "
+                           "released by the first; use model.train_backend = 'torch' if you need retain_graph)")
+    ctx.saved = None
+    return saved
+
+
 def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False, out=None, accumulate=False):
     """z (M,c_out) (+)= act(a) @ Wop^T + bias through dal3_tr_linear"""
     M = a.shape[0]
@@ -395,12 +408,17 @@ class _PointStack(torch.autograd.Function):
         zarg = _gather_at(zs[3], arg, N)
         zs[3] = None                                          # the pooled layer's output is not needed again
         biases = [params[4 * k + 1].detach().contiguous() for k in range(4)]
-        ctx.saved = (a0, Ws, bns, zs, arg, N, [tuple(p.shape) for p in params], zarg, g, biases)
+        # g is the OUTPUT: kept through save_for_backward. As a plain attribute it closes a reference cycle (g -> its
+        # grad_fn -> ctx -> g) that only Python's cyclic collector breaks, and until it runs every step's activations
+        # stay allocated: a DynamicModel run held 4-9 GB of dead steps and peaked at 13 GB instead of 8.
+        ctx.save_for_backward(g)
+        ctx.saved = (a0, Ws, bns, zs, arg, N, [tuple(p.shape) for p in params], zarg, biases)
         return g
 
     @staticmethod
     def backward(ctx, dg):
-        a0, Ws, bns, zs, arg, N, shapes, zarg, g, biases = ctx.saved
+        a0, Ws, bns, zs, arg, N, shapes, zarg, biases = _take_saved(ctx)
+        (g,) = ctx.saved_tensors
         grads = [None] * 16
         zero = _zero_grads(shapes, [1, 5, 9, 13], a0.device)
         da = None
@@ -501,7 +519,7 @@ class _InsSeg(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
-        a0, Ws, bns, zs, g, arg, a4, drop, W5, N, shapes, zarg, b_conv5, conv5_cache = ctx.saved
+        a0, Ws, bns, zs, g, arg, a4, drop, W5, N, shapes, zarg, b_conv5, conv5_cache = _take_saved(ctx)
         Mp = a0.shape[0]
         M = dlogits.shape[0] * dlogits.shape[1]
         dev = a0.device
@@ -598,7 +616,7 @@ class _FcTail(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        a_in, Ws, bns, zs, last, n_bn, shapes = ctx.saved
+        a_in, Ws, bns, zs, last, n_bn, shapes = _take_saved(ctx)
         grads = [None] * len(shapes)
         dev = dout.device
         B, Bp = dout.shape[0], a_in.shape[0]

@@ -696,3 +696,45 @@ def test_bn_backward_with_segment_sums_equals_the_two_pass_route(B, N, C):
     assert float((sums - ref).abs().max()) <= 1e-6 * scale
     assert bn.backward(z[: M - 32], da=da[: M - 32], sum_seg=N)[3] is None    # ragged: left to the separate pass
 
+
+@pytest.mark.parametrize("kind", ["static_one", "dynamic"])
+def test_a_training_step_leaves_no_buffers_behind_without_the_garbage_collector(kind):
+    """a step's activations must be released by its own backward. Two ways they were not: the point stack kept its OUTPUT
+    as a plain ctx attribute (a reference cycle g -> grad_fn -> ctx -> g that only Python's cyclic collector breaks:
+    4-9 GB of dead steps at DynamicModel's batch, 13 GB peak), and the ctx attributes outlived backward for as long as
+    the caller held the loss. With the collector off and the previous step's loss still referenced, the allocation after
+    every step must be the same."""
+    import gc
+    losses = importlib.import_module("3dal_pytorch_amd.losses")
+    B = 8
+    model = build_model(kind, synth.state_dict(kind, seed=24)).train()
+    model.train_backend, model.sampler = "hip", "device"
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    if kind == "dynamic":
+        p, bx, _, g = synth.dynamic_items(B, n_per_frame=256, seed=24)
+        args = (torch.from_numpy(p).cuda().transpose(2, 1), torch.from_numpy(bx).cuda().transpose(2, 1), torch.from_numpy(g).cuda())
+        crit, n = losses.DynamicModelLoss(), p.shape[1]
+    else:
+        p, i, g = synth.static_crops(B, 1024, seed=24)
+        args = (torch.from_numpy(p).cuda().transpose(2, 1), torch.from_numpy(i).cuda(), torch.from_numpy(g).cuda())
+        crit, n = losses.FrustumPointNetLossOneBoxEst(), 1024
+    labels = _labels_for(B, n, 25, "cuda")
+    gc.collect()
+    gc.disable()
+    try:
+        seen, loss = [], None
+        for _ in range(6):
+            o = model(*args)
+            loss = crit(o, *labels)["total_loss"]            # (the previous step's loss dies here, after this forward)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            del o
+            torch.cuda.synchronize()
+            seen.append(torch.cuda.memory_allocated())
+        assert max(seen[2:]) - min(seen[2:]) <= 1 << 20, seen    # (steps 0-1: Adam's state and the scratch buffer appear)
+        with pytest.raises(RuntimeError, match="a second time"):
+            loss.backward()
+    finally:
+        gc.enable()
+
