@@ -5,6 +5,10 @@ all_gather of per-rank results (det3d/torchie/trainer/utils.py:114-154); the hea
 single-GPU in the reference.
 
 No data-path collective exists besides that gather: every crop is independent in eval mode.
+
+Two transports. RCCL ("nccl"): the collective runs on the device buffers. gloo (a rehearsal of the multi-rank
+path where RCCL cannot run, e.g. two ranks sharing the one GPU of a box): gloo has no device all-gather, so the
+boxes are staged through pinned host memory — same sharding, same buffers, same overlap, real kernels.
 """
 import os
 
@@ -19,13 +23,21 @@ def shard_range(n_items, rank, world_size):
     return lo, min(lo + per, n_items)
 
 
+def _active(group=None):
+    return dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size(group) > 1 or os.environ.get("DAL3_FORCE_DIST") == "1")
+
+
+def host_staged(device, group=None):
+    """True when collectives on tensors of `device` must go through host memory (gloo + a GPU tensor)"""
+    return torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+
+
 def all_gather_boxes(local_boxes, n_items, group=None):
     """local_boxes (hi-lo, 7) of this rank's shard -> (n_items, 7) on every rank. The ragged tail
     is padded to ceil(n/world) rows so that one fixed-size all_gather_into_tensor moves it
     (a 14 KiB-per-rank message at B=4096, W=8: latency-bound, so one collective, not W)."""
-    if not dist.is_available() or not dist.is_initialized():
-        return local_boxes
-    if dist.get_world_size(group) == 1 and os.environ.get("DAL3_FORCE_DIST") != "1":
+    if not _active(group):
         return local_boxes                       # (DAL3_FORCE_DIST=1: run the collective even on one rank)
     world = dist.get_world_size(group)
     per = (n_items + world - 1) // world
@@ -35,6 +47,11 @@ def all_gather_boxes(local_boxes, n_items, group=None):
     else:
         send = local_boxes.new_zeros((per, width))
         send[: local_boxes.shape[0]] = local_boxes
+    if host_staged(local_boxes.device, group):
+        send_h = send.cpu()                      # synchronises with the stream that produced the boxes
+        out_h = send_h.new_empty((world * per, width))
+        dist.all_gather_into_tensor(out_h, send_h, group=group)
+        return out_h[:n_items].to(local_boxes.device)
     out = local_boxes.new_empty((world * per, width))
     dist.all_gather_into_tensor(out, send, group=group)
     return out[:n_items]
@@ -52,20 +69,28 @@ class BoxGatherer:
             done = g.collect(keep=1)              # (n_items,7) boxes of the PREVIOUS batch, or None
         last = g.collect(keep=0)
 
-    Without an initialised process group it degenerates to passing the local boxes through."""
+    LIFETIME of what collect() returns: by default a fresh tensor (a 28-byte-per-box device copy) that the caller
+    may keep. With copy=False it is a VIEW of this object's receive buffer of that slot, overwritten by the
+    all-gather submitted `slots` batches later (with the loop above and slots = 2: valid until the second submit()
+    after the collect) — for callers that consume the boxes at once and want no extra launch.
+
+    Without an initialised process group it degenerates to passing the local boxes through (no copy either way:
+    the tensor is the caller's own)."""
 
     def __init__(self, n_items, device, width=7, group=None, slots=2):
         self.n_items, self.width, self.group = n_items, width, group
-        self.active = dist.is_available() and dist.is_initialized() and (
-            dist.get_world_size(group) > 1 or os.environ.get("DAL3_FORCE_DIST") == "1")
+        self.active = _active(group)
         self.world = dist.get_world_size(group) if self.active else 1
         self.per = (n_items + self.world - 1) // self.world
         self.slots = slots
-        self.send = [torch.zeros((self.per, width), dtype=torch.float32, device=device) for _ in range(slots)] \
-            if self.active else None
-        self.recv = [torch.empty((self.world * self.per, width), dtype=torch.float32, device=device)
-                     for _ in range(slots)] if self.active else None
-        self.pending = []                        # [(slot | local boxes, work)] oldest first
+        self.staged = self.active and host_staged(device, group)
+        mk = dict(dtype=torch.float32, device=device)
+        self.send = [torch.zeros((self.per, width), **mk) for _ in range(slots)] if self.active else None
+        self.recv = [torch.empty((self.world * self.per, width), **mk) for _ in range(slots)] if self.active else None
+        if self.staged:
+            self.send_h = [torch.zeros((self.per, width), dtype=torch.float32).pin_memory() for _ in range(slots)]
+            self.recv_h = [torch.empty((self.world * self.per, width), dtype=torch.float32).pin_memory() for _ in range(slots)]
+        self.pending = []                        # [(slot | local boxes, work | event)] oldest first
         self.turn = 0
 
     def submit(self, local_boxes):
@@ -76,19 +101,31 @@ class BoxGatherer:
             return
         slot = self.turn
         self.turn = (self.turn + 1) % self.slots
+        if self.staged:                          # device -> pinned host, asynchronous; the collective waits for it in collect()
+            self.send_h[slot][: local_boxes.shape[0]].copy_(local_boxes, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.pending.append((slot, ev))
+            return
         self.send[slot][: local_boxes.shape[0]].copy_(local_boxes)
         work = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
         self.pending.append((slot, work))
 
-    def collect(self, keep=0):
+    def collect(self, keep=0, copy=True):
         """Result of the oldest outstanding batch once more than `keep` are in flight, else None."""
         if len(self.pending) <= keep:
             return None
         slot, work = self.pending.pop(0)
         if work is None:
             return slot[: self.n_items]
-        work.wait()                              # orders the current stream behind the collective; no host sync
-        return self.recv[slot][: self.n_items]
+        if self.staged:
+            work.synchronize()                   # that batch's boxes are in host memory (later batches keep the GPU busy)
+            dist.all_gather_into_tensor(self.recv_h[slot], self.send_h[slot], group=self.group)
+            self.recv[slot].copy_(self.recv_h[slot], non_blocking=True)
+        else:
+            work.wait()                          # orders the current stream behind the collective; no host sync
+        out = self.recv[slot][: self.n_items]
+        return out.clone() if copy else out
 
 
 def world_census(device, group=None):
@@ -96,10 +133,37 @@ def world_census(device, group=None):
     all-reduce (= the number of ranks that really took part)."""
     if not (dist.is_available() and dist.is_initialized()):
         return {"backend": None, "world_size": 1, "ranks_counted": 1}
-    one = torch.ones(1, dtype=torch.float32, device=device)
+    one = torch.ones(1, dtype=torch.float32, device="cpu" if host_staged(device, group) else device)
     dist.all_reduce(one, group=group)
     return {"backend": dist.get_backend(group), "world_size": dist.get_world_size(group),
             "ranks_counted": int(round(float(one.item())))}
+
+
+def replicate_(tensor, src=0, group=None):
+    """Weights are REPLICATED: overwrite `tensor` on every rank with rank `src`'s values (a start-up broadcast, not
+    part of the data path). No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tensor
+    with torch.no_grad():
+        if host_staged(tensor.device, group):
+            t = tensor.detach().cpu()
+            dist.broadcast(t, src, group=group)
+            tensor.copy_(t)
+        else:
+            dist.broadcast(tensor.detach(), src, group=group)
+    return tensor
+
+
+def gather_scalars(value, device, group=None):
+    """one float per rank -> the list of all ranks' values, on every rank (per-rank step times of a bench line)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    world = dist.get_world_size(group)
+    dev = "cpu" if host_staged(device, group) else device
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    out = torch.empty(world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return [float(v) for v in out.cpu()]
 
 
 def refine_sharded(model, n_items, make_shard, group=None):

@@ -15,9 +15,11 @@ sharded inference: `--launcher pytorch` + LOCAL_RANK from torch.distributed.laun
 det3d/torchie/trainer/utils.py:114-154).
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
+import threading
 
 
 def under_launcher():
@@ -39,13 +41,46 @@ def visible_gpus():
     return torch.cuda.device_count()
 
 
-def spawn_ranks(script, argv, nproc, need_gpus=True, env=None, timeout=None):
+def _pump(stream, sink, keep):
+    """copy a child's pipe to `sink` line by line as it arrives (a hung job shows what it printed) and keep the text"""
+    for line in iter(stream.readline, ""):
+        keep.append(line)
+        if sink is not None:
+            sink.write(line)
+            sink.flush()
+    stream.close()
+
+
+def _kill_group(p):
+    """end the launcher AND its ranks: they share the session started for them. SIGTERM, then SIGKILL."""
+    for sig, wait in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+        try:
+            os.killpg(p.pid, sig)
+        except ProcessLookupError:
+            return
+        try:
+            p.wait(timeout=wait)
+            # the agent is gone; ranks it had no time to reap die with the group's next signal
+        except subprocess.TimeoutExpired:
+            continue
+    try:
+        os.killpg(p.pid, signal.SIGKILL)
+    except ProcessLookupError:
+        pass
+
+
+def spawn_ranks(script, argv, nproc, need_gpus=True, env=None, timeout=None, share_gpu=False):
     """Start `nproc` ranks of `script argv...` and wait. Returns (exit code, stdout of the job).
-    stderr of the ranks goes straight to this process's stderr. A rank that fails makes
-    torch.distributed.run tear the others down and return non-zero; that code is passed on."""
+    stderr of the ranks is passed through to this process's stderr as it is written. A rank that fails makes
+    torch.distributed.run tear the others down and return non-zero; that code is passed on. The job runs in a
+    session of its own: on `timeout` (exit code 124) or KeyboardInterrupt the WHOLE process group is ended — killing
+    only the launcher would orphan the ranks with the GPUs and the rendezvous port in their hands. The rendezvous
+    port is picked free and the launch retried when another job took it in between (free_port closes its socket
+    before torch.distributed.run binds it).
+    share_gpu: the ranks may share devices (rank -> device LOCAL_RANK % device_count; a rehearsal on a 1-GPU box)."""
     if need_gpus:
         have = visible_gpus()
-        if have < nproc:
+        if have < (1 if share_gpu else nproc):
             sys.stderr.write(f"{os.path.basename(script)}: needs {nproc} GPUs, this machine shows {have}\n")
             return 2, ""
     e = dict(os.environ if env is None else env)
@@ -53,10 +88,33 @@ def spawn_ranks(script, argv, nproc, need_gpus=True, env=None, timeout=None):
     e.setdefault("OMP_NUM_THREADS", "4")                     # torch.distributed.run would set 1 and warn
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         e.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=e, text=True, timeout=timeout)
-    return p.returncode, p.stdout
+    rc, out = 1, []
+    for attempt in range(3):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, text=True, bufsize=1,
+                             start_new_session=True)
+        out, err = [], []
+        pumps = [threading.Thread(target=_pump, args=(p.stdout, None, out), daemon=True),
+                 threading.Thread(target=_pump, args=(p.stderr, sys.stderr, err), daemon=True)]
+        for t in pumps:
+            t.start()
+        try:
+            rc = p.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            sys.stderr.write(f"{os.path.basename(script)}: {nproc} ranks still running after {timeout} s, ending them\n")
+            _kill_group(p)
+            rc = 124
+        except KeyboardInterrupt:
+            _kill_group(p)
+            raise
+        for t in pumps:
+            t.join(timeout=5.0)
+        in_use = rc not in (0, 124) and any("address already in use" in ln.lower() or "EADDRINUSE" in ln for ln in err)
+        if not in_use:
+            break
+        sys.stderr.write(f"{os.path.basename(script)}: rendezvous port taken by another job, retrying ({attempt + 1}/3)\n")
+    return rc, "".join(out)
 
 
 def relay_json_line(stdout):

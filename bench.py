@@ -85,18 +85,41 @@ def recentre(model, fwd):
     model.invalidate_packed()
 
 
-def make_static(B, N, dev, first, precision="fp32"):
+def make_static(B, N, dev, first, precision="fp32", two=False):
     pts_np, init_np, gt_np = synth.static_crops(B, N, first=first)
-    model = sm.StaticModelOneBoxEst()
-    sd = synth.state_dict("static_one")
+    model = sm.StaticModelTwoBoxEst() if two else sm.StaticModelOneBoxEst()
+    sd = synth.state_dict("static_two" if two else "static_one")
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
     model = model.to(dev).eval()
     pts = torch.from_numpy(pts_np).to(dev).transpose(2, 1)          # the callers' layout (static_eval.py:265)
     init, gt = torch.from_numpy(init_np).to(dev), torch.from_numpy(gt_np).to(dev)
     recentre(model, lambda: model(pts, init, gt))
+    replicate_weights(model)
     model.item_offset = first
     model.precision = precision
     return model, (pts, init, gt), (pts_np, init_np, sd)
+
+
+def static_inputs(first, count, N, dev):
+    """refine() arguments for the global crops [first, first + count): what the rank that owns them holds"""
+    pts_np, init_np, gt_np = synth.static_crops(count, N, first=first)
+    return (torch.from_numpy(pts_np).to(dev).transpose(2, 1), torch.from_numpy(init_np).to(dev),
+            torch.from_numpy(gt_np).to(dev))
+
+
+def dynamic_inputs(first, count, n_per_frame, dev):
+    pts_np, box_np, init8_np, _ = synth.dynamic_items(count, n_per_frame=n_per_frame, first=first)
+    return (torch.from_numpy(pts_np).to(dev).transpose(2, 1), torch.from_numpy(box_np).to(dev).transpose(2, 1),
+            torch.from_numpy(init8_np).to(dev))
+
+
+def replicate_weights(model):
+    """Weights are replicated over the ranks. synth's weights are a function of the seed, identical
+    everywhere; the one rank-dependent value is the segmentation bias `recentre` shifts by the mean margin of the
+    rank's OWN crops — rank 0's is broadcast (start-up, outside every timed region), so that any rank can reproduce
+    any other rank's boxes bit for bit (gather_self_check)."""
+    dal3_dist.replicate_(model.ins_seg.dconv5.bias)
+    model.invalidate_packed()
 
 
 def make_dynamic(B, dev, first, precision="fp32", n_per_frame=1024):
@@ -108,6 +131,7 @@ def make_dynamic(B, dev, first, precision="fp32", n_per_frame=1024):
     box = torch.from_numpy(box_np).to(dev).transpose(2, 1)
     init8 = torch.from_numpy(init8_np).to(dev)
     recentre(model, lambda: model(pts, box, None))
+    replicate_weights(model)
     model.item_offset = first
     model.precision = precision
     return model, (pts, box, init8)
@@ -152,9 +176,14 @@ def kernel_table(model, inputs, static, B, N, iters):
         hip.check(lib.dal3_mask_compact_sample(hip.ptr(mask), x, B, N, c_in, M, hip.SAMPLER_DEVICE, None, model.seed,
                                                model.item_offset, hip.ptr(counts), hip.ptr(idx), hip.ptr(obj),
                                                hip.ptr(gws), gws.numel(), st()))
-    heads = [("box_est", "one", model.box_est, arch.STATIC_BOX_EST, obj.transpose(2, 1), M, counts)] if static else \
-            [("point_emb", "pe", model.point_emb, arch.POINT_EMB, obj.transpose(2, 1), M, counts),
-             ("box_emb", "be", model.box_emb, arch.BOX_EMB, inputs[1], inputs[1].shape[2], None)]
+    if static and getattr(model, "two_stage", False):       # (stage two runs on the re-centred copies of the same points)
+        heads = [("box_est_one", "one", model.box_est_one, arch.STATIC_BOX_EST, obj.transpose(2, 1), M, counts),
+                 ("box_est_two", "two", model.box_est_two, arch.STATIC_BOX_EST, obj.transpose(2, 1), M, counts)]
+    elif static:
+        heads = [("box_est", "one", model.box_est, arch.STATIC_BOX_EST, obj.transpose(2, 1), M, counts)]
+    else:
+        heads = [("point_emb", "pe", model.point_emb, arch.POINT_EMB, obj.transpose(2, 1), M, counts),
+                 ("box_emb", "be", model.box_emb, arch.BOX_EMB, inputs[1], inputs[1].shape[2], None)]
     enc(), fc(), dec(), samp()
     torch.cuda.synchronize()
     cnt = counts.cpu().numpy()
@@ -162,9 +191,13 @@ def kernel_table(model, inputs, static, B, N, iters):
 
     def row(name, t, alg_mac, exe_mac, note=None):
         tf = 2.0 * alg_mac / (t * 1e-3) / 1e12
+        tfe = 2.0 * exe_mac / (t * 1e-3) / 1e12
+        # frac_executed = what the silicon did; frac_algorithmic = the reference's work over the same time (above 1 where
+        # the kernel skips work the reference formulation does: the point head's duplicated object points)
         r = {"ms": round(t, 4), "algorithmic_gflop": round(2.0 * alg_mac / 1e9, 2),
-             "executed_gflop": round(2.0 * exe_mac / 1e9, 2), "tflops": round(tf, 2), "frac": round(tf / peak, 4),
-             "tflops_executed": round(2.0 * exe_mac / (t * 1e-3) / 1e12, 2)}
+             "executed_gflop": round(2.0 * exe_mac / 1e9, 2), "tflops_executed": round(tfe, 2),
+             "frac_executed": round(tfe / peak, 4), "tflops_algorithmic": round(tf, 2),
+             "frac_algorithmic": round(tf / peak, 4)}
         if note:
             r["note"] = note
         out[name] = r
@@ -195,6 +228,11 @@ def kernel_table(model, inputs, static, B, N, iters):
 
 
 def maxpool_roofline(dev, iters):
+    """The standalone N-axis max-pool (the HBM-roofline kernel) timed two ways. `achieved` is the PER-KERNEL rate: each
+    launch between two device fences, HIP events around that one launch — the duration rocprofv3's kernel trace
+    reports (profiles/*_kernel_stats_maxpool.csv). `back_to_back` is the rate of `iters` launches queued behind each
+    other: a launch's first waves start while its predecessor's last waves drain, so the per-launch time reads ~6 %
+    under the kernel's own duration — a pipelined rate, not a kernel duration."""
     rows, n = 4096 * 1024, 1024
     try:
         x = torch.empty((rows, n), device=dev)
@@ -204,13 +242,33 @@ def maxpool_roofline(dev, iters):
     x.normal_()
     out = torch.empty(rows, device=dev)
     lib = hip.lib()
-    t = events_ms(lambda: hip.check(lib.dal3_maxpool_n(hip.ptr(x), rows, n, hip.ptr(out), hip.stream())), iters)
+
+    def run():
+        hip.check(lib.dal3_maxpool_n(hip.ptr(x), rows, n, hip.ptr(out), hip.stream()))
+    t_b2b = events_ms(run, iters)
+    single = []
+    for _ in range(max(iters, 5)):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        run()
+        b.record()
+        b.synchronize()
+        single.append(a.elapsed_time(b))
+    single.sort()
+    t = single[len(single) // 2]
     nbytes = rows * n * 4 + rows * 4
     gbs = nbytes / (t * 1e-3) / 1e9
+    gbs_b2b = nbytes / (t_b2b * 1e-3) / 1e9
     ok = bool(torch.equal(out[:4096], x[:4096].max(1)[0]))
     del x
     return {"kernel": "maxpool_rows_kernel", "shape": [rows // 1024, 1024, n], "bound": "hbm", "ms": round(t, 4),
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "timing": "median of single launches, each between two device fences (= the kernel's own duration)",
+            "ms_min": round(single[0], 4),
+            "back_to_back": {"ms_per_launch": round(t_b2b, 4), "achieved": round(gbs_b2b, 1),
+                             "frac": round(gbs_b2b / HBM_PEAK_GBS, 4),
+                             "note": f"{iters} launches queued behind each other: consecutive launches overlap at their ends"},
             "algorithmic_bytes": nbytes, "exact": ok}
 
 
@@ -278,7 +336,7 @@ def torch_gpu_baseline(model, inputs, sample=256, iters=3):
                       f"loop, {iters} x (B={pts.shape[0]}, N={pts.shape[2]}) fp32 on the same GPU"}
 
 
-def committed_profile(kernel, precision, B, N):
+def committed_profile(kernel, precision, B, N, tag=""):
     """HBM bytes per launch and PMC ratios from the COMMITTED rocprofv3 passes (profiles/*.json, written by
     tools/prof_summary.py on an earlier run of this very command) — only when that profile was taken at this
     precision and shape; always labelled with its file, never presented as measured in this run."""
@@ -292,20 +350,64 @@ def committed_profile(kernel, precision, B, N):
             out["traffic_source"] = {"file": "profiles/traffic.json", "taken": t.get("_taken", "round 1"),
                                      "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
                                             "FETCH_SIZE x 2 per MI355X_MICROARCH.md, per launch; not measured in this run"}
-    pfile = os.path.join(ROOT, "profiles", "r01_pmc.json")
-    if precision == "fp32" and (B, N) == (4096, 1024) and os.path.exists(pfile):
-        d = json.load(open(pfile)).get(kernel, {})
+    import glob
+    # tag "": the passes of the default command (fp32 and bf16 at 4096 x 1024); "_c3" / "_c5": passes of --config C3 / C5
+    pfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc{tag}.json")))
+    pshape = (t if os.path.exists(tfile) else {}).get("_shape", {"precisions": ["fp32"], "B": 4096, "N": 1024})
+    if pfiles and (tag or (precision in pshape.get("precisions", []) and (pshape.get("B"), pshape.get("N")) == (B, N))):
+        pfile = pfiles[-1]                                          # the newest round's passes (tools/profile_round.sh)
+        d = json.load(open(pfile)).get(kernel.split("[")[0], {})
         if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
             cyc = d["GRBM_GUI_ACTIVE"] / 8.0                        # the counter sums the 8 XCDs
-            out["pmc"] = {"source": "profiles/r01_pmc.json (rocprofv3 --pmc, separate passes, round 1; not measured in this run)",
+            out["pmc"] = {"source": f"profiles/{os.path.basename(pfile)} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
+                                    "GRBM_GUI_ACTIVE in a pass of its own; an earlier run of this command, not this run)",
                           "mfma_busy": round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), 4),
                           "clock_ghz": round(cyc / d["avg_ns_under_GRBM_GUI_ACTIVE"], 3)}
     return out
 
 
+def roofline_of(kr, peak, precision, B, N, tag=""):
+    """the `roofline` object for the dominant MFMA kernel of a kernel table: `achieved` = ALGORITHMIC FLOP per launch
+     / the launch's average duration measured live (HIP events on the launch stream); the executed
+    rate beside it; HBM traffic and PMC ratios from the committed rocprofv3 passes when they were taken at this shape"""
+    dom = max((k for k in kr if "frac_algorithmic" in kr[k]), key=lambda k: kr[k]["ms"])
+    prof = committed_profile(dom, precision, B, N, tag)
+    r = {"kernel": dom, "bound": "mfma", "achieved": kr[dom]["tflops_algorithmic"], "peak": peak, "unit": "TFLOP/s",
+         "frac": kr[dom]["frac_algorithmic"], "traffic": prof["traffic"], "ms_per_launch": kr[dom]["ms"],
+         "algorithmic_gflop_per_launch": kr[dom]["algorithmic_gflop"],
+         "executed_gflop_per_launch": kr[dom]["executed_gflop"], "frac_executed": kr[dom]["frac_executed"],
+         "pmc": prof["pmc"]}
+    if "traffic_source" in prof:
+        r["traffic_source"] = prof["traffic_source"]
+    return r
+
+
+def executed_gflop_per_step(kr, static, B):
+    """every kernel's executed GFLOP + the per-item FC tails (which have no row of their own)"""
+    return sum(kr[k]["executed_gflop"] for k in kr) + 2.0 * B * sum(
+        ci * co for t in ([arch.STATIC_BOX_EST] if static else [arch.POINT_EMB, arch.BOX_EMB, arch.DYNAMIC_BOX_EST])
+        for _, _, ci, co in t["fcs"]) / 1e9
+
+
 # ---------------------------------------------------------------------------------------- workloads
+class Part:
+    """one head of a workload on this rank: `run()` -> this rank's (n_local,7) boxes; `shard(rank)` -> (lo, n) of any
+    rank's contiguous range of the head's n_total items; `inputs_for(first, count)` -> refine() arguments of global
+    items [first, first + count) (what gather_self_check recomputes a peer's rows from)"""
+
+    def __init__(self, name, model, inputs, n_local, n_total, shard, inputs_for):
+        self.name, self.model, self.inputs = name, model, inputs
+        self.n_local, self.n_total, self.shard, self.inputs_for = n_local, n_total, shard, inputs_for
+
+    def run(self):
+        return self.model.refine(*self.inputs)[: self.n_local]
+
+    def __iter__(self):                                    # (fn, n_local, n_total), the shape older call sites unpack
+        return iter((self.run, self.n_local, self.n_total))
+
+
 class Workload:
-    """what one rank does per step: `parts` = [(refine closure -> local (n,7) boxes, n_local, n_total)], one per head"""
+    """what one rank does per step: `parts` = one Part per head"""
 
     def __init__(self):
         self.parts = []
@@ -325,8 +427,12 @@ def build_workload(args, dev, rank, world):
         d_lo, d_hi = dal3_dist.shard_range(n_dyn, rank, world)
         smodel, sin, _ = make_static(max(s_hi - s_lo, 1), 4096, dev, s_lo, prec)
         dmodel, din = make_dynamic(max(d_hi - d_lo, 1), dev, d_lo, prec)
-        wl.parts = [(lambda: smodel.refine(*sin)[:s_hi - s_lo], s_hi - s_lo, n_static),
-                    (lambda: dmodel.refine(*din)[:d_hi - d_lo], d_hi - d_lo, n_dyn)]
+        wl.parts = [Part("static", smodel, sin, s_hi - s_lo, n_static,
+                         lambda r: (lambda lo, hi: (lo, hi - lo))(*dal3_dist.shard_range(n_static, r, world)),
+                         lambda first, count: static_inputs(first, count, 4096, dev)),
+                    Part("dynamic", dmodel, din, d_hi - d_lo, n_dyn,
+                         lambda r: (lambda lo, hi: (lo, hi - lo))(*dal3_dist.shard_range(n_dyn, r, world)),
+                         lambda first, count: dynamic_inputs(first, count, 1024, dev))]
         wl.model, wl.inputs, wl.host, wl.static = smodel, None, None, False
         wl.B, wl.N = (s_hi - s_lo) + (d_hi - d_lo), 0
         wl.n_total = n_static + n_dyn
@@ -339,10 +445,11 @@ def build_workload(args, dev, rank, world):
     B = args.batch or (4096 if static else 1024)
     N = args.points if static else 5 * args.points
     first = rank * B                                            # weak scaling: B items per GPU
+    two = static and getattr(args, "two_stage", False)
     if static:
-        model, inputs, host = make_static(B, N, dev, first, prec)
-        flop_item = arch.static_one_flop(N)
-        desc = f"StaticModelOneBoxEst forward+decode, {B} crops x {N} pts per GPU, {prec}" + \
+        model, inputs, host = make_static(B, N, dev, first, prec, two=two)
+        flop_item = arch.static_two_flop(N) if two else arch.static_one_flop(N)
+        desc = f"StaticModel{'Two' if two else 'One'}BoxEst forward+decode, {B} crops x {N} pts per GPU, {prec}" + \
             (" (BASELINE.json configs[1])" if (B, N, prec) == (4096, 1024, "fp32") else
              " (BASELINE.json configs[4] shape)" if (N, prec) == (4096, "fp16") else "")
     else:
@@ -351,7 +458,9 @@ def build_workload(args, dev, rank, world):
         flop_item = arch.dynamic_flop(N)
         desc = (f"DynamicModel forward+decode, {B} items x {N} pts + 101 boxes per GPU, {prec} arithmetic"
                 + (" (BASELINE.json configs[2])" if (B, N, prec) == (1024, 5120, "bf16") else ""))
-    wl.parts = [(lambda: model.refine(*inputs), B, B * world)]
+    wl.parts = [Part("static" if static else "dynamic", model, inputs, B, B * world, lambda r: (r * B, B),
+                     (lambda first, count: static_inputs(first, count, N, dev)) if static else
+                     (lambda first, count: dynamic_inputs(first, count, args.points, dev)))]
     wl.model, wl.inputs, wl.host, wl.static = model, inputs, host, static
     wl.B, wl.N, wl.n_total, wl.flop_item, wl.scaling, wl.desc = B, N, B * world, flop_item, "weak", desc
     return wl
@@ -415,11 +524,45 @@ def time_steps(wl, dev, steps, warmup, use_dist, overlap=True):
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     boxes = torch.cat(last)
     assert boxes.shape == (wl.n_total, 7) and bool(torch.isfinite(boxes).all())
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    wl.last_boxes = last                                    # per head: the (n_total,7) boxes of the last timed step
+    wl.rank_seconds = [dt]
+    if use_dist:                                            # the job's time is the slowest rank's; every rank's is kept
+        wl.rank_seconds = dal3_dist.gather_scalars(dt, dev)
+        dt = max(wl.rank_seconds)
     return dt, per_step, boxes
+
+
+def gather_self_check(wl, dev, rank, world, rows=64):
+    """SURVEY.md 8(e) determinism check, inside the bench run: rank 0 recomputes the first `rows` items of OTHER
+    ranks' shards (rank 1 and the last rank) from scratch — the peer's synthetic inputs regenerated from their
+    global indices, the replicated weights, the sampler keyed with the peer's item_offset — and compares them with
+    the rows the all-gather delivered, bit for bit. One entry per head and peer; `equal` is their conjunction."""
+    if world < 2:
+        return None
+    out = {"rows_per_peer": rows, "checks": []}
+    if rank == 0:
+        for part, gathered in zip(wl.parts, wl.last_boxes):
+            for peer in sorted({1, world - 1}):
+                lo, n = part.shard(peer)
+                n = min(n, rows)
+                if n <= 0:
+                    out["checks"].append({"head": part.name, "peer": peer, "rows": 0, "equal": None})
+                    continue
+                saved = part.model.item_offset
+                part.model.item_offset = lo
+                try:
+                    mine = part.model.refine(*part.inputs_for(lo, n))[:n]
+                finally:
+                    part.model.item_offset = saved
+                theirs = gathered[lo:lo + n]
+                eq = bool(torch.equal(mine, theirs))
+                c = {"head": part.name, "peer": peer, "first_item": lo, "rows": n, "equal": eq}
+                if not eq:
+                    c["max_abs_diff"] = float((mine - theirs).abs().max())
+                out["checks"].append(c)
+        done = [c["equal"] for c in out["checks"] if c["equal"] is not None]
+        out["equal"] = bool(done) and all(done)
+    return out
 
 
 def gather_latency(wl, dev, iters=50):
@@ -433,25 +576,29 @@ def gather_latency(wl, dev, iters=50):
 
 def other_config(name, dev, steps):
     """one of BASELINE.json's other configurations on this GPU: whole-path rate (same step definition)"""
-    ns = argparse.Namespace(config=name, head="static", precision="fp32", batch=0, points=1024)
+    ns = argparse.Namespace(config=name, head="static", precision="fp32", batch=0, points=1024, two_stage=False)
     apply_config(ns)
     wl = build_workload(ns, dev, 0, 1)
     dt, per_step, _ = time_steps(wl, dev, steps, 5, False)
     value = wl.n_total * steps / dt
     peak = MFMA_PEAK_TFLOPS[ns.precision]
-    r = {"workload": wl.desc, "value": round(value, 1), "unit": "items/s", "ms_per_step": round(dt / steps * 1e3, 3),
+    ms = dt / steps * 1e3
+    r = {"workload": wl.desc, "value": round(value, 1), "unit": "items/s", "ms_per_step": round(ms, 3),
          "ms_per_step_min": round(per_step[0], 3), "steps": steps, "dtype": DNAME[ns.precision],
          "algorithmic_gflop_per_item": round(wl.flop_item / 1e9, 4),
-         "whole_path_tflops": round(value * wl.flop_item / 1e12, 1),
-         "whole_path_mfma_frac": round(value * wl.flop_item / 1e12 / peak, 4)}
+         "whole_path_tflops_algorithmic": round(value * wl.flop_item / 1e12, 1),
+         "whole_path_mfma_frac_algorithmic": round(value * wl.flop_item / 1e12 / peak, 4)}
     if name != "C4":
         kr, _ = kernel_table(wl.model, wl.inputs, wl.static, wl.B, wl.N, iters=max(3, min(steps, 5)))
-        dom = max((k for k in kr if "frac" in kr[k]), key=lambda k: kr[k]["ms"])
-        r["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kr[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": kr[dom]["frac"], "ms_per_launch": kr[dom]["ms"]}
+        r["whole_path_mfma_frac_executed"] = round(executed_gflop_per_step(kr, wl.static, wl.B) / ms / peak, 4)
+        r["roofline"] = roofline_of(kr, peak, ns.precision, wl.B, wl.N, tag="_" + name.lower() if name in ("C3", "C5") else "")
     del wl
     torch.cuda.empty_cache()
     return r
+
+
+def two_stage(args):
+    return bool(getattr(args, "two_stage", False))
 
 
 def apply_config(args):
@@ -461,34 +608,60 @@ def apply_config(args):
         args.head, args.precision, args.batch, args.points = "static", "fp16", 2048, 4096
     elif args.config == "C2":
         args.head, args.precision, args.batch, args.points = "static", "fp32", 4096, 1024
+    elif args.config == "TwoBoxEst":                       # the reference's second static model class, C2's shape
+        args.head, args.precision, args.batch, args.points, args.two_stage = "static", "fp32", 4096, 1024, True
+    elif args.config == "Dynamic_fp32":                    # the dynamic head in the reference's own arithmetic, C3's shape
+        args.head, args.precision, args.batch, args.points = "dynamic", "fp32", 1024, 1024
 
 
 def plumbing_only(args, rank, world):
     """No GPU work: every rank makes the boxes a refine() of its shard would return (a function of the global item
     index), the launcher / process-group / gather path runs on DAL3_BENCH_BACKEND (gloo on CPU), and rank 0 prints a
-    line whose `value` is null. What tests/test_launch_cpu.py drives at world size 2."""
+    line whose `value` is null — with the fields a real N > 1 line carries (per-rank step times, the replicated
+    weight, the self-check of another rank's rows). What tests/test_launch_cpu.py drives at world size 2."""
     backend = os.environ.get("DAL3_BENCH_BACKEND", "gloo")
     torch.distributed.init_process_group(backend, rank=rank, world_size=world)
+    cpu = torch.device("cpu")
     n_total = 37
+
+    class _Stub:                                            # refine() stand-in: boxes = f(global item index, bias)
+        item_offset = 0
+        bias = torch.tensor([1.0 + rank])                  # rank-dependent until replicated
+
+        def refine(self, idx):
+            return idx[:, None] * 10 + torch.arange(7, dtype=torch.float32)[None] + self.bias
+    stub = _Stub()
+    dal3_dist.replicate_(stub.bias)
     lo, hi = dal3_dist.shard_range(n_total, rank, world)
-    local = (torch.arange(lo, hi, dtype=torch.float32)[:, None] * 10 + torch.arange(7, dtype=torch.float32)[None])
-    g = dal3_dist.BoxGatherer(n_total, torch.device("cpu"))
+    wl = Workload()
+    wl.parts = [Part("stub", stub, (torch.arange(lo, hi, dtype=torch.float32),), hi - lo, n_total,
+                     lambda r: (lambda a, b: (a, b - a))(*dal3_dist.shard_range(n_total, r, world)),
+                     lambda first, count: (torch.arange(first, first + count, dtype=torch.float32),))]
+    g = dal3_dist.BoxGatherer(n_total, cpu)
     got = None
+    t0 = time.perf_counter()
     for _ in range(3):
-        g.submit(local)
+        g.submit(wl.parts[0].run())
         r = g.collect(keep=1)
         got = r if r is not None else got
     got = g.collect(keep=0)
-    want = torch.arange(n_total, dtype=torch.float32)[:, None] * 10 + torch.arange(7, dtype=torch.float32)[None]
-    ok = bool(torch.equal(got, want)) and bool(torch.equal(dal3_dist.all_gather_boxes(local, n_total), want))
-    census = dal3_dist.world_census(torch.device("cpu"))
+    wl.last_boxes = [got]
+    rank_ms = [round(t * 1e3, 3) for t in dal3_dist.gather_scalars(time.perf_counter() - t0, cpu)]
+    want = torch.arange(n_total, dtype=torch.float32)[:, None] * 10 + torch.arange(7, dtype=torch.float32)[None] + 1.0
+    ok = bool(torch.equal(got, want)) and bool(torch.equal(dal3_dist.all_gather_boxes(wl.parts[0].run(), n_total), want))
+    check = gather_self_check(wl, cpu, rank, world, rows=5)
+    census = dal3_dist.world_census(cpu)
     if os.environ.get("DAL3_BENCH_FAIL_RANK") == str(rank):          # the launcher's failure path, for its test
         sys.exit(3)
+    if os.environ.get("DAL3_BENCH_HANG_RANK") == str(rank):          # a rank that never comes back, for the launcher's timeout
+        time.sleep(3600)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "object-crops/sec through static+dynamic refinement heads", "value": None,
-                          "plumbing_only": True, "n_gpus": world, "gathered_ok": ok, "rccl": census}), flush=True)
+                          "plumbing_only": True, "n_gpus": world, "gathered_ok": ok, "rccl": census,
+                          "ms_per_step_per_rank": rank_ms, "gather_equals_single_rank": check["equal"] if check else None,
+                          "gather_self_check": check}), flush=True)
     sys.exit(0 if ok else 4)
 
 
@@ -507,10 +680,12 @@ def main():
     ap.add_argument("--serial-gather", action="store_true", help="wait for each step's all-gather inside the step")
     ap.add_argument("--streams", type=int, default=1,
                     help="run consecutive steps on this many HIP streams (graph.StreamPipe): small batches, one GPU")
-    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5"],
+    ap.add_argument("--two-stage", action="store_true", help="static head: StaticModelTwoBoxEst instead of OneBoxEst")
+    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5", "TwoBoxEst", "Dynamic_fp32"],
                     help="BASELINE.json configs by name: C2 = the default (static, 4096 x 1024, fp32); C3 = dynamic head, "
                          "1024 items x 5 x 1024 pts, bf16; C4 = one segment (64 static crops x 4096 pts + 40 dynamic tracks), sharded "
-                         "over the GPUs (strong scaling); C5 = static, N=4096, 2048 crops per GPU, fp16 MFMA")
+                         "over the GPUs (strong scaling); C5 = static, N=4096, 2048 crops per GPU, fp16 MFMA; TwoBoxEst = StaticModelTwoBoxEst "
+                         "at C2's shape; Dynamic_fp32 = DynamicModel at C3's shape in fp32")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launcher + process group + gather only, no GPU work (CPU test of the N > 1 start-up path)")
     ap.add_argument("--cpu-sweep", type=int, nargs="+", default=None, metavar="THREADS",
@@ -524,8 +699,10 @@ def main():
         return
 
     # ---- N > 1 without a launcher: start the ranks as children; this process never touches the GPU
+    share_gpu = os.environ.get("DAL3_BENCH_SHARE_GPU") == "1"      # rehearsal: ranks share devices (1-GPU box)
     if args.gpus > 1 and not launch.under_launcher():
-        rc, out = launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, need_gpus=not args.plumbing_only)
+        rc, out = launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, need_gpus=not args.plumbing_only,
+                                     share_gpu=share_gpu)
         line = launch.relay_json_line(out)
         if line:
             print(line, flush=True)
@@ -541,8 +718,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         plumbing_only(args, rank, world)
     apply_config(args)
-    if torch.cuda.device_count() <= local:
-        sys.exit(f"bench.py: needs {max(args.gpus, local + 1)} GPUs, this machine shows {torch.cuda.device_count()}")
+    n_dev = torch.cuda.device_count()
+    if share_gpu and n_dev > 0:
+        local = local % n_dev
+    if n_dev <= local:
+        sys.exit(f"bench.py: needs {max(args.gpus, local + 1)} GPUs, this machine shows {n_dev}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # DAL3_FORCE_DIST=1 runs the RCCL path even with one rank (exercises init + all-gather on a 1-GPU box)
@@ -555,7 +735,14 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # "nccl" = RCCL over xGMI, the product transport. DAL3_BENCH_BACKEND=gloo: the rehearsal transport (boxes
+        # staged through pinned host memory, dist.BoxGatherer) for boxes where RCCL cannot connect the ranks, e.g. two
+        # ranks on ONE GPU with DAL3_BENCH_SHARE_GPU=1 — launcher, sharding, fences, overlap and self-check as in the real run.
+        backend = os.environ.get("DAL3_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     if args.only_maxpool:
         rec = {"maxpool": maxpool_roofline(dev, iters=args.steps)}
@@ -586,40 +773,43 @@ def main():
                                    + (", collected one step later (overlapped)" if not args.serial_gather else ", serial"))
                    if use_dist else "single GPU",
                    "algorithmic_gflop_per_item": round(wl.flop_item / 1e9, 4)},
-        "whole_path_tflops": round(value * wl.flop_item / 1e12, 2),
-        "whole_path_mfma_frac": round(value / world * wl.flop_item / 1e12 / peak, 4),
+        "whole_path_tflops_algorithmic": round(value * wl.flop_item / 1e12, 2),
+        "whole_path_mfma_frac_algorithmic": round(value / world * wl.flop_item / 1e12 / peak, 4),
     }
     if use_dist:
         census = dal3_dist.world_census(dev)
+        rank_ms = [round(t / args.steps * 1e3, 3) for t in wl.rank_seconds]
+        rec["ms_per_step_per_rank"] = rank_ms                   # each rank's own clock between the two fences
+        rec["ms_per_step_rank_min"], rec["ms_per_step_rank_max"] = min(rank_ms), max(rank_ms)
+        check = gather_self_check(wl, dev, rank, world)
+        rec["gather_equals_single_rank"] = check["equal"] if check and rank == 0 else None
+        rec["gather_self_check"] = check
         rec["rccl"] = dict(census, allgather_us=gather_latency(wl, dev),
                            message_bytes_per_rank=[((n_total + world - 1) // world) * 28 for _, _, n_total in wl.parts],
+                           transport="RCCL on the device buffers" if census["backend"] == "nccl" else
+                           f"{census['backend']} (rehearsal): boxes staged through pinned host memory",
+                           ranks_share_gpus=share_gpu,
                            rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()))
         rec["rccl_world_size"] = census["world_size"]
         if not args.no_extras:
             # the same steps with the gather waited for inside each step: what the overlap is worth
             dt2, _, _ = time_steps(wl, dev, args.steps, 1, use_dist, overlap=args.serial_gather)
             rec["rccl"]["ms_per_step_" + ("overlapped" if args.serial_gather else "serial_gather")] = round(dt2 / args.steps * 1e3, 3)
-    if rank == 0 and world == 1 and not args.no_extras and not mixed:
+    if rank == 0 and not args.no_extras and not mixed:
+        # per-kernel table and roofline: on rank 0 at every world size (the other ranks wait at the closing barrier)
         B, N, model, inputs, static = wl.B, wl.N, wl.model, wl.inputs, wl.static
         kr, mean_count = kernel_table(model, inputs, static, B, N, iters=max(3, min(args.steps, 10)))
-        mf = [k for k in kr if "frac" in kr[k]]
-        dom = max(mf, key=lambda k: kr[k]["ms"])
-        prof = committed_profile(dom, args.precision, B, N)
-        rec["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kr[dom]["tflops"], "peak": peak,
-                           "unit": "TFLOP/s", "frac": kr[dom]["frac"], "traffic": prof["traffic"],
-                           "ms_per_launch": kr[dom]["ms"], "algorithmic_gflop_per_launch": kr[dom]["algorithmic_gflop"],
-                           "executed_gflop_per_launch": kr[dom]["executed_gflop"], "pmc": prof["pmc"]}
-        if "traffic_source" in prof:
-            rec["roofline"]["traffic_source"] = prof["traffic_source"]
+        rec["roofline"] = roofline_of(kr, peak, args.precision, B, N,
+                                      tag="_" + args.config.lower() if args.config in ("C3", "C5") else "")
         rec["kernels"] = kr
         rec["mean_segmented_points_per_item"] = round(mean_count, 1)
-        exe = sum(kr[k]["executed_gflop"] for k in kr) + 2.0 * B * sum(
-            ci * co for t in ([arch.STATIC_BOX_EST] if static else [arch.POINT_EMB, arch.BOX_EMB, arch.DYNAMIC_BOX_EST])
-            for _, _, ci, co in t["fcs"]) / 1e9
+        exe = executed_gflop_per_step(kr, static, B)
         rec["executed_gflop_per_step"] = round(exe, 1)
         rec["algorithmic_gflop_per_step"] = round(B * wl.flop_item / 1e9, 1)
-        rec["whole_path_mfma_frac_executed"] = round(exe / ms_per_step / peak, 4)      # GFLOP/ms = TFLOP/s
-        if static and args.precision == "fp32":
+        # the headline whole-path fraction: what the silicon executed per rank-0 step over the MFMA peak
+        rec["whole_path_mfma_frac_executed"] = round(exe / (wl.rank_seconds[0] / args.steps * 1e3) / peak, 4)   # GFLOP/ms = TFLOP/s
+    if rank == 0 and world == 1 and not args.no_extras and not mixed:
+        if static and args.precision == "fp32" and not two_stage(args):
             # the same workload on the 16-bit MFMA path (BASELINE.json configs C3/C5 arithmetic): reported beside
             # the fp32 headline, never as `value`
             rec["lowprec"] = {}
@@ -628,23 +818,23 @@ def main():
                 d, _, _ = time_steps(wl, dev, args.steps, 5, False)
                 d /= args.steps
                 k2, _ = kernel_table(model, inputs, static, B, N, iters=max(3, min(args.steps, 10)))
-                d2 = max((k for k in k2 if "frac" in k2[k]), key=lambda k: k2[k]["ms"])
                 rec["lowprec"][prec] = {"value": round(B / d, 1), "unit": "object-crops/s", "ms_per_step": round(d * 1e3, 3),
-                                        "whole_path_tflops": round(B / d * wl.flop_item / 1e12, 1),
-                                        "roofline": {"kernel": d2, "bound": "mfma", "achieved": k2[d2]["tflops"],
-                                                     "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s",
-                                                     "frac": k2[d2]["frac"], "ms_per_launch": k2[d2]["ms"]},
+                                        "whole_path_tflops_algorithmic": round(B / d * wl.flop_item / 1e12, 1),
+                                        "whole_path_mfma_frac_executed": round(
+                                            executed_gflop_per_step(k2, static, B) / (d * 1e3) / MFMA_PEAK_TFLOPS[prec], 4),
+                                        "roofline": roofline_of(k2, MFMA_PEAK_TFLOPS[prec], prec, B, N),
                                         "kernels": k2}
             model.precision = args.precision
         rec["maxpool"] = maxpool_roofline(dev, iters=5)
-        if static and args.precision == "fp32" and (B, N) == (4096, 1024):
+        if static and args.precision == "fp32" and (B, N) == (4096, 1024) and not two_stage(args):
             rec["torch_gpu_baseline"] = torch_gpu_baseline(model, inputs)
             rec["cpu_baseline"] = cpu_baseline(wl.host)
             del wl, model, inputs
             torch.cuda.empty_cache()
-            # BASELINE.json's other configurations, driver-timed in the same run (the metric is "static+dynamic heads")
+            # BASELINE.json's other configurations and the reference's other two model classes in its own arithmetic,
+            # driver-timed in the same run (the metric is "static+dynamic heads")
             rec["configs"] = {"C2": "this line's `value`"}
-            for name, st in (("C3", 10), ("C5", 10), ("C4", 3)):
+            for name, st in (("C3", 10), ("C5", 10), ("TwoBoxEst", 5), ("Dynamic_fp32", 5), ("C4", 3)):
                 rec["configs"][name] = other_config(name, dev, st)
         elif static:
             rec["cpu_baseline"] = cpu_baseline(wl.host)

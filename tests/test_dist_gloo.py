@@ -104,9 +104,24 @@ def _gatherer_worker(rank, world, port, n_items, ret):
             g.submit(local)
             r = g.collect(keep=1)
             if r is not None:
-                got.append(r.clone())
-        got.append(g.collect(keep=0).clone())
+                got.append(r)                                   # kept WITHOUT a clone: collect() returns the caller's own copy
+        got.append(g.collect(keep=0))
         assert g.collect(keep=0) is None
+        # copy=False hands out a VIEW of the slot's receive buffer: the gather two submits later overwrites it (the
+        # lifetime the docstring states); the default copies survive (checked by the caller against every step)
+        g.submit(local)
+        view = g.collect(keep=0, copy=False)
+        before = view.clone()
+        g.submit(local + 1)
+        g.collect(keep=0)
+        g.submit(local + 2)
+        g.collect(keep=0)
+        assert not torch.equal(view, before) and view.data_ptr() in [r.data_ptr() for r in g.recv]
+        # replicated weights / per-rank scalars (what a bench line at N > 1 is built from)
+        w = torch.full((3,), float(rank + 1))
+        dal3_dist.replicate_(w)
+        assert torch.equal(w, torch.ones(3))
+        assert dal3_dist.gather_scalars(10.0 + rank, torch.device("cpu")) == [10.0 + r for r in range(world)]
         with pytest.raises(RuntimeError):
             for _ in range(3):
                 g.submit(local)

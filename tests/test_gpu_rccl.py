@@ -37,3 +37,45 @@ def test_one_rank_rccl_all_gather_returns_the_refined_boxes():
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
+
+
+def _rehearsal(extra_args, timeout=900):
+    """`bench.py --gpus 2` on the ONE GPU of the test box: both ranks on device 0 (DAL3_BENCH_SHARE_GPU=1), the boxes
+    gathered over gloo through pinned host memory (DAL3_BENCH_BACKEND=gloo; RCCL cannot connect two ranks that share a
+    device). Everything else is the real N > 1 run: the self-launch from a parent that never touches the GPU, device
+    selection, sharding by global item index, the real kernels, fences, the overlapped gather, rank 0's stdout relay."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DAL3_BENCH_SHARE_GPU="1", DAL3_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra_args, capture_output=True,
+                         text=True, env=env, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_rank_rehearsal_on_one_gpu_static_line_proves_its_gather():
+    """C2's head at a reduced batch: the gathered (2B,7) boxes hold rank 1's rows, and rank 0 — recomputing rank 1's
+    first 64 crops from their global indices with rank 1's sampler key — gets the same bits."""
+    rec = _rehearsal(["--steps", "3", "--warmup", "1", "--batch", "512"])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["rccl"]["backend"] == "gloo" and rec["rccl"]["world_size"] == 2 and rec["rccl"]["ranks_counted"] == 2
+    assert rec["rccl"]["ranks_share_gpus"] is True
+    assert len(rec["ms_per_step_per_rank"]) == 2 and rec["ms_per_step_rank_max"] >= rec["ms_per_step_rank_min"] > 0
+    assert rec["gather_equals_single_rank"] is True, rec["gather_self_check"]
+    (c,) = rec["gather_self_check"]["checks"]
+    assert (c["head"], c["peer"], c["first_item"], c["rows"]) == ("static", 1, 512, 64)
+    # rank 0's per-kernel table and roofline are part of the line at every world size
+    assert rec["roofline"]["kernel"].startswith("ins_seg_decode") and 0 < rec["roofline"]["frac"] < 1
+    assert rec["config"]["items_per_gpu"] == 512
+
+
+def test_two_rank_rehearsal_on_one_gpu_mixed_segment_checks_both_heads():
+    """C4 (one segment, static + dynamic heads, strong scaling): one all-gather per head, both self-checked"""
+    rec = _rehearsal(["--config", "C4", "--steps", "1", "--warmup", "1", "--no-extras"], timeout=1500)
+    assert rec["scaling"] == "strong" and rec["gather_equals_single_rank"] is True, rec["gather_self_check"]
+    heads = {(c["head"], c["peer"]): c for c in rec["gather_self_check"]["checks"]}
+    assert set(heads) == {("static", 1), ("dynamic", 1)}
+    assert heads[("static", 1)]["first_item"] == 32 and heads[("static", 1)]["rows"] == 32
+    assert heads[("dynamic", 1)]["rows"] == 64

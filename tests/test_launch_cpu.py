@@ -38,6 +38,11 @@ def test_bench_self_launches_two_ranks_and_relays_one_line():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["plumbing_only"] and rec["gathered_ok"]
     assert rec["rccl"] == {"backend": "gloo", "world_size": 2, "ranks_counted": 2}
+    # what a real N > 1 line carries: every rank's own step time, and rank 0's recomputation of rank 1's first rows
+    # (its inputs regenerated from their global indices, the replicated weight) equal to what the gather delivered
+    assert len(rec["ms_per_step_per_rank"]) == 2
+    assert rec["gather_equals_single_rank"] is True
+    assert rec["gather_self_check"]["checks"] == [{"head": "stub", "peer": 1, "first_item": 19, "rows": 5, "equal": True}]
 
 
 def test_a_failing_rank_fails_the_launcher():
@@ -59,3 +64,16 @@ def test_under_a_launcher_the_process_is_a_rank():
 def test_relay_picks_the_json_line():
     assert launch.relay_json_line("NCCL version 2.x\n{\"a\": 1}\ntrailing\n") == '{"a": 1}'
     assert launch.relay_json_line("nothing here\n") is None
+
+
+def test_launcher_timeout_ends_the_whole_process_group():
+    """a timeout that kills only torch.distributed.run orphans the ranks (GPUs and the rendezvous port stay
+    taken). spawn_ranks starts the job in its own session and ends the group: no rank survives, exit code 124."""
+    import time
+    env = _env(DAL3_BENCH_HANG_RANK="1")
+    t0 = time.time()
+    rc, out = launch.spawn_ranks(BENCH, ["--gpus", "2", "--plumbing-only"], 2, need_gpus=False, env=env, timeout=45)
+    assert rc == 124 and time.time() - t0 < 120
+    time.sleep(1.0)
+    left = subprocess.run(["pgrep", "-f", "bench.py --gpus 2 --plumbing-only"], capture_output=True, text=True).stdout.split()
+    assert left == [], f"ranks left behind: {left}"
