@@ -62,6 +62,7 @@ _i, _i64, _u64, _sz = C.c_int, C.c_int64, C.c_uint64, C.c_size_t
 SIGNATURES = {
     "dal3_version": (_i, []),
     "dal3_last_error": (C.c_char_p, []),
+    "dal3_mean_size": (C.POINTER(C.c_float), []),
     "dal3_pack_weights": (_i, [_i, C.POINTER(Layer), _i, _i, vp, C.POINTER(_sz), vp]),
     "dal3_ins_seg_workspace_bytes": (_sz, [_i]),
     "dal3_ins_seg_forward": (_i, [vp, _i, _i, BCN, _i, _i, vp, vp, vp, vp, _sz, vp]),
@@ -141,6 +142,11 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        from . import arch
+        lib_mean = [handle.dal3_mean_size()[i] for i in range(9)]
+        want = [C.c_float(v).value for row in arch.MEAN_SIZE for v in row]
+        if lib_mean != want:                                # two copies of one table: they may not drift apart
+            raise RuntimeError(f"lib3dal_hip.so was built with MEAN_SIZE {lib_mean}, arch.MEAN_SIZE is {want}: rebuild the library")
         _lib = handle
     return _lib
 

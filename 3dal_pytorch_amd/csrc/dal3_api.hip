@@ -30,6 +30,10 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 extern "C" int dal3_version(void) { return DAL3_VERSION; }
+extern "C" const float* dal3_mean_size(void) {
+    static const float v[9] = {DAL3_MEAN_SIZE_VALUES};
+    return v;
+}
 extern "C" const char* dal3_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------- layout

@@ -28,6 +28,9 @@
 #ifndef DAL3_PF
 #define DAL3_PF 8
 #endif
+// MEAN_SIZE_ARR of the reference (tools/static_model.py:17-21), the ONE copy in the library: the decode kernels, the
+// criterion kernel and dal3_mean_size() (which the Python side checks against arch.MEAN_SIZE when it loads the library)
+#define DAL3_MEAN_SIZE_VALUES 4.8, 1.8, 1.5, 10.0, 2.6, 3.2, 2.0, 1.0, 1.6
 #define DAL3_BLOB_TAIL_FLOATS 8192   // 32 KiB: room for a ring's over-read past the last stream
 
 // ---- packed PointNetInstanceSeg (BN folded). A "frag block" is [4 q][64 lanes] float4 x KT k-tiles

@@ -452,8 +452,8 @@ hipError_t launch_compact_sample(const uint8_t* mask, BCN pts, int B, int N, int
 }
 
 // ================================================================================== decode / parse
-__constant__ float c_mean_size[9] = {4.8f, 1.8f, 1.5f, 10.0f, 2.6f, 3.2f, 2.0f, 1.0f, 1.6f};
-__constant__ double c_mean_size_d[9] = {4.8, 1.8, 1.5, 10.0, 2.6, 3.2, 2.0, 1.0, 1.6};
+__constant__ float c_mean_size[9] = {DAL3_MEAN_SIZE_VALUES};
+__constant__ double c_mean_size_d[9] = {DAL3_MEAN_SIZE_VALUES};
 
 // One thread per crop. fp32 where the reference computes in fp32 tensors (parse_output_to_tensors),
 // fp64 where its eval driver computes in NumPy float64 (class2angle / class2size), rounded to fp32

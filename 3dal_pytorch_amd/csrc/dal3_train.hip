@@ -1743,7 +1743,7 @@ hipError_t launch_tr_seg_ce(const float* logits, const void* labels, int labels_
 // the mean over the B items — and the gradient of every mean w.r.t. its inputs, in the same pass. O(B) work that stock
 // ops spread over ~60 launches per estimate and step. One workgroup; per-thread float64 sums over items tid, tid+256, ...,
 // added in thread order (reproducible).
-__constant__ float c_tr_mean_size[9] = {4.8f, 1.8f, 1.5f, 10.0f, 2.6f, 3.2f, 2.0f, 1.0f, 1.6f};
+__constant__ float c_tr_mean_size[9] = {DAL3_MEAN_SIZE_VALUES};
 
 struct BoxLossArgs {
     const float* center;        // (B,3)
@@ -1781,8 +1781,22 @@ __global__ __launch_bounds__(256) void tr_box_loss_kernel(BoxLossArgs a, int B) 
         acc[0] += (double)(0.5f * q * q + 2.0f * (dist - q));
 #pragma unroll
         for (int k = 0; k < 3; ++k) a.g_center[b * 3 + k] = dist > 0.0f ? q * d[k] / dist * inv_b : 0.0f;
+        // class labels out of range (an ignore value, a -1): F.nll_loss of the stock criterion raises; here the item's
+        // rows of the gradients are zeroed and every loss term comes back NaN — loud, and no out-of-bounds read
+        const int64_t hc64 = a.hcl[b], sc64 = a.scl[b];
+        if (hc64 < 0 || hc64 >= 12 || sc64 < 0 || sc64 >= 3) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) acc[t] = __builtin_nan("");
+#pragma unroll
+            for (int k = 0; k < 12; ++k) a.g_hs[b * 12 + k] = a.g_hrn[b * 12 + k] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.g_ss[b * 3 + k] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a.g_srn[b * 9 + k] = 0.0f;
+            continue;
+        }
         // heading class
-        const int hc = (int)a.hcl[b];
+        const int hc = (int)hc64;
         float mx = a.hs[b * 12];
 #pragma unroll
         for (int k = 1; k < 12; ++k) mx = fmaxf(mx, a.hs[b * 12 + k]);
@@ -1803,7 +1817,7 @@ __global__ __launch_bounds__(256) void tr_box_loss_kernel(BoxLossArgs a, int B) 
 #pragma unroll
         for (int k = 0; k < 12; ++k) a.g_hrn[b * 12 + k] = k == hc ? (er > 0.0f ? q : (er < 0.0f ? -q : 0.0f)) * inv_b : 0.0f;
         // size class
-        const int sc = (int)a.scl[b];
+        const int sc = (int)sc64;
         const float s0 = a.ss[b * 3], s1 = a.ss[b * 3 + 1], s2 = a.ss[b * 3 + 2];
         const float smx = fmaxf(s0, fmaxf(s1, s2));
         const float f0 = expf(s0 - smx), f1 = expf(s1 - smx), f2 = expf(s2 - smx);

@@ -684,7 +684,11 @@ def ins_seg_train_forward(ins_seg, pts, p_drop=0.5, drop_mask=None):
         # on every hipGraph replay); the backward re-creates the multiplier from the same key
         step = draw_step(ins_seg, pts.device)
         step.add_(1)
-        drop = (int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF, step, float(p_drop))
+        # the key carries a SNAPSHOT of the counter, not the live tensor: the backward re-creates the multiplier from the
+        # key, and a second train-mode forward of the same module before this graph's backward (loss(model(a)) +
+        # loss(model(b)), a recompute) has moved the live counter on by then. The clone is an ordinary device
+        # op: captured into a hipGraph it copies the replay's counter value, so a replayed step still draws afresh.
+        drop = (int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF, step.clone(), float(p_drop))
     params = []
     for conv, bn in ins_seg.pairs():
         params += [conv.weight, conv.bias] + ([bn.weight, bn.bias] if bn is not None else [])

@@ -74,6 +74,10 @@ typedef struct {
 /* ------------------------------------------------------------------------------------------ */
 int dal3_version(void);
 const char* dal3_last_error(void);       /* thread-local, static storage */
+/* MEAN_SIZE_ARR (tools/static_model.py:17-21) as the library holds it: 9 floats, (3 size clusters) x (l, w, h), HOST
+ * memory with static storage. The one copy that the decode and criterion kernels are compiled with; a binding that
+ * keeps the table on its side as well (3dal_pytorch_amd/arch.py) compares the two when it loads the library. */
+const float* dal3_mean_size(void);
 
 /* Fold BN (eps 1e-5) into each layer and write the MFMA-fragment-ordered / row-major image the
  * kernels consume. Call with packed_dev == NULL to query *bytes_inout. Layers come in forward
@@ -341,7 +345,9 @@ int dal3_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int
  * bins), heading residual (Huber, delta 1, of the label bin's normalised residual against label / (pi/12)), size class
  * (cross-entropy, 3), size residual (Huber, delta 1, of ||label / mean_size[class] - the label class's normalised
  * residual||) — unweighted; and g_* = the gradient of the matching loss w.r.t. that input (the other entries 0).
- * All inputs contiguous fp32 except the two int64 class labels (values in range). One launch. */
+ * All inputs contiguous fp32 except the two int64 class labels. A class label outside [0, 12) / [0, 3) (an ignore value
+ * such as -1: F.nll_loss of the stock criterion raises on those) makes every entry of `losses` NaN and zeroes that item's
+ * gradient rows; nothing is read out of bounds. One launch. */
 int dal3_tr_box_loss(const float* center, const float* center_label, const float* heading_scores,
                      const float* heading_residuals_normalized, const int64_t* heading_class_label,
                      const float* heading_residuals_label, const float* size_scores,

@@ -56,8 +56,35 @@ STATS = {"static_two": ["ins_seg.bn3", "ins_seg.dbn1", "box_est_one.bn1", "box_e
                      "box_emb.fcbn2", "box_est.fcbn2"]}
 
 
+# The LARGE fixtures (VERDICT r2 / ADVICE r2): the same step at B*N >= 65,536 points. ONE activation that falls on the other
+# side of a ReLU (or of a pooling tie) in a float32 run moves the gradients in front of it by ~1/(B*N) of their scale;
+# at the small fixtures' 1,280 - 2,048 points that alone is 5e-4 ... 8e-4 and their gate had to allow for it, at 65,536
+# points it is 1.5e-5 and the gate is max(1e-4, 1.5 x the reference's own float32 error) with nothing else in it.
+# kind -> (model kind, items, points per item (per frame for the dynamic head), synth seed)
+BIG = {"static_one_big": ("static_one", 16, 4096, 51), "static_two_big": ("static_two", 16, 4096, 54),
+       "dynamic_big": ("dynamic", 13, 1024, 52)}
+
+
+def big_case(kind):
+    base, B, n, seed = BIG[kind]
+    if base != "dynamic":
+        pts, init, gt = synth.static_crops(B, n, seed=seed)
+        return dict(pts=pts, init=init, gt=gt), synth.loss_case(seed, batch=B, n_pts=n)[1]
+    pts, box, init8, gt = synth.dynamic_items(B, n_per_frame=n, seed=seed)
+    return dict(pts=pts, box=box, gt=gt), synth.loss_case(seed, batch=B, n_pts=5 * n)[1]
+
+
+def big_keep(kind, n_points):
+    """the Dropout keep pattern of a large fixture: a function of the seed (synth's hash), not torch's generator — the
+    float64 run is given a forced pattern anyway (torch draws another one for float64 tensors), and a (65536, 128)
+    pattern regenerated from four numbers need not be stored"""
+    return synth.uniform(BIG[kind][3], "dropout_keep", (n_points, 128)) >= 0.5
+
+
 def case(kind):
     """inputs (numpy, float32) and labels of the step"""
+    if kind in BIG:
+        return big_case(kind)
     if kind in ("static_one", "static_two"):
         B, N = 8, 256
         seed = 41 if kind == "static_one" else 44
@@ -75,6 +102,8 @@ def one_step(kind, mods, sd_np, inp, labels, dtype, torch_seed, np_seed, force_k
     force_keep (B*N,128) bool: replace nn.Dropout's own draw by this keep pattern (torch draws a different pattern
     for float64 tensors from the same seed, so the float64 run is given the float32 run's)"""
     sm, dm = mods
+    full = kind
+    kind = BIG[kind][0] if kind in BIG else kind
     saved_float, saved_default = torch.Tensor.float, torch.get_default_dtype()
     if dtype == torch.float64:
         torch.set_default_dtype(torch.float64)
@@ -97,6 +126,17 @@ def one_step(kind, mods, sd_np, inp, labels, dtype, torch_seed, np_seed, force_k
             drop.update(x=i[0].detach(), y=o.detach())
             return o
         h = model.ins_seg.dropout.register_forward_hook(hook)
+        # the layers torch.max pools over points (ins_seg.bn5, the point stacks' bn4): how close the two largest values
+        # of an (item, channel) row come — a pooling tie within float32 rounding reroutes that row's gradient
+        gaps, pool_hooks = [], []
+        def gap_hook(m, i, o):
+            top = torch.topk(o.detach().double(), 2, dim=2).values
+            live = top[:, :, 0] > 0                                            # (a row whose maximum is <= 0 is gated off by the ReLU)
+            if bool(live.any()):
+                gaps.append(float(((top[:, :, 0] - top[:, :, 1]) / top[:, :, 0].abs().clamp_min(1e-30))[live].min()))
+        for name, mod in model.named_modules():
+            if name in ("ins_seg.bn5", "box_est.bn4", "box_est_one.bn4", "box_est_two.bn4", "point_emb.bn4", "box_emb.bn4"):
+                pool_hooks.append(mod.register_forward_hook(gap_hook))
         torch.manual_seed(torch_seed)
         np.random.seed(np_seed)
         if kind != "dynamic":
@@ -104,12 +144,15 @@ def one_step(kind, mods, sd_np, inp, labels, dtype, torch_seed, np_seed, force_k
         else:
             out = model(t(inp["pts"]).transpose(2, 1), t(inp["box"]).transpose(2, 1), t(inp["gt"]))
         h.remove()
+        for ph in pool_hooks:
+            ph.remove()
         lab = [torch.from_numpy(a).to(dtype) if a.dtype == np.float32 else torch.from_numpy(a) for a in labels]
         losses = crit(out, *lab)
         opt.zero_grad()
         losses["total_loss"].backward()
         params = dict(model.named_parameters())
-        res = {"logits": out["logits"].detach().numpy(), "mask": out["mask"].numpy()}
+        res = {"logits": out["logits"].detach().numpy(), "mask": out["mask"].numpy(),
+               "min_pool_gap": np.float64(min(gaps) if gaps else np.inf)}
         for k, v in losses.items():
             res["loss_" + k] = np.float64(v.detach())
         for k in (("center", "heading_scores", "size_scores", "heading_residuals_normalized", "size_residuals_normalized")
@@ -118,6 +161,7 @@ def one_step(kind, mods, sd_np, inp, labels, dtype, torch_seed, np_seed, force_k
                    "heading_scores_two", "size_scores_two", "heading_residuals_normalized_two",
                    "size_residuals_normalized_two", "heading_class_label_two", "heading_residuals_label_two")):
             res["out_" + k] = out[k].detach().numpy()
+        del full
         for name in PICK[kind]:
             res["grad_" + name] = params[name].grad.numpy().copy()
         # the Dropout multiplier as the reference drew it: kept where output != 0 OR input == 0 (a dropped zero and a
@@ -201,5 +245,58 @@ def main():
               "| reference fp32-vs-fp64 worst:", worst, f"{noise[worst]:.2e}")
 
 
+def main_big(only=None):
+    """the large fixtures: float64 step with the synthetic Dropout pattern (twice: threshold search, then the step) and
+    the float32 step with the same pattern (the reference's own rounding noise at this size)"""
+    sm, dm, _, _, _ = G.import_reference()
+    torch.set_grad_enabled(True)
+    torch.set_num_threads(8)
+    for kind, torch_seed, np_seed in (("static_one_big", 111, 212), ("dynamic_big", 113, 214), ("static_two_big", 115, 216)):
+        if only and kind not in only:
+            continue
+        base, B, n, seed = BIG[kind]
+        inp, labels = case(kind)
+        n_points = B * (n if base != "dynamic" else 5 * n)
+        keep = big_keep(kind, n_points)
+        sd = synth.state_dict(base, seed=seed + 2)
+        r0 = one_step(kind, (sm, dm), sd, inp, labels, torch.float64, torch_seed, np_seed, force_keep=keep)
+        thr, half = synth.widest_gap_centre(r0["logits"][:, :, 1] - r0["logits"][:, :, 0], window=0.02)
+        del r0
+        sd = synth.recentre_seg_bias(sd, thr)
+        ref = one_step(kind, (sm, dm), sd, inp, labels, torch.float64, torch_seed, np_seed, force_keep=keep)
+        f32 = one_step(kind, (sm, dm), sd, inp, labels, torch.float32, torch_seed, np_seed, force_keep=keep)
+        margin = ref["logits"][:, :, 1] - ref["logits"][:, :, 0]
+        assert np.array_equal(ref["mask"], f32["mask"]), "the float32 run of the reference flipped a mask bit"
+        out = {"margin_shift": np.float64(thr), "min_abs_margin": np.float64(np.abs(margin).min()),
+               "min_pool_gap": ref["min_pool_gap"], "weights_seed": seed + 2,
+               "torch_seed": torch_seed, "np_seed": np_seed, "lr": LR, "mask_bits": np.packbits(ref["mask"], axis=1),
+               "in_sum": np.float64(sum(np.asarray(v, np.float64).sum() for v in inp.values())),
+               "ref_logits": synth.fixture_sample(ref["logits"]).astype(np.float32),
+               "refmax_logits": np.float64(np.abs(ref["logits"]).max())}
+        for k, v in ref.items():
+            if k in ("drop_keep", "mask", "keep", "logits", "min_pool_gap"):
+                continue
+            if k.startswith(("grad_", "new_")):
+                out["ref_" + k] = synth.fixture_sample(v).astype(np.float32)
+                out["refmax_" + k] = np.float64(np.abs(v).max())
+            else:
+                out["ref_" + k] = v.astype(np.float32) if v.dtype == np.float64 and v.ndim else v
+        noise = {}
+        for k, v in f32.items():
+            if k.startswith(("grad_", "loss_", "new_")) or k == "logits":
+                a, b = np.asarray(v, np.float64), np.asarray(ref[k], np.float64)
+                noise[k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+        out["f32_noise_keys"] = np.array(list(noise))
+        out["f32_noise"] = np.array([noise[k] for k in noise])
+        np.savez_compressed(os.path.join(HERE, f"train_step_{kind}.npz"), **out)
+        worst = max((k for k in noise if k.startswith("grad_")), key=noise.get)
+        print(kind, "loss", float(ref["loss_total_loss"]), "min|margin|", float(np.abs(margin).min()), "min pool gap",
+              float(ref["min_pool_gap"]), "counts", ref["mask"].sum(1), "| reference fp32-vs-fp64 worst gradient:", worst,
+              f"{noise[worst]:.2e}", flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        main_big(sys.argv[2:])
+    else:
+        main()

@@ -116,7 +116,7 @@ def test_drivers_imports_resolve_in_the_dropin():
 
 
 # ------------------------------------------------------------------ the reference's training step, in float64
-@pytest.mark.parametrize("kind", ["static_one", "static_two", "dynamic"])
+@pytest.mark.parametrize("kind", ["static_one", "static_two", "dynamic", "static_one_big"])
 def test_composite_in_float64_reproduces_the_reference_training_step(kind):
     """tests/golden/train_step_*.npz: one step of the REAL reference (forward, its criterion, backward; float64 run of
     the imported code with the float32 run's Dropout and NumPy draws, tests/golden/gen_train_step.py). This package's
@@ -126,7 +126,14 @@ def test_composite_in_float64_reproduces_the_reference_training_step(kind):
     tests/test_gpu_train_reference.py.)"""
     from _common import golden
     g = golden("train_step_" + kind)
-    if kind in ("static_one", "static_two"):
+    big = kind.endswith("_big")            # the 16 x 4096 fixture (B*N = 65,536): one of the three is re-run here, ~1 min of CPU
+    if big:
+        torch.set_num_threads(8)
+        kind, B, N, seed = "static_one", 16, 4096, 51
+        pts, init, gt = synth.static_crops(B, N, seed=seed)
+        labels = synth.loss_case(seed, batch=B, n_pts=N)[1]
+        model, crit = sm.StaticModelOneBoxEst(), losses.FrustumPointNetLossOneBoxEst()
+    elif kind in ("static_one", "static_two"):
         B, N = 8, 256
         seed = 41 if kind == "static_one" else 44
         pts, init, gt = synth.static_crops(B, N, seed=seed)
@@ -138,11 +145,13 @@ def test_composite_in_float64_reproduces_the_reference_training_step(kind):
         pts, box, _, gt = synth.dynamic_items(B, n_per_frame=64, seed=42)
         labels = synth.loss_case(42, batch=B, n_pts=N)[1]
         model, crit = dm.DynamicModel(), losses.DynamicModelLoss()
-    sd = synth.recentre_seg_bias(synth.state_dict(kind, seed=43), float(g["margin_shift"]))
+    sd = synth.recentre_seg_bias(synth.state_dict(kind, seed=int(g["weights_seed"]) if big else 43), float(g["margin_shift"]))
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
     model = model.double().train()
     model.train_backend, model.sampler = "torch", "numpy"
-    keep = torch.from_numpy(np.unpackbits(g["drop_keep"], axis=1).astype(np.float64)).reshape(B, N, 128).permute(0, 2, 1)
+    keep_np = ((synth.uniform(seed, "dropout_keep", (B * N, 128)) >= 0.5) if big else
+               np.unpackbits(g["drop_keep"], axis=1)).astype(np.float64)
+    keep = torch.from_numpy(keep_np).reshape(B, N, 128).permute(0, 2, 1)
     model.ins_seg.dropout.register_forward_hook(lambda m, i, o: i[0] * keep / (1.0 - m.p))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()          # noqa: E731
     np.random.seed(int(g["np_seed"]))
@@ -150,7 +159,10 @@ def test_composite_in_float64_reproduces_the_reference_training_step(kind):
         out = model(t(pts).transpose(2, 1), t(init), t(gt))
     else:
         out = model(t(pts).transpose(2, 1), t(box).transpose(2, 1), t(gt))
-    assert np.array_equal(out["mask"].numpy(), g["mask"])
+    if big:
+        assert np.array_equal(np.packbits(out["mask"].numpy(), axis=1), g["mask_bits"])
+    else:
+        assert np.array_equal(out["mask"].numpy(), g["mask"])
     for k in g:
         if k.startswith("ref_out_"):
             v, ref = out[k[8:]].detach().numpy(), g[k]
@@ -158,7 +170,10 @@ def test_composite_in_float64_reproduces_the_reference_training_step(kind):
                 assert np.array_equal(v, ref), k
             else:
                 assert np.abs(v - ref).max() < 1e-6 * max(np.abs(ref).max(), 1.0), k
-    assert np.abs(out["logits"].detach().numpy() - g["ref_logits"]).max() < 1e-6 * np.abs(g["ref_logits"]).max()
+    if big:
+        assert np.abs(synth.fixture_sample(out["logits"].detach().numpy()) - g["ref_logits"]).max() < 1e-6 * float(g["refmax_logits"])
+    else:
+        assert np.abs(out["logits"].detach().numpy() - g["ref_logits"]).max() < 1e-6 * np.abs(g["ref_logits"]).max()
     ls = crit(out, *[t(a) if a.dtype == np.float32 else torch.from_numpy(a) for a in labels])
     for k, v in ls.items():
         assert abs(float(v.detach()) - float(g["ref_loss_" + k])) < 1e-6 * max(1.0, abs(float(g["ref_loss_" + k]))), k
