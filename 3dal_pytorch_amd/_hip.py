@@ -75,7 +75,8 @@ SIGNATURES = {
     "dal3_mask_compact_sample_step": (_i, [vp, BCN, _i, _i, _i, _i, _u64, vp, _i64, vp, vp, vp, vp, _sz, vp]),
     "dal3_point_head_workspace_bytes": (_sz, [_i]),
     "dal3_point_head_forward": (_i, [_i, vp, _i, BCN, _i, _i, vp, _i64, vp, _sz, vp]),
-    "dal3_point_head_pool": (_i, [_i, vp, _i, BCN, _i, _i, vp, vp, vp]),
+    "dal3_point_head_pool_workspace_bytes": (_sz, [_i, _i]),
+    "dal3_point_head_pool": (_i, [_i, vp, _i, BCN, _i, _i, vp, vp, vp, _sz, vp]),
     "dal3_dynamic_box_est_forward": (_i, [vp, vp, _i, vp, vp, _sz, vp]),
     "dal3_decode_boxes": (_i, [vp, _i, vp, _i64, _i, vp, _i64, vp, _i64, vp, vp, vp, vp, vp]),
     "dal3_recenter_rotz": (_i, [vp, _i, _i, vp, vp, vp, vp, vp, vp, vp]),

@@ -532,12 +532,17 @@ extern "C" int dal3_mask_compact_sample_step(const uint8_t* mask, dal3_bcn pts, 
 }
 
 // ---------------------------------------------------------------------------------- point heads
-struct HeadWs { float* feat; float* t1; float* t2; };
+// `work`: the live-tile worklist of the point heads' persistent kernel (dal3_pointmlp.hip), sized for items of up to
+// HEAD_WORK_MAX_POINTS points (the dynamic head's 5 x 512 object points); longer items take the per-tile kernel
+#define HEAD_WORK_MAX_POINTS 2560
+struct HeadWs { float* feat; float* t1; float* t2; void* work; size_t work_bytes; };
 static HeadWs carve_head(Carver& c, int B) {
     HeadWs w;
     w.feat = c.take<float>((size_t)B * 512);
     w.t1 = c.take<float>((size_t)B * 512);
     w.t2 = c.take<float>((size_t)B * 512);
+    w.work_bytes = point_head_worklist_bytes(B, HEAD_WORK_MAX_POINTS);
+    w.work = c.take<char>(w.work_bytes);
     return w;
 }
 extern "C" size_t dal3_point_head_workspace_bytes(int B) {
@@ -578,7 +583,7 @@ static int point_head_run(int head_kind, const void* packed, int dtype, const da
         return fc_chain(w.fc, ws.feat, 512, out, out_stride, B, ws.t1, ws.t2, s);
     }
     const PointHeadW w = point_head_view(static_cast<const float*>(packed), head_kind);
-    HIP_TRY(launch_point_head(head_kind, w, to_bcn(x), c_in, B, M, ws.feat, distinct, s));
+    HIP_TRY(launch_point_head(head_kind, w, to_bcn(x), c_in, B, M, ws.feat, distinct, s, ws.work, ws.work_bytes));
     return fc_chain(w.fc, ws.feat, 512, out, out_stride, B, ws.t1, ws.t2, s);
 }
 
@@ -593,8 +598,13 @@ extern "C" int dal3_point_head_forward(int head_kind, const void* packed, int dt
 }
 
 /* the per-point stack + max of a point head alone (no FC tail): feat (B,512). n_distinct: see dal3.h */
+extern "C" size_t dal3_point_head_pool_workspace_bytes(int B, int M) {
+    return B > 0 && M > 0 ? point_head_worklist_bytes(B, M) : 0;
+}
+
 extern "C" int dal3_point_head_pool(int head_kind, const void* packed, int dtype, dal3_bcn x, int B, int M,
-                                    const int32_t* n_distinct, float* feat, dal3_stream stream) {
+                                    const int32_t* n_distinct, float* feat, void* workspace, size_t workspace_bytes,
+                                    dal3_stream stream) {
     TRY(check_dtype(dtype));
     if (head_kind != DAL3_HEAD_STATIC_BOX_EST && head_kind != DAL3_HEAD_POINT_EMB && head_kind != DAL3_HEAD_BOX_EMB)
         return fail(DAL3_EINVAL, "point_head_pool: head_kind %d is not a point head", head_kind);
@@ -611,7 +621,8 @@ extern "C" int dal3_point_head_pool(int head_kind, const void* packed, int dtype
         return 0;
     }
     const PointHeadW w = point_head_view(static_cast<const float*>(packed), head_kind);
-    HIP_TRY(launch_point_head(head_kind, w, to_bcn(x), c_in, B, M, feat, n_distinct, s));
+    if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) return fail(DAL3_EINVAL, "point_head_pool: workspace must be 16-byte aligned");
+    HIP_TRY(launch_point_head(head_kind, w, to_bcn(x), c_in, B, M, feat, n_distinct, s, workspace, workspace_bytes));
     return 0;
 }
 

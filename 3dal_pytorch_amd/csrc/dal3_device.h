@@ -95,20 +95,24 @@ __device__ __forceinline__ void mma_block(const f32x4* __restrict__ wblk, const 
 // single group of VALU instructions in the fp32 kernels. Reads past the stream's end stay inside the 2 GiB window
 // of the descriptor (blobs carry tail padding); their values are unused.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <int D>
+// CYC: the stream is read CYCLICALLY (a persistent wave runs it once per tile: the ring's last D fetches of a tile
+// are the first D fragments of the next one, so no tile starts with an exposed L2 round trip); `len` = its bytes.
+template <int D, bool CYC = false>
 struct WRing {
     __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t voff, soff;
+    uint32_t voff, soff, len;
     f32x4 slot[D];
     __device__ __forceinline__ f32x4 fetch() {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
         soff += 1024;
+        if (CYC && soff == len) soff = 0;                  // scalar compare + select
         return __builtin_bit_cast(f32x4, v);
     }
-    __device__ __forceinline__ void init(const f32x4* stream, int lane) {
+    __device__ __forceinline__ void init(const f32x4* stream, int lane, uint32_t bytes = 0) {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(stream), 0, 0x7fffffff, 0x00020000);
         voff = (uint32_t)lane * 16u;
         soff = 0;
+        len = bytes;
 #pragma unroll
         for (int i = 0; i < D; ++i) slot[i] = fetch();
     }
@@ -124,8 +128,8 @@ struct WRing {
 #ifndef DAL3_WAIT_BATCH
 #define DAL3_WAIT_BATCH 1
 #endif
-template <int D>
-__device__ __forceinline__ void ring_batch_wait(WRing<D>& ring, int i) {
+template <int D, bool CYC = false>
+__device__ __forceinline__ void ring_batch_wait(WRing<D, CYC>& ring, int i) {
     static_assert(D % DAL3_WAIT_BATCH == 0, "wait batch must divide the ring depth");
     if (DAL3_WAIT_BATCH > 1 && i % DAL3_WAIT_BATCH == 0)
         asm volatile("" : "+v"(ring.slot[(i + DAL3_WAIT_BATCH - 1) % D][0]));
@@ -142,13 +146,13 @@ struct NoSide {
 };
 // SWAP: the operands change places, acc[j] += X[j]^T . W'^T — the TRANSPOSED tile (points on the rows = registers,
 // channels on the columns = lanes); the A and B fragment layouts are mirror images, so the same registers serve.
-template <int KT, int T, int D, typename Side = NoSide, bool SWAP = false>
-__device__ __forceinline__ void mma_block_ring(WRing<D>& ring, const f32x16 (&X)[T][KT], f32x16 (&acc)[T],
+template <int KT, int T, int D, typename Side = NoSide, bool SWAP = false, bool CYC = false>
+__device__ __forceinline__ void mma_block_ring(WRing<D, CYC>& ring, const f32x16 (&X)[T][KT], f32x16 (&acc)[T],
                                                Side side = Side()) {
     static_assert((KT * 4) % D == 0, "ring depth must divide the fragments per block");
 #pragma unroll
     for (int i = 0; i < KT * 4; ++i) {
-        ring_batch_wait<D>(ring, i);
+        ring_batch_wait<D, CYC>(ring, i);
         const f32x4 a = ring.slot[i % D];
         ring.slot[i % D] = ring.fetch();
 #ifdef DAL3_ABLATE_WINDOW   // timing experiment only: every fetch hits the same 8 KiB (L1-resident)
@@ -170,8 +174,8 @@ __device__ __forceinline__ void mma_block_ring(WRing<D>& ring, const f32x16 (&X)
 // weight stream. Two accumulator sets alternate so that the ReLU of tile mt-1 and the bias fetch of
 // tile mt+1 ride under the MFMAs of tile mt. bias_cur arrives holding this layer's tile-0 bias and
 // leaves holding the first tile's bias of the NEXT layer (b_next), fetched a whole tile ahead.
-template <int KT, int MT, int T, int D>
-__device__ __forceinline__ void mlp_layer_ring(WRing<D>& ring, const float* __restrict__ b,
+template <int KT, int MT, int T, int D, bool CYC = false>
+__device__ __forceinline__ void mlp_layer_ring(WRing<D, CYC>& ring, const float* __restrict__ b,
                                                const float* __restrict__ b_next, f32x16& bias_cur,
                                                const f32x16 (&X)[T][KT], f32x16 (&Y)[T][MT], int lane) {
     const int h = lane >> 5;
@@ -180,7 +184,7 @@ __device__ __forceinline__ void mlp_layer_ring(WRing<D>& ring, const float* __re
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int j = 0; j < T; ++j) acc[mt & 1][j] = bias_cur;
-        mma_block_ring<KT, T, D>(ring, X, acc[mt & 1], [&](int i) {
+        mma_block_ring(ring, X, acc[mt & 1], [&](int i) {
             if (i == 0) bias_cur = tile_from_channels(mt + 1 < MT ? b + 32 * (mt + 1) : b_next, h);
             if (mt > 0 && i < 8) {                     // ReLU of the previous tile, two registers per fragment group
 #pragma unroll
@@ -284,8 +288,8 @@ struct MaxEpilogueT {
 // channels, swept with two accumulator sets; the epilogue of tile mt-1 rides under the MFMAs of tile mt.
 // The fragments [n_tiles][KT][4][64] are next on the kernel's weight stream; bias/dst: the n_tiles*32 channels.
 // Computed transposed (SWAP): see MaxEpilogueT.
-template <int KT, int T, int D>
-__device__ __forceinline__ void conv_max_layer(WRing<D>& ring, const float* __restrict__ bias,
+template <int KT, int T, int D, bool CYC = false>
+__device__ __forceinline__ void conv_max_layer(WRing<D, CYC>& ring, const float* __restrict__ bias,
                                                const f32x16 (&X)[T][KT], float* __restrict__ dst, int n_tiles,
                                                int lane) {
     f32x16 accA[T], accB[T];
@@ -294,7 +298,7 @@ __device__ __forceinline__ void conv_max_layer(WRing<D>& ring, const float* __re
     for (int mt = 0; mt < n_tiles; ++mt) {
 #pragma unroll
         for (int j = 0; j < T; ++j) accA[j] = f32x16{};
-        mma_block_ring<KT, T, D, NoSide, true>(ring, X, accA);
+        mma_block_ring<KT, T, D, NoSide, true, CYC>(ring, X, accA);
 #pragma unroll
         for (int j = 0; j < T; ++j) {
 #pragma unroll
@@ -305,7 +309,7 @@ __device__ __forceinline__ void conv_max_layer(WRing<D>& ring, const float* __re
 #endif
 #pragma unroll
     for (int j = 0; j < T; ++j) accA[j] = f32x16{};
-    mma_block_ring<KT, T, D, NoSide, true>(ring, X, accA);                // tile 0
+    mma_block_ring<KT, T, D, NoSide, true, CYC>(ring, X, accA);                // tile 0
     // The loop body is two whole tiles and nothing else. With the last tile's un-hidden epilogue inside it (an
     // `if (mt + 1 < n_tiles) ... else ep.all(...)`) the two paths left the ring's eight fragment registers and the two
     // accumulator sets in different places, and hipcc reconciled them on the back edge: s_waitcnt vmcnt(7) ... vmcnt(0)
@@ -316,7 +320,7 @@ __device__ __forceinline__ void conv_max_layer(WRing<D>& ring, const float* __re
         auto epA = [&](int i) {
             if (i < MaxEpilogueT<T>::STEPS) ep.step(i, accA, bias + 32 * (mt - 1), dst + 32 * (mt - 1), lane);
         };
-        mma_block_ring<KT, T, D, decltype(epA), true>(ring, X, accB, epA);
+        mma_block_ring<KT, T, D, decltype(epA), true, CYC>(ring, X, accB, epA);
     };
     int mt = 1;
     for (; mt + 1 < n_tiles; mt += 2) {
@@ -326,7 +330,7 @@ __device__ __forceinline__ void conv_max_layer(WRing<D>& ring, const float* __re
         auto epB = [&](int i) {                                            // tile mt+1, epilogue of tile mt
             if (i < MaxEpilogueT<T>::STEPS) ep.step(i, accB, bias + 32 * mt, dst + 32 * mt, lane);
         };
-        mma_block_ring<KT, T, D, decltype(epB), true>(ring, X, accA, epB);
+        mma_block_ring<KT, T, D, decltype(epB), true, CYC>(ring, X, accA, epB);
     }
     tile_b(mt);                                                            // n_tiles is even: mt == n_tiles - 1
     ep.all(accB, bias + 32 * mt, dst + 32 * mt, lane);                    // last tile: nothing left to hide under

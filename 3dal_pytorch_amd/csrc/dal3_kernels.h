@@ -145,8 +145,11 @@ hipError_t launch_ins_seg_encode(const InsSegW& w, BCN pts, int c_in, int B, int
 hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int N, const float* gbias,
                                  float* logits, uint8_t* mask, hipStream_t s);
 // distinct (B) i32 or NULL: only the first distinct[b] points of item b are distinct (the rest duplicate them)
+// worklist (optional, point_head_worklist_bytes(B, M) bytes of device scratch): lets the throughput family run as
+// persistent waves over the compacted list of live tiles (dal3_pointmlp.hip); NULL -> one workgroup per (item, tile)
+size_t point_head_worklist_bytes(int B, int M);
 hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat,
-                             const int32_t* distinct, hipStream_t s);
+                             const int32_t* distinct, hipStream_t s, void* worklist = nullptr, size_t worklist_bytes = 0);
 hipError_t launch_generic_layer(const f32x4* wf, const float* w1, const float* bias, int kt_n, int ks_n, int mt_n,
                                 int relu, BCN x, int c_in, int B, int N, float* y, hipStream_t s);
 

@@ -248,6 +248,113 @@ __global__ __launch_bounds__(64 * DAL3_WG_WAVES) void point_head_kernel(PointHea
 }
 
 // ------------------------------------------------------------------------------------------------
+// The point heads on a WORKLIST of live tiles (round 3). With the device sampler only the first min(count, M) object
+// points of an item are distinct, so most items have tiles that hold nothing but copies; point_head_kernel above
+// launches a one-wave workgroup for every (item, tile) and lets the dead ones exit — 26 % of the grid on the bench's mix
+// of crops — and every live one pays its own launch, bias preload and cold weight ring for ONE 32-point tile (~90 us).
+// Here a one-workgroup kernel turns `distinct` into the compacted list of (item, tile, points that count) entries, and
+// persistent one-wave workgroups (as many as the chip holds at this register count) take entries from a device-side
+// cursor: no dead workgroups, no relaunch, the weight ring runs on cyclically from tile to tile, and the next entry
+// and its points are fetched while the current tile is computed. Per-point arithmetic and the atomicMax combine are
+// those of point_head_kernel: bit-identical results (tests/test_gpu_parity.py).
+//   ctl[0] = n_live (written by head_worklist_kernel), ctl[1] = cursor (zeroed by it); list[i] = {item, tile, n_eff, 0}
+__global__ __launch_bounds__(1024) void head_worklist_kernel(const int32_t* __restrict__ distinct, int n_items, int n_pts,
+                                                             uint32_t* __restrict__ ctl, u32x4* __restrict__ list) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < n_items; b0 += 1024) {
+        const int b = b0 + tid;
+        int n_eff = 0, n_t = 0;
+        if (b < n_items) {
+            n_eff = n_pts;
+            if (distinct) {
+                const int d = distinct[b];
+                n_eff = d <= 0 ? 1 : (d < n_pts ? d : n_pts);
+            }
+            n_t = (n_eff + 31) >> 5;
+        }
+        int inc = n_t;                                      // inclusive scan over the wave, then over the 16 waves
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(inc, off);
+            if (lane >= off) inc += up;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        int base = s_base;
+        for (int wv = 0; wv < wave; ++wv) base += s_wave[wv];
+        int total = 0;
+        for (int wv = 0; wv < 16; ++wv) total += s_wave[wv];
+        const int first = base + inc - n_t;
+        for (int t = 0; t < n_t; ++t) {
+            u32x4 e;
+            e[0] = (uint32_t)b;
+            e[1] = (uint32_t)t;
+            e[2] = (uint32_t)n_eff;
+            e[3] = 0u;
+            list[first + t] = e;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        ctl[0] = (uint32_t)s_base;
+        ctl[1] = 0u;
+    }
+}
+
+template <int KS, int C1, int C2, int C3>
+__global__ __launch_bounds__(64) void point_head_pers_kernel(PointHeadW w, BCN x, int c_in, float* __restrict__ feat,
+                                                             uint32_t* __restrict__ ctl, const u32x4* __restrict__ list) {
+    constexpr int T = 1;
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    __shared__ float s_b4[512];                        // conv4's folded bias, read by the max epilogue
+    for (int i = threadIdx.x; i < 512; i += 64) s_b4[i] = w.b4[i];
+    __syncthreads();
+    const uint32_t n_live = ctl[0];
+    uint32_t cur = blockIdx.x;                         // the first entry is the block's own, the others come from the cursor
+    if (cur >= n_live) return;
+
+    constexpr uint32_t STREAM_BYTES =
+        ((C2 / 32) * (C1 / 32) + (C3 / 32) * (C2 / 32) + 16 * (C3 / 32)) * 4u * 1024u;   // conv2 | conv3 | conv4 fragments
+    WRing<DAL3_PF, true> ring;
+    ring.init(w.stream, lane, STREAM_BYTES);
+    f32x16 bias = tile_from_channels(w.b2, h);
+    u32x4 e = list[cur];
+    float in[T][KS];
+    load_points<KS, T>(x, (int64_t)e[0], (int)e[1] * 32, (int)e[2], c_in, in, lane);
+    for (;;) {
+        const int64_t b = (int64_t)e[0];
+        // the next entry: one returning atomic per tile, issued a whole layer before its result is looked at (by then
+        // it is older than everything the ring has in flight, so the wait for it costs the ring nothing)
+        uint32_t nxt = 0;
+        if (lane == 0) nxt = atomicAdd(&ctl[1], 1u);
+        f32x16 x3[T][C3 / 32];
+        float in_n[T][KS];
+        {
+            f32x16 x1[T][C1 / 32], x2[T][C2 / 32];
+            first_layer<KS, C1 / 32, T>(w.w1, w.b1, in, x1, lane);
+            mlp_layer_ring<C1 / 32, C2 / 32, T>(ring, w.b2, w.b3, bias, x1, x2, lane);
+            nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt) + gridDim.x;
+            const uint32_t nclamp = nxt < n_live ? nxt : cur;          // (past the end: re-read this tile's entry, unused)
+            e = list[nclamp];
+            mlp_layer_ring<C2 / 32, C3 / 32, T>(ring, w.b3, w.b2, bias, x2, x3, lane);   // leaves bias = conv2's tile 0
+            load_points<KS, T>(x, (int64_t)e[0], (int)e[1] * 32, (int)e[2], c_in, in_n, lane);
+        }
+        conv_max_layer<C3 / 32, T>(ring, s_b4, x3, feat + b * 512, 16, lane);
+        if (nxt >= n_live) break;
+        cur = nxt;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) in[0][k] = in_n[0][k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // One layer, any Cin = 32*KT (or a raw first layer when kt == 0 && ks > 0) -> y (B,N,Cout)
 // point-major. Layer-wise test entry (dal3_shared_mlp_layer); not on the production path.
 __global__ __launch_bounds__(256) void generic_layer_kernel(const f32x4* __restrict__ wf, const float* __restrict__ w1,
@@ -343,11 +450,58 @@ hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int
     return hipGetLastError();
 }
 
+// bytes of the worklist a launch_point_head of (B items, M points) may need: ctl (2 words, padded) + one entry per tile
+size_t point_head_worklist_bytes(int B, int M) { return 256 + (size_t)B * ((M + 31) / 32) * sizeof(u32x4); }
+
+// persistent one-wave workgroups the chip holds at this kernel's register count (one wave per SIMD): 4 per CU
+static int head_slots() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        n = 4 * v;
+    }
+    return n;
+}
+
+// DAL3_HEAD_WORKLIST=0: the one-workgroup-per-(item, tile) kernel for every job (A/B measurements); default: the
+// worklist kernel whenever the caller gave room for the list
+static bool head_worklist_on() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("DAL3_HEAD_WORKLIST");
+        on = !(e && e[0] == '0');
+    }
+    return on != 0;
+}
+
 hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat,
-                             const int32_t* distinct, hipStream_t s) {
+                             const int32_t* distinct, hipStream_t s, void* worklist, size_t worklist_bytes) {
     if (lat_use((int64_t)B * ((M + 31) / 32))) return launch_point_head_lat(head_kind, w, x, c_in, B, M, feat, distinct, s);
     constexpr int T = DAL3_HEAD_T;
     const int tpi = (M + 32 * T - 1) / (32 * T);       // one-wave workgroups
+    if (worklist && worklist_bytes >= point_head_worklist_bytes(B, M) && head_worklist_on() && T == 1) {
+        uint32_t* ctl = static_cast<uint32_t*>(worklist);
+        u32x4* list = reinterpret_cast<u32x4*>(static_cast<char*>(worklist) + 256);
+        hipLaunchKernelGGL(head_worklist_kernel, dim3(1), dim3(1024), 0, s, distinct, B, M, ctl, list);
+        const int64_t tiles = (int64_t)B * tpi;
+        const dim3 grid((unsigned)(tiles < head_slots() ? tiles : head_slots())), block(64);
+        switch (head_kind) {
+            case 1:
+                hipLaunchKernelGGL((point_head_pers_kernel<2, 128, 128, 256>), grid, block, 0, s, w, x, c_in, feat, ctl, list);
+                break;
+            case 2:
+                hipLaunchKernelGGL((point_head_pers_kernel<2, 64, 128, 256>), grid, block, 0, s, w, x, c_in, feat, ctl, list);
+                break;
+            case 3:
+                hipLaunchKernelGGL((point_head_pers_kernel<4, 64, 64, 128>), grid, block, 0, s, w, x, c_in, feat, ctl, list);
+                break;
+            default:
+                return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)((int64_t)B * tpi)), block(64);
     switch (head_kind) {
         case 1:  // static box_est 3 -> 128 -> 128 -> 256 -> 512

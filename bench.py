@@ -216,8 +216,11 @@ def kernel_table(model, inputs, static, B, N, iters):
         hw = model._cache.get(key, mod, mod.HEAD_KIND, dt)
         hxb = hip.bcn(hx)
 
-        def pool(hw=hw, hxb=hxb, m=m, distinct=distinct, kind=mod.HEAD_KIND):
-            hip.check(lib.dal3_point_head_pool(kind, hip.ptr(hw), dt, hxb, B, m, hip.ptr(distinct), hip.ptr(feat), st()))
+        pws = torch.empty(max(int(lib.dal3_point_head_pool_workspace_bytes(B, m)), 16), dtype=torch.uint8, device=dev)
+
+        def pool(hw=hw, hxb=hxb, m=m, distinct=distinct, kind=mod.HEAD_KIND, pws=pws):
+            hip.check(lib.dal3_point_head_pool(kind, hip.ptr(hw), dt, hxb, B, m, hip.ptr(distinct), hip.ptr(feat),
+                                               hip.ptr(pws), pws.numel(), st()))
         t = events_ms(pool, iters)
         granule = 256 if lp else 32
         exe_pts = arch.head_executed_points(cnt, m, granule) if distinct is not None else B * arch._pad(m, granule)

@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dal3_stream;               /* hipStream_t */
 
-#define DAL3_VERSION 100                 /* 0.1.0 */
+#define DAL3_VERSION 110                 /* 0.1.1: dal3_point_head_pool takes a workspace; dal3_mean_size */
 
 enum {
     DAL3_OK = 0,
@@ -154,8 +154,13 @@ int dal3_point_head_forward(int head_kind, const void* packed, int dtype, dal3_b
  * one of them (what dal3_mask_compact_sample's device sampler writes when fewer than M points are segmented);
  * repeated points cannot change a max over points, so the kernel skips them. The whole-model sequencers pass
  * `counts` here. */
+/* workspace (optional): dal3_point_head_pool_workspace_bytes(B, M) bytes of 16-byte aligned device scratch for the
+ * list of tiles that hold distinct points; with it large jobs run as persistent waves over that list instead of one
+ * workgroup per (item, tile) — same bits either way. NULL / too small: the per-tile launch. */
+size_t dal3_point_head_pool_workspace_bytes(int B, int M);
 int dal3_point_head_pool(int head_kind, const void* packed, int dtype, dal3_bcn x, int B, int M,
-                         const int32_t* n_distinct, float* feat, dal3_stream stream);
+                         const int32_t* n_distinct, float* feat, void* workspace, size_t workspace_bytes,
+                         dal3_stream stream);
 
 /* ---- dynamic PointNetEstimation.forward (dynamic_model.py:300-312): (B,384) -> (B,39). */
 int dal3_dynamic_box_est_forward(const void* packed, const float* embedding, int B, float* box_pred,
