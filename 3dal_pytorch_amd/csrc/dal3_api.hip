@@ -414,7 +414,7 @@ static int ins_seg_run(const void* packed, int dtype, int c_in, const dal3_bcn& 
     if (c_in != 3 && c_in != 4) return fail(DAL3_EINVAL, "ins_seg: c_in must be 3 or 4");
     TRY(check_bcn(pts, "pts"));
     const BCN x = to_bcn(pts);
-    HIP_TRY(launch_fill_words(ws.g, (size_t)B * 1024, 0u, s));
+    HIP_TRY(launch_nonfinite_rows(x, B, N, c_in, ws.g, 1024, s));      // g = 0 (NaN for a crop with a non-finite coordinate)
     if (dtype == DAL3_F32) {
         const InsSegW w = ins_seg_view(static_cast<const float*>(packed), c_in);
         HIP_TRY(launch_ins_seg_encode(w, x, c_in, B, N, ws.g, s));
@@ -436,6 +436,7 @@ extern "C" int dal3_ins_seg_forward(const void* packed, int dtype, int c_in, dal
                                     uint8_t* mask, float* global_feat_out, void* workspace, size_t workspace_bytes,
                                     dal3_stream stream) {
     if (!workspace) return fail(DAL3_EINVAL, "ins_seg: workspace is NULL");
+    if (B <= 0 || N <= 0) return fail(DAL3_EINVAL, "ins_seg: B and N must be positive (B=%d N=%d)", B, N);
     Carver c(workspace, workspace_bytes);
     const InsSegWs ws = carve_ins_seg(c, B);
     if (!c.ok) return fail(DAL3_EWORKSPACE, "ins_seg: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
@@ -576,7 +577,7 @@ static int point_head_run(int head_kind, const void* packed, int dtype, const da
     TRY(check_bcn(x, "x"));
     int c_in, ks, c[4], n_fc, fi[3], fo[3];
     point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
-    HIP_TRY(launch_fill_words(ws.feat, (size_t)B * 512, 0u, s));
+    HIP_TRY(launch_nonfinite_rows(to_bcn(x), B, M, c_in, ws.feat, 512, s));   // feat = 0 (NaN for an item with a non-finite input)
     if (dtype != DAL3_F32) {
         const PointHeadLpW w = point_head_lp_view(packed, head_kind);
         HIP_TRY(launch_point_head_lp(dtype, head_kind, w, to_bcn(x), c_in, B, M, ws.feat, distinct, s));
@@ -609,19 +610,19 @@ extern "C" int dal3_point_head_pool(int head_kind, const void* packed, int dtype
     if (head_kind != DAL3_HEAD_STATIC_BOX_EST && head_kind != DAL3_HEAD_POINT_EMB && head_kind != DAL3_HEAD_BOX_EMB)
         return fail(DAL3_EINVAL, "point_head_pool: head_kind %d is not a point head", head_kind);
     if (!packed || !feat) return fail(DAL3_EINVAL, "point_head_pool: null pointer");
+    if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) return fail(DAL3_EINVAL, "point_head_pool: workspace must be 16-byte aligned");
     if (B <= 0 || M <= 0) return fail(DAL3_EINVAL, "point_head_pool: B and M must be positive");
     TRY(check_bcn(x, "x"));
     hipStream_t s = static_cast<hipStream_t>(stream);
     int c_in, ks, c[4], n_fc, fi[3], fo[3];
     point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
-    HIP_TRY(launch_fill_words(feat, (size_t)B * 512, 0u, s));
+    HIP_TRY(launch_nonfinite_rows(to_bcn(x), B, M, c_in, feat, 512, s));
     if (dtype != DAL3_F32) {
         const PointHeadLpW w = point_head_lp_view(packed, head_kind);
         HIP_TRY(launch_point_head_lp(dtype, head_kind, w, to_bcn(x), c_in, B, M, feat, n_distinct, s));
         return 0;
     }
     const PointHeadW w = point_head_view(static_cast<const float*>(packed), head_kind);
-    if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) return fail(DAL3_EINVAL, "point_head_pool: workspace must be 16-byte aligned");
     HIP_TRY(launch_point_head(head_kind, w, to_bcn(x), c_in, B, M, feat, n_distinct, s, workspace, workspace_bytes));
     return 0;
 }

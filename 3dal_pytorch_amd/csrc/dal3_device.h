@@ -44,6 +44,15 @@ __device__ __forceinline__ f32x16 tile_from_channels(const float* __restrict__ v
     return t;
 }
 
+// Non-finite inputs (include/dal3.h "Non-finite coordinates"): a crop with a NaN / Inf coordinate gets the quiet-NaN
+// pattern in every channel of its pooled feature BEFORE the encoder runs (nonfinite_rows_kernel, dal3_misc.hip) —
+// as a signed integer that pattern lies above every finite value and +inf, so the encoder's atomicMax leaves it in
+// place; the per-crop FC carries it into the crop's dconv1 term, where the decode kernels look for it.
+#define DAL3_QNAN_BITS 0x7FC00000
+__device__ __forceinline__ bool bits_nonfinite(float v) {   // NaN or +-Inf, on the bit pattern (the shared-MLP kernels
+    return (__float_as_uint(v) & 0x7F800000u) == 0x7F800000u;   // are built -fno-honor-nans: no float compare here)
+}
+
 // max(x, 0) as ONE integer v_max_i32 on the bit pattern (negatives and -0.0 have the sign bit set ->
 // +0; positives unchanged). fmaxf() on an MFMA result makes hipcc emit a canonicalising v_max_f32 x,x
 // in front of it, doubling the ReLU's VALU cost; an inline-asm v_max_f32 would read the MFMA result

@@ -202,6 +202,8 @@ hipError_t launch_segment_counts(const uint8_t* mask, int B, int N, int32_t* cou
 // p[0..n_words) = value (32-bit words) as a kernel launch; used instead of hipMemsetAsync wherever the call may be
 // captured into a hipGraph (see dal3_misc.hip)
 hipError_t launch_fill_words(void* p, size_t n_words, uint32_t value, hipStream_t s);
+// dst (B, C) = 0, or the quiet-NaN pattern in the rows of items whose input x (B, c_in, n_pts) holds a NaN / Inf
+hipError_t launch_nonfinite_rows(BCN x, int B, int n_pts, int c_in, float* dst, int C, hipStream_t s);
 hipError_t launch_compact_sample(const uint8_t* mask, BCN pts, int B, int N, int C, int M, int sampler,
                                  const int32_t* choice, uint64_t seed, int64_t item_offset, int32_t* counts,
                                  int32_t* pos, int32_t* obj_idx, float* obj_pts, hipStream_t s, const int64_t* step = nullptr);

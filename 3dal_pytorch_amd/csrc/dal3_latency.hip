@@ -185,15 +185,17 @@ __global__ __launch_bounds__(64 * LAT_WAVES) void ins_seg_decode_lat_kernel(InsS
                 }
             }
         }
-        const float s0 = l0 + __shfl_xor(l0, 32) + s_b[1408];
-        const float s1 = l1 + __shfl_xor(l1, 32) + s_b[1409];
+        float s0 = l0 + __shfl_xor(l0, 32) + s_b[1408];
+        float s1 = l1 + __shfl_xor(l1, 32) + s_b[1409];
+        const bool crop_bad = bits_nonfinite(s_b[128]);     // the crop's dconv1 term is NaN: a non-finite coordinate (dal3_device.h)
+        if (crop_bad) s0 = s1 = __int_as_float(DAL3_QNAN_BITS);
         const int n = n0 + m;
         if (h == 0 && n < n_pts) {
             f32x2 o;
             o[0] = s0;
             o[1] = s1;
             *reinterpret_cast<f32x2*>(logits + (b * n_pts + n) * 2) = o;
-            mask[b * n_pts + n] = s0 < s1 ? 1 : 0;
+            mask[b * n_pts + n] = (!crop_bad && s0 < s1) ? 1 : 0;
         }
     }
 }

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ W, co
     for (int r = 0; r < 16; ++r) {
         const int ch = 32 * mt + tile_chan(r, h);
         const float v = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
-        if (ch < c_out) yp[ch] = relu ? fmaxf(v, 0.0f) : v;
+        if (ch < c_out) yp[ch] = relu ? (v < 0.0f ? 0.0f : v) : v;   // (NaN stays NaN, as torch's relu: a non-finite item, dal3.h)
     }
 }
 
@@ -430,6 +430,33 @@ __global__ __launch_bounds__(256) void fill_words_kernel(uint32_t* __restrict__ 
         for (size_t k = i; k < n_words; k += stride) p[k] = value;
     }
 }
+// The zero-fill of a pooled-feature accumulator (B, C) that also applies the library's contract for NON-FINITE inputs
+// (include/dal3.h): one workgroup per item scans the item's n_pts x c_in input values; an item with a NaN / +-Inf gets
+// the quiet-NaN pattern in all C channels instead of zeros. The pooling kernels combine with an integer atomicMax on the
+// bit pattern, and that pattern is above every finite value's, so the NaN survives the pooling whatever the kernels
+// compute for the item — as torch.max returns NaN for a row that holds one (static_model.py:284,334).
+__global__ __launch_bounds__(256) void nonfinite_rows_kernel(BCN x, int n_pts, int c_in, uint32_t* __restrict__ dst, int C) {
+    const int64_t b = blockIdx.x;
+    const float* base = x.data + b * x.sb;
+    bool bad = false;
+    const int total = n_pts * c_in;
+    if (x.sc == 1 && x.sn == c_in) {                        // point-major storage: the item is one contiguous run
+        for (int i = threadIdx.x; i < total; i += 256) bad |= bits_nonfinite(base[i]);
+    } else {
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int n = i / c_in, c = i - n * c_in;
+            bad |= bits_nonfinite(base[(int64_t)n * x.sn + (int64_t)c * x.sc]);
+        }
+    }
+    const uint32_t v = __syncthreads_or(bad) ? (uint32_t)DAL3_QNAN_BITS : 0u;
+    for (int c = threadIdx.x; c < C; c += 256) dst[b * C + c] = v;
+}
+hipError_t launch_nonfinite_rows(BCN x, int B, int n_pts, int c_in, float* dst, int C, hipStream_t s) {
+    hipLaunchKernelGGL(nonfinite_rows_kernel, dim3((unsigned)B), dim3(256), 0, s, x, n_pts, c_in,
+                       reinterpret_cast<uint32_t*>(dst), C);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill_words(void* p, size_t n_words, uint32_t value, hipStream_t s) {
     if (n_words == 0) return hipSuccess;
     const size_t want = (n_words / 4 + 255) / 256;

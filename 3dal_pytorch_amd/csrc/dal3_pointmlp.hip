@@ -83,6 +83,9 @@ __global__ __launch_bounds__(64 * DAL3_WG_WAVES) void ins_seg_decode_kernel(InsS
     ring.init(w.dec_stream, lane);
     f32x16 bias = tile_from_channels(w.b2, h);
     const float* gb = gbias + b * 512;                 // W1g . g + b1' of this crop
+    // a crop with a non-finite coordinate: its pooled feature, hence this term, is NaN (dal3_device.h); as in the
+    // reference every logit of the crop is then NaN and its mask empty (static_model.py:284-289, :59)
+    const bool crop_bad = bits_nonfinite(gb[0]);
 
     f32x16 x2[T][2];
     {
@@ -188,15 +191,16 @@ __global__ __launch_bounds__(64 * DAL3_WG_WAVES) void ins_seg_decode_kernel(InsS
     const float bias0 = w.db5[0], bias1 = w.db5[1];
 #pragma unroll
     for (int j = 0; j < T; ++j) {
-        const float s0 = l0[j] + __shfl_xor(l0[j], 32) + bias0;
-        const float s1 = l1[j] + __shfl_xor(l1[j], 32) + bias1;
+        float s0 = l0[j] + __shfl_xor(l0[j], 32) + bias0;
+        float s1 = l1[j] + __shfl_xor(l1[j], 32) + bias1;
+        if (crop_bad) s0 = s1 = __int_as_float(DAL3_QNAN_BITS);
         const int n = n0 + 32 * j + (lane & 31);
         if (h == 0 && n < n_pts) {
             f32x2 o;
             o[0] = s0;
             o[1] = s1;
             *reinterpret_cast<f32x2*>(logits + (b * n_pts + n) * 2) = o;
-            mask[b * n_pts + n] = s0 < s1 ? 1 : 0;      // strict '<': ties are background
+            mask[b * n_pts + n] = (!crop_bad && s0 < s1) ? 1 : 0;      // strict '<': ties are background
         }
     }
     STAMP(4);
@@ -256,10 +260,13 @@ __global__ __launch_bounds__(64 * DAL3_WG_WAVES) void point_head_kernel(PointHea
 // persistent one-wave workgroups (as many as the chip holds at this register count) take entries from a device-side
 // cursor: no dead workgroups, no relaunch, the weight ring runs on cyclically from tile to tile, and the next entry
 // and its points are fetched while the current tile is computed. Per-point arithmetic and the atomicMax combine are
-// those of point_head_kernel: bit-identical results (tests/test_gpu_parity.py).
+// those of point_head_kernel: bit-identical results (tests/test_gpu_parity.py). (The 16-bit heads were given the
+// same list, in groups of 256 points, and timed both ways: 3.52 ms per C3 step either way — their kernel is persistent
+// already and a group of copies is a uniform 1-us skip there — so they keep walking (item, group) pairs.)
 //   ctl[0] = n_live (written by head_worklist_kernel), ctl[1] = cursor (zeroed by it); list[i] = {item, tile, n_eff, 0}
 __global__ __launch_bounds__(1024) void head_worklist_kernel(const int32_t* __restrict__ distinct, int n_items, int n_pts,
-                                                             uint32_t* __restrict__ ctl, u32x4* __restrict__ list) {
+                                                             int tile_pts, uint32_t* __restrict__ ctl,
+                                                             u32x4* __restrict__ list) {
     __shared__ int s_wave[16];
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(1024) void head_worklist_kernel(const int32_t* __re
                 const int d = distinct[b];
                 n_eff = d <= 0 ? 1 : (d < n_pts ? d : n_pts);
             }
-            n_t = (n_eff + 31) >> 5;
+            n_t = (n_eff + tile_pts - 1) / tile_pts;
         }
         int inc = n_t;                                      // inclusive scan over the wave, then over the 16 waves
 #pragma unroll
@@ -484,7 +491,7 @@ hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in
     if (worklist && worklist_bytes >= point_head_worklist_bytes(B, M) && head_worklist_on() && T == 1) {
         uint32_t* ctl = static_cast<uint32_t*>(worklist);
         u32x4* list = reinterpret_cast<u32x4*>(static_cast<char*>(worklist) + 256);
-        hipLaunchKernelGGL(head_worklist_kernel, dim3(1), dim3(1024), 0, s, distinct, B, M, ctl, list);
+        hipLaunchKernelGGL(head_worklist_kernel, dim3(1), dim3(1024), 0, s, distinct, B, M, 32, ctl, list);
         const int64_t tiles = (int64_t)B * tpi;
         const dim3 grid((unsigned)(tiles < head_slots() ? tiles : head_slots())), block(64);
         switch (head_kind) {

@@ -217,6 +217,9 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     const int64_t b = grp / tiles_per_item;
     const int n0 = ((grp % tiles_per_item) * LP_WAVES + wave) * (32 * T);
     LP_STAMP(0);
+    // a crop with a non-finite coordinate: its dconv1 term is NaN (dal3_device.h) -> NaN logits, empty mask below. Read here,
+    // while s_gb holds THIS group's term (the next group's is published in front of dconv4), into a scalar register.
+    const bool crop_bad = (__builtin_amdgcn_readfirstlane(__float_as_int(s_gb[0])) & 0x7F800000) == 0x7F800000;
 
     ActTile<DT> x1[T][2], x2[T][2];
     const int lnA = fresh_lane(), hA = lnA >> 5;          // for the prologue (see fresh_lane)
@@ -509,14 +512,15 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     LP_SUB(7);
 #pragma unroll
     for (int j = 0; j < T; ++j) {
-        const float s0 = accA[j][0], s1 = accA[j][1];      // rows 0, 1 of the tile: lanes 0..31, one point each
+        float s0 = accA[j][0], s1 = accA[j][1];            // rows 0, 1 of the tile: lanes 0..31, one point each
+        if (crop_bad) s0 = s1 = __int_as_float(DAL3_QNAN_BITS);
         const int n = n0 + 32 * j + (lnB & 31);
         if (hB == 0 && n < n_pts) {
             f32x2 o;
             o[0] = s0;
             o[1] = s1;
             *reinterpret_cast<f32x2*>(logits + (b * n_pts + n) * 2) = o;
-            mask[b * n_pts + n] = s0 < s1 ? 1 : 0;
+            mask[b * n_pts + n] = (!crop_bad && s0 < s1) ? 1 : 0;
         }
     }
     LP_STAMP(6);

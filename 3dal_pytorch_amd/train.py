@@ -27,6 +27,11 @@ _MOM = 0.1
 
 _SCRATCH = {}
 
+# Test hook (tests/test_gpu_train_reference.py): when a dict, _InsSeg.forward leaves references to what decides its
+# discrete events there — every layer's pre-BN output and BatchNorm affine (the ReLU gates are relu(z*scale+shift) > 0)
+# and the pooled points — so that a float64 composite can be evaluated AT THE SAME gates. None in production.
+CAPTURE = None
+
 
 def _ws(nbytes, dev):
     """grow-only scratch per (device, stream). Every user enqueues on the current stream and is done with the buffer when its
@@ -515,6 +520,8 @@ class _InsSeg(torch.autograd.Function):
         zl = _linear(a4, W5, 128, 128, 32, bias=b5)
         ctx.saved = (a0, Ws, bns, zs, g, arg, a4, drop, W5, N, [tuple(p.shape) for p in params], zarg, P[17].contiguous(),
                      (a4c, S4, m14))
+        if CAPTURE is not None:
+            CAPTURE["ins_seg"] = {"zs": list(zs), "bns": list(bns), "g": g, "arg": arg, "M": M, "N": N, "B": B}
         return zl[:M, :2].reshape(B, N, 2).contiguous()
 
     @staticmethod

@@ -471,9 +471,10 @@ def test_whole_static_forward_on_tiny_crops_vs_oracle(n):
         assert rel_err(got[k].cpu().numpy(), want[k].numpy()) < TOL, k
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("kind,head,c,B,M", [("static_one", "box_est", 3, 300, 512), ("dynamic", "point_emb", 4, 70, 2560),
                                              ("dynamic", "box_emb", 8, 200, 101)])
-def test_point_head_on_the_live_tile_worklist_equals_the_per_tile_launch_bitwise(kind, head, c, B, M):
+def test_point_head_on_the_live_tile_worklist_equals_the_per_tile_launch_bitwise(kind, head, c, B, M, prec):
     """round 3: large jobs run the point heads as persistent waves over the compacted list of tiles that hold distinct
     points (dal3_point_head_pool with a workspace) instead of one workgroup per (item, tile) (without one). Same
     per-point arithmetic, same atomicMax combine: the pooled features must agree bit for bit — with counts of distinct
@@ -481,7 +482,8 @@ def test_point_head_on_the_live_tile_worklist_equals_the_per_tile_launch_bitwise
     lib = hip.lib()
     model = build_model(kind, synth.state_dict(kind, seed=23))
     mod = getattr(model, head)
-    w = model._cache.get(head, mod, mod.HEAD_KIND, hip.F32)
+    dt = hip.DTYPES[prec]
+    w = model._cache.get(head, mod, mod.HEAD_KIND, dt)
     rng = np.random.default_rng(5)
     x = torch.from_numpy(rng.standard_normal((B, M, c)).astype(np.float32)).cuda()
     special = np.array([0, 1, 31, 32, 33, 63, 64, 65, M - 1, M, M + 7, -3])
@@ -497,19 +499,19 @@ def test_point_head_on_the_live_tile_worklist_equals_the_per_tile_launch_bitwise
     bcn = hip.bcn(xs.transpose(2, 1))
     for distinct in (torch.from_numpy(d_np).cuda(), None):
         f_list, f_tile = torch.empty((B, 512), device="cuda"), torch.empty((B, 512), device="cuda")
-        hip.check(lib.dal3_point_head_pool(mod.HEAD_KIND, hip.ptr(w), hip.F32, bcn, B, M, hip.ptr(distinct), hip.ptr(f_list),
+        hip.check(lib.dal3_point_head_pool(mod.HEAD_KIND, hip.ptr(w), dt, bcn, B, M, hip.ptr(distinct), hip.ptr(f_list),
                                            hip.ptr(ws), ws.numel(), hip.stream()))
-        hip.check(lib.dal3_point_head_pool(mod.HEAD_KIND, hip.ptr(w), hip.F32, bcn, B, M, hip.ptr(distinct), hip.ptr(f_tile),
+        hip.check(lib.dal3_point_head_pool(mod.HEAD_KIND, hip.ptr(w), dt, bcn, B, M, hip.ptr(distinct), hip.ptr(f_tile),
                                            None, 0, hip.stream()))
         torch.cuda.synchronize()
         assert torch.equal(f_list, f_tile)
         assert float(f_list.abs().max()) > 0
     # skipping the copies changes nothing: the run with counts equals the run that computes every point
     f_all = torch.empty((B, 512), device="cuda")
-    hip.check(lib.dal3_point_head_pool(mod.HEAD_KIND, hip.ptr(w), hip.F32, bcn, B, M, None, hip.ptr(f_all), hip.ptr(ws),
+    hip.check(lib.dal3_point_head_pool(mod.HEAD_KIND, hip.ptr(w), dt, bcn, B, M, None, hip.ptr(f_all), hip.ptr(ws),
                                        ws.numel(), hip.stream()))
     f_cnt = torch.empty((B, 512), device="cuda")
-    hip.check(lib.dal3_point_head_pool(mod.HEAD_KIND, hip.ptr(w), hip.F32, bcn, B, M, hip.ptr(torch.from_numpy(d_np).cuda()),
+    hip.check(lib.dal3_point_head_pool(mod.HEAD_KIND, hip.ptr(w), dt, bcn, B, M, hip.ptr(torch.from_numpy(d_np).cuda()),
                                        hip.ptr(f_cnt), hip.ptr(ws), ws.numel(), hip.stream()))
     torch.cuda.synchronize()
     assert torch.equal(f_all, f_cnt)
