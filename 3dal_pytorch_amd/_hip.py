@@ -118,6 +118,7 @@ SIGNATURES = {
     "dal3_tr_linear_pool": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, vp, vp, vp, _i64, _i, vp, vp, vp, _sz, vp]),
     "dal3_tr_segsum": (_i, [vp, _i64, _i64, _i, vp, _i64, vp]),
     "dal3_maxpool_n": (_i, [vp, _i64, _i64, vp, vp]),
+    "dal3_maxpool_n_dtype": (_i, [vp, _i, _i64, _i64, vp, vp]),
     "dal3_shared_mlp_layer": (_i, [C.POINTER(Layer), _i, BCN, _i, _i, vp, vp, _sz, vp]),
     "dal3_shared_mlp_layer_workspace_bytes": (_sz, [_i, _i]),
     "dal3_static_workspace_bytes": (_sz, [_i, _i, _i]),

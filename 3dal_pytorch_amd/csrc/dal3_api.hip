@@ -552,14 +552,22 @@ extern "C" size_t dal3_point_head_workspace_bytes(int B) {
     return c.off;
 }
 
+// dec (optional): the chain ends in a box estimator's 39-wide layer written to dec->box_pred (= out, row stride 39), and
+// that layer is launched together with the decode of its rows (fc39_decode_kernel) instead of on its own
 static int fc_chain(const FcW& f, const float* x, int64_t xs, float* out, int64_t out_stride, int B, float* t1,
-                    float* t2, hipStream_t s) {
+                    float* t2, hipStream_t s, const DecodeArgs* dec = nullptr) {
     const float* cur = x;
     int64_t cs = xs;
     for (int i = 0; i < f.n; ++i) {
         const bool last = i == f.n - 1;
         float* dst = last ? out : (i % 2 == 0 ? t1 : t2);
         const int64_t ds = last ? out_stride : f.c_out[i];
+        if (last && dec) {
+            if (f.c_out[i] != 39 || out_stride != 39 || dec->box_pred != out || f.relu[i])
+                return fail(DAL3_EINVAL, "fc_chain: a fused decode needs the 39-wide box_pred layer last");
+            HIP_TRY(launch_fc39_decode(f.w[i], f.b[i], cur, cs, B, f.c_in[i], *dec, s));
+            return 0;
+        }
         HIP_TRY(launch_fc(f.w[i], f.b[i], cur, cs, dst, ds, B, f.c_in[i], f.c_out[i], f.relu[i], s));
         cur = dst;
         cs = ds;
@@ -568,7 +576,8 @@ static int fc_chain(const FcW& f, const float* x, int64_t xs, float* out, int64_
 }
 
 static int point_head_run(int head_kind, const void* packed, int dtype, const dal3_bcn& x, int B, int M, float* out,
-                          int64_t out_stride, const HeadWs& ws, hipStream_t s, const int32_t* distinct = nullptr) {
+                          int64_t out_stride, const HeadWs& ws, hipStream_t s, const int32_t* distinct = nullptr,
+                          const DecodeArgs* dec = nullptr) {
     TRY(check_dtype(dtype));
     if (head_kind != DAL3_HEAD_STATIC_BOX_EST && head_kind != DAL3_HEAD_POINT_EMB && head_kind != DAL3_HEAD_BOX_EMB)
         return fail(DAL3_EINVAL, "point_head: head_kind %d is not a point head", head_kind);
@@ -577,15 +586,14 @@ static int point_head_run(int head_kind, const void* packed, int dtype, const da
     TRY(check_bcn(x, "x"));
     int c_in, ks, c[4], n_fc, fi[3], fo[3];
     point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
-    HIP_TRY(launch_nonfinite_rows(to_bcn(x), B, M, c_in, ws.feat, 512, s));   // feat = 0 (NaN for an item with a non-finite input)
     if (dtype != DAL3_F32) {
         const PointHeadLpW w = point_head_lp_view(packed, head_kind);
         HIP_TRY(launch_point_head_lp(dtype, head_kind, w, to_bcn(x), c_in, B, M, ws.feat, distinct, s));
-        return fc_chain(w.fc, ws.feat, 512, out, out_stride, B, ws.t1, ws.t2, s);
+        return fc_chain(w.fc, ws.feat, 512, out, out_stride, B, ws.t1, ws.t2, s, dec);
     }
     const PointHeadW w = point_head_view(static_cast<const float*>(packed), head_kind);
     HIP_TRY(launch_point_head(head_kind, w, to_bcn(x), c_in, B, M, ws.feat, distinct, s, ws.work, ws.work_bytes));
-    return fc_chain(w.fc, ws.feat, 512, out, out_stride, B, ws.t1, ws.t2, s);
+    return fc_chain(w.fc, ws.feat, 512, out, out_stride, B, ws.t1, ws.t2, s, dec);
 }
 
 extern "C" int dal3_point_head_forward(int head_kind, const void* packed, int dtype, dal3_bcn x, int B, int M, float* out,
@@ -616,7 +624,6 @@ extern "C" int dal3_point_head_pool(int head_kind, const void* packed, int dtype
     hipStream_t s = static_cast<hipStream_t>(stream);
     int c_in, ks, c[4], n_fc, fi[3], fo[3];
     point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
-    HIP_TRY(launch_nonfinite_rows(to_bcn(x), B, M, c_in, feat, 512, s));
     if (dtype != DAL3_F32) {
         const PointHeadLpW w = point_head_lp_view(packed, head_kind);
         HIP_TRY(launch_point_head_lp(dtype, head_kind, w, to_bcn(x), c_in, B, M, feat, n_distinct, s));
@@ -1049,7 +1056,16 @@ extern "C" int dal3_tr_segsum(const float* x, int64_t ldx, int64_t seg, int C, f
 
 extern "C" int dal3_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, dal3_stream stream) {
     if (!x || !out || rows <= 0 || n <= 0) return fail(DAL3_EINVAL, "maxpool_n: bad argument");
-    HIP_TRY(launch_maxpool_n(x, rows, n, out, static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_maxpool_n(x, DAL3_F32, rows, n, out, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_maxpool_n_dtype(const void* x, int dtype, int64_t rows, int64_t n, void* out, dal3_stream stream) {
+    TRY(check_dtype(dtype));
+    if (!x || !out || rows <= 0 || n <= 0) return fail(DAL3_EINVAL, "maxpool_n: bad argument");
+    if (dtype != DAL3_F32 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 1))
+        return fail(DAL3_EINVAL, "maxpool_n: 16-bit rows must be 2-byte aligned");
+    HIP_TRY(launch_maxpool_n(x, dtype, rows, n, out, static_cast<hipStream_t>(stream)));
     return 0;
 }
 
@@ -1126,26 +1142,31 @@ extern "C" int dal3_static_forward(const dal3_static_args* a, int phases, dal3_s
     const dal3_bcn obj{ws.obj, (int64_t)M * 3, 1, 3};
     // device sampler: the first min(count, M) object points are distinct, the rest are copies -> skipped by the head
     const int32_t* distinct = a->sampler == DAL3_SAMPLER_DEVICE ? a->counts : nullptr;
-    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_one, a->dtype, obj, B, M, a->box_pred_one, 39, ws.head, s, distinct));
+    // (the estimator's last FC layer and the decode of its output are one launch: fc39_decode_kernel)
     if (!a->two_stage) {
         // center = center_boxnet + init_box[:, :3] (static_model.py:132); yaw += init yaw (static_eval.py:280)
-        HIP_TRY(launch_decode_boxes(a->box_pred_one, B, a->init_box, 7, 0, nullptr, 0, a->init_box + 6, 7,
-                                    a->heading_residuals_one, a->size_residuals_one, a->center_one, a->boxes7, s));
+        const DecodeArgs d1{a->box_pred_one, a->init_box, 7, 0, nullptr, 0, a->init_box + 6, 7,
+                            a->heading_residuals_one, a->size_residuals_one, a->center_one, a->boxes7};
+        TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_one, a->dtype, obj, B, M, a->box_pred_one, 39, ws.head, s,
+                           distinct, &d1));
         return 0;
     }
     if (!a->w_box_est_two || !a->box_pred_two || !a->box_one || !a->center_one)
         return fail(DAL3_EINVAL, "static_forward: two_stage needs w_box_est_two, box_pred_two, box_one, center_one");
     // center_one += init_box[:, :3] in place (static_model.py:174); box_one (:176-190)
-    HIP_TRY(launch_decode_boxes(a->box_pred_one, B, a->init_box, 7, 1, nullptr, 0, a->init_box + 6, 7,
-                                a->heading_residuals_one, a->size_residuals_one, a->center_one, a->box_one, s));
+    const DecodeArgs d1{a->box_pred_one, a->init_box, 7, 1, nullptr, 0, a->init_box + 6, 7,
+                        a->heading_residuals_one, a->size_residuals_one, a->center_one, a->box_one};
+    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_one, a->dtype, obj, B, M, a->box_pred_one, 39, ws.head, s,
+                       distinct, &d1));
     HIP_TRY(launch_recenter(ws.obj, B, M, a->init_box, a->box_one, a->bbox_gt, ws.obj2,
                             a->bbox_gt ? a->heading_class_label_two : nullptr,
                             a->bbox_gt ? a->heading_residuals_label_two : nullptr, s));
     const dal3_bcn obj2{ws.obj2, (int64_t)M * 3, 1, 3};
-    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_two, a->dtype, obj2, B, M, a->box_pred_two, 39, ws.head, s, distinct));
     // center_two += center_one (static_model.py:211); final yaw += box_one yaw (static_eval.py:282)
-    HIP_TRY(launch_decode_boxes(a->box_pred_two, B, a->center_one, 3, 1, nullptr, 0, a->box_one + 6, 7,
-                                a->heading_residuals_two, a->size_residuals_two, a->center_two, a->boxes7, s));
+    const DecodeArgs d2{a->box_pred_two, a->center_one, 3, 1, nullptr, 0, a->box_one + 6, 7,
+                        a->heading_residuals_two, a->size_residuals_two, a->center_two, a->boxes7};
+    TRY(point_head_run(DAL3_HEAD_STATIC_BOX_EST, a->w_box_est_two, a->dtype, obj2, B, M, a->box_pred_two, 39, ws.head, s,
+                       distinct, &d2));
     return 0;
 }
 
@@ -1192,10 +1213,10 @@ extern "C" int dal3_dynamic_forward(const dal3_dynamic_args* a, int phases, dal3
     TRY(point_head_run(DAL3_HEAD_POINT_EMB, a->w_point_emb, a->dtype, obj, B, M, a->embedding, 384, ws.head, s,
                        a->sampler == DAL3_SAMPLER_DEVICE ? a->counts : nullptr));
     TRY(point_head_run(DAL3_HEAD_BOX_EMB, a->w_box_emb, a->dtype, a->box, B, a->n_box, a->embedding + 256, 384, ws.head, s));
-    TRY(fc_chain(fc_head_view(static_cast<const float*>(a->w_box_est)), a->embedding, 384, a->box_pred, 39, B,
-                 ws.head.t1, ws.head.t2, s));
     // forward() adds nothing to the centre; the eval driver adds init_box[:, :3] and yaw init_box[:, -2]
-    HIP_TRY(launch_decode_boxes(a->box_pred, B, nullptr, 0, 0, a->init_box8, 8, a->init_box8 ? a->init_box8 + 6 : nullptr,
-                                8, a->heading_residuals, a->size_residuals, nullptr, a->boxes7, s));
+    const DecodeArgs dd{a->box_pred, nullptr, 0, 0, a->init_box8, 8, a->init_box8 ? a->init_box8 + 6 : nullptr, 8,
+                        a->heading_residuals, a->size_residuals, nullptr, a->boxes7};
+    TRY(fc_chain(fc_head_view(static_cast<const float*>(a->w_box_est)), a->embedding, 384, a->box_pred, 39, B,
+                 ws.head.t1, ws.head.t2, s, &dd));
     return 0;
 }

@@ -145,6 +145,7 @@ hipError_t launch_ins_seg_encode(const InsSegW& w, BCN pts, int c_in, int B, int
 hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int N, const float* gbias,
                                  float* logits, uint8_t* mask, hipStream_t s);
 // distinct (B) i32 or NULL: only the first distinct[b] points of item b are distinct (the rest duplicate them)
+// feat (B,512) need NOT be initialised: the launchers zero it (NaN rows for items with non-finite inputs) themselves.
 // worklist (optional, point_head_worklist_bytes(B, M) bytes of device scratch): lets the throughput family run as
 // persistent waves over the compacted list of live tiles (dal3_pointmlp.hip); NULL -> one workgroup per (item, tile)
 size_t point_head_worklist_bytes(int B, int M);
@@ -197,16 +198,36 @@ hipError_t launch_writeback(const double* final_boxes, const int32_t* final_idx,
                             const double* pose_inv, const double* track_box, float* det, const int64_t* det_start,
                             const int32_t* det_count, const uint8_t* active, int P, int64_t n_det, int32_t* match,
                             int32_t* owner, hipStream_t s);
-hipError_t launch_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, hipStream_t s);
+hipError_t launch_maxpool_n(const void* x, int dtype, int64_t rows, int64_t n, void* out, hipStream_t s);
 hipError_t launch_segment_counts(const uint8_t* mask, int B, int N, int32_t* counts, hipStream_t s);
 // p[0..n_words) = value (32-bit words) as a kernel launch; used instead of hipMemsetAsync wherever the call may be
 // captured into a hipGraph (see dal3_misc.hip)
 hipError_t launch_fill_words(void* p, size_t n_words, uint32_t value, hipStream_t s);
 // dst (B, C) = 0, or the quiet-NaN pattern in the rows of items whose input x (B, c_in, n_pts) holds a NaN / Inf
-hipError_t launch_nonfinite_rows(BCN x, int B, int n_pts, int c_in, float* dst, int C, hipStream_t s);
+// distinct / worklist (optional): also build the point heads' worklist (ctl at worklist, entries at worklist + 256)
+hipError_t launch_nonfinite_rows(BCN x, int B, int n_pts, int c_in, float* dst, int C, hipStream_t s,
+                                 const int32_t* distinct = nullptr, void* worklist = nullptr);
 hipError_t launch_compact_sample(const uint8_t* mask, BCN pts, int B, int N, int C, int M, int sampler,
                                  const int32_t* choice, uint64_t seed, int64_t item_offset, int32_t* counts,
                                  int32_t* pos, int32_t* obj_idx, float* obj_pts, hipStream_t s, const int64_t* step = nullptr);
+// arguments of the box decode (dal3_decode_boxes of include/dal3.h), also taken by the fused last-FC + decode launch
+struct DecodeArgs {
+    float* box_pred;
+    const float* center_add;
+    int64_t ca_stride;
+    int center_inplace;
+    const float* boxes_center_add;
+    int64_t bca_stride;
+    const float* yaw_base;
+    int64_t yaw_stride;
+    float* heading_residuals;
+    float* size_residuals;
+    float* center;
+    float* boxes7;
+};
+// box_pred (B,39) = W (39, c_in) x + bias, then the decode of those rows, one launch; box_pred = d.box_pred
+hipError_t launch_fc39_decode(const float* W, const float* bias, const float* x, int64_t xs, int B, int c_in,
+                              const DecodeArgs& d, hipStream_t s);
 hipError_t launch_decode_boxes(float* box_pred, int B, const float* center_add, int64_t center_add_stride,
                                int center_inplace, const float* boxes_center_add, int64_t boxes_center_add_stride,
                                const float* yaw_base, int64_t yaw_stride, float* heading_residuals,

@@ -180,61 +180,106 @@ hipError_t launch_fc(const float* W, const float* bias, const float* x, int64_t 
 }
 
 // ================================================================================== max-pool over N
-// torch.max(x, 2)[0] for contiguous (rows, n) fp32: one wave per row, 16-byte loads coalesced along
-// N (1 KiB per wave-instruction), per-lane running max, then a wave64 butterfly. HBM-bound.
-template <int UNROLL>
-__global__ __launch_bounds__(256) void maxpool_rows_kernel(const float* __restrict__ x, int64_t rows, int64_t n,
-                                                           float* __restrict__ out) {
+// torch.max(x, 2)[0] for contiguous (rows, n): one wave per row, 16-byte loads coalesced along N (1 KiB per
+// wave-instruction: 4 fp32 or 8 bf16 / fp16 values per lane), per-lane running max, then a wave64 butterfly. HBM-bound.
+// A row that holds a NaN gives NaN, as torch.max does (fmaxf alone would drop it): every lane keeps a sticky flag.
+// 16-bit rows: the values are widened exactly (bf16: a 16-bit shift; fp16: v_cvt_f32_f16), compared as fp32 and the
+// maximum — one of the inputs — is narrowed back exactly.
+template <int DT> struct MpElem;                            // DT: DAL3_F32 / DAL3_BF16 / DAL3_F16
+template <> struct MpElem<DAL3_F32> {
+    typedef float T;
+    static constexpr int PER16 = 4;
+    static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
+    }
+    static __device__ __forceinline__ float load1(const T* p) { return *p; }
+    static __device__ __forceinline__ void store1(T* p, float v) { *p = v; }
+};
+template <> struct MpElem<DAL3_BF16> {
+    typedef uint16_t T;
+    static constexpr int PER16 = 8;
+    static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(v[i] << 16);
+            f[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+        }
+    }
+    static __device__ __forceinline__ float load1(const T* p) { return __uint_as_float((uint32_t)*p << 16); }
+    static __device__ __forceinline__ void store1(T* p, float v) { *p = (uint16_t)(__float_as_uint(v) >> 16); }
+};
+template <> struct MpElem<DAL3_F16> {
+    typedef uint16_t T;
+    static constexpr int PER16 = 8;
+    static __device__ __forceinline__ float widen(uint32_t h) {
+        return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+    }
+    static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = widen(v[i] & 0xFFFFu);
+            f[2 * i + 1] = widen(v[i] >> 16);
+        }
+    }
+    static __device__ __forceinline__ float load1(const T* p) { return widen(*p); }
+    static __device__ __forceinline__ void store1(T* p, float v) { *p = __builtin_bit_cast(uint16_t, (_Float16)v); }
+};
+
+template <int DT, int UNROLL, bool VEC>
+__global__ __launch_bounds__(256) void maxpool_rows_kernel(const void* __restrict__ xv, int64_t rows, int64_t n,
+                                                           void* __restrict__ outv) {
+    typedef MpElem<DT> E;
+    typedef typename E::T T;
+    const T* x = static_cast<const T*>(xv);
+    T* out = static_cast<T*>(outv);
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
-    const int64_t n4 = n >> 2;                              // float4 per row (n % 4 == 0 on this path)
     for (int64_t row = wave0; row < rows; row += n_waves) {
-        const f32x4* p = reinterpret_cast<const f32x4*>(x + row * n);
-        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int64_t i = lane;
-        for (; i + (UNROLL - 1) * 64 < n4; i += UNROLL * 64) {
-            f32x4 v[UNROLL];
+        float m = -INFINITY;
+        bool nan = false;
+        if (VEC) {                                          // n % PER16 == 0 and 16-byte aligned base
+            const int64_t nv = n / E::PER16;
+            const u32x4* p = reinterpret_cast<const u32x4*>(x + row * n);
+            float mm[E::PER16];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(p + i + u * 64);
+            for (int k = 0; k < E::PER16; ++k) mm[k] = -INFINITY;
+            auto take = [&](const u32x4& v) {
+                float f[8];
+                E::unpack(v, f);
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                m[0] = fmaxf(m[0], v[u][0]);
-                m[1] = fmaxf(m[1], v[u][1]);
-                m[2] = fmaxf(m[2], v[u][2]);
-                m[3] = fmaxf(m[3], v[u][3]);
+                for (int k = 0; k < E::PER16; ++k) {
+                    nan |= f[k] != f[k];
+                    mm[k] = fmaxf(mm[k], f[k]);
+                }
+            };
+            int64_t i = lane;
+            for (; i + (UNROLL - 1) * 64 < nv; i += UNROLL * 64) {
+                u32x4 v[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(p + i + u * 64);
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) take(v[u]);
+            }
+            for (; i < nv; i += 64) take(__builtin_nontemporal_load(p + i));
+#pragma unroll
+            for (int k = 0; k < E::PER16; ++k) m = fmaxf(m, mm[k]);
+        } else {                                            // any n, any alignment: one element per lane and trip
+            for (int64_t i = lane; i < n; i += 64) {
+                const float f = E::load1(x + row * n + i);
+                nan |= f != f;
+                m = fmaxf(m, f);
             }
         }
-        for (; i < n4; i += 64) {
-            const f32x4 v = __builtin_nontemporal_load(p + i);
-            m[0] = fmaxf(m[0], v[0]);
-            m[1] = fmaxf(m[1], v[1]);
-            m[2] = fmaxf(m[2], v[2]);
-            m[3] = fmaxf(m[3], v[3]);
-        }
-        float r = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) r = fmaxf(r, __shfl_xor(r, off));
-        if (lane == 0) out[row] = r;
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (__any(nan)) m = __uint_as_float(0x7FC00000u);
+        if (lane == 0) E::store1(out + row, m);
     }
 }
 
-// generic fallback (n % 4 != 0 or unaligned base): scalar loads
-__global__ __launch_bounds__(256) void maxpool_rows_scalar_kernel(const float* __restrict__ x, int64_t rows, int64_t n,
-                                                                  float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
-    for (int64_t row = wave0; row < rows; row += n_waves) {
-        float r = -INFINITY;
-        for (int64_t i = lane; i < n; i += 64) r = fmaxf(r, x[row * n + i]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) r = fmaxf(r, __shfl_xor(r, off));
-        if (lane == 0) out[row] = r;
-    }
-}
-
-hipError_t launch_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, hipStream_t s) {
+hipError_t launch_maxpool_n(const void* x, int dtype, int64_t rows, int64_t n, void* out, hipStream_t s) {
     if (rows <= 0 || n <= 0) return hipErrorInvalidValue;
     // one wave per row, as many workgroups as that takes: with the grid capped at 16 workgroups per CU (waves walking
     // 256 rows each) the same kernel read 6.5 TB/s, uncapped 7.1 (one box, (4096, 1024, 1024) fp32) — a wave's next row
@@ -242,9 +287,21 @@ hipError_t launch_maxpool_n(const float* x, int64_t rows, int64_t n, float* out,
     // plain instead of non-temporal loads: 6.5. tools/ab_maxpool.py)
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 0x7fffffff) blocks = 0x7fffffff;
-    const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-    if (vec) hipLaunchKernelGGL(maxpool_rows_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, x, rows, n, out);
-    else hipLaunchKernelGGL(maxpool_rows_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, rows, n, out);
+    const int per16 = dtype == DAL3_F32 ? 4 : 8;
+    const bool vec = (n % per16 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const dim3 grid((unsigned)blocks), block(256);
+#define MP_LAUNCH(DT)                                                                                            \
+    do {                                                                                                         \
+        if (vec) hipLaunchKernelGGL((maxpool_rows_kernel<DT, 4, true>), grid, block, 0, s, x, rows, n, out);    \
+        else hipLaunchKernelGGL((maxpool_rows_kernel<DT, 1, false>), grid, block, 0, s, x, rows, n, out);       \
+    } while (0)
+    switch (dtype) {
+        case DAL3_F32: MP_LAUNCH(DAL3_F32); break;
+        case DAL3_BF16: MP_LAUNCH(DAL3_BF16); break;
+        case DAL3_F16: MP_LAUNCH(DAL3_F16); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef MP_LAUNCH
     return hipGetLastError();
 }
 
@@ -435,8 +492,40 @@ __global__ __launch_bounds__(256) void fill_words_kernel(uint32_t* __restrict__ 
 // the quiet-NaN pattern in all C channels instead of zeros. The pooling kernels combine with an integer atomicMax on the
 // bit pattern, and that pattern is above every finite value's, so the NaN survives the pooling whatever the kernels
 // compute for the item — as torch.max returns NaN for a row that holds one (static_model.py:284,334).
-__global__ __launch_bounds__(256) void nonfinite_rows_kernel(BCN x, int n_pts, int c_in, uint32_t* __restrict__ dst, int C) {
+//
+// With `list` it also builds the point heads' WORKLIST (dal3_pointmlp.hip, point_head_pers_kernel): entry
+// {item, tile, n_eff, 0} for every 32-point tile that holds distinct points (n_eff = min(max(distinct[item], 1),
+// n_pts), or n_pts without `distinct`), items in order; ctl[0] = number of entries, ctl[1] = 0 (the cursor). Every
+// workgroup sums the tile counts of the items in front of its own from `distinct` itself (B ints, L2-resident: 16 per
+// thread at B = 4096) — deterministic, no atomics, nothing to zero beforehand, and no launch of its own.
+__global__ __launch_bounds__(256) void nonfinite_rows_kernel(BCN x, int n_pts, int c_in, uint32_t* __restrict__ dst, int C,
+                                                             const int32_t* __restrict__ distinct,
+                                                             uint32_t* __restrict__ ctl, u32x4* __restrict__ list) {
+    __shared__ int lds_wave[8];
     const int64_t b = blockIdx.x;
+    if (list) {
+        auto eff = [&](int i) {
+            if (!distinct) return n_pts;
+            const int d = distinct[i];
+            return d <= 0 ? 1 : (d < n_pts ? d : n_pts);
+        };
+        int before = 0;
+        for (int i = threadIdx.x; i < (int)b; i += 256) before += (eff(i) + 31) >> 5;
+        before = block_sum(before, lds_wave);
+        const int n_eff = eff((int)b), n_t = (n_eff + 31) >> 5;
+        for (int t = threadIdx.x; t < n_t; t += 256) {
+            u32x4 e;
+            e[0] = (uint32_t)b;
+            e[1] = (uint32_t)t;
+            e[2] = (uint32_t)n_eff;
+            e[3] = 0u;
+            list[before + t] = e;
+        }
+        if (b == gridDim.x - 1 && threadIdx.x == 0) {
+            ctl[0] = (uint32_t)(before + n_t);
+            ctl[1] = 0u;
+        }
+    }
     const float* base = x.data + b * x.sb;
     bool bad = false;
     const int total = n_pts * c_in;
@@ -451,9 +540,12 @@ __global__ __launch_bounds__(256) void nonfinite_rows_kernel(BCN x, int n_pts, i
     const uint32_t v = __syncthreads_or(bad) ? (uint32_t)DAL3_QNAN_BITS : 0u;
     for (int c = threadIdx.x; c < C; c += 256) dst[b * C + c] = v;
 }
-hipError_t launch_nonfinite_rows(BCN x, int B, int n_pts, int c_in, float* dst, int C, hipStream_t s) {
+hipError_t launch_nonfinite_rows(BCN x, int B, int n_pts, int c_in, float* dst, int C, hipStream_t s, const int32_t* distinct,
+                                 void* worklist) {
+    uint32_t* ctl = static_cast<uint32_t*>(worklist);
+    u32x4* list = worklist ? reinterpret_cast<u32x4*>(static_cast<char*>(worklist) + 256) : nullptr;
     hipLaunchKernelGGL(nonfinite_rows_kernel, dim3((unsigned)B), dim3(256), 0, s, x, n_pts, c_in,
-                       reinterpret_cast<uint32_t*>(dst), C);
+                       reinterpret_cast<uint32_t*>(dst), C, distinct, ctl, list);
     return hipGetLastError();
 }
 
@@ -485,20 +577,14 @@ __constant__ double c_mean_size_d[9] = {DAL3_MEAN_SIZE_VALUES};
 // One thread per crop. fp32 where the reference computes in fp32 tensors (parse_output_to_tensors),
 // fp64 where its eval driver computes in NumPy float64 (class2angle / class2size), rounded to fp32
 // on store.
-__global__ void decode_boxes_kernel(float* __restrict__ box_pred, int B, const float* __restrict__ center_add,
-                                    int64_t ca_stride, int center_inplace, const float* __restrict__ boxes_center_add,
-                                    int64_t bca_stride, const float* __restrict__ yaw_base, int64_t yaw_stride,
-                                    float* __restrict__ heading_residuals, float* __restrict__ size_residuals,
-                                    float* __restrict__ center, float* __restrict__ boxes7) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    float* bp = box_pred + (int64_t)b * 39;
+__device__ __forceinline__ void decode_one(const DecodeArgs& d, int b) {
+    float* bp = d.box_pred + (int64_t)b * 39;
     float c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        c[k] = bp[k] + (center_add ? center_add[b * ca_stride + k] : 0.0f);
-        if (center_inplace) bp[k] = c[k];
-        if (center) center[b * 3 + k] = c[k];
+        c[k] = bp[k] + (d.center_add ? d.center_add[b * d.ca_stride + k] : 0.0f);
+        if (d.center_inplace) bp[k] = c[k];
+        if (d.center) d.center[b * 3 + k] = c[k];
     }
     const float hr_scale = (float)(3.14159265358979323846 / 12.0);
     int hc = 0;
@@ -507,7 +593,7 @@ __global__ void decode_boxes_kernel(float* __restrict__ box_pred, int B, const f
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const float hr = bp[15 + i] * hr_scale;
-        if (heading_residuals) heading_residuals[b * 12 + i] = hr;
+        if (d.heading_residuals) d.heading_residuals[b * 12 + i] = hr;
         if (i == 0) hr_sel = hr;
         if (bp[3 + i] > hbest) {                                // first maximum, as np.argmax
             hbest = bp[3 + i];
@@ -528,28 +614,99 @@ __global__ void decode_boxes_kernel(float* __restrict__ box_pred, int B, const f
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         sr[i] = bp[30 + i] * c_mean_size[i];
-        if (size_residuals) size_residuals[b * 9 + i] = sr[i];
+        if (d.size_residuals) d.size_residuals[b * 9 + i] = sr[i];
     }
-    if (!boxes7) return;
+    if (!d.boxes7) return;
     double ang = (double)hc * (2.0 * 3.14159265358979323846 / 12.0) + (double)hr_sel;
     if (ang > 3.14159265358979323846) ang -= 2.0 * 3.14159265358979323846;
-    if (yaw_base) ang += (double)yaw_base[b * yaw_stride];
-    float* o = boxes7 + (int64_t)b * 7;
+    if (d.yaw_base) ang += (double)d.yaw_base[b * d.yaw_stride];
+    float* o = d.boxes7 + (int64_t)b * 7;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        o[k] = c[k] + (boxes_center_add ? boxes_center_add[b * bca_stride + k] : 0.0f);
+        o[k] = c[k] + (d.boxes_center_add ? d.boxes_center_add[b * d.bca_stride + k] : 0.0f);
         o[3 + k] = (float)(c_mean_size_d[sc * 3 + k] + (double)sr[sc * 3 + k]);
     }
     o[6] = (float)ang;
+}
+
+__global__ void decode_boxes_kernel(DecodeArgs d, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) decode_one(d, b);
 }
 
 hipError_t launch_decode_boxes(float* box_pred, int B, const float* center_add, int64_t center_add_stride,
                                int center_inplace, const float* boxes_center_add, int64_t boxes_center_add_stride,
                                const float* yaw_base, int64_t yaw_stride, float* heading_residuals,
                                float* size_residuals, float* center, float* boxes7, hipStream_t s) {
-    hipLaunchKernelGGL(decode_boxes_kernel, dim3((B + 127) / 128), dim3(128), 0, s, box_pred, B, center_add,
-                       center_add_stride, center_inplace, boxes_center_add, boxes_center_add_stride, yaw_base,
-                       yaw_stride, heading_residuals, size_residuals, center, boxes7);
+    const DecodeArgs d{box_pred, center_add, center_add_stride, center_inplace, boxes_center_add, boxes_center_add_stride,
+                       yaw_base, yaw_stride, heading_residuals, size_residuals, center, boxes7};
+    hipLaunchKernelGGL(decode_boxes_kernel, dim3((B + 127) / 128), dim3(128), 0, s, d, B);
+    return hipGetLastError();
+}
+
+// The last FC layer of a box estimator (c_in -> 39, no ReLU) and the decode of its output in ONE launch (round 3: one
+// launch boundary less per call, 7 -> 6 kernels behind the point head of a static call). One workgroup per tile of 32
+// items computes BOTH output tiles (rows 0..31, 32..38) with fc_kernel's own split of the contraction — wave w takes
+// the w-th quarter of K, the partial sums meet in LDS in the same fixed order — so box_pred has the bits fc_kernel
+// gives it; then the tile's first 32 threads decode their items from the rows just written.
+__global__ __launch_bounds__(256) void fc39_decode_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                          const float* __restrict__ x, int64_t xs, int B, int c_in,
+                                                          DecodeArgs d) {
+    __shared__ float red[3][2][16][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
+    const int bt = blockIdx.x;
+    const int item = 32 * bt + (lane & 31);
+    const bool item_ok = item < B;
+    const int row1 = 32 + (lane & 31);
+    const float* wp0 = W + (int64_t)(lane & 31) * c_in + 4 * h;
+    const float* wp1 = W + (int64_t)(row1 < 39 ? row1 : 0) * c_in + 4 * h;     // (rows past 38: row 0, never stored)
+    const float* xp = x + (int64_t)(item_ok ? item : 0) * xs + 4 * h;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = tile_chan(r, h);
+        acc0[r] = wave == 0 ? bias[ch] : 0.0f;
+        acc1[r] = (wave == 0 && 32 + ch < 39) ? bias[32 + ch] : 0.0f;
+    }
+    const int chunk = ((c_in + 31) / 32) * 8;               // fc_kernel's per-wave share of K
+    const int k_end = min(c_in, (wave + 1) * chunk);
+    for (int k0 = wave * chunk; k0 < k_end; k0 += 8) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(wp0 + k0);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(wp1 + k0);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(xp + k0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc0 = mfma32(a0[e], bv[e], acc0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc1 = mfma32(a1[e], bv[e], acc1);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            red[wave - 1][0][r][lane] = acc0[r];
+            red[wave - 1][1][r][lane] = acc1[r];
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && item_ok) {
+        float* yp = d.box_pred + (int64_t)item * 39;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = tile_chan(r, h);
+            yp[ch] = ((acc0[r] + red[0][0][r][lane]) + red[1][0][r][lane]) + red[2][0][r][lane];
+            if (32 + ch < 39) yp[32 + ch] = ((acc1[r] + red[0][1][r][lane]) + red[1][1][r][lane]) + red[2][1][r][lane];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();                                        // the tile's 32 rows of box_pred are visible to the workgroup
+    if (threadIdx.x < 32 && 32 * bt + (int)threadIdx.x < B) decode_one(d, 32 * bt + (int)threadIdx.x);
+}
+
+hipError_t launch_fc39_decode(const float* W, const float* bias, const float* x, int64_t xs, int B, int c_in,
+                              const DecodeArgs& d, hipStream_t s) {
+    if (c_in % 8 != 0 || xs % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fc39_decode_kernel, dim3((unsigned)((B + 31) / 32)), dim3(256), 0, s, W, bias, x, xs, B, c_in, d);
     return hipGetLastError();
 }
 

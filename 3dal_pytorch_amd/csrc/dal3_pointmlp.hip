@@ -256,64 +256,15 @@ __global__ __launch_bounds__(64 * DAL3_WG_WAVES) void point_head_kernel(PointHea
 // points of an item are distinct, so most items have tiles that hold nothing but copies; point_head_kernel above
 // launches a one-wave workgroup for every (item, tile) and lets the dead ones exit — 26 % of the grid on the bench's mix
 // of crops — and every live one pays its own launch, bias preload and cold weight ring for ONE 32-point tile (~90 us).
-// Here a one-workgroup kernel turns `distinct` into the compacted list of (item, tile, points that count) entries, and
+// Here the zero-fill of `feat` also turns `distinct` into the compacted list of (item, tile, points that count) entries, and
 // persistent one-wave workgroups (as many as the chip holds at this register count) take entries from a device-side
 // cursor: no dead workgroups, no relaunch, the weight ring runs on cyclically from tile to tile, and the next entry
 // and its points are fetched while the current tile is computed. Per-point arithmetic and the atomicMax combine are
 // those of point_head_kernel: bit-identical results (tests/test_gpu_parity.py). (The 16-bit heads were given the
 // same list, in groups of 256 points, and timed both ways: 3.52 ms per C3 step either way — their kernel is persistent
 // already and a group of copies is a uniform 1-us skip there — so they keep walking (item, group) pairs.)
-//   ctl[0] = n_live (written by head_worklist_kernel), ctl[1] = cursor (zeroed by it); list[i] = {item, tile, n_eff, 0}
-__global__ __launch_bounds__(1024) void head_worklist_kernel(const int32_t* __restrict__ distinct, int n_items, int n_pts,
-                                                             int tile_pts, uint32_t* __restrict__ ctl,
-                                                             u32x4* __restrict__ list) {
-    __shared__ int s_wave[16];
-    __shared__ int s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < n_items; b0 += 1024) {
-        const int b = b0 + tid;
-        int n_eff = 0, n_t = 0;
-        if (b < n_items) {
-            n_eff = n_pts;
-            if (distinct) {
-                const int d = distinct[b];
-                n_eff = d <= 0 ? 1 : (d < n_pts ? d : n_pts);
-            }
-            n_t = (n_eff + tile_pts - 1) / tile_pts;
-        }
-        int inc = n_t;                                      // inclusive scan over the wave, then over the 16 waves
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(inc, off);
-            if (lane >= off) inc += up;
-        }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        int base = s_base;
-        for (int wv = 0; wv < wave; ++wv) base += s_wave[wv];
-        int total = 0;
-        for (int wv = 0; wv < 16; ++wv) total += s_wave[wv];
-        const int first = base + inc - n_t;
-        for (int t = 0; t < n_t; ++t) {
-            u32x4 e;
-            e[0] = (uint32_t)b;
-            e[1] = (uint32_t)t;
-            e[2] = (uint32_t)n_eff;
-            e[3] = 0u;
-            list[first + t] = e;
-        }
-        __syncthreads();
-        if (tid == 0) s_base += total;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        ctl[0] = (uint32_t)s_base;
-        ctl[1] = 0u;
-    }
-}
-
+//   ctl[0] = n_live, ctl[1] = cursor (zero), list[i] = {item, tile, n_eff, 0}: written by nonfinite_rows_kernel
+//   (dal3_misc.hip), the launch that zero-fills `feat` in front of this kernel anyway
 template <int KS, int C1, int C2, int C3>
 __global__ __launch_bounds__(64) void point_head_pers_kernel(PointHeadW w, BCN x, int c_in, float* __restrict__ feat,
                                                              uint32_t* __restrict__ ctl, const u32x4* __restrict__ list) {
@@ -485,13 +436,17 @@ static bool head_worklist_on() {
 
 hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat,
                              const int32_t* distinct, hipStream_t s, void* worklist, size_t worklist_bytes) {
-    if (lat_use((int64_t)B * ((M + 31) / 32))) return launch_point_head_lat(head_kind, w, x, c_in, B, M, feat, distinct, s);
     constexpr int T = DAL3_HEAD_T;
     const int tpi = (M + 32 * T - 1) / (32 * T);       // one-wave workgroups
-    if (worklist && worklist_bytes >= point_head_worklist_bytes(B, M) && head_worklist_on() && T == 1) {
+    const bool lat = lat_use((int64_t)B * ((M + 31) / 32));
+    const bool pers = !lat && worklist && worklist_bytes >= point_head_worklist_bytes(B, M) && head_worklist_on() && T == 1;
+    // feat = 0 (NaN rows for items with a non-finite input, dal3.h) and, for the persistent kernel, the worklist
+    hipError_t e0 = launch_nonfinite_rows(x, B, M, c_in, feat, 512, s, distinct, pers ? worklist : nullptr);
+    if (e0 != hipSuccess) return e0;
+    if (lat) return launch_point_head_lat(head_kind, w, x, c_in, B, M, feat, distinct, s);
+    if (pers) {
         uint32_t* ctl = static_cast<uint32_t*>(worklist);
         u32x4* list = reinterpret_cast<u32x4*>(static_cast<char*>(worklist) + 256);
-        hipLaunchKernelGGL(head_worklist_kernel, dim3(1), dim3(1024), 0, s, distinct, B, M, 32, ctl, list);
         const int64_t tiles = (int64_t)B * tpi;
         const dim3 grid((unsigned)(tiles < head_slots() ? tiles : head_slots())), block(64);
         switch (head_kind) {

@@ -717,6 +717,9 @@ hipError_t launch_ins_seg_decode_lp(int dtype, const InsSegLpW& w, BCN pts, int 
 hipError_t launch_point_head_lp(int dtype, int head_kind, const PointHeadLpW& w, BCN x, int c_in, int B, int M,
                                 float* feat, const int32_t* distinct, hipStream_t s) {
     const bool bf = dtype == DAL3_BF16;
+    // feat = 0 (NaN rows for items with a non-finite input, include/dal3.h)
+    hipError_t e0 = launch_nonfinite_rows(x, B, M, c_in, feat, 512, s);
+    if (e0 != hipSuccess) return e0;
     switch (head_kind) {
         case DAL3_HEAD_STATIC_BOX_EST:
             return bf ? head_lp<BF16, 2, 128, 128, 256>(w, x, c_in, B, M, feat, distinct, s)

@@ -193,6 +193,10 @@ int dal3_recenter_rotz(const float* obj_pts, int B, int M, const float* init_box
 /* ---- torch.max(x, 2)[0] as a standalone kernel (static_model.py:284,334): x (B,C,N)
  * contiguous fp32 -> out (B,C). The HBM-roofline kernel of BASELINE.json. */
 int dal3_maxpool_n(const float* x, int64_t rows, int64_t n, float* out, dal3_stream stream);
+/* The same for rows stored as DAL3_F32, DAL3_BF16 or DAL3_F16 (BASELINE.json configs C3 / C5: "bf16 storage"; 2-byte rows
+ * move half the bytes: B*C*N*2 + B*C*2): x (rows, n) contiguous in `dtype`, out (rows) in the same dtype. Exact — the
+ * maximum is one of the inputs — and, as torch.max, NaN for a row that holds a NaN (both entries). */
+int dal3_maxpool_n_dtype(const void* x, int dtype, int64_t rows, int64_t n, void* out, dal3_stream stream);
 
 /* ---- crop preparation right before the heads, float64 in, fp32 out ------------------
  * STATICTRACK.__getitem__ (static_model.py:529-546, 568-572) for B tracks at once: points = all frames' points
