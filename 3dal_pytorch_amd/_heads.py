@@ -238,6 +238,13 @@ def as_f32(t, what):
     return t if t.dtype == torch.float32 else t.float()
 
 
+def as_points(t, what):
+    """points / box windows as the library reads them: fp32, or bf16 / fp16 storage IN PLACE (widened exactly inside the
+    kernels' loads — no fp32 copy; include/dal3.h dal3_bcn.dtype); anything else (float64 from a Dataset) becomes fp32"""
+    _hip.require_gpu(t, what)
+    return t if t.dtype in _hip.STORAGE else t.float()
+
+
 def rows_contiguous(t):
     """(B,K) fp32 with contiguous rows (the library takes these as plain (B,K) arrays)."""
     return t if t.is_contiguous() else t.contiguous()

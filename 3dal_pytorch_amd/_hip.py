@@ -29,7 +29,8 @@ class Layer(C.Structure):
 
 
 class BCN(C.Structure):
-    _fields_ = [("data", vp), ("stride_b", C.c_int64), ("stride_c", C.c_int64), ("stride_n", C.c_int64)]
+    _fields_ = [("data", vp), ("stride_b", C.c_int64), ("stride_c", C.c_int64), ("stride_n", C.c_int64),
+                ("dtype", C.c_int32), ("reserved", C.c_int32)]
 
 
 class StaticArgs(C.Structure):
@@ -173,11 +174,15 @@ def require_gpu(t, what):
             "lib3dal_hip.so (no CPU fallback). Move the model and its inputs to the GPU.")
 
 
+STORAGE = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+
 def bcn(t):
-    """logical (B,C,N) fp32 tensor with arbitrary element strides -> dal3_bcn (no copy)."""
-    assert t.dim() == 3 and t.dtype == torch.float32
+    """logical (B,C,N) tensor (fp32, or bf16 / fp16 storage read in place) with arbitrary element strides -> dal3_bcn
+    (no copy)."""
+    assert t.dim() == 3 and t.dtype in STORAGE
     sb, sc, sn = t.stride()
-    return BCN(ptr(t), sb, sc, sn)
+    return BCN(ptr(t), sb, sc, sn, STORAGE[t.dtype], 0)
 
 
 def layer_struct(conv, bn):

@@ -16,11 +16,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// logical (B,C,N) view with element strides (mirrors dal3_bcn of include/dal3.h)
+// logical (B,C,N) view with element strides (mirrors dal3_bcn of include/dal3.h). dtype: how the values are STORED
+// (0 = fp32, 1 = bf16, 2 = fp16, the DAL3_* codes); 16-bit storage is widened exactly on load, in place — no fp32 copy
+// of the points is made (BASELINE.json configs C3 / C5: "bf16 storage"). `data` is typed float* for the common case.
 struct BCN {
     const float* data;
     int64_t sb, sc, sn;
+    int dtype;
 };
+__device__ __forceinline__ float widen_bf16(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ float widen_f16(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// element `idx` (in elements of the stored type) of a BCN view, as fp32
+__device__ __forceinline__ float bcn_value(const BCN& x, int64_t idx) {
+    if (x.dtype == 0) return x.data[idx];
+    const uint16_t v = reinterpret_cast<const uint16_t*>(x.data)[idx];
+    return x.dtype == 1 ? widen_bf16(v) : widen_f16(v);
+}
 
 // channel (within a 32-channel tile) held by accumulator register r in lane half h
 __host__ __device__ constexpr int tile_chan(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -238,15 +249,31 @@ template <int KS, int T>
 __device__ __forceinline__ void load_points(const BCN& x, int64_t b, int n0, int n_pts, int c_in,
                                             float (&in)[T][KS], int lane) {
     const int h = lane >> 5;
+    if (x.dtype == 0) {                                    // fp32 storage (one uniform branch per call)
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            int n = n0 + 32 * j + (lane & 31);
+            n = n < n_pts ? n : n_pts - 1;
+            const float* p = x.data + b * x.sb + (int64_t)n * x.sn;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int c = 2 * s + h;
+                in[j][s] = c < c_in ? p[c * x.sc] : 0.0f;
+            }
+        }
+        return;
+    }
+    const bool bf = x.dtype == 1;                          // bf16 / fp16 storage, widened exactly
 #pragma unroll
     for (int j = 0; j < T; ++j) {
         int n = n0 + 32 * j + (lane & 31);
         n = n < n_pts ? n : n_pts - 1;
-        const float* p = x.data + b * x.sb + (int64_t)n * x.sn;
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(x.data) + b * x.sb + (int64_t)n * x.sn;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int c = 2 * s + h;
-            in[j][s] = c < c_in ? p[c * x.sc] : 0.0f;
+            const uint16_t v = c < c_in ? p[c * x.sc] : (uint16_t)0;
+            in[j][s] = bf ? widen_bf16(v) : widen_f16(v);
         }
     }
 }

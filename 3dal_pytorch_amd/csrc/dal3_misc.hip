@@ -464,8 +464,8 @@ __global__ __launch_bounds__(256) void compact_sample_kernel(const uint8_t* __re
     __threadfence_block();
     for (int k = tid; k < M; k += 256) {
         const int n = idx_b[k];
-        const float* p = pts.data + b * pts.sb + (int64_t)n * pts.sn;
-        for (int c = 0; c < C; ++c) obj_pts[(b * M + k) * C + c] = p[c * pts.sc];
+        const int64_t o = b * pts.sb + (int64_t)n * pts.sn;
+        for (int c = 0; c < C; ++c) obj_pts[(b * M + k) * C + c] = bcn_value(pts, o + c * pts.sc);   // (16-bit points: widened here)
     }
 }
 
@@ -526,15 +526,15 @@ __global__ __launch_bounds__(256) void nonfinite_rows_kernel(BCN x, int n_pts, i
             ctl[1] = 0u;
         }
     }
-    const float* base = x.data + b * x.sb;
+    const int64_t base = b * x.sb;
     bool bad = false;
     const int total = n_pts * c_in;
     if (x.sc == 1 && x.sn == c_in) {                        // point-major storage: the item is one contiguous run
-        for (int i = threadIdx.x; i < total; i += 256) bad |= bits_nonfinite(base[i]);
+        for (int i = threadIdx.x; i < total; i += 256) bad |= bits_nonfinite(bcn_value(x, base + i));
     } else {
         for (int i = threadIdx.x; i < total; i += 256) {
             const int n = i / c_in, c = i - n * c_in;
-            bad |= bits_nonfinite(base[(int64_t)n * x.sn + (int64_t)c * x.sc]);
+            bad |= bits_nonfinite(bcn_value(x, base + (int64_t)n * x.sn + (int64_t)c * x.sc));
         }
     }
     const uint32_t v = __syncthreads_or(bad) ? (uint32_t)DAL3_QNAN_BITS : 0u;

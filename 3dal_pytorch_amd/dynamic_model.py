@@ -15,7 +15,7 @@ from . import _hip, arch
 from .datasets import DYNAMICTRACK                                  # noqa: F401  (the drivers import it from here)
 from .losses import DynamicModelLoss, huber_loss                    # noqa: F401
 from ._heads import (BoxEmbedding, DynamicPointNetEstimation as PointNetEstimation, PackedCache, PackedModelMixin,
-                     PointEmbedding, PointNetInstanceSeg, Workspace, as_f32, dtype_of, numpy_choice, rows_contiguous)
+                     PointEmbedding, PointNetInstanceSeg, Workspace, as_f32, as_points, dtype_of, numpy_choice, rows_contiguous)
 from .static_model import _box_pred, _mask_and_gather, _parse, _seg_logits
 
 NUM_HEADING_BIN = arch.NUM_HEADING_BIN
@@ -51,8 +51,8 @@ class DynamicModel(PackedModelMixin, nn.Module):
 
     def _run(self, pts, box, init_box8=None, choice=None, mask_override=None):
         lib = _hip.lib()
-        pts = as_f32(pts, "pts")
-        box = as_f32(box, "box")
+        pts = as_points(pts, "pts")
+        box = as_points(box, "box")
         if init_box8 is not None:
             init_box8 = rows_contiguous(as_f32(init_box8, "init_box"))
         if pts.dim() != 3 or pts.shape[1] != 4:

@@ -23,7 +23,7 @@ from . import train as _train
 from .datasets import STATICTRACK                                   # noqa: F401  (the drivers import it from here)
 from .losses import FrustumPointNetLossOneBoxEst, FrustumPointNetLossTwoBoxEst, huber_loss   # noqa: F401
 from ._heads import (PackedCache, PackedModelMixin, PointNetInstanceSeg, StaticPointNetEstimation as PointNetEstimation,
-                     Workspace, as_f32, dtype_of, numpy_choice, rows_contiguous)
+                     Workspace, as_f32, as_points, dtype_of, numpy_choice, rows_contiguous)
 
 NUM_HEADING_BIN = arch.NUM_HEADING_BIN
 NUM_SIZE_CLUSTER = arch.NUM_SIZE_CLUSTER
@@ -53,7 +53,7 @@ class _StaticBase(PackedModelMixin, nn.Module):
     # ------------------------------------------------------------------ HIP path
     def _run(self, pts, init_box, bbox_gt, choice=None, mask_override=None):
         lib = _hip.lib()
-        pts = as_f32(pts, "pts")
+        pts = as_points(pts, "pts")
         init_box = rows_contiguous(as_f32(init_box, "init_box"))
         if bbox_gt is not None:
             bbox_gt = rows_contiguous(as_f32(bbox_gt, "bbox_gt"))

@@ -85,13 +85,20 @@ def recentre(model, fwd):
     model.invalidate_packed()
 
 
+def storage_of(precision):
+    """how a workload's points (and box windows) are STORED on the device: BASELINE.json's 16-bit configurations say
+    "bf16 storage" (C3: bf16 arithmetic; C5: bf16 storage, fp16 MFMA), the fp32 ones fp32. The kernels read either in
+    place (dal3_bcn.dtype); no fp32 copy of 16-bit points is made."""
+    return torch.float32 if precision == "fp32" else torch.bfloat16
+
+
 def make_static(B, N, dev, first, precision="fp32", two=False):
     pts_np, init_np, gt_np = synth.static_crops(B, N, first=first)
     model = sm.StaticModelTwoBoxEst() if two else sm.StaticModelOneBoxEst()
     sd = synth.state_dict("static_two" if two else "static_one")
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
     model = model.to(dev).eval()
-    pts = torch.from_numpy(pts_np).to(dev).transpose(2, 1)          # the callers' layout (static_eval.py:265)
+    pts = torch.from_numpy(pts_np).to(dev).to(storage_of(precision)).transpose(2, 1)   # the callers' layout (static_eval.py:265)
     init, gt = torch.from_numpy(init_np).to(dev), torch.from_numpy(gt_np).to(dev)
     recentre(model, lambda: model(pts, init, gt))
     replicate_weights(model)
@@ -100,16 +107,17 @@ def make_static(B, N, dev, first, precision="fp32", two=False):
     return model, (pts, init, gt), (pts_np, init_np, sd)
 
 
-def static_inputs(first, count, N, dev):
+def static_inputs(first, count, N, dev, precision="fp32"):
     """refine() arguments for the global crops [first, first + count): what the rank that owns them holds"""
     pts_np, init_np, gt_np = synth.static_crops(count, N, first=first)
-    return (torch.from_numpy(pts_np).to(dev).transpose(2, 1), torch.from_numpy(init_np).to(dev),
+    return (torch.from_numpy(pts_np).to(dev).to(storage_of(precision)).transpose(2, 1), torch.from_numpy(init_np).to(dev),
             torch.from_numpy(gt_np).to(dev))
 
 
-def dynamic_inputs(first, count, n_per_frame, dev):
+def dynamic_inputs(first, count, n_per_frame, dev, precision="fp32"):
     pts_np, box_np, init8_np, _ = synth.dynamic_items(count, n_per_frame=n_per_frame, first=first)
-    return (torch.from_numpy(pts_np).to(dev).transpose(2, 1), torch.from_numpy(box_np).to(dev).transpose(2, 1),
+    st = storage_of(precision)
+    return (torch.from_numpy(pts_np).to(dev).to(st).transpose(2, 1), torch.from_numpy(box_np).to(dev).to(st).transpose(2, 1),
             torch.from_numpy(init8_np).to(dev))
 
 
@@ -127,8 +135,8 @@ def make_dynamic(B, dev, first, precision="fp32", n_per_frame=1024):
     model = dm.DynamicModel()
     model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict("dynamic").items()})
     model = model.to(dev).eval()
-    pts = torch.from_numpy(pts_np).to(dev).transpose(2, 1)
-    box = torch.from_numpy(box_np).to(dev).transpose(2, 1)
+    pts = torch.from_numpy(pts_np).to(dev).to(storage_of(precision)).transpose(2, 1)
+    box = torch.from_numpy(box_np).to(dev).to(storage_of(precision)).transpose(2, 1)
     init8 = torch.from_numpy(init8_np).to(dev)
     recentre(model, lambda: model(pts, box, None))
     replicate_weights(model)
@@ -230,24 +238,25 @@ def kernel_table(model, inputs, static, B, N, iters):
     return out, float(cnt.mean())
 
 
-def maxpool_roofline(dev, iters):
+def maxpool_roofline(dev, iters, dtype=torch.float32):
     """The standalone N-axis max-pool (the HBM-roofline kernel) timed three ways: `achieved` from single launches, each
     between two device fences with HIP events around that one launch; `back_to_back` from HIP events around `iters`
     launches queued behind each other; `host_clock` from the host's clock around a fenced run of launches. (VERDICT r2:
     rocprofv3's kernel trace reads ~6 % longer per launch than the events do in the same process; three clocks that
     agree with each other say which side the difference is on — DESIGN.md 5.)"""
     rows, n = 4096 * 1024, 1024
+    es = torch.empty((), dtype=dtype).element_size()        # SURVEY 8(d): bytes = B*C*N*s + B*C*s, s = 4 (fp32) / 2 (bf16, fp16)
     try:
-        x = torch.empty((rows, n), device=dev)
+        x = torch.empty((rows, n), device=dev, dtype=dtype)
     except RuntimeError:
         rows = 1024 * 1024
-        x = torch.empty((rows, n), device=dev)
+        x = torch.empty((rows, n), device=dev, dtype=dtype)
     x.normal_()
-    out = torch.empty(rows, device=dev)
+    out = torch.empty(rows, device=dev, dtype=dtype)
     lib = hip.lib()
 
     def run():
-        hip.check(lib.dal3_maxpool_n(hip.ptr(x), rows, n, hip.ptr(out), hip.stream()))
+        hip.check(lib.dal3_maxpool_n_dtype(hip.ptr(x), hip.STORAGE[dtype], rows, n, hip.ptr(out), hip.stream()))
     t_b2b = events_ms(run, iters)
     single = []
     for _ in range(max(iters, 5)):
@@ -268,12 +277,13 @@ def maxpool_roofline(dev, iters):
         run()
     torch.cuda.synchronize()
     t_wall = (time.perf_counter() - w0) / n_wall * 1e3
-    nbytes = rows * n * 4 + rows * 4
+    nbytes = rows * n * es + rows * es
     gbs = nbytes / (t * 1e-3) / 1e9
     gbs_b2b = nbytes / (t_b2b * 1e-3) / 1e9
     ok = bool(torch.equal(out[:4096], x[:4096].max(1)[0]))
     del x
-    return {"kernel": "maxpool_rows_kernel", "shape": [rows // 1024, 1024, n], "bound": "hbm", "ms": round(t, 4),
+    return {"kernel": "maxpool_rows_kernel", "shape": [rows // 1024, 1024, n], "storage": str(dtype).replace("torch.", ""),
+            "bound": "hbm", "ms": round(t, 4),
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "timing": "median of single launches, each between two device fences (= the kernel's own duration)",
             "ms_min": round(single[0], 4),
@@ -442,10 +452,10 @@ def build_workload(args, dev, rank, world):
         dmodel, din = make_dynamic(max(d_hi - d_lo, 1), dev, d_lo, prec)
         wl.parts = [Part("static", smodel, sin, s_hi - s_lo, n_static,
                          lambda r: (lambda lo, hi: (lo, hi - lo))(*dal3_dist.shard_range(n_static, r, world)),
-                         lambda first, count: static_inputs(first, count, 4096, dev)),
+                         lambda first, count: static_inputs(first, count, 4096, dev, prec)),
                     Part("dynamic", dmodel, din, d_hi - d_lo, n_dyn,
                          lambda r: (lambda lo, hi: (lo, hi - lo))(*dal3_dist.shard_range(n_dyn, r, world)),
-                         lambda first, count: dynamic_inputs(first, count, 1024, dev))]
+                         lambda first, count: dynamic_inputs(first, count, 1024, dev, prec))]
         wl.model, wl.inputs, wl.host, wl.static = smodel, None, None, False
         wl.B, wl.N = (s_hi - s_lo) + (d_hi - d_lo), 0
         wl.n_total = n_static + n_dyn
@@ -472,8 +482,8 @@ def build_workload(args, dev, rank, world):
         desc = (f"DynamicModel forward+decode, {B} items x {N} pts + 101 boxes per GPU, {prec} arithmetic"
                 + (" (BASELINE.json configs[2])" if (B, N, prec) == (1024, 5120, "bf16") else ""))
     wl.parts = [Part("static" if static else "dynamic", model, inputs, B, B * world, lambda r: (r * B, B),
-                     (lambda first, count: static_inputs(first, count, N, dev)) if static else
-                     (lambda first, count: dynamic_inputs(first, count, args.points, dev)))]
+                     (lambda first, count: static_inputs(first, count, N, dev, prec)) if static else
+                     (lambda first, count: dynamic_inputs(first, count, args.points, dev, prec)))]
     wl.model, wl.inputs, wl.host, wl.static = model, inputs, host, static
     wl.B, wl.N, wl.n_total, wl.flop_item, wl.scaling, wl.desc = B, N, B * world, flop_item, "weak", desc
     return wl
@@ -690,6 +700,7 @@ def main():
                     help="arithmetic of the shared-MLP kernels (fp32 = the reference's; bf16/fp16 = configs C3/C5)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / maxpool / configs / cpu_baseline legs")
     ap.add_argument("--only-maxpool", action="store_true", help="run only the standalone max-pool kernel (profiling)")
+    ap.add_argument("--maxpool-storage", default="fp32", choices=["fp32", "bf16", "fp16"], help="row storage for --only-maxpool")
     ap.add_argument("--serial-gather", action="store_true", help="wait for each step's all-gather inside the step")
     ap.add_argument("--streams", type=int, default=1,
                     help="run consecutive steps on this many HIP streams (graph.StreamPipe): small batches, one GPU")
@@ -758,7 +769,8 @@ def main():
             torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     if args.only_maxpool:
-        rec = {"maxpool": maxpool_roofline(dev, iters=args.steps)}
+        rec = {"maxpool": maxpool_roofline(dev, iters=args.steps, dtype={"fp32": torch.float32, "bf16": torch.bfloat16,
+                                                                            "fp16": torch.float16}[args.maxpool_storage])}
         os.write(real_stdout, (json.dumps(rec) + "\n").encode())
         return
 
@@ -839,6 +851,7 @@ def main():
                                         "kernels": k2}
             model.precision = args.precision
         rec["maxpool"] = maxpool_roofline(dev, iters=5)
+        rec["maxpool_bf16"] = maxpool_roofline(dev, iters=5, dtype=torch.bfloat16)     # the same rows in 2-byte storage (C3 / C5)
         if static and args.precision == "fp32" and (B, N) == (4096, 1024) and not two_stage(args):
             rec["torch_gpu_baseline"] = torch_gpu_baseline(model, inputs)
             rec["cpu_baseline"] = cpu_baseline(wl.host)

@@ -89,10 +89,15 @@ int dal3_pack_weights(int head_kind, const dal3_layer* layers, int n_layers, int
 
 /* logical (B, C, N) tensor with element strides: the callers hand pts.transpose(2,1) of a
  * point-major buffer, i.e. strides (N*C, 1, C) (static_eval.py:265); contiguous (C*N, N, 1)
- * is accepted too. */
+ * is accepted too. dtype = how the values are STORED: DAL3_F32 (0, what a zero-initialised struct says), DAL3_BF16 or
+ * DAL3_F16 — 16-bit points / box windows (BASELINE.json configs C3, C5: "bf16 storage") are read in place and widened
+ * exactly in the kernels' loads, no fp32 copy is made; `data` then points at 2-byte elements and the strides count
+ * those. Independent of the arithmetic dtype of the packed weights. Outputs are fp32 whatever the storage. */
 typedef struct {
     const float* data;
     int64_t stride_b, stride_c, stride_n;
+    int32_t dtype;
+    int32_t reserved;
 } dal3_bcn;
 
 /* ---- PointNetInstanceSeg.forward (static_model.py:271-296, dynamic_model.py:187-212) plus

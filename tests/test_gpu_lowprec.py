@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from _common import build_model, positions_from_indices, rel_err, synth
+from _common import build_model, positions_from_indices, recentred_sd, rel_err, synth
 from oracle import ref_heads as R
 
 hip = importlib.import_module("3dal_pytorch_amd._hip")
@@ -223,3 +223,75 @@ def test_persistent_groups_equal_single_group_launches(kind, n):
     if kind != "dynamic":
         counts = whole["counts"].cpu().numpy()
         assert (counts < 256).any() and (counts > 256).any()                              # both head paths: tile skipped / not
+
+
+# ------------------------------------------------------------------ 16-bit STORAGE of points and box windows (round 3)
+@pytest.mark.parametrize("store", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,N", [(5, 512), (40, 1024)])      # latency family / throughput family
+def test_static_points_stored_in_16_bits_are_read_in_place(store, prec, B, N):
+    """configs C3 / C5 say "bf16 storage": points handed over as bf16 / fp16 tensors are read by the kernels as they are
+    (dal3_bcn.dtype) and widened exactly in the loads — so the call must give, bit for bit, what it gives on the fp32
+    copy of the same rounded points, and no fp32 copy may be made on the way."""
+    pts_np, init_np, gt_np = synth.static_crops(B, N, seed=91)
+    sd = recentred_sd("static_two", pts_np[:2], seed=91)
+    model = build_model("static_two", sd)
+    model.precision = prec
+    p16 = torch.from_numpy(pts_np).cuda().to(store)            # (B,N,3) point-major 16-bit storage
+    init, gt = torch.from_numpy(init_np).cuda(), torch.from_numpy(gt_np).cuda()
+    seen = {}
+    bcn = hip.bcn
+
+    def spy(t):
+        seen[t.dtype] = seen.get(t.dtype, 0) + 1
+        return bcn(t)
+    hip.bcn = spy
+    try:
+        a = model._run(p16.transpose(2, 1), init, gt)
+    finally:
+        hip.bcn = bcn
+    assert store in seen and torch.float32 not in seen, seen   # the 16-bit tensor itself went to the library
+    b = model._run(p16.float().transpose(2, 1), init, gt)
+    for k in ("logits", "mask", "counts", "obj_idx", "bp1", "box_one", "bp2", "boxes7"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["logits"].dtype == torch.float32
+
+
+@pytest.mark.parametrize("store", [torch.bfloat16, torch.float16])
+def test_dynamic_points_and_box_windows_stored_in_16_bits(store):
+    B = 12
+    p, bx, i8, gt = synth.dynamic_items(B, n_per_frame=256, seed=92)
+    sd = recentred_sd("dynamic", p[:1], seed=92)
+    model = build_model("dynamic", sd)
+    p16, b16 = torch.from_numpy(p).cuda().to(store), torch.from_numpy(bx).cuda().to(store)
+    init = torch.from_numpy(i8).cuda()
+    for prec in ("fp32", "bf16", "fp16"):
+        model.precision = prec
+        a = model.refine(p16.transpose(2, 1), b16.transpose(2, 1), init).clone()
+        b = model.refine(p16.float().transpose(2, 1), b16.float().transpose(2, 1), init)
+        assert torch.equal(a, b), prec
+    # a contiguous (B,C,N) 16-bit tensor goes through the strides like the point-major one
+    c = model.refine(p16.transpose(2, 1).contiguous(), b16.transpose(2, 1).contiguous(), init)
+    assert torch.equal(c, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,n", [(4096, 1024), (1000, 1000), (37, 1023), (5, 3), (64, 5120), (3, 101)])
+def test_maxpool_over_rows_of_any_storage_is_exact_and_propagates_nan(dtype, rows, n):
+    """dal3_maxpool_n_dtype: exact for fp32 / bf16 / fp16 rows (the maximum is one of the inputs), NaN for a row that
+    holds one (torch.max), -inf / +inf are ordinary values"""
+    x = torch.from_numpy(synth.normal(3, f"mp{rows}x{n}", (rows, n)).astype(np.float32)).cuda().to(dtype)
+    x[0, n // 2] = float("nan")
+    if rows > 2:
+        x[1, :] = float("-inf")
+        x[2, n - 1] = float("inf")
+    out = torch.empty(rows, dtype=dtype, device="cuda")
+    hip.check(hip.lib().dal3_maxpool_n_dtype(hip.ptr(x), hip.STORAGE[dtype], rows, n, hip.ptr(out), hip.stream()))
+    want = x.float().max(1)[0]
+    got = out.float()
+    assert bool(torch.isnan(got[0])) and bool(torch.isnan(want[0]))
+    assert torch.equal(got[1:], want[1:])
+    if dtype == torch.float32:                                  # the fp32 entry is the same kernel
+        out2 = torch.empty(rows, device="cuda")
+        hip.check(hip.lib().dal3_maxpool_n(hip.ptr(x), rows, n, hip.ptr(out2), hip.stream()))
+        assert torch.equal(out2[1:], want[1:]) and bool(torch.isnan(out2[0]))
