@@ -18,8 +18,8 @@ tag, src = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(root, "profiles")
 os.makedirs(out_dir, exist_ok=True)
-OURS = ("ins_seg_", "point_head_kernel", "maxpool_rows", "fc_kernel", "compact_sample", "decode_boxes",
-        "segment_counts", "recenter_kernel", "pack_", "generic_layer", "tr_", "fill_words", "lat_kernel")
+OURS = ("ins_seg_", "point_head_", "maxpool_rows", "fc_kernel", "fc39_decode", "compact_sample", "decode_boxes",
+        "segment_counts", "recenter_kernel", "pack_", "generic_layer", "tr_", "fill_words", "lat_kernel", "nonfinite_rows")
 
 
 def short(name):
@@ -27,7 +27,8 @@ def short(name):
 
 
 for sub, sfx in (("prof_kt", ""), ("prof_kt_bf16", "_bf16"), ("prof_kt_c3", "_c3"), ("prof_kt_c5", "_c5"),
-                 ("prof_kt_maxpool", "_maxpool"), ("prof_kt_train", "_train")):
+                 ("prof_kt_maxpool", "_maxpool"), ("prof_kt_maxpool_bf16", "_maxpool_bf16"), ("prof_kt_b64", "_b64"),
+                 ("prof_kt_train", "_train")):
     stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
     if not stats:
         continue
@@ -37,9 +38,51 @@ for sub, sfx in (("prof_kt", ""), ("prof_kt_bf16", "_bf16"), ("prof_kt_c3", "_c3
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows:
-            if any(k in r["Name"] for k in OURS) or float(r["Percentage"]) > 0.5:
+            if sfx == "_train" or any(k in r["Name"] for k in OURS) or float(r["Percentage"]) > 0.5:
                 w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                             r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+def collect(dirs, keep=lambda d, k: True):
+    acc = defaultdict(lambda: defaultdict(list))
+    for d in dirs:
+        for fn in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(fn)):
+                k = short(r["Kernel_Name"])
+                if not any(o in k for o in OURS) or not keep(d, k):
+                    continue
+                acc[k][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"]),
+                                                  int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return acc
+
+
+def summarise(acc):
+    out = {}
+    for k, ctrs in acc.items():
+        s = {}
+        for c, vals in ctrs.items():
+            gmax = max(g for g, _, _ in vals)
+            full = [(v, t) for g, v, t in vals if g == gmax]      # full-size launches only
+            s[c] = sum(v for v, _ in full) / len(full)
+            s.setdefault("launches", len(full))
+            s[f"avg_ns_under_{c}"] = sum(t for _, t in full) / len(full)
+        out[k] = s
+    return out
+
+
+# the 16-bit configurations at their own shapes (bench.py --config C3 / C5): <tag>_pmc_c3.json, <tag>_pmc_c5.json
+for cfg in ("c3", "c5"):
+    acc = collect([f"prof_mfma_{cfg}"])
+    if acc:
+        json.dump(summarise(acc), open(os.path.join(out_dir, f"{tag}_pmc_{cfg}.json"), "w"), indent=1, sort_keys=True)
+# the max-pool on bf16 rows: its own file (same kernel name as the fp32 run)
+acc = collect(["prof_fetch_maxpool_bf16", "prof_write_maxpool_bf16"])
+if acc:
+    sm = summarise(acc)
+    for k, s in sm.items():
+        if "FETCH_SIZE" in s and "WRITE_SIZE" in s:
+            s["hbm_read_bytes_corrected"] = s["FETCH_SIZE"] * 1024 * 2
+            s["hbm_write_bytes"] = s["WRITE_SIZE"] * 1024
+    json.dump(sm, open(os.path.join(out_dir, f"{tag}_pmc_maxpool_bf16.json"), "w"), indent=1, sort_keys=True)
 
 pmc = defaultdict(lambda: defaultdict(list))
 for d in ("prof_fetch", "prof_write", "prof_mfma", "prof_fetch_bf16", "prof_write_bf16", "prof_mfma_bf16",

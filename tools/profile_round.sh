@@ -1,10 +1,10 @@
 #!/bin/bash
-# tools/profile_round.sh [TAG] — run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r02'): the bench line plus
+# tools/profile_round.sh [TAG] — run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r03'): the bench line plus
 # the rocprofv3 passes whose summaries tools/prof_summary.py condenses into profiles/. Counters are collected in their
 # own passes (never together with a trace domain), as /opt/skills/guides/MI355X_MICROARCH.md prescribes. The program
 # after `--` is python3 itself (no env / bash -c hop: the profiler's preload has initialised the GPU by then).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
@@ -20,8 +20,16 @@ rocprofv3 $KT -d $O/prof_kt_train -o kt -- python3 $R/tools/bench_train.py --bac
 python3 $R/tools/bench_train.py --sampler device > $O/bench_train.json 2>/dev/null
 python3 $R/tools/bench_train.py --kind dynamic --sampler device > $O/bench_train_dynamic.json 2>/dev/null
 python3 $R/tools/bench_latency.py > $O/bench_latency.json 2>/dev/null
-# the HBM-roofline kernel on its own: kernel trace, then FETCH_SIZE and WRITE_SIZE in separate passes
+# the reference's own eval batch (64 crops x 4096 points): where the small kernels between the three big ones show
+rocprofv3 $KT -d $O/prof_kt_b64 -o kt -- python3 $R/bench.py --no-extras --batch 64 --points 4096 --steps 20 --warmup 3 > $O/bench_b64_under_rocprof.json 2>/dev/null
+# the N > 1 path rehearsed on this box's one GPU: two ranks on device 0, boxes gathered over gloo through pinned host memory
+DAL3_BENCH_SHARE_GPU=1 DAL3_BENCH_BACKEND=gloo python3 $R/bench.py --gpus 2 --steps 10 --warmup 3 > $O/bench_rehearsal_2ranks.json 2>/dev/null
+DAL3_BENCH_SHARE_GPU=1 DAL3_BENCH_BACKEND=gloo python3 $R/bench.py --gpus 2 --config C4 --steps 2 --warmup 1 --no-extras > $O/bench_rehearsal_2ranks_c4.json 2>/dev/null
+# the HBM-roofline kernel on its own: kernel trace, then FETCH_SIZE and WRITE_SIZE in separate passes (fp32 rows, then bf16 rows)
 rocprofv3 $KT -d $O/prof_kt_maxpool -o kt -- python3 $R/bench.py --only-maxpool --steps 10 > $O/bench_maxpool_under_rocprof.json 2>/dev/null
+rocprofv3 $KT -d $O/prof_kt_maxpool_bf16 -o kt -- python3 $R/bench.py --only-maxpool --maxpool-storage bf16 --steps 10 > $O/bench_maxpool_bf16_under_rocprof.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch_maxpool_bf16 -o c -- python3 $R/bench.py --only-maxpool --maxpool-storage bf16 --steps 3 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write_maxpool_bf16 -o c -- python3 $R/bench.py --only-maxpool --maxpool-storage bf16 --steps 3 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch_maxpool -o c -- python3 $R/bench.py --only-maxpool --steps 3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write_maxpool -o c -- python3 $R/bench.py --only-maxpool --steps 3 > /dev/null 2>&1
 for P in fp32 bf16; do
@@ -29,6 +37,11 @@ for P in fp32 bf16; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch$S -o c -- python3 $R/bench.py --no-extras --precision $P --steps 3 --warmup 1 > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write$S -o c -- python3 $R/bench.py --no-extras --precision $P --steps 3 --warmup 1 > /dev/null 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_mfma$S -o c -- python3 $R/bench.py --no-extras --precision $P --steps 3 --warmup 1 > /dev/null 2>&1
+done
+# the 16-bit configurations at their own shapes: MFMA-busy and the clock the chip holds (GRBM_GUI_ACTIVE / 8 / kernel time)
+for CFG in C3 C5; do
+  L=$(echo $CFG | tr A-Z a-z)
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_mfma_$L -o c -- python3 $R/bench.py --no-extras --config $CFG --steps 3 --warmup 1 > /dev/null 2>&1
 done
 python3 $R/tools/prof_summary.py $TAG $O > $O/prof_summary.log 2>&1
 cp $R/profiles/${TAG}_* $R/profiles/traffic.json $O/ 2>/dev/null
