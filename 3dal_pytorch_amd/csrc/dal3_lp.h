@@ -140,6 +140,7 @@ __device__ __forceinline__ void lds_dma16(const char* gbase, uint32_t lane_off, 
 template <int SEG, int SLOTS = LP_SLOTS>
 struct LdsRing {
     static_assert(SLOTS == 2 || SLOTS == 3, "SLOTS - 1 segments are in flight ahead of the one in use");
+    static constexpr int N_SLOTS = SLOTS;
     static constexpr int SLOT_BYTES = SEG * 1024;
     static constexpr int MY_LOADS = SEG / 4;              // LDS-DMA instructions per wave per segment (4 waves)
     static_assert(SEG % 4 == 0, "segment must split evenly over the 4 waves");
@@ -408,10 +409,19 @@ __device__ __forceinline__ void lp_tile_max_t(const f32x16 (&acc)[T], const floa
 // group's MFMAs. (Taken in one piece in front of a segment, wait + barrier + refill + first reads cost ~1,100 cycles
 // with the matrix pipe idle.) After the layer's last segment the ring is one segment ahead, which is what a following
 // layer's acquire() or the next group of a persistent kernel expects... so the caller must not acquire again.
-template <class DT, int KT, int T, int SEG, int TPS, bool FIRST, class Ring>
+// Round 3 (three-slot rings only): PEND_IN / DEFER_OUT spread a refill over a whole segment instead of the 8 consecutive
+// gaps behind the barrier. With DEFER_OUT the call opens the next segment as before (wait + barrier) but does NOT issue
+// the refill of the slot it frees; the following call, instantiated with PEND_IN, issues that refill's ML parts one per
+// group of four fragments, in the gap behind the group's second MFMA (groups 0 .. NG-2: all of them before its own
+// acquire_wait, whose counted vmcnt takes exactly ML younger loads to be in flight). The third slot gives the refill a
+// whole further segment to land. A layer's last call is not DEFER_OUT, so the ring is in its usual state when the layer
+// is left.
+template <class DT, int KT, int T, int SEG, int TPS, bool FIRST, bool PEND_IN = false, bool DEFER_OUT = false, class Ring>
 __device__ __forceinline__ void lp_max_tiles(Ring& ring, const ActTile<DT> (&X)[T][KT], const float* bias,
                                              int* smax, int lane, typename DT::v8 (&g)[2][4], f32x16 (&acc)[2][T]) {
     constexpr int FPT = KT * 2, NG = TPS * FPT / 4, ML = Ring::MY_LOADS;
+    static_assert(!(PEND_IN || DEFER_OUT) || Ring::N_SLOTS == 3, "a deferred refill needs the third slot");
+    static_assert(!PEND_IN || (NG >= 4 && ML <= 4 * (NG / 2 - 1)), "the pending refill's parts must fit the odd groups in front of the last one");
     static_assert(FPT % 8 == 0, "at least two groups of four fragments per tile");
     static_assert(NG % 2 == 0 && TPS % 2 == 0, "the carried group must be g[0], the carried tile acc[1]");
     static_assert(ML <= 4 * T * 2, "two refill parts per MFMA gap at most");
@@ -451,12 +461,25 @@ __device__ __forceinline__ void lp_max_tiles(Ring& ring, const ActTile<DT> (&X)[
 #pragma unroll
                         for (int q = 0; q < 4; ++q) g[0][q] = ring.template frag<DT>(q);
                     }
-                    lp_refill_gap<SEG, 4 * T>(ring, n);
+                    if (!DEFER_OUT) lp_refill_gap<SEG, 4 * T>(ring, n);
                     DAL3_SCHED_FENCE();
+                } else if (PEND_IN && (gi & 1) && j == 1) {
+                    // the previous call's refill: the ODD groups (an even group's MFMAs are the ones a tile's max
+                    // epilogue is interleaved with) take PER parts each, one behind the second MFMA of a fragment
+                    constexpr int ODD = NG / 2 - 1;        // odd groups in front of the last one
+                    constexpr int PER = (ML + ODD - 1) / ODD;
+                    static_assert(PER <= 4, "one part per fragment of a group");
+                    const int part = (gi / 2) * PER + i;
+                    if (i < PER && part < ML) {
+                        DAL3_SCHED_FENCE();
+                        ring.issue_part(part);
+                        if (part == ML - 1) ring.issue_done();
+                        DAL3_SCHED_FENCE();
+                    }
                 }
             }
         }
-        if (last) ring.issue_done();
+        if (last && !DEFER_OUT) ring.issue_done();
         if ((4 * gi) % FPT == 0 && !last && (gi > 0 || !FIRST)) {
             const int t = 4 * gi / FPT - 1;                // the tile that finished with the previous group (-1: the
             lp_tile_max_t<T>(acc[t & 1], bias + 32 * t, smax + 32 * t, lane);              // previous segment's last)

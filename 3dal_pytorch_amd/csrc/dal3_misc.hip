@@ -226,7 +226,10 @@ template <> struct MpElem<DAL3_F16> {
     static __device__ __forceinline__ void store1(T* p, float v) { *p = __builtin_bit_cast(uint16_t, (_Float16)v); }
 };
 
-template <int DT, int UNROLL, bool VEC>
+// R rows per wave, NL 16-byte loads per lane and row, all R * NL loads of a wave issued before the first is used
+// (NL = 0: any row length, loads in batches of four, the last batch's indices clamped — a repeated element cannot
+// change a maximum — so that no load is conditional: to hipcc a conditional load is a branch).
+template <int DT, int R, int NL, bool VEC>
 __global__ __launch_bounds__(256) void maxpool_rows_kernel(const void* __restrict__ xv, int64_t rows, int64_t n,
                                                            void* __restrict__ outv) {
     typedef MpElem<DT> E;
@@ -236,69 +239,118 @@ __global__ __launch_bounds__(256) void maxpool_rows_kernel(const void* __restric
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
-    for (int64_t row = wave0; row < rows; row += n_waves) {
-        float m = -INFINITY;
+    for (int64_t row0 = wave0 * R; row0 < rows; row0 += n_waves * R) {
+        float m[R];
         bool nan = false;
-        if (VEC) {                                          // n % PER16 == 0 and 16-byte aligned base
-            const int64_t nv = n / E::PER16;
-            const u32x4* p = reinterpret_cast<const u32x4*>(x + row * n);
-            float mm[E::PER16];
 #pragma unroll
-            for (int k = 0; k < E::PER16; ++k) mm[k] = -INFINITY;
-            auto take = [&](const u32x4& v) {
+        for (int r = 0; r < R; ++r) m[r] = -INFINITY;
+        if (VEC) {                                          // n % PER16 == 0 and 16-byte aligned rows
+            const int64_t nv = n / E::PER16;
+            auto take = [&](const u32x4& v, int r) {
                 float f[8];
                 E::unpack(v, f);
 #pragma unroll
                 for (int k = 0; k < E::PER16; ++k) {
                     nan |= f[k] != f[k];
-                    mm[k] = fmaxf(mm[k], f[k]);
+                    m[r] = fmaxf(m[r], f[k]);
                 }
             };
-            int64_t i = lane;
-            for (; i + (UNROLL - 1) * 64 < nv; i += UNROLL * 64) {
-                u32x4 v[UNROLL];
+            if (NL > 0) {                                   // nv == 64 * NL: straight-line
+                u32x4 v[R][NL];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(p + i + u * 64);
+                for (int r = 0; r < R; ++r) {
+                    const int64_t row = row0 + r < rows ? row0 + r : rows - 1;     // (a repeated row is stored once)
+                    const u32x4* p = reinterpret_cast<const u32x4*>(x + row * n);
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) take(v[u]);
+                    for (int u = 0; u < NL; ++u) v[r][u] = __builtin_nontemporal_load(p + lane + u * 64);
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int u = 0; u < NL; ++u) take(v[r][u], r);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+                    const u32x4* p = reinterpret_cast<const u32x4*>(x + row * n);
+                    for (int64_t i = lane; i < nv; i += 4 * 64) {
+                        u32x4 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int64_t j = i + u * 64;
+                            v[u] = __builtin_nontemporal_load(p + (j < nv ? j : nv - 1));
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) take(v[u], r);
+                    }
+                }
             }
-            for (; i < nv; i += 64) take(__builtin_nontemporal_load(p + i));
-#pragma unroll
-            for (int k = 0; k < E::PER16; ++k) m = fmaxf(m, mm[k]);
         } else {                                            // any n, any alignment: one element per lane and trip
-            for (int64_t i = lane; i < n; i += 64) {
-                const float f = E::load1(x + row * n + i);
-                nan |= f != f;
-                m = fmaxf(m, f);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+                for (int64_t i = lane; i < n; i += 64) {
+                    const float f = E::load1(x + row * n + i);
+                    nan |= f != f;
+                    m[r] = fmaxf(m[r], f);
+                }
             }
         }
+        // (the NaN flag is per lane and row-blind for R > 1: redo the flag per row only in that rare case)
+        const bool any_nan = __any(nan);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        if (__any(nan)) m = __uint_as_float(0x7FC00000u);
-        if (lane == 0) E::store1(out + row, m);
+        for (int r = 0; r < R; ++r) {
+            float v = m[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+            m[r] = v;
+        }
+        if (any_nan) {                                      // rare: which of the wave's rows hold the NaN
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+                bool rn = false;
+                for (int64_t i = lane; i < n; i += 64) {
+                    const float f = E::load1(x + row * n + i);
+                    rn |= f != f;
+                }
+                if (__any(rn)) m[r] = __uint_as_float(0x7FC00000u);
+            }
+        }
+        if (lane < R && row0 + lane < rows) {
+            float v = m[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) v = lane == r ? m[r] : v;
+            E::store1(out + row0 + lane, v);
+        }
     }
 }
 
 hipError_t launch_maxpool_n(const void* x, int dtype, int64_t rows, int64_t n, void* out, hipStream_t s) {
     if (rows <= 0 || n <= 0) return hipErrorInvalidValue;
-    // one wave per row, as many workgroups as that takes: with the grid capped at 16 workgroups per CU (waves walking
-    // 256 rows each) the same kernel read 6.5 TB/s, uncapped 7.1 (one box, (4096, 1024, 1024) fp32) — a wave's next row
-    // starts behind its butterfly and store, a fresh wave's loads do not. (Two rows per wave: 6.9 in the same process;
-    // plain instead of non-temporal loads: 6.5. tools/ab_maxpool.py)
-    int64_t blocks = (rows + 3) / 4;
-    if (blocks > 0x7fffffff) blocks = 0x7fffffff;
+    // one wave per row (fp32 rows) / per two rows (16-bit rows: a 1024-value row is 2 KiB, two loads per lane — too
+    // little per wave to hide its butterfly and store behind), as many workgroups as that takes: with the grid capped
+    // at 16 workgroups per CU (waves walking 256 rows each) the fp32 kernel read 6.5 TB/s, uncapped 7.1 (one box,
+    // (4096, 1024, 1024) fp32) — a wave's next row starts behind its butterfly and store, a fresh wave's loads do not.
+    // (Two fp32 rows per wave: 6.9 in the same process; plain instead of non-temporal loads: 6.5. tools/ab_maxpool.py)
     const int per16 = dtype == DAL3_F32 ? 4 : 8;
     const bool vec = (n % per16 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const int R = dtype == DAL3_F32 ? 1 : 2;
+    int64_t blocks = ((rows + R - 1) / R + 3) / 4;
+    if (blocks > 0x7fffffff) blocks = 0x7fffffff;
     const dim3 grid((unsigned)blocks), block(256);
-#define MP_LAUNCH(DT)                                                                                            \
-    do {                                                                                                         \
-        if (vec) hipLaunchKernelGGL((maxpool_rows_kernel<DT, 4, true>), grid, block, 0, s, x, rows, n, out);    \
-        else hipLaunchKernelGGL((maxpool_rows_kernel<DT, 1, false>), grid, block, 0, s, x, rows, n, out);       \
+    const int64_t nl = vec && (n / per16) % 64 == 0 ? n / per16 / 64 : 0;      // 16-byte loads per lane and row
+#define MP_LAUNCH(DT, RR)                                                                                              \
+    do {                                                                                                               \
+        if (!vec) hipLaunchKernelGGL((maxpool_rows_kernel<DT, RR, 0, false>), grid, block, 0, s, x, rows, n, out);     \
+        else if (nl == 4) hipLaunchKernelGGL((maxpool_rows_kernel<DT, RR, 4, true>), grid, block, 0, s, x, rows, n, out); \
+        else if (nl == 2) hipLaunchKernelGGL((maxpool_rows_kernel<DT, RR, 2, true>), grid, block, 0, s, x, rows, n, out); \
+        else hipLaunchKernelGGL((maxpool_rows_kernel<DT, RR, 0, true>), grid, block, 0, s, x, rows, n, out);          \
     } while (0)
     switch (dtype) {
-        case DAL3_F32: MP_LAUNCH(DAL3_F32); break;
-        case DAL3_BF16: MP_LAUNCH(DAL3_BF16); break;
-        case DAL3_F16: MP_LAUNCH(DAL3_F16); break;
+        case DAL3_F32: MP_LAUNCH(DAL3_F32, 1); break;
+        case DAL3_BF16: MP_LAUNCH(DAL3_BF16, 2); break;
+        case DAL3_F16: MP_LAUNCH(DAL3_F16, 2); break;
         default: return hipErrorInvalidValue;
     }
 #undef MP_LAUNCH

@@ -119,9 +119,15 @@ __global__ __launch_bounds__(256, DAL3_LP_ENC_SLOTS == 2 ? 2 : 1) void ins_seg_e
     LP_STAMP(2);
     typename DT::v8 g5[2][4];
     f32x16 acc5[2][T];                                     // conv5: 4 out-tiles (32 fragments) per segment; the last
-    lp_max_tiles<DT, 4, T, SEG, 4, true>(ring, x4, s_bias + 256, s_max, lane, g5, acc5);
-    for (int seg = 1; seg < 8; ++seg)                      // call has already opened the next group's segment 0
-        lp_max_tiles<DT, 4, T, SEG, 4, false>(ring, x4, s_bias + 256 + 128 * seg, s_max + 128 * seg, lane, g5, acc5);
+#ifndef DAL3_LP_ENC_DEFER
+#define DAL3_LP_ENC_DEFER 1                                // conv5's ring refills spread over the following segment (dal3_lp.h)
+#endif
+    constexpr bool DEFER = DAL3_LP_ENC_DEFER && DAL3_LP_ENC_SLOTS == 3;
+    lp_max_tiles<DT, 4, T, SEG, 4, true, false, DEFER>(ring, x4, s_bias + 256, s_max, lane, g5, acc5);
+    for (int seg = 1; seg < 7; ++seg)
+        lp_max_tiles<DT, 4, T, SEG, 4, false, DEFER, DEFER>(ring, x4, s_bias + 256 + 128 * seg, s_max + 128 * seg, lane, g5, acc5);
+    // the last call: issues its own refill at once, it has already opened the next group's segment 0
+    lp_max_tiles<DT, 4, T, SEG, 4, false, DEFER, false>(ring, x4, s_bias + 256 + 128 * 7, s_max + 128 * 7, lane, g5, acc5);
     lp_max_tiles_finish<T>(acc5, s_bias + 256 + 1024 - 32, s_max + 1024 - 32, lane);
     LP_STAMP(3);
     __syncthreads();
