@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--backends", default="hip,torch")
+    ap.add_argument("--adam", default="default", choices=["default", "fused"],
+                    help="default: torch.optim.Adam as static_train.py:220 builds it; fused: the same with fused=True")
     ap.add_argument("--graph", action="store_true", help="also time the step captured into a hipGraph (device sampler)")
     ap.add_argument("--kind", default="static_one", choices=["static_one", "dynamic"],
                     help="static_train.py's StaticModelOneBoxEst (64 x 4096) or dynamic_train.py's DynamicModel (5 x 1024 points "
@@ -74,7 +76,10 @@ def main():
         model = model.to(dev).train()
         model.train_backend = backend
         model.sampler = args.sampler
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        # --adam default: what static_train.py:220 constructs (torch picks its multi-tensor "foreach" path: ~12 launches
+        # per step over the 150 tensors); fused: torch.optim.Adam(..., fused=True), ONE multi-tensor launch — the same
+        # update, the setting this path is measured and supported with when the optimizer's launches matter
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, **({"fused": True} if args.adam == "fused" else {}))
 
         def step():
             o = model(pts, init, gt)
@@ -120,7 +125,8 @@ def main():
             g_ms = round((time.perf_counter() - t0) / args.iters * 1e3, 2)
             model, opt = gm, gopt
         out[backend] = {"ms": round(ms, 2), "graph_ms": g_ms, "crops_per_s": round(B / ms * 1e3, 1), "tflops_per_point_stacks": round(flop / ms / 1e9, 1),
-                        "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "loss": round(float(loss), 4)}
+                        "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "loss": round(float(loss), 4),
+                        "adam": args.adam}
         del model, opt
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
