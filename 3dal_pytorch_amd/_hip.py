@@ -28,6 +28,11 @@ class Layer(C.Structure):
                 ("bn_var", vp), ("c_in", C.c_int32), ("c_out", C.c_int32)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("W", vp), ("ldw", C.c_int64), ("transpose_w", C.c_int32), ("c_out", C.c_int32), ("c_in", C.c_int32),
+                ("mtb", C.c_int32), ("out", vp)]
+
+
 class BCN(C.Structure):
     _fields_ = [("data", vp), ("stride_b", C.c_int64), ("stride_c", C.c_int64), ("stride_n", C.c_int64),
                 ("dtype", C.c_int32), ("reserved", C.c_int32)]
@@ -92,6 +97,9 @@ SIGNATURES = {
     "dal3_crop_fill": (_i, [vp, vp, vp, vp, vp, _i, _i64, _i64, vp, vp, vp, vp, vp, vp, _sz, vp]),
     "dal3_tr_linear": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _i, vp, _i64, _i, vp, _i64, _i, vp, _sz, vp]),
     "dal3_tr_linear_workspace_bytes": (_sz, [_i, _i]),
+    "dal3_tr_linear_pack_layout": (_i, [_i64, _i, _i64, _i, _i, _i]),
+    "dal3_tr_pack_many": (_i, [vp, _i, vp]),
+    "dal3_tr_linear_prepacked": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _i, vp, _i64, _i, vp, _i64, _i, vp, vp]),
     "dal3_tr_colred_workspace_bytes": (_sz, [_i64, _i]),
     "dal3_tr_colred": (_i, [vp, _i64, _i, _i64, _i, vp, _i64, vp, vp, _i64, vp, vp, vp, vp, vp, _sz, vp, vp]),
     "dal3_tr_pool_coef": (_i, [vp, vp, vp, vp, vp, vp, _i, _i, _i64, vp, vp, vp]),

@@ -805,6 +805,37 @@ extern "C" int dal3_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, 
     return 0;
 }
 
+extern "C" int dal3_tr_linear_pack_layout(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act) {
+    if (!mult32(M) || !mult32(c_in) || !mult32(c_out)) return 0;
+    return tr_linear_pack_mtb(M, c_in, seg, c_out, accumulate, has_act);
+}
+
+extern "C" int dal3_tr_pack_many(const dal3_tr_pack_item* items, int n, dal3_stream stream) {
+    if (!items || n <= 0 || n > 48) return fail(DAL3_EINVAL, "tr_pack_many: 1 .. 48 items");
+    for (int i = 0; i < n; ++i) {
+        const dal3_tr_pack_item& t = items[i];
+        if (!t.W || !t.out || !mult32(t.c_in) || !mult32(t.c_out) || t.mtb <= 0 || (t.c_out / 32) % t.mtb != 0 ||
+            (reinterpret_cast<uintptr_t>(t.out) & 15) || (!t.transpose_w && t.ldw < t.c_in) || (t.transpose_w && t.ldw < t.c_out))
+            return fail(DAL3_EINVAL, "tr_pack_many: bad item %d", i);
+    }
+    HIP_TRY(launch_tr_pack_many(items, n, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_linear_prepacked(const float* a, int64_t M, int c_in, int64_t lda, const float* scale,
+                                        const float* shift, int relu_in, const float* W, int64_t ldw, int transpose_w,
+                                        const float* bias, int64_t seg, int c_out, float* z, int64_t ldz, int accumulate,
+                                        const void* packed, dal3_stream stream) {
+    if (!a || !W || !z || !mult32(M) || !mult32(c_in) || !mult32(c_out) || lda < c_in || ldz < c_out || lda % 4 || ldz % 4 ||
+        (scale && !shift) || seg < 0 || !packed || (reinterpret_cast<uintptr_t>(packed) & 15))
+        return fail(DAL3_EINVAL, "tr_linear_prepacked: bad argument");
+    if (tr_linear_pack_mtb(M, c_in, seg, c_out, accumulate, scale != nullptr) == 0)
+        return fail(DAL3_EINVAL, "tr_linear_prepacked: this call reads no packed image (dal3_tr_linear_pack_layout() == 0)");
+    HIP_TRY(launch_tr_linear(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz, accumulate,
+                             const_cast<float*>(static_cast<const float*>(packed)), static_cast<hipStream_t>(stream), true));
+    return 0;
+}
+
 extern "C" size_t dal3_tr_linear_workspace_bytes(int c_in, int c_out) {
     return (c_in > 0 && c_out > 0) ? tr_linear_workspace_bytes(c_in, c_out) : 0;
 }

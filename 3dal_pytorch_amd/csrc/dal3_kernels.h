@@ -238,8 +238,11 @@ hipError_t launch_recenter(const float* obj_pts, int B, int M, const float* init
 // dal3_train.hip: training-mode building blocks over point-major (M x C) fp32 activations
 hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                             int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
-                            int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s);
+                            int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s, bool prepacked = false);
 size_t tr_linear_workspace_bytes(int c_in, int c_out);
+// the fragment layout (output tiles per wave) launch_tr_linear will read for this shape, 0: it packs nothing
+int tr_linear_pack_mtb(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act);
+hipError_t launch_tr_pack_many(const dal3_tr_pack_item* items, int n, hipStream_t s);
 size_t tr_colred_workspace_bytes(int64_t M, int C);
 hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                             const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,

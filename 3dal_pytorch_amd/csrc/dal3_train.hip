@@ -186,9 +186,8 @@ __global__ __launch_bounds__(256) void tr_linear_kernel(const float* __restrict_
 // 1-KiB load, and they are streamed through the 8-deep prefetch ring of the eval kernels (dal3_device.h) instead of
 // being double-buffered per k-tile: 128 accumulator + 64 activation + 32 ring registers leave room for two waves per
 // SIMD, so one wave's prologue/epilogue hides under the other's MFMAs.
-__global__ void tr_pack_kernel(const float* __restrict__ W, int64_t ldw, int transpose_w, int c_out, int c_in, int mtb,
-                               float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void tr_pack_element(const float* __restrict__ W, int64_t ldw, int transpose_w, int c_out, int c_in,
+                                                int mtb, float* __restrict__ out, int64_t i) {
     if (i >= (int64_t)c_out * c_in) return;
     const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
     int64_t f = i >> 8;                                       // fragment index
@@ -200,6 +199,32 @@ __global__ void tr_pack_kernel(const float* __restrict__ W, int64_t ldw, int tra
     const int kt = (int)(f % KT), mblk = (int)(f / KT);
     const int row = 32 * (mtb * mblk + t) + (lane & 31), col = 32 * kt + 8 * q + 4 * (lane >> 5) + e;
     out[i] = transpose_w ? W[(int64_t)col * ldw + row] : W[(int64_t)row * ldw + col];
+}
+__global__ void tr_pack_kernel(const float* __restrict__ W, int64_t ldw, int transpose_w, int c_out, int c_in, int mtb,
+                               float* __restrict__ out) {
+    tr_pack_element(W, ldw, transpose_w, c_out, c_in, mtb, out, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// Every layer of a step packed by ONE launch (round 3: a training step issued 32 tr_pack launches of ~4 us, one in front
+// of each linear / dgrad call; the weights do not change between a step's forward and its backward, so both orientations
+// of every layer can be packed when the forward starts). The item table travels by value in the kernel arguments.
+#define TR_PACK_MAX 48
+struct TrPackItem {
+    const float* W;
+    float* out;
+    int64_t ldw;
+    int32_t transpose_w, c_out, c_in, mtb;
+    uint32_t first_block;                                   // of 256 threads; blocks [first_block, next item's) belong to it
+};
+struct TrPackMany {
+    TrPackItem it[TR_PACK_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void tr_pack_many_kernel(TrPackMany p) {
+    int k = 0;
+    for (int i = 1; i < p.n; ++i) k = blockIdx.x >= p.it[i].first_block ? i : k;      // (first_block is ascending)
+    const TrPackItem& t = p.it[k];
+    tr_pack_element(t.W, t.ldw, t.transpose_w, t.c_out, t.c_in, t.mtb, t.out,
+                    (int64_t)(blockIdx.x - t.first_block) * 256 + threadIdx.x);
 }
 
 template <int T>
@@ -820,12 +845,13 @@ static bool tr_linear_pers_ok(int64_t M, int c_in, int64_t seg, int c_out, int a
 template <int T, int MTB, int OCC>
 static void tr_linear_ring_launch(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                                   int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
-                                  int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s) {
+                                  int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s, bool prepacked) {
     const int n_mblk = c_out / (32 * MTB);
     const int64_t units = ((M + 32 * T - 1) / (32 * T)) * n_mblk;
     const int64_t n = (int64_t)c_out * c_in;
-    hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, transpose_w, c_out, c_in,
-                       MTB, ws);
+    if (!prepacked)                                          // (prepacked: ws already holds this layer in fragment order, MTB = this path's)
+        hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, transpose_w, c_out, c_in,
+                           MTB, ws);
     const int KT = c_in / 32;
     const unsigned pers_grid = 256u * OCC;
     if constexpr (MTB >= 2) {
@@ -849,31 +875,65 @@ static void tr_linear_ring_launch(const float* a, int64_t M, int c_in, int64_t l
                        n_mblk);
 }
 
-hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
-                            int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
-                            int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s) {
-    const bool ring_ok = ws && (!scale || c_in <= TR_MAX_ACT_CIN);
-    // K <= 128 through the one-unit-per-wave kernel: a wave's whole K loop is a few microseconds, about as long as its
-    // prologue and its stores; the smaller <2, 2> tile fits two waves per SIMD, so one wave's ends run under the other's
-    // MFMAs (64 -> 512: 282 -> 258 us). Where the persistent kernel applies it overlaps the ends itself and the big tile
-    // wins again (64 -> 512: 185 us)
+// Which kernel family a layer takes — the ONE place that decides it (launch_tr_linear and the pack plan both ask):
+// 0: the strided-weight kernel (no packed weights); otherwise the ring path's output tiles per wave (1, 2 or TR_MTB),
+// with *small set when M <= TR_SMALL_M (the <1, 1, 2> instantiation).
+// K <= 128 through the one-unit-per-wave kernel: a wave's whole K loop is a few microseconds, about as long as its
+// prologue and its stores; the smaller <2, 2> tile fits two waves per SIMD, so one wave's ends run under the other's
+// MFMAs (64 -> 512: 282 -> 258 us). Where the persistent kernel applies it overlaps the ends itself and the big tile
+// wins again (64 -> 512: 185 us)
 #ifndef TR_SMALL_K
 #define TR_SMALL_K 128
 #endif
-    const int small_k = TR_SMALL_K;
-    if (ring_ok && M <= TR_SMALL_M) {
+static int tr_linear_path(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, bool has_ws, bool has_act, bool* small) {
+    const bool ring_ok = has_ws && c_out % 32 == 0 && (!has_act || c_in <= TR_MAX_ACT_CIN);
+    *small = false;
+    if (!ring_ok) return 0;
+    if (M <= TR_SMALL_M) {
+        *small = true;
+        return 1;
+    }
+    if (c_out % 128 == 0 && (c_in > TR_SMALL_K || tr_linear_pers_ok<TR_T, TR_MTB, TR_RING_OCC>(M, c_in, seg, c_out, accumulate)))
+        return TR_MTB;
+    if (c_out % 64 == 0) return 2;
+    return 1;
+}
+int tr_linear_pack_mtb(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act) {
+    bool small;
+    return tr_linear_path(M, c_in, seg, c_out, accumulate, true, has_act != 0, &small);
+}
+
+hipError_t launch_tr_pack_many(const dal3_tr_pack_item* items, int n, hipStream_t s) {
+    if (n <= 0 || n > TR_PACK_MAX) return hipErrorInvalidValue;
+    TrPackMany p;
+    p.n = n;
+    uint32_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const dal3_tr_pack_item& t = items[i];
+        p.it[i] = TrPackItem{t.W, t.out, t.ldw, t.transpose_w, t.c_out, t.c_in, t.mtb, blocks};
+        blocks += (uint32_t)(((int64_t)t.c_out * t.c_in + 255) / 256);
+    }
+    hipLaunchKernelGGL(tr_pack_many_kernel, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                            int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
+                            int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s, bool prepacked) {
+    bool small;
+    const int mtb = tr_linear_path(M, c_in, seg, c_out, accumulate, ws != nullptr, scale != nullptr, &small);
+    if (small) {
         tr_linear_ring_launch<1, 1, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
-                                       accumulate, ws, s);
-    } else if (ring_ok && c_out % 128 == 0 &&
-               (c_in > small_k || tr_linear_pers_ok<TR_T, TR_MTB, TR_RING_OCC>(M, c_in, seg, c_out, accumulate))) {
+                                       accumulate, ws, s, prepacked);
+    } else if (mtb == TR_MTB) {
         tr_linear_ring_launch<TR_T, TR_MTB, TR_RING_OCC>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg,
-                                                         c_out, z, ldz, accumulate, ws, s);
-    } else if (ring_ok && c_out % 64 == 0) {
+                                                         c_out, z, ldz, accumulate, ws, s, prepacked);
+    } else if (mtb == 2) {
         tr_linear_ring_launch<TR_T, 2, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
-                                          accumulate, ws, s);
-    } else if (ring_ok) {                                   // c_out = 32, 96, ...: one output tile per wave
+                                          accumulate, ws, s, prepacked);
+    } else if (mtb == 1) {                                  // c_out = 32, 96, ...: one output tile per wave
         tr_linear_ring_launch<TR_T, 1, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
-                                          accumulate, ws, s);
+                                          accumulate, ws, s, prepacked);
     } else {
         const int n_mblk = (c_out / 32 + TR_MTB - 1) / TR_MTB;
         const int64_t units = ((M + 32 * TR_T - 1) / (32 * TR_T)) * n_mblk;

@@ -58,12 +58,18 @@ def _take_saved(ctx):
     return saved
 
 
-def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False, out=None, accumulate=False):
-    """z (M,c_out) (+)= act(a) @ Wop^T + bias through dal3_tr_linear"""
+def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False, out=None, accumulate=False, packed=None):
+    """z (M,c_out) (+)= act(a) @ Wop^T + bias through dal3_tr_linear. packed: this call's weights already in fragment
+    order (_prepack: one launch for all the layers of a stack instead of one in front of every call)"""
     M = a.shape[0]
     z = out if out is not None else torch.empty((M, c_out), dtype=torch.float32, device=a.device)
     sc, sh, relu = (act if act is not None else (None, None, False))
     lib = _hip.lib()
+    if packed is not None:
+        _hip.check(lib.dal3_tr_linear_prepacked(_hip.ptr(a), M, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu),
+                                                _hip.ptr(W), ldw, int(transpose), _hip.ptr(bias), seg, c_out, _hip.ptr(z),
+                                                z.stride(0), int(accumulate), _hip.ptr(packed), _hip.stream()))
+        return z
     need = lib.dal3_tr_linear_workspace_bytes(c_in, c_out)
     ws = _ws(need, a.device) if need else None
     _hip.check(lib.dal3_tr_linear(_hip.ptr(a), M, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu), _hip.ptr(W), ldw,
@@ -74,6 +80,32 @@ def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False,
 
 def _pad32(n):
     return (n + 31) // 32 * 32
+
+
+def _prepack(specs, dev):
+    """Fragment-order images of the weights of several dal3_tr_linear calls from ONE launch (dal3_tr_pack_many).
+    specs: [(W 2-D fp32 with contiguous rows, c_in, c_out, transpose, M, seg, accumulate, has_act)] as each CALL will see
+    them (c_in / c_out swapped for a transposed weight). Returns one packed tensor per spec, None where the call reads
+    no packed image. The weights must not change between this and the calls (a step's forward and backward: they do not)."""
+    lib = _hip.lib()
+    lay = [lib.dal3_tr_linear_pack_layout(M, ci, seg, co, int(acc), int(has_act)) for _, ci, co, _, M, seg, acc, has_act in specs]
+    size = [int(lib.dal3_tr_linear_workspace_bytes(ci, co)) if l else 0 for l, (_, ci, co, *_r) in zip(lay, specs)]
+    size = [(n + 255) // 256 * 256 for n in size]
+    buf = torch.empty(max(sum(size), 16), dtype=torch.uint8, device=dev)
+    out, items, off = [], [], 0
+    for l, n, (W, ci, co, tr, *_r) in zip(lay, size, specs):
+        if not l:
+            out.append(None)
+            continue
+        view = buf[off:off + n]
+        off += n
+        out.append(view)
+        items.append(_hip.PackItem(_hip.ptr(W), W.stride(0), int(tr), co, ci, l, _hip.ptr(view)))
+    for i in range(0, len(items), 48):
+        chunk = items[i:i + 48]
+        arr = (_hip.PackItem * len(chunk))(*chunk)
+        _hip.check(lib.dal3_tr_pack_many(arr, len(chunk), _hip.stream()))
+    return out
 
 
 def _zero_grads(shapes, idx, dev):
@@ -400,12 +432,18 @@ class _PointStack(torch.autograd.Function):
         Ws, bns, zs = [], [], []
         act = None
         for k in range(4):
+            W2 = params[4 * k].detach().reshape(params[4 * k].shape[0], -1)
+            Ws.append(_pad_cols(W2, 32) if k == 0 else W2.contiguous())
+        Mp = a0.shape[0]
+        # one packing launch for the stack: conv1..4 forward and the dgrads of conv2, conv3 (the pooled layer's goes through
+        # its algebraic shortcut) — the weights are the same when the backward runs
+        pk = _prepack([(Ws[k], Ws[k].shape[1], Ws[k].shape[0], False, Mp, 0, False, k > 0) for k in range(4)] +
+                      [(Ws[k], Ws[k].shape[0], Ws[k].shape[1], True, Mp, 0, False, False) for k in (1, 2)], a0.device)
+        for k in range(4):
             W, b, gamma, beta = (p.detach() for p in params[4 * k:4 * k + 4])
-            W2 = W.reshape(W.shape[0], -1)
-            W2 = _pad_cols(W2, 32) if k == 0 else W2.contiguous()
-            z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous())
+            W2 = Ws[k]
+            z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous(), packed=pk[k])
             bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), rows=B * N)
-            Ws.append(W2)
             bns.append(bn)
             zs.append(z)
             a, act = z, bn.act
@@ -417,12 +455,12 @@ class _PointStack(torch.autograd.Function):
         # grad_fn -> ctx -> g) that only Python's cyclic collector breaks, and until it runs every step's activations
         # stay allocated: a DynamicModel run held 4-9 GB of dead steps and peaked at 13 GB instead of 8.
         ctx.save_for_backward(g)
-        ctx.saved = (a0, Ws, bns, zs, arg, N, [tuple(p.shape) for p in params], zarg, biases)
+        ctx.saved = (a0, Ws, bns, zs, arg, N, [tuple(p.shape) for p in params], zarg, biases, {1: pk[4], 2: pk[5]})
         return g
 
     @staticmethod
     def backward(ctx, dg):
-        a0, Ws, bns, zs, arg, N, shapes, zarg, biases = _take_saved(ctx)
+        a0, Ws, bns, zs, arg, N, shapes, zarg, biases, pkT = _take_saved(ctx)
         (g,) = ctx.saved_tensors
         grads = [None] * 16
         zero = _zero_grads(shapes, [1, 5, 9, 13], a0.device)
@@ -442,7 +480,7 @@ class _PointStack(torch.autograd.Function):
             grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
             if k > 0:
-                da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
+                da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, packed=pkT[k])
         return (None, None, *grads)
 
 
@@ -458,13 +496,30 @@ class _InsSeg(torch.autograd.Function):
         M = B * N
         P = [p.detach() for p in params]
         a0 = _points_major(pts.detach())
+        Mp = a0.shape[0]
         Ws, bns, zs = [], [], []
+        # every layer's weight as the linear kernels take it, and ONE launch that puts them all into fragment order — the
+        # forward calls and the transposed (dgrad) calls of the backward: 19 images instead of a ~4 us packing launch in
+        # front of each of the 19 calls
+        W2s = {}
+        for k in (0, 1, 2, 3, 6, 7, 8):
+            W2 = P[4 * k].reshape(P[4 * k].shape[0], -1)
+            W2s[k] = _pad_cols(W2, 32) if k == 0 else W2.contiguous()
+        Wd1 = P[20].reshape(P[20].shape[0], -1).contiguous()            # dconv1 (512, 1088): columns 0..63 per point
+        W5 = torch.zeros((32, 128), dtype=torch.float32, device=pts.device)
+        W5[:2] = P[36].reshape(2, 128)                                  # dconv5, rows padded to a tile
+        fw = lambda k: (W2s[k], W2s[k].shape[1], W2s[k].shape[0], False, Mp, 0, False, k > 0)      # noqa: E731
+        tr = lambda k, acc=False: (W2s[k], W2s[k].shape[0], W2s[k].shape[1], True, Mp, 0, acc, False)   # noqa: E731
+        order = ["f0", "f1", "f2", "f3", "fd1", "f6", "f7", "f8", "fd5", "td5", "t8", "t7", "t6", "td1", "t3", "t2", "t1"]
+        specs = [fw(0), fw(1), fw(2), fw(3), (Wd1, 64, 512, False, Mp, N, False, True), fw(6), fw(7), fw(8),
+                 (W5, 128, 32, False, Mp, 0, False, False), (W5, 32, 128, True, Mp, 0, False, False), tr(8), tr(7), tr(6),
+                 (Wd1, 512, 64, True, Mp, 0, False, False), tr(3), tr(2, True), tr(1)]
+        pk = dict(zip(order, _prepack(specs, pts.device)))
         a, act = a0, None
         for k in range(4):                                              # conv1..4
             W, b, gamma, beta = P[4 * k:4 * k + 4]
-            W2 = W.reshape(W.shape[0], -1)
-            W2 = _pad_cols(W2, 32) if k == 0 else W2.contiguous()
-            z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous())
+            W2 = W2s[k]
+            z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous(), packed=pk[f"f{k}"])
             bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), rows=M)
             Ws.append(W2)
             bns.append(bn)
@@ -492,10 +547,9 @@ class _InsSeg(torch.autograd.Function):
         bns.append(bn5)
         zs.append(None)
         # dconv1 on cat([out2, g.expand]): per-point part W[:, :64] out2, per-crop part W[:, 64:] g + b
-        Wd1 = P[20].reshape(P[20].shape[0], -1).contiguous()            # (512, 1088)
         gb = torch.zeros(((a0.shape[0] - 1) // N + 1, 512), dtype=torch.float32, device=g.device)  # (padding rows index past B)
         torch.addmm(P[21], g, Wd1[:, 64:].t(), out=gb[:B])             # (B,512)
-        z = _linear(zs[1], Wd1, Wd1.shape[1], 64, 512, act=bns[1].act, bias=gb, seg=N)
+        z = _linear(zs[1], Wd1, Wd1.shape[1], 64, 512, act=bns[1].act, bias=gb, seg=N, packed=pk["fd1"])
         bn = _BN(z, P[22], P[23], *(stats[5] if stats is not None else (None, None)), rows=M)
         Ws.append(Wd1)
         bns.append(bn)
@@ -503,8 +557,8 @@ class _InsSeg(torch.autograd.Function):
         a, act = z, bn.act
         for k in range(6, 9):                                           # dconv2..4
             W, b, gamma, beta = P[4 * k:4 * k + 4]
-            W2 = W.reshape(W.shape[0], -1).contiguous()
-            z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous())
+            W2 = W2s[k]
+            z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous(), packed=pk[f"f{k}"])
             bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), rows=M)
             Ws.append(W2)
             bns.append(bn)
@@ -513,20 +567,18 @@ class _InsSeg(torch.autograd.Function):
         if torch.is_tensor(drop) and drop.shape[0] < zs[8].shape[0]:     # a supplied multiplier: pad its rows too
             drop = torch.cat([drop, drop.new_zeros((zs[8].shape[0] - drop.shape[0], drop.shape[1]))])
         a4 = _act_dropout(zs[8], bns[8].act, drop)                      # Dropout sits between dbn4's ReLU and dconv5
-        W5 = torch.zeros((32, 128), dtype=torch.float32, device=pts.device)
-        W5[:2] = P[36].reshape(2, 128)
         b5 = torch.zeros(32, dtype=torch.float32, device=pts.device)
         b5[:2] = P[37]
-        zl = _linear(a4, W5, 128, 128, 32, bias=b5)
+        zl = _linear(a4, W5, 128, 128, 32, bias=b5, packed=pk["fd5"])
         ctx.saved = (a0, Ws, bns, zs, g, arg, a4, drop, W5, N, [tuple(p.shape) for p in params], zarg, P[17].contiguous(),
-                     (a4c, S4, m14))
+                     (a4c, S4, m14), pk)
         if CAPTURE is not None:
             CAPTURE["ins_seg"] = {"zs": list(zs), "bns": list(bns), "g": g, "arg": arg, "M": M, "N": N, "B": B}
         return zl[:M, :2].reshape(B, N, 2).contiguous()
 
     @staticmethod
     def backward(ctx, dlogits):
-        a0, Ws, bns, zs, g, arg, a4, drop, W5, N, shapes, zarg, b_conv5, conv5_cache = _take_saved(ctx)
+        a0, Ws, bns, zs, g, arg, a4, drop, W5, N, shapes, zarg, b_conv5, conv5_cache, pk = _take_saved(ctx)
         Mp = a0.shape[0]
         M = dlogits.shape[0] * dlogits.shape[1]
         dev = a0.device
@@ -536,7 +588,7 @@ class _InsSeg(torch.autograd.Function):
         dzl[:M, :2] = dlogits.reshape(M, 2)
         grads[36] = _wgrad(dzl, a4, 32, 128)[:2].reshape(shapes[36])
         grads[37] = dzl[:, :2].sum(0)
-        da = _linear(dzl, W5, 128, 32, 128, transpose=True)
+        da = _linear(dzl, W5, 128, 32, 128, transpose=True, packed=pk["td5"])
         if drop is not None:
             da = _act_dropout(da, None, drop)                           # the same multiplier, re-created from its key
         for k in (8, 7, 6):                                             # dconv4..2
@@ -544,7 +596,7 @@ class _InsSeg(torch.autograd.Function):
             grads[4 * k] = _wgrad(dz, zs[k - 1], Ws[k].shape[0], Ws[k].shape[1], bns[k - 1].act).reshape(shapes[4 * k])
             grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
-            da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
+            da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, packed=pk[f"t{k}"])
         # dconv1: per-point part against out2, per-crop part against g
         dz, dgam, dbet, dgb = bns[5].backward(zs[5], da=da, sum_seg=N)   # dgb (B,512): dz summed over each crop's points
         Wd1 = Ws[5]
@@ -556,7 +608,7 @@ class _InsSeg(torch.autograd.Function):
         grads[21] = zero[21]
         grads[22], grads[23] = dgam, dbet
         dg = dgb @ Wd1[:, 64:]                                          # (B,1024)
-        da2_dec = _linear(dz, Wd1, Wd1.shape[1], 512, 64, transpose=True)
+        da2_dec = _linear(dz, Wd1, Wd1.shape[1], 512, 64, transpose=True, packed=pk["td1"])
         # conv5..1
         da = None
         for k in (4, 3, 2, 1, 0):
@@ -575,9 +627,9 @@ class _InsSeg(torch.autograd.Function):
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
             if k == 2:                                                  # out2 also feeds the decoder
                 da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, out=da2_dec,
-                             accumulate=True)
+                             accumulate=True, packed=pk["t2"])
             elif k > 0:
-                da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
+                da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, packed=pk[f"t{k}"])
         return (None, None, None, *grads)
 
 
@@ -595,18 +647,10 @@ class _FcTail(torch.autograd.Function):
         if B % 32:
             a = torch.cat([a, a.new_zeros((_pad32(B) - B, a.shape[1]))])
         a_in = a
-        Ws, bns, zs = [], [], []
-        for k in range(n_bn):
-            W, b, gamma, beta = P[4 * k:4 * k + 4]
-            W = W.contiguous()
-            z = _linear(a, W, W.shape[1], W.shape[1], W.shape[0], act=act, bias=b.contiguous())
-            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), rows=B)
-            Ws.append(W)
-            bns.append(bn)
-            zs.append(z)
-            a, act = z, bn.act
-        last = None
-        if len(P) > 4 * n_bn:
+        Bp = a.shape[0]
+        Ws, bns, zs = [P[4 * k].contiguous() for k in range(n_bn)], [], []
+        Wp = None
+        if len(P) > 4 * n_bn:                                     # the last layer, without a BatchNorm: rows padded to a tile
             W, b = P[4 * n_bn], P[4 * n_bn + 1]
             c_out = W.shape[0]
             cp = (c_out + 31) // 32 * 32
@@ -614,16 +658,32 @@ class _FcTail(torch.autograd.Function):
             Wp[:c_out] = W
             bp = torch.zeros(cp, dtype=torch.float32, device=W.device)
             bp[:c_out] = b
-            out = _linear(a, Wp, Wp.shape[1], Wp.shape[1], cp, act=act, bias=bp)[:B, :c_out]
+        # one packing launch for the tail: every layer forward and transposed (the backward's dgrads)
+        specs = [(Ws[k], Ws[k].shape[1], Ws[k].shape[0], False, Bp, 0, False, k > 0) for k in range(n_bn)]
+        specs += [(Ws[k], Ws[k].shape[0], Ws[k].shape[1], True, Bp, 0, False, False) for k in range(n_bn)]
+        if Wp is not None:
+            specs += [(Wp, Wp.shape[1], Wp.shape[0], False, Bp, 0, False, n_bn > 0), (Wp, Wp.shape[0], Wp.shape[1], True, Bp, 0, False, False)]
+        pk = _prepack(specs, a.device)
+        for k in range(n_bn):
+            W, b, gamma, beta = P[4 * k:4 * k + 4]
+            W = Ws[k]
+            z = _linear(a, W, W.shape[1], W.shape[1], W.shape[0], act=act, bias=b.contiguous(), packed=pk[k])
+            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), rows=B)
+            bns.append(bn)
+            zs.append(z)
+            a, act = z, bn.act
+        last = None
+        if Wp is not None:
+            out = _linear(a, Wp, Wp.shape[1], Wp.shape[1], cp, act=act, bias=bp, packed=pk[2 * n_bn])[:B, :c_out]
             last = (Wp, c_out)
         else:
             out = _act_dropout(a, act, None)[:B]                  # relu(bn(z)) of the last BN layer
-        ctx.saved = (a_in, Ws, bns, zs, last, n_bn, [tuple(p.shape) for p in params])
+        ctx.saved = (a_in, Ws, bns, zs, last, n_bn, [tuple(p.shape) for p in params], pk)
         return out.contiguous()
 
     @staticmethod
     def backward(ctx, dout):
-        a_in, Ws, bns, zs, last, n_bn, shapes = _take_saved(ctx)
+        a_in, Ws, bns, zs, last, n_bn, shapes, pk = _take_saved(ctx)
         grads = [None] * len(shapes)
         dev = dout.device
         B, Bp = dout.shape[0], a_in.shape[0]
@@ -635,7 +695,7 @@ class _FcTail(torch.autograd.Function):
             src, act = (zs[-1], bns[-1].act) if n_bn else (a_in, None)
             grads[4 * n_bn] = _wgrad(dz, src, Wp.shape[0], Wp.shape[1], act)[:c_out].reshape(shapes[4 * n_bn])
             grads[4 * n_bn + 1] = dout.sum(0)
-            da = _linear(dz, Wp, Wp.shape[1], Wp.shape[0], Wp.shape[1], transpose=True)
+            da = _linear(dz, Wp, Wp.shape[1], Wp.shape[0], Wp.shape[1], transpose=True, packed=pk[2 * n_bn + 1])
         elif Bp > B:
             da = torch.cat([dout, dout.new_zeros((Bp - B, dout.shape[1]))])
         else:
@@ -646,7 +706,7 @@ class _FcTail(torch.autograd.Function):
             grads[4 * k] = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act).reshape(shapes[4 * k])
             grads[4 * k + 1] = zero[4 * k + 1]                                 # a bias in front of a train-mode BN
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
-            da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True)
+            da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, packed=pk[n_bn + k])
         return (da[:B], None, None, *grads)
 
 

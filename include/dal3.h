@@ -314,6 +314,26 @@ int dal3_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, const float
                    const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg, int c_out, float* z,
                    int64_t ldz, int accumulate, void* workspace, size_t workspace_bytes, dal3_stream stream);
 size_t dal3_tr_linear_workspace_bytes(int c_in, int c_out);   /* 0 when the layer needs none (c_out % 128 != 0) */
+/* dal3_tr_linear re-orders its weights into MFMA fragment order in front of every call (a ~4 us launch; a training step
+ * makes 32 such calls). A caller that knows a step's layers up front packs them all — forward and transposed, the weights
+ * do not change between a step's forward and backward — with ONE launch and hands each call its own image:
+ *   dal3_tr_linear_pack_layout  -> the layout code (> 0) dal3_tr_linear will read for a call of this shape, 0 when that
+ *                                  call uses no packed image (then pass it a plain workspace as before);
+ *   dal3_tr_pack_many           packs n <= 48 layers (items: HOST array; out: device, 16-byte aligned,
+ *                               dal3_tr_linear_workspace_bytes(c_in, c_out) bytes each; c_out / c_in as the CALL sees
+ *                               them, i.e. swapped for transpose_w != 0);
+ *   dal3_tr_linear_prepacked    dal3_tr_linear reading `packed` instead of packing. */
+typedef struct {
+    const float* W;
+    int64_t ldw;
+    int32_t transpose_w, c_out, c_in, mtb;               /* mtb: dal3_tr_linear_pack_layout() of the call */
+    float* out;
+} dal3_tr_pack_item;
+int dal3_tr_linear_pack_layout(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act);
+int dal3_tr_pack_many(const dal3_tr_pack_item* items, int n, dal3_stream stream);
+int dal3_tr_linear_prepacked(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                             int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
+                             int c_out, float* z, int64_t ldz, int accumulate, const void* packed, dal3_stream stream);
 size_t dal3_tr_colred_workspace_bytes(int64_t M, int C);
 int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                    const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
