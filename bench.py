@@ -232,7 +232,8 @@ def kernel_table(model, inputs, static, B, N, iters):
         t = events_ms(pool, iters)
         granule = 256 if lp else 32
         exe_pts = arch.head_executed_points(cnt, m, granule) if distinct is not None else B * arch._pad(m, granule)
-        row(f"point_head{sfx}[{name}]", t, arch.head_point_mac(table) * B * m, arch.head_point_mac(table, True) * exe_pts,
+        pers = not lp and B * ((m + 31) // 32) > 512            # fp32 throughput family: persistent waves over the live-tile worklist
+        row(f"point_head{'_pers' if pers else ''}{sfx}[{name}]", t, arch.head_point_mac(table) * B * m, arch.head_point_mac(table, True) * exe_pts,
             note=f"{exe_pts / (B * m):.3f} of the {m} object points per item are computed"
                  + (" (copies skipped)" if distinct is not None else " (padding)"))
     return out, float(cnt.mean())

@@ -227,6 +227,42 @@ def test_ins_seg_random_dropout_and_eval_after_training_step():
     assert bool(torch.isfinite(after).all()) and not torch.equal(before, after)
 
 
+def test_two_forwards_before_their_backwards_keep_their_own_dropout_masks():
+    """the backward re-creates the Dropout multiplier from its key (seed, step). The key used to hold the module's
+    LIVE device counter, so `loss(model(a)) + loss(model(b))` — two train-mode forwards, then the backwards — gave the
+    first graph's backward the counter value of the SECOND forward: another mask than its forward used, wrong gradients,
+    no error. The key now carries a snapshot. Two orders of the same two draws must give the same gradients, bit for bit:
+    forward a, forward b, backward a, backward b  ==  forward a, backward a, forward b, backward b."""
+    pa, _, _ = synth.static_crops(4, 256, seed=31)
+    pb, _, _ = synth.static_crops(4, 256, seed=32)
+    pa, pb = (torch.from_numpy(x).cuda().transpose(2, 1) for x in (pa, pb))
+    wa = torch.from_numpy(synth.normal(31, "w", (4, 256, 2)).astype(np.float32)).cuda()
+
+    def grads(interleaved):
+        model = build_model("static_one", synth.state_dict("static_one", seed=23)).train()
+        seg = model.ins_seg
+        torch.manual_seed(77)                               # the two draws' seeds come from torch's CPU generator
+        out = []
+        if interleaved:
+            for p in (pa, pb):
+                seg.zero_grad()
+                (train.ins_seg_train_forward(seg, p) * wa).sum().backward()
+                out.append([q.grad.clone() for q in seg.parameters()])
+        else:
+            la = (train.ins_seg_train_forward(seg, pa) * wa).sum()
+            lb = (train.ins_seg_train_forward(seg, pb) * wa).sum()
+            for loss in (la, lb):
+                seg.zero_grad()
+                loss.backward()
+                out.append([q.grad.clone() for q in seg.parameters()])
+        return out
+    one, two = grads(True), grads(False)
+    for k in range(2):
+        for g1, g2 in zip(one[k], two[k]):
+            assert torch.equal(g1, g2)
+    assert not all(torch.equal(a, b) for a, b in zip(one[0], one[1]))
+
+
 @pytest.mark.parametrize("kind,attr,B,C,N", [("static_one", "box_est", 6, 3, 512), ("dynamic", "point_emb", 2, 4, 2560),
                                               ("dynamic", "box_emb", 32, 8, 101), ("dynamic", "box_emb", 5, 8, 101),
                                               ("static_one", "box_est", 3, 3, 90)])
