@@ -14,8 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib3dal_hip.so")
 
 OK, EINVAL, EWORKSPACE, EHIP = 0, -1, -2, -3
-F32, BF16, F16 = 0, 1, 2
-DTYPES = {"fp32": F32, "bf16": BF16, "fp16": F16}
+F32, BF16, F16, F16X3 = 0, 1, 2, 3
+DTYPES = {"fp32": F32, "bf16": BF16, "fp16": F16, "f16x3": F16X3}
 HEAD_INS_SEG, HEAD_STATIC_BOX_EST, HEAD_POINT_EMB, HEAD_BOX_EMB, HEAD_DYNAMIC_BOX_EST = range(5)
 SAMPLER_DEVICE, SAMPLER_CHOICE = 0, 1
 PHASE_SEG, PHASE_BOX, PHASE_ALL = 1, 2, 3

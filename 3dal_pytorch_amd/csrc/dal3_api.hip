@@ -200,6 +200,58 @@ PointHeadLpW point_head_lp_view(const void* base, int head_kind) {
     return point_head_lp_walk(c, head_kind);
 }
 
+// ---- "f16x3" ins_seg: fp32 sections, then the two fragment streams (18 / 27 segments of 32 KiB)
+static InsSegX3W ins_seg_x3_walk(Cursor& c) {
+    InsSegX3W w;
+    w.w1 = c.take(2 * 2 * 64);
+    w.b1 = c.take(64);
+    w.bias_enc = c.take(1280);
+    w.bias_dec = c.take(608);
+    w.dw1g = c.take(512 * 1024);
+    w.db1 = c.take(512);
+    w.enc_stream = reinterpret_cast<const uint16_t*>(c.take((size_t)18 * 32 * 256));
+    w.dec_stream = reinterpret_cast<const uint16_t*>(c.take((size_t)27 * 32 * 256));
+    return w;
+}
+size_t ins_seg_x3_packed_bytes() {
+    Cursor c{nullptr, 0};
+    ins_seg_x3_walk(c);
+    return c.off * sizeof(float) + DAL3_BLOB_TAIL_FLOATS * sizeof(float);
+}
+InsSegX3W ins_seg_x3_view(const void* base) {
+    Cursor c{static_cast<const float*>(base), 0};
+    return ins_seg_x3_walk(c);
+}
+
+// ---- "f16x3" heads: the 16-bit heads' blob with a stream of (hi, lo) fragment pairs, padded to whole ring segments
+static PointHeadX3W point_head_x3_walk(Cursor& cur, int head_kind) {
+    int c_in, ks, c[4], n_fc, fi[3], fo[3];
+    point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
+    PointHeadX3W w;
+    w.w1 = cur.take((size_t)(c[0] / 32) * ks * 64);
+    w.b1 = cur.take(c[0]);
+    w.bias = cur.take(c[1] + c[2] + c[3]);
+    w.fc.n = n_fc;
+    for (int i = 0; i < 3; ++i) {
+        w.fc.c_in[i] = fi[i];
+        w.fc.c_out[i] = fo[i];
+        w.fc.relu[i] = !(head_kind == DAL3_HEAD_STATIC_BOX_EST && i == 2);
+        w.fc.w[i] = i < n_fc ? cur.take((size_t)fi[i] * fo[i]) : nullptr;
+        w.fc.b[i] = i < n_fc ? cur.take((fo[i] + 31) / 32 * 32) : nullptr;
+    }
+    w.stream = reinterpret_cast<const uint16_t*>(cur.take((size_t)point_head_x3_segments(head_kind) * 32 * 256));   // 32 fragments of 256 floats per segment
+    return w;
+}
+size_t point_head_x3_packed_bytes(int head_kind) {
+    Cursor c{nullptr, 0};
+    point_head_x3_walk(c, head_kind);
+    return c.off * sizeof(float) + DAL3_BLOB_TAIL_FLOATS * sizeof(float);
+}
+PointHeadX3W point_head_x3_view(const void* base, int head_kind) {
+    Cursor c{static_cast<const float*>(base), 0};
+    return point_head_x3_walk(c, head_kind);
+}
+
 // ---------------------------------------------------------------------------------- packing
 static float* mut(const void* p) { return const_cast<float*>(reinterpret_cast<const float*>(p)); }
 
@@ -234,17 +286,21 @@ static int pack_fc(const dal3_layer* L, const FcW& f, hipStream_t s) {
 
 extern "C" int dal3_pack_weights(int head_kind, const dal3_layer* L, int n_layers, int dtype, void* packed_dev,
                                  size_t* bytes_inout, dal3_stream stream) {
-    if (dtype != DAL3_F32 && dtype != DAL3_BF16 && dtype != DAL3_F16)
+    if (dtype != DAL3_F32 && dtype != DAL3_BF16 && dtype != DAL3_F16 && dtype != DAL3_F16X3)
         return fail(DAL3_EINVAL, "dal3_pack_weights: unknown dtype %d", dtype);
     if (!bytes_inout) return fail(DAL3_EINVAL, "dal3_pack_weights: bytes_inout is NULL");
-    const bool lp = dtype != DAL3_F32;
+    const bool x3 = dtype == DAL3_F16X3;
+    const bool lp = dtype != DAL3_F32 && !x3;
     size_t need;
     switch (head_kind) {
-        case DAL3_HEAD_INS_SEG: need = lp ? ins_seg_lp_packed_bytes() : ins_seg_packed_floats(0) * sizeof(float); break;
+        case DAL3_HEAD_INS_SEG:
+            need = x3 ? ins_seg_x3_packed_bytes() : lp ? ins_seg_lp_packed_bytes() : ins_seg_packed_floats(0) * sizeof(float);
+            break;
         case DAL3_HEAD_STATIC_BOX_EST:
         case DAL3_HEAD_POINT_EMB:
         case DAL3_HEAD_BOX_EMB:
-            need = lp ? point_head_lp_packed_bytes(head_kind) : point_head_packed_floats(head_kind) * sizeof(float);
+            need = x3 ? point_head_x3_packed_bytes(head_kind)
+                      : lp ? point_head_lp_packed_bytes(head_kind) : point_head_packed_floats(head_kind) * sizeof(float);
             break;
         case DAL3_HEAD_DYNAMIC_BOX_EST: need = fc_head_packed_floats() * sizeof(float); break;   // FC only: fp32 in every dtype
         default: return fail(DAL3_EINVAL, "dal3_pack_weights: unknown head_kind %d", head_kind);
@@ -267,6 +323,41 @@ extern "C" int dal3_pack_weights(int head_kind, const dal3_layer* L, int n_layer
         static const int co[10] = {64, 64, 64, 128, 1024, 512, 256, 128, 128, 2};
         static const int ci[10] = {0, 64, 64, 64, 128, 1088, 512, 256, 128, 128};
         for (int i = 0; i < 10; ++i) TRY(check_layer(L[i], i == 0 ? c_in : ci[i], co[i], "ins_seg layer"));
+        if (x3) {
+            const InsSegX3W w = ins_seg_x3_view(packed_dev);
+            uint16_t* enc = const_cast<uint16_t*>(w.enc_stream);
+            uint16_t* dec = const_cast<uint16_t*>(w.dec_stream);
+            float* be = mut(w.bias_enc);
+            float* bd = mut(w.bias_dec);
+            const int64_t F = 512;                                    // 16-bit elements per fragment
+            HIP_TRY(launch_pack_weight(L[0], PACK_FIRST, 0, c_in, 2, 2, mut(w.w1), s));
+            HIP_TRY(launch_pack_bias(L[0], mut(w.b1), s));
+            HIP_TRY(launch_pack_bias(L[1], be, s));
+            HIP_TRY(launch_pack_bias(L[2], be + 64, s));
+            HIP_TRY(launch_pack_bias(L[3], be + 128, s));
+            HIP_TRY(launch_pack_bias(L[4], be + 256, s));
+            HIP_TRY(launch_pack_bias(L[1], bd, s));
+            HIP_TRY(launch_pack_bias(L[6], bd + 64, s));
+            HIP_TRY(launch_pack_bias(L[7], bd + 320, s));
+            HIP_TRY(launch_pack_bias(L[8], bd + 448, s));
+            HIP_TRY(launch_pack_bias(L[9], bd + 576, s));             // db5: 2 real rows, padded to 32
+            HIP_TRY(launch_pack_weight(L[5], PACK_ROWMAJOR, 64, 1024, 0, 0, mut(w.dw1g), s));
+            HIP_TRY(launch_pack_bias(L[5], mut(w.db1), s));
+            // encode stream (fragments): conv2 @0 (16) | conv3 @16 (16) | conv4 @32 (32) | conv5 @64 (512)
+            HIP_TRY(launch_pack_weight_x3(L[1], 0, 0, 64, 2, 2, enc, s));
+            HIP_TRY(launch_pack_weight_x3(L[2], 0, 0, 64, 2, 2, enc + 16 * F, s));
+            HIP_TRY(launch_pack_weight_x3(L[3], 0, 0, 64, 4, 2, enc + 32 * F, s));
+            HIP_TRY(launch_pack_weight_x3(L[4], 0, 0, 128, 32, 4, enc + 64 * F, s));
+            // decode stream: conv2 @0 (16) | 16 x { dconv1a chunk (8), dconv2 chunk (32) } @16 | dconv3 @656 (128) |
+            // dconv4 @784 (64) | dconv5 @848 (16: one out-tile, rows 0, 1 real)
+            HIP_TRY(launch_pack_weight_x3(L[1], 0, 0, 64, 2, 2, dec, s));
+            HIP_TRY(launch_pack_weight_x3(L[5], 0, 0, 64, 16, 2, dec, s, 2, 16 * F, 56 * F, 40 * F));
+            HIP_TRY(launch_pack_weight_x3(L[6], 1, 0, 512, 8, 16, dec, s, 8, 24 * F, 64 * F, 40 * F));
+            HIP_TRY(launch_pack_weight_x3(L[7], 0, 0, 256, 4, 8, dec + 656 * F, s));
+            HIP_TRY(launch_pack_weight_x3(L[8], 0, 0, 128, 4, 4, dec + 784 * F, s));
+            HIP_TRY(launch_pack_weight_x3(L[9], 0, 0, 128, 1, 4, dec + 848 * F, s));
+            return 0;
+        }
         if (lp) {
             const InsSegLpW w = ins_seg_lp_view(packed_dev);
             uint16_t* enc = const_cast<uint16_t*>(w.enc_stream);
@@ -335,6 +426,22 @@ extern "C" int dal3_pack_weights(int head_kind, const dal3_layer* L, int n_layer
     if (n_layers != 4 + n_fc) return fail(DAL3_EINVAL, "head %d expects %d layers, got %d", head_kind, 4 + n_fc, n_layers);
     TRY(check_layer(L[0], c_in, c[0], "conv1"));
     for (int i = 1; i < 4; ++i) TRY(check_layer(L[i], c[i - 1], c[i], "conv"));
+    if (x3) {
+        const PointHeadX3W w = point_head_x3_view(packed_dev, head_kind);
+        HIP_TRY(launch_pack_weight(L[0], PACK_FIRST, 0, c_in, c[0] / 32, ks, mut(w.w1), s));
+        HIP_TRY(launch_pack_bias(L[0], mut(w.b1), s));
+        HIP_TRY(launch_pack_bias(L[1], mut(w.bias), s));
+        HIP_TRY(launch_pack_bias(L[2], mut(w.bias) + c[1], s));
+        HIP_TRY(launch_pack_bias(L[3], mut(w.bias) + c[1] + c[2], s));
+        uint16_t* st = const_cast<uint16_t*>(w.stream);          // conv2 | conv3 | conv4, out-tile major, back to back
+        int64_t off = 0;
+        for (int l = 1; l < 4; ++l) {
+            const int kt = c[l - 1] / 32, mt = c[l] / 32;
+            HIP_TRY(launch_pack_weight_x3(L[l], 0, 0, c[l - 1], mt, kt, st + off, s));
+            off += (int64_t)mt * kt * 2048;
+        }
+        return pack_fc(L + 4, w.fc, s);
+    }
     if (lp) {
         const PointHeadLpW w = point_head_lp_view(packed_dev, head_kind);
         HIP_TRY(launch_pack_weight(L[0], PACK_FIRST, 0, c_in, c[0] / 32, ks, mut(w.w1), s));
@@ -405,7 +512,8 @@ extern "C" size_t dal3_ins_seg_workspace_bytes(int B) {
 }
 
 static int check_dtype(int dtype) {
-    if (dtype != DAL3_F32 && dtype != DAL3_BF16 && dtype != DAL3_F16) return fail(DAL3_EINVAL, "unknown dtype %d", dtype);
+    if (dtype != DAL3_F32 && dtype != DAL3_BF16 && dtype != DAL3_F16 && dtype != DAL3_F16X3)
+        return fail(DAL3_EINVAL, "unknown dtype %d", dtype);
     return 0;
 }
 
@@ -424,6 +532,11 @@ static int ins_seg_run(const void* packed, int dtype, int c_in, const dal3_bcn& 
         // per-crop part of dconv1: gb = W1g' . g + b1'   (static_model.py:286-289 without the repeat+cat)
         HIP_TRY(launch_fc(w.dw1g, w.db1, ws.g, 1024, ws.gb, 512, B, 1024, 512, 0, s));
         HIP_TRY(launch_ins_seg_decode(w, x, c_in, B, N, ws.gb, logits, mask, s));
+    } else if (dtype == DAL3_F16X3) {
+        const InsSegX3W w = ins_seg_x3_view(packed);
+        HIP_TRY(launch_ins_seg_encode_x3(w, x, c_in, B, N, ws.g, s));
+        HIP_TRY(launch_fc(w.dw1g, w.db1, ws.g, 1024, ws.gb, 512, B, 1024, 512, 0, s));
+        HIP_TRY(launch_ins_seg_decode_x3(w, x, c_in, B, N, ws.gb, logits, mask, s));
     } else {
         const InsSegLpW w = ins_seg_lp_view(packed);
         HIP_TRY(launch_ins_seg_encode_lp(dtype, w, x, c_in, B, N, ws.g, s));
@@ -456,6 +569,8 @@ extern "C" int dal3_ins_seg_encode(const void* packed, int dtype, int c_in, dal3
     if (dtype == DAL3_F32)
         HIP_TRY(launch_ins_seg_encode(ins_seg_view(static_cast<const float*>(packed), c_in), to_bcn(pts), c_in, B, N,
                                       global_feat, s));
+    else if (dtype == DAL3_F16X3)
+        HIP_TRY(launch_ins_seg_encode_x3(ins_seg_x3_view(packed), to_bcn(pts), c_in, B, N, global_feat, s));
     else
         HIP_TRY(launch_ins_seg_encode_lp(dtype, ins_seg_lp_view(packed), to_bcn(pts), c_in, B, N, global_feat, s));
     return 0;
@@ -465,8 +580,10 @@ extern "C" int dal3_ins_seg_global_bias(const void* packed, int dtype, const flo
                                         dal3_stream stream) {
     TRY(check_dtype(dtype));
     if (!packed || !global_feat || !gbias || B <= 0) return fail(DAL3_EINVAL, "ins_seg_global_bias: bad argument");
-    const float* dw1g = dtype == DAL3_F32 ? ins_seg_view(static_cast<const float*>(packed), 3).dw1g : ins_seg_lp_view(packed).dw1g;
-    const float* db1 = dtype == DAL3_F32 ? ins_seg_view(static_cast<const float*>(packed), 3).db1 : ins_seg_lp_view(packed).db1;
+    const float* dw1g = dtype == DAL3_F32 ? ins_seg_view(static_cast<const float*>(packed), 3).dw1g
+                        : dtype == DAL3_F16X3 ? ins_seg_x3_view(packed).dw1g : ins_seg_lp_view(packed).dw1g;
+    const float* db1 = dtype == DAL3_F32 ? ins_seg_view(static_cast<const float*>(packed), 3).db1
+                       : dtype == DAL3_F16X3 ? ins_seg_x3_view(packed).db1 : ins_seg_lp_view(packed).db1;
     HIP_TRY(launch_fc(dw1g, db1, global_feat, 1024, gbias, 512, B, 1024, 512, 0, static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -481,6 +598,8 @@ extern "C" int dal3_ins_seg_decode(const void* packed, int dtype, int c_in, dal3
     if (dtype == DAL3_F32)
         HIP_TRY(launch_ins_seg_decode(ins_seg_view(static_cast<const float*>(packed), c_in), to_bcn(pts), c_in, B, N,
                                       gbias, logits, mask, s));
+    else if (dtype == DAL3_F16X3)
+        HIP_TRY(launch_ins_seg_decode_x3(ins_seg_x3_view(packed), to_bcn(pts), c_in, B, N, gbias, logits, mask, s));
     else
         HIP_TRY(launch_ins_seg_decode_lp(dtype, ins_seg_lp_view(packed), to_bcn(pts), c_in, B, N, gbias, logits, mask, s));
     return 0;
@@ -589,6 +708,11 @@ static int point_head_run(int head_kind, const void* packed, int dtype, const da
     TRY(check_bcn(x, "x"));
     int c_in, ks, c[4], n_fc, fi[3], fo[3];
     point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
+    if (dtype == DAL3_F16X3) {
+        const PointHeadX3W w = point_head_x3_view(packed, head_kind);
+        HIP_TRY(launch_point_head_x3(head_kind, w, to_bcn(x), c_in, B, M, ws.feat, distinct, s));
+        return fc_chain(w.fc, ws.feat, 512, out, out_stride, B, ws.t1, ws.t2, s, dec);
+    }
     if (dtype != DAL3_F32) {
         const PointHeadLpW w = point_head_lp_view(packed, head_kind);
         HIP_TRY(launch_point_head_lp(dtype, head_kind, w, to_bcn(x), c_in, B, M, ws.feat, distinct, s));
@@ -627,6 +751,10 @@ extern "C" int dal3_point_head_pool(int head_kind, const void* packed, int dtype
     hipStream_t s = static_cast<hipStream_t>(stream);
     int c_in, ks, c[4], n_fc, fi[3], fo[3];
     point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
+    if (dtype == DAL3_F16X3) {
+        HIP_TRY(launch_point_head_x3(head_kind, point_head_x3_view(packed, head_kind), to_bcn(x), c_in, B, M, feat, n_distinct, s));
+        return 0;
+    }
     if (dtype != DAL3_F32) {
         const PointHeadLpW w = point_head_lp_view(packed, head_kind);
         HIP_TRY(launch_point_head_lp(dtype, head_kind, w, to_bcn(x), c_in, B, M, feat, n_distinct, s));
@@ -1095,7 +1223,7 @@ extern "C" int dal3_maxpool_n(const float* x, int64_t rows, int64_t n, float* ou
 }
 
 extern "C" int dal3_maxpool_n_dtype(const void* x, int dtype, int64_t rows, int64_t n, void* out, dal3_stream stream) {
-    TRY(check_dtype(dtype));
+    if (dtype != DAL3_F32 && dtype != DAL3_BF16 && dtype != DAL3_F16) return fail(DAL3_EINVAL, "maxpool_n: storage dtype %d", dtype);
     if (!x || !out || rows <= 0 || n <= 0) return fail(DAL3_EINVAL, "maxpool_n: bad argument");
     if (dtype != DAL3_F32 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 1))
         return fail(DAL3_EINVAL, "maxpool_n: 16-bit rows must be 2-byte aligned");

@@ -116,6 +116,44 @@ struct PointHeadLpW {
     const uint16_t* stream;
     FcW fc;
 };
+// ---- "f16x3" (dal3_pointmlp_x3.hip): fp16 MFMAs on (hi, lo) split operands, fp32 accuracy. Same blob shape as the 16-bit
+// heads (fp32 first layer, biases, FC; one fragment stream), the stream holding a (hi, lo) fragment pair per k-step and
+// padded to whole ring segments per group of points.
+#ifndef DAL3_X3_HEAD_T
+#define DAL3_X3_HEAD_T 2
+#endif
+#ifndef DAL3_X3_ENC_T
+#define DAL3_X3_ENC_T 4
+#endif
+#ifndef DAL3_X3_DEC_T
+#define DAL3_X3_DEC_T 2
+#endif
+typedef PointHeadLpW PointHeadX3W;
+struct InsSegX3W {
+    const float* w1;          // fp32 first layer [2][2][64]
+    const float* b1;
+    const float* bias_enc;    // b2 64 | b3 64 | b4 128 | b5 1024
+    const float* bias_dec;    // b2 64 | db2 256 | db3 128 | db4 128 | db5 (32: rows 0, 1 real)
+    const float* dw1g;        // fp32 row-major (512,1024): the per-crop part of dconv1
+    const float* db1;         // 512
+    const uint16_t* enc_stream;   // 18 segments of 32 fragments
+    const uint16_t* dec_stream;   // 27 segments
+};
+size_t ins_seg_x3_packed_bytes();
+InsSegX3W ins_seg_x3_view(const void* base);
+hipError_t launch_ins_seg_encode_x3(const InsSegX3W& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s);
+hipError_t launch_ins_seg_decode_x3(const InsSegX3W& w, BCN pts, int c_in, int B, int N, const float* gbias, float* logits,
+                                    uint8_t* mask, hipStream_t s);
+size_t point_head_x3_packed_bytes(int head_kind);
+PointHeadX3W point_head_x3_view(const void* base, int head_kind);
+int point_head_x3_segments(int head_kind);
+hipError_t launch_point_head_x3(int head_kind, const PointHeadX3W& w, BCN x, int c_in, int B, int M, float* feat,
+                                const int32_t* distinct, hipStream_t s);
+// (hi, lo) fragment pairs of a layer, out-tile major: [mt][kt][k-step][hi | lo][64 lanes][8]; element order as
+// launch_pack_weight_lp; kt_major: [kt][mt][...] (a K-major layer consumed chunk by chunk)
+hipError_t launch_pack_weight_x3(const dal3_layer& L, int kt_major, int col_off, int n_cols, int mt_n, int kt_n, uint16_t* out,
+                                 hipStream_t s, int grp_blocks = 0, int64_t grp_a0 = 0, int64_t grp_a1 = 0,
+                                 int64_t grp_stride = 0);
 size_t ins_seg_lp_packed_bytes();
 InsSegLpW ins_seg_lp_view(const void* base);
 size_t point_head_lp_packed_bytes(int head_kind);

@@ -38,7 +38,11 @@ enum {
  * precision). DAL3_BF16 / DAL3_F16: weights and inter-layer activations rounded to 16 bits, fp32 accumulate,
  * v_mfma_f32_32x32x16_{bf16,f16} (BASELINE.json configs C3 / C5); first layer, FC heads, dconv5, mask and all
  * I/O stay fp32. The same dtype must be given to dal3_pack_weights and to the forward calls. */
-enum { DAL3_F32 = 0, DAL3_BF16 = 1, DAL3_F16 = 2 };
+enum { DAL3_F32 = 0, DAL3_BF16 = 1, DAL3_F16 = 2,
+       /* fp16 MFMAs on (hi, lo) SPLIT operands: x = x_hi + x_lo, w = w_hi + w_lo in fp16, w x ~ w_hi x_hi + w_hi x_lo + w_lo x_hi,
+        * fp32 accumulate — fp32 ACCURACY (logits ~1e-6 of their range, like DAL3_F32) from three fp16 MFMAs per fp32 one.
+        * An arithmetic dtype of packed weights only (never a storage dtype of dal3_bcn / dal3_maxpool_n_dtype). */
+       DAL3_F16X3 = 3 };
 
 /* which sub-network a packed-weight blob belongs to */
 enum {
