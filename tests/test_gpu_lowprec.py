@@ -227,7 +227,7 @@ def test_persistent_groups_equal_single_group_launches(kind, n):
 
 # ------------------------------------------------------------------ 16-bit STORAGE of points and box windows (round 3)
 @pytest.mark.parametrize("store", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16x3"])
 @pytest.mark.parametrize("B,N", [(5, 512), (40, 1024)])      # latency family / throughput family
 def test_static_points_stored_in_16_bits_are_read_in_place(store, prec, B, N):
     """configs C3 / C5 say "bf16 storage": points handed over as bf16 / fp16 tensors are read by the kernels as they are
@@ -265,7 +265,7 @@ def test_dynamic_points_and_box_windows_stored_in_16_bits(store):
     model = build_model("dynamic", sd)
     p16, b16 = torch.from_numpy(p).cuda().to(store), torch.from_numpy(bx).cuda().to(store)
     init = torch.from_numpy(i8).cuda()
-    for prec in ("fp32", "bf16", "fp16"):
+    for prec in ("fp32", "bf16", "fp16", "f16x3"):
         model.precision = prec
         a = model.refine(p16.transpose(2, 1), b16.transpose(2, 1), init).clone()
         b = model.refine(p16.float().transpose(2, 1), b16.float().transpose(2, 1), init)

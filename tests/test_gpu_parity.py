@@ -16,6 +16,7 @@ hip = importlib.import_module("3dal_pytorch_amd._hip")
 heads = importlib.import_module("3dal_pytorch_amd._heads")
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+MARGIN_FACTOR = 20          # how many times the measured logit error the fixtures' smallest |margin| must be (f16x3: 10, test_gpu_x3.py)
 
 
 def dev(x):
@@ -299,7 +300,7 @@ def test_dynamic_forward_vs_reference_golden():
     # point is >= min_abs_margin from the tie, far above the fp32 error of the logits, so the free-running mask,
     # the draws and every box parameter must agree — unconditionally
     err = np.abs(out["logits"].cpu().numpy() - g["logits"]).max()
-    assert float(g["min_abs_margin"]) > 20 * err, (float(g["min_abs_margin"]), err)
+    assert float(g["min_abs_margin"]) > MARGIN_FACTOR * err, (float(g["min_abs_margin"]), err)
     assert np.array_equal(out["mask"].cpu().numpy(), g["mask"])
     assert np.array_equal(model.last["obj_idx"].cpu().numpy(), g["indices"])
     for k in ("center", "heading_scores", "heading_residuals_normalized", "heading_residuals", "size_scores",
