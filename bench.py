@@ -57,9 +57,12 @@ dal3_graph = importlib.import_module("3dal_pytorch_amd.graph")
 
 # dense peaks per arithmetic dtype (MI355X_MICROARCH.md "Chip-level parameters": f32 MFMA = v_mfma_f32_32x32x2_f32,
 # exact f32; bf16/fp16 ~2.5 PF dense)
-MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0, "f16x3": 2500.0}   # f16x3 executes on the fp16 MFMA
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
-DNAME = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}
+DNAME = {"fp32": "f32", "bf16": "bf16", "fp16": "f16", "f16x3": "f16x3 (fp16 MFMA on (hi, lo) split operands, fp32 accumulate)"}
+# f16x3: three fp16 MFMAs per multiply-accumulate of the fp32 formulation (w_hi x_hi + w_hi x_lo + w_lo x_hi): the EXECUTED
+# work of its MFMA layers is 3 x the algorithmic one, against the fp16 peak; `frac_algorithmic` is then at most 1/3
+EXEC_MULT = {"fp32": 1, "bf16": 1, "fp16": 1, "f16x3": 3}
 
 
 def events_ms(fn, iters, warmup=2):
@@ -86,6 +89,8 @@ def recentre(model, fwd):
 
 
 def storage_of(precision):
+    if precision == "f16x3":                               # fp32 accuracy: fp32-stored points, like the fp32 path
+        return torch.float32
     """how a workload's points (and box windows) are STORED on the device: BASELINE.json's 16-bit configurations say
     "bf16 storage" (C3: bf16 arithmetic; C5: bf16 storage, fp16 MFMA), the fp32 ones fp32. The kernels read either in
     place (dal3_bcn.dtype); no fp32 copy of 16-bit points is made."""
@@ -198,6 +203,8 @@ def kernel_table(model, inputs, static, B, N, iters):
     out = {}
 
     def row(name, t, alg_mac, exe_mac, note=None):
+        if "fc_kernel" not in name:
+            exe_mac = exe_mac * EXEC_MULT[prec]
         tf = 2.0 * alg_mac / (t * 1e-3) / 1e12
         tfe = 2.0 * exe_mac / (t * 1e-3) / 1e12
         # frac_executed = what the silicon did; frac_algorithmic = the reference's work over the same time (above 1 where
@@ -206,11 +213,13 @@ def kernel_table(model, inputs, static, B, N, iters):
              "executed_gflop": round(2.0 * exe_mac / 1e9, 2), "tflops_executed": round(tfe, 2),
              "frac_executed": round(tfe / peak, 4), "tflops_algorithmic": round(tf, 2),
              "frac_algorithmic": round(tf / peak, 4)}
+        if prec == "f16x3":                                # what the fp32 formulation's work runs at, next to the fp32 MFMA's peak
+            r["x_fp32_mfma_peak"] = round(tf / MFMA_PEAK_TFLOPS["fp32"], 3)
         if note:
             r["note"] = note
         out[name] = r
     lp = prec != "fp32"
-    sfx = "_lp_kernel" if lp else "_kernel"
+    sfx = "_x3_kernel" if prec == "f16x3" else "_lp_kernel" if lp else "_kernel"
     row("ins_seg_encode" + sfx, events_ms(enc, iters), arch.ins_seg_encode_mac(c_in) * B * N,
         arch.ins_seg_encode_mac(c_in, True) * B * N)
     row("fc_kernel[dconv1 global term]", events_ms(fc, iters), 1024 * 512 * B, 1024 * 512 * arch._pad(B, 32))
@@ -636,6 +645,10 @@ def apply_config(args):
         args.head, args.precision, args.batch, args.points, args.two_stage = "static", "fp32", 4096, 1024, True
     elif args.config == "Dynamic_fp32":                    # the dynamic head in the reference's own arithmetic, C3's shape
         args.head, args.precision, args.batch, args.points = "dynamic", "fp32", 1024, 1024
+    elif args.config == "Dynamic_f16x3":                   # the same, split-fp16 arithmetic (fp32 accuracy: DESIGN.md 5.4)
+        args.head, args.precision, args.batch, args.points = "dynamic", "f16x3", 1024, 1024
+    elif args.config == "TwoBoxEst_f16x3":
+        args.head, args.precision, args.batch, args.points, args.two_stage = "static", "f16x3", 4096, 1024, True
 
 
 def plumbing_only(args, rank, world):
@@ -697,7 +710,7 @@ def main():
     ap.add_argument("--head", default="static", choices=["static", "dynamic"])
     ap.add_argument("--batch", type=int, default=0, help="items per GPU (default: 4096 static, 1024 dynamic)")
     ap.add_argument("--points", type=int, default=1024)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16", "f16x3"],
                     help="arithmetic of the shared-MLP kernels (fp32 = the reference's; bf16/fp16 = configs C3/C5)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / maxpool / configs / cpu_baseline legs")
     ap.add_argument("--only-maxpool", action="store_true", help="run only the standalone max-pool kernel (profiling)")
@@ -706,7 +719,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="run consecutive steps on this many HIP streams (graph.StreamPipe): small batches, one GPU")
     ap.add_argument("--two-stage", action="store_true", help="static head: StaticModelTwoBoxEst instead of OneBoxEst")
-    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5", "TwoBoxEst", "Dynamic_fp32"],
+    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5", "TwoBoxEst", "Dynamic_fp32", "TwoBoxEst_f16x3", "Dynamic_f16x3"],
                     help="BASELINE.json configs by name: C2 = the default (static, 4096 x 1024, fp32); C3 = dynamic head, "
                          "1024 items x 5 x 1024 pts, bf16; C4 = one segment (64 static crops x 4096 pts + 40 dynamic tracks), sharded "
                          "over the GPUs (strong scaling); C5 = static, N=4096, 2048 crops per GPU, fp16 MFMA; TwoBoxEst = StaticModelTwoBoxEst "
@@ -850,6 +863,36 @@ def main():
                                             executed_gflop_per_step(k2, static, B) / (d * 1e3) / MFMA_PEAK_TFLOPS[prec], 4),
                                         "roofline": roofline_of(k2, MFMA_PEAK_TFLOPS[prec], prec, B, N),
                                         "kernels": k2}
+            # the fp32 formulation on the fp16 MFMA: every operand as an (hi, lo) fp16 pair, three MFMAs per product,
+            # fp32 accumulate. Its distance from the exact-fp32 path is measured here on this very
+            # input, beside its step; `value` stays the exact-fp32 path's.
+            with torch.no_grad():
+                model.precision = args.precision
+                ref = model(*inputs)
+                model.precision = "f16x3"
+                got = model(*inputs)
+            d, _, _ = time_steps(wl, dev, args.steps, 5, False)
+            d /= args.steps
+            k3, _ = kernel_table(model, inputs, static, B, N, iters=max(3, min(args.steps, 10)))
+            same = (ref["mask"] == got["mask"]).all(1)
+            lg = (ref["logits"] - got["logits"]).abs().max().item() / ref["logits"].abs().max().item()
+            bx = {k: round(((ref[k] - got[k])[same].abs().max() / ref[k].abs().max()).item(), 9)
+                  for k in ref if k not in ("logits", "mask") and torch.is_tensor(ref[k]) and ref[k].is_floating_point()
+                  and ref[k].shape[0] == B}
+            rec["f16x3"] = {"value": round(B / d, 1), "unit": "object-crops/s", "ms_per_step": round(d * 1e3, 3),
+                            "dtype": DNAME["f16x3"],
+                            "vs_exact_fp32_path": {
+                                "logits_max_rel": round(lg, 9), "mask_bits_flipped": int((ref["mask"] != got["mask"]).sum()),
+                                "mask_bits": int(ref["mask"].numel()), "crops_with_identical_mask": int(same.sum()),
+                                "outputs_max_rel_on_those": bx,
+                                "note": "the exact-fp32 path itself is 1e-6 from the reference's PyTorch-CPU forward; parity tests: "
+                                        "tests/test_gpu_x3.py (the reference's golden vectors at the fp32 tolerance 1e-4)"},
+                            "whole_path_tflops_algorithmic": round(B / d * wl.flop_item / 1e12, 1),
+                            "x_fp32_mfma_peak": round(B / d * wl.flop_item / 1e12 / MFMA_PEAK_TFLOPS["fp32"], 3),
+                            "whole_path_mfma_frac_executed": round(
+                                executed_gflop_per_step(k3, static, B) / (d * 1e3) / MFMA_PEAK_TFLOPS["f16x3"], 4),
+                            "roofline": roofline_of(k3, MFMA_PEAK_TFLOPS["f16x3"], "f16x3", B, N),
+                            "kernels": k3}
             model.precision = args.precision
         rec["maxpool"] = maxpool_roofline(dev, iters=5)
         rec["maxpool_bf16"] = maxpool_roofline(dev, iters=5, dtype=torch.bfloat16)     # the same rows in 2-byte storage (C3 / C5)
@@ -861,7 +904,8 @@ def main():
             # BASELINE.json's other configurations and the reference's other two model classes in its own arithmetic,
             # driver-timed in the same run (the metric is "static+dynamic heads")
             rec["configs"] = {"C2": "this line's `value`"}
-            for name, st in (("C3", 10), ("C5", 10), ("TwoBoxEst", 5), ("Dynamic_fp32", 5), ("C4", 3)):
+            for name, st in (("C3", 10), ("C5", 10), ("TwoBoxEst", 5), ("TwoBoxEst_f16x3", 5), ("Dynamic_fp32", 5),
+                                 ("Dynamic_f16x3", 5), ("C4", 3)):
                 rec["configs"][name] = other_config(name, dev, st)
         elif static:
             rec["cpu_baseline"] = cpu_baseline(wl.host)
