@@ -348,11 +348,12 @@ extern "C" int dal3_pack_weights(int head_kind, const dal3_layer* L, int n_layer
             HIP_TRY(launch_pack_weight_x3(L[2], 0, 0, 64, 2, 2, enc + 16 * F, s));
             HIP_TRY(launch_pack_weight_x3(L[3], 0, 0, 64, 4, 2, enc + 32 * F, s));
             HIP_TRY(launch_pack_weight_x3(L[4], 0, 0, 128, 32, 4, enc + 64 * F, s));
-            // decode stream: conv2 @0 (16) | 16 x { dconv1a chunk (8), dconv2 chunk (32) } @16 | dconv3 @656 (128) |
-            // dconv4 @784 (64) | dconv5 @848 (16: one out-tile, rows 0, 1 real)
+            // decode stream (chunks software-pipelined, dal3_pointmlp_x3.hip): conv2 @0 (16) | A_0 @16 (8) |
+            // 15 x { A_{c+1} @24+40c (8), D_c @32+40c (32) } | D_15 @624 (32) | dconv3 @656 (128) | dconv4 @784 (64) |
+            // dconv5 @848 (16: one out-tile, rows 0, 1 real)
             HIP_TRY(launch_pack_weight_x3(L[1], 0, 0, 64, 2, 2, dec, s));
-            HIP_TRY(launch_pack_weight_x3(L[5], 0, 0, 64, 16, 2, dec, s, 2, 16 * F, 56 * F, 40 * F));
-            HIP_TRY(launch_pack_weight_x3(L[6], 1, 0, 512, 8, 16, dec, s, 8, 24 * F, 64 * F, 40 * F));
+            HIP_TRY(launch_pack_weight_x3(L[5], 0, 0, 64, 16, 2, dec, s, 2, 16 * F, 24 * F, 40 * F));
+            HIP_TRY(launch_pack_weight_x3(L[6], 1, 0, 512, 8, 16, dec, s, 8, 32 * F, 72 * F, 40 * F, 624 * F));
             HIP_TRY(launch_pack_weight_x3(L[7], 0, 0, 256, 4, 8, dec + 656 * F, s));
             HIP_TRY(launch_pack_weight_x3(L[8], 0, 0, 128, 4, 4, dec + 784 * F, s));
             HIP_TRY(launch_pack_weight_x3(L[9], 0, 0, 128, 1, 4, dec + 848 * F, s));

@@ -123,7 +123,7 @@ struct PointHeadLpW {
 #define DAL3_X3_HEAD_T 2
 #endif
 #ifndef DAL3_X3_ENC_T
-#define DAL3_X3_ENC_T 4
+#define DAL3_X3_ENC_T 2
 #endif
 #ifndef DAL3_X3_DEC_T
 #define DAL3_X3_DEC_T 2
@@ -153,7 +153,7 @@ hipError_t launch_point_head_x3(int head_kind, const PointHeadX3W& w, BCN x, int
 // launch_pack_weight_lp; kt_major: [kt][mt][...] (a K-major layer consumed chunk by chunk)
 hipError_t launch_pack_weight_x3(const dal3_layer& L, int kt_major, int col_off, int n_cols, int mt_n, int kt_n, uint16_t* out,
                                  hipStream_t s, int grp_blocks = 0, int64_t grp_a0 = 0, int64_t grp_a1 = 0,
-                                 int64_t grp_stride = 0);
+                                 int64_t grp_stride = 0, int64_t grp_last = -1);
 size_t ins_seg_lp_packed_bytes();
 InsSegLpW ins_seg_lp_view(const void* base);
 size_t point_head_lp_packed_bytes(int head_kind);

@@ -75,7 +75,7 @@ __global__ void pack_weight_lp_kernel(dal3_layer L, int dtype, int kt_major, int
 // is four 1-KiB fragments [k-step 0: hi, lo][k-step 1: hi, lo]; element order inside a fragment as above.
 __global__ void pack_weight_x3_kernel(dal3_layer L, int kt_major, int col_off, int n_cols, int mt_n, int kt_n,
                                       uint16_t* __restrict__ out, int64_t total, int grp_blocks, int64_t grp_a0,
-                                      int64_t grp_a1, int64_t grp_stride) {
+                                      int64_t grp_a1, int64_t grp_stride, int64_t grp_last) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int j = (int)(i & 7), lane = (int)((i >> 3) & 63), half = (int)((i >> 9) & 1), s = (int)((i >> 10) & 1);
@@ -89,15 +89,18 @@ __global__ void pack_weight_x3_kernel(dal3_layer L, int kt_major, int col_off, i
     int64_t o = i;
     if (grp_blocks > 0) {
         const int g = blk / grp_blocks;
-        o = (g == 0 ? grp_a0 : grp_a1 + (int64_t)(g - 1) * grp_stride) + (int64_t)(blk % grp_blocks) * 2048 + (i & 2047);
+        // (grp_last >= 0: the last group sits there instead — the decoder's D_15, which has no A block in front of it)
+        const bool last = grp_last >= 0 && g == mt_n * kt_n / grp_blocks - 1;
+        o = (last ? grp_last : g == 0 ? grp_a0 : grp_a1 + (int64_t)(g - 1) * grp_stride) + (int64_t)(blk % grp_blocks) * 2048 + (i & 2047);
     }
     out[o] = __builtin_bit_cast(uint16_t, half ? lo : hi);
 }
 hipError_t launch_pack_weight_x3(const dal3_layer& L, int kt_major, int col_off, int n_cols, int mt_n, int kt_n, uint16_t* out,
-                                 hipStream_t s, int grp_blocks, int64_t grp_a0, int64_t grp_a1, int64_t grp_stride) {
+                                 hipStream_t s, int grp_blocks, int64_t grp_a0, int64_t grp_a1, int64_t grp_stride,
+                                 int64_t grp_last) {
     const int64_t total = (int64_t)mt_n * kt_n * 2048;
     hipLaunchKernelGGL(pack_weight_x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L, kt_major, col_off, n_cols,
-                       mt_n, kt_n, out, total, grp_blocks, grp_a0, grp_a1, grp_stride);
+                       mt_n, kt_n, out, total, grp_blocks, grp_a0, grp_a1, grp_stride, grp_last);
     return hipGetLastError();
 }
 

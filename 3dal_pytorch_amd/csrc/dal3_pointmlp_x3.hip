@@ -28,143 +28,284 @@ typedef f16x8_t x3v8;
 
 // one 32-channel x 32-point activation tile as the B operands of its two k-steps (16 channels each), split in two halves
 struct X3Tile {
-    x3v8 hi[2], lo[2];
+    int hi[2][4], lo[2][4];             // (32-bit pieces, written one split unit at a time)
 };
+__device__ __forceinline__ x3v8 x3_operand(const int (&p)[4]) {
+    const int4_t v = {p[0], p[1], p[2], p[3]};
+    return __builtin_bit_cast(x3v8, v);
+}
 
 __device__ __forceinline__ f32x16 x3_mfma(x3v8 a, x3v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// relu, then hi = fp16(x), lo = fp16(x - hi) pair by pair (register pair i of k-step s holds channels 16s + 8(i>>1)... as
-// in pack_relu of dal3_lp.h: the A operands' k order is permuted to match by the packer)
+// One UNIT of a tile's split (q = 0..7: registers 8 (q >> 2) + 2 (q & 3), + 1 of the accumulator): bias, relu, then
+// hi = fp16(x), lo = fp16(x - hi) for the pair -> one 32-bit element of the tile's hi and lo operands (register pair i of
+// k-step s holds channels 16 s + 8 (i >> 1) ... as in pack_relu of dal3_lp.h: the A operands' k order is permuted to
+// match by the packer). Ten issue slots (2 accumulator reads, pk_add, 2 max, cvt_pk, 2 cvt, pk_add, cvt_pk): a tile is
+// 80, i.e. as long as 10 of its 6 KT MFMAs — which is why the units are dealt out under the NEXT block's MFMAs
+// (x3_layer) instead of standing between two blocks with the matrix pipe idle.
+template <bool BIAS>
+__device__ __forceinline__ void x3_split_unit(const f32x16& acc, const f32x16& bv, X3Tile& t, int q) {
+    const int s = q >> 2, i = q & 3, r = 8 * s + 2 * i;
+    f32x2 p = {acc[r], acc[r + 1]};
+    if (BIAS) {
+        const f32x2 b = {bv[r], bv[r + 1]};
+        p = p + b;
+    }
+    p[0] = relu1(p[0]);
+    p[1] = relu1(p[1]);
+    const f16x2_t hh = __builtin_convertvector(p, f16x2_t);
+    const f32x2 back = __builtin_convertvector(hh, f32x2);
+    const f32x2 rest = p - back;
+    const f16x2_t ll = __builtin_convertvector(rest, f16x2_t);
+    t.hi[s][i] = __builtin_bit_cast(int, hh);
+    t.lo[s][i] = __builtin_bit_cast(int, ll);
+}
+// a whole tile at once (the fp32 first layer's output: bias already in the accumulator)
 __device__ __forceinline__ X3Tile x3_split_relu(const f32x16& acc) {
     X3Tile t;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        int4_t wh, wl;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x2 p = {relu1(acc[8 * s + 2 * i]), relu1(acc[8 * s + 2 * i + 1])};
-            const f16x2_t h = __builtin_convertvector(p, f16x2_t);
-            const f32x2 back = __builtin_convertvector(h, f32x2);
-            const f32x2 rest = {p[0] - back[0], p[1] - back[1]};
-            const f16x2_t l = __builtin_convertvector(rest, f16x2_t);
-            wh[i] = __builtin_bit_cast(int, h);
-            wl[i] = __builtin_bit_cast(int, l);
-        }
-        t.hi[s] = __builtin_bit_cast(x3v8, wh);
-        t.lo[s] = __builtin_bit_cast(x3v8, wl);
-    }
+    for (int q = 0; q < 8; ++q) x3_split_unit<false>(acc, acc, t, q);
     return t;
 }
+// units [step PER, (step + 1) PER) of the split of T accumulator tiles a[.] into Y[.][m] (unit u: tile u / 8, piece u % 8)
+template <int PER, int T, int MT>
+__device__ __forceinline__ void x3_split_steps(const f32x16 (&a)[T], const f32x16& bv, X3Tile (&Y)[T][MT], int m, int step) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int u = step * PER + k;
+        if (u >= 0 && u < 8 * T) x3_split_unit<true>(a[u >> 3], bv, Y[u >> 3][m], u & 7);
+    }
+}
 
-// The weight stream of one kernel, walked by a wave-uniform cursor. Stream order = consumption order; a k-step is a
-// (hi, lo) fragment pair; the stream is padded to whole segments per group of points, so every group starts at the
-// beginning of a segment. next(): the segment in use is finished (every fragment of it is in registers or used) ->
-// counted wait + barrier (LdsRing::acquire_wait), then the refill of the slot just freed is PENDING: pump() issues one
-// of its LDS-DMA instructions and is called once per k-step from the blocks that follow, i.e. the refill is spread over
-// the next segment's MFMAs (the third slot gives it a further segment to land). All parts are out before the next
-// acquire_wait (flush()), whose counted vmcnt relies on it.
+// The weight stream of one kernel, walked by a wave-uniform cursor that is a compile-time constant everywhere (all loops
+// over the stream are unrolled; a runtime loop's body consumes whole segments and re-pins the cursor at its top, pin()).
+// Stream order = consumption order; a k-step is a (hi, lo) fragment pair. The pair of the NEXT k-step is always in
+// registers already (nh, nl): take() hands it out and requests the one after it, so its LDS round trip runs under the
+// k-step's own 3 T MFMAs — across blocks, layers and groups of points (the stream is cyclic, a group ends where the
+// next one starts). after(), behind the k-step's MFMAs: one instruction of the pending refill (pump()), and, when
+// the pair just requested was the last of its segment, the next segment is opened right there — counted wait + barrier
+// (LdsRing::acquire_wait) with the matrix pipe still busy, a k-step before anything of that segment is needed. The
+// refill of the slot this frees is then PENDING: its LDS-DMA instructions go out one per k-step (the third slot gives it
+// a further segment to land); all of them are out before the next acquire_wait, whose counted vmcnt relies on it.
 struct X3Stream {
     typedef LdsRing<X3_SEG, 3> Ring;
     Ring ring;
     int cur, pending;
-    __device__ __forceinline__ void init(const void* stream, char* lds, int n_segs, int wave, int lane) {
-        ring.init(stream, lds, n_segs, wave, lane, true);  // segments 0 and 1 in flight
-        cur = X3_SEG;                                      // the first pair() opens segment 0: every group of points then
-        pending = 0;                                       // starts in the same cursor state (cur == X3_SEG)
-    }
+    x3v8 nh, nl;
     __device__ __forceinline__ void pump() {
         if (pending > 0) {
             ring.issue_part(Ring::MY_LOADS - pending);
             if (--pending == 0) ring.issue_done();
         }
     }
-    __device__ __forceinline__ void next() {
+    __device__ __forceinline__ void flush() {
         while (pending > 0) pump();
+    }
+    __device__ __forceinline__ void open() {
+        flush();
         ring.acquire_wait();
         pending = Ring::MY_LOADS;
         cur = 0;
     }
-    // the (hi, lo) pair of the next k-step
-    __device__ __forceinline__ void pair(x3v8& wh, x3v8& wl) {
-        if (cur == X3_SEG) next();
-        wh = ring.template frag<FP16>(cur);
-        wl = ring.template frag<FP16>(cur + 1);
+    __device__ __forceinline__ void fetch() {
+        nh = ring.template frag<FP16>(cur);
+        nl = ring.template frag<FP16>(cur + 1);
         cur += 2;
     }
-    // end of a group of points: whatever is left of the open segment is padding, the next pair() opens the following one
-    __device__ __forceinline__ void skip_padding() { cur = X3_SEG; }
+    // state at the start of every group of points: first pair in (nh, nl), cur == 2, nothing pending
+    __device__ __forceinline__ void init(const void* stream, char* lds, int n_segs, int wave, int lane) {
+        ring.init(stream, lds, n_segs, wave, lane, true);  // segments 0 and 1 in flight
+        pending = 0;
+        open();
+        flush();
+        fetch();
+    }
+    __device__ __forceinline__ void take(x3v8& wh, x3v8& wl) {
+        wh = nh;
+        wl = nl;
+        fetch();
+    }
+    __device__ __forceinline__ void after() {
+        pump();
+        if (cur == X3_SEG) open();
+    }
+    // end of a group of points: a stream of whole segments needs nothing (the last take() fetched the next group's first
+    // pair); otherwise what is left of the open segment is padding
+    __device__ __forceinline__ void end_group() {
+        if (cur != 2) {
+            open();
+            fetch();
+        }
+        flush();
+    }
+    // top of a runtime loop whose body leaves the cursor where it found it: tell the compiler
+    __device__ __forceinline__ void pin(int c, int p) {
+#ifdef DAL3_X3_CHECK
+        if (cur != c || pending != p) __builtin_trap();
+#endif
+        cur = c;
+        pending = p;
+    }
 };
 
-// acc[j] += W'(32 x 32 KT) . X[j] for the wave's T point tiles: 2 KT k-steps, three MFMAs per k-step and tile.
-// SWAP: operands exchanged, acc[j] += X[j]^T . W'^T — the transposed tile of the max-pooled layers (points on the
-// accumulator's registers, channels on its lanes: the max over points is a max over registers).
-template <int KT, int T, bool SWAP = false>
-__device__ __forceinline__ void x3_block(X3Stream& st, const X3Tile (&X)[T][KT], f32x16 (&acc)[T]) {
-    x3v8 wh, wl, nh, nl;
-    st.pair(wh, wl);
+struct X3NoSide {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+// The same MFMA with its accumulator in ARCHITECTURAL VGPRs, written as inline asm: hipcc selects one form per function
+// (accumulators in AccVGPRs as soon as a kernel needs more than fit the VGPR file) and the decoder's resident dconv2
+// accumulators alone are all 256 AccVGPRs — 32 more for the dconv1 chunk were spilled to scratch, and every reload
+// waited with vmcnt(0) for the weight ring's loads in flight. Hazards the compiler does not see inside asm, by hand:
+// a chain alternates its T >= 2 accumulators (exact-overlap SrcC, an independent MFMA in between); the VALU that reads
+// the result comes behind x3_mfma_v_settle() (8-pass MFMA: 11 wait states); operands written by VALU / LDS are tracked
+// by the compiler's own waitcnt and hazard passes through the asm's register operands.
+template <bool ZEROC>
+__device__ __forceinline__ void x3_mfma_v(f32x16& acc, x3v8 a, x3v8 b) {
+    if (ZEROC)
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+    else
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <int T>
+__device__ __forceinline__ void x3_mfma_v_settle(f32x16 (&acc)[T]) {
+    static_assert(T == 2, "one asm statement naming every accumulator");
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+}
+
+// acc[j] (+)= W'(32 x 32 KT) . X[j] for the wave's T point tiles: 2 KT k-steps, three MFMAs per k-step and tile
+// (hi hi, hi lo, lo hi; tiles innermost, so consecutive MFMAs never share an accumulator). ZERO: the first MFMA of every
+// tile takes the constant 0 as C — accumulators are never initialised, biases are added by the split (x3_split_unit).
+// SWAP: operands exchanged, acc[j] = X[j]^T . W'^T — the transposed tile of the max-pooled layers (points on the
+// accumulator's registers, channels on its lanes: the max over points is a max over registers). VG: accumulators in
+// VGPRs (x3_mfma_v).
+// side(s): work for the shadow of k-step s's MFMAs (a slice of the previous tile's split, of a max epilogue ...), dealt
+// out between them VPG VALU instructions per MFMA (sched_group_barrier); s is a constant after unrolling.
+template <int KT, int T, bool SWAP, bool ZERO, int VPG, bool VG = false, class Side>
+__device__ __forceinline__ void x3_block(X3Stream& st, const X3Tile (&X)[T][KT], f32x16 (&acc)[T], Side&& side) {
+    static_assert(!(VG && SWAP) && !(VG && T < 2), "x3_mfma_v");
 #pragma unroll
     for (int s = 0; s < 2 * KT; ++s) {
-        // the next k-step's pair is read before this one's MFMAs (an LDS round trip hides under 3 T MFMAs) — unless it
-        // lies in the next segment, which the barrier in pair() has to open first
-        const bool ahead = s + 1 < 2 * KT && st.cur != X3_SEG;
-        if (ahead) st.pair(nh, nl);
+        x3v8 wh, wl;
+        st.take(wh, wl);
         DAL3_SCHED_FENCE();
 #pragma unroll
-        for (int j = 0; j < T; ++j) {
-            const x3v8 xh = X[j][s >> 1].hi[s & 1], xl = X[j][s >> 1].lo[s & 1];
-            if (SWAP) {
-                acc[j] = x3_mfma(xh, wh, acc[j]);
-                acc[j] = x3_mfma(xl, wh, acc[j]);
-                acc[j] = x3_mfma(xh, wl, acc[j]);
-            } else {
-                acc[j] = x3_mfma(wh, xh, acc[j]);
-                acc[j] = x3_mfma(wh, xl, acc[j]);
-                acc[j] = x3_mfma(wl, xh, acc[j]);
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const x3v8 xh = x3_operand(X[j][s >> 1].hi[s & 1]), xl = x3_operand(X[j][s >> 1].lo[s & 1]);
+                const x3v8 a = r == 2 ? wl : wh, b = r == 1 ? xl : xh;
+                if (VG) {
+                    if (ZERO && s == 0 && r == 0) x3_mfma_v<true>(acc[j], a, b);
+                    else x3_mfma_v<false>(acc[j], a, b);
+                } else {
+                    const f32x16 c = (ZERO && s == 0 && r == 0) ? f32x16{} : acc[j];
+                    acc[j] = SWAP ? x3_mfma(b, a, c) : x3_mfma(a, b, c);
+                }
             }
         }
+        if (VG && s == 2 * KT - 1) x3_mfma_v_settle(acc);
+        side(s);
         st.pump();
-        DAL3_SCHED_FENCE();
-        if (s + 1 < 2 * KT) {
-            if (!ahead) st.pair(nh, nl);
-            wh = nh;
-            wl = nl;
+        if (VPG > 0) {
+#pragma unroll
+            for (int n = 0; n < 3 * T; ++n) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);       // up to VPG VALU
+            }
         }
+        DAL3_SCHED_FENCE();
+        if (st.cur == X3_SEG) st.open();
     }
 }
 
-// Y = split(relu(W' X + b')) for a 32 KT -> 32 MT layer; bias: LDS pointer to the layer's folded bias
-template <int KT, int MT, int T>
-__device__ __forceinline__ void x3_layer(X3Stream& st, const float* bias, const X3Tile (&X)[T][KT], X3Tile (&Y)[T][MT], int h) {
+// what a layer leaves behind: its LAST out-tile still as accumulators, with that tile's bias — whoever consumes the
+// layer's output splits it into its own X[.][KT - 1] under the first k-steps of its first block (x3_carry_steps)
+template <int T>
+struct X3Carry {
+    f32x16 acc[T];
+    f32x16 bv;
+};
+// VALU slots per MFMA for a side of `per` split units per k-step
+__host__ __device__ constexpr int x3_vpg(int per, int t) { return (per * 10 + 3 * t - 1) / (3 * t); }
+// units per k-step so that 8 T units are done within the first 2 KT - 2 k-steps (the last two read X[.][KT - 1])
+__host__ __device__ constexpr int x3_carry_per(int kt, int t) { return (8 * t + 2 * kt - 3) / (2 * kt - 2); }
+template <int KT, int T>
+__device__ __forceinline__ void x3_carry_steps(const X3Carry<T>& c, X3Tile (&X)[T][KT], int s) {
+    static_assert(KT >= 2, "the carried tile is the block's last k-tile");
+    x3_split_steps<x3_carry_per(KT, T)>(c.acc, c.bv, X, KT - 1, s);
+}
+
+// Y = split(relu(W' X + b')) for a 32 KT -> 32 MT layer; bias: LDS pointer to the layer's folded bias. Two accumulator
+// sets: out-tile m - 1 is split under the MFMAs of out-tile m (PER units per k-step), its bias vector read from LDS a
+// k-step before the first unit needs it. The last out-tile is left in `carry`. first(s): the side of the first block
+// (the previous layer's carry, normally), VPG0 its VALU slots per MFMA.
+template <int KT, int MT, int T, int VPG0, class First>
+__device__ __forceinline__ void x3_layer(X3Stream& st, const float* bias, const X3Tile (&X)[T][KT], X3Tile (&Y)[T][MT], int h,
+                                         X3Carry<T>& carry, First&& first) {
+    constexpr int PER = (8 * T + 2 * KT - 1) / (2 * KT);
+    f32x16 acc[2][T];
+    f32x16 bv;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        f32x16 acc[T];
-        const f32x16 b = tile_from_channels(bias + 32 * m, h);
+        if (m == 0) {
+            x3_block<KT, T, false, true, VPG0>(st, X, acc[0], [&](int s) {
+                first(s);
+                if (s == 2 * KT - 1) bv = tile_from_channels(bias, h);
+            });
+        } else {
+            x3_block<KT, T, false, true, x3_vpg(PER, T)>(st, X, acc[m & 1], [&](int s) {
+                x3_split_steps<PER>(acc[(m - 1) & 1], bv, Y, m - 1, s);
+                if (s == 2 * KT - 1) bv = tile_from_channels(bias + 32 * m, h);
+            });
+        }
+    }
 #pragma unroll
-        for (int j = 0; j < T; ++j) acc[j] = b;
-        x3_block<KT, T>(st, X, acc);
+    for (int j = 0; j < T; ++j) carry.acc[j] = acc[(MT - 1) & 1][j];
+    carry.bv = bv;
+}
+
+// slice s of NS of a transposed tile's max epilogue (lp_tile_max_t of dal3_lp.h: max over the wave's 32 T points = over
+// registers, bias added after the max, ReLU on the bit pattern, LDS integer atomicMax), mx carried between the slices
+template <int NS, int T>
+__device__ __forceinline__ void x3_max_step(const f32x16 (&a)[T], float& mx, int s, const float* bias, int* smax, int lane) {
+    constexpr int R = (16 * T + NS - 1) / NS;
 #pragma unroll
-        for (int j = 0; j < T; ++j) Y[j][m] = x3_split_relu(acc[j]);
+    for (int k = 0; k < R; ++k) {
+        const int u = s * R + k;
+        if (u < 16 * T) mx = u == 0 ? a[0][0] : __builtin_fmaxf(mx, a[u >> 4][u & 15]);
+    }
+    if (s == NS - 1) {
+        const int ch = lane & 31;
+        int bits = __float_as_int(mx + bias[ch]);
+        bits = bits > 0 ? bits : 0;
+        atomicMax(smax + ch, bits);
     }
 }
 
-// the max-pooled last layer: n_tiles out-tiles computed transposed, each tile's maxima over the wave's 32 T points joined
-// into the workgroup's LDS array (lp_tile_max_t of dal3_lp.h: bias added after the max, ReLU on the bit pattern, LDS
-// integer atomicMax). Two accumulator sets: a tile's epilogue is issued behind the next tile's first MFMAs.
+// the max-pooled last layer: n_tiles (even) out-tiles computed transposed, each tile's maxima joined into the
+// workgroup's LDS array. Two accumulator sets: a tile's epilogue runs under the next tile's MFMAs; tile 0 runs with the
+// previous layer's carry as its side, the last tile's epilogue stands alone. The loop body is two tiles = a whole
+// number of segments.
 template <int KT, int T>
-__device__ __forceinline__ void x3_max_layer(X3Stream& st, const float* bias, const X3Tile (&X)[T][KT], int* smax, int n_tiles,
-                                             int lane) {
+__device__ __forceinline__ void x3_max_layer(X3Stream& st, const float* bias, X3Tile (&X)[T][KT], int* smax, int n_tiles,
+                                             int lane, const X3Carry<T>& carry) {
+    static_assert((2 * KT * 4) % X3_SEG == 0, "two tiles = whole segments");
+    constexpr int NS = 2 * KT, VPG = ((16 * T + NS - 1) / NS * 2 + 6 + 3 * T - 1) / (3 * T);
     f32x16 acc[2][T];
-    for (int m = 0; m < n_tiles; m += 2) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-#pragma unroll
-            for (int j = 0; j < T; ++j) acc[c][j] = f32x16{};
-            x3_block<KT, T, true>(st, X, acc[c]);
-            lp_tile_max_t<T>(acc[c], bias + 32 * (m + c), smax + 32 * (m + c), lane);
-        }
+    float mx = 0.0f;
+    x3_block<KT, T, true, true, x3_vpg(x3_carry_per(KT, T), T)>(st, X, acc[0], [&](int s) { x3_carry_steps<KT, T>(carry, X, s); });
+    const int c0 = st.cur, p0 = st.pending;
+    for (int m = 1; m + 1 < n_tiles; m += 2) {
+        st.pin(c0, p0);
+        x3_block<KT, T, true, true, VPG>(st, X, acc[1], [&](int s) { x3_max_step<NS>(acc[0], mx, s, bias + 32 * (m - 1), smax + 32 * (m - 1), lane); });
+        x3_block<KT, T, true, true, VPG>(st, X, acc[0], [&](int s) { x3_max_step<NS>(acc[1], mx, s, bias + 32 * m, smax + 32 * m, lane); });
     }
+    const int m = n_tiles - 1;
+    x3_block<KT, T, true, true, VPG>(st, X, acc[1], [&](int s) { x3_max_step<NS>(acc[0], mx, s, bias + 32 * (m - 1), smax + 32 * (m - 1), lane); });
+#pragma unroll
+    for (int s = 0; s < NS; ++s) x3_max_step<NS>(acc[1], mx, s, bias + 32 * m, smax + 32 * m, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ point heads
@@ -208,6 +349,7 @@ __global__ __launch_bounds__(256) void point_head_x3_kernel(PointHeadX3W w, BCN 
             np = d <= 0 ? 1 : (d < np ? d : np);
         }
         if (wg_tile * X3_WAVES * 32 * T >= np) continue;   // only copies in this group: uniform skip (the stream stays put)
+        st.pin(2, 0);
         float in[T][KS];
         load_points<KS, T>(x, b, (wg_tile * X3_WAVES + wave) * (32 * T), np, c_in, in, lane);
         X3Tile x1[T][K2], x2[T][M2], x3[T][M3];
@@ -222,10 +364,12 @@ __global__ __launch_bounds__(256) void point_head_x3_kernel(PointHeadX3W w, BCN 
                 x1[j][mt] = x3_split_relu(acc);
             }
         }
-        x3_layer<K2, M2, T>(st, s_bias, x1, x2, h);
-        x3_layer<K3, M3, T>(st, s_bias + C2, x2, x3, h);
-        x3_max_layer<K4, T>(st, s_bias + C2 + C3, x3, s_max, 16, lane);
-        st.skip_padding();
+        X3Carry<T> carry;
+        x3_layer<K2, M2, T, 0>(st, s_bias, x1, x2, h, carry, X3NoSide());
+        x3_layer<K3, M3, T, x3_vpg(x3_carry_per(K3, T), T)>(st, s_bias + C2, x2, x3, h, carry,
+                                                           [&](int s) { x3_carry_steps<K3, T>(carry, x2, s); });
+        x3_max_layer<K4, T>(st, s_bias + C2 + C3, x3, s_max, 16, lane, carry);
+        st.end_group();
         __syncthreads();
         int* fi = reinterpret_cast<int*>(feat + b * 512);
 #pragma unroll
@@ -313,6 +457,7 @@ __global__ __launch_bounds__(256) void ins_seg_encode_x3_kernel(InsSegX3W w, BCN
     };
     prefetch(blockIdx.x);
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        st.pin(2, 0);
         const int64_t b = grp / tiles_per_item;
         X3Tile x1[T][2], x2[T][2], x3[T][2], x4[T][4];
 #pragma unroll
@@ -330,11 +475,13 @@ __global__ __launch_bounds__(256) void ins_seg_encode_x3_kernel(InsSegX3W w, BCN
             const int nx = grp + (int)gridDim.x;
             prefetch(nx < n_groups ? nx : grp);            // (the last group re-reads itself: uniform control flow)
         }
-        x3_layer<2, 2, T>(st, s_bias, x1, x2, h);
-        x3_layer<2, 2, T>(st, s_bias + 64, x2, x3, h);
-        x3_layer<2, 4, T>(st, s_bias + 128, x3, x4, h);
-        x3_max_layer<4, T>(st, s_bias + 256, x4, s_max, 32, lane);
-        st.skip_padding();
+        X3Carry<T> carry;
+        constexpr int VC = x3_vpg(x3_carry_per(2, T), T);
+        x3_layer<2, 2, T, 0>(st, s_bias, x1, x2, h, carry, X3NoSide());
+        x3_layer<2, 2, T, VC>(st, s_bias + 64, x2, x3, h, carry, [&](int s) { x3_carry_steps<2, T>(carry, x2, s); });
+        x3_layer<2, 4, T, VC>(st, s_bias + 128, x3, x4, h, carry, [&](int s) { x3_carry_steps<2, T>(carry, x3, s); });
+        x3_max_layer<4, T>(st, s_bias + 256, x4, s_max, 32, lane, carry);
+        st.end_group();
         __syncthreads();
         int* gi = reinterpret_cast<int*>(g + b * 1024);
         for (int i = threadIdx.x; i < 1024; i += 256) {
@@ -360,13 +507,51 @@ hipError_t launch_ins_seg_encode_x3(const InsSegX3W& w, BCN pts, int c_in, int B
 }
 
 // ------------------------------------------------------------------------------------------------ decode
-// conv1 (fp32), conv2, then dconv1's per-point part in 16 chunks of 32 channels (initial value: the crop's dconv1 term,
-// fp32) each split and fed straight into dconv2's eight resident accumulator tiles, dconv3, dconv4, and dconv5 as one
-// more out-tile (rows 0, 1) -> logits, mask. Stream per group: conv2 16 | 16 x { dconv1a chunk 8, dconv2 chunk 32 } |
-// dconv3 128 | dconv4 64 | dconv5 16 fragments = 27 segments. LDS small arrays: b2 64 | db2 256 | db3 128 | db4 128 |
-// db5 32 | gb 512 | b1 64 | w1 256 floats.
+// conv1 (fp32), conv2, then dconv1's per-point part in 16 chunks of 32 channels (A_c: 64 -> 32, bias: the crop's dconv1
+// term, fp32) each split and fed straight into dconv2's eight resident accumulator tiles (D_c: 32 -> 256), dconv3,
+// dconv4, and dconv5 as one more out-tile (rows 0, 1) -> logits, mask. The chunks are software-pipelined: A_{c+1} runs
+// BEFORE D_c and its output is split under D_c's MFMAs, so the stream order per group is
+//   conv2 16 | A_0 8 | 15 x { A_{c+1} 8, D_c 32 } | D_15 32 | dconv3 128 | dconv4 64 | dconv5 16 fragments = 27 segments.
+// LDS small arrays: b2 64 | db2 256 | db3 128 | db4 128 | db5 32 | gb 512 | b1 64 | w1 256 floats.
 #define X3_DEC_SMALL_BYTES 6144
 #define X3_DEC_SEGS 27
+
+// one chunk pair: A_{c+1} into t (side: aside, VA slots), then D_c from tc[P] (chunk c, split already) into a2, with
+// chunk c + 1 split into tc[P ^ 1] under its 16 k-steps
+template <int T, bool FIRST, int P, int VA, class ASide>
+__device__ __forceinline__ void x3_dec_pair(X3Stream& st, const X3Tile (&x2)[T][2], f32x16 (&t)[T], X3Tile (&tc)[2][T][1],
+                                            f32x16 (&a2)[8][T], const float* s_gb, int c, int h, ASide&& aside) {
+    constexpr int PER = (8 * T + 15) / 16;
+    f32x16 bv;
+    x3_block<2, T, false, true, VA, true>(st, x2, t, [&](int s) {
+        aside(s);
+        if (s == 3) bv = tile_from_channels(s_gb + 32 * (c + 1), h);
+    });
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+        x3_block<1, T, false, FIRST, x3_vpg(PER, T)>(st, tc[P], a2[mt],
+                                                     [&](int s) { x3_split_steps<PER>(t, bv, tc[P ^ 1], 0, 2 * mt + s); });
+}
+
+// units [step PER, (step + 1) PER) of the split of dconv2's out-tiles TILE0 .. TILE0 + NT - 1 (accumulators a2, bias
+// db2) into dconv3's input xd; bv / bvn: the current and the next tile's bias vectors (read a tile ahead)
+template <int PER, int TILE0, int NT, int T>
+__device__ __forceinline__ void x3_xd_steps(const f32x16 (&a2)[8][T], X3Tile (&xd)[T][8], const float* db2, int h, f32x16& bv,
+                                            f32x16& bvn, int step) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int id = step * PER + k;
+        if (id >= 0 && id < NT * 8 * T) {
+            const int tile = TILE0 + id / (8 * T), u = id % (8 * T);
+            if (u == 0) {
+                bv = bvn;
+                if (tile + 1 < 8) bvn = tile_from_channels(db2 + 32 * (tile + 1), h);
+            }
+            x3_split_unit<true>(a2[tile][u >> 3], bv, xd[u >> 3][tile], u & 7);
+        }
+    }
+}
+
 template <int T>
 __global__ __launch_bounds__(256) void ins_seg_decode_x3_kernel(InsSegX3W w, BCN pts, int c_in, int n_pts, int tiles_per_item,
                                                                 int n_groups, const float* __restrict__ gbias,
@@ -399,6 +584,7 @@ __global__ __launch_bounds__(256) void ins_seg_decode_x3_kernel(InsSegX3W w, BCN
     };
     prefetch(blockIdx.x);
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        st.pin(2, 0);
         const int64_t b = grp / tiles_per_item;
         const int n0 = ((grp % tiles_per_item) * X3_WAVES + wave) * (32 * T);
         __syncthreads();                                   // everyone is done with the previous group's s_gb
@@ -424,53 +610,58 @@ __global__ __launch_bounds__(256) void ins_seg_decode_x3_kernel(InsSegX3W w, BCN
             const int nx = grp + (int)gridDim.x;
             prefetch(nx < n_groups ? nx : grp);
         }
-        x3_layer<2, 2, T>(st, s_bias, x1, x2, h);
+        X3Carry<T> carry;
+        constexpr int VC2 = x3_vpg(x3_carry_per(2, T), T), VC4 = x3_vpg(x3_carry_per(4, T), T);
+        x3_layer<2, 2, T, 0>(st, s_bias, x1, x2, h, carry, X3NoSide());
 
-        f32x16 a2[T][8];
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const f32x16 bv = tile_from_channels(s_db2 + 32 * mt, h);
-#pragma unroll
-            for (int j = 0; j < T; ++j) a2[j][mt] = bv;
+        f32x16 a2[8][T];                                   // dconv2's accumulators (zero C in the first chunk)
+        X3Tile tc[2][T][1];
+        f32x16 t[T];
+        {
+            f32x16 t0[T], bv0;                             // A_0 (side: conv2's last tile), split under A_1
+            x3_block<2, T, false, true, VC2, true>(st, x2, t0, [&](int s) {
+                x3_carry_steps<2, T>(carry, x2, s);
+                if (s == 3) bv0 = tile_from_channels(s_gb, h);
+            });
+            constexpr int PA = (8 * T + 3) / 4;
+            x3_dec_pair<T, true, 0, x3_vpg(PA, T)>(st, x2, t, tc, a2, s_gb, 0, h,
+                                                   [&](int s) { x3_split_steps<PA>(t0, bv0, tc[0], 0, s); });
         }
-        for (int c = 0; c < 16; ++c) {                     // dconv1 chunk c -> dconv2
-            f32x16 t[T];
-            const f32x16 gv = tile_from_channels(s_gb + 32 * c, h);
-#pragma unroll
-            for (int j = 0; j < T; ++j) t[j] = gv;
-            x3_block<2, T>(st, x2, t);
-            X3Tile tc[T][1];
-#pragma unroll
-            for (int j = 0; j < T; ++j) tc[j][0] = x3_split_relu(t[j]);
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
-                f32x16 acc[T];
-#pragma unroll
-                for (int j = 0; j < T; ++j) acc[j] = a2[j][mt];
-                x3_block<1, T>(st, tc, acc);
-#pragma unroll
-                for (int j = 0; j < T; ++j) a2[j][mt] = acc[j];
+        x3_dec_pair<T, false, 1, 0>(st, x2, t, tc, a2, s_gb, 1, h, X3NoSide());
+        x3_dec_pair<T, false, 0, 0>(st, x2, t, tc, a2, s_gb, 2, h, X3NoSide());
+        {
+            const int c0 = st.cur, p0 = st.pending;        // four pairs = 160 fragments = 5 segments: the state repeats
+            for (int it = 0; it < 3; ++it) {
+                st.pin(c0, p0);
+                const int c = 3 + 4 * it;
+                x3_dec_pair<T, false, 1, 0>(st, x2, t, tc, a2, s_gb, c, h, X3NoSide());
+                x3_dec_pair<T, false, 0, 0>(st, x2, t, tc, a2, s_gb, c + 1, h, X3NoSide());
+                x3_dec_pair<T, false, 1, 0>(st, x2, t, tc, a2, s_gb, c + 2, h, X3NoSide());
+                x3_dec_pair<T, false, 0, 0>(st, x2, t, tc, a2, s_gb, c + 3, h, X3NoSide());
             }
         }
+        // D_15 (chunk 15 is tc[1]); dconv2's out-tiles 0..3 are split under it, 4..7 under dconv3's first block
         X3Tile xd[T][8], y3[T][4], y4[T][4];
+        f32x16 bvx, bvn;
+        constexpr int PX = (4 * 8 * T + 13) / 14, VX = x3_vpg(PX, T);
 #pragma unroll
-        for (int j = 0; j < T; ++j) {
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt) xd[j][mt] = x3_split_relu(a2[j][mt]);
-        }
-        x3_layer<8, 4, T>(st, s_db3, xd, y3, h);
-        x3_layer<4, 4, T>(st, s_db4, y3, y4, h);
+        for (int mt = 0; mt < 8; ++mt)
+            x3_block<1, T, false, false, VX>(st, tc[1], a2[mt], [&](int s) {
+                if (mt == 0) {
+                    if (s == 0) bvn = tile_from_channels(s_db2, h);
+                } else {
+                    x3_xd_steps<PX, 0, 4>(a2, xd, s_db2, h, bvx, bvn, 2 * (mt - 1) + s);
+                }
+            });
+        x3_layer<8, 4, T, VX>(st, s_db3, xd, y3, h, carry, [&](int s) { x3_xd_steps<PX, 4, 4>(a2, xd, s_db2, h, bvx, bvn, s); });
+        x3_layer<4, 4, T, VC4>(st, s_db4, y3, y4, h, carry, [&](int s) { x3_carry_steps<4, T>(carry, y3, s); });
         f32x16 lg[T];                                      // dconv5 (128 -> 2, no ReLU): rows 0, 1 of one more out-tile
-        {
-            const f32x16 bv = tile_from_channels(s_db5, h);
-#pragma unroll
-            for (int j = 0; j < T; ++j) lg[j] = bv;
-            x3_block<4, T>(st, y4, lg);
-        }
-        st.skip_padding();
+        x3_block<4, T, false, true, VC4>(st, y4, lg, [&](int s) { x3_carry_steps<4, T>(carry, y4, s); });
+        st.end_group();
+        const float b50 = s_db5[0], b51 = s_db5[1];
 #pragma unroll
         for (int j = 0; j < T; ++j) {
-            float s0 = lg[j][0], s1 = lg[j][1];            // rows 0, 1: registers 0, 1 of lanes 0..31, one point each
+            float s0 = lg[j][0] + b50, s1 = lg[j][1] + b51;    // rows 0, 1: registers 0, 1 of lanes 0..31, one point each
             if (crop_bad) s0 = s1 = __int_as_float(DAL3_QNAN_BITS);
             const int n = n0 + 32 * j + (lane & 31);
             if (h == 0 && n < n_pts) {
