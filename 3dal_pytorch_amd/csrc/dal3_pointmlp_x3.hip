@@ -308,6 +308,25 @@ __device__ __forceinline__ void x3_max_layer(X3Stream& st, const float* bias, X3
     for (int s = 0; s < NS; ++s) x3_max_step<NS>(acc[1], mx, s, bias + 32 * m, smax + 32 * m, lane);
 }
 
+// This file is compiled twice (Makefile), like dal3_pointmlp_lp.hip: X3_PART=1 -> point heads + encode with `-mllvm
+// -amdgpu-mfma-vgpr-form` (their accumulators fit the VGPR file: the splits and max epilogues read them in place instead
+// of through one v_accvgpr_read per value), X3_PART=2 -> decode without it (its resident dconv2 accumulators ARE the
+// AccVGPR file).
+#ifndef X3_PART
+#define X3_PART 3
+#endif
+static int x3_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        n = v;
+    }
+    return n;
+}
+
+#if X3_PART & 1
 // ------------------------------------------------------------------------------------------------ point heads
 // LDS: b2 C2 | b3 C3 | b4 512 | s_max 512 | b1 C1 | w1 (C1/32) KS 64 floats, then the ring (3 x 32 KiB)
 __host__ __device__ constexpr int x3_head_small_bytes(int c1, int c2, int c3, int ks) {
@@ -380,17 +399,6 @@ __global__ __launch_bounds__(256) void point_head_x3_kernel(PointHeadX3W w, BCN 
             s_max[i] = 0;                                  // for the next group: its LDS atomics come after >= 1 barrier
         }
     }
-}
-
-static int x3_cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        n = v;
-    }
-    return n;
 }
 
 template <int KS, int C1, int C2, int C3>
@@ -506,6 +514,8 @@ hipError_t launch_ins_seg_encode_x3(const InsSegX3W& w, BCN pts, int c_in, int B
     return hipGetLastError();
 }
 
+#endif  // X3_PART & 1
+#if X3_PART & 2
 // ------------------------------------------------------------------------------------------------ decode
 // conv1 (fp32), conv2, then dconv1's per-point part in 16 chunks of 32 channels (A_c: 64 -> 32, bias: the crop's dconv1
 // term, fp32) each split and fed straight into dconv2's eight resident accumulator tiles (D_c: 32 -> 256), dconv3,
@@ -689,3 +699,4 @@ hipError_t launch_ins_seg_decode_x3(const InsSegX3W& w, BCN pts, int c_in, int B
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, s, w, pts, c_in, N, tpi, (int)n_groups, gbias, logits, mask);
     return hipGetLastError();
 }
+#endif  // X3_PART & 2

@@ -12,7 +12,9 @@ done
 CC="$CC $NONAN"
 $CC $2 -c 3dal_pytorch_amd/csrc/dal3_pointmlp.hip -o variants/obj_$1/dal3_pointmlp.o &
 $CC $2 -c 3dal_pytorch_amd/csrc/dal3_latency.hip -o variants/obj_$1/dal3_latency.o &
-$CC $2 -mllvm -pragma-unroll-threshold=1000000 -c 3dal_pytorch_amd/csrc/dal3_pointmlp_x3.hip -o variants/obj_$1/dal3_pointmlp_x3.o &
+X3="-mllvm -pragma-unroll-threshold=1000000"
+$CC $2 $X3 -DX3_PART=1 ${X3_ENC_FORM--mllvm -amdgpu-mfma-vgpr-form} -c 3dal_pytorch_amd/csrc/dal3_pointmlp_x3.hip -o variants/obj_$1/x3_enc.o &
+$CC $2 $X3 -DX3_PART=2 -c 3dal_pytorch_amd/csrc/dal3_pointmlp_x3.hip -o variants/obj_$1/x3_dec.o &
 $CC $2 -DLP_PART=1 -mllvm -amdgpu-mfma-vgpr-form -c 3dal_pytorch_amd/csrc/dal3_pointmlp_lp.hip -o variants/obj_$1/lp_enc.o &
 $CC $2 -DLP_PART=2 -c 3dal_pytorch_amd/csrc/dal3_pointmlp_lp.hip -o variants/obj_$1/lp_dec.o &
 wait
