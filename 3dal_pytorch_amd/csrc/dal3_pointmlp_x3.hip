@@ -10,9 +10,10 @@
 // channels on MFMA rows, points on columns, the fp32 accumulator of layer k split in registers into the B operands of
 // layer k+1 (activations never leave registers), weights as one stream of 1-KiB fragments — a (hi, lo) PAIR per k-step —
 // shared by the four waves of a workgroup through the three-slot LDS ring filled by LDS-DMA, persistent workgroups.
-// What is deliberately simpler than the 16-bit kernels: ONE generic block (x3_block) walks the fragment stream with a
-// cursor, opens a segment when the cursor reaches its end and deals the refill's LDS-DMA instructions out one per
-// k-step behind it; no per-kernel hand schedule yet.
+// ONE generic block (x3_block) walks the fragment stream with a cursor that is a compile-time constant everywhere; the
+// next k-step's pair is always in registers, a segment is opened a k-step before it is needed, the refill's LDS-DMA
+// instructions go out one per k-step, and the VALU work between layers (bias, ReLU, the (hi, lo) split; the max
+// epilogues) is dealt out under the NEXT block's MFMAs.
 //
 // The first layer (raw coordinates, K = 3/4/8) stays on the fp32 MFMA, biases and the per-crop dconv1 term are fp32,
 // logits / mask / pooled features and all I/O are fp32, as in the other two families.
@@ -48,6 +49,11 @@ __device__ __forceinline__ f32x16 x3_mfma(x3v8 a, x3v8 b, f32x16 c) {
 template <bool BIAS>
 __device__ __forceinline__ void x3_split_unit(const f32x16& acc, const f32x16& bv, X3Tile& t, int q) {
     const int s = q >> 2, i = q & 3, r = 8 * s + 2 * i;
+#ifdef DAL3_X3_ABL_SPLIT                                   // timing experiment only: what the split's VALU work costs
+    t.hi[s][i] = __float_as_int(acc[r]);
+    t.lo[s][i] = __float_as_int(acc[r + 1]);
+    return;
+#endif
     f32x2 p = {acc[r], acc[r + 1]};
     if (BIAS) {
         const f32x2 b = {bv[r], bv[r + 1]};
@@ -56,11 +62,16 @@ __device__ __forceinline__ void x3_split_unit(const f32x16& acc, const f32x16& b
     p[0] = relu1(p[0]);
     p[1] = relu1(p[1]);
     const f16x2_t hh = __builtin_convertvector(p, f16x2_t);
-    const f32x2 back = __builtin_convertvector(hh, f32x2);
-    const f32x2 rest = p - back;
-    const f16x2_t ll = __builtin_convertvector(rest, f16x2_t);
-    t.hi[s][i] = __builtin_bit_cast(int, hh);
-    t.lo[s][i] = __builtin_bit_cast(int, ll);
+    const int hi = __builtin_bit_cast(int, hh);
+    // lo = fp16(x - float(hi)) straight from the packed hi and the two fp32 values: v_fma_mixlo/mixhi_f16 read an fp16
+    // half as a source of an fp32 fma and round the result to fp16 (the fma is exact, one rounding) — two instructions
+    // instead of two conversions back, a subtraction and a packing conversion. (hipcc does not select them from C.)
+    int lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo)
+        : "v"(hi), "v"(p[0]), "v"(p[1]));
+    t.hi[s][i] = hi;
+    t.lo[s][i] = lo;
 }
 // a whole tile at once (the fp32 first layer's output: bias already in the accumulator)
 __device__ __forceinline__ X3Tile x3_split_relu(const f32x16& acc) {
@@ -84,7 +95,7 @@ __device__ __forceinline__ void x3_split_steps(const f32x16 (&a)[T], const f32x1
 // Stream order = consumption order; a k-step is a (hi, lo) fragment pair. The pair of the NEXT k-step is always in
 // registers already (nh, nl): take() hands it out and requests the one after it, so its LDS round trip runs under the
 // k-step's own 3 T MFMAs — across blocks, layers and groups of points (the stream is cyclic, a group ends where the
-// next one starts). after(), behind the k-step's MFMAs: one instruction of the pending refill (pump()), and, when
+// next one starts). Behind the k-step's MFMAs (x3_block): one instruction of the pending refill (pump()), and, when
 // the pair just requested was the last of its segment, the next segment is opened right there — counted wait + barrier
 // (LdsRing::acquire_wait) with the matrix pipe still busy, a k-step before anything of that segment is needed. The
 // refill of the slot this frees is then PENDING: its LDS-DMA instructions go out one per k-step (the third slot gives it
@@ -126,10 +137,6 @@ struct X3Stream {
         wh = nh;
         wl = nl;
         fetch();
-    }
-    __device__ __forceinline__ void after() {
-        pump();
-        if (cur == X3_SEG) open();
     }
     // end of a group of points: a stream of whole segments needs nothing (the last take() fetched the next group's first
     // pair); otherwise what is left of the open segment is padding
@@ -228,7 +235,7 @@ struct X3Carry {
     f32x16 bv;
 };
 // VALU slots per MFMA for a side of `per` split units per k-step
-__host__ __device__ constexpr int x3_vpg(int per, int t) { return (per * 10 + 3 * t - 1) / (3 * t); }
+__host__ __device__ constexpr int x3_vpg(int per, int t) { return (per * 7 + 3 * t - 1) / (3 * t); }
 // units per k-step so that 8 T units are done within the first 2 KT - 2 k-steps (the last two read X[.][KT - 1])
 __host__ __device__ constexpr int x3_carry_per(int kt, int t) { return (8 * t + 2 * kt - 3) / (2 * kt - 2); }
 template <int KT, int T>

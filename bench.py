@@ -839,7 +839,8 @@ def main():
         B, N, model, inputs, static = wl.B, wl.N, wl.model, wl.inputs, wl.static
         kr, mean_count = kernel_table(model, inputs, static, B, N, iters=max(3, min(args.steps, 10)))
         rec["roofline"] = roofline_of(kr, peak, args.precision, B, N,
-                                      tag="_" + args.config.lower() if args.config in ("C3", "C5") else "")
+                                      tag="_" + args.config.lower() if args.config in ("C3", "C5") else
+                                      "_f16x3" if (args.precision, B, N) == ("f16x3", 4096, 1024) else "")
         rec["kernels"] = kr
         rec["mean_segmented_points_per_item"] = round(mean_count, 1)
         exe = executed_gflop_per_step(kr, static, B)
@@ -891,7 +892,7 @@ def main():
                             "x_fp32_mfma_peak": round(B / d * wl.flop_item / 1e12 / MFMA_PEAK_TFLOPS["fp32"], 3),
                             "whole_path_mfma_frac_executed": round(
                                 executed_gflop_per_step(k3, static, B) / (d * 1e3) / MFMA_PEAK_TFLOPS["f16x3"], 4),
-                            "roofline": roofline_of(k3, MFMA_PEAK_TFLOPS["f16x3"], "f16x3", B, N),
+                            "roofline": roofline_of(k3, MFMA_PEAK_TFLOPS["f16x3"], "f16x3", B, N, tag="_f16x3"),
                             "kernels": k3}
             model.precision = args.precision
         rec["maxpool"] = maxpool_roofline(dev, iters=5)

@@ -26,7 +26,7 @@ def short(name):
     return name.split("(")[0].replace("void ", "").split("<")[0]
 
 
-for sub, sfx in (("prof_kt", ""), ("prof_kt_bf16", "_bf16"), ("prof_kt_c3", "_c3"), ("prof_kt_c5", "_c5"),
+for sub, sfx in (("prof_kt", ""), ("prof_kt_bf16", "_bf16"), ("prof_kt_f16x3", "_f16x3"), ("prof_kt_c3", "_c3"), ("prof_kt_c5", "_c5"),
                  ("prof_kt_maxpool", "_maxpool"), ("prof_kt_maxpool_bf16", "_maxpool_bf16"), ("prof_kt_b64", "_b64"),
                  ("prof_kt_train", "_train")):
     stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
@@ -70,8 +70,8 @@ def summarise(acc):
 
 
 # the 16-bit configurations at their own shapes (bench.py --config C3 / C5): <tag>_pmc_c3.json, <tag>_pmc_c5.json
-for cfg in ("c3", "c5"):
-    acc = collect([f"prof_mfma_{cfg}"])
+for cfg in ("c3", "c5", "f16x3"):
+    acc = collect([f"prof_mfma_{cfg}"] + (["prof_insts_f16x3"] if cfg == "f16x3" else []))
     if acc:
         json.dump(summarise(acc), open(os.path.join(out_dir, f"{tag}_pmc_{cfg}.json"), "w"), indent=1, sort_keys=True)
 # the max-pool on bf16 rows: its own file (same kernel name as the fp32 run)

@@ -13,6 +13,7 @@ python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 KT="--kernel-trace --stats --output-format csv"
 rocprofv3 $KT -d $O/prof_kt -o kt -- python3 $R/bench.py --no-extras --steps 10 --warmup 2 > $O/bench_under_rocprof.json 2>/dev/null
 rocprofv3 $KT -d $O/prof_kt_bf16 -o kt -- python3 $R/bench.py --no-extras --precision bf16 --steps 10 --warmup 2 > $O/bench_bf16_under_rocprof.json 2>/dev/null
+rocprofv3 $KT -d $O/prof_kt_f16x3 -o kt -- python3 $R/bench.py --no-extras --precision f16x3 --steps 10 --warmup 2 > $O/bench_f16x3_under_rocprof.json 2>/dev/null
 rocprofv3 $KT -d $O/prof_kt_c3 -o kt -- python3 $R/bench.py --no-extras --config C3 --steps 10 --warmup 2 > $O/bench_c3_under_rocprof.json 2>/dev/null
 rocprofv3 $KT -d $O/prof_kt_c5 -o kt -- python3 $R/bench.py --no-extras --config C5 --steps 10 --warmup 2 > $O/bench_c5_under_rocprof.json 2>/dev/null
 # one training step (64 x 4096, fp32, Adam, device sampler): kernel trace of tools/bench_train.py
@@ -39,6 +40,8 @@ for P in fp32 bf16; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_mfma$S -o c -- python3 $R/bench.py --no-extras --precision $P --steps 3 --warmup 1 > /dev/null 2>&1
 done
 # the 16-bit configurations at their own shapes: MFMA-busy and the clock the chip holds (GRBM_GUI_ACTIVE / 8 / kernel time)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_mfma_f16x3 -o c -- python3 $R/bench.py --no-extras --precision f16x3 --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $O/prof_insts_f16x3 -o c -- python3 $R/bench.py --no-extras --precision f16x3 --steps 3 --warmup 1 > /dev/null 2>&1
 for CFG in C3 C5; do
   L=$(echo $CFG | tr A-Z a-z)
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_mfma_$L -o c -- python3 $R/bench.py --no-extras --config $CFG --steps 3 --warmup 1 > /dev/null 2>&1
