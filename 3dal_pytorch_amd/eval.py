@@ -320,7 +320,7 @@ def main(argv=None):
     parser.add_argument("--det_annos", required=True, help="Path to detection annos.")
     parser.add_argument("--batch_size", type=int, default=64)
     parser.add_argument("--sampler", choices=["numpy", "device"], default="numpy")
-    parser.add_argument("--precision", choices=["fp32", "bf16", "fp16"], default="fp32",
+    parser.add_argument("--precision", choices=["fp32", "f16x3", "bf16", "fp16"], default="fp32",
                         help="MFMA operand type of the shared MLPs (fp32 = the reference's arithmetic).")
     parser.add_argument("--result", default=None, help="Output pickle (default: the reference's location).")
     args = parser.parse_args(argv)

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 
+import test_gpu_fullsize as FS
 import test_gpu_nonfinite as NF
 import test_gpu_parity as P
 from _common import build_model, recentred_sd, rel_err, synth
@@ -26,7 +27,7 @@ def x3(monkeypatch):
         m = build_model(kind, sd, device)
         m.precision = "f16x3"
         return m
-    for mod in (P, NF):
+    for mod in (P, NF, FS):
         monkeypatch.setattr(mod, "build_model", bm)
     # the dynamic fixture's smallest |margin| (5.9e-4) is 40 x the fp32 kernels' logit error and 20 x this family's (3.0e-5
     # of logits up to 13): the safety factor the borrowed test asserts is 10 here; masks and draws are then compared exactly
@@ -113,3 +114,18 @@ def test_f16x3_shards_and_point_permutations_are_bitwise(x3):
     model.item_offset = 16
     part = model._run(pts[16:].transpose(2, 1), init_t[16:], None)
     assert torch.equal(part["logits"], whole["logits"][16:]) and torch.equal(part["boxes7"], whole["boxes7"][16:])
+
+
+def test_static_c2_full_batch_properties(x3):
+    """BASELINE.json configs[1] at its full size (4096 x 1024) in f16x3: finite, a 64-crop slice run alone with its item
+    offset equals the job's rows bit for bit, logits permute with the points"""
+    FS.test_static_c2_full_batch_properties()
+
+
+def test_dynamic_c3_shape_properties(x3):
+    FS.test_dynamic_c3_shape_properties()
+
+
+def test_c4_mixed_segment_sharded_over_8_equals_whole_job(x3):
+    """the mixed segment (64 crops x 4096 points + ~4,400 track frames) cut into 8 rank shards == the one-rank job, bitwise"""
+    FS.test_c4_mixed_segment_sharded_over_8_equals_whole_job()
