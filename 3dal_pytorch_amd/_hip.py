@@ -100,6 +100,8 @@ SIGNATURES = {
     "dal3_tr_linear_pack_layout": (_i, [_i64, _i, _i64, _i, _i, _i]),
     "dal3_tr_pack_many": (_i, [vp, _i, vp]),
     "dal3_tr_linear_prepacked": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _i, vp, _i64, _i, vp, _i64, _i, vp, vp]),
+    "dal3_tr_linear_x3_layout": (_i, [_i64, _i, _i64, _i, _i, _i]),
+    "dal3_tr_linear_x3": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _i, vp, _i64, vp, vp]),
     "dal3_tr_colred_workspace_bytes": (_sz, [_i64, _i]),
     "dal3_tr_colred": (_i, [vp, _i64, _i, _i64, _i, vp, _i64, vp, vp, _i64, vp, vp, vp, vp, vp, _sz, vp, vp]),
     "dal3_tr_pool_coef": (_i, [vp, vp, vp, vp, vp, vp, _i, _i, _i64, vp, vp, vp]),
@@ -125,6 +127,8 @@ SIGNATURES = {
     "dal3_tr_act_dropout": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _u64, vp, C.c_float, vp, _i64, vp]),
     "dal3_tr_linear_pool_workspace_bytes": (_sz, [_i, _i, _i64]),
     "dal3_tr_linear_pool": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, vp, vp, vp, _i64, _i, vp, vp, vp, _sz, vp]),
+    "dal3_tr_linear_pool_x3": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, vp, vp, vp, _i64, _i, vp, vp, vp, _sz, vp]),
+    "dal3_tr_linear_pool_x3_ok": (_i, [_i64, _i, _i64, _i]),
     "dal3_tr_segsum": (_i, [vp, _i64, _i64, _i, vp, _i64, vp]),
     "dal3_maxpool_n": (_i, [vp, _i64, _i64, vp, vp]),
     "dal3_maxpool_n_dtype": (_i, [vp, _i, _i64, _i64, vp, vp]),

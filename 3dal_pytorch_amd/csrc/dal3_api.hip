@@ -943,7 +943,9 @@ extern "C" int dal3_tr_pack_many(const dal3_tr_pack_item* items, int n, dal3_str
     if (!items || n <= 0 || n > 48) return fail(DAL3_EINVAL, "tr_pack_many: 1 .. 48 items");
     for (int i = 0; i < n; ++i) {
         const dal3_tr_pack_item& t = items[i];
-        if (!t.W || !t.out || !mult32(t.c_in) || !mult32(t.c_out) || t.mtb <= 0 || (t.c_out / 32) % t.mtb != 0 ||
+        const int mtb = t.mtb & 0xff;
+        if ((t.mtb & ~0x1ff) || ((t.mtb & 0x100) && mtb != 8)) return fail(DAL3_EINVAL, "tr_pack_many: bad layout code in item %d", i);
+        if (!t.W || !t.out || !mult32(t.c_in) || !mult32(t.c_out) || mtb <= 0 || (t.c_out / 32) % mtb != 0 ||
             (reinterpret_cast<uintptr_t>(t.out) & 15) || (!t.transpose_w && t.ldw < t.c_in) || (t.transpose_w && t.ldw < t.c_out))
             return fail(DAL3_EINVAL, "tr_pack_many: bad item %d", i);
     }
@@ -962,6 +964,26 @@ extern "C" int dal3_tr_linear_prepacked(const float* a, int64_t M, int c_in, int
         return fail(DAL3_EINVAL, "tr_linear_prepacked: this call reads no packed image (dal3_tr_linear_pack_layout() == 0)");
     HIP_TRY(launch_tr_linear(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz, accumulate,
                              const_cast<float*>(static_cast<const float*>(packed)), static_cast<hipStream_t>(stream), true));
+    return 0;
+}
+
+extern "C" int dal3_tr_linear_x3_layout(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act) {
+    if (!mult32(M) || !mult32(c_in) || !mult32(c_out)) return 0;
+    return tr_linear_x3_layout(M, c_in, seg, c_out, accumulate, has_act);
+}
+
+extern "C" int dal3_tr_linear_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                                 int relu_in, const float* bias, int64_t seg, int c_out, float* z, int64_t ldz,
+                                 const void* packed, dal3_stream stream) {
+    if (!a || !z || !mult32(M) || !mult32(c_in) || !mult32(c_out) || lda < c_in || ldz < c_out || lda % 4 || ldz % 4 ||
+        (scale && !shift) || seg < 0 || !packed || (reinterpret_cast<uintptr_t>(packed) & 15) ||
+        (reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(z) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
+        return fail(DAL3_EINVAL, "tr_linear_x3: bad argument (16-byte aligned a / z / bias / packed, row strides multiples of 4)");
+    const int layout = tr_linear_x3_layout(M, c_in, seg, c_out, 0, scale != nullptr);
+    if (layout == 0) return fail(DAL3_EINVAL, "tr_linear_x3: this shape does not take the f16x3 kernel (dal3_tr_linear_x3_layout() == 0)");
+    if (lda * 64 * (int64_t)sizeof(float) >= ((int64_t)1 << 31)) return fail(DAL3_EINVAL, "tr_linear_x3: lda too large");
+    HIP_TRY(launch_tr_linear_x3(a, M, c_in, lda, scale, shift, relu_in, static_cast<const uint16_t*>(packed), layout, bias, seg, c_out,
+                                z, ldz, static_cast<hipStream_t>(stream)));
     return 0;
 }
 
@@ -1207,6 +1229,30 @@ extern "C" int dal3_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t 
     HIP_TRY(launch_tr_linear_pool(a, M, c_in, lda, scale, shift, relu_in, W, ldw, bias, out_scale, out_shift, seg, c_out, g, arg,
                                   reinterpret_cast<float*>(base), reinterpret_cast<unsigned long long*>(base + wbytes),
                                   static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_linear_pool_x3_ok(int64_t M, int c_in, int64_t seg, int c_out) {
+    return (mult32(M) && mult32(c_in) && c_out > 0 && seg > 0 && M % seg == 0 && tr_linear_pool_x3_ok(M, c_in, seg, c_out)) ? 1 : 0;
+}
+
+extern "C" int dal3_tr_linear_pool_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                                      int relu_in, const float* W, int64_t ldw, const float* bias, const float* out_scale,
+                                      const float* out_shift, int64_t seg, int c_out, float* g, int32_t* arg, void* workspace,
+                                      size_t workspace_bytes, dal3_stream stream) {
+    if (!a || !W || !out_scale || !out_shift || !g || !arg || !mult32(M) || !mult32(c_in) || c_out <= 0 || lda < c_in || (lda & 3) ||
+        ldw < c_in || (ldw & 3) || (scale && !shift) || seg <= 0 || M % seg != 0 || (reinterpret_cast<uintptr_t>(a) & 15) ||
+        lda * 64 * (int64_t)sizeof(float) >= ((int64_t)1 << 31))
+        return fail(DAL3_EINVAL, "tr_linear_pool_x3: bad argument");
+    if (!tr_linear_pool_x3_ok(M, c_in, seg, c_out))
+        return fail(DAL3_EINVAL, "tr_linear_pool_x3: this shape does not take the f16x3 kernel (dal3_tr_linear_pool_x3_ok() == 0)");
+    const size_t wbytes = tr_linear_workspace_bytes(c_in, c_out), need = wbytes + (size_t)(M / seg) * c_out * 8;
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) || (wbytes & 7))
+        return fail(DAL3_EWORKSPACE, "tr_linear_pool_x3: workspace smaller than dal3_tr_linear_pool_workspace_bytes() or not 16-byte aligned");
+    char* base = static_cast<char*>(workspace);
+    HIP_TRY(launch_tr_linear_pool_x3(a, M, c_in, lda, scale, shift, relu_in, W, ldw, bias, out_scale, out_shift, seg, c_out, g, arg,
+                                     reinterpret_cast<float*>(base), reinterpret_cast<unsigned long long*>(base + wbytes),
+                                     static_cast<hipStream_t>(stream)));
     return 0;
 }
 

@@ -281,6 +281,12 @@ size_t tr_linear_workspace_bytes(int c_in, int c_out);
 // the fragment layout (output tiles per wave) launch_tr_linear will read for this shape, 0: it packs nothing
 int tr_linear_pack_mtb(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act);
 hipError_t launch_tr_pack_many(const dal3_tr_pack_item* items, int n, hipStream_t s);
+// the training forward's big layers on the f16x3 engine (dal3_train_x3.hip): layout code 0x100 | MTB, or 0 when the call
+// does not qualify (then it takes launch_tr_linear)
+int tr_linear_x3_layout(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act);
+hipError_t launch_tr_linear_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift, int relu_in,
+                               const uint16_t* wpk, int layout, const float* bias, int64_t seg, int c_out, float* z, int64_t ldz,
+                               hipStream_t s);
 size_t tr_colred_workspace_bytes(int64_t M, int C);
 hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                             const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
@@ -332,6 +338,12 @@ hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t ld
                                  int relu_in, const float* W, int64_t ldw, const float* bias, const float* out_scale,
                                  const float* out_shift, int64_t seg, int c_out, float* g, int32_t* arg, float* ws,
                                  unsigned long long* packed, hipStream_t s);
+hipError_t launch_tr_segmax_unpack(const unsigned long long* packed, int64_t total, float* g, int32_t* arg, hipStream_t s);
+bool tr_linear_pool_x3_ok(int64_t M, int c_in, int64_t seg, int c_out);
+hipError_t launch_tr_linear_pool_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                                    int relu_in, const float* W, int64_t ldw, const float* bias, const float* out_scale,
+                                    const float* out_shift, int64_t seg, int c_out, float* g, int32_t* arg, float* ws,
+                                    unsigned long long* packed, hipStream_t s);
 // small jobs: one 16-wave workgroup per 32-point tile, activations through LDS (dal3_latency.hip); bit-identical results
 hipError_t launch_ins_seg_encode_lat(const InsSegW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s);
 hipError_t launch_ins_seg_decode_lat(const InsSegW& w, BCN pts, int c_in, int B, int N, const float* gbias, float* logits,

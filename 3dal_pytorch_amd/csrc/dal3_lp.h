@@ -217,6 +217,19 @@ struct LdsRing {
         __builtin_amdgcn_sched_barrier(0);
         slot_use = slot_use + 1 == SLOTS ? 0 : slot_use + 1;
     }
+    // acquire_wait() for a kernel that also has compiler-visible VMEM traffic of its own (dal3_train_x3.hip): EVERYTHING
+    // this wave has outstanding has landed or left (vmcnt(0)) before the barrier. hipcc cannot see the LDS-DMA loads
+    // (inline asm), so its own vmcnt(N) in front of the first use of a loaded register is N too small by the number of
+    // DMA loads issued after that load: it then waits for a load issued moments ago. With every such use placed right
+    // behind this call its waits find the counter at zero.
+    __device__ __forceinline__ void acquire_wait_all() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        slot_use = slot_use + 1 == SLOTS ? 0 : slot_use + 1;
+    }
     __device__ __forceinline__ void issue_part(int k) {
         const int seg = seg_issue < n_segs ? seg_issue : n_segs - 1;
         const int f = wave + 4 * k;

@@ -200,6 +200,24 @@ __device__ __forceinline__ void tr_pack_element(const float* __restrict__ W, int
     const int row = 32 * (mtb * mblk + t) + (lane & 31), col = 32 * kt + 8 * q + 4 * (lane >> 5) + e;
     out[i] = transpose_w ? W[(int64_t)col * ldw + row] : W[(int64_t)row * ldw + col];
 }
+// The f16x3 image of the same matrix (dal3_train_x3.hip; layout code 0x100 | MTB): per output block of MTB tiles one stream
+// [k-tile][out-tile][k-step][hi | lo] of 1-KiB fp16 fragments (64 lanes x 8 values, k order as launch_pack_weight_lp),
+// hi = fp16(w), lo = fp16(w - hi). i runs over c_out * c_in * 2 fp16 values: the same number of bytes as the fp32 image.
+__device__ __forceinline__ void tr_pack_x3_element(const float* __restrict__ W, int64_t ldw, int transpose_w, int c_out, int c_in,
+                                                   int mtb, uint16_t* __restrict__ out, int64_t i) {
+    if (i >= (int64_t)c_out * c_in * 2) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63), half = (int)((i >> 9) & 1), s = (int)((i >> 10) & 1);
+    int64_t f = i >> 11;                                      // (out-tile, k-tile) block
+    const int t = (int)(f % mtb);
+    f /= mtb;
+    const int KT = c_in / 32;
+    const int kt = (int)(f % KT), mblk = (int)(f / KT);
+    const int row = 32 * (mtb * mblk + t) + (lane & 31), col = 32 * kt + 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+    const float v = transpose_w ? W[(int64_t)col * ldw + row] : W[(int64_t)row * ldw + col];
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    out[i] = __builtin_bit_cast(uint16_t, half ? lo : hi);
+}
 __global__ void tr_pack_kernel(const float* __restrict__ W, int64_t ldw, int transpose_w, int c_out, int c_in, int mtb,
                                float* __restrict__ out) {
     tr_pack_element(W, ldw, transpose_w, c_out, c_in, mtb, out, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
@@ -223,8 +241,11 @@ __global__ __launch_bounds__(256) void tr_pack_many_kernel(TrPackMany p) {
     int k = 0;
     for (int i = 1; i < p.n; ++i) k = blockIdx.x >= p.it[i].first_block ? i : k;      // (first_block is ascending)
     const TrPackItem& t = p.it[k];
-    tr_pack_element(t.W, t.ldw, t.transpose_w, t.c_out, t.c_in, t.mtb, t.out,
-                    (int64_t)(blockIdx.x - t.first_block) * 256 + threadIdx.x);
+    const int64_t i = (int64_t)(blockIdx.x - t.first_block) * 256 + threadIdx.x;
+    if (t.mtb & 0x100)
+        tr_pack_x3_element(t.W, t.ldw, t.transpose_w, t.c_out, t.c_in, t.mtb & 0xff, reinterpret_cast<uint16_t*>(t.out), i);
+    else
+        tr_pack_element(t.W, t.ldw, t.transpose_w, t.c_out, t.c_in, t.mtb, t.out, i);
 }
 
 template <int T>
@@ -825,6 +846,11 @@ hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t ld
     return hipGetLastError();
 }
 
+hipError_t launch_tr_segmax_unpack(const unsigned long long* packed, int64_t total, float* g, int32_t* arg, hipStream_t s) {
+    hipLaunchKernelGGL(tr_segmax_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, packed, total, g, arg);
+    return hipGetLastError();
+}
+
 // every layer with whole 32-channel tiles can take a ring path (which one depends on M: see launch_tr_linear)
 size_t tr_linear_workspace_bytes(int c_in, int c_out) {
     return c_out % 32 == 0 ? (size_t)c_out * c_in * sizeof(float) + DAL3_PF * 1024 : 0;
@@ -911,7 +937,7 @@ hipError_t launch_tr_pack_many(const dal3_tr_pack_item* items, int n, hipStream_
     for (int i = 0; i < n; ++i) {
         const dal3_tr_pack_item& t = items[i];
         p.it[i] = TrPackItem{t.W, t.out, t.ldw, t.transpose_w, t.c_out, t.c_in, t.mtb, blocks};
-        blocks += (uint32_t)(((int64_t)t.c_out * t.c_in + 255) / 256);
+        blocks += (uint32_t)(((int64_t)t.c_out * t.c_in * ((t.mtb & 0x100) ? 2 : 1) + 255) / 256);
     }
     hipLaunchKernelGGL(tr_pack_many_kernel, dim3(blocks), dim3(256), 0, s, p);
     return hipGetLastError();

@@ -1,0 +1,351 @@
+// dal3_train_x3.hip — the training FORWARD's big layers on the "f16x3" engine (dal3_x3.h): z = act(a) W^T + b with every
+// product formed as w_hi x_hi + w_hi x_lo + w_lo x_hi on the fp16 MFMA, fp32 accumulate — the accuracy of the fp32-MFMA
+// kernels of dal3_train.hip (1e-6 of the output's range) at a third of their MFMA time. Forward only: its operands
+// (post-BatchNorm activations, weights) are O(1), inside fp16's exponent range; the backward's dz operands are 1e-6 and
+// would need a per-tensor scale first, so dgrad / wgrad stay on the fp32 MFMA.
+//
+// Unlike the eval kernels the activations come from HBM, not from the previous layer's accumulators: a wave owns T = 2
+// tiles of 32 points and MTB output tiles; per 32-channel k-tile it loads its 2 x 32 x 32 fp32 inputs (16 B per lane and
+// instruction, two k-tiles ahead of their use), applies the input activation (BatchNorm affine + ReLU of the producing
+// layer) and splits them into (hi, lo) fp16 operands UNDER the MFMAs of the k-tile in front (x3_block's side work), and
+// walks the layer's weight stream — [k-tile][out-tile][k-step][hi | lo] fragments, shared by the workgroup's four waves
+// through the three-slot LDS ring — with the compile-time cursor of X3Stream: a loop iteration is two k-tiles = one or
+// two whole ring segments. Workgroups are persistent (one per CU) over groups of 256 points of ONE output block.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "dal3_kernels.h"
+#include "dal3_lp.h"
+#include "dal3_x3.h"
+
+#define TRX_T 2
+
+// Two units (two pairs of values: registers 4 q .. 4 q + 3 of a point tile, i.e. channels 8 q + 4 h .. + 3 of the k-tile) of
+// a staged k-tile: activation, then the (hi, lo) split of x3_split_unit. xq / scq / shq: the quad, its scale and shift.
+template <bool ACT>
+__device__ __forceinline__ void trx_split_quad(const f32x4& xq, const f32x4& scq, const f32x4& shq, float floor_v, X3Tile& t, int q) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int s = q >> 1, i = 2 * (q & 1) + u;          // register pair 4 q + 2 u = 8 s + 2 i
+        f32x2 p = {xq[2 * u], xq[2 * u + 1]};
+        if (ACT) {
+            const f32x2 a = {scq[2 * u], scq[2 * u + 1]}, b = {shq[2 * u], shq[2 * u + 1]};
+            p = p * a + b;                                  // (contracted to one packed fma)
+            p[0] = __builtin_fmaxf(p[0], floor_v);          // floor_v: 0 with ReLU, -FLT_MAX without
+            p[1] = __builtin_fmaxf(p[1], floor_v);
+        }
+        const f16x2_t hh = __builtin_convertvector(p, f16x2_t);
+        const int hi = __builtin_bit_cast(int, hh);
+        int lo;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(lo)
+            : "v"(hi), "v"(p[0]), "v"(p[1]));
+        t.hi[s][i] = hi;
+        t.lo[s][i] = lo;
+    }
+}
+
+// Every VMEM load of a wave is an LDS-DMA instruction (inline asm, invisible to hipcc's wait-count pass: a compiler-visible
+// load in the same queue would be waited for with a count that is too small by the DMA loads issued behind it, i.e. together
+// with loads issued moments ago): the weight ring's refills, the wave's own input k-tiles (staged in LDS, 8 KiB per k-tile:
+// lane (m, h) of instruction (j, q) fetches the 16 bytes it will read back, so staging is conflict-free), and — wave 0 —
+// the next group's bias row. A segment's open() drains the wave's whole queue (X3StreamT<true, 2>: vmcnt(0) + barrier), so
+// what was requested at open(n) is readable behind open(n + 1): a whole segment (16 k-steps, ~1.6 us) to land.
+// One k-tile = 8 out-tiles x 4 fragments = one ring segment (MTB = 8: c_out % 256 == 0). Pipeline, by k-tile n:
+//   input(n + 3) requested at open(n + 1)  |  input(n + 1) read from its stage and split under the first 8 k-steps of
+//   k-tile n  |  MFMAs on split(n)  |  in a group's last k-tile: an out-tile's bias add + stores under the next tile's MFMAs.
+// LDS: ring 2 x 32 KiB | input stages 4 waves x 2 x 8 KiB | scale | shift (c_in floats each) | bias rows 2 x 256 floats.
+#define TRX_STAGE_BYTES 8192
+// POOL: the pooled layer's forward without its output tensor (tr_linear_pool_kernel of dal3_train.hip): the blocks run
+// with the MFMA operands swapped (points on the accumulator's registers, channels on its lanes), an out-tile's epilogue is
+// conv bias -> BN affine -> ReLU -> max over the tile's 32 points with the point index (first maximum wins) -> the packed
+// 64-bit atomicMax of tr_segmax_kernel; bias / out_scale / out_shift are per channel (LDS: 3 x 256 floats), z is unused.
+template <bool ACT, bool POOL>
+__global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restrict__ a, int64_t lda, int c_in,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           int relu_in, const uint16_t* __restrict__ wpk,
+                                                           const float* __restrict__ bias, int64_t seg, int c_out,
+                                                           float* __restrict__ z, int64_t ldz, int n_mblk, int n_groups,
+                                                           const float* __restrict__ out_scale, const float* __restrict__ out_shift,
+                                                           unsigned long long* __restrict__ packed) {
+    constexpr int T = TRX_T, MTB = 8;
+    constexpr int PER = 2, VS = x3_vpg(PER, T) + 1;         // a k-tile's 8 T split units done within its first 8 k-steps
+    static_assert(T == 2, "one point tile per k-step of a block in the epilogue; stage layout");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const stage0 = smem + 2 * X3_SEG * 1024;
+    float* s_sc = reinterpret_cast<float*>(stage0 + X3_WAVES * 2 * TRX_STAGE_BYTES);
+    float* s_sh = s_sc + c_in;
+    float* s_bias = s_sh + c_in;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    const float floor_v = relu_in ? 0.0f : -3.0e38f;
+    const int mblk = (int)(blockIdx.x % (unsigned)n_mblk);
+    const int g0 = (int)(blockIdx.x / (unsigned)n_mblk), gstride = (int)(gridDim.x / (unsigned)n_mblk);
+    if (g0 >= n_groups) return;
+    const int KT = c_in / 32, mt0 = mblk * MTB;
+    const auto bias_row = [&](int g) {                          // (scalar; a group of 256 points lies in one segment)
+        return bias + (seg > 0 ? (int64_t)((uint32_t)((int64_t)g * 256) / (uint32_t)seg) * c_out : 0) + 32 * mt0;
+    };
+    if (ACT) {
+        for (int i = threadIdx.x; i < c_in; i += 256) {
+            s_sc[i] = scale[i];
+            s_sh[i] = shift[i];
+        }
+    }
+    if (POOL) {                                                 // per-channel constants of this output block
+        s_bias[threadIdx.x] = bias ? bias[32 * mt0 + threadIdx.x] : 0.0f;
+        s_bias[256 + threadIdx.x] = out_scale[32 * mt0 + threadIdx.x];
+        s_bias[512 + threadIdx.x] = out_shift[32 * mt0 + threadIdx.x];
+    } else {
+        s_bias[threadIdx.x] = bias ? bias_row(g0)[threadIdx.x] : 0.0f;   // 256 = 32 MTB floats: the first group's row, buffer 0
+        s_bias[256 + threadIdx.x] = 0.0f;
+    }
+    __syncthreads();
+    X3StreamT<true, 2> st;
+    st.init(wpk + (size_t)mblk * KT * MTB * 4 * 512, smem, KT, wave, lane);
+
+    char* const stage = stage0 + wave * (2 * TRX_STAGE_BYTES);  // this wave's two input stages (k-tile n in stage n & 1)
+    const uint32_t lane_off = (uint32_t)(((int64_t)m * lda + 4 * h) * sizeof(float));
+    // k-tile tau of group g's sequence (tau >= KT: a following group's; past the last group: a harmless re-read of g's own)
+    const auto request = [&](int buf, int g, int tau) {
+        const int gq = tau >= 2 * KT ? 2 : tau >= KT ? 1 : 0;
+        const int gt = g + gq * gstride < n_groups ? g + gq * gstride : g;
+        const char* src = reinterpret_cast<const char*>(a + ((int64_t)gt * 256 + wave * 64) * lda + 32 * (tau - gq * KT));
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                lds_dma16(src + ((int64_t)32 * j * lda + 8 * q) * sizeof(float), lane_off, stage + buf * TRX_STAGE_BYTES + (4 * j + q) * 1024);
+    };
+    // quad q of point tile j of a staged k-tile / of a k-tile's scale and shift: this lane's four values
+    const auto staged = [&](int buf, int j, int q) {
+        return *reinterpret_cast<const f32x4*>(stage + buf * TRX_STAGE_BYTES + (4 * j + q) * 1024 + lane * 16);
+    };
+    const auto act_quad = [&](const float* v, int k, int q) { return *reinterpret_cast<const f32x4*>(v + 32 * k + 8 * q + 4 * h); };
+    X3Tile xs[2][T][1];                                     // split k-tiles
+    f32x4 xq, scq = f32x4{}, shq = f32x4{};                 // the quad split next: read one k-step ahead of its split
+    // prologue: k-tiles 0 and 1 of the first group staged, 0 split in the open, 2 requested into its stage
+    request(0, g0, 0);
+    request(1, g0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xq = staged(0, j, q);
+            if (ACT) {
+                scq = act_quad(s_sc, 0, q);
+                shq = act_quad(s_sh, 0, q);
+            }
+            trx_split_quad<ACT>(xq, scq, shq, floor_v, xs[0][j][0], q);
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (stage 0 has been read: it may be overwritten)
+    request(0, g0, 2);
+    xq = staged(1, 0, 0);
+    if (ACT) {
+        scq = act_quad(s_sc, 1 % KT, 0);
+        shq = act_quad(s_sh, 1 % KT, 0);
+    }
+
+    // POOL: the epilogue of out-tile t, point tile j of the group whose first row (this wave's) is `row`
+    const auto pool_tile = [&](const f32x16& acc_tj, int t, int j, int64_t row) {
+        const int c = 32 * t + m;                               // this lane's channel within the output block
+        const float bch = s_bias[c], osc = s_bias[256 + c], osh = s_bias[512 + c];
+        float bv = -1.0f;
+        int bi = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                          // increasing point index: '>' keeps the first maximum
+            const float y = fmaxf(__builtin_fmaf(acc_tj[r] + bch, osc, osh), 0.0f);
+            if (y > bv) {
+                bv = y;
+                bi = (r & 3) + 8 * (r >> 2) + 4 * h;
+            }
+        }
+        const float ov = __shfl_xor(bv, 32);
+        const int oi = __shfl_xor(bi, 32);
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+        if (h == 0) {
+            const int64_t p0 = row + 32 * j;
+            const int64_t s_idx = (int64_t)((uint32_t)p0 / (uint32_t)seg);
+            const uint32_t in_seg = (uint32_t)(p0 - s_idx * seg) + (uint32_t)bi;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(bv) << 32) | (0xffffffffu - in_seg);
+            atomicMax(packed + s_idx * c_out + 32 * mt0 + c, key);
+        }
+    };
+    int par = 0;                                            // which bias buffer this group reads
+    for (int g = g0; g < n_groups; g += gstride, par ^= 1) {
+        const int gn = g + gstride < n_groups ? g + gstride : g;          // (the last group re-reads itself: uniform control flow)
+        const int64_t row = (int64_t)g * 256 + wave * 64;
+        const float* sb = s_bias + 256 * par;
+        f32x16 acc[MTB][T];
+        f32x16 bprev = f32x16{};
+        // one pair of k-tiles = two segments (kt even)
+        auto pair = [&](int kt, auto first_c, auto last_c) {
+            constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int k = kt + kk;                              // this k-tile; its split is xs[kk], k + 1 is in stage kk ^ 1
+                const int k1 = k + 1 < KT ? k + 1 : 0;              // the k-tile split under this one (index of its activation)
+                const int k2 = k + 2 < KT ? k + 2 : k + 2 - KT;     // the one after it
+#pragma unroll
+                for (int t = 0; t < MTB; ++t) {
+                    const auto side = [&](int s) {
+                        const int sg = 2 * t + s;                   // k-step of the segment
+                        // k-tile k + 1 (stage kk ^ 1): point tile 0 split under k-steps 0..3, tile 1 under 4..7, a quad per
+                        // k-step, read (with its scale and shift) a k-step ahead; k-step 15 — behind the open — reads the
+                        // first quad of k-tile k + 2, which has landed in stage kk
+                        if (sg < 8) trx_split_quad<ACT>(xq, scq, shq, floor_v, xs[kk ^ 1][sg >> 2][0], sg & 3);
+                        if (sg < 7 || sg == 15) {
+                            const int nb = sg == 15 ? kk : kk ^ 1, ns = sg == 15 ? 0 : sg + 1, nk = sg == 15 ? k2 : k1;
+                            xq = staged(nb, ns >> 2, ns & 3);
+                            if (ACT) {
+                                scq = act_quad(s_sc, nk, ns & 3);
+                                shq = act_quad(s_sh, nk, ns & 3);
+                            }
+                        }
+                        if (POOL && LAST && kk == 1) {
+                            if (t > 0) pool_tile(acc[t - 1][s], t - 1, s, row);
+                        } else if (LAST && kk == 1) {
+                            // an output tile is final behind its last block: bias, store — under the next tile's MFMAs
+                            if (t > 0) {
+                                const int j = s;                    // (T == 2: one point tile per k-step)
+                                float* zp = z + (row + 32 * j + m) * ldz + 32 * (mt0 + t - 1) + 4 * h;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    f32x4 o = {acc[t - 1][j][4 * q], acc[t - 1][j][4 * q + 1], acc[t - 1][j][4 * q + 2], acc[t - 1][j][4 * q + 3]};
+                                    o[0] += bprev[4 * q];
+                                    o[1] += bprev[4 * q + 1];
+                                    o[2] += bprev[4 * q + 2];
+                                    o[3] += bprev[4 * q + 3];
+                                    *reinterpret_cast<f32x4*>(zp + 8 * q) = o;
+                                }
+                            }
+                            if (s == 1) bprev = tile_from_channels(sb + 32 * t, h);      // (behind its last use: tile t's, for the next block)
+                        }
+                    };
+                    // the segment's open (in its last out-tile's block): k-tile k + 1's stage has been read (k-steps 0..3 of
+                    // this segment) and takes k-tile k + 3
+                    const auto opened = [&](int) {
+                        request(kk ^ 1, g, k + 3);
+                        if (!POOL && LAST && kk == 1 && bias && wave == 0)
+                            lds_dma16(reinterpret_cast<const char*>(bias_row(gn)), (uint32_t)(lane * 16),
+                                      reinterpret_cast<char*>(s_bias + 256 * (par ^ 1)));
+                    };
+                    if (FIRST && kk == 0)
+                        x3_block<1, T, POOL, true, VS>(st, xs[kk], acc[t], side, opened);
+                    else
+                        x3_block<1, T, POOL, false, VS>(st, xs[kk], acc[t], side, opened);
+                }
+            }
+        };
+        // FIRST / LAST are compile-time (the first block takes C = 0, the last k-tile carries the stores); in between a
+        // runtime loop whose body is whole segments (the cursor state repeats: pin)
+        if (KT == 2) {
+            st.pin(2, 0);
+            pair(0, std::true_type{}, std::true_type{});
+        } else {
+            st.pin(2, 0);
+            pair(0, std::true_type{}, std::false_type{});
+            const int c0 = st.cur, p0 = st.pending;
+            for (int kt = 2; kt + 2 < KT; kt += 2) {
+                st.pin(c0, p0);
+                pair(kt, std::false_type{}, std::false_type{});
+            }
+            st.pin(c0, p0);
+            pair(KT - 2, std::false_type{}, std::true_type{});
+        }
+        st.end_group();
+        if (POOL) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) pool_tile(acc[MTB - 1][j], MTB - 1, j, row);
+        } else {                                                // the last output tile
+            const int t = MTB - 1;
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                float* zp = z + (row + 32 * j + m) * ldz + 32 * (mt0 + t) + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 o = {acc[t][j][4 * q], acc[t][j][4 * q + 1], acc[t][j][4 * q + 2], acc[t][j][4 * q + 3]};
+                    o[0] += bprev[4 * q];
+                    o[1] += bprev[4 * q + 1];
+                    o[2] += bprev[4 * q + 2];
+                    o[3] += bprev[4 * q + 3];
+                    *reinterpret_cast<f32x4*>(zp + 8 * q) = o;
+                }
+            }
+        }
+    }
+}
+
+static int trx_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        n = v;
+    }
+    return n;
+}
+
+// 0: this call does not take the f16x3 kernel; otherwise its packed-image layout code, 0x100 | MTB
+int tr_linear_x3_layout(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act) {
+    (void)has_act;
+    if (accumulate || M < 4096 || M % 256 != 0 || M >= ((int64_t)1 << 31) || c_in % 64 != 0 || c_in < 64 || c_in > 4096 ||
+        c_out % 256 != 0 || (seg != 0 && seg % 256 != 0))
+        return 0;
+    return 0x100 | 8;
+}
+
+static hipError_t trx_launch(bool pool, const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                             int relu_in, const uint16_t* wpk, const float* bias, int64_t seg, int c_out, float* z, int64_t ldz,
+                             const float* out_scale, const float* out_shift, unsigned long long* packed, hipStream_t s) {
+    const int n_mblk = c_out / 256;
+    const int n_groups = (int)(M / 256);
+    int per = trx_cu_count() / n_mblk;                               // workgroups per output block: one workgroup per CU in all
+    if (per < 1) per = 1;
+    if (per > n_groups) per = n_groups;
+    const unsigned grid = (unsigned)(per * n_mblk);
+    const size_t lds = 2 * X3_SEG * 1024 + X3_WAVES * 2 * TRX_STAGE_BYTES + 2 * (size_t)c_in * sizeof(float) + 3 * 256 * sizeof(float);
+    const auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, lda, c_in, scale, shift, relu_in, wpk, bias, seg, c_out, z, ldz,
+                           n_mblk, n_groups, out_scale, out_shift, packed);
+        return hipGetLastError();
+    };
+    if (pool) return scale ? go(tr_linear_x3_kernel<true, true>) : go(tr_linear_x3_kernel<false, true>);
+    return scale ? go(tr_linear_x3_kernel<true, false>) : go(tr_linear_x3_kernel<false, false>);
+}
+
+hipError_t launch_tr_linear_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift, int relu_in,
+                               const uint16_t* wpk, int layout, const float* bias, int64_t seg, int c_out, float* z, int64_t ldz,
+                               hipStream_t s) {
+    if ((layout & 0xff) != 8) return hipErrorInvalidValue;
+    return trx_launch(false, a, M, c_in, lda, scale, shift, relu_in, wpk, bias, seg, c_out, z, ldz, nullptr, nullptr, nullptr, s);
+}
+
+// the pooled layer (launch_tr_linear_pool of dal3_train.hip on the f16x3 engine); ok: tr_linear_pool_x3_ok()
+bool tr_linear_pool_x3_ok(int64_t M, int c_in, int64_t seg, int c_out) {
+    return tr_linear_x3_layout(M, c_in, seg, c_out, 0, 1) != 0 && seg > 0;
+}
+hipError_t launch_tr_linear_pool_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                                    int relu_in, const float* W, int64_t ldw, const float* bias, const float* out_scale,
+                                    const float* out_shift, int64_t seg, int c_out, float* g, int32_t* arg, float* ws,
+                                    unsigned long long* packed, hipStream_t s) {
+    const int64_t n_seg = M / seg;
+    hipError_t e = launch_fill_words(packed, (size_t)n_seg * c_out * 2, 0u, s);
+    if (e != hipSuccess) return e;
+    dal3_tr_pack_item it{W, ldw, 0, c_out, c_in, 0x108, ws};
+    e = launch_tr_pack_many(&it, 1, s);
+    if (e != hipSuccess) return e;
+    e = trx_launch(true, a, M, c_in, lda, scale, shift, relu_in, reinterpret_cast<const uint16_t*>(ws), bias, seg, c_out, nullptr, 0,
+                   out_scale, out_shift, packed, s);
+    if (e != hipSuccess) return e;
+    return launch_tr_segmax_unpack(packed, n_seg * c_out, g, arg, s);
+}

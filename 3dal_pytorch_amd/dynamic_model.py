@@ -16,7 +16,8 @@ from .datasets import DYNAMICTRACK                                  # noqa: F401
 from .losses import DynamicModelLoss, huber_loss                    # noqa: F401
 from ._heads import (BoxEmbedding, DynamicPointNetEstimation as PointNetEstimation, PackedCache, PackedModelMixin,
                      PointEmbedding, PointNetInstanceSeg, Workspace, as_f32, as_points, dtype_of, numpy_choice, rows_contiguous)
-from .static_model import _box_pred, _mask_and_gather, _parse, _seg_logits
+from . import train as _train
+from .static_model import _box_pred, _mask_and_gather, _parse, _seg_logits, _train_arith
 
 NUM_HEADING_BIN = arch.NUM_HEADING_BIN
 NUM_SIZE_CLUSTER = arch.NUM_SIZE_CLUSTER
@@ -112,7 +113,8 @@ class DynamicModel(PackedModelMixin, nn.Module):
 
     def forward(self, pts, box, bbox_gt):
         if self.training:
-            return _train_forward(self, pts, box)
+            with _train.arithmetic(_train_arith(self)):
+                return _train_forward(self, pts, box)
         o = self._run(pts, box)
         bp = o["bp"]
         B = bp.shape[0]

@@ -147,7 +147,8 @@ class StaticModelOneBoxEst(_StaticBase):
 
     def forward(self, pts, init_box, bbox_gt):
         if self.training:
-            return _train_forward_one(self, pts, init_box)
+            with _train.arithmetic(_train_arith(self)):
+                return _train_forward_one(self, pts, init_box)
         o = self._run(pts, init_box, bbox_gt)
         bp = o["bp1"]
         B = bp.shape[0]
@@ -174,7 +175,8 @@ class StaticModelTwoBoxEst(_StaticBase):
 
     def forward(self, pts, init_box, bbox_gt):
         if self.training:
-            return _train_forward_two(self, pts, init_box, bbox_gt)
+            with _train.arithmetic(_train_arith(self)):
+                return _train_forward_two(self, pts, init_box, bbox_gt)
         o = self._run(pts, init_box, bbox_gt)
         b1, b2 = o["bp1"], o["bp2"]
         B = b1.shape[0]
@@ -264,6 +266,12 @@ def _hip_training(m, pts):
     if backend not in ("hip", "torch"):
         raise ValueError(f"unknown train_backend {backend!r}")
     return backend == "hip" and _train.supported(pts)
+
+
+def _train_arith(m):
+    """model.precision in train mode: "f16x3" runs the forward's big layers on the f16x3 training kernels (train.ARITH);
+    anything else trains in exact fp32 (the 16-bit eval precisions have no training path)"""
+    return "f16x3" if getattr(m, "precision", "fp32") == "f16x3" else "fp32"
 
 
 def _seg_logits(m, pts):

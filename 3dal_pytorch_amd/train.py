@@ -32,6 +32,38 @@ _SCRATCH = {}
 # and the pooled points — so that a float64 composite can be evaluated AT THE SAME gates. None in production.
 CAPTURE = None
 
+# Arithmetic of the training FORWARD's big layers (c_out % 256 == 0, M % 256 == 0 ...: dal3_tr_linear_x3_layout):
+# "fp32" — the exact-fp32 MFMA kernels; "f16x3" — fp16 MFMAs on (hi, lo) split operands, fp32 accumulate
+# (dal3_train_x3.hip: the same 1e-6 of the output's range, 1.3-2.3 x faster per layer). The backward's dgrad / wgrad stay
+# fp32 either way (their dz operands are far below fp16's exponent range). Set by the drop-ins from model.precision.
+ARITH = "fp32"
+
+
+class arithmetic:
+    """with arithmetic("f16x3"): ...  — the training forward inside runs its big layers on the f16x3 kernels"""
+
+    def __init__(self, name):
+        if name not in ("fp32", "f16x3"):
+            raise ValueError(f"unknown training arithmetic {name!r}")
+        self.name = name
+
+    def __enter__(self):
+        global ARITH
+        self.prev, ARITH = ARITH, self.name
+        return self
+
+    def __exit__(self, *exc):
+        global ARITH
+        ARITH = self.prev
+        return False
+
+
+class _X3Image:
+    """a dal3_tr_pack_many image in the f16x3 layout (read by dal3_tr_linear_x3)"""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
 
 def _ws(nbytes, dev):
     """grow-only scratch per (device, stream). Every user enqueues on the current stream and is done with the buffer when its
@@ -65,6 +97,10 @@ def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False,
     z = out if out is not None else torch.empty((M, c_out), dtype=torch.float32, device=a.device)
     sc, sh, relu = (act if act is not None else (None, None, False))
     lib = _hip.lib()
+    if isinstance(packed, _X3Image):
+        _hip.check(lib.dal3_tr_linear_x3(_hip.ptr(a), M, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu), _hip.ptr(bias), seg,
+                                         c_out, _hip.ptr(z), z.stride(0), _hip.ptr(packed.tensor), _hip.stream()))
+        return z
     if packed is not None:
         _hip.check(lib.dal3_tr_linear_prepacked(_hip.ptr(a), M, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu),
                                                 _hip.ptr(W), ldw, int(transpose), _hip.ptr(bias), seg, c_out, _hip.ptr(z),
@@ -89,6 +125,9 @@ def _prepack(specs, dev):
     no packed image. The weights must not change between this and the calls (a step's forward and backward: they do not)."""
     lib = _hip.lib()
     lay = [lib.dal3_tr_linear_pack_layout(M, ci, seg, co, int(acc), int(has_act)) for _, ci, co, _, M, seg, acc, has_act in specs]
+    if ARITH == "f16x3":                                    # forward calls that qualify take the f16x3 image instead
+        lay = [(lib.dal3_tr_linear_x3_layout(M, ci, seg, co, int(acc), int(has_act)) if not tr else 0) or l
+               for l, (_, ci, co, tr, M, seg, acc, has_act) in zip(lay, specs)]
     size = [int(lib.dal3_tr_linear_workspace_bytes(ci, co)) if l else 0 for l, (_, ci, co, *_r) in zip(lay, specs)]
     size = [(n + 255) // 256 * 256 for n in size]
     buf = torch.empty(max(sum(size), 16), dtype=torch.uint8, device=dev)
@@ -99,7 +138,7 @@ def _prepack(specs, dev):
             continue
         view = buf[off:off + n]
         off += n
-        out.append(view)
+        out.append(_X3Image(view) if l & 0x100 else view)
         items.append(_hip.PackItem(_hip.ptr(W), W.stride(0), int(tr), co, ci, l, _hip.ptr(view)))
     for i in range(0, len(items), 48):
         chunk = items[i:i + 48]
@@ -239,7 +278,10 @@ def _linear_pool(a, act, W, b, bn, seg):
     g = torch.empty((n_seg, c_out), dtype=torch.float32, device=a.device)
     arg = torch.empty((n_seg, c_out), dtype=torch.int32, device=a.device)
     sc, sh, relu = act
-    _hip.check(lib.dal3_tr_linear_pool(_hip.ptr(a), M, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu), _hip.ptr(W),
+    pool = lib.dal3_tr_linear_pool
+    if ARITH == "f16x3" and lib.dal3_tr_linear_pool_x3_ok(M, c_in, seg, c_out):
+        pool = lib.dal3_tr_linear_pool_x3
+    _hip.check(pool(_hip.ptr(a), M, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu), _hip.ptr(W),
                                        W.stride(0), _hip.ptr(b), _hip.ptr(bn.scale), _hip.ptr(bn.shift), seg, c_out,
                                        _hip.ptr(g), _hip.ptr(arg), _hip.ptr(ws), need, _hip.stream()))
     return g, arg

@@ -338,6 +338,25 @@ int dal3_tr_pack_many(const dal3_tr_pack_item* items, int n, dal3_stream stream)
 int dal3_tr_linear_prepacked(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                              int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
                              int c_out, float* z, int64_t ldz, int accumulate, const void* packed, dal3_stream stream);
+/* The same layer on the "f16x3" arithmetic (DAL3_F16X3: fp16 MFMAs on (hi, lo) split operands, fp32 accumulate — the fp32
+ * kernels' accuracy at a third of their MFMA time), for the FORWARD's big layers: operands must lie inside fp16's exponent
+ * range (post-BatchNorm activations and weights do; gradients do not, so dgrad / wgrad calls stay on dal3_tr_linear).
+ *   dal3_tr_linear_x3_layout -> 0 when the call does not qualify (accumulate, M % 256, c_in % 64, c_out % 256, seg % 256,
+ *                               M < 4096), else the layout code to put into dal3_tr_pack_item.mtb for dal3_tr_pack_many
+ *                               (image size: dal3_tr_linear_workspace_bytes(c_in, c_out), as for the fp32 image);
+ *   dal3_tr_linear_x3           z = act(a) W^T + bias from that image. a, z, bias 16-byte aligned. */
+int dal3_tr_linear_x3_layout(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act);
+int dal3_tr_linear_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift, int relu_in,
+                      const float* bias, int64_t seg, int c_out, float* z, int64_t ldz, const void* packed,
+                      dal3_stream stream);
+/* dal3_tr_linear_pool on the same arithmetic (same arguments and workspace); _ok: 1 when the shape qualifies
+ * (M % 256, c_in % 64, c_out % 256, seg % 256 == 0, M >= 4096). g / arg agree with dal3_tr_linear_pool's to the fp32 kernels'
+ * accuracy (not bit for bit: the products are formed differently). */
+int dal3_tr_linear_pool_x3_ok(int64_t M, int c_in, int64_t seg, int c_out);
+int dal3_tr_linear_pool_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift, int relu_in,
+                           const float* W, int64_t ldw, const float* bias, const float* out_scale, const float* out_shift,
+                           int64_t seg, int c_out, float* g, int32_t* arg, void* workspace, size_t workspace_bytes,
+                           dal3_stream stream);
 size_t dal3_tr_colred_workspace_bytes(int64_t M, int C);
 int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                    const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,

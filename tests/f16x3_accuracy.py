@@ -10,7 +10,8 @@ run:   f32     plain float32 (what the fp32-MFMA kernels do)
 The first layer (raw coordinates) and the per-crop dconv1 term stay fp32, as in the kernels.
 Result (8 crops x 1024 points, max |logit error| / max |logit|):  f32 2.0e-6 | f16x3 1.0e-6 | bf16x3 5.2e-5 | f16 2.7e-3 |
 bf16 2.6e-2  ->  the fp16 split is as exact as fp32 arithmetic itself; at 16x the MFMA rate for 3x the MFMAs it is what
-dal3_pointmlp_x3.hip builds on."""
+dal3_pointmlp_x3.hip builds on. Lives under tests/ because it uses the oracle package (test infrastructure
+only); tests/test_host_cpu.py runs it at a small size."""
 import os
 import sys
 
@@ -19,14 +20,13 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _common import recentred_sd, synth                     # noqa: E402
 from oracle import ref_heads as R                           # noqa: E402
 
 
-def main():
+def main(B=8, N=1024):
     torch.set_num_threads(8)
-    B, N = 8, 1024
     pts_np, _, _ = synth.static_crops(B, N, seed=5)
     t = R.as_torch_sd(recentred_sd("static_one", pts_np[:2], seed=5))
 
@@ -76,8 +76,11 @@ def main():
         W, b = Wb[9]
         return mm(a, W, mode) + b
     ref = net("f64")
+    out = {}
     for m in ("f32", "f16x3", "bf16x3", "f16", "bf16"):
-        print(f"{m:7s} max |logit error| / max |logit| = {float((net(m) - ref).abs().max() / ref.abs().max()):.2e}")
+        out[m] = float((net(m) - ref).abs().max() / ref.abs().max())
+        print(f"{m:7s} max |logit error| / max |logit| = {out[m]:.2e}")
+    return out
 
 
 if __name__ == "__main__":

@@ -1,0 +1,149 @@
+"""The training forward's big layers on the f16x3 engine (dal3_train_x3.hip; model.precision = "f16x3" in train mode,
+train.arithmetic("f16x3")): each kernel against float64 at the fp32 kernels' accuracy, the pooled layer's argmax against
+the fp32 kernel's, and ONE WHOLE TRAINING STEP against the reference's own (the big fixtures of
+test_gpu_train_reference.py: forward, criterion, gradients gated at the forward's decisions, BatchNorm statistics, Adam
+step) with the f16x3 kernels in the forward."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import test_gpu_train_reference as R
+from _common import build_model
+
+hip = importlib.import_module("3dal_pytorch_amd._hip")
+train = importlib.import_module("3dal_pytorch_amd.train")
+pytestmark = pytest.mark.gpu
+
+
+def _x3_linear(a, W, act, bias, seg):
+    lib = hip.lib()
+    M, ci = a.shape
+    co = W.shape[0]
+    lay = lib.dal3_tr_linear_x3_layout(M, ci, seg, co, 0, int(act is not None))
+    assert lay == 0x108
+    pk = torch.empty(lib.dal3_tr_linear_workspace_bytes(ci, co), dtype=torch.uint8, device="cuda")
+    item = (hip.PackItem * 1)(hip.PackItem(hip.ptr(W), W.stride(0), 0, co, ci, lay, hip.ptr(pk)))
+    hip.check(lib.dal3_tr_pack_many(item, 1, hip.stream()))
+    z = torch.empty((M, co), device="cuda")
+    sc, sh, relu = act if act is not None else (None, None, False)
+    hip.check(lib.dal3_tr_linear_x3(hip.ptr(a), M, ci, a.stride(0), hip.ptr(sc), hip.ptr(sh), int(relu), hip.ptr(bias), seg, co,
+                                    hip.ptr(z), z.stride(0), hip.ptr(pk), hip.stream()))
+    return z
+
+
+@pytest.mark.parametrize("M,ci,co,act,relu,seg,with_bias", [
+    (8192, 512, 256, True, True, 0, True),          # dconv2
+    (8192, 64, 512, True, True, 4096, True),        # dconv1's per-point part: a bias ROW per crop
+    (4096, 64, 256, False, False, 0, False),        # two k-tiles: first and last pair are the same one
+    (12288, 128, 768, True, False, 256, True),      # three output blocks, affine without ReLU, a row per group
+    (70 * 256, 256, 512, True, True, 0, True),      # more groups than workgroups per block can be dealt evenly
+])
+def test_linear_x3_against_float64(M, ci, co, act, relu, seg, with_bias):
+    g = torch.Generator(device="cuda").manual_seed(M + ci + co)
+    lda = ci + 8                                              # a row stride that is not the row length
+    a = (torch.randn((M, lda), device="cuda", generator=g) * 1.5)[:, :ci]
+    W = torch.randn((co, ci), device="cuda", generator=g) / ci ** 0.5
+    sc = torch.rand(ci, device="cuda", generator=g) + 0.5
+    sc[::5] *= -1.0
+    sh = torch.randn(ci, device="cuda", generator=g) * 0.3
+    n_row = M // seg if seg else 1
+    bias = torch.randn((n_row, co), device="cuda", generator=g) if with_bias else None
+    x = a.double()
+    if act:
+        x = x * sc.double() + sh.double()
+        if relu:
+            x = torch.relu(x)
+    ref = x @ W.double().t()
+    if with_bias:
+        ref = ref + (bias.double().repeat_interleave(seg, 0) if seg else bias.double())
+    z = _x3_linear(a, W, (sc, sh, relu) if act else None, bias, seg)
+    z32 = train._linear(a, W, ci, ci, co, act=(sc, sh, relu) if act else None, bias=bias, seg=seg)
+    rng = float(ref.abs().max())
+    ex, e32 = float((z.double() - ref).abs().max()) / rng, float((z32.double() - ref).abs().max()) / rng
+    assert ex < 2e-6, (ex, e32)                                 # (measured 2.5e-7 .. 7e-7; the fp32 kernel 3e-7 .. 1e-6)
+    assert ex < 2 * e32 + 2e-7
+
+
+def test_linear_x3_layout_rules():
+    lib = hip.lib()
+    ok = lambda *a: lib.dal3_tr_linear_x3_layout(*a)          # noqa: E731   (M, c_in, seg, c_out, accumulate, has_act)
+    assert ok(262144, 512, 0, 256, 0, 1) == 0x108 and ok(262144, 64, 4096, 512, 0, 1) == 0x108
+    assert ok(262144, 512, 0, 256, 1, 1) == 0                 # accumulate: the fp32 kernel
+    assert ok(262144, 512, 0, 128, 0, 1) == 0                 # c_out % 256
+    assert ok(262144, 96, 0, 256, 0, 1) == 0                  # c_in % 64
+    assert ok(262144 + 32, 512, 0, 256, 0, 1) == 0            # M % 256
+    assert ok(2048, 512, 0, 256, 0, 1) == 0                   # few rows: the small-M kernels
+    assert ok(262144, 64, 4000, 512, 0, 1) == 0               # a group of 256 points must lie in one segment
+    # a call that does not qualify is refused, not mis-computed
+    a = torch.zeros((512, 64), device="cuda")
+    z = torch.empty((512, 256), device="cuda")
+    pk = torch.empty(lib.dal3_tr_linear_workspace_bytes(64, 256), dtype=torch.uint8, device="cuda")
+    rc = lib.dal3_tr_linear_x3(hip.ptr(a), 512, 64, 64, None, None, 0, None, 0, 256, hip.ptr(z), 256, hip.ptr(pk), hip.stream())
+    assert rc == hip.EINVAL if hasattr(hip, "EINVAL") else rc != 0
+
+
+@pytest.mark.parametrize("M,ci,co,seg", [(16 * 4096, 128, 1024, 4096), (64 * 512, 256, 512, 512), (4096, 64, 256, 256)])
+def test_linear_pool_x3_against_the_fp32_kernel(M, ci, co, seg):
+    g = torch.Generator(device="cuda").manual_seed(co)
+    a = torch.randn((M, ci), device="cuda", generator=g) * 1.5
+    W = torch.randn((co, ci), device="cuda", generator=g) / ci ** 0.5
+    b = torch.randn(co, device="cuda", generator=g) * 0.1
+    sc = torch.rand(ci, device="cuda", generator=g) + 0.5
+    sh = torch.randn(ci, device="cuda", generator=g) * 0.3
+
+    class BN:
+        scale = torch.rand(co, device="cuda", generator=g) + 0.5
+        shift = torch.randn(co, device="cuda", generator=g) * 0.3
+    BN.scale[::7] *= -1.0
+    BN.shift[::11] = -50.0                                    # channels that ReLU clamps everywhere: max 0 at the FIRST point
+    g32, a32 = train._linear_pool(a, (sc, sh, True), W, b, BN, seg)
+    with train.arithmetic("f16x3"):
+        assert hip.lib().dal3_tr_linear_pool_x3_ok(M, ci, seg, co)
+        gx, ax = train._linear_pool(a, (sc, sh, True), W, b, BN, seg)
+    n_seg = M // seg
+    x = torch.relu(a.double() * sc.double() + sh.double())
+    y = torch.relu((x @ W.double().t() + b.double()) * BN.scale.double() + BN.shift.double()).view(n_seg, seg, co)
+    ref, rarg = y.max(1)
+    rng = float(ref.abs().max())
+    assert float((gx.double() - ref).abs().max()) / rng < 2e-6
+    clamped = ref == 0
+    assert bool((ax[clamped] == 0).all()) and bool((gx[clamped] == 0).all())
+    # the argmax may differ from float64's only between points whose values tie within the arithmetic's error
+    differ = ax.long() != rarg
+    assert float(differ.float().mean()) < 1e-3
+    if bool(differ.any()):
+        picked = y.gather(1, ax.long()[:, None, :].clamp(0, seg - 1))[:, 0]
+        assert float((picked - ref)[differ].abs().max()) / rng < 2e-6
+    assert float((a32.long() != ax.long()).float().mean()) < 1e-3
+
+
+@pytest.fixture
+def x3_train(monkeypatch, tmp_path):
+    def bm(kind, sd, device="cuda"):
+        m = build_model(kind, sd, device)
+        m.precision = "f16x3"
+        return m
+    monkeypatch.setattr(R, "build_model", bm)
+    monkeypatch.chdir(tmp_path)                               # (the borrowed test writes its table under ./gpurun_out when there is one)
+    calls = {"x3": 0, "pool": 0}
+    lib = hip.lib()
+    real_lin, real_pool = lib.dal3_tr_linear_x3, lib.dal3_tr_linear_pool_x3
+
+    class Counting:                                           # the f16x3 kernels really ran in the borrowed test's forward
+        def __init__(self, fn, key):
+            self.fn, self.key = fn, key
+
+        def __call__(self, *a):
+            calls[self.key] += 1
+            return self.fn(*a)
+    monkeypatch.setattr(lib, "dal3_tr_linear_x3", Counting(real_lin, "x3"), raising=False)
+    monkeypatch.setattr(lib, "dal3_tr_linear_pool_x3", Counting(real_pool, "pool"), raising=False)
+    return calls
+
+
+@pytest.mark.parametrize("kind", ["static_one_big", "static_two_big", "dynamic_big"])
+def test_one_training_step_matches_the_reference_f16x3(x3_train, kind):
+    R.test_one_training_step_matches_the_reference(kind)
+    assert x3_train["x3"] >= 2 and x3_train["pool"] >= 1, x3_train

@@ -229,3 +229,16 @@ def test_box_gatherer_without_a_process_group_passes_the_boxes_through():
     with pytest.raises(RuntimeError):
         g.submit(b)
     assert torch.equal(g.collect(keep=0), b) and torch.equal(g.collect(keep=0), a) and g.collect(keep=0) is None
+
+
+def test_f16x3_split_is_as_exact_as_fp32_arithmetic_in_emulation():
+    """tests/f16x3_accuracy.py (every product of ins_seg formed as the named arithmetic forms it, logits against float64):
+    the (hi, lo) fp16 split is within a factor of two of plain float32 — the premise of the f16x3 kernels — while one rounding
+    to fp16 costs three digits and a bf16 split one and a half"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("f16x3_accuracy", os.path.join(ROOT, "tests", "f16x3_accuracy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    e = mod.main(B=2, N=512)
+    assert e["f16x3"] < 2 * e["f32"] and e["f16x3"] < 5e-6
+    assert e["f16"] > 100 * e["f16x3"] and e["bf16x3"] > 5 * e["f16x3"]

@@ -74,7 +74,9 @@ def main():
         model = dm.DynamicModel() if dynamic else sm.StaticModelOneBoxEst()
         model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict(args.kind).items()})
         model = model.to(dev).train()
-        model.train_backend = backend
+        model.train_backend = "hip" if backend == "hip_f16x3" else backend
+        if backend == "hip_f16x3":                              # the forward's big layers on the f16x3 training kernels
+            model.precision = "f16x3"
         model.sampler = args.sampler
         # --adam default: what static_train.py:220 constructs (torch picks its multi-tensor "foreach" path: ~12 launches
         # per step over the 150 tensors); fused: torch.optim.Adam(..., fused=True), ONE multi-tensor launch — the same
@@ -111,7 +113,9 @@ def main():
             gm = dm.DynamicModel() if dynamic else sm.StaticModelOneBoxEst()
             gm.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict(args.kind).items()})
             gm = gm.to(dev).train()
-            gm.train_backend, gm.sampler = backend, "device"
+            gm.train_backend, gm.sampler = ("hip" if backend == "hip_f16x3" else backend), "device"
+            if backend == "hip_f16x3":
+                gm.precision = "f16x3"
             gopt = torch.optim.Adam(gm.parameters(), lr=1e-3, weight_decay=1e-4, capturable=True)
             cap = graph.CapturedTrainStep(gm, gopt, lambda p_, i_, g_: crit(gm(p_, i_, g_), *labels)["total_loss"],
                                           pts, init, gt)

@@ -9,6 +9,7 @@ NONAN=-fno-honor-nans          # the shared-MLP kernels only, as in the Makefile
 for f in dal3_api dal3_misc dal3_prep dal3_crops dal3_train; do
   $CC $2 -c 3dal_pytorch_amd/csrc/$f.hip -o variants/obj_$1/$f.o &
 done
+$CC $2 -mllvm -pragma-unroll-threshold=1000000 -c 3dal_pytorch_amd/csrc/dal3_train_x3.hip -o variants/obj_$1/dal3_train_x3.o &
 CC="$CC $NONAN"
 $CC $2 -c 3dal_pytorch_amd/csrc/dal3_pointmlp.hip -o variants/obj_$1/dal3_pointmlp.o &
 $CC $2 -c 3dal_pytorch_amd/csrc/dal3_latency.hip -o variants/obj_$1/dal3_latency.o &
