@@ -18,8 +18,9 @@ rocprofv3 $KT -d $O/prof_kt_c3 -o kt -- python3 $R/bench.py --no-extras --config
 rocprofv3 $KT -d $O/prof_kt_c5 -o kt -- python3 $R/bench.py --no-extras --config C5 --steps 10 --warmup 2 > $O/bench_c5_under_rocprof.json 2>/dev/null
 # one training step (64 x 4096, fp32, Adam, device sampler): kernel trace of tools/bench_train.py
 rocprofv3 $KT -d $O/prof_kt_train -o kt -- python3 $R/tools/bench_train.py --backends hip --sampler device --iters 10 > $O/bench_train_under_rocprof.json 2>/dev/null
-python3 $R/tools/bench_train.py --sampler device > $O/bench_train.json 2>/dev/null
-python3 $R/tools/bench_train.py --kind dynamic --sampler device > $O/bench_train_dynamic.json 2>/dev/null
+python3 $R/tools/bench_train.py --sampler device --backends hip,hip_f16x3,torch > $O/bench_train.json 2>/dev/null
+python3 $R/tools/bench_train.py --kind dynamic --sampler device --backends hip,hip_f16x3,torch > $O/bench_train_dynamic.json 2>/dev/null
+python3 $R/tools/trx_probe.py > $O/trx_probe.txt 2>/dev/null
 python3 $R/tools/bench_latency.py > $O/bench_latency.json 2>/dev/null
 # the reference's own eval batch (64 crops x 4096 points): where the small kernels between the three big ones show
 rocprofv3 $KT -d $O/prof_kt_b64 -o kt -- python3 $R/bench.py --no-extras --batch 64 --points 4096 --steps 20 --warmup 3 > $O/bench_b64_under_rocprof.json 2>/dev/null
