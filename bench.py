@@ -894,6 +894,9 @@ def main():
                                 executed_gflop_per_step(k3, static, B) / (d * 1e3) / MFMA_PEAK_TFLOPS["f16x3"], 4),
                             "roofline": roofline_of(k3, MFMA_PEAK_TFLOPS["f16x3"], "f16x3", B, N, tag="_f16x3"),
                             "kernels": k3}
+            # the same three numbers at the top level of the line, next to `value` (which stays the exact-fp32 path's)
+            rec["f16x3_value"], rec["f16x3_ms_per_step"] = rec["f16x3"]["value"], rec["f16x3"]["ms_per_step"]
+            rec["f16x3_logits_max_rel_vs_exact_fp32_path"] = rec["f16x3"]["vs_exact_fp32_path"]["logits_max_rel"]
             model.precision = args.precision
         rec["maxpool"] = maxpool_roofline(dev, iters=5)
         rec["maxpool_bf16"] = maxpool_roofline(dev, iters=5, dtype=torch.bfloat16)     # the same rows in 2-byte storage (C3 / C5)
