@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void point_head_x3_kernel(PointHeadX3W w, BCN 
             np = d <= 0 ? 1 : (d < np ? d : np);
         }
         if (wg_tile * X3_WAVES * 32 * T >= np) continue;   // only copies in this group: uniform skip (the stream stays put)
-        st.pin(2, 0);
+        st.pin(st.START, 0);
         float in[T][KS];
         load_points<KS, T>(x, b, (wg_tile * X3_WAVES + wave) * (32 * T), np, c_in, in, lane);
         X3Tile x1[T][K2], x2[T][M2], x3[T][M3];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void ins_seg_encode_x3_kernel(InsSegX3W w, BCN
     };
     prefetch(blockIdx.x);
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        st.pin(2, 0);
+        st.pin(st.START, 0);
         const int64_t b = grp / tiles_per_item;
         X3Tile x1[T][2], x2[T][2], x3[T][2], x4[T][4];
 #pragma unroll
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void ins_seg_decode_x3_kernel(InsSegX3W w, BCN
     };
     prefetch(blockIdx.x);
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        st.pin(2, 0);
+        st.pin(st.START, 0);
         const int64_t b = grp / tiles_per_item;
         const int n0 = ((grp % tiles_per_item) * X3_WAVES + wave) * (32 * T);
         __syncthreads();                                   // everyone is done with the previous group's s_gb

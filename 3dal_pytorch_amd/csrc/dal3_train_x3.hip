@@ -246,10 +246,10 @@ __global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restri
         // FIRST / LAST are compile-time (the first block takes C = 0, the last k-tile carries the stores); in between a
         // runtime loop whose body is whole segments (the cursor state repeats: pin)
         if (KT == 2) {
-            st.pin(2, 0);
+            st.pin(st.START, 0);
             pair(0, std::true_type{}, std::true_type{});
         } else {
-            st.pin(2, 0);
+            st.pin(st.START, 0);
             pair(0, std::true_type{}, std::false_type{});
             const int c0 = st.cur, p0 = st.pending;
             for (int kt = 2; kt + 2 < KT; kt += 2) {

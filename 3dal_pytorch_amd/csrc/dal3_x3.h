@@ -82,9 +82,14 @@ __device__ __forceinline__ void x3_split_steps(const f32x16 (&a)[T], const f32x1
 // (LdsRing::acquire_wait) with the matrix pipe still busy, a k-step before anything of that segment is needed. The
 // refill of the slot this frees is then PENDING: its LDS-DMA instructions go out one per k-step (the third slot gives it
 // a further segment to land); all of them are out before the next acquire_wait, whose counted vmcnt relies on it.
-template <bool DRAIN = false, int SLOTS = 3>  // DRAIN: open() waits for all of the wave's VMEM traffic (LdsRing::acquire_wait_all)
+#ifndef DAL3_X3_DEPTH
+#define DAL3_X3_DEPTH 1                 // fragment pairs in registers ahead of the one in use (A/B: 2)
+#endif
+template <bool DRAIN = false, int SLOTS = 3, int DEPTH = DAL3_X3_DEPTH>  // DRAIN: open() waits for all of the wave's VMEM traffic (LdsRing::acquire_wait_all)
 struct X3StreamT {
     typedef LdsRing<X3_SEG, SLOTS> Ring;
+    static constexpr int START = 2 * DEPTH;                // the cursor at the start of a group of points
+    x3v8 n2h, n2l;                                         // (DEPTH == 2: the pair after (nh, nl))
     Ring ring;
     int cur, pending;
     x3v8 nh, nl;
@@ -111,8 +116,15 @@ struct X3StreamT {
         cur = 0;
     }
     __device__ __forceinline__ void fetch() {
-        nh = ring.template frag<FP16>(cur);
-        nl = ring.template frag<FP16>(cur + 1);
+        if (DEPTH == 2) {
+            nh = n2h;
+            nl = n2l;
+            n2h = ring.template frag<FP16>(cur);
+            n2l = ring.template frag<FP16>(cur + 1);
+        } else {
+            nh = ring.template frag<FP16>(cur);
+            nl = ring.template frag<FP16>(cur + 1);
+        }
         cur += 2;
     }
     // state at the start of every group of points: first pair in (nh, nl), cur == 2, nothing pending
@@ -122,6 +134,7 @@ struct X3StreamT {
         open();
         flush();
         fetch();
+        if (DEPTH == 2) fetch();
     }
     __device__ __forceinline__ void take(x3v8& wh, x3v8& wl) {
         wh = nh;
@@ -131,9 +144,10 @@ struct X3StreamT {
     // end of a group of points: a stream of whole segments needs nothing (the last take() fetched the next group's first
     // pair); otherwise what is left of the open segment is padding
     __device__ __forceinline__ void end_group() {
-        if (cur != 2) {
+        if (cur != START) {
             open();
             fetch();
+            if (DEPTH == 2) fetch();
         }
         flush();
     }
