@@ -147,3 +147,31 @@ def x3_train(monkeypatch, tmp_path):
 def test_one_training_step_matches_the_reference_f16x3(x3_train, kind):
     R.test_one_training_step_matches_the_reference(kind)
     assert x3_train["x3"] >= 2 and x3_train["pool"] >= 1, x3_train
+
+
+def test_x3_training_kernels_are_reproducible_bit_for_bit():
+    """persistent workgroups, a two-slot LDS-DMA ring, per-wave LDS stages, queue drains at segment opens: a race or a
+    missing wait shows up as a launch that differs from the first one"""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for M, ci, co, seg in ((32768, 512, 256, 0), (16384, 64, 512, 4096)):
+        a = torch.randn((M, ci), device="cuda", generator=g)
+        W = torch.randn((co, ci), device="cuda", generator=g) / ci ** 0.5
+        sc, sh = torch.rand(ci, device="cuda", generator=g) + 0.5, torch.randn(ci, device="cuda", generator=g) * 0.3
+        bias = torch.randn((M // seg if seg else 1, co), device="cuda", generator=g)
+        first = _x3_linear(a, W, (sc, sh, True), bias, seg).clone()
+        for _ in range(40):
+            assert torch.equal(_x3_linear(a, W, (sc, sh, True), bias, seg), first)
+    M, ci, co, seg = 32768, 128, 1024, 4096
+    a = torch.randn((M, ci), device="cuda", generator=g)
+    W = torch.randn((co, ci), device="cuda", generator=g) / ci ** 0.5
+    b = torch.randn(co, device="cuda", generator=g) * 0.1
+    sc, sh = torch.rand(ci, device="cuda", generator=g) + 0.5, torch.randn(ci, device="cuda", generator=g) * 0.3
+
+    class BN:
+        scale = torch.rand(co, device="cuda", generator=g) + 0.5
+        shift = torch.randn(co, device="cuda", generator=g) * 0.3
+    with train.arithmetic("f16x3"):
+        g0, a0 = (t.clone() for t in train._linear_pool(a, (sc, sh, True), W, b, BN, seg))
+        for _ in range(40):
+            g1, a1 = train._linear_pool(a, (sc, sh, True), W, b, BN, seg)
+            assert torch.equal(g1, g0) and torch.equal(a1, a0)

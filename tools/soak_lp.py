@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak test of the 16-bit kernels (persistent workgroups, raw barriers, LDS-DMA ring, hand-written MFMA statements):
+"""Soak test of the 16-bit and f16x3 kernels (persistent workgroups, raw barriers, LDS-DMA ring, hand-written MFMA statements):
 many launches at several shapes and both 16-bit types, every output compared bit for bit with the first launch of its
 shape. A race or a missing wait state shows up as a rare mismatch.   python tools/soak_lp.py [--launches 300]"""
 import argparse
@@ -20,6 +20,8 @@ dm = importlib.import_module("3dal_pytorch_amd.dynamic_model")
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--launches", type=int, default=300)
+    ap.add_argument("--precisions", default="bf16,fp16", help="comma list of bf16, fp16, f16x3 (the split-fp16 family: inline-asm "
+                                                               "MFMAs with VGPR accumulators, two-slot / three-slot rings)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cases = []
@@ -39,7 +41,7 @@ def main():
                    torch.from_numpy(np.tile(b, (4, 1, 1))).to(dev).transpose(2, 1), torch.from_numpy(np.tile(i8, (4, 1))).to(dev))))
     bad = 0
     t0 = time.time()
-    for prec in ("bf16", "fp16"):
+    for prec in args.precisions.split(","):
         for name, model, inputs in cases:
             model.precision = prec
             keys = ("logits", "mask", "counts", "obj_idx", "boxes7")
