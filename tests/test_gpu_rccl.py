@@ -79,3 +79,12 @@ def test_two_rank_rehearsal_on_one_gpu_mixed_segment_checks_both_heads():
     assert set(heads) == {("static", 1), ("dynamic", 1)}
     assert heads[("static", 1)]["first_item"] == 32 and heads[("static", 1)]["rows"] == 32
     assert heads[("dynamic", 1)]["rows"] == 64
+
+
+def test_two_rank_rehearsal_on_one_gpu_f16x3():
+    """the same rehearsal on the f16x3 kernels: shard == whole is a property of the arithmetic too (per-point products,
+    exact max): rank 0's recomputation of rank 1's rows gives the gathered bits"""
+    rec = _rehearsal(["--steps", "3", "--warmup", "1", "--batch", "512", "--precision", "f16x3"])
+    assert rec["n_gpus"] == 2 and rec["dtype"].startswith("f16x3") and rec["value"] > 0
+    assert rec["gather_equals_single_rank"] is True, rec["gather_self_check"]
+    assert rec["roofline"]["kernel"] == "ins_seg_decode_x3_kernel" and rec["roofline"]["peak"] == 2500.0
