@@ -296,7 +296,7 @@ static int trx_cu_count() {
 // 0: this call does not take the f16x3 kernel; otherwise its packed-image layout code, 0x100 | MTB
 int tr_linear_x3_layout(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act) {
     (void)has_act;
-    if (accumulate || M < 4096 || M % 256 != 0 || M >= ((int64_t)1 << 31) || c_in % 64 != 0 || c_in < 64 || c_in > 4096 ||
+    if (accumulate || M < 4096 || M % 256 != 0 || M >= ((int64_t)1 << 31) || c_in % 64 != 0 || c_in < 64 || c_in > 2048 ||    // (LDS: ring 64 KiB + stages 64 KiB + 8 c_in + 3 KiB <= 160 KiB)
         c_out % 256 != 0 || (seg != 0 && seg % 256 != 0))
         return 0;
     return 0x100 | 8;

@@ -341,7 +341,7 @@ int dal3_tr_linear_prepacked(const float* a, int64_t M, int c_in, int64_t lda, c
 /* The same layer on the "f16x3" arithmetic (DAL3_F16X3: fp16 MFMAs on (hi, lo) split operands, fp32 accumulate — the fp32
  * kernels' accuracy at a third of their MFMA time), for the FORWARD's big layers: operands must lie inside fp16's exponent
  * range (post-BatchNorm activations and weights do; gradients do not, so dgrad / wgrad calls stay on dal3_tr_linear).
- *   dal3_tr_linear_x3_layout -> 0 when the call does not qualify (accumulate, M % 256, c_in % 64, c_out % 256, seg % 256,
+ *   dal3_tr_linear_x3_layout -> 0 when the call does not qualify (accumulate, M % 256, c_in % 64 or > 2048, c_out % 256, seg % 256,
  *                               M < 4096), else the layout code to put into dal3_tr_pack_item.mtb for dal3_tr_pack_many
  *                               (image size: dal3_tr_linear_workspace_bytes(c_in, c_out), as for the fp32 image);
  *   dal3_tr_linear_x3           z = act(a) W^T + bias from that image. a, z, bias 16-byte aligned. */

@@ -76,6 +76,7 @@ def test_linear_x3_layout_rules():
     assert ok(262144 + 32, 512, 0, 256, 0, 1) == 0            # M % 256
     assert ok(2048, 512, 0, 256, 0, 1) == 0                   # few rows: the small-M kernels
     assert ok(262144, 64, 4000, 512, 0, 1) == 0               # a group of 256 points must lie in one segment
+    assert ok(262144, 2048, 0, 256, 0, 1) == 0x108 and ok(262144, 2112, 0, 256, 0, 1) == 0   # LDS: scale + shift beside ring and stages
     # a call that does not qualify is refused, not mis-computed
     a = torch.zeros((512, 64), device="cuda")
     z = torch.empty((512, 256), device="cuda")
