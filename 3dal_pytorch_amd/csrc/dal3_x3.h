@@ -122,6 +122,12 @@ struct X3StreamT {
             n2h = ring.template frag<FP16>(cur);
             n2l = ring.template frag<FP16>(cur + 1);
         } else {
+#ifdef DAL3_X3_ABL_HALFREADS                               // timing experiment only: every other pair is not read (what LDS weight reads cost)
+            if (cur & 2) {
+                cur += 2;
+                return;
+            }
+#endif
             nh = ring.template frag<FP16>(cur);
             nl = ring.template frag<FP16>(cur + 1);
         }
