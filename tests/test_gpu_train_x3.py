@@ -39,6 +39,7 @@ def _x3_linear(a, W, act, bias, seg):
     (4096, 64, 256, False, False, 0, False),        # two k-tiles: first and last pair are the same one
     (12288, 128, 768, True, False, 256, True),      # three output blocks, affine without ReLU, a row per group
     (70 * 256, 256, 512, True, True, 0, True),      # more groups than workgroups per block can be dealt evenly
+    (4096, 2048, 256, True, True, 0, True),         # the widest input the LDS budget admits (64 k-tiles)
 ])
 def test_linear_x3_against_float64(M, ci, co, act, relu, seg, with_bias):
     g = torch.Generator(device="cuda").manual_seed(M + ci + co)
