@@ -621,7 +621,7 @@ def other_config(name, dev, steps):
          "algorithmic_gflop_per_item": round(wl.flop_item / 1e9, 4),
          "whole_path_tflops_algorithmic": round(value * wl.flop_item / 1e12, 1),
          "whole_path_mfma_frac_algorithmic": round(value * wl.flop_item / 1e12 / peak, 4)}
-    if name != "C4":
+    if not name.startswith("C4"):
         kr, _ = kernel_table(wl.model, wl.inputs, wl.static, wl.B, wl.N, iters=max(3, min(steps, 5)))
         r["whole_path_mfma_frac_executed"] = round(executed_gflop_per_step(kr, wl.static, wl.B) / ms / peak, 4)
         r["roofline"] = roofline_of(kr, peak, ns.precision, wl.B, wl.N, tag="_" + name.lower() if name in ("C3", "C5") else "")
@@ -645,6 +645,8 @@ def apply_config(args):
         args.head, args.precision, args.batch, args.points, args.two_stage = "static", "fp32", 4096, 1024, True
     elif args.config == "Dynamic_fp32":                    # the dynamic head in the reference's own arithmetic, C3's shape
         args.head, args.precision, args.batch, args.points = "dynamic", "fp32", 1024, 1024
+    elif args.config == "C4_f16x3":                        # the mixed segment on the split-fp16 kernels
+        args.config, args.precision = "C4", "f16x3"
     elif args.config == "Dynamic_f16x3":                   # the same, split-fp16 arithmetic (fp32 accuracy: DESIGN.md 5.4)
         args.head, args.precision, args.batch, args.points = "dynamic", "f16x3", 1024, 1024
     elif args.config == "TwoBoxEst_f16x3":
@@ -719,7 +721,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="run consecutive steps on this many HIP streams (graph.StreamPipe): small batches, one GPU")
     ap.add_argument("--two-stage", action="store_true", help="static head: StaticModelTwoBoxEst instead of OneBoxEst")
-    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5", "TwoBoxEst", "Dynamic_fp32", "TwoBoxEst_f16x3", "Dynamic_f16x3"],
+    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5", "TwoBoxEst", "Dynamic_fp32", "TwoBoxEst_f16x3", "Dynamic_f16x3", "C4_f16x3"],
                     help="BASELINE.json configs by name: C2 = the default (static, 4096 x 1024, fp32); C3 = dynamic head, "
                          "1024 items x 5 x 1024 pts, bf16; C4 = one segment (64 static crops x 4096 pts + 40 dynamic tracks), sharded "
                          "over the GPUs (strong scaling); C5 = static, N=4096, 2048 crops per GPU, fp16 MFMA; TwoBoxEst = StaticModelTwoBoxEst "
@@ -909,7 +911,7 @@ def main():
             # driver-timed in the same run (the metric is "static+dynamic heads")
             rec["configs"] = {"C2": "this line's `value`"}
             for name, st in (("C3", 10), ("C5", 10), ("TwoBoxEst", 5), ("TwoBoxEst_f16x3", 5), ("Dynamic_fp32", 5),
-                                 ("Dynamic_f16x3", 5), ("C4", 3)):
+                                 ("Dynamic_f16x3", 5), ("C4", 3), ("C4_f16x3", 3)):
                 rec["configs"][name] = other_config(name, dev, st)
         elif static:
             rec["cpu_baseline"] = cpu_baseline(wl.host)
