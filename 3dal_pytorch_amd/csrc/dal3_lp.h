@@ -230,6 +230,17 @@ struct LdsRing {
         __builtin_amdgcn_sched_barrier(0);
         slot_use = slot_use + 1 == SLOTS ? 0 : slot_use + 1;
     }
+    // ... and the same with the KEEP youngest operations left in flight (a request issued in front of this call that has
+    // until the NEXT call to land; the caller's issue order makes them the youngest)
+    template <int KEEP>
+    __device__ __forceinline__ void acquire_wait_keep() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        slot_use = slot_use + 1 == SLOTS ? 0 : slot_use + 1;
+    }
     __device__ __forceinline__ void issue_part(int k) {
         const int seg = seg_issue < n_segs ? seg_issue : n_segs - 1;
         const int f = wave + 4 * k;

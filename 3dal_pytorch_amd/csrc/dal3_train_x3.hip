@@ -50,13 +50,23 @@ __device__ __forceinline__ void trx_split_quad(const f32x4& xq, const f32x4& scq
 // load in the same queue would be waited for with a count that is too small by the DMA loads issued behind it, i.e. together
 // with loads issued moments ago): the weight ring's refills, the wave's own input k-tiles (staged in LDS, 8 KiB per k-tile:
 // lane (m, h) of instruction (j, q) fetches the 16 bytes it will read back, so staging is conflict-free), and — wave 0 —
-// the next group's bias row. A segment's open() drains the wave's whole queue (X3StreamT<true, 2>: vmcnt(0) + barrier), so
-// what was requested at open(n) is readable behind open(n + 1): a whole segment (16 k-steps, ~1.6 us) to land.
+// the next group's bias row. The order of issue is this source's, so a segment's open waits with an exact count
+// (X3StreamT<true, 2, 1, 8>: vmcnt(8) + barrier): the 8 instructions of the input request issued under k-step 8 stay in
+// flight over the open at k-step 14 and have until the NEXT open to land (22 k-steps, ~2.2 us); in a group's last k-tile
+// the stores / atomics issued behind the request are counted with them (st.keep).
 // One k-tile = 8 out-tiles x 4 fragments = one ring segment (MTB = 8: c_out % 256 == 0). Pipeline, by k-tile n:
-//   input(n + 3) requested at open(n + 1)  |  input(n + 1) read from its stage and split under the first 8 k-steps of
+//   input(n + 3) requested under k-step 8 of k-tile n  |  input(n + 1) read from its stage and split under the first 8 k-steps of
 //   k-tile n  |  MFMAs on split(n)  |  in a group's last k-tile: an out-tile's bias add + stores under the next tile's MFMAs.
 // LDS: ring 2 x 32 KiB | input stages 4 waves x 2 x 8 KiB | scale | shift (c_in floats each) | bias rows 2 x 256 floats.
+#ifdef TRX_ABL_NOSTORE_X3                                    // timing experiment only: the output is not written
+#define TRX_STORE(p, o) do { if ((o)[0] == 12345.678f) *reinterpret_cast<f32x4*>(p) = (o); } while (0)
+#else
+#define TRX_STORE(p, o) (*reinterpret_cast<f32x4*>(p) = (o))
+#endif
 #define TRX_STAGE_BYTES 8192
+#ifndef TRX_EARLY_REQUEST
+#define TRX_EARLY_REQUEST 1             // 0: request a stage's next k-tile at the open (A/B)
+#endif
 // POOL: the pooled layer's forward without its output tensor (tr_linear_pool_kernel of dal3_train.hip): the blocks run
 // with the MFMA operands swapped (points on the accumulator's registers, channels on its lanes), an out-tile's epilogue is
 // conv bias -> BN affine -> ReLU -> max over the tile's 32 points with the point index (first maximum wins) -> the packed
@@ -103,7 +113,7 @@ __global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restri
         s_bias[256 + threadIdx.x] = 0.0f;
     }
     __syncthreads();
-    X3StreamT<true, 2> st;
+    X3StreamT<true, 2, 1, TRX_EARLY_REQUEST ? 8 : 0> st;      // (8: the input request's LDS-DMA instructions stay in flight over an open)
     st.init(wpk + (size_t)mblk * KT * MTB * 4 * 512, smem, KT, wave, lane);
 
     char* const stage = stage0 + wave * (2 * TRX_STAGE_BYTES);  // this wave's two input stages (k-tile n in stage n & 1)
@@ -111,7 +121,11 @@ __global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restri
     // k-tile tau of group g's sequence (tau >= KT: a following group's; past the last group: a harmless re-read of g's own)
     const auto request = [&](int buf, int g, int tau) {
         const int gq = tau >= 2 * KT ? 2 : tau >= KT ? 1 : 0;
+#ifdef TRX_ABL_SAMEROWS                                       // timing experiment only: every group reads the first group's rows (L2 hits)
+        const int gt = (int)(blockIdx.x / (unsigned)n_mblk) + 0 * (g + gq);
+#else
         const int gt = g + gq * gstride < n_groups ? g + gq * gstride : g;
+#endif
         const char* src = reinterpret_cast<const char*>(a + ((int64_t)gt * 256 + wave * 64) * lda + 32 * (tau - gq * KT));
 #pragma unroll
         for (int j = 0; j < T; ++j)
@@ -200,6 +214,19 @@ __global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restri
                         // k-step, read (with its scale and shift) a k-step ahead; k-step 15 — behind the open — reads the
                         // first quad of k-tile k + 2, which has landed in stage kk
                         if (sg < 8) trx_split_quad<ACT>(xq, scq, shq, floor_v, xs[kk ^ 1][sg >> 2][0], sg & 3);
+                        // stage kk ^ 1 has been read (its last quad at k-step 6, split at 7): it takes k-tile k + 3 NOW, six
+                        // k-steps before the open — 22 k-steps instead of 16 to land before the open after this one drains
+                        if (TRX_EARLY_REQUEST && sg == 8) {
+                            // In a group's last k-tile the stores (POOL: the atomics) of the out-tiles that finish behind this
+                            // point are issued behind the request too: 7 sides x 4 stores (x 1 atomic) until the open at k-step
+                            // 14. They stay in flight with it — counted exactly, see X3StreamT::open.
+                            if (LAST && kk == 1) st.keep = 8 + (POOL ? 7 : 28);
+                            // (the next group's bias row first: at the open the request's 8 instructions must be the youngest)
+                            if (!POOL && LAST && kk == 1 && bias && wave == 0)
+                                lds_dma16(reinterpret_cast<const char*>(bias_row(gn)), (uint32_t)(lane * 16),
+                                          reinterpret_cast<char*>(s_bias + 256 * (par ^ 1)));
+                            request(kk ^ 1, g, k + 3);
+                        }
                         if (sg < 7 || sg == 15) {
                             const int nb = sg == 15 ? kk : kk ^ 1, ns = sg == 15 ? 0 : sg + 1, nk = sg == 15 ? k2 : k1;
                             xq = staged(nb, ns >> 2, ns & 3);
@@ -222,7 +249,7 @@ __global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restri
                                     o[1] += bprev[4 * q + 1];
                                     o[2] += bprev[4 * q + 2];
                                     o[3] += bprev[4 * q + 3];
-                                    *reinterpret_cast<f32x4*>(zp + 8 * q) = o;
+                                    TRX_STORE(zp + 8 * q, o);
                                 }
                             }
                             if (s == 1) bprev = tile_from_channels(sb + 32 * t, h);      // (behind its last use: tile t's, for the next block)
@@ -231,10 +258,13 @@ __global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restri
                     // the segment's open (in its last out-tile's block): k-tile k + 1's stage has been read (k-steps 0..3 of
                     // this segment) and takes k-tile k + 3
                     const auto opened = [&](int) {
-                        request(kk ^ 1, g, k + 3);
-                        if (!POOL && LAST && kk == 1 && bias && wave == 0)
-                            lds_dma16(reinterpret_cast<const char*>(bias_row(gn)), (uint32_t)(lane * 16),
-                                      reinterpret_cast<char*>(s_bias + 256 * (par ^ 1)));
+                        st.keep = 8;
+                        if (!TRX_EARLY_REQUEST) {
+                            request(kk ^ 1, g, k + 3);
+                            if (!POOL && LAST && kk == 1 && bias && wave == 0)
+                                lds_dma16(reinterpret_cast<const char*>(bias_row(gn)), (uint32_t)(lane * 16),
+                                          reinterpret_cast<char*>(s_bias + 256 * (par ^ 1)));
+                        }
                     };
                     if (FIRST && kk == 0)
                         x3_block<1, T, POOL, true, VS>(st, xs[kk], acc[t], side, opened);
@@ -275,7 +305,7 @@ __global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restri
                     o[1] += bprev[4 * q + 1];
                     o[2] += bprev[4 * q + 2];
                     o[3] += bprev[4 * q + 3];
-                    *reinterpret_cast<f32x4*>(zp + 8 * q) = o;
+                    TRX_STORE(zp + 8 * q, o);
                 }
             }
         }

@@ -85,13 +85,15 @@ __device__ __forceinline__ void x3_split_steps(const f32x16 (&a)[T], const f32x1
 #ifndef DAL3_X3_DEPTH
 #define DAL3_X3_DEPTH 1                 // fragment pairs in registers ahead of the one in use (A/B: 2)
 #endif
-template <bool DRAIN = false, int SLOTS = 3, int DEPTH = DAL3_X3_DEPTH>  // DRAIN: open() waits for all of the wave's VMEM traffic (LdsRing::acquire_wait_all)
+// DRAIN: open() waits for the wave's VMEM traffic except its KEEP youngest operations (LdsRing::acquire_wait_all / _keep)
+template <bool DRAIN = false, int SLOTS = 3, int DEPTH = DAL3_X3_DEPTH, int KEEP = 0>
 struct X3StreamT {
     typedef LdsRing<X3_SEG, SLOTS> Ring;
     static constexpr int START = 2 * DEPTH;                // the cursor at the start of a group of points
     x3v8 n2h, n2l;                                         // (DEPTH == 2: the pair after (nh, nl))
     Ring ring;
     int cur, pending;
+    int keep = KEEP;
     x3v8 nh, nl;
     __device__ __forceinline__ void pump1() {
         if (pending > 0) {
@@ -108,7 +110,18 @@ struct X3StreamT {
     }
     __device__ __forceinline__ void open() {
         flush();
-        if (DRAIN)
+        if (DRAIN && KEEP > 0) {
+            // `keep` (a constant after unrolling): how many VMEM operations the caller has issued behind the last thing
+            // this open must wait for — they stay in flight. Too small only waits longer; too large would be a race.
+            if (keep == KEEP)
+                ring.template acquire_wait_keep<KEEP>();
+            else if (keep == KEEP + 7)
+                ring.template acquire_wait_keep<KEEP + 7>();
+            else if (keep == KEEP + 28)
+                ring.template acquire_wait_keep<KEEP + 28>();
+            else
+                ring.acquire_wait_all();
+        } else if (DRAIN)
             ring.acquire_wait_all();
         else
             ring.acquire_wait();
@@ -137,7 +150,13 @@ struct X3StreamT {
     __device__ __forceinline__ void init(const void* stream, char* lds, int n_segs, int wave, int lane) {
         ring.init(stream, lds, n_segs, wave, lane, true);  // segments 0 and (three slots) 1 in flight
         pending = 0;
-        open();
+        if (DRAIN) {                                       // (nothing of the caller's is in flight yet: a full drain)
+            ring.acquire_wait_all();
+            pending = Ring::MY_LOADS;
+            cur = 0;
+        } else {
+            open();
+        }
         flush();
         fetch();
         if (DEPTH == 2) fetch();
