@@ -43,8 +43,11 @@ enum { DAL3_F32 = 0, DAL3_BF16 = 1, DAL3_F16 = 2,
         * fp32 accumulate — fp32 ACCURACY (logits ~1e-6 of their range, like DAL3_F32) from three fp16 MFMAs per fp32 one.
         * An arithmetic dtype of packed weights only (never a storage dtype of dal3_bcn / dal3_maxpool_n_dtype).
         * Range: folded weights and every layer's activations must stay below fp16's largest finite value (65504) in
-        * magnitude — beyond it a half overflows to infinity and the crop's outputs become NaN (DAL3_F32 has no such limit;
-        * DAL3_F16 shares it). Values below fp16's normal range lose nothing that fp32 accumulation would keep. */
+        * magnitude — beyond it a half saturates and the crop's outputs are WRONG WITHOUT NOTICE (DAL3_F32 has no such
+        * limit; DAL3_F16 turns NaN there). The margin is three orders of magnitude on this path: the first layer, which sees
+        * the raw coordinates, runs in fp32, and crops scaled 1,000 x (box-frame coordinates of kilometres) still match
+        * DAL3_F32 to 1e-6 (tests/test_gpu_x3.py). Values below fp16's normal range lose nothing that fp32 accumulation
+        * would keep. */
        DAL3_F16X3 = 3 };
 
 /* which sub-network a packed-weight blob belongs to */

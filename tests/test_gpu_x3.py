@@ -129,3 +129,19 @@ def test_dynamic_c3_shape_properties(x3):
 def test_c4_mixed_segment_sharded_over_8_equals_whole_job(x3):
     """the mixed segment (64 crops x 4096 points + ~4,400 track frames) cut into 8 rank shards == the one-rank job, bitwise"""
     FS.test_c4_mixed_segment_sharded_over_8_equals_whole_job()
+
+
+def test_f16x3_range_margin():
+    """the arithmetic's one limit is fp16's largest finite value for activations and folded weights (include/dal3.h): the first
+    layer sees the raw coordinates in fp32, so crops scaled a thousandfold — box-frame coordinates of kilometres — still agree
+    with the exact-fp32 path as closely as unscaled ones"""
+    p, init, _ = synth.static_crops(8, 1024, seed=9)
+    model = build_model("static_one", recentred_sd("static_one", p[:2], seed=9))
+    for scale in (1.0, 30.0, 1000.0):
+        pts = torch.from_numpy(p * np.float32(scale)).cuda().transpose(2, 1)
+        model.precision = "fp32"
+        a = model._run(pts, torch.from_numpy(init).cuda(), None)["logits"].clone()
+        model.precision = "f16x3"
+        b = model._run(pts, torch.from_numpy(init).cuda(), None)["logits"]
+        assert bool(torch.isfinite(b).all())
+        assert float((a - b).abs().max()) < 1e-5 * float(a.abs().max()), scale
