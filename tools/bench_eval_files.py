@@ -93,6 +93,9 @@ def main():
         _, dt = timed(lambda: ev.run(head, paths[head], paths["infos"], paths["det_annos"], ckpt, batch_size=args.batch,
                                      sampler="device", precision="bf16"))
         res["run[device,bf16]_s"] = round(dt, 3)
+        _, dt = timed(lambda: ev.run(head, paths[head], paths["infos"], paths["det_annos"], ckpt, batch_size=args.batch,
+                                     sampler="device", precision="f16x3"))
+        res["run[device,f16x3]_s"] = round(dt, 3)
         track = pickle.load(open(paths[head], "rb"))
         if head == "static":
             track = ev.preprocessing(track, ev.Annos(infos))
