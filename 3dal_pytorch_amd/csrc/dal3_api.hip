@@ -974,16 +974,17 @@ extern "C" int dal3_tr_linear_x3_layout(int64_t M, int c_in, int64_t seg, int c_
 
 extern "C" int dal3_tr_linear_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                                  int relu_in, const float* bias, int64_t seg, int c_out, float* z, int64_t ldz,
-                                 const void* packed, dal3_stream stream) {
+                                 const void* packed, const uint32_t* in_amax, dal3_stream stream) {
     if (!a || !z || !mult32(M) || !mult32(c_in) || !mult32(c_out) || lda < c_in || ldz < c_out || lda % 4 || ldz % 4 ||
-        (scale && !shift) || seg < 0 || !packed || (reinterpret_cast<uintptr_t>(packed) & 15) ||
+        (scale && !shift) || seg < 0 || !packed || (reinterpret_cast<uintptr_t>(packed) & 15) || (in_amax && scale) ||
+        (reinterpret_cast<uintptr_t>(in_amax) & 3) ||
         (reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(z) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
         return fail(DAL3_EINVAL, "tr_linear_x3: bad argument (16-byte aligned a / z / bias / packed, row strides multiples of 4)");
     const int layout = tr_linear_x3_layout(M, c_in, seg, c_out, 0, scale != nullptr);
     if (layout == 0) return fail(DAL3_EINVAL, "tr_linear_x3: this shape does not take the f16x3 kernel (dal3_tr_linear_x3_layout() == 0)");
     if (lda * 64 * (int64_t)sizeof(float) >= ((int64_t)1 << 31)) return fail(DAL3_EINVAL, "tr_linear_x3: lda too large");
     HIP_TRY(launch_tr_linear_x3(a, M, c_in, lda, scale, shift, relu_in, static_cast<const uint16_t*>(packed), layout, bias, seg, c_out,
-                                z, ldz, static_cast<hipStream_t>(stream)));
+                                z, ldz, static_cast<hipStream_t>(stream), in_amax));
     return 0;
 }
 
@@ -1148,6 +1149,20 @@ extern "C" int dal3_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz
         return fail(DAL3_EINVAL, "tr_bnbwd_apply: bad argument (C and the row strides must be multiples of 4)");
     HIP_TRY(launch_tr_bnbwd_apply(z, M, C, ldz, da, ldda, dg, arg, seg, scale, shift, mu, rstd, k1, k2, k3, dz, lddz,
                                   static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_bnbwd_apply_amax(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda,
+                                        const float* dg, const int32_t* arg, int64_t seg, const float* scale,
+                                        const float* shift, const float* mu, const float* rstd, const float* k1,
+                                        const float* k2, const float* k3, float* dz, int64_t lddz, uint32_t* amax,
+                                        dal3_stream stream) {
+    if (!z || M <= 0 || C <= 0 || C % 64 || !scale || !shift || !mu || !rstd || !k1 || !k2 || !k3 || !dz || ldz < C ||
+        lddz < C || ldz % 4 || lddz % 4 || (da && ldda % 4) || (!da && (!dg || !arg || seg <= 0)) || !amax ||
+        (reinterpret_cast<uintptr_t>(amax) & 3))
+        return fail(DAL3_EINVAL, "tr_bnbwd_apply_amax: bad argument (C a multiple of 64, the row strides of 4, amax 64 device words)");
+    HIP_TRY(launch_tr_bnbwd_apply(z, M, C, ldz, da, ldda, dg, arg, seg, scale, shift, mu, rstd, k1, k2, k3, dz, lddz,
+                                  static_cast<hipStream_t>(stream), amax));
     return 0;
 }
 

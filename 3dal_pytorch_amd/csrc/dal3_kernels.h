@@ -286,7 +286,7 @@ hipError_t launch_tr_pack_many(const dal3_tr_pack_item* items, int n, hipStream_
 int tr_linear_x3_layout(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act);
 hipError_t launch_tr_linear_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift, int relu_in,
                                const uint16_t* wpk, int layout, const float* bias, int64_t seg, int c_out, float* z, int64_t ldz,
-                               hipStream_t s);
+                               hipStream_t s, const uint32_t* in_amax = nullptr);
 size_t tr_colred_workspace_bytes(int64_t M, int C);
 hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                             const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
@@ -324,7 +324,7 @@ hipError_t launch_tr_bnbwd_coef(const double* sums, int C, int64_t M, const floa
 hipError_t launch_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda,
                                  const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                                  const float* mu, const float* rstd, const float* k1, const float* k2, const float* k3,
-                                 float* dz, int64_t lddz, hipStream_t s);
+                                 float* dz, int64_t lddz, hipStream_t s, uint32_t* amax = nullptr);
 size_t tr_bnbwd_apply_segsum_workspace_bytes(int64_t M, int C);
 hipError_t launch_tr_bnbwd_apply_segsum(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda,
                                         const float* scale, const float* shift, const float* mu, const float* rstd,

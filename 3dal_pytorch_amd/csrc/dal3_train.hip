@@ -1277,7 +1277,8 @@ __global__ __launch_bounds__(256) void tr_bnbwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ rstd, const float* __restrict__ k1,
                                                              const float* __restrict__ k2, const float* __restrict__ k3,
                                                              float* __restrict__ dz, int64_t lddz,
-                                                             double* __restrict__ seg_part = nullptr) {
+                                                             double* __restrict__ seg_part = nullptr,
+                                                             uint32_t* __restrict__ amax = nullptr) {
     // block: 16 groups of 4 channels x 16 rows; grid (C/64, M/128): a thread walks 8 rows, all their loads issued before
     // the first is used (rows past the end are clamped for the loads and skipped for the stores)
     constexpr int U = 8;
@@ -1290,6 +1291,7 @@ __global__ __launch_bounds__(256) void tr_bnbwd_apply_kernel(const float* __rest
     const int64_t p0 = (int64_t)blockIdx.y * (16 * U) + (threadIdx.x >> 4);
     f32x4 v[U], d[U];
     double ssum[4] = {0.0, 0.0, 0.0, 0.0};                 // (SEGSUM; the host asks for it only when C % 64 == 0: no early return)
+    uint32_t mx = 0;                                        // (amax: the bit pattern of the largest |dz| this thread wrote)
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int64_t p = min(p0 + 16 * i, M - 1);
@@ -1313,10 +1315,26 @@ __global__ __launch_bounds__(256) void tr_bnbwd_apply_kernel(const float* __rest
             o[e] = a1[e] * (dy - a2[e] - (v[i][e] - mean[e]) * rs[e] * a3[e]);
         }
         *reinterpret_cast<f32x4*>(dz + p * lddz + c) = o;
+        if (amax) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t b = __float_as_uint(o[e]) & 0x7fffffffu;
+                mx = b > mx ? b : mx;
+            }
+        }
         if (SEGSUM) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) ssum[e] += (double)o[e];
         }
+    }
+    if (amax) {                                             // (C % 64 == 0: whole waves; one atomic per wave)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)mx, off);
+            mx = other > mx ? other : mx;
+        }
+        // 64 words, a wave's by its index: 32,768 waves on ONE word are ~370 us of serialised atomics (88 per us), on 64 a few
+        if ((threadIdx.x & 63) == 0) atomicMax(amax + ((blockIdx.y * 4u + (threadIdx.x >> 6)) & 63u), mx);
     }
     if (SEGSUM) {
         __shared__ double sm[16][64];
@@ -1350,15 +1368,15 @@ __global__ __launch_bounds__(256) void tr_blocksum_final_kernel(const double* __
 hipError_t launch_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda,
                                  const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                                  const float* mu, const float* rstd, const float* k1, const float* k2, const float* k3,
-                                 float* dz, int64_t lddz, hipStream_t s) {
+                                 float* dz, int64_t lddz, hipStream_t s, uint32_t* amax) {
     DaSrc src{da, ldda, dg, arg, seg};
     const dim3 grid((C + 63) / 64, (unsigned)((M + 127) / 128));
     if (da)
         hipLaunchKernelGGL((tr_bnbwd_apply_kernel<true>), grid, dim3(256), 0, s, z, M, C, ldz, src, scale, shift, mu, rstd, k1,
-                           k2, k3, dz, lddz);
+                           k2, k3, dz, lddz, nullptr, amax);
     else
         hipLaunchKernelGGL((tr_bnbwd_apply_kernel<false>), grid, dim3(256), 0, s, z, M, C, ldz, src, scale, shift, mu, rstd, k1,
-                           k2, k3, dz, lddz);
+                           k2, k3, dz, lddz, nullptr, amax);
     return hipGetLastError();
 }
 

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restri
                                                            const float* __restrict__ bias, int64_t seg, int c_out,
                                                            float* __restrict__ z, int64_t ldz, int n_mblk, int n_groups,
                                                            const float* __restrict__ out_scale, const float* __restrict__ out_shift,
-                                                           unsigned long long* __restrict__ packed) {
+                                                           unsigned long long* __restrict__ packed,
+                                                           const uint32_t* __restrict__ in_amax) {
     constexpr int T = TRX_T, MTB = 8;
     constexpr int PER = 2, VS = x3_vpg(PER, T) + 1;         // a k-tile's 8 T split units done within its first 8 k-steps
     static_assert(T == 2, "one point tile per k-step of a block in the epilogue; stage layout");
@@ -91,6 +92,23 @@ __global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restri
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, m = lane & 31;
     const float floor_v = relu_in ? 0.0f : -3.0e38f;
+    // an operand below fp16's range (a dgrad's dz; ACT instantiation, scale == NULL): in_amax holds the bits of its largest
+    // |value|; the operand is multiplied by the power of two that brings that value to [2^14, 2^15) — inside fp16's range
+    // with the full 22 bits of the split for everything down to 2^-28 of it — and the result by the inverse. Both exact.
+    float s_in = 1.0f, s_out = 1.0f;
+    if (in_amax) {
+        uint32_t mxb = in_amax[lane];                           // 64 words (dal3_tr_bnbwd_apply_amax spreads its atomics): their maximum
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)mxb, off);
+            mxb = other > mxb ? other : mxb;
+        }
+        const int ex = (int)((__builtin_amdgcn_readfirstlane((int)mxb) >> 23) & 0xff);           // biased exponent of the max
+        int sh_e = ex == 0 ? 0 : 14 - (ex - 127);
+        sh_e = sh_e < -100 ? -100 : (sh_e > 100 ? 100 : sh_e);
+        s_in = __int_as_float((127 + sh_e) << 23);
+        s_out = __int_as_float((127 - sh_e) << 23);
+    }
     const int mblk = (int)(blockIdx.x % (unsigned)n_mblk);
     const int g0 = (int)(blockIdx.x / (unsigned)n_mblk), gstride = (int)(gridDim.x / (unsigned)n_mblk);
     if (g0 >= n_groups) return;
@@ -100,8 +118,8 @@ __global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restri
     };
     if (ACT) {
         for (int i = threadIdx.x; i < c_in; i += 256) {
-            s_sc[i] = scale[i];
-            s_sh[i] = shift[i];
+            s_sc[i] = scale ? scale[i] : s_in;
+            s_sh[i] = scale ? shift[i] : 0.0f;
         }
     }
     if (POOL) {                                                 // per-channel constants of this output block
@@ -245,10 +263,10 @@ __global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restri
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     f32x4 o = {acc[t - 1][j][4 * q], acc[t - 1][j][4 * q + 1], acc[t - 1][j][4 * q + 2], acc[t - 1][j][4 * q + 3]};
-                                    o[0] += bprev[4 * q];
-                                    o[1] += bprev[4 * q + 1];
-                                    o[2] += bprev[4 * q + 2];
-                                    o[3] += bprev[4 * q + 3];
+                                    o[0] = __builtin_fmaf(o[0], s_out, bprev[4 * q]);
+                                    o[1] = __builtin_fmaf(o[1], s_out, bprev[4 * q + 1]);
+                                    o[2] = __builtin_fmaf(o[2], s_out, bprev[4 * q + 2]);
+                                    o[3] = __builtin_fmaf(o[3], s_out, bprev[4 * q + 3]);
                                     TRX_STORE(zp + 8 * q, o);
                                 }
                             }
@@ -301,10 +319,10 @@ __global__ __launch_bounds__(256) void tr_linear_x3_kernel(const float* __restri
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 o = {acc[t][j][4 * q], acc[t][j][4 * q + 1], acc[t][j][4 * q + 2], acc[t][j][4 * q + 3]};
-                    o[0] += bprev[4 * q];
-                    o[1] += bprev[4 * q + 1];
-                    o[2] += bprev[4 * q + 2];
-                    o[3] += bprev[4 * q + 3];
+                    o[0] = __builtin_fmaf(o[0], s_out, bprev[4 * q]);
+                    o[1] = __builtin_fmaf(o[1], s_out, bprev[4 * q + 1]);
+                    o[2] = __builtin_fmaf(o[2], s_out, bprev[4 * q + 2]);
+                    o[3] = __builtin_fmaf(o[3], s_out, bprev[4 * q + 3]);
                     TRX_STORE(zp + 8 * q, o);
                 }
             }
@@ -334,7 +352,8 @@ int tr_linear_x3_layout(int64_t M, int c_in, int64_t seg, int c_out, int accumul
 
 static hipError_t trx_launch(bool pool, const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                              int relu_in, const uint16_t* wpk, const float* bias, int64_t seg, int c_out, float* z, int64_t ldz,
-                             const float* out_scale, const float* out_shift, unsigned long long* packed, hipStream_t s) {
+                             const float* out_scale, const float* out_shift, unsigned long long* packed, hipStream_t s,
+                             const uint32_t* in_amax = nullptr) {
     const int n_mblk = c_out / 256;
     const int n_groups = (int)(M / 256);
     int per = trx_cu_count() / n_mblk;                               // workgroups per output block: one workgroup per CU in all
@@ -346,18 +365,19 @@ static hipError_t trx_launch(bool pool, const float* a, int64_t M, int c_in, int
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, lda, c_in, scale, shift, relu_in, wpk, bias, seg, c_out, z, ldz,
-                           n_mblk, n_groups, out_scale, out_shift, packed);
+                           n_mblk, n_groups, out_scale, out_shift, packed, in_amax);
         return hipGetLastError();
     };
     if (pool) return scale ? go(tr_linear_x3_kernel<true, true>) : go(tr_linear_x3_kernel<false, true>);
-    return scale ? go(tr_linear_x3_kernel<true, false>) : go(tr_linear_x3_kernel<false, false>);
+    return (scale || in_amax) ? go(tr_linear_x3_kernel<true, false>) : go(tr_linear_x3_kernel<false, false>);
 }
 
 hipError_t launch_tr_linear_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift, int relu_in,
                                const uint16_t* wpk, int layout, const float* bias, int64_t seg, int c_out, float* z, int64_t ldz,
-                               hipStream_t s) {
+                               hipStream_t s, const uint32_t* in_amax) {
     if ((layout & 0xff) != 8) return hipErrorInvalidValue;
-    return trx_launch(false, a, M, c_in, lda, scale, shift, relu_in, wpk, bias, seg, c_out, z, ldz, nullptr, nullptr, nullptr, s);
+    return trx_launch(false, a, M, c_in, lda, scale, shift, in_amax ? 0 : relu_in, wpk, bias, seg, c_out, z, ldz, nullptr, nullptr,
+                      nullptr, s, in_amax);
 }
 
 // the pooled layer (launch_tr_linear_pool of dal3_train.hip on the f16x3 engine); ok: tr_linear_pool_x3_ok()

@@ -90,7 +90,8 @@ def _take_saved(ctx):
     return saved
 
 
-def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False, out=None, accumulate=False, packed=None):
+def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False, out=None, accumulate=False, packed=None,
+            amax=None):
     """z (M,c_out) (+)= act(a) @ Wop^T + bias through dal3_tr_linear. packed: this call's weights already in fragment
     order (_prepack: one launch for all the layers of a stack instead of one in front of every call)"""
     M = a.shape[0]
@@ -98,8 +99,11 @@ def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False,
     sc, sh, relu = (act if act is not None else (None, None, False))
     lib = _hip.lib()
     if isinstance(packed, _X3Image):
+        # amax: 64 device words whose maximum is the bit pattern of the operand's largest |value| (a dgrad's dz, far below fp16's range: the
+        # kernel scales by a power of two around the products); a transposed image is only ever packed for such a caller
+        assert amax is not None or not transpose
         _hip.check(lib.dal3_tr_linear_x3(_hip.ptr(a), M, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu), _hip.ptr(bias), seg,
-                                         c_out, _hip.ptr(z), z.stride(0), _hip.ptr(packed.tensor), _hip.stream()))
+                                         c_out, _hip.ptr(z), z.stride(0), _hip.ptr(packed.tensor), _hip.ptr(amax), _hip.stream()))
         return z
     if packed is not None:
         _hip.check(lib.dal3_tr_linear_prepacked(_hip.ptr(a), M, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu),
@@ -124,10 +128,11 @@ def _prepack(specs, dev):
     them (c_in / c_out swapped for a transposed weight). Returns one packed tensor per spec, None where the call reads
     no packed image. The weights must not change between this and the calls (a step's forward and backward: they do not)."""
     lib = _hip.lib()
-    lay = [lib.dal3_tr_linear_pack_layout(M, ci, seg, co, int(acc), int(has_act)) for _, ci, co, _, M, seg, acc, has_act in specs]
-    if ARITH == "f16x3":                                    # forward calls that qualify take the f16x3 image instead
-        lay = [(lib.dal3_tr_linear_x3_layout(M, ci, seg, co, int(acc), int(has_act)) if not tr else 0) or l
-               for l, (_, ci, co, tr, M, seg, acc, has_act) in zip(lay, specs)]
+    specs = [sp if len(sp) == 9 else (*sp, False) for sp in specs]      # 9th element: a dgrad whose caller supplies the operand's amax
+    lay = [lib.dal3_tr_linear_pack_layout(M, ci, seg, co, int(acc), int(has_act)) for _, ci, co, _, M, seg, acc, has_act, _d in specs]
+    if ARITH == "f16x3":                                    # forward calls (and marked dgrads) that qualify take the f16x3 image instead
+        lay = [(lib.dal3_tr_linear_x3_layout(M, ci, seg, co, int(acc), int(has_act)) if (not tr or dg) else 0) or l
+               for l, (_, ci, co, tr, M, seg, acc, has_act, dg) in zip(lay, specs)]
     size = [int(lib.dal3_tr_linear_workspace_bytes(ci, co)) if l else 0 for l, (_, ci, co, *_r) in zip(lay, specs)]
     size = [(n + 255) // 256 * 256 for n in size]
     buf = torch.empty(max(sum(size), 16), dtype=torch.uint8, device=dev)
@@ -218,7 +223,7 @@ class _BN:
     def act(self):
         return (self.scale, self.shift, True)
 
-    def backward(self, z, da=None, dg=None, arg=None, seg=0, sum_seg=0):
+    def backward(self, z, da=None, dg=None, arg=None, seg=0, sum_seg=0, amax=None):
         """(dz, dgamma, dbeta) from the gradient w.r.t. relu(bn(z)); with sum_seg also the column sums of dz over every
         segment of sum_seg rows, (M / sum_seg, C), taken in the same pass (dal3_tr_bnbwd_apply_segsum)"""
         C = z.shape[1]
@@ -245,10 +250,16 @@ class _BN:
                                                           _hip.ptr(dz), dz.stride(0), sum_seg, _hip.ptr(sums), _hip.ptr(ws2),
                                                           need2, _hip.stream()))
                 return dz, co[0], co[1], sums
-        _hip.check(lib.dal3_tr_bnbwd_apply(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(da), da.stride(0) if da is not None else 0,
-                                           _hip.ptr(dg), _hip.ptr(arg), seg, _hip.ptr(self.scale), _hip.ptr(self.shift),
-                                           _hip.ptr(self.mu), _hip.ptr(self.rstd), _hip.ptr(co[2]), _hip.ptr(co[3]),
-                                           _hip.ptr(co[4]), _hip.ptr(dz), dz.stride(0), _hip.stream()))
+        if amax is not None:                            # (64 zeroed int32 words: the bits of max |dz| are atomicMax'ed into them)
+            _hip.check(lib.dal3_tr_bnbwd_apply_amax(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(da), da.stride(0) if da is not None else 0,
+                                                    _hip.ptr(dg), _hip.ptr(arg), seg, _hip.ptr(self.scale), _hip.ptr(self.shift),
+                                                    _hip.ptr(self.mu), _hip.ptr(self.rstd), _hip.ptr(co[2]), _hip.ptr(co[3]),
+                                                    _hip.ptr(co[4]), _hip.ptr(dz), dz.stride(0), _hip.ptr(amax), _hip.stream()))
+        else:
+            _hip.check(lib.dal3_tr_bnbwd_apply(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(da), da.stride(0) if da is not None else 0,
+                                               _hip.ptr(dg), _hip.ptr(arg), seg, _hip.ptr(self.scale), _hip.ptr(self.shift),
+                                               _hip.ptr(self.mu), _hip.ptr(self.rstd), _hip.ptr(co[2]), _hip.ptr(co[3]),
+                                               _hip.ptr(co[4]), _hip.ptr(dz), dz.stride(0), _hip.stream()))
         if z.shape[0] > M:
             dz[M:].zero_()                                                  # (wgrad sums over every row it is given)
         if sum_seg:                                                         # (ragged sizes: the caller takes the separate pass)
@@ -551,10 +562,13 @@ class _InsSeg(torch.autograd.Function):
         W5 = torch.zeros((32, 128), dtype=torch.float32, device=pts.device)
         W5[:2] = P[36].reshape(2, 128)                                  # dconv5, rows padded to a tile
         fw = lambda k: (W2s[k], W2s[k].shape[1], W2s[k].shape[0], False, Mp, 0, False, k > 0)      # noqa: E731
-        tr = lambda k, acc=False: (W2s[k], W2s[k].shape[0], W2s[k].shape[1], True, Mp, 0, acc, False)   # noqa: E731
+        # (dg: the decoder's dgrads get their operand's amax from the BatchNorm backward in front of them, so they may take
+        # the f16x3 image when the arithmetic says so and the shape qualifies — dconv3's and dconv2's do)
+        tr = lambda k, acc=False, dg=False: (W2s[k], W2s[k].shape[0], W2s[k].shape[1], True, Mp, 0, acc, False, dg)   # noqa: E731
         order = ["f0", "f1", "f2", "f3", "fd1", "f6", "f7", "f8", "fd5", "td5", "t8", "t7", "t6", "td1", "t3", "t2", "t1"]
         specs = [fw(0), fw(1), fw(2), fw(3), (Wd1, 64, 512, False, Mp, N, False, True), fw(6), fw(7), fw(8),
-                 (W5, 128, 32, False, Mp, 0, False, False), (W5, 32, 128, True, Mp, 0, False, False), tr(8), tr(7), tr(6),
+                 (W5, 128, 32, False, Mp, 0, False, False), (W5, 32, 128, True, Mp, 0, False, False), tr(8, dg=True), tr(7, dg=True),
+                 tr(6, dg=True),
                  (Wd1, 512, 64, True, Mp, 0, False, False), tr(3), tr(2, True), tr(1)]
         pk = dict(zip(order, _prepack(specs, pts.device)))
         a, act = a0, None
@@ -633,12 +647,15 @@ class _InsSeg(torch.autograd.Function):
         da = _linear(dzl, W5, 128, 32, 128, transpose=True, packed=pk["td5"])
         if drop is not None:
             da = _act_dropout(da, None, drop)                           # the same multiplier, re-created from its key
+        amaxes = torch.zeros(3 * 64, dtype=torch.int32, device=dlogits.device)
         for k in (8, 7, 6):                                             # dconv4..2
-            dz, dgam, dbet = bns[k].backward(zs[k], da=da)
+            x3 = isinstance(pk[f"t{k}"], _X3Image)                      # (f16x3 dgrad: dz's largest |value| comes with it)
+            amax = amaxes[64 * (8 - k):64 * (9 - k)] if x3 and zs[k].shape[1] % 64 == 0 else None
+            dz, dgam, dbet = bns[k].backward(zs[k], da=da, amax=amax)
             grads[4 * k] = _wgrad(dz, zs[k - 1], Ws[k].shape[0], Ws[k].shape[1], bns[k - 1].act).reshape(shapes[4 * k])
             grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
-            da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, packed=pk[f"t{k}"])
+            da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, packed=pk[f"t{k}"], amax=amax)
         # dconv1: per-point part against out2, per-crop part against g
         dz, dgam, dbet, dgb = bns[5].backward(zs[5], da=da, sum_seg=N)   # dgb (B,512): dz summed over each crop's points
         Wd1 = Ws[5]

@@ -354,7 +354,17 @@ int dal3_tr_linear_prepacked(const float* a, int64_t M, int c_in, int64_t lda, c
 int dal3_tr_linear_x3_layout(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act);
 int dal3_tr_linear_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift, int relu_in,
                       const float* bias, int64_t seg, int c_out, float* z, int64_t ldz, const void* packed,
-                      dal3_stream stream);
+                      const uint32_t* in_amax, dal3_stream stream);
+/* ... and for an operand far below fp16's range (a dgrad's dz): in_amax (64 device words; scale must be NULL then) hold, as
+ * their maximum, the bit pattern of the operand's largest |value| — what dal3_tr_bnbwd_apply_amax leaves there,
+ * atomicMax'ed into 64 words the caller zeroed (64, not one: the atomics of 32,768 waves on one word take longer than
+ * the layer) — and the kernel multiplies the operand by the power of two that brings that value to 2^14 and the result
+ * by its inverse (both exact). Entries down to 2^-17 of the largest keep the split's 22 bits, down to 2^-28 at least 11;
+ * the error stays below 1e-6 of the RESULT's range throughout. */
+int dal3_tr_bnbwd_apply_amax(const float* z, int64_t M, int C, int64_t ldz, const float* da, int64_t ldda, const float* dg,
+                             const int32_t* arg, int64_t seg, const float* scale, const float* shift, const float* mu,
+                             const float* rstd, const float* k1, const float* k2, const float* k3, float* dz, int64_t lddz,
+                             uint32_t* amax, dal3_stream stream);
 /* dal3_tr_linear_pool on the same arithmetic (same arguments and workspace); _ok: 1 when the shape qualifies
  * (M % 256, c_in % 64, c_out % 256, seg % 256 == 0, M >= 4096). g / arg agree with dal3_tr_linear_pool's to the fp32 kernels'
  * accuracy (not bit for bit: the products are formed differently). */

@@ -29,7 +29,7 @@ def _x3_linear(a, W, act, bias, seg):
     z = torch.empty((M, co), device="cuda")
     sc, sh, relu = act if act is not None else (None, None, False)
     hip.check(lib.dal3_tr_linear_x3(hip.ptr(a), M, ci, a.stride(0), hip.ptr(sc), hip.ptr(sh), int(relu), hip.ptr(bias), seg, co,
-                                    hip.ptr(z), z.stride(0), hip.ptr(pk), hip.stream()))
+                                    hip.ptr(z), z.stride(0), hip.ptr(pk), None, hip.stream()))
     return z
 
 
@@ -82,7 +82,7 @@ def test_linear_x3_layout_rules():
     a = torch.zeros((512, 64), device="cuda")
     z = torch.empty((512, 256), device="cuda")
     pk = torch.empty(lib.dal3_tr_linear_workspace_bytes(64, 256), dtype=torch.uint8, device="cuda")
-    rc = lib.dal3_tr_linear_x3(hip.ptr(a), 512, 64, 64, None, None, 0, None, 0, 256, hip.ptr(z), 256, hip.ptr(pk), hip.stream())
+    rc = lib.dal3_tr_linear_x3(hip.ptr(a), 512, 64, 64, None, None, 0, None, 0, 256, hip.ptr(z), 256, hip.ptr(pk), None, hip.stream())
     assert rc == hip.EINVAL if hasattr(hip, "EINVAL") else rc != 0
 
 
@@ -177,3 +177,49 @@ def test_x3_training_kernels_are_reproducible_bit_for_bit():
         for _ in range(40):
             g1, a1 = train._linear_pool(a, (sc, sh, True), W, b, BN, seg)
             assert torch.equal(g1, g0) and torch.equal(a1, a0)
+
+
+@pytest.mark.parametrize("M,K,co,mag", [(8192, 256, 512, 3e-6), (8192, 128, 256, 1e-9), (4096, 256, 256, 40.0)])
+def test_dgrad_x3_with_the_operands_amax(M, K, co, mag):
+    """a dgrad's operand (dz) lies far below fp16's range: dal3_tr_bnbwd_apply_amax leaves the bits of its largest |value| in
+    64 device words, dal3_tr_linear_x3 scales by a power of two around the products. Here the word is filled the same way
+    (atomicMax of the bit patterns == the maximum, for non-negative floats) and the result held to the fp32 kernel's
+    accuracy, for magnitudes from 1e-9 to 40 and a log-uniform spread of eight decades inside the tensor."""
+    lib = hip.lib()
+    g = torch.Generator(device="cuda").manual_seed(K + co)
+    spread = torch.exp(torch.rand((M, 1), device="cuda", generator=g) * -18.0)       # per-point scale, 1 .. 1.5e-8
+    dz = torch.randn((M, K), device="cuda", generator=g) * spread * mag
+    W = torch.randn((K, co), device="cuda", generator=g) / K ** 0.5                 # the layer's (c_out = K, c_in = co) weight
+    ref = dz.double() @ W.double()
+    z32 = train._linear(dz, W, W.stride(0), K, co, transpose=True)
+    lay = lib.dal3_tr_linear_x3_layout(M, K, 0, co, 0, 0)
+    assert lay == 0x108
+    pk = torch.empty(lib.dal3_tr_linear_workspace_bytes(K, co), dtype=torch.uint8, device="cuda")
+    item = (hip.PackItem * 1)(hip.PackItem(hip.ptr(W), W.stride(0), 1, co, K, lay, hip.ptr(pk)))
+    hip.check(lib.dal3_tr_pack_many(item, 1, hip.stream()))
+    amax = torch.zeros(64, dtype=torch.int32, device="cuda")
+    amax[17] = dz.abs().max().reshape(1).view(torch.int32)[0]
+    zx = train._linear(dz, W, W.stride(0), K, co, transpose=True, packed=train._X3Image(pk), amax=amax)
+    rng = float(ref.abs().max())
+    ex, e32 = float((zx.double() - ref).abs().max()) / rng, float((z32.double() - ref).abs().max()) / rng
+    assert ex < 2e-6 and ex < 2 * e32 + 2e-7, (ex, e32)
+    # rows two to four decades below the tensor's maximum keep their RELATIVE accuracy too (the split holds 22 bits down to
+    # 2^-17 of the maximum, 11 bits down to 2^-28: include/dal3.h); further down only the absolute bound above holds
+    small = (spread[:, 0] < 1e-2) & (spread[:, 0] > 1e-4)
+    rel = ((zx.double() - ref)[small].abs().max(1)[0] / ref[small].abs().max(1)[0]).max()
+    assert float(rel) < 1e-5, float(rel)
+
+
+def test_bnbwd_apply_amax_is_the_maximum():
+    """the word dal3_tr_bnbwd_apply_amax fills == the bit pattern of max |dz| of the dz it writes (and dz is what
+    dal3_tr_bnbwd_apply writes)"""
+    M, C = 8192, 256
+    g = torch.Generator(device="cuda").manual_seed(5)
+    z = torch.randn((M, C), device="cuda", generator=g)
+    bn = train._BN(z, torch.rand(C, device="cuda", generator=g) + 0.5, torch.randn(C, device="cuda", generator=g), None, None, rows=M)
+    da = torch.randn((M, C), device="cuda", generator=g) * 1e-6
+    dz0 = bn.backward(z, da=da)[0]
+    words = torch.zeros(64, dtype=torch.int32, device="cuda")
+    dz1 = bn.backward(z, da=da, amax=words)[0]
+    assert torch.equal(dz0, dz1)
+    assert int(words.max()) == int(dz1.abs().max().view(torch.int32)) and int((words > 0).sum()) == 64

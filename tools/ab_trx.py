@@ -27,6 +27,6 @@ for ci, co in ((512, 256), (128, 1024), (64, 512)):
         item = (hip.PackItem * 1)(hip.PackItem(hip.ptr(W), W.stride(0), 0, co, ci, 0x108, hip.ptr(pk)))
         assert lib.dal3_tr_pack_many(item, 1, hip.stream()) == 0
         def run(lib=lib, pk=pk):
-            assert lib.dal3_tr_linear_x3(hip.ptr(a), M, ci, a.stride(0), hip.ptr(sc), hip.ptr(sh), 1, hip.ptr(bias), 0, co, hip.ptr(z), z.stride(0), hip.ptr(pk), hip.stream()) == 0
+            assert lib.dal3_tr_linear_x3(hip.ptr(a), M, ci, a.stride(0), hip.ptr(sc), hip.ptr(sh), 1, hip.ptr(bias), 0, co, hip.ptr(z), z.stride(0), hip.ptr(pk), None, hip.stream()) == 0
         out.append(f"{os.path.basename(name)} {ms(run):.3f}")
     print(ci, co, " | ".join(out), flush=True)

@@ -49,7 +49,7 @@ def case(M, ci, co, act, seg=0):
 
     def run_x3():
         hip.check(lib.dal3_tr_linear_x3(hip.ptr(a), M, ci, a.stride(0), hip.ptr(sc), hip.ptr(sh), 1, hip.ptr(bias), seg, co,
-                                        hip.ptr(zx), zx.stride(0), hip.ptr(pk), hip.stream()))
+                                        hip.ptr(zx), zx.stride(0), hip.ptr(pk), None, hip.stream()))
 
     def run_32():
         train._linear(a, W, ci, ci, co, act=(sc, sh, True) if act else None, bias=bias, seg=seg, out=z32)
