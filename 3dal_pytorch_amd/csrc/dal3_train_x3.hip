@@ -1,8 +1,10 @@
-// dal3_train_x3.hip — the training FORWARD's big layers on the "f16x3" engine (dal3_x3.h): z = act(a) W^T + b with every
+// dal3_train_x3.hip — the training step's big linear layers on the "f16x3" engine (dal3_x3.h): z = act(a) W^T + b with every
 // product formed as w_hi x_hi + w_hi x_lo + w_lo x_hi on the fp16 MFMA, fp32 accumulate — the accuracy of the fp32-MFMA
-// kernels of dal3_train.hip (1e-6 of the output's range) at a third of their MFMA time. Forward only: its operands
-// (post-BatchNorm activations, weights) are O(1), inside fp16's exponent range; the backward's dz operands are 1e-6 and
-// would need a per-tensor scale first, so dgrad / wgrad stay on the fp32 MFMA.
+// kernels of dal3_train.hip (1e-6 of the output's range) at a third of their MFMA time. The forward's operands
+// (post-BatchNorm activations, weights) are O(1), inside fp16's exponent range. A dgrad's operand, dz, is 1e-6 and smaller:
+// its producer (tr_bnbwd_apply_kernel) leaves the bit pattern of its largest |value| in device words, and the kernel
+// multiplies the operand by the power of two that brings that value to 2^14 and the result by the inverse (in_amax).
+// wgrad (both operands transposed with respect to memory) stays on the fp32 MFMA.
 //
 // Unlike the eval kernels the activations come from HBM, not from the previous layer's accumulators: a wave owns T = 2
 // tiles of 32 points and MTB output tiles; per 32-channel k-tile it loads its 2 x 32 x 32 fp32 inputs (16 B per lane and
