@@ -124,6 +124,8 @@ SIGNATURES = {
     "dal3_tr_bnbwd_apply_segsum": (_i, [vp, _i64, _i, _i64, vp, _i64, vp, vp, vp, vp, vp, vp, vp, vp, _i64, _i64, vp, vp, _sz, vp]),
     "dal3_tr_wgrad_workspace_bytes": (_sz, [_i64, _i, _i]),
     "dal3_tr_wgrad": (_i, [vp, _i64, vp, _i64, vp, vp, _i, _i64, _i, _i, vp, _sz, vp, vp]),
+    "dal3_tr_wgrad_x3_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "dal3_tr_wgrad_x3": (_i, [vp, _i64, vp, _i64, vp, vp, _i, vp, _i64, _i, _i, vp, _sz, vp, vp]),
     "dal3_tr_segmax": (_i, [vp, _i64, _i64, _i, vp, vp, vp, vp, _i64, vp, _sz, vp]),
     "dal3_tr_act_dropout": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _u64, vp, C.c_float, vp, _i64, vp]),
     "dal3_tr_linear_pool_workspace_bytes": (_sz, [_i, _i, _i64]),

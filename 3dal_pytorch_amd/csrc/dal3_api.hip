@@ -1201,6 +1201,27 @@ extern "C" int dal3_tr_wgrad(const float* dz, int64_t lddz, const float* a, int6
     return 0;
 }
 
+extern "C" size_t dal3_tr_wgrad_x3_workspace_bytes(int64_t M, int c_out, int c_in) {
+    return (M > 0 && c_out > 0 && c_in > 0 && tr_wgrad_x3_ok(M, c_out, c_in)) ? tr_wgrad_x3_workspace_bytes(M, c_out, c_in) : 0;
+}
+
+extern "C" int dal3_tr_wgrad_x3(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale,
+                                const float* shift, int relu_in, const uint32_t* dz_amax, int64_t M, int c_out, int c_in,
+                                void* workspace, size_t workspace_bytes, float* dW, dal3_stream stream) {
+    if (!dz || !a || !dW || !mult32(M) || !mult32(c_out) || !mult32(c_in) || lddz < c_out || lda < c_in || (scale && !shift) ||
+        (lddz & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(dz) & 15) || (reinterpret_cast<uintptr_t>(a) & 15) ||
+        (scale && ((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15)) ||
+        (reinterpret_cast<uintptr_t>(dz_amax) & 3))
+        return fail(DAL3_EINVAL, "tr_wgrad_x3: bad argument (M, c_in, c_out multiples of 32; 16-byte aligned operands, strides multiples of 4)");
+    if (!tr_wgrad_x3_ok(M, c_out, c_in))
+        return fail(DAL3_EINVAL, "tr_wgrad_x3: this shape does not take the f16x3 kernel (dal3_tr_wgrad_x3_workspace_bytes() == 0)");
+    if (!workspace || workspace_bytes < tr_wgrad_x3_workspace_bytes(M, c_out, c_in))
+        return fail(DAL3_EWORKSPACE, "tr_wgrad_x3: workspace smaller than dal3_tr_wgrad_x3_workspace_bytes()");
+    HIP_TRY(launch_tr_wgrad_x3(dz, lddz, a, lda, scale, shift, relu_in, dz_amax, M, c_out, c_in, static_cast<float*>(workspace), dW,
+                               static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float* scale, const float* shift,
                               float* g, int32_t* arg, int64_t n_seg, void* workspace, size_t workspace_bytes,
                               dal3_stream stream) {

@@ -338,6 +338,12 @@ hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t ld
                                  int relu_in, const float* W, int64_t ldw, const float* bias, const float* out_scale,
                                  const float* out_shift, int64_t seg, int c_out, float* g, int32_t* arg, float* ws,
                                  unsigned long long* packed, hipStream_t s);
+// wgrad on the f16x3 engine (dal3_train_x3.hip): ok -> the layer's shape qualifies; the workspace holds its slices' partial sums
+bool tr_wgrad_x3_ok(int64_t M, int c_out, int c_in);
+size_t tr_wgrad_x3_workspace_bytes(int64_t M, int c_out, int c_in);
+hipError_t launch_tr_wgrad_x3(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale, const float* shift,
+                              int relu_in, const uint32_t* dz_amax, int64_t M, int c_out, int c_in, float* part, float* dW,
+                              hipStream_t s);
 hipError_t launch_tr_segmax_unpack(const unsigned long long* packed, int64_t total, float* g, int32_t* arg, hipStream_t s);
 bool tr_linear_pool_x3_ok(int64_t M, int c_in, int64_t seg, int c_out);
 hipError_t launch_tr_linear_pool_x3(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,

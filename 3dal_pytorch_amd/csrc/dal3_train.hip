@@ -1603,6 +1603,11 @@ size_t tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in) {
     return (size_t)((M + pts - 1) / pts) * c_out * c_in * sizeof(float);
 }
 
+hipError_t launch_tr_wgrad_final(const float* part, int n_slices, int64_t n, float* dW, hipStream_t s) {
+    hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, n_slices, n, dW);
+    return hipGetLastError();
+}
+
 hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale,
                            const float* shift, int relu_in, int64_t M, int c_out, int c_in, float* part, float* dW,
                            hipStream_t s) {

@@ -401,3 +401,276 @@ hipError_t launch_tr_linear_pool_x3(const float* a, int64_t M, int c_in, int64_t
     if (e != hipSuccess) return e;
     return launch_tr_segmax_unpack(packed, n_seg * c_out, g, arg, s);
 }
+
+// ================================================================================================ wgrad
+// dW[co][ci] = sum over the points p of dz[p][co] * act(a[p][ci]) on the same arithmetic. Both operands are "transposed" with
+// respect to memory (a lane of an MFMA operand holds 8 consecutive POINTS of one channel; memory holds a point's channels
+// together), so a block of 16 points is staged through LDS: loaded row-wise (16 B per lane, coalesced), scaled (dz: the
+// power of two from its amax words, as the dgrad) or sent through the producing layer's activation (a), split into
+// (hi, lo) fp16 and written as [point][channel] images — 128-channel panels of 256-byte rows, 16-byte chunks
+// XOR-swizzled by the row (cdna guide T10 (b): conflict-free for the transposed reads) — and read back with gfx950's
+// ds_read_b64_tr_b16, which hands every lane 4 points of its channel. No LDS-DMA here: every load is the compiler's, its
+// wait counts are exact. A workgroup of 4 waves (WM x WN) owns a (WM MT 32) x (WN KT 32) block of dW and a slice of the
+// points; three register sets of raw blocks (a block is loaded two iterations before it is converted), two LDS stages,
+// one barrier per 16 points. The slices' partial sums go to part[slice][co][ci] and are added in slice order by
+// tr_wgrad_final_kernel (dal3_train.hip).
+typedef __fp16 trx_fh4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef int int2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int wgx_off(int row, int chan) {
+    const int c = chan & 127, ch = c >> 3;                  // ch: 16-byte chunk of the panel's 256-byte row
+    return (chan >> 7) * 4096 + 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 2 * (c & 7);
+}
+__host__ __device__ constexpr int wgx_image_bytes(int c_blk) { return (c_blk + 127) / 128 * 4096; }
+
+// four consecutive channels of one point -> 8 bytes of the hi image and 8 of the lo image
+__device__ __forceinline__ void wgx_put(const f32x4& v, char* hi_img, char* lo_img, int off) {
+    int2_t hi, lo;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const f32x2 p = {v[2 * u], v[2 * u + 1]};
+        const f16x2_t hh = __builtin_convertvector(p, f16x2_t);
+        const int h = __builtin_bit_cast(int, hh);
+        int l;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(l)
+            : "v"(h), "v"(p[0]), "v"(p[1]));
+        hi[u] = h;
+        lo[u] = l;
+    }
+    *reinterpret_cast<int2_t*>(hi_img + off) = hi;
+    *reinterpret_cast<int2_t*>(lo_img + off) = lo;
+}
+// the MFMA operand of a 32-channel tile (first channel chan0) for the 16 points of a stage image: two transposed reads
+__device__ __forceinline__ x3v8 wgx_operand(const char* img, int chan0, int lane) {
+    const int g = lane >> 4, j = lane & 15, q = j >> 2, p = j & 3;
+    const int chan = chan0 + 16 * (g & 1) + 4 * p;
+    typedef __attribute__((address_space(3))) trx_fh4* lds_fh4;
+    const trx_fh4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fh4)(img + wgx_off(8 * (g >> 1) + q, chan)));
+    const trx_fh4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fh4)(img + wgx_off(8 * (g >> 1) + 4 + q, chan)));
+    const int2_t a = __builtin_bit_cast(int2_t, r0), b = __builtin_bit_cast(int2_t, r1);
+    const int4_t v = {a[0], a[1], b[0], b[1]};
+    return __builtin_bit_cast(x3v8, v);
+}
+
+#ifndef WGX_VPG
+#define WGX_VPG 6
+#endif
+template <int MT, int KT, int WM, int WN, int NG = 3>     // NG: register sets of raw blocks (a block is loaded NG - 1 iterations before its conversion)
+__global__ __launch_bounds__(64 * WM * WN) void tr_wgrad_x3_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ a,
+                                                          int64_t lda, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int relu_in,
+                                                          const uint32_t* __restrict__ dz_amax, int64_t M, int64_t slice_pts,
+                                                          int n_cb, int c_out, int c_in, float* __restrict__ part) {
+    static_assert(WM * WN == 4 || WM * WN == 8, "four waves, or eight (two per SIMD: 256 registers each)");
+    constexpr int CO = WM * MT * 32, CI = WN * KT * 32, NT = 64 * WM * WN;
+    constexpr int NA = 4 * CO / NT, NB = 4 * CI / NT;       // 16-byte loads per thread and 16-point block
+    static_assert(NA >= 1 && NB >= 1 && (4 * CO) % NT == 0 && (4 * CI) % NT == 0, "whole loads per thread");
+    constexpr int IMG_A = wgx_image_bytes(CO), IMG_B = wgx_image_bytes(CI), STAGE = 2 * IMG_A + 2 * IMG_B;
+    constexpr int PERIOD = NG == 3 ? 6 : 2;                 // the loop is unrolled over a common period of stages and register sets
+    static_assert(NG == 2 || NG == 3, "register sets");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_sc = reinterpret_cast<float*>(smem + 2 * STAGE);   // the a operand's activation of this block's CI channels
+    float* s_sh = s_sc + CI;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int blk = (int)blockIdx.x, slice = blk / n_cb / (c_out / CO), cb = blk % n_cb, mb = (blk / n_cb) % (c_out / CO);
+    const int64_t p_lo = (int64_t)slice * slice_pts, p_hi = p_lo + slice_pts < M ? p_lo + slice_pts : M;
+    const int n_it = (int)((p_hi - p_lo) / 16);
+    float s_in = 1.0f, s_out = 1.0f;                        // dz's power-of-two scale (see tr_linear_x3_kernel)
+    if (dz_amax) {
+        uint32_t mxb = dz_amax[lane];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)mxb, off);
+            mxb = other > mxb ? other : mxb;
+        }
+        const int ex = (int)((__builtin_amdgcn_readfirstlane((int)mxb) >> 23) & 0xff);
+        int sh_e = ex == 0 ? 0 : 14 - (ex - 127);
+        sh_e = sh_e < -100 ? -100 : (sh_e > 100 ? 100 : sh_e);
+        s_in = __int_as_float((127 + sh_e) << 23);
+        s_out = __int_as_float((127 - sh_e) << 23);
+    }
+    const float floor_v = relu_in ? 0.0f : -3.0e38f;
+    // this thread's pieces of a block: piece i of the dz block is 16-byte load number threadIdx.x + 256 i of its 16 x CO floats
+    const float* ga[NA];
+    int oa[NA];
+    const float* gb[NB];
+    int ob[NB], cb4[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int v = threadIdx.x + NT * i, row = v / (CO / 4), c4 = v % (CO / 4);
+        ga[i] = dz + (p_lo + row) * lddz + (int64_t)mb * CO + 4 * c4;
+        oa[i] = wgx_off(row, 4 * c4);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int v = threadIdx.x + NT * i, row = v / (CI / 4), c4 = v % (CI / 4);
+        gb[i] = a + (p_lo + row) * lda + (int64_t)cb * CI + 4 * c4;
+        ob[i] = wgx_off(row, 4 * c4);
+        cb4[i] = 4 * c4;
+    }
+    if (scale) {
+        for (int i = threadIdx.x; i < CI; i += NT) {
+            s_sc[i] = scale[(int64_t)cb * CI + i];
+            s_sh[i] = shift[(int64_t)cb * CI + i];
+        }
+    }
+    struct Raw {
+        f32x4 a[NA], b[NB];
+    };
+    Raw G[NG];
+    const auto load = [&](Raw& g, int it) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) g.a[i] = *reinterpret_cast<const f32x4*>(ga[i] + (int64_t)it * 16 * lddz);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) g.b[i] = *reinterpret_cast<const f32x4*>(gb[i] + (int64_t)it * 16 * lda);
+    };
+    const auto convert = [&](const Raw& g, char* st) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            f32x4 v = g.a[i];
+            v[0] *= s_in;
+            v[1] *= s_in;
+            v[2] *= s_in;
+            v[3] *= s_in;
+            wgx_put(v, st, st + IMG_A, oa[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            f32x4 v = g.b[i];
+            if (scale) {
+                const f32x4 sc4 = *reinterpret_cast<const f32x4*>(s_sc + cb4[i]), sh4 = *reinterpret_cast<const f32x4*>(s_sh + cb4[i]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(__builtin_fmaf(v[e], sc4[e], sh4[e]), floor_v);
+            }
+            wgx_put(v, st + 2 * IMG_A, st + 2 * IMG_A + IMG_B, ob[i]);
+        }
+    };
+    f32x16 acc[MT][KT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) acc[m][k] = f32x16{};
+    if (n_it > 0) {
+#pragma unroll
+        for (int i = 0; i < NG - 1; ++i) load(G[i], i < n_it ? i : n_it - 1);
+        __syncthreads();                                        // (s_sc / s_sh)
+        convert(G[0], smem);
+        __syncthreads();
+        for (int base = 0; base < n_it; base += PERIOD) {
+#pragma unroll
+            for (int u = 0; u < PERIOD; ++u) {
+                const int it = base + u;
+                if (it >= n_it) break;
+                // (past the slice's end the last block is loaded and converted again, into a stage nobody reads: no branch
+                // between the MFMAs and the conversion they are interleaved with)
+                const int nx = it + NG - 1;
+                load(G[(u + NG - 1) % NG], nx < n_it ? nx : n_it - 1);
+                const char* st = smem + (u & 1) * STAGE;
+                x3v8 ah[MT], al[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    ah[m] = wgx_operand(st, 32 * (wm * MT + m), lane);
+                    al[m] = wgx_operand(st + IMG_A, 32 * (wm * MT + m), lane);
+                }
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const x3v8 bh = wgx_operand(st + 2 * IMG_A, 32 * (wn * KT + k), lane);
+                    const x3v8 bl = wgx_operand(st + 2 * IMG_A + IMG_B, 32 * (wn * KT + k), lane);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        acc[m][k] = x3_mfma(ah[m], bh, acc[m][k]);
+                        acc[m][k] = x3_mfma(ah[m], bl, acc[m][k]);
+                        acc[m][k] = x3_mfma(al[m], bh, acc[m][k]);
+                    }
+                }
+                convert(G[(u + 1) % NG], smem + ((u + 1) & 1) * STAGE);
+                // the next block's conversion (6 VALU + two 8-byte LDS writes per 16 bytes loaded) rides under this block's MFMAs
+#pragma unroll
+                for (int n = 0; n < 3 * MT * KT; ++n) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, WGX_VPG, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // part[slice][co][ci]: register r of half h is row 8 (r >> 2) + 4 h + (r & 3) of the tile, the lane its column
+    const int h = lane >> 5, col = lane & 31;
+    float* out = part + ((int64_t)slice * c_out + (int64_t)mb * CO + 32 * wm * MT) * c_in + (int64_t)cb * CI + 32 * wn * KT + col;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(int64_t)(32 * m + 8 * (r >> 2) + 4 * h + (r & 3)) * c_in + 32 * k] = acc[m][k][r] * s_out;
+}
+
+// which instantiation a layer takes (0: none — the fp32 kernel): the block shape is the largest that divides the layer
+static int wgx_shape(int c_out, int c_in) {
+    if (c_out % 256 == 0 && c_in % 256 == 0) return 1;      // 256 x 256
+    if (c_out % 128 == 0 && c_in % 256 == 0) return 2;      // 128 x 256
+    if (c_out % 128 == 0 && c_in % 128 == 0) return 3;      // 128 x 128
+    if (c_out % 512 == 0 && c_in % 64 == 0) return 4;       // 512 x 64
+    return 0;
+}
+static void wgx_dims(int shape, int* co, int* ci) {
+    static const int d[5][2] = {{0, 0}, {256, 256}, {128, 256}, {128, 128}, {512, 64}};
+    *co = d[shape][0];
+    *ci = d[shape][1];
+}
+static int64_t wgx_slice_pts(int64_t M, int c_out, int c_in, int shape) {
+    int co, ci;
+    wgx_dims(shape, &co, &ci);
+    const int64_t blocks = (int64_t)(c_out / co) * (c_in / ci);
+    int64_t want = (2 * trx_cu_count() + blocks - 1) / blocks;   // ~two workgroups per CU in all
+    if (want < 1) want = 1;
+    int64_t pts = (M + want - 1) / want;
+    pts = (pts + 95) / 96 * 96;                              // (whole 16-point blocks; a multiple of the loop's unroll)
+    return pts < 96 ? 96 : pts;
+}
+bool tr_wgrad_x3_ok(int64_t M, int c_out, int c_in) {
+    return M >= 8192 && M % 16 == 0 && M < ((int64_t)1 << 31) && wgx_shape(c_out, c_in) != 0;
+}
+size_t tr_wgrad_x3_workspace_bytes(int64_t M, int c_out, int c_in) {
+    const int shape = wgx_shape(c_out, c_in);
+    if (!shape) return 0;
+    const int64_t pts = wgx_slice_pts(M, c_out, c_in, shape);
+    return (size_t)((M + pts - 1) / pts) * c_out * c_in * sizeof(float);
+}
+hipError_t launch_tr_wgrad_final(const float* part, int n_slices, int64_t n, float* dW, hipStream_t s);
+hipError_t launch_tr_wgrad_x3(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale, const float* shift,
+                              int relu_in, const uint32_t* dz_amax, int64_t M, int c_out, int c_in, float* part, float* dW,
+                              hipStream_t s) {
+    const int shape = wgx_shape(c_out, c_in);
+    int co, ci;
+    wgx_dims(shape, &co, &ci);
+    const int64_t pts = wgx_slice_pts(M, c_out, c_in, shape);
+    const int n_slices = (int)((M + pts - 1) / pts), n_cb = c_in / ci, n_mb = c_out / co;
+    const unsigned grid = (unsigned)(n_slices * n_cb * n_mb);
+    const auto go = [&](auto kern, size_t lds, unsigned threads = 256) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, dz, lddz, a, lda, scale, shift, relu_in, dz_amax, M, pts, n_cb,
+                           c_out, c_in, part);
+        return hipGetLastError();
+    };
+    const size_t lds = 2 * (2 * (size_t)wgx_image_bytes(co) + 2 * (size_t)wgx_image_bytes(ci)) + 2 * (size_t)ci * sizeof(float);
+    hipError_t e = hipSuccess;
+    switch (shape) {
+        case 1: e = go(tr_wgrad_x3_kernel<2, 4, 4, 2>, lds, 512); break;     // 256 x 256: eight waves of 64 x 128
+#ifdef TRX_WGRAD_S2_4WAVES
+        case 2: e = go(tr_wgrad_x3_kernel<2, 4, 2, 2>, lds); break;
+#else
+        case 2: e = go(tr_wgrad_x3_kernel<2, 2, 2, 4>, lds, 512); break;     // 128 x 256: eight waves of 64 x 64
+#endif
+        case 3: e = go(tr_wgrad_x3_kernel<2, 2, 2, 2>, lds); break;
+        case 4: e = go(tr_wgrad_x3_kernel<4, 2, 4, 1>, lds); break;
+        default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+    return launch_tr_wgrad_final(part, n_slices, (int64_t)c_out * c_in, dW, s);
+}

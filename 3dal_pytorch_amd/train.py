@@ -17,6 +17,8 @@ Parity: tests/test_gpu_train.py compares outputs, running statistics and every p
 torch autograd over the stock-torch composite (`PointNetInstanceSeg.forward`, `_PointHead.forward`), which
 tests/test_host_cpu.py ties to the oracle.
 """
+import os
+
 import torch
 
 from . import _hip
@@ -38,6 +40,7 @@ CAPTURE = None
 # qualify with them (their dz operand is scaled by a power of two around the products: _BN.backward(amax=)). wgrad stays
 # fp32. Set by the drop-ins from model.precision; a backward uses the images its forward packed.
 ARITH = "fp32"
+_WGRAD_X3 = os.environ.get("DAL3_TRAIN_WGRAD_X3", "1") != "0"      # (A/B switch: 0 keeps wgrad on the fp32 kernel in an f16x3 step)
 
 
 class arithmetic:
@@ -180,9 +183,20 @@ def _colred(z, mode, da=None, dg=None, arg=None, seg=0, bn=None, rows=None):
     return out
 
 
-def _wgrad(dz, a, c_out, c_in, act=None):
+def _wgrad(dz, a, c_out, c_in, act=None, amax=None):
+    """dW (c_out, c_in) = dz^T act(a). amax (64 device words holding the bits of max |dz|, _BN.backward(amax=)): the caller's
+    step runs on the f16x3 arithmetic — the layer takes dal3_tr_wgrad_x3 when its shape qualifies"""
     M = dz.shape[0]
     lib = _hip.lib()
+    if amax is not None and _WGRAD_X3:
+        need = lib.dal3_tr_wgrad_x3_workspace_bytes(M, c_out, c_in)
+        if need:
+            ws = _ws(need, dz.device)
+            dW = torch.empty((c_out, c_in), dtype=torch.float32, device=dz.device)
+            sc, sh, relu = (act if act is not None else (None, None, False))
+            _hip.check(lib.dal3_tr_wgrad_x3(_hip.ptr(dz), dz.stride(0), _hip.ptr(a), a.stride(0), _hip.ptr(sc), _hip.ptr(sh),
+                                            int(relu), _hip.ptr(amax), M, c_out, c_in, _hip.ptr(ws), need, _hip.ptr(dW), _hip.stream()))
+            return dW
     need = lib.dal3_tr_wgrad_workspace_bytes(M, c_out, c_in)
     ws = _ws(need, dz.device)
     dW = torch.empty((c_out, c_in), dtype=torch.float32, device=dz.device)
@@ -572,6 +586,7 @@ class _InsSeg(torch.autograd.Function):
                  tr(6, dg=True),
                  (Wd1, 512, 64, True, Mp, 0, False, False), tr(3), tr(2, True), tr(1)]
         pk = dict(zip(order, _prepack(specs, pts.device)))
+        pk["arith"] = ARITH                                             # (the backward runs outside the forward's context)
         a, act = a0, None
         for k in range(4):                                              # conv1..4
             W, b, gamma, beta = P[4 * k:4 * k + 4]
@@ -650,13 +665,15 @@ class _InsSeg(torch.autograd.Function):
             da = _act_dropout(da, None, drop)                           # the same multiplier, re-created from its key
         amaxes = torch.zeros(3 * 64, dtype=torch.int32, device=dlogits.device)
         for k in (8, 7, 6):                                             # dconv4..2
-            x3 = isinstance(pk[f"t{k}"], _X3Image)                      # (f16x3 dgrad: dz's largest |value| comes with it)
-            amax = amaxes[64 * (8 - k):64 * (9 - k)] if x3 and zs[k].shape[1] % 64 == 0 else None
+            # f16x3 step: dz's largest |value| comes with it (64 words), for the wgrad and — where its image is the f16x3
+            # one — the dgrad of this layer
+            amax = amaxes[64 * (8 - k):64 * (9 - k)] if pk.get("arith") == "f16x3" and zs[k].shape[1] % 64 == 0 else None
             dz, dgam, dbet = bns[k].backward(zs[k], da=da, amax=amax)
-            grads[4 * k] = _wgrad(dz, zs[k - 1], Ws[k].shape[0], Ws[k].shape[1], bns[k - 1].act).reshape(shapes[4 * k])
+            grads[4 * k] = _wgrad(dz, zs[k - 1], Ws[k].shape[0], Ws[k].shape[1], bns[k - 1].act, amax=amax).reshape(shapes[4 * k])
             grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
-            da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, packed=pk[f"t{k}"], amax=amax)
+            da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, packed=pk[f"t{k}"],
+                         amax=amax if isinstance(pk[f"t{k}"], _X3Image) else None)
         # dconv1: per-point part against out2, per-crop part against g
         dz, dgam, dbet, dgb = bns[5].backward(zs[5], da=da, sum_seg=N)   # dgb (B,512): dz summed over each crop's points
         Wd1 = Ws[5]

@@ -461,6 +461,14 @@ int dal3_tr_bnbwd_apply_segsum(const float* z, int64_t M, int C, int64_t ldz, co
                                const float* scale, const float* shift, const float* mu, const float* rstd, const float* k1,
                                const float* k2, const float* k3, float* dz, int64_t lddz, int64_t sum_seg, float* seg_sums,
                                void* workspace, size_t workspace_bytes, dal3_stream stream);
+/* dal3_tr_wgrad on the f16x3 arithmetic (both operands split in two fp16 halves, fp32 accumulate). dz_amax: 64 device words
+ * whose maximum is the bit pattern of dz's largest |value| (dal3_tr_bnbwd_apply_amax), or NULL for a dz inside fp16's
+ * range. _workspace_bytes() == 0: the shape does not qualify (c_out x c_in must be cut by 256 x 256, 128 x 256, 128 x 128
+ * or 512 x 64 blocks; M >= 8192) — use dal3_tr_wgrad. */
+size_t dal3_tr_wgrad_x3_workspace_bytes(int64_t M, int c_out, int c_in);
+int dal3_tr_wgrad_x3(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale, const float* shift,
+                     int relu_in, const uint32_t* dz_amax, int64_t M, int c_out, int c_in, void* workspace,
+                     size_t workspace_bytes, float* dW, dal3_stream stream);
 size_t dal3_tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in);
 int dal3_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale, const float* shift,
                   int relu_in, int64_t M, int c_out, int c_in, void* workspace, size_t workspace_bytes, float* dW,

@@ -223,3 +223,40 @@ def test_bnbwd_apply_amax_is_the_maximum():
     dz1 = bn.backward(z, da=da, amax=words)[0]
     assert torch.equal(dz0, dz1)
     assert int(words.max()) == int(dz1.abs().max().view(torch.int32)) and int((words > 0).sum()) == 64
+
+
+@pytest.mark.parametrize("M,co,ci,act,mag", [(16384, 256, 512, True, 3e-6), (16384, 128, 256, True, 1e-9), (8192, 128, 128, False, 2.0),
+                                             (8192 + 32, 512, 64, True, 1e-5), (24576, 384, 256, True, 1e-4)])
+def test_wgrad_x3_against_float64(M, co, ci, act, mag):
+    """dW = dz^T act(a) with both operands split in fp16 halves (staged through LDS, read back transposed): the fp32 kernel's
+    accuracy for dz at gradient magnitudes with its amax words; point counts that leave a ragged last slice; row strides
+    that are not the row length"""
+    lib = hip.lib()
+    g = torch.Generator(device="cuda").manual_seed(co + ci + M)
+    spread = torch.exp(torch.rand((M, 1), device="cuda", generator=g) * -9.0)
+    dz = (torch.randn((M, co + 8), device="cuda", generator=g) * spread * mag)[:, :co]
+    a = (torch.randn((M, ci + 4), device="cuda", generator=g) * 1.5)[:, :ci]
+    sc = torch.rand(ci, device="cuda", generator=g) + 0.5
+    sc[::3] *= -1.0
+    sh = torch.randn(ci, device="cuda", generator=g) * 0.3
+    x = torch.relu(a.double() * sc.double() + sh.double()) if act else a.double()
+    ref = dz.double().t() @ x
+    amax = torch.zeros(64, dtype=torch.int32, device="cuda")
+    amax[40] = dz.abs().max().reshape(1).view(torch.int32)[0]
+    assert lib.dal3_tr_wgrad_x3_workspace_bytes(M, co, ci) > 0
+    wx = train._wgrad(dz, a, co, ci, (sc, sh, True) if act else None, amax=amax)
+    w32 = train._wgrad(dz, a, co, ci, (sc, sh, True) if act else None)
+    rng = float(ref.abs().max())
+    ex, e32 = float((wx.double() - ref).abs().max()) / rng, float((w32.double() - ref).abs().max()) / rng
+    assert ex < 2e-6 and ex < 2 * e32 + 2e-7, (ex, e32)
+    for _ in range(10):                                       # (two LDS stages, one barrier per 16 points: reproducible bit for bit)
+        assert torch.equal(train._wgrad(dz, a, co, ci, (sc, sh, True) if act else None, amax=amax), wx)
+
+
+def test_wgrad_x3_shapes_that_do_not_qualify_take_the_fp32_kernel():
+    lib = hip.lib()
+    assert lib.dal3_tr_wgrad_x3_workspace_bytes(262144, 64, 64) == 0 and lib.dal3_tr_wgrad_x3_workspace_bytes(262144, 128, 64) == 0
+    assert lib.dal3_tr_wgrad_x3_workspace_bytes(4096, 256, 512) == 0            # few points: the fp32 kernel's slices
+    dz, a = torch.randn((8192, 64), device="cuda") * 1e-6, torch.randn((8192, 64), device="cuda")
+    amax = torch.zeros(64, dtype=torch.int32, device="cuda")
+    assert torch.equal(train._wgrad(dz, a, 64, 64, None, amax=amax), train._wgrad(dz, a, 64, 64, None))
