@@ -4,7 +4,7 @@
 // (post-BatchNorm activations, weights) are O(1), inside fp16's exponent range. A dgrad's operand, dz, is 1e-6 and smaller:
 // its producer (tr_bnbwd_apply_kernel) leaves the bit pattern of its largest |value| in device words, and the kernel
 // multiplies the operand by the power of two that brings that value to 2^14 and the result by the inverse (in_amax).
-// wgrad (both operands transposed with respect to memory) stays on the fp32 MFMA.
+// wgrad — both operands transposed with respect to memory — is the second kernel of this file (tr_wgrad_x3_kernel, below).
 //
 // Unlike the eval kernels the activations come from HBM, not from the previous layer's accumulators: a wave owns T = 2
 // tiles of 32 points and MTB output tiles; per 32-channel k-tile it loads its 2 x 32 x 32 fp32 inputs (16 B per lane and

@@ -37,8 +37,8 @@ CAPTURE = None
 # Arithmetic of the training FORWARD's big layers (c_out % 256 == 0, M % 256 == 0 ...: dal3_tr_linear_x3_layout):
 # "fp32" — the exact-fp32 MFMA kernels; "f16x3" — fp16 MFMAs on (hi, lo) split operands, fp32 accumulate
 # (dal3_train_x3.hip: the same 1e-6 of the output's range, 1.3-2.5 x faster per layer), and the decoder's dgrads that
-# qualify with them (their dz operand is scaled by a power of two around the products: _BN.backward(amax=)). wgrad stays
-# fp32. Set by the drop-ins from model.precision; a backward uses the images its forward packed.
+# qualify and the decoder's wgrads with them (their dz operand is scaled by a power of two around the products:
+# _BN.backward(amax=)). Set by the drop-ins from model.precision; a backward follows what its forward ran on.
 ARITH = "fp32"
 _WGRAD_X3 = os.environ.get("DAL3_TRAIN_WGRAD_X3", "1") != "0"      # (A/B switch: 0 keeps wgrad on the fp32 kernel in an f16x3 step)
 

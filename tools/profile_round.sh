@@ -21,6 +21,7 @@ rocprofv3 $KT -d $O/prof_kt_train -o kt -- python3 $R/tools/bench_train.py --bac
 python3 $R/tools/bench_train.py --sampler device --backends hip,hip_f16x3,torch > $O/bench_train.json 2>/dev/null
 python3 $R/tools/bench_train.py --kind dynamic --sampler device --backends hip,hip_f16x3,torch > $O/bench_train_dynamic.json 2>/dev/null
 python3 $R/tools/trx_probe.py > $O/trx_probe.txt 2>/dev/null
+python3 $R/tools/wgx_probe.py >> $O/trx_probe.txt 2>/dev/null
 python3 $R/tools/bench_latency.py > $O/bench_latency.json 2>/dev/null
 # the reference's own eval batch (64 crops x 4096 points): where the small kernels between the three big ones show
 rocprofv3 $KT -d $O/prof_kt_b64 -o kt -- python3 $R/bench.py --no-extras --batch 64 --points 4096 --steps 20 --warmup 3 > $O/bench_b64_under_rocprof.json 2>/dev/null
