@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dal3_stream;               /* hipStream_t */
 
-#define DAL3_VERSION 110                 /* 0.1.1: dal3_point_head_pool takes a workspace; dal3_mean_size */
+#define DAL3_VERSION 120                 /* 0.1.2: DAL3_F16X3; dal3_tr_linear_x3 / _pool_x3 / dal3_tr_wgrad_x3, dal3_tr_bnbwd_apply_amax */
 
 enum {
     DAL3_OK = 0,

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib().dal3_version() == 110
+    assert hip.lib().dal3_version() == 120
 
 
 def test_argument_errors_are_reported_without_a_gpu():
