@@ -260,3 +260,44 @@ def test_wgrad_x3_shapes_that_do_not_qualify_take_the_fp32_kernel():
     dz, a = torch.randn((8192, 64), device="cuda") * 1e-6, torch.randn((8192, 64), device="cuda")
     amax = torch.zeros(64, dtype=torch.int32, device="cuda")
     assert torch.equal(train._wgrad(dz, a, 64, 64, None, amax=amax), train._wgrad(dz, a, 64, 64, None))
+
+
+def test_captured_f16x3_train_step_matches_eager_steps():
+    """forward + criterion + backward + Adam as one hipGraph with the f16x3 kernels in it (linear, pooled, dgrad with its amax
+    words zeroed inside the graph, wgrad): a warm-up step + one replay leave the parameters where two eager steps leave them"""
+    graph = importlib.import_module("3dal_pytorch_amd.graph")
+    losses = importlib.import_module("3dal_pytorch_amd.losses")
+    from _common import synth
+    B, N = 4, 4096                                           # 16,384 points: the f16x3 training kernels qualify
+    p, i, g = (torch.from_numpy(a).cuda() for a in synth.static_crops(B, N, seed=6))
+    pts = p.transpose(2, 1)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    labels = ((torch.rand((B, N), device="cuda", generator=gen) > 0.6).float(), torch.randn((B, 3), device="cuda", generator=gen),
+              torch.randint(0, 12, (B,), device="cuda", generator=gen), 0.1 * torch.randn((B,), device="cuda", generator=gen),
+              torch.randint(0, 3, (B,), device="cuda", generator=gen), 0.3 * torch.randn((B, 3), device="cuda", generator=gen))
+    crit = losses.FrustumPointNetLossOneBoxEst()
+    runs = {}
+    lib = hip.lib()
+    for mode in ("graph", "eager"):
+        model = build_model("static_one", synth.state_dict("static_one", seed=6)).train()
+        model.precision, model.sampler = "f16x3", "device"
+        model.ins_seg.dropout.p = 0.0
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+
+        def step(p_, i_, g_, model=model):
+            return crit(model(p_, i_, g_), *labels)["total_loss"]
+        if mode == "graph":
+            cap = graph.CapturedTrainStep(model, opt, step, pts, i, g, warmup=1)
+            last = cap(pts, i, g)
+        else:
+            for _ in range(2):
+                opt.zero_grad(set_to_none=True)
+                last = step(pts, i, g)
+                last.backward()
+                opt.step()
+        torch.cuda.synchronize()
+        runs[mode] = (float(last.detach()), {k: v.detach().clone() for k, v in model.named_parameters()})
+    assert lib.dal3_tr_linear_x3_layout(B * N, 512, 0, 256, 0, 1) == 0x108 and lib.dal3_tr_wgrad_x3_workspace_bytes(B * N, 256, 512) > 0
+    assert abs(runs["graph"][0] - runs["eager"][0]) <= 1e-5 * abs(runs["eager"][0])
+    for k, v in runs["eager"][1].items():
+        assert torch.allclose(runs["graph"][1][k], v, rtol=1e-5, atol=1e-6), k

@@ -145,3 +145,19 @@ def test_f16x3_range_margin():
         b = model._run(pts, torch.from_numpy(init).cuda(), None)["logits"]
         assert bool(torch.isfinite(b).all())
         assert float((a - b).abs().max()) < 1e-5 * float(a.abs().max()), scale
+
+
+def test_captured_f16x3_refine_equals_eager():
+    """hipGraph capture of refine() on the f16x3 kernels (dynamic LDS sizes set per launch, persistent workgroups): replays
+    reproduce the eager path bit for bit, also on new inputs"""
+    import importlib
+    graph = importlib.import_module("3dal_pytorch_amd.graph")
+    B, N = 16, 1024
+    model = build_model("static_two", synth.state_dict("static_two", seed=3))
+    model.precision = "f16x3"
+    p, i, g = (torch.from_numpy(a).cuda() for a in synth.static_crops(B, N, seed=3))
+    cap = graph.CapturedRefine(model, p.transpose(2, 1), i, g)
+    assert torch.equal(cap(p.transpose(2, 1), i, g), model.refine(p.transpose(2, 1), i, g))
+    p2, i2, g2 = (torch.from_numpy(a).cuda() for a in synth.static_crops(B, N, seed=4))
+    want = model.refine(p2.transpose(2, 1), i2, g2).clone()
+    assert torch.equal(cap(p2.transpose(2, 1), i2, g2), want)
