@@ -10,7 +10,7 @@ for f in bench bench_under_rocprof bench_bf16_under_rocprof bench_f16x3_under_ro
          bench_train_dynamic bench_train_under_rocprof bench_rehearsal_2ranks bench_rehearsal_2ranks_c4; do
   [ -s $O/$f.json ] && cp $O/$f.json profiles/${TAG}_$f.json
 done
-for f in $O/${TAG}_kernel_stats*.csv $O/${TAG}_train_kernel_stats.csv $O/${TAG}_pmc*.json $O/traffic.json; do
+for f in $O/${TAG}_kernel_stats*.csv $O/${TAG}_train_kernel_stats*.csv $O/${TAG}_pmc*.json $O/traffic.json; do
   [ -s $f ] && cp $f profiles/
 done
 [ -s $O/trx_probe.txt ] && cp $O/trx_probe.txt profiles/${TAG}_trx_probe.txt

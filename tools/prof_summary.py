@@ -28,17 +28,18 @@ def short(name):
 
 for sub, sfx in (("prof_kt", ""), ("prof_kt_bf16", "_bf16"), ("prof_kt_f16x3", "_f16x3"), ("prof_kt_c3", "_c3"), ("prof_kt_c5", "_c5"),
                  ("prof_kt_maxpool", "_maxpool"), ("prof_kt_maxpool_bf16", "_maxpool_bf16"), ("prof_kt_b64", "_b64"),
-                 ("prof_kt_train", "_train")):
+                 ("prof_kt_train", "_train"), ("prof_kt_train_x3", "_train_x3")):
     stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
     if not stats:
         continue
     rows = list(csv.DictReader(open(stats[0])))
-    name = f"{tag}_train_kernel_stats.csv" if sfx == "_train" else f"{tag}_kernel_stats{sfx}.csv"
+    name = (f"{tag}_train_kernel_stats.csv" if sfx == "_train" else f"{tag}_train_kernel_stats_f16x3.csv" if sfx == "_train_x3"
+            else f"{tag}_kernel_stats{sfx}.csv")
     with open(os.path.join(out_dir, name), "w") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows:
-            if sfx == "_train" or any(k in r["Name"] for k in OURS) or float(r["Percentage"]) > 0.5:
+            if sfx.startswith("_train") or any(k in r["Name"] for k in OURS) or float(r["Percentage"]) > 0.5:
                 w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                             r["MinNs"], r["MaxNs"], r["StdDev"]])
 
@@ -86,7 +87,7 @@ if acc:
 
 pmc = defaultdict(lambda: defaultdict(list))
 for d in ("prof_fetch", "prof_write", "prof_mfma", "prof_fetch_bf16", "prof_write_bf16", "prof_mfma_bf16",
-          "prof_fetch_maxpool", "prof_write_maxpool"):
+          "prof_fetch_f16x3", "prof_write_f16x3", "prof_fetch_maxpool", "prof_write_maxpool"):
     for fn in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(fn)):
             k = short(r["Kernel_Name"])
@@ -94,6 +95,8 @@ for d in ("prof_fetch", "prof_write", "prof_mfma", "prof_fetch_bf16", "prof_writ
                 continue
             if d.endswith("_bf16") and "_lp_" not in k:
                 continue                                          # the fp32 passes already hold the shared small kernels
+            if d.endswith("_f16x3") and "_x3_" not in k:
+                continue
             pmc[k][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"]),
                                               int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 summary, traffic = {}, {}
@@ -113,7 +116,7 @@ for k, ctrs in pmc.items():
     summary[k] = s
 json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 import datetime                                              # noqa: E402
-traffic["_shape"] = {"precisions": ["fp32", "bf16"], "B": 4096, "N": 1024}   # what the PMC passes ran (`_lp_` rows: bf16)
+traffic["_shape"] = {"precisions": ["fp32", "bf16", "f16x3"], "B": 4096, "N": 1024}   # what the PMC passes ran (`_lp_` rows: bf16, `_x3_`: f16x3)
 traffic["_taken"] = f"{tag}, {datetime.date.today().isoformat()}, tools/profile_round.sh"
 json.dump(traffic, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1, sort_keys=True))

@@ -18,6 +18,7 @@ rocprofv3 $KT -d $O/prof_kt_c3 -o kt -- python3 $R/bench.py --no-extras --config
 rocprofv3 $KT -d $O/prof_kt_c5 -o kt -- python3 $R/bench.py --no-extras --config C5 --steps 10 --warmup 2 > $O/bench_c5_under_rocprof.json 2>/dev/null
 # one training step (64 x 4096, fp32, Adam, device sampler): kernel trace of tools/bench_train.py
 rocprofv3 $KT -d $O/prof_kt_train -o kt -- python3 $R/tools/bench_train.py --backends hip --sampler device --iters 10 > $O/bench_train_under_rocprof.json 2>/dev/null
+rocprofv3 $KT -d $O/prof_kt_train_x3 -o kt -- python3 $R/tools/bench_train.py --backends hip_f16x3 --sampler device --iters 10 > /dev/null 2>&1
 python3 $R/tools/bench_train.py --sampler device --backends hip,hip_f16x3,torch > $O/bench_train.json 2>/dev/null
 python3 $R/tools/bench_train.py --kind dynamic --sampler device --backends hip,hip_f16x3,torch > $O/bench_train_dynamic.json 2>/dev/null
 python3 $R/tools/trx_probe.py > $O/trx_probe.txt 2>/dev/null
@@ -35,14 +36,13 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch_maxpool_bf16 -o 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write_maxpool_bf16 -o c -- python3 $R/bench.py --only-maxpool --maxpool-storage bf16 --steps 3 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch_maxpool -o c -- python3 $R/bench.py --only-maxpool --steps 3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write_maxpool -o c -- python3 $R/bench.py --only-maxpool --steps 3 > /dev/null 2>&1
-for P in fp32 bf16; do
-  S=""; [ $P = bf16 ] && S="_bf16"
+for P in fp32 bf16 f16x3; do
+  S=""; [ $P = bf16 ] && S="_bf16"; [ $P = f16x3 ] && S="_f16x3"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch$S -o c -- python3 $R/bench.py --no-extras --precision $P --steps 3 --warmup 1 > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write$S -o c -- python3 $R/bench.py --no-extras --precision $P --steps 3 --warmup 1 > /dev/null 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_mfma$S -o c -- python3 $R/bench.py --no-extras --precision $P --steps 3 --warmup 1 > /dev/null 2>&1
 done
 # the 16-bit configurations at their own shapes: MFMA-busy and the clock the chip holds (GRBM_GUI_ACTIVE / 8 / kernel time)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_mfma_f16x3 -o c -- python3 $R/bench.py --no-extras --precision f16x3 --steps 3 --warmup 1 > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $O/prof_insts_f16x3 -o c -- python3 $R/bench.py --no-extras --precision f16x3 --steps 3 --warmup 1 > /dev/null 2>&1
 for CFG in C3 C5; do
   L=$(echo $CFG | tr A-Z a-z)
