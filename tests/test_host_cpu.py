@@ -242,3 +242,19 @@ def test_f16x3_split_is_as_exact_as_fp32_arithmetic_in_emulation():
     e = mod.main(B=2, N=512)
     assert e["f16x3"] < 2 * e["f32"] and e["f16x3"] < 5e-6
     assert e["f16"] > 100 * e["f16x3"] and e["bf16x3"] > 5 * e["f16x3"]
+
+
+def test_f16x3_training_kernels_shape_rules_are_host_side():
+    """which calls take the f16x3 training kernels is decided on the host (no GPU needed): the rules include/dal3.h states"""
+    lib = hip.lib()
+    lay = lib.dal3_tr_linear_x3_layout                       # (M, c_in, seg, c_out, accumulate, has_act)
+    assert lay(262144, 512, 0, 256, 0, 1) == 0x108 and lay(262144, 64, 4096, 512, 0, 1) == 0x108
+    for bad in ((262144, 512, 0, 256, 1, 1), (262144, 512, 0, 128, 0, 1), (262144, 96, 0, 256, 0, 1), (262144 + 32, 512, 0, 256, 0, 1),
+                (2048, 512, 0, 256, 0, 1), (262144, 64, 4000, 512, 0, 1), (262144, 2112, 0, 256, 0, 1)):
+        assert lay(*bad) == 0, bad
+    assert lib.dal3_tr_linear_pool_x3_ok(262144, 128, 4096, 1024) == 1 and lib.dal3_tr_linear_pool_x3_ok(262144, 128, 4000, 1024) == 0
+    wg = lib.dal3_tr_wgrad_x3_workspace_bytes
+    assert wg(262144, 256, 512) > 0 and wg(262144, 128, 256) > 0 and wg(262144, 128, 128) > 0 and wg(262144, 512, 64) > 0
+    assert wg(262144, 64, 64) == 0 and wg(262144, 128, 64) == 0 and wg(4096, 256, 512) == 0
+    # a slice's partial sums fit the workspace the function reports: slices x c_out x c_in floats, at most ~2 workgroups per CU
+    assert wg(262144, 256, 512) % (256 * 512 * 4) == 0 and wg(262144, 256, 512) // (256 * 512 * 4) <= 1024
