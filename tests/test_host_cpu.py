@@ -13,6 +13,8 @@ import torch
 from _common import ROOT, arch, golden, rel_err, static_case, synth
 from oracle import ref_heads as R
 
+graft_entry = importlib.import_module("__graft_entry__")
+
 hip = importlib.import_module("3dal_pytorch_amd._hip")
 static_model = importlib.import_module("3dal_pytorch_amd.static_model")
 dynamic_model = importlib.import_module("3dal_pytorch_amd.dynamic_model")
@@ -26,7 +28,14 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib().dal3_version() == 120
+    assert hip.lib().dal3_version() == graft_entry.header_version()
+
+
+def test_build_entry_runs_and_agrees_with_the_header():
+    """The driver's own door: __graft_entry__.build() (make + import + version check against include/dal3.h). With
+    the objects already built, make is a no-op; from a clean tree this is the full gfx950 cross-compile."""
+    graft_entry.build()
+    assert graft_entry.header_version() >= 120
 
 
 def test_argument_errors_are_reported_without_a_gpu():
