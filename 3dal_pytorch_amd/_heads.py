@@ -118,9 +118,11 @@ class DynamicPointNetEstimation(_PointHead):
     HEAD_KIND = _hip.HEAD_DYNAMIC_BOX_EST
 
 
-# Bumped whenever ANY module registers a parameter or a buffer (assigning a new nn.Parameter to `conv.weight` goes through
-# register_parameter): a PackedCache's cached tensor lists carry the value they were built at and are rebuilt when it
-# moved — one integer compare per forward instead of a walk over the module tree.
+# Bumped whenever ANY module registers a parameter, a buffer or a SUBMODULE (assigning a new nn.Parameter to `conv.weight`
+# goes through register_parameter, `head.conv1 = nn.Conv1d(...)` through register_module): a PackedCache's cached tensor
+# lists carry the value they were built at and are rebuilt when it moved — one integer compare per forward instead of a
+# walk over the module tree. What still bypasses it: direct writes into `module._parameters[...]` / `_modules[...]`
+# (no hook fires) — call `model.invalidate_packed()` after those, as after `.data` writes.
 _REGISTRATION_EPOCH = [0]
 
 
@@ -130,6 +132,7 @@ def _bump_registration_epoch(*_a, **_k):
 
 nn.modules.module.register_module_parameter_registration_hook(_bump_registration_epoch)
 nn.modules.module.register_module_buffer_registration_hook(_bump_registration_epoch)
+nn.modules.module.register_module_module_registration_hook(_bump_registration_epoch)
 
 
 class PackedCache:

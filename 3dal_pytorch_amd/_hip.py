@@ -35,7 +35,7 @@ class PackItem(C.Structure):
 
 class BCN(C.Structure):
     _fields_ = [("data", vp), ("stride_b", C.c_int64), ("stride_c", C.c_int64), ("stride_n", C.c_int64),
-                ("dtype", C.c_int32), ("reserved", C.c_int32)]
+                ("dtype", C.c_int32), ("flags", C.c_int32)]
 
 
 class StaticArgs(C.Structure):
@@ -190,6 +190,10 @@ def require_gpu(t, what):
 
 
 STORAGE = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+BCN_NO_SMALL_JOB_KERNELS, BCN_NO_WORKLIST = 1, 2
+# dal3_bcn.flags of every view bcn() builds (include/dal3.h, DAL3_BCN_*). 0 in normal use; A/B measurements and the
+# tests that pin "both kernel families give the same bits" set it around a call (binding-side, the library has no switch).
+DISPATCH_FLAGS = 0
 
 
 def bcn(t):
@@ -197,7 +201,7 @@ def bcn(t):
     (no copy)."""
     assert t.dim() == 3 and t.dtype in STORAGE
     sb, sc, sn = t.stride()
-    return BCN(ptr(t), sb, sc, sn, STORAGE[t.dtype], 0)
+    return BCN(ptr(t), sb, sc, sn, STORAGE[t.dtype], DISPATCH_FLAGS)
 
 
 def layer_struct(conv, bn):

@@ -487,7 +487,7 @@ struct Carver {
     }
 };
 
-static BCN to_bcn(const dal3_bcn& t) { return BCN{t.data, t.stride_b, t.stride_c, t.stride_n, t.dtype}; }
+static BCN to_bcn(const dal3_bcn& t) { return BCN{t.data, t.stride_b, t.stride_c, t.stride_n, t.dtype, t.flags}; }
 
 static int check_bcn(const dal3_bcn& t, const char* what) {
     if (!t.data) return fail(DAL3_EINVAL, "%s: null data pointer", what);
@@ -495,6 +495,7 @@ static int check_bcn(const dal3_bcn& t, const char* what) {
     if (t.dtype != DAL3_F32 && t.dtype != DAL3_BF16 && t.dtype != DAL3_F16)
         return fail(DAL3_EINVAL, "%s: storage dtype %d is none of DAL3_F32 / DAL3_BF16 / DAL3_F16", what, t.dtype);
     if (t.dtype != DAL3_F32 && (reinterpret_cast<uintptr_t>(t.data) & 1)) return fail(DAL3_EINVAL, "%s: 16-bit data must be 2-byte aligned", what);
+    if (t.flags & ~(DAL3_BCN_NO_SMALL_JOB_KERNELS | DAL3_BCN_NO_WORKLIST)) return fail(DAL3_EINVAL, "%s: unknown bits in flags (%d)", what, t.flags);
     return 0;
 }
 
@@ -1385,7 +1386,7 @@ extern "C" int dal3_static_forward(const dal3_static_args* a, int phases, dal3_s
         return fail(DAL3_EINVAL, "static_forward: null pointer in box phase");
     TRY(gather_run(a->mask, a->pts, B, N, 3, M, a->sampler, a->choice, a->seed, a->item_offset, a->counts, a->obj_idx,
                    ws.obj, ws.pos, s));
-    const dal3_bcn obj{ws.obj, (int64_t)M * 3, 1, 3, DAL3_F32, 0};
+    const dal3_bcn obj{ws.obj, (int64_t)M * 3, 1, 3, DAL3_F32, a->pts.flags};
     // device sampler: the first min(count, M) object points are distinct, the rest are copies -> skipped by the head
     const int32_t* distinct = a->sampler == DAL3_SAMPLER_DEVICE ? a->counts : nullptr;
     // (the estimator's last FC layer and the decode of its output are one launch: fc39_decode_kernel)
@@ -1407,7 +1408,7 @@ extern "C" int dal3_static_forward(const dal3_static_args* a, int phases, dal3_s
     HIP_TRY(launch_recenter(ws.obj, B, M, a->init_box, a->box_one, a->bbox_gt, ws.obj2,
                             a->bbox_gt ? a->heading_class_label_two : nullptr,
                             a->bbox_gt ? a->heading_residuals_label_two : nullptr, s));
-    const dal3_bcn obj2{ws.obj2, (int64_t)M * 3, 1, 3, DAL3_F32, 0};
+    const dal3_bcn obj2{ws.obj2, (int64_t)M * 3, 1, 3, DAL3_F32, a->pts.flags};
     // center_two += center_one (static_model.py:211); final yaw += box_one yaw (static_eval.py:282)
     const DecodeArgs d2{a->box_pred_two, a->center_one, 3, 1, nullptr, 0, a->box_one + 6, 7,
                         a->heading_residuals_two, a->size_residuals_two, a->center_two, a->boxes7};
@@ -1454,7 +1455,7 @@ extern "C" int dal3_dynamic_forward(const dal3_dynamic_args* a, int phases, dal3
         return fail(DAL3_EINVAL, "dynamic_forward: null pointer in box phase");
     TRY(gather_run(a->mask, a->pts, B, N, 4, M, a->sampler, a->choice, a->seed, a->item_offset, a->counts, a->obj_idx,
                    ws.obj, ws.pos, s));
-    const dal3_bcn obj{ws.obj, (int64_t)M * 4, 1, 4, DAL3_F32, 0};
+    const dal3_bcn obj{ws.obj, (int64_t)M * 4, 1, 4, DAL3_F32, a->pts.flags};
     // embedding = cat[point_e (256), box_e (128)] (dynamic_model.py:133-137): written side by side
     TRY(point_head_run(DAL3_HEAD_POINT_EMB, a->w_point_emb, a->dtype, obj, B, M, a->embedding, 384, ws.head, s,
                        a->sampler == DAL3_SAMPLER_DEVICE ? a->counts : nullptr));

@@ -23,6 +23,7 @@ struct BCN {
     const float* data;
     int64_t sb, sc, sn;
     int dtype;
+    int flags;      // DAL3_BCN_* dispatch hints (host side only; the kernels never read it)
 };
 __device__ __forceinline__ float widen_bf16(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
 __device__ __forceinline__ float widen_f16(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }

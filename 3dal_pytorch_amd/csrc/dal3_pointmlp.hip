@@ -371,19 +371,14 @@ static inline int tiles_per_item(int n_pts, int T) {
 }
 
 // Which family runs: the latency kernels (dal3_latency.hip: a 16-wave workgroup per tile, one per CU) while the job has
-// at most DAL3_LAT_MAX_TILES tiles (default 512 = two rounds of workgroups on the 256 CUs), the throughput kernels
-// above that. Both give the same bits. DAL3_LAT_MAX_TILES=0 turns the latency family off (A/B measurements).
-bool lat_use(int64_t tiles) {
-    static int64_t limit = -1;
-    if (limit < 0) {
-        const char* e = getenv("DAL3_LAT_MAX_TILES");
-        limit = e ? atoll(e) : 512;
-    }
-    return tiles <= limit;
-}
+// at most DAL3_LAT_MAX_TILES tiles (512 = two rounds of workgroups on the 256 CUs), the throughput kernels above that.
+// Both give the same bits. A pure function of the job and of the caller's flags (dal3.h: DAL3_BCN_NO_SMALL_JOB_KERNELS):
+// no environment variable, no process-wide switch.
+static constexpr int64_t DAL3_LAT_MAX_TILES = 512;
+bool lat_use(int64_t tiles, int flags) { return !(flags & DAL3_BCN_NO_SMALL_JOB_KERNELS) && tiles <= DAL3_LAT_MAX_TILES; }
 
 hipError_t launch_ins_seg_encode(const InsSegW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
-    if (lat_use((int64_t)B * ((N + 31) / 32))) return launch_ins_seg_encode_lat(w, pts, c_in, B, N, g, s);
+    if (lat_use((int64_t)B * ((N + 31) / 32), pts.flags)) return launch_ins_seg_encode_lat(w, pts, c_in, B, N, g, s);
     constexpr int T = DAL3_ENC_T;
     // A wave runs its T tiles through the whole encoder one after the other (~150 us per tile at 2.4 GHz). When the
     // job cannot fill the chip's 1024 SIMDs anyway (small eval batches), one tile per wave halves that serial
@@ -400,7 +395,7 @@ hipError_t launch_ins_seg_encode(const InsSegW& w, BCN pts, int c_in, int B, int
 
 hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int N, const float* gbias,
                                  float* logits, uint8_t* mask, hipStream_t s) {
-    if (lat_use((int64_t)B * ((N + 31) / 32))) return launch_ins_seg_decode_lat(w, pts, c_in, B, N, gbias, logits, mask, s);
+    if (lat_use((int64_t)B * ((N + 31) / 32), pts.flags)) return launch_ins_seg_decode_lat(w, pts, c_in, B, N, gbias, logits, mask, s);
     constexpr int T = DAL3_DEC_T;
     const int tpi = tiles_per_item(N, T);
     hipLaunchKernelGGL(ins_seg_decode_kernel<T>, dim3((unsigned)((int64_t)B * tpi)), dim3(64 * DAL3_WG_WAVES), 0, s, w, pts, c_in, N, tpi,
@@ -411,35 +406,22 @@ hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int
 // bytes of the worklist a launch_point_head of (B items, M points) may need: ctl (2 words, padded) + one entry per tile
 size_t point_head_worklist_bytes(int B, int M) { return 256 + (size_t)B * ((M + 31) / 32) * sizeof(u32x4); }
 
-// persistent one-wave workgroups the chip holds at this kernel's register count (one wave per SIMD): 4 per CU
+// persistent one-wave workgroups the CURRENT device holds at this kernel's register count (one wave per SIMD): 4 per
+// CU. Asked per call: hipGetDevice + hipDeviceGetAttribute are host-side table lookups (~0.1 us), and a process that
+// drives several devices gets each one's own count.
 static int head_slots() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        n = 4 * v;
-    }
-    return n;
-}
-
-// DAL3_HEAD_WORKLIST=0: the one-workgroup-per-(item, tile) kernel for every job (A/B measurements); default: the
-// worklist kernel whenever the caller gave room for the list
-static bool head_worklist_on() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("DAL3_HEAD_WORKLIST");
-        on = !(e && e[0] == '0');
-    }
-    return on != 0;
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+        v = 256;
+    return 4 * v;
 }
 
 hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat,
                              const int32_t* distinct, hipStream_t s, void* worklist, size_t worklist_bytes) {
     constexpr int T = DAL3_HEAD_T;
     const int tpi = (M + 32 * T - 1) / (32 * T);       // one-wave workgroups
-    const bool lat = lat_use((int64_t)B * ((M + 31) / 32));
-    const bool pers = !lat && worklist && worklist_bytes >= point_head_worklist_bytes(B, M) && head_worklist_on() && T == 1;
+    const bool lat = lat_use((int64_t)B * ((M + 31) / 32), x.flags);
+    const bool pers = !lat && worklist && worklist_bytes >= point_head_worklist_bytes(B, M) && !(x.flags & DAL3_BCN_NO_WORKLIST) && T == 1;
     // feat = 0 (NaN rows for items with a non-finite input, dal3.h) and, for the persistent kernel, the worklist
     hipError_t e0 = launch_nonfinite_rows(x, B, M, c_in, feat, 512, s, distinct, pers ? worklist : nullptr);
     if (e0 != hipSuccess) return e0;
@@ -448,7 +430,8 @@ hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in
         uint32_t* ctl = static_cast<uint32_t*>(worklist);
         u32x4* list = reinterpret_cast<u32x4*>(static_cast<char*>(worklist) + 256);
         const int64_t tiles = (int64_t)B * tpi;
-        const dim3 grid((unsigned)(tiles < head_slots() ? tiles : head_slots())), block(64);
+        const int64_t slots = head_slots();
+        const dim3 grid((unsigned)(tiles < slots ? tiles : slots)), block(64);
         switch (head_kind) {
             case 1:
                 hipLaunchKernelGGL((point_head_pers_kernel<2, 128, 128, 256>), grid, block, 0, s, w, x, c_in, feat, ctl, list);

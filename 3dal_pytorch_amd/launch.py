@@ -84,14 +84,17 @@ def spawn_ranks(script, argv, nproc, need_gpus=True, env=None, timeout=None, sha
             sys.stderr.write(f"{os.path.basename(script)}: needs {nproc} GPUs, this machine shows {have}\n")
             return 2, ""
     e = dict(os.environ if env is None else env)
-    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs between ranks on this driver
+    # dmabuf IPC between the ranks' HIP runtimes: the only flavour this pool's host driver implements (see bench.py);
+    # a value the caller exported wins
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     e.setdefault("OMP_NUM_THREADS", "4")                     # torch.distributed.run would set 1 and warn
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         e.pop(k, None)
     rc, out = 1, []
     for attempt in range(3):
+        port = free_port()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+               "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
         p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, text=True, bufsize=1,
                              start_new_session=True)
         out, err = [], []
@@ -110,11 +113,23 @@ def spawn_ranks(script, argv, nproc, need_gpus=True, env=None, timeout=None, sha
             raise
         for t in pumps:
             t.join(timeout=5.0)
-        in_use = rc not in (0, 124) and any("address already in use" in ln.lower() or "EADDRINUSE" in ln for ln in err)
-        if not in_use:
+        if not rendezvous_port_was_taken(rc, port, err, out):
             break
-        sys.stderr.write(f"{os.path.basename(script)}: rendezvous port taken by another job, retrying ({attempt + 1}/3)\n")
+        sys.stderr.write(f"{os.path.basename(script)}: rendezvous port {port} taken by another job, retrying ({attempt + 1}/3)\n")
     return rc, "".join(out)
+
+
+def rendezvous_port_was_taken(rc, port, stderr_lines, stdout_lines):
+    """True only for the one failure a re-launch can cure: torch.distributed.run could not bind ITS rendezvous store to
+    the port picked for it (free_port closes its socket before the launcher binds — another job can take the port in
+    between). c10d reports that as one line naming the port ("... port: 29500 ... EADDRINUSE ... address already in
+    use"), before any rank has started, so the job has printed nothing. An 'address already in use' from anything else — a
+    rank's own server, gloo's secondary sockets, a different port — is the job's own failure: it is passed on, not
+    re-run (a blanket match re-ran whole multi-rank jobs up to three times)."""
+    if rc in (0, 124) or any(ln.strip() for ln in stdout_lines):
+        return False
+    tag = f"port: {port}"
+    return any(tag in ln and ("EADDRINUSE" in ln or "address already in use" in ln.lower()) for ln in stderr_lines)
 
 
 def relay_json_line(stdout):

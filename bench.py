@@ -39,7 +39,12 @@ import os
 import sys
 import time
 
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL needs between ranks on this driver
+# RCCL shares device buffers between the ranks of a node through HIP IPC handles. The host driver of this pool (ROCm 7.2
+# user space on the MI355X boxes) implements only the dmabuf flavour; with the legacy flavour (the runtime's default)
+# hipIpcGetMemHandle fails with "invalid argument" as soon as two ranks connect. The pool exports the variable itself;
+# setdefault keeps a value the caller exported (a driver that wants the legacy mode sets HSA_ENABLE_IPC_MODE_LEGACY=1)
+# and only fills it in for a shell that lost it. It must be set before the HSA runtime loads, hence at import time.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np                                           # noqa: E402
 import torch                                                 # noqa: E402
@@ -447,24 +452,42 @@ class Workload:
         self.gatherers = None
 
 
+def c4_segment_sizes():
+    """198 frames; 64 static tracks -> 64 crops at N=4096; 40 dynamic tracks with lengths
+    rng.integers(20,199) -> one item per track-frame"""
+    lens = np.random.default_rng(10922081).integers(20, 199, size=40)
+    return 64, int(lens.sum())
+
+
+def workload_shards(args, world):
+    """[(head, items of the whole job, rank -> (first item, count))] of the configured workload: the ONE place a bench
+    workload's sharding is written. build_workload (the GPU run) and plumbing_only (the CPU rehearsal of the N > 1 path,
+    world 8 in tests/test_launch_cpu.py) both read it. C4 is a fixed segment split in contiguous index ranges (strong
+    scaling, ragged last rank); every other config gives each rank its own B items (weak scaling)."""
+    def span(n):
+        return lambda r: (lambda lo, hi: (lo, hi - lo))(*dal3_dist.shard_range(n, r, world))
+    if args.config == "C4":
+        n_static, n_dyn = c4_segment_sizes()
+        return [("static", n_static, span(n_static)), ("dynamic", n_dyn, span(n_dyn))]
+    static = args.head == "static"
+    B = args.batch or (4096 if static else 1024)
+    return [("static" if static else "dynamic", B * world, lambda r: (r * B, B))]
+
+
 def build_workload(args, dev, rank, world):
     wl = Workload()
     prec = args.precision
     if args.config == "C4":
-        # 198 frames; 64 static tracks -> 64 crops at N=4096; 40 dynamic tracks with lengths
-        # rng.integers(20,199) -> one item per track-frame; contiguous index sharding, static and dynamic batches
-        # back to back, one all-gather per head. The segment is fixed: strong scaling.
-        lens = np.random.default_rng(10922081).integers(20, 199, size=40)
-        n_static, n_dyn = 64, int(lens.sum())
-        s_lo, s_hi = dal3_dist.shard_range(n_static, rank, world)
-        d_lo, d_hi = dal3_dist.shard_range(n_dyn, rank, world)
+        # contiguous index sharding, static and dynamic batches back to back, one all-gather per head. The segment is
+        # fixed: strong scaling.
+        (_, n_static, s_span), (_, n_dyn, d_span) = workload_shards(args, world)
+        (s_lo, s_n), (d_lo, d_n) = s_span(rank), d_span(rank)
+        s_hi, d_hi = s_lo + s_n, d_lo + d_n
         smodel, sin, _ = make_static(max(s_hi - s_lo, 1), 4096, dev, s_lo, prec)
         dmodel, din = make_dynamic(max(d_hi - d_lo, 1), dev, d_lo, prec)
-        wl.parts = [Part("static", smodel, sin, s_hi - s_lo, n_static,
-                         lambda r: (lambda lo, hi: (lo, hi - lo))(*dal3_dist.shard_range(n_static, r, world)),
+        wl.parts = [Part("static", smodel, sin, s_hi - s_lo, n_static, s_span,
                          lambda first, count: static_inputs(first, count, 4096, dev, prec)),
-                    Part("dynamic", dmodel, din, d_hi - d_lo, n_dyn,
-                         lambda r: (lambda lo, hi: (lo, hi - lo))(*dal3_dist.shard_range(n_dyn, r, world)),
+                    Part("dynamic", dmodel, din, d_hi - d_lo, n_dyn, d_span,
                          lambda first, count: dynamic_inputs(first, count, 1024, dev, prec))]
         wl.model, wl.inputs, wl.host, wl.static = smodel, None, None, False
         wl.B, wl.N = (s_hi - s_lo) + (d_hi - d_lo), 0
@@ -491,7 +514,7 @@ def build_workload(args, dev, rank, world):
         flop_item = arch.dynamic_flop(N)
         desc = (f"DynamicModel forward+decode, {B} items x {N} pts + 101 boxes per GPU, {prec} arithmetic"
                 + (" (BASELINE.json configs[2])" if (B, N, prec) == (1024, 5120, "bf16") else ""))
-    wl.parts = [Part("static" if static else "dynamic", model, inputs, B, B * world, lambda r: (r * B, B),
+    wl.parts = [Part("static" if static else "dynamic", model, inputs, B, B * world, workload_shards(args, world)[0][2],
                      (lambda first, count: static_inputs(first, count, N, dev, prec)) if static else
                      (lambda first, count: dynamic_inputs(first, count, args.points, dev, prec)))]
     wl.model, wl.inputs, wl.host, wl.static = model, inputs, host, static
@@ -657,37 +680,55 @@ def plumbing_only(args, rank, world):
     """No GPU work: every rank makes the boxes a refine() of its shard would return (a function of the global item
     index), the launcher / process-group / gather path runs on DAL3_BENCH_BACKEND (gloo on CPU), and rank 0 prints a
     line whose `value` is null — with the fields a real N > 1 line carries (per-rank step times, the replicated
-    weight, the self-check of another rank's rows). What tests/test_launch_cpu.py drives at world size 2."""
+    weight, the self-check of other ranks' rows). Without --config: one 37-item head (ragged over any world size).
+    With --config C2 / C3 / C4 / C5: that workload's heads, item counts and rank -> range map (workload_shards, the
+    same function the GPU run shards with) — what tests/test_launch_cpu.py drives at world sizes 2 and 8."""
     backend = os.environ.get("DAL3_BENCH_BACKEND", "gloo")
     torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     cpu = torch.device("cpu")
-    n_total = 37
+    if args.config is None:
+        n = 37
+        shards = [("stub", n, lambda r: (lambda lo, hi: (lo, hi - lo))(*dal3_dist.shard_range(n, r, world)))]
+        scaling = "strong"
+    else:
+        apply_config(args)
+        shards = workload_shards(args, world)
+        scaling = "strong" if args.config == "C4" else "weak"
 
     class _Stub:                                            # refine() stand-in: boxes = f(global item index, bias)
         item_offset = 0
-        bias = torch.tensor([1.0 + rank])                  # rank-dependent until replicated
+
+        def __init__(self, salt):
+            self.salt = salt
+            self.bias = torch.tensor([1.0 + rank])          # rank-dependent until replicated
 
         def refine(self, idx):
-            return idx[:, None] * 10 + torch.arange(7, dtype=torch.float32)[None] + self.bias
-    stub = _Stub()
-    dal3_dist.replicate_(stub.bias)
-    lo, hi = dal3_dist.shard_range(n_total, rank, world)
+            return idx[:, None] * 10 + torch.arange(7, dtype=torch.float32)[None] + self.bias + self.salt
+
+    def idx(first, count):
+        return (torch.arange(first, first + count, dtype=torch.float32),)
     wl = Workload()
-    wl.parts = [Part("stub", stub, (torch.arange(lo, hi, dtype=torch.float32),), hi - lo, n_total,
-                     lambda r: (lambda a, b: (a, b - a))(*dal3_dist.shard_range(n_total, r, world)),
-                     lambda first, count: (torch.arange(first, first + count, dtype=torch.float32),))]
-    g = dal3_dist.BoxGatherer(n_total, cpu)
-    got = None
+    for k, (name, n_total, span) in enumerate(shards):
+        stub = _Stub(100.0 * k)
+        dal3_dist.replicate_(stub.bias)
+        lo, cnt = span(rank)
+        wl.parts.append(Part(name, stub, idx(lo, cnt), cnt, n_total, span, idx))
+    gatherers = [dal3_dist.BoxGatherer(p.n_total, cpu) for p in wl.parts]
+    got = [None] * len(wl.parts)
     t0 = time.perf_counter()
-    for _ in range(3):
-        g.submit(wl.parts[0].run())
-        r = g.collect(keep=1)
-        got = r if r is not None else got
-    got = g.collect(keep=0)
-    wl.last_boxes = [got]
+    for _ in range(3):                                      # the step loop of time_steps: submit, collect one step later
+        for i, p in enumerate(wl.parts):
+            gatherers[i].submit(p.run())
+            r = gatherers[i].collect(keep=1)
+            got[i] = r if r is not None else got[i]
+    got = [g.collect(keep=0) for g in gatherers]
+    wl.last_boxes = got
     rank_ms = [round(t * 1e3, 3) for t in dal3_dist.gather_scalars(time.perf_counter() - t0, cpu)]
-    want = torch.arange(n_total, dtype=torch.float32)[:, None] * 10 + torch.arange(7, dtype=torch.float32)[None] + 1.0
-    ok = bool(torch.equal(got, want)) and bool(torch.equal(dal3_dist.all_gather_boxes(wl.parts[0].run(), n_total), want))
+    ok = True
+    for k, (p, g) in enumerate(zip(wl.parts, got)):
+        want = torch.arange(p.n_total, dtype=torch.float32)[:, None] * 10 + torch.arange(7, dtype=torch.float32)[None] + 1.0 + 100.0 * k
+        ok = ok and g.shape == (p.n_total, 7) and bool(torch.equal(g, want))
+        ok = ok and bool(torch.equal(dal3_dist.all_gather_boxes(p.run(), p.n_total), want))
     check = gather_self_check(wl, cpu, rank, world, rows=5)
     census = dal3_dist.world_census(cpu)
     if os.environ.get("DAL3_BENCH_FAIL_RANK") == str(rank):          # the launcher's failure path, for its test
@@ -698,7 +739,10 @@ def plumbing_only(args, rank, world):
     torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "object-crops/sec through static+dynamic refinement heads", "value": None,
-                          "plumbing_only": True, "n_gpus": world, "gathered_ok": ok, "rccl": census,
+                          "plumbing_only": True, "n_gpus": world, "gathered_ok": ok, "rccl": census, "scaling": scaling,
+                          "config": {"workload": args.config or "stub", "heads": [
+                              {"head": p.name, "items": p.n_total, "items_per_rank": [p.shard(r)[1] for r in range(world)]}
+                              for p in wl.parts]},
                           "ms_per_step_per_rank": rank_ms, "gather_equals_single_rank": check["equal"] if check else None,
                           "gather_self_check": check}), flush=True)
     sys.exit(0 if ok else 4)
@@ -761,8 +805,9 @@ def main():
     n_dev = torch.cuda.device_count()
     if share_gpu and n_dev > 0:
         local = local % n_dev
-    if n_dev <= local:
-        sys.exit(f"bench.py: needs {max(args.gpus, local + 1)} GPUs, this machine shows {n_dev}")
+    if n_dev <= local:                                      # a rank started by a launcher on a box with too few GPUs: the same
+        sys.stderr.write(f"bench.py: needs {max(args.gpus, local + 1)} GPUs, this machine shows {n_dev}\n")   # line and exit code
+        sys.exit(2)                                         # as the self-launching parent gives (launch.spawn_ranks)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # DAL3_FORCE_DIST=1 runs the RCCL path even with one rank (exercises init + all-gather on a 1-GPU box)

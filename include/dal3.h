@@ -107,8 +107,16 @@ typedef struct {
     const float* data;
     int64_t stride_b, stride_c, stride_n;
     int32_t dtype;
-    int32_t reserved;
+    int32_t flags;                       /* 0, or DAL3_BCN_* dispatch hints for the call this view is the input of */
 } dal3_bcn;
+
+/* Per-call dispatch hints (dal3_bcn.flags; dal3_static_args / dal3_dynamic_args take them from args.pts.flags for every
+ * kernel of the call). Which kernel family runs is a function of the job's size and of these bits ONLY — the library
+ * reads no environment variable and keeps no process-wide switch. Results are bit-identical either way; the bits exist
+ * for A/B measurements and for the tests that pin that identity (tests/test_gpu_latency.py, test_gpu_parity.py).
+ *   DAL3_BCN_NO_SMALL_JOB_KERNELS  never the small-job ("latency") family (jobs of <= 512 tiles of 32 points)
+ *   DAL3_BCN_NO_WORKLIST           point heads: one workgroup per (item, tile) instead of the live-tile worklist */
+enum { DAL3_BCN_NO_SMALL_JOB_KERNELS = 1, DAL3_BCN_NO_WORKLIST = 2 };
 
 /* ---- PointNetInstanceSeg.forward (static_model.py:271-296, dynamic_model.py:187-212) plus
  * the mask of point_cloud_masking (static_model.py:59). logits (B,N,2) fp32, mask (B,N) u8.

@@ -132,7 +132,7 @@ def _gatherer_worker(rank, world, port, n_items, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_items", [(2, 9), (3, 4)])
+@pytest.mark.parametrize("world,n_items", [(2, 9), (3, 4), (8, 61)])
 def test_box_gatherer_pipelines_steps_in_order(world, n_items):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

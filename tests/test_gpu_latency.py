@@ -1,18 +1,18 @@
 """The latency kernels (csrc/dal3_latency.hip: small jobs, one 16-wave workgroup per 32-point tile, activations
 through LDS) against the throughput kernels (one wave per tile, activations in registers): the dispatch between the
 two families must be invisible — bit-identical logits, masks, counts, drawn indices, box parameters and refined boxes.
-The throughput family's outputs are computed in a child process with DAL3_LAT_MAX_TILES=0 (the dispatch rule is read
-once per process); both are pinned to the oracle elsewhere (tests/test_gpu_parity.py runs the small fixtures through
+The throughput family's outputs come from the same calls with DAL3_BCN_NO_SMALL_JOB_KERNELS in dal3_bcn.flags (the
+dispatch is a function of the job size and of that per-call bit; the library reads no environment); both are pinned to the oracle elsewhere (tests/test_gpu_parity.py runs the small fixtures through
 the latency family now, the large ones through the throughput family)."""
-import os
-import subprocess
-import sys
-
 import numpy as np
 import pytest
 import torch
 
-from _common import ROOT, build_model, synth
+import importlib
+
+from _common import build_model, synth
+
+hip = importlib.import_module("3dal_pytorch_amd._hip")
 
 pytestmark = pytest.mark.gpu
 
@@ -34,35 +34,32 @@ def _run(kind, B, N):
     return {k: v.cpu().numpy() for k, v in o.items() if torch.is_tensor(v)}
 
 
-CHILD = r"""
-import os, sys, numpy as np
-sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
-import test_gpu_latency as T
-out = {}
-for kind, B, N in T.CASES:
-    for k, v in T._run(kind, B, N).items():
-        out[f"{kind}_{B}_{N}_{k}"] = v
-np.savez(%(path)r, **out)
-"""
-
-
-def test_latency_family_equals_throughput_family_bitwise(tmp_path):
-    path = str(tmp_path / "throughput.npz")
-    env = dict(os.environ, DAL3_LAT_MAX_TILES="0")
-    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "path": path}], capture_output=True, text=True, env=env,
-                       timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    want = np.load(path)
-    assert os.environ.get("DAL3_LAT_MAX_TILES") is None, "this process must run the default dispatch"
+def test_latency_family_equals_throughput_family_bitwise():
+    want = {}
+    hip.DISPATCH_FLAGS = hip.BCN_NO_SMALL_JOB_KERNELS        # dal3_bcn.flags: the throughput family for every kernel of the call
+    try:
+        for kind, B, N in CASES:
+            want[kind, B, N] = _run(kind, B, N)
+    finally:
+        hip.DISPATCH_FLAGS = 0
     n = 0
     for kind, B, N in CASES:
         got = _run(kind, B, N)
         for k, v in got.items():
-            w = want[f"{kind}_{B}_{N}_{k}"]
+            w = want[kind, B, N][k]
             assert v.shape == w.shape and v.dtype == w.dtype, (kind, B, N, k)
             assert np.array_equal(v, w, equal_nan=True), (kind, B, N, k, float(np.abs(v.astype(np.float64) - w).max()))
             n += 1
     assert n >= 50
+
+
+def test_unknown_dispatch_flag_bits_are_rejected():
+    p, _, _ = synth.static_crops(1, 64, seed=1)
+    v = hip.bcn(torch.from_numpy(p).cuda().transpose(2, 1))
+    v.flags = 4
+    g = torch.zeros((1, 1024), device="cuda")
+    assert hip.lib().dal3_ins_seg_encode(hip.ptr(g), hip.F32, 3, v, 1, 64, hip.ptr(g), hip.stream()) == hip.EINVAL
+    assert b"flags" in hip.lib().dal3_last_error()
 
 
 def test_small_job_latency_is_below_the_single_wave_chain():

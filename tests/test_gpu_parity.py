@@ -504,8 +504,14 @@ def test_point_head_on_the_live_tile_worklist_equals_the_per_tile_launch_bitwise
                                            hip.ptr(ws), ws.numel(), hip.stream()))
         hip.check(lib.dal3_point_head_pool(mod.HEAD_KIND, hip.ptr(w), dt, bcn, B, M, hip.ptr(distinct), hip.ptr(f_tile),
                                            None, 0, hip.stream()))
+        # ... and with the workspace given but DAL3_BCN_NO_WORKLIST in the view's flags (the per-call dispatch hint)
+        f_flag = torch.empty((B, 512), device="cuda")
+        bcn_flag = hip.bcn(xs.transpose(2, 1))
+        bcn_flag.flags = hip.BCN_NO_WORKLIST
+        hip.check(lib.dal3_point_head_pool(mod.HEAD_KIND, hip.ptr(w), dt, bcn_flag, B, M, hip.ptr(distinct), hip.ptr(f_flag),
+                                           hip.ptr(ws), ws.numel(), hip.stream()))
         torch.cuda.synchronize()
-        assert torch.equal(f_list, f_tile)
+        assert torch.equal(f_list, f_tile) and torch.equal(f_list, f_flag)
         assert float(f_list.abs().max()) > 0
     # skipping the copies changes nothing: the run with counts equals the run that computes every point
     f_all = torch.empty((B, 512), device="cuda")

@@ -206,6 +206,12 @@ def test_packed_cache_stamps_follow_parameter_identity():
     assert cache._stamp_of(m.box_est, 0) == s1            # invisible: the documented case for invalidate_packed()
     m.load_state_dict(m.state_dict())
     assert cache._stamp_of(m.box_est, 0) != s1
+    # a submodule replaced AFTER the tensor list was built at the current epoch: the new conv is constructed
+    # first (its parameters bump the epoch), a stamp is taken (list rebuilt with the OLD conv), then it is assigned
+    new_fc = torch.nn.Linear(m.box_est.fc3.in_features, m.box_est.fc3.out_features)
+    s2 = cache._stamp_of(m.box_est, 0)
+    m.box_est.fc3 = new_fc
+    assert cache._stamp_of(m.box_est, 0) != s2
     # the hooks empty the model's own cache
     m._cache._stamp["x"], m._cache._blob["x"], m._cache._src["x"] = (1,), None, (m.box_est, 0)
     m.load_state_dict(m.state_dict())

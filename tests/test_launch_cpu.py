@@ -16,7 +16,8 @@ BENCH = os.path.join(ROOT, "bench.py")
 
 def _env(**extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(DAL3_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2", **extra)
+    env.update(DAL3_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
+    env.update(extra)
     return env
 
 
@@ -27,6 +28,55 @@ def test_bench_without_enough_gpus_fails_cleanly():
     assert out.returncode != 0
     assert "needs 2 GPUs" in out.stderr, out.stderr[-1000:]
     assert out.stdout.strip() == ""
+
+
+def test_eight_ranks_on_a_box_without_eight_gpus_exit_2_with_one_line():
+    """what the driver's `bench.py --gpus 8` meets on a smaller box: exit code 2, ONE line on stderr, nothing on stdout —
+    from the self-launching parent, and from a rank that a launcher started (LOCAL_RANK beyond the devices)"""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8"], capture_output=True, text=True, env=_env(), timeout=300)
+    assert out.returncode == 2 and out.stdout.strip() == ""
+    assert [ln for ln in out.stderr.splitlines() if ln.strip()] == ["bench.py: needs 8 GPUs, this machine shows 0"], out.stderr
+    env = _env(RANK="7", LOCAL_RANK="7", WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(launch.free_port()))
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 2 and out.stdout.strip() == ""
+    assert "bench.py: needs 8 GPUs, this machine shows 0" in out.stderr
+
+
+def test_eight_ranks_c2_weak_and_c4_ragged_on_gloo():
+    """the 8-rank job as the driver will start it (`bench.py --gpus 8`), rehearsed on gloo with the
+    workloads' real item counts and rank -> range maps (bench.workload_shards — the function the GPU run shards with):
+    C2 = 4096 crops per rank (weak), C4 = one segment of 64 static crops (8 per rank) + 4,531 dynamic track-frames
+    (567 per rank, 562 on the last). Every rank takes part, the gathered boxes equal the single-process result, and
+    rank 0's recomputation of rank 1's and rank 7's first rows equals what the gather delivered."""
+    for config, want_heads in (("C2", [("static", 8 * 4096, [4096] * 8)]),
+                               ("C4", [("static", 64, [8] * 8), ("dynamic", 4531, [567] * 7 + [562])])):
+        out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--plumbing-only", "--config", config],
+                             capture_output=True, text=True, env=_env(OMP_NUM_THREADS="1"), timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, out.stdout
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 8 and rec["gathered_ok"] is True
+        assert rec["rccl"] == {"backend": "gloo", "world_size": 8, "ranks_counted": 8}
+        assert rec["scaling"] == ("strong" if config == "C4" else "weak")
+        heads = [(h["head"], h["items"], h["items_per_rank"]) for h in rec["config"]["heads"]]
+        assert heads == want_heads, heads
+        assert len(rec["ms_per_step_per_rank"]) == 8
+        assert rec["gather_equals_single_rank"] is True
+        peers = sorted((c["head"], c["peer"]) for c in rec["gather_self_check"]["checks"])
+        assert peers == sorted((h, p) for h, _, _ in want_heads for p in (1, 7))
+        assert all(c["equal"] and c["rows"] == 5 for c in rec["gather_self_check"]["checks"])
+
+
+def test_rendezvous_retry_only_for_the_launchers_own_port():
+    """only torch.distributed.run failing to bind the port picked for it is re-launched; any other 'address
+    already in use' (a rank's own server, another port, a job that already printed) is the job's failure"""
+    line = "[E] The server socket has failed to listen on any local network address. port: 29611, useIpv6: 0, code: -98, name: EADDRINUSE, message: address already in use\n"
+    assert launch.rendezvous_port_was_taken(1, 29611, [line], [])
+    assert not launch.rendezvous_port_was_taken(1, 29612, [line], [])                     # some other port
+    assert not launch.rendezvous_port_was_taken(1, 29611, ["OSError: [Errno 98] Address already in use\n"], [])
+    assert not launch.rendezvous_port_was_taken(1, 29611, [line], ['{"value": 1}\n'])      # the job had got going
+    assert not launch.rendezvous_port_was_taken(0, 29611, [line], []) and not launch.rendezvous_port_was_taken(124, 29611, [line], [])
 
 
 def test_bench_self_launches_two_ranks_and_relays_one_line():
