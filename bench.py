@@ -630,6 +630,42 @@ def gather_latency(wl, dev, iters=50):
     return [round(t * 1e3, 1) for t in outs]
 
 
+def accuracy_vs_fp32_path(model, inputs, prec):
+    """What `prec` costs on THIS input, next to its throughput: the same launch in the exact-fp32 arithmetic
+    (1e-6 from the reference's PyTorch-CPU forward, tests/test_gpu_parity.py) is the yardstick. Three runs of the whole
+    path: fp32; `prec` free-running (its own mask, its own draws); `prec` with the fp32 run's mask forced
+    (mask_override: the device sampler, keyed on the item and the count, then draws the very same points), which
+    isolates the box estimator's error from the discrete effect of a flipped point. Box error per parameter group:
+    centre (m, absolute), size (relative to the largest size), yaw (rad, absolute)."""
+    keep = model.precision
+    with torch.no_grad():
+        model.precision = "fp32"
+        ref = model._run(*inputs)
+        model.precision = prec
+        got = model._run(*inputs)
+        forced = model._run(*inputs, mask_override=ref["mask"])
+    model.precision = keep
+    assert torch.equal(forced["obj_idx"], ref["obj_idx"])
+    B = ref["mask"].shape[0]
+    same = (ref["mask"] == got["mask"]).all(1)
+    flipped = int((ref["mask"] != got["mask"]).sum())
+
+    def box_err(a, b):
+        d = (a.double() - b.double()).abs()
+        return {"centre_m_max_abs": round(d[:, :3].max().item(), 6),
+                "size_max_rel": round((d[:, 3:6].max() / b[:, 3:6].abs().max()).item(), 6),
+                "yaw_rad_max_abs": round(d[:, 6].max().item(), 6),
+                "centre_m_median_abs": round(d[:, :3].max(1).values.median().item(), 6)}
+    bp = "bp1" if "bp1" in ref else "bp"
+    return {"logits_max_rel": round(((ref["logits"] - got["logits"]).abs().max() / ref["logits"].abs().max()).item(), 6),
+            "mask_bits_flipped": flipped, "mask_bits": int(ref["mask"].numel()),
+            "mask_agreement": round(1.0 - flipped / ref["mask"].numel(), 6),
+            "crops_with_identical_mask": int(same.sum()), "crops": B,
+            "box_params_max_rel_fp32_mask_forced": round(((ref[bp] - forced[bp]).abs().max() / ref[bp].abs().max()).item(), 6),
+            "boxes7_fp32_mask_forced": box_err(forced["boxes7"], ref["boxes7"]),
+            "boxes7_free_running": box_err(got["boxes7"], ref["boxes7"])}
+
+
 def other_config(name, dev, steps):
     """one of BASELINE.json's other configurations on this GPU: whole-path rate (same step definition)"""
     ns = argparse.Namespace(config=name, head="static", precision="fp32", batch=0, points=1024, two_stage=False)
@@ -648,6 +684,8 @@ def other_config(name, dev, steps):
         kr, _ = kernel_table(wl.model, wl.inputs, wl.static, wl.B, wl.N, iters=max(3, min(steps, 5)))
         r["whole_path_mfma_frac_executed"] = round(executed_gflop_per_step(kr, wl.static, wl.B) / ms / peak, 4)
         r["roofline"] = roofline_of(kr, peak, ns.precision, wl.B, wl.N, tag="_" + name.lower() if name in ("C3", "C5") else "")
+        if ns.precision in ("bf16", "fp16"):                # a 16-bit rate is half a result without its error on the same input
+            r["vs_exact_fp32_path"] = accuracy_vs_fp32_path(wl.model, wl.inputs, ns.precision)
     del wl
     torch.cuda.empty_cache()
     return r
@@ -910,6 +948,7 @@ def main():
                                         "whole_path_mfma_frac_executed": round(
                                             executed_gflop_per_step(k2, static, B) / (d * 1e3) / MFMA_PEAK_TFLOPS[prec], 4),
                                         "roofline": roofline_of(k2, MFMA_PEAK_TFLOPS[prec], prec, B, N),
+                                        "vs_exact_fp32_path": accuracy_vs_fp32_path(model, inputs, prec),
                                         "kernels": k2}
             # the fp32 formulation on the fp16 MFMA: every operand as an (hi, lo) fp16 pair, three MFMAs per product,
             # fp32 accumulate. Its distance from the exact-fp32 path is measured here on this very
