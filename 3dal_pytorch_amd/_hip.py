@@ -114,6 +114,11 @@ SIGNATURES = {
     "dal3_tr_box_loss": (_i, [vp] * 10 + [_i] + [vp] * 7),
     "dal3_tr_seg_ce_workspace_bytes": (_sz, [_i64]),
     "dal3_tr_seg_ce": (_i, [vp, vp, _i, _i64, vp, vp, vp, _sz, vp]),
+    "dal3_tr_linear_red_workspace_bytes": (_sz, [_i64, _i]),
+    "dal3_tr_linear_bn_stats": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, vp, _i64, _i, vp, _i64, vp, _i64, vp, vp, vp, vp,
+                                     C.c_float, C.c_float, vp, vp, vp, vp, vp, _sz, vp]),
+    "dal3_tr_linear_bnbwd_sums": (_i, [vp, _i64, _i, _i64, vp, _i64, _i, vp, _i64, vp, _i64, vp, _i64, vp, vp, vp, vp, vp,
+                                       vp, vp, vp, vp, vp, vp, _sz, vp]),
     "dal3_tr_bn_stats": (_i, [vp, _i64, _i, _i64, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, _sz, vp]),
     "dal3_tr_bnbwd_sums": (_i, [vp, _i64, _i, _i64, vp, _i64, vp, vp, _i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, _sz,
                                 vp]),

@@ -968,6 +968,58 @@ extern "C" int dal3_tr_linear_prepacked(const float* a, int64_t M, int c_in, int
     return 0;
 }
 
+extern "C" size_t dal3_tr_linear_red_workspace_bytes(int64_t rows, int c_out) {
+    if (rows <= 0 || c_out <= 0) return 0;
+    const size_t a = tr_colred_workspace_bytes(rows, c_out), b = tr_linear_red_workspace_bytes();
+    return a > b ? a : b;
+}
+
+static int tr_linear_red_args_ok(const float* a, int64_t M, int c_in, int64_t lda, int c_out, const float* z, int64_t ldz,
+                                 const void* packed, int64_t rows) {
+    return a && z && mult32(M) && mult32(c_in) && mult32(c_out) && lda >= c_in && ldz >= c_out && lda % 4 == 0 && ldz % 4 == 0 &&
+           packed && !(reinterpret_cast<uintptr_t>(packed) & 15) && rows >= 2 && rows <= M;
+}
+
+extern "C" int dal3_tr_linear_bn_stats(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                                       int relu_in, const float* W, int64_t ldw, const float* bias, int64_t seg, int c_out,
+                                       float* z, int64_t ldz, const void* packed, int64_t rows, const float* gamma,
+                                       const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                       float* mu, float* rstd, float* bn_scale, float* bn_shift, void* workspace,
+                                       size_t workspace_bytes, dal3_stream stream) {
+    if (!tr_linear_red_args_ok(a, M, c_in, lda, c_out, z, ldz, packed, rows) || !W || (scale && !shift) || seg < 0 || !gamma ||
+        !beta || !mu || !rstd || !bn_scale || !bn_shift || (!running_mean != !running_var))
+        return fail(DAL3_EINVAL, "tr_linear_bn_stats: bad argument");
+    if (tr_linear_pack_mtb(M, c_in, seg, c_out, 0, scale != nullptr) == 0)
+        return fail(DAL3_EINVAL, "tr_linear_bn_stats: this call reads no packed image (dal3_tr_linear_pack_layout() == 0)");
+    if (!workspace || workspace_bytes < dal3_tr_linear_red_workspace_bytes(rows, c_out))
+        return fail(DAL3_EWORKSPACE, "tr_linear_bn_stats: workspace smaller than dal3_tr_linear_red_workspace_bytes()");
+    int fused = 0;
+    HIP_TRY(launch_tr_linear_bn_stats(a, M, c_in, lda, scale, shift, relu_in, W, ldw, bias, seg, c_out, z, ldz,
+                                      const_cast<float*>(static_cast<const float*>(packed)), rows, gamma, beta, running_mean,
+                                      running_var, momentum, eps, mu, rstd, bn_scale, bn_shift, static_cast<double*>(workspace),
+                                      static_cast<hipStream_t>(stream), &fused));
+    return fused;
+}
+
+extern "C" int dal3_tr_linear_bnbwd_sums(const float* dz, int64_t M, int c_in, int64_t lddz, const float* W, int64_t ldw, int c_out,
+                                         float* da, int64_t ldda, const void* packed, int64_t rows, const float* bz, int64_t ldbz,
+                                         const float* bscale, const float* bshift, const float* bmu, const float* brstd,
+                                         const float* gamma, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
+                                         void* workspace, size_t workspace_bytes, dal3_stream stream) {
+    if (!tr_linear_red_args_ok(dz, M, c_in, lddz, c_out, da, ldda, packed, rows) || !W || !bz || ldbz < c_out || ldbz % 4 ||
+        !bscale || !bshift || !bmu || !brstd || !gamma || !dgamma || !dbeta || !k1 || !k2 || !k3)
+        return fail(DAL3_EINVAL, "tr_linear_bnbwd_sums: bad argument");
+    if (tr_linear_pack_mtb(M, c_in, 0, c_out, 0, 0) == 0)
+        return fail(DAL3_EINVAL, "tr_linear_bnbwd_sums: this call reads no packed image (dal3_tr_linear_pack_layout() == 0)");
+    if (!workspace || workspace_bytes < dal3_tr_linear_red_workspace_bytes(rows, c_out))
+        return fail(DAL3_EWORKSPACE, "tr_linear_bnbwd_sums: workspace smaller than dal3_tr_linear_red_workspace_bytes()");
+    int fused = 0;
+    HIP_TRY(launch_tr_linear_bnbwd_sums(dz, M, c_in, lddz, W, ldw, c_out, da, ldda, const_cast<float*>(static_cast<const float*>(packed)),
+                                        rows, bz, ldbz, bscale, bshift, bmu, brstd, gamma, dgamma, dbeta, k1, k2, k3,
+                                        static_cast<double*>(workspace), static_cast<hipStream_t>(stream), &fused));
+    return fused;
+}
+
 extern "C" int dal3_tr_linear_x3_layout(int64_t M, int c_in, int64_t seg, int c_out, int accumulate, int has_act) {
     if (!mult32(M) || !mult32(c_in) || !mult32(c_out)) return 0;
     return tr_linear_x3_layout(M, c_in, seg, c_out, accumulate, has_act);

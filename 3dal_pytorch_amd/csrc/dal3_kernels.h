@@ -309,6 +309,18 @@ hipError_t launch_tr_box_loss(const float* center, const float* center_label, co
 size_t tr_seg_ce_workspace_bytes(int64_t M);
 hipError_t launch_tr_seg_ce(const float* logits, const void* labels, int labels_i64, int64_t M, float* loss, float* dlogits,
                             double* part, hipStream_t s);
+// linear + a column reduction of its output in the kernel's epilogue (dal3_train.hip, TrRed)
+size_t tr_linear_red_workspace_bytes();
+hipError_t launch_tr_linear_bn_stats(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                                     int relu_in, const float* W, int64_t ldw, const float* bias, int64_t seg, int c_out,
+                                     float* z, int64_t ldz, float* packed, int64_t rows, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
+                                     float* bn_scale, float* bn_shift, double* part, hipStream_t s, int* fused);
+hipError_t launch_tr_linear_bnbwd_sums(const float* a, int64_t M, int c_in, int64_t lda, const float* W, int64_t ldw, int c_out,
+                                       float* da, int64_t ldda, float* packed, int64_t rows, const float* bz, int64_t ldbz,
+                                       const float* bscale, const float* bshift, const float* bmu, const float* brstd,
+                                       const float* gamma, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
+                                       double* part, hipStream_t s, int* fused);
 hipError_t launch_tr_bn_stats(const float* z, int64_t M, int C, int64_t ldz, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
                               float* scale, float* shift, double* part, hipStream_t s);

@@ -296,7 +296,11 @@ __device__ __forceinline__ void tr_load_x(TrX<T>& st, int kt, const float* __res
 struct TrNoSide {
     __device__ __forceinline__ void operator()(int) const {}
 };
-template <int T, int MTB, int BASE, class Ring, class Side = TrNoSide>
+// SWAP: the operands exchanged — the accumulator tile comes out TRANSPOSED (lane = output channel 32 t + m, register r =
+// point 8 (r / 4) + 4 h + r % 4 of the tile): what a reduction over the points wants (sums over registers, no cross-lane
+// work), and its stores are whole 128-byte rows. The fragments themselves are the same (lane (m, h) of a weight fragment
+// holds row m, k = h; of an activation fragment point m, k = h: either can be the A or the B operand).
+template <int T, int MTB, int BASE, bool SWAP = false, class Ring, class Side = TrNoSide>
 __device__ __forceinline__ void tr_ring_block(Ring& ring, const f32x16 (&X)[T], f32x16 (&acc)[T][MTB], Side side = Side()) {
 #pragma unroll
     for (int i = 0; i < 4 * MTB; ++i) {
@@ -305,7 +309,8 @@ __device__ __forceinline__ void tr_ring_block(Ring& ring, const f32x16 (&X)[T], 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int j = 0; j < T; ++j) acc[j][i / 4] = mfma32(w[e], X[j][4 * (i % 4) + e], acc[j][i / 4]);
+            for (int j = 0; j < T; ++j)
+                acc[j][i / 4] = SWAP ? mfma32(X[j][4 * (i % 4) + e], w[e], acc[j][i / 4]) : mfma32(w[e], X[j][4 * (i % 4) + e], acc[j][i / 4]);
         }
         DAL3_SCHED_FENCE();
         side(i);
@@ -454,14 +459,35 @@ struct WRingCyc {
     }
 };
 
-template <int T, int MTB, int OCC, int KTC>                  // KTC: c_in / 32 when it is 2 or 4 (straight-line code per unit), else 0
+// RED != 0: a column reduction over the points of the kernel's OWN OUTPUT, taken in the epilogue instead of by a second
+// pass over the tensor (round 4: the statistics / BatchNorm-backward passes were 1.0 of a training step's 7.9 ms, each a
+// full read of a tensor the producing kernel had in registers a moment before):
+//   RED == 1  sum z, sum z^2 of the output z                                   (dal3_tr_colred mode 0: batch statistics)
+//   RED == 2  the output is da, the gradient w.r.t. relu(bn(bz)) of the layer whose pre-BN output is `bz`:
+//             dy = da * [bz*bscale + bshift > 0];  sum dy, sum dy * (bz - bmu)*brstd    (mode 1: dbeta, dgamma)
+// The tile is computed transposed (tr_ring_block SWAP): a lane owns ONE output channel of each tile and sixteen points of
+// it, so the sums run over registers; a wave's units all lie in one channel block, so the running sums (float64, like
+// the separate pass) stay in registers for the wave's whole life and are written once: part[wave of the block][c][2],
+// added in wave order by tr_colred_final_kernel. Fixed unit -> wave map, fixed order of additions: deterministic.
+struct TrRed {
+    double* part;
+    const float* bz;                     // RED == 2
+    int64_t ldbz;
+    const float* bscale;
+    const float* bshift;
+    const float* bmu;
+    const float* brstd;
+};
+
+template <int T, int MTB, int OCC, int KTC, int RED = 0>     // KTC: c_in / 32 when it is 2 or 4 (straight-line code per unit), else 0
 __global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* __restrict__ a, int64_t M, int c_in, int64_t lda,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, int relu_in,
                                                                 const f32x4* __restrict__ wpk, const float* __restrict__ bias,
                                                                 int64_t seg, int c_out, float* __restrict__ z, int64_t ldz,
-                                                                int n_mblk, uint32_t n_units) {
+                                                                int n_mblk, uint32_t n_units, TrRed red) {
     static_assert(DAL3_PF == 8 && (MTB == 1 || MTB == 2 || MTB == 4), "fragment order of tr_pack_kernel, ring slots");
+    constexpr bool SW = RED != 0;
     __shared__ float s_sc[TR_MAX_ACT_CIN], s_sh[TR_MAX_ACT_CIN];
     const bool act = scale != nullptr;
     if (act) {
@@ -473,6 +499,7 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* _
     }
     const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
     uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave0 = unit;                              // this wave's index on the chip
     const uint32_t n_waves = gridDim.x * 4u;
     if (unit >= n_units) return;
     const int mblk = (int)(unit % (uint32_t)n_mblk);          // the same for every unit of this wave
@@ -483,14 +510,46 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* _
     auto bias_row = [&](int64_t pt0) {                        // scalar: one 32-bit division per unit
         return seg > 0 ? bias + (int64_t)((uint32_t)pt0 / (uint32_t)seg) * c_out + 32 * mt0 : bias + 32 * mt0;
     };
+    auto bias_tile = [&](int64_t pt0, int t) {
+        if (!bias) return f32x16{};
+        if constexpr (SW) {                                   // transposed tile: this lane's one channel in every register
+            const float v = bias_row(pt0)[32 * t + m];
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = v;
+            return o;
+        } else {
+            return tile_from_channels(bias_row(pt0) + 32 * t, h);
+        }
+    };
     int64_t pt0 = (int64_t)(unit / (uint32_t)n_mblk) * (32 * T);
     f32x16 bnext[MTB];
 #pragma unroll
-    for (int t = 0; t < MTB; ++t) bnext[t] = bias ? tile_from_channels(bias_row(pt0) + 32 * t, h) : f32x16{};
+    for (int t = 0; t < MTB; ++t) bnext[t] = bias_tile(pt0, t);
     int64_t prow[T];
 #pragma unroll
     for (int j = 0; j < T; ++j) prow[j] = pt0 + 32 * j + m;
     constexpr int BASE2 = (4 * MTB) % DAL3_PF;
+    // RED: this lane's running sums per output tile, and (RED == 2) its channel's BatchNorm constants
+    double r0[MTB], r1[MTB];
+    float bsc[MTB], bsh[MTB], bmu[MTB], brs[MTB];
+    if constexpr (RED != 0) {
+#pragma unroll
+        for (int t = 0; t < MTB; ++t) {
+            r0[t] = 0.0;
+            r1[t] = 0.0;
+            if constexpr (RED == 2) {
+                const int c = 32 * (mt0 + t) + m;
+                bsc[t] = red.bscale[c];
+                bsh[t] = red.bshift[c];
+                bmu[t] = red.bmu[c];
+                brs[t] = red.brstd[c];
+            }
+        }
+    }
+    // this lane's place inside a transposed tile, in bytes: row 4 h, column m (the host keeps 64 rows of either tensor below 2^31 bytes)
+    const uint32_t loff_z = ((uint32_t)(4 * h) * (uint32_t)ldz + (uint32_t)m) * 4u;
+    const uint32_t loff_bz = RED == 2 ? ((uint32_t)(4 * h) * (uint32_t)red.ldbz + (uint32_t)m) * 4u : 0u;
     TrX<T> xa, xb;
     tr_load_x<T>(xa, 0, a, lda, prow, h);
     // everything fetched so far has landed before the loop is entered: hipcc's wait-count pass merges the state at the
@@ -511,8 +570,25 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* _
         for (int j = 0; j < T; ++j) prow_n[j] = pt0_n + 32 * j + m;
         if (bias && seg > 0) {                                  // the next unit's bias row: waited for at the next unit's top
 #pragma unroll
-            for (int t = 0; t < MTB; ++t) bnext[t] = tile_from_channels(bias_row(pt0_n) + 32 * t, h);
+            for (int t = 0; t < MTB; ++t) bnext[t] = bias_tile(pt0_n, t);
         }
+        __amdgpu_buffer_rsrc_t zrs, bzrs;                       // (scalar: the unit's first row of z / bz)
+        if constexpr (SW) zrs = __builtin_amdgcn_make_buffer_rsrc(z + pt0 * ldz, 0, 0x7fffffff, 0x00020000);
+        if constexpr (RED == 2) bzrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(red.bz) + pt0 * red.ldbz, 0, 0x7fffffff, 0x00020000);
+        // RED == 2: the tile of bz under output tile t (the same rows and channels, the transposed tile's own pattern: two
+        // whole 128-byte rows per instruction), requested one output tile ahead of its use
+        f32x16 bzt[1][T];
+        auto load_bz = [&](int t) {
+            if constexpr (RED == 2) {
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        bzt[0][j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            bzrs, loff_bz, (uint32_t)(((32 * j + (r & 3) + 8 * (r >> 2)) * (uint32_t)red.ldbz + 32 * (mt0 + t)) * 4u), 0));
+                }
+            }
+        };
         // an output tile's stores go out as soon as its last MFMA has been issued (tile t: after fragment 4 t + 3 of the
         // LAST k-tile), between the MFMAs of the tiles behind it: issued in one burst at the end of the unit, the
         // 16 * T * MTB KiB of the workgroup's four waves queue up in front of the CU's one path to L2 and every wave
@@ -523,12 +599,45 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* _
 #ifdef TR_ABL_NOSTORE
                 if (acc[j][0][0] != 12345.678f) continue;
 #endif
-                float* zp = z + (pt0 + 32 * j + m) * ldz + 4 * h + 32 * (mt0 + t);
+                if constexpr (SW) {
+                    // through a buffer descriptor based at the unit's first row: the address of every store is that base +
+                    // ONE per-lane offset register + a scalar offset (with flat pointers hipcc keeps a 64-bit VGPR pair
+                    // per store in flight: 64 registers for a tile pair, and the kernel spilled)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 o = {acc[j][t][4 * q], acc[j][t][4 * q + 1], acc[j][t][4 * q + 2], acc[j][t][4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(zp + 8 * q) = o;
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][t][r]), zrs, loff_z,   // (not __builtin_bit_cast: on a vector ELEMENT it read element 0)
+                                                              (uint32_t)(((32 * j + (r & 3) + 8 * (r >> 2)) * (uint32_t)ldz + 32 * (mt0 + t)) * 4u), 0);
+                } else {
+                    float* zp = z + (pt0 + 32 * j + m) * ldz + 4 * h + 32 * (mt0 + t);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 o = {acc[j][t][4 * q], acc[j][t][4 * q + 1], acc[j][t][4 * q + 2], acc[j][t][4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(zp + 8 * q) = o;
+                    }
                 }
+            }
+        };
+        auto reduce_tile = [&](int t) {                         // (float64 per element, as the separate pass adds them)
+            if constexpr (RED == 1) {
+#pragma unroll
+                for (int j = 0; j < T; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const double v = (double)acc[j][t][r];
+                        r0[t] += v;
+                        r1[t] = __builtin_fma(v, v, r1[t]);
+                    }
+            } else if constexpr (RED == 2) {
+#pragma unroll
+                for (int j = 0; j < T; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float zz = bzt[0][j][r];
+                        const float y = zz * bsc[t] + bsh[t];
+                        const float dy = y > 0.0f ? acc[j][t][r] : 0.0f;
+                        r0[t] += (double)dy;
+                        r1[t] += (double)dy * ((zz - bmu[t]) * brs[t]);
+                    }
             }
         };
         auto kstep = [&](int kt, auto last_c) {                 // k-tiles kt and kt + 1 (KT is even on this path)
@@ -536,17 +645,22 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* _
             tr_load_x<T>(xb, kt + 1, a, lda, prow, h);
             DAL3_SCHED_FENCE();
             if (act) tr_act_lds<T>(xa.X, s_sc, s_sh, kt, h, relu_in);
-            tr_ring_block<T, MTB, 0>(ring, xa.X, acc);
+            if (LAST) load_bz(0);
+            tr_ring_block<T, MTB, 0, SW>(ring, xa.X, acc);
             // k-tile kt + 2 of this unit, or — in the last round — the NEXT unit's first k-tile, ahead of the stores
             tr_load_x<T>(xa, LAST ? 0 : kt + 2, a, lda, LAST ? prow_n : prow, h);
             DAL3_SCHED_FENCE();
             if (act) tr_act_lds<T>(xb.X, s_sc, s_sh, kt + 1, h, relu_in);
             if (LAST)
-                tr_ring_block<T, MTB, BASE2>(ring, xb.X, acc, [&](int i) {
-                    if (i % 4 == 3) store_tile(i / 4);
+                tr_ring_block<T, MTB, BASE2, SW>(ring, xb.X, acc, [&](int i) {
+                    if (i % 4 == 3) {
+                        store_tile(i / 4);
+                        reduce_tile(i / 4);
+                        if (i / 4 + 1 < MTB) load_bz(i / 4 + 1);
+                    }
                 });
             else
-                tr_ring_block<T, MTB, BASE2>(ring, xb.X, acc);
+                tr_ring_block<T, MTB, BASE2, SW>(ring, xb.X, acc);
         };
         // first and last round peeled (the same one when K = 64): hipcc's wait counts are per code location, and the
         // waits of a unit's first fragments — fetched before the previous unit's stores — must count those stores as
@@ -567,6 +681,19 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* _
         pt0 = pt0_n;
 #pragma unroll
         for (int j = 0; j < T; ++j) prow[j] = prow_n[j];
+    }
+    if constexpr (RED != 0) {
+        // the two half-waves of a channel hold disjoint points: fold them, one partial row per wave
+        double* row = red.part + ((int64_t)(wave0 / (uint32_t)n_mblk) * c_out + 32 * mt0 + m) * 2;
+#pragma unroll
+        for (int t = 0; t < MTB; ++t) {
+            const double s0 = r0[t] + __shfl_xor(r0[t], 32, 64);
+            const double s1 = r1[t] + __shfl_xor(r1[t], 32, 64);
+            if (h == 0) {
+                row[64 * t] = s0;
+                row[64 * t + 1] = s1;
+            }
+        }
     }
 }
 
@@ -871,7 +998,8 @@ static bool tr_linear_pers_ok(int64_t M, int c_in, int64_t seg, int c_out, int a
 template <int T, int MTB, int OCC>
 static void tr_linear_ring_launch(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                                   int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
-                                  int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s, bool prepacked) {
+                                  int c_out, float* z, int64_t ldz, int accumulate, float* ws, hipStream_t s, bool prepacked,
+                                  int red_mode = 0, const TrRed* red = nullptr) {
     const int n_mblk = c_out / (32 * MTB);
     const int64_t units = ((M + 32 * T - 1) / (32 * T)) * n_mblk;
     const int64_t n = (int64_t)c_out * c_in;
@@ -882,16 +1010,33 @@ static void tr_linear_ring_launch(const float* a, int64_t M, int c_in, int64_t l
     const unsigned pers_grid = 256u * OCC;
     if constexpr (MTB >= 2) {
         if (tr_linear_pers_ok<T, MTB, OCC>(M, c_in, seg, c_out, accumulate)) {
+            const TrRed rd = red ? *red : TrRed{};
             const auto args = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(pers_grid), dim3(256), 0, s, a, M, c_in, lda, scale, shift, relu_in,
-                                   reinterpret_cast<const f32x4*>(ws), bias, seg, c_out, z, ldz, n_mblk, (uint32_t)units);
+                                   reinterpret_cast<const f32x4*>(ws), bias, seg, c_out, z, ldz, n_mblk, (uint32_t)units, rd);
             };
-            if (KT == 2) {
-                args(tr_linear_pers_kernel<T, MTB, OCC, 2>);
-            } else if (KT == 4 && MTB == 4) {                  // (<2, 2, 2, 4> spills 64 registers; the generic one does not)
-                if constexpr (MTB == 4) args(tr_linear_pers_kernel<T, MTB, OCC, 4>);
-            } else {
-                args(tr_linear_pers_kernel<T, MTB, OCC, 0>);
+            const auto pick = [&](auto red_c) {
+                constexpr int RED = decltype(red_c)::value;
+                if (KT == 2) {
+                    args(tr_linear_pers_kernel<T, MTB, OCC, 2, RED>);
+                } else if (KT == 4 && MTB == 4) {              // (<2, 2, 2, 4> spills 64 registers; the generic one does not)
+                    if constexpr (MTB == 4) args(tr_linear_pers_kernel<T, MTB, OCC, 4, RED>);
+                } else {
+                    args(tr_linear_pers_kernel<T, MTB, OCC, 0, RED>);
+                }
+            };
+            if constexpr (MTB == 4) {
+                if (red_mode == 1)
+                    pick(std::integral_constant<int, 1>{});
+                else if (red_mode == 2)
+                    pick(std::integral_constant<int, 2>{});
+                else
+                    pick(std::integral_constant<int, 0>{});
+            } else {                                           // (tr_linear_red_ok: forward statistics of K = 64 only)
+                if (red_mode == 1 && KT == 2)
+                    args(tr_linear_pers_kernel<T, MTB, OCC, 2, 1>);
+                else
+                    pick(std::integral_constant<int, 0>{});
             }
             return;
         }
@@ -966,6 +1111,44 @@ hipError_t launch_tr_linear(const float* a, int64_t M, int c_in, int64_t lda, co
         hipLaunchKernelGGL(tr_linear_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, M, c_in, lda, scale, shift,
                            relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz, accumulate, n_mblk);
     }
+    return hipGetLastError();
+}
+
+// A linear layer whose epilogue takes a column reduction of its output (TrRed; tr_linear_pers_kernel RED): the shapes
+// the persistent kernels take, with room for the transposed tile's 32-bit lane offsets. *n_part = partial rows written
+// per channel (one per wave of a channel block) = what the second stage (tr_colred_final_kernel) must be told.
+bool tr_linear_red_ok(int red_mode, int64_t M, int c_in, int64_t seg, int c_out, bool has_ws, bool has_act, int64_t ldz, int64_t ldbz,
+                      int* n_part) {
+    bool small;
+    const int mtb = tr_linear_path(M, c_in, seg, c_out, 0, has_ws, has_act, &small);
+    if (small || ldz >= ((int64_t)1 << 22) || ldbz >= ((int64_t)1 << 22)) return false;     // (64 rows x ld x 4 B < 2^31)
+    if (mtb == TR_MTB && tr_linear_pers_ok<TR_T, TR_MTB, TR_RING_OCC>(M, c_in, seg, c_out, 0)) {
+        *n_part = (int)(4u * 256u * TR_RING_OCC) / (c_out / (32 * TR_MTB));
+        return true;
+    }
+    // the two-output-tile kernel runs two waves per SIMD (256 registers): only the forward statistics of a K = 64 layer
+    // fit without spilling (conv2 / conv3 of ins_seg); the other combinations keep the separate pass
+    if (mtb == 2 && red_mode == 1 && c_in == 64 && tr_linear_pers_ok<TR_T, 2, 2>(M, c_in, seg, c_out, 0)) {
+        *n_part = (int)(4u * 256u * 2) / (c_out / 64);
+        return true;
+    }
+    return false;
+}
+// (n_part * c_out is 4 * 256 * OCC * 32 * MTB channels-rows whatever the layer: 2 MiB of float64 pairs at most)
+size_t tr_linear_red_workspace_bytes() { return (size_t)2048 * 128 * 2 * sizeof(double); }
+
+// precondition: tr_linear_red_ok(...) and a packed weight image in ws
+static hipError_t launch_tr_linear_red(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                                       int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
+                                       int c_out, float* z, int64_t ldz, float* ws, hipStream_t s, int red_mode, const TrRed& red) {
+    bool small;
+    const int mtb = tr_linear_path(M, c_in, seg, c_out, 0, true, scale != nullptr, &small);
+    if (mtb == TR_MTB)
+        tr_linear_ring_launch<TR_T, TR_MTB, TR_RING_OCC>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg,
+                                                         c_out, z, ldz, 0, ws, s, true, red_mode, &red);
+    else
+        tr_linear_ring_launch<TR_T, 2, 2>(a, M, c_in, lda, scale, shift, relu_in, W, ldw, transpose_w, bias, seg, c_out, z, ldz,
+                                          0, ws, s, true, red_mode, &red);
     return hipGetLastError();
 }
 
@@ -1209,6 +1392,57 @@ hipError_t launch_tr_bnbwd_sums(const float* z, int64_t M, int C, int64_t ldz, c
     BnEpi e{};
     e.M = M, e.gamma = gamma, e.rstd = const_cast<float*>(rstd), e.dgamma = dgamma, e.dbeta = dbeta, e.k1 = k1, e.k2 = k2, e.k3 = k3;
     hipLaunchKernelGGL(tr_colred_final_kernel<2>, dim3((C + 15) / 16), dim3(256), 0, s, part, nb, C, nullptr, e);
+    return hipGetLastError();
+}
+
+// z = linear(...) and the batch statistics of z (launch_tr_bn_stats of the output) — in the linear kernel's epilogue when
+// the shape takes the persistent kernel and every row is real (rows == M: padding rows would enter the sums), else as the
+// two separate steps. `part`: max(tr_colred_workspace_bytes(rows, c_out), tr_linear_red_workspace_bytes()).
+hipError_t launch_tr_linear_bn_stats(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                                     int relu_in, const float* W, int64_t ldw, const float* bias, int64_t seg, int c_out,
+                                     float* z, int64_t ldz, float* packed, int64_t rows, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
+                                     float* bn_scale, float* bn_shift, double* part, hipStream_t s, int* fused) {
+    int n_part = 0;
+    *fused = rows == M && tr_linear_red_ok(1, M, c_in, seg, c_out, true, scale != nullptr, ldz, 0, &n_part);
+    if (!*fused) {
+        hipError_t e = launch_tr_linear(a, M, c_in, lda, scale, shift, relu_in, W, ldw, 0, bias, seg, c_out, z, ldz, 0, packed, s, true);
+        if (e != hipSuccess) return e;
+        return launch_tr_bn_stats(z, rows, c_out, ldz, gamma, beta, running_mean, running_var, momentum, eps, mu, rstd, bn_scale,
+                                  bn_shift, part, s);
+    }
+    TrRed red{};
+    red.part = part;
+    hipError_t e = launch_tr_linear_red(a, M, c_in, lda, scale, shift, relu_in, W, ldw, 0, bias, seg, c_out, z, ldz, packed, s, 1, red);
+    if (e != hipSuccess) return e;
+    BnEpi ep{};
+    ep.M = rows, ep.gamma = gamma, ep.beta = beta, ep.running_mean = running_mean, ep.running_var = running_var;
+    ep.momentum = momentum, ep.eps = eps, ep.mu = mu, ep.rstd = rstd, ep.scale = bn_scale, ep.shift = bn_shift;
+    hipLaunchKernelGGL(tr_colred_final_kernel<1>, dim3((c_out + 15) / 16), dim3(256), 0, s, part, n_part, c_out, nullptr, ep);
+    return hipGetLastError();
+}
+
+// da = dz W (a dgrad: transposed weight image) and the BatchNorm-backward sums of the layer that da belongs to
+// (launch_tr_bnbwd_sums with da = the output, z = bz), fused the same way; c_out here = that layer's channel count.
+hipError_t launch_tr_linear_bnbwd_sums(const float* a, int64_t M, int c_in, int64_t lda, const float* W, int64_t ldw, int c_out,
+                                       float* da, int64_t ldda, float* packed, int64_t rows, const float* bz, int64_t ldbz,
+                                       const float* bscale, const float* bshift, const float* bmu, const float* brstd,
+                                       const float* gamma, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
+                                       double* part, hipStream_t s, int* fused) {
+    int n_part = 0;
+    *fused = rows == M && tr_linear_red_ok(2, M, c_in, 0, c_out, true, false, ldda, ldbz, &n_part);
+    if (!*fused) {
+        hipError_t e = launch_tr_linear(a, M, c_in, lda, nullptr, nullptr, 0, W, ldw, 1, nullptr, 0, c_out, da, ldda, 0, packed, s, true);
+        if (e != hipSuccess) return e;
+        return launch_tr_bnbwd_sums(bz, rows, c_out, ldbz, da, ldda, nullptr, nullptr, 0, bscale, bshift, bmu, brstd, gamma, dgamma,
+                                    dbeta, k1, k2, k3, part, s);
+    }
+    TrRed red{part, bz, ldbz, bscale, bshift, bmu, brstd};
+    hipError_t e = launch_tr_linear_red(a, M, c_in, lda, nullptr, nullptr, 0, W, ldw, 1, nullptr, 0, c_out, da, ldda, packed, s, 2, red);
+    if (e != hipSuccess) return e;
+    BnEpi ep{};
+    ep.M = rows, ep.gamma = gamma, ep.rstd = const_cast<float*>(brstd), ep.dgamma = dgamma, ep.dbeta = dbeta, ep.k1 = k1, ep.k2 = k2, ep.k3 = k3;
+    hipLaunchKernelGGL(tr_colred_final_kernel<2>, dim3((c_out + 15) / 16), dim3(256), 0, s, part, n_part, c_out, nullptr, ep);
     return hipGetLastError();
 }
 

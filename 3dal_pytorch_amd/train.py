@@ -209,10 +209,12 @@ def _wgrad(dz, a, c_out, c_in, act=None, amax=None):
 class _BN:
     """batch statistics of one layer's pre-BN output and everything derived from them"""
 
-    def __init__(self, z, gamma, beta, running_mean, running_var, sums=None, rows=None):
+    def __init__(self, z, gamma, beta, running_mean, running_var, sums=None, rows=None, lin=None):
         """z: the layer's pre-BN output (M,C), or just its shape (M, C) when `sums` is given. rows: how many of z's
         rows are real (the buffers are padded to a multiple of 32 rows; the padding takes no part in the statistics).
-        sums: optional float64 (2*C,) [sum z, sum z^2] obtained without a pass over z (see _moments_through)"""
+        sums: optional float64 (2*C,) [sum z, sum z^2] obtained without a pass over z (see _moments_through).
+        lin: z has NOT been computed yet — (a, W, ldw, c_in, act, bias, seg, packed): z = act(a) W^T + bias is written
+        by this call too, its statistics taken in the linear kernel's epilogue (dal3_tr_linear_bn_stats)"""
         M, C = z if isinstance(z, tuple) else z.shape
         M = rows if rows is not None else M
         dev = sums.device if sums is not None else z.device
@@ -220,7 +222,19 @@ class _BN:
         self.mu, self.rstd, self.scale, self.shift = st[0], st[1], st[2], st[3]
         self.gamma = gamma.contiguous()
         lib = _hip.lib()
-        if sums is None:                                    # reduction + epilogue: two launches
+        if lin is not None:
+            a, W, ldw, c_in, act, bias, seg, packed = lin
+            sc, sh, relu = (act if act is not None else (None, None, False))
+            need = lib.dal3_tr_linear_red_workspace_bytes(M, C)
+            ws = _ws(need, dev)
+            rc = lib.dal3_tr_linear_bn_stats(_hip.ptr(a), a.shape[0], c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu),
+                                             _hip.ptr(W), ldw, _hip.ptr(bias), seg, C, _hip.ptr(z), z.stride(0), _hip.ptr(packed), M,
+                                             _hip.ptr(self.gamma), _hip.ptr(beta.contiguous()), _hip.ptr(running_mean),
+                                             _hip.ptr(running_var), _MOM, _EPS, _hip.ptr(self.mu), _hip.ptr(self.rstd),
+                                             _hip.ptr(self.scale), _hip.ptr(self.shift), _hip.ptr(ws), need, _hip.stream())
+            if rc < 0:
+                _hip.check(rc)
+        elif sums is None:                                  # reduction + epilogue: two launches
             need = lib.dal3_tr_colred_workspace_bytes(M, C)
             ws = _ws(need, dev)
             _hip.check(lib.dal3_tr_bn_stats(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(self.gamma), _hip.ptr(beta.contiguous()),
@@ -238,20 +252,41 @@ class _BN:
     def act(self):
         return (self.scale, self.shift, True)
 
-    def backward(self, z, da=None, dg=None, arg=None, seg=0, sum_seg=0, amax=None):
+    def dgrad_with_sums(self, z, dz_next, W, ldw, c_in, packed):
+        """da = dz_next W (the dgrad of the layer ABOVE, through its own weight: the gradient w.r.t. this layer's relu(bn(z)))
+        together with this layer's BatchNorm-backward sums, taken in the dgrad kernel's epilogue
+        (dal3_tr_linear_bnbwd_sums): returns (da, co) — pass co on to backward(), which then skips its reduction pass"""
+        C = z.shape[1]
+        lib = _hip.lib()
+        da = torch.empty((dz_next.shape[0], C), dtype=torch.float32, device=z.device)
+        co = torch.empty((5, C), dtype=torch.float32, device=z.device)      # dgamma, dbeta, k1, k2, k3
+        need = lib.dal3_tr_linear_red_workspace_bytes(self.M, C)
+        ws = _ws(need, z.device)
+        rc = lib.dal3_tr_linear_bnbwd_sums(_hip.ptr(dz_next), dz_next.shape[0], c_in, dz_next.stride(0), _hip.ptr(W), ldw, C,
+                                           _hip.ptr(da), da.stride(0), _hip.ptr(packed), self.M, _hip.ptr(z), z.stride(0),
+                                           _hip.ptr(self.scale), _hip.ptr(self.shift), _hip.ptr(self.mu), _hip.ptr(self.rstd),
+                                           _hip.ptr(self.gamma), _hip.ptr(co[0]), _hip.ptr(co[1]), _hip.ptr(co[2]), _hip.ptr(co[3]),
+                                           _hip.ptr(co[4]), _hip.ptr(ws), need, _hip.stream())
+        if rc < 0:
+            _hip.check(rc)
+        return da, co
+
+    def backward(self, z, da=None, dg=None, arg=None, seg=0, sum_seg=0, amax=None, co=None):
         """(dz, dgamma, dbeta) from the gradient w.r.t. relu(bn(z)); with sum_seg also the column sums of dz over every
-        segment of sum_seg rows, (M / sum_seg, C), taken in the same pass (dal3_tr_bnbwd_apply_segsum)"""
+        segment of sum_seg rows, (M / sum_seg, C), taken in the same pass (dal3_tr_bnbwd_apply_segsum). co: the sums and
+        coefficients, when dgrad_with_sums has already produced them with da"""
         C = z.shape[1]
         M = self.M                                                          # the real rows; padding rows get dz = 0
         lib = _hip.lib()
-        co = torch.empty((5, C), dtype=torch.float32, device=z.device)      # dgamma, dbeta, k1, k2, k3
-        need = lib.dal3_tr_colred_workspace_bytes(M, C)
-        ws = _ws(need, z.device)
-        _hip.check(lib.dal3_tr_bnbwd_sums(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(da), da.stride(0) if da is not None else 0,
-                                          _hip.ptr(dg), _hip.ptr(arg), seg, _hip.ptr(self.scale), _hip.ptr(self.shift),
-                                          _hip.ptr(self.mu), _hip.ptr(self.rstd), _hip.ptr(self.gamma), _hip.ptr(co[0]),
-                                          _hip.ptr(co[1]), _hip.ptr(co[2]), _hip.ptr(co[3]), _hip.ptr(co[4]), _hip.ptr(ws),
-                                          need, _hip.stream()))
+        if co is None:
+            co = torch.empty((5, C), dtype=torch.float32, device=z.device)      # dgamma, dbeta, k1, k2, k3
+            need = lib.dal3_tr_colred_workspace_bytes(M, C)
+            ws = _ws(need, z.device)
+            _hip.check(lib.dal3_tr_bnbwd_sums(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(da), da.stride(0) if da is not None else 0,
+                                              _hip.ptr(dg), _hip.ptr(arg), seg, _hip.ptr(self.scale), _hip.ptr(self.shift),
+                                              _hip.ptr(self.mu), _hip.ptr(self.rstd), _hip.ptr(self.gamma), _hip.ptr(co[0]),
+                                              _hip.ptr(co[1]), _hip.ptr(co[2]), _hip.ptr(co[3]), _hip.ptr(co[4]), _hip.ptr(ws),
+                                              need, _hip.stream()))
         dz = torch.empty_like(z)
         if sum_seg:
             fused = da is not None and C % 64 == 0 and sum_seg % 128 == 0 and M % sum_seg == 0 and M == z.shape[0]
@@ -280,6 +315,18 @@ class _BN:
         if sum_seg:                                                         # (ragged sizes: the caller takes the separate pass)
             return dz, co[0], co[1], None
         return dz, co[0], co[1]
+
+
+def _linear_bn(a, W, c_in, c_out, act, bias, seg, packed, gamma, beta, stats, rows):
+    """z = act(a) W^T + bias and its _BN (batch statistics, running-statistics update): one library call that takes the
+    statistics in the linear kernel's epilogue where the shape allows and runs the two steps itself where not; the f16x3
+    images and unpacked calls keep the separate statistics pass"""
+    rm, rv = stats if stats is not None else (None, None)
+    if packed is None or isinstance(packed, _X3Image):
+        z = _linear(a, W, W.shape[1], c_in, c_out, act=act, bias=bias, seg=seg, packed=packed)
+        return z, _BN(z, gamma, beta, rm, rv, rows=rows)
+    z = torch.empty((a.shape[0], c_out), dtype=torch.float32, device=a.device)
+    return z, _BN(z, gamma, beta, rm, rv, rows=rows, lin=(a, W, W.shape[1], c_in, act, bias, seg, packed))
 
 
 def _segmax(z, bn, seg):
@@ -591,8 +638,8 @@ class _InsSeg(torch.autograd.Function):
         for k in range(4):                                              # conv1..4
             W, b, gamma, beta = P[4 * k:4 * k + 4]
             W2 = W2s[k]
-            z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous(), packed=pk[f"f{k}"])
-            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), rows=M)
+            z, bn = _linear_bn(a, W2, W2.shape[1], W2.shape[0], act, b.contiguous(), 0, pk[f"f{k}"], gamma, beta,
+                               stats[k] if stats is not None else None, M)
             Ws.append(W2)
             bns.append(bn)
             zs.append(z)
@@ -621,8 +668,7 @@ class _InsSeg(torch.autograd.Function):
         # dconv1 on cat([out2, g.expand]): per-point part W[:, :64] out2, per-crop part W[:, 64:] g + b
         gb = torch.zeros(((a0.shape[0] - 1) // N + 1, 512), dtype=torch.float32, device=g.device)  # (padding rows index past B)
         torch.addmm(P[21], g, Wd1[:, 64:].t(), out=gb[:B])             # (B,512)
-        z = _linear(zs[1], Wd1, Wd1.shape[1], 64, 512, act=bns[1].act, bias=gb, seg=N, packed=pk["fd1"])
-        bn = _BN(z, P[22], P[23], *(stats[5] if stats is not None else (None, None)), rows=M)
+        z, bn = _linear_bn(zs[1], Wd1, 64, 512, bns[1].act, gb, N, pk["fd1"], P[22], P[23], stats[5] if stats is not None else None, M)
         Ws.append(Wd1)
         bns.append(bn)
         zs.append(z)
@@ -630,8 +676,8 @@ class _InsSeg(torch.autograd.Function):
         for k in range(6, 9):                                           # dconv2..4
             W, b, gamma, beta = P[4 * k:4 * k + 4]
             W2 = W2s[k]
-            z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous(), packed=pk[f"f{k}"])
-            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), rows=M)
+            z, bn = _linear_bn(a, W2, W2.shape[1], W2.shape[0], act, b.contiguous(), 0, pk[f"f{k}"], gamma, beta,
+                               stats[k] if stats is not None else None, M)
             Ws.append(W2)
             bns.append(bn)
             zs.append(z)
@@ -664,18 +710,22 @@ class _InsSeg(torch.autograd.Function):
         if drop is not None:
             da = _act_dropout(da, None, drop)                           # the same multiplier, re-created from its key
         amaxes = torch.zeros(3 * 64, dtype=torch.int32, device=dlogits.device)
+        co = None
         for k in (8, 7, 6):                                             # dconv4..2
             # f16x3 step: dz's largest |value| comes with it (64 words), for the wgrad and — where its image is the f16x3
             # one — the dgrad of this layer
             amax = amaxes[64 * (8 - k):64 * (9 - k)] if pk.get("arith") == "f16x3" and zs[k].shape[1] % 64 == 0 else None
-            dz, dgam, dbet = bns[k].backward(zs[k], da=da, amax=amax)
+            dz, dgam, dbet = bns[k].backward(zs[k], da=da, amax=amax, co=co)
             grads[4 * k] = _wgrad(dz, zs[k - 1], Ws[k].shape[0], Ws[k].shape[1], bns[k - 1].act, amax=amax).reshape(shapes[4 * k])
             grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
-            da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, packed=pk[f"t{k}"],
-                         amax=amax if isinstance(pk[f"t{k}"], _X3Image) else None)
+            if isinstance(pk[f"t{k}"], _X3Image):
+                da, co = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, packed=pk[f"t{k}"],
+                                 amax=amax), None
+            else:                                                       # the dgrad and the sums of the layer below in one kernel
+                da, co = bns[k - 1].dgrad_with_sums(zs[k - 1], dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], pk[f"t{k}"])
         # dconv1: per-point part against out2, per-crop part against g
-        dz, dgam, dbet, dgb = bns[5].backward(zs[5], da=da, sum_seg=N)   # dgb (B,512): dz summed over each crop's points
+        dz, dgam, dbet, dgb = bns[5].backward(zs[5], da=da, sum_seg=N, co=co)   # dgb (B,512): dz summed over each crop's points
         Wd1 = Ws[5]
         dWa = _wgrad(dz, zs[1], 512, 64, bns[1].act)
         if dgb is None:
@@ -687,7 +737,7 @@ class _InsSeg(torch.autograd.Function):
         dg = dgb @ Wd1[:, 64:]                                          # (B,1024)
         da2_dec = _linear(dz, Wd1, Wd1.shape[1], 512, 64, transpose=True, packed=pk["td1"])
         # conv5..1
-        da = None
+        da = co = None
         for k in (4, 3, 2, 1, 0):
             if k == 4:                                                  # conv5 -> max: the algebraic shortcut
                 da, dW, dgam, dbet = _pooled_layer_backward(zs[3], bns[3], Ws[4], b_conv5, bns[4], zarg, g, arg, dg, N,
@@ -696,7 +746,8 @@ class _InsSeg(torch.autograd.Function):
                 grads[17] = zero[17]
                 grads[18], grads[19] = dgam, dbet
                 continue
-            dz, dgam, dbet = bns[k].backward(zs[k], da=da)
+            dz, dgam, dbet = bns[k].backward(zs[k], da=da, co=co)
+            co = None
             src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a0, None)
             dW = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
             grads[4 * k] = dW[:, :shapes[4 * k][1]].reshape(shapes[4 * k])
@@ -705,8 +756,8 @@ class _InsSeg(torch.autograd.Function):
             if k == 2:                                                  # out2 also feeds the decoder
                 da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, out=da2_dec,
                              accumulate=True, packed=pk["t2"])
-            elif k > 0:
-                da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, packed=pk[f"t{k}"])
+            elif k > 0:                                                 # (with the sums of the layer below: conv3's and conv1's)
+                da, co = bns[k - 1].dgrad_with_sums(zs[k - 1], dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], pk[f"t{k}"])
         return (None, None, None, *grads)
 
 

@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dal3_stream;               /* hipStream_t */
 
-#define DAL3_VERSION 120                 /* 0.1.2: DAL3_F16X3; dal3_tr_linear_x3 / _pool_x3 / dal3_tr_wgrad_x3, dal3_tr_bnbwd_apply_amax */
+#define DAL3_VERSION 130                 /* 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums */
 
 enum {
     DAL3_OK = 0,
@@ -352,6 +352,29 @@ int dal3_tr_pack_many(const dal3_tr_pack_item* items, int n, dal3_stream stream)
 int dal3_tr_linear_prepacked(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                              int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int64_t seg,
                              int c_out, float* z, int64_t ldz, int accumulate, const void* packed, dal3_stream stream);
+/* A linear layer TOGETHER with the column reduction that follows it in a training step, taken in the kernel's epilogue
+ * (round 4: the separate reduction passes re-read every activation / gradient tensor once — 1.0 of a step's 7.9 ms):
+ *   dal3_tr_linear_bn_stats    = dal3_tr_linear_prepacked (forward, no accumulate) + dal3_tr_bn_stats over the first `rows`
+ *                                rows of its output z;
+ *   dal3_tr_linear_bnbwd_sums  = dal3_tr_linear_prepacked with transpose_w = 1, no activation, no bias (a dgrad:
+ *                                da = dz W) + dal3_tr_bnbwd_sums(z = bz, da = its output): the sums of the BatchNorm/ReLU
+ *                                backward of the layer whose post-activation gradient the dgrad has just produced
+ *                                (bz, bscale .. brstd, gamma: that layer's pre-BN output and BatchNorm).
+ * Same results as the two-call sequences up to the order of the float64 additions (deterministic either way). Fused
+ * when the shape takes the persistent linear kernel and rows == M (padding rows must stay out of the sums); otherwise
+ * the library runs the two steps itself. Return: 1 fused, 0 ran as two steps, < 0 error.
+ * workspace: dal3_tr_linear_red_workspace_bytes(rows, c_out). */
+size_t dal3_tr_linear_red_workspace_bytes(int64_t rows, int c_out);
+int dal3_tr_linear_bn_stats(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
+                            int relu_in, const float* W, int64_t ldw, const float* bias, int64_t seg, int c_out, float* z,
+                            int64_t ldz, const void* packed, int64_t rows, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
+                            float* bn_scale, float* bn_shift, void* workspace, size_t workspace_bytes, dal3_stream stream);
+int dal3_tr_linear_bnbwd_sums(const float* dz, int64_t M, int c_in, int64_t lddz, const float* W, int64_t ldw, int c_out,
+                              float* da, int64_t ldda, const void* packed, int64_t rows, const float* bz, int64_t ldbz,
+                              const float* bscale, const float* bshift, const float* bmu, const float* brstd,
+                              const float* gamma, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
+                              void* workspace, size_t workspace_bytes, dal3_stream stream);
 /* The same layer on the "f16x3" arithmetic (DAL3_F16X3: fp16 MFMAs on (hi, lo) split operands, fp32 accumulate — the fp32
  * kernels' accuracy at a third of their MFMA time), for the FORWARD's big layers: operands must lie inside fp16's exponent
  * range (post-BatchNorm activations and weights do; gradients do not, so dgrad / wgrad calls stay on dal3_tr_linear).

@@ -17,11 +17,11 @@ pytestmark = pytest.mark.gpu
 # The bars. Each is the largest value MEASURED for that quantity over this file's cases on MI355X (round 4,
 # profiles/r04_lowprec_measured.json: every `_bar` call of a run, written by the fixture below) with at most 2x
 # headroom — not a round number. `mask_flip` = fraction of mask bits that differ from the fp32 path's.
-BARS = {
-    "logits":    {"bf16": 4e-2, "fp16": 6e-3},       # max |dlogit| / max |logit|, vs the oracle or the fp32 path
-    "box":       {"bf16": 2e-2, "fp16": 3e-3},       # stage-one box parameters / embeddings, segmentation forced
-    "box_tail":  {"bf16": 5e-2, "fp16": 7.5e-3},     # what sits behind a second estimator or the FC tail (bp2, bp, boxes7)
-    "mask_flip": {"bf16": 0.07, "fp16": 0.01},
+BARS = {                                             # measured worst (bf16 / fp16)      -> bar
+    "logits":    {"bf16": 4.0e-2, "fp16": 5.0e-3},   # 2.67e-2 / 3.04e-3: max |dlogit| / max |logit| vs the oracle or the fp32 path
+    "box":       {"bf16": 1.4e-2, "fp16": 1.5e-3},   # 8.32e-3 / 8.46e-4: stage-one box parameters / embeddings, segmentation forced
+    "box_tail":  {"bf16": 2.5e-2, "fp16": 3.3e-3},   # 1.49e-2 / 1.94e-3: behind a second estimator or the FC tail (bp2, bp, boxes7)
+    "mask_flip": {"bf16": 0.05, "fp16": 0.0065},     # 2.99e-2 / 3.85e-3 of the mask bits differ from the fp32 path's
 }
 TOL_LOGITS = BARS["logits"]                          # (the margin band for "only near-ties may flip")
 MEASURED = []
