@@ -1082,6 +1082,15 @@ extern "C" int dal3_tr_pool_moments(const float* W, int64_t ldw, const float* b,
     return 0;
 }
 
+extern "C" int dal3_tr_pool_zarg(const int32_t* arg, const float* a, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                                 int B, int C, int K, int N, float* zarg, dal3_stream stream) {
+    if (!arg || !a || !W || !bias || !zarg || B <= 0 || C <= 0 || N <= 0 || K <= 0 || K % 4 || lda < K || ldw < K || lda % 4 || ldw % 4 ||
+        (reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(W) & 15))
+        return fail(DAL3_EINVAL, "tr_pool_zarg: bad argument (K and the row strides multiples of 4, 16-byte aligned a / W)");
+    HIP_TRY(launch_tr_pool_zarg(arg, a, lda, W, ldw, bias, B, C, K, N, zarg, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" size_t dal3_tr_pool_gv_workspace_bytes(int K) { return pool_k_ok(K) ? tr_pool_gv_workspace_bytes(K) : 0; }
 
 extern "C" int dal3_tr_pool_gv(const double* coef, const float* W, int64_t ldw, const float* b, int C, int K, float* G, float* v,

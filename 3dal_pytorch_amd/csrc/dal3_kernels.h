@@ -300,6 +300,8 @@ hipError_t launch_tr_pool_gv(const double* coef, const float* W, int64_t ldw, co
                              double* ws, hipStream_t s);
 hipError_t launch_tr_pool_dw(const double* coef, const float* W, int64_t ldw, const float* b, const float* S, const double* m1,
                              int64_t M, int centred, const float* dWs, int C, int K, float* dW, hipStream_t s);
+hipError_t launch_tr_pool_zarg(const int32_t* arg, const float* a, int64_t lda, const float* W, int64_t ldw, const float* bias, int B,
+                               int C, int K, int N, float* zarg, hipStream_t s);
 hipError_t launch_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a, int64_t lda,
                                  int B, int C, int K, int N, float* da, int64_t ldda, float* dWs, hipStream_t s);
 hipError_t launch_tr_box_loss(const float* center, const float* center_label, const float* hs, const float* hrn,

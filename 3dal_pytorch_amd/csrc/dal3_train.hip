@@ -487,7 +487,10 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* _
                                                                 int64_t seg, int c_out, float* __restrict__ z, int64_t ldz,
                                                                 int n_mblk, uint32_t n_units, TrRed red) {
     static_assert(DAL3_PF == 8 && (MTB == 1 || MTB == 2 || MTB == 4), "fragment order of tr_pack_kernel, ring slots");
-    constexpr bool SW = RED != 0;
+#ifndef TR_PERS_SW
+#define TR_PERS_SW 1                   // 1: every persistent linear kernel computes its tile transposed (whole-row stores), reduction or not
+#endif
+    constexpr bool SW = RED != 0 || TR_PERS_SW;
     __shared__ float s_sc[TR_MAX_ACT_CIN], s_sh[TR_MAX_ACT_CIN];
     const bool act = scale != nullptr;
     if (act) {
@@ -2367,6 +2370,39 @@ __global__ void tr_pool_gather_kernel(const int32_t* __restrict__ arg, const flo
         for (int u = 0; u < 8; ++u) acc += w[u] * v[u];
     }
     dWs[(int64_t)c * K + k] = acc;
+}
+
+// zarg[b][c] = W[c] . a[b*N + arg[b][c]] + bias[c]: the pooled layer's PRE-BatchNorm value at each pooled point (what the
+// backward's xhat needs; the fused forward never writes the layer's output). Sixteen lanes per (item, channel): each takes
+// every 16th float4 of the two K-rows, partial dots in lane order through a fixed shuffle tree — deterministic. Replaces
+// index arithmetic + a gather of B*C rows + a batched dot on stock ops (seven launches, 65 us at 64 x 1024 x 128).
+__global__ __launch_bounds__(256) void tr_pool_zarg_kernel(const int32_t* __restrict__ arg, const float* __restrict__ a, int64_t lda,
+                                                           const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
+                                                           int64_t n, int C, int K, int N, float* __restrict__ zarg) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    const int64_t ii = i < n ? i : n - 1;
+    const int c = (int)(ii % C);
+    const int64_t b = ii / C;
+    const f32x4* ar = reinterpret_cast<const f32x4*>(a + (b * N + arg[ii]) * lda);
+    const f32x4* wr = reinterpret_cast<const f32x4*>(W + (int64_t)c * ldw);
+    float acc = 0.0f;
+    for (int k = l; k < K / 4; k += 16) {
+        const f32x4 x = ar[k], w = wr[k];
+        acc += (x[0] * w[0] + x[1] * w[1]) + (x[2] * w[2] + x[3] * w[3]);
+    }
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 1, 64);
+    if (l == 0 && i < n) zarg[i] = acc + bias[c];
+}
+hipError_t launch_tr_pool_zarg(const int32_t* arg, const float* a, int64_t lda, const float* W, int64_t ldw, const float* bias, int B,
+                               int C, int K, int N, float* zarg, hipStream_t s) {
+    const int64_t n = (int64_t)B * C;
+    hipLaunchKernelGGL(tr_pool_zarg_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, arg, a, lda, W, ldw, bias, n, C, K,
+                       N, zarg);
+    return hipGetLastError();
 }
 
 hipError_t launch_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a, int64_t lda,

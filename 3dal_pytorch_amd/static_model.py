@@ -250,11 +250,47 @@ def _mean_size(device, dtype=torch.float32):
     return t
 
 
+class _ParseBoxPred(torch.autograd.Function):
+    """parse_output_to_tensors (tools/static_model.py:64-92) as ONE autograd node: the seven outputs are slices / scaled
+    slices of the (B,39) box_pred, and its backward puts their gradients back side by side with one concatenation —
+    sliced with stock ops, autograd answers every slice with a zero-filled (B,39) tensor, a copy into it and an add
+    (sixteen launches per estimate in a training step)."""
+
+    @staticmethod
+    def forward(ctx, box_pred, mean):
+        B = box_pred.shape[0]
+        srn = box_pred[:, 30:39].contiguous().view(B, 3, 3)
+        ctx.save_for_backward(mean)
+        ctx.meta = (B, box_pred.dtype, box_pred.device)
+        # copies, not views: an output of a custom Function that is a VIEW of its input makes autograd rebase the view on
+        # the Function's node (and aborted the process in a later backward on this build); four small copies forward
+        # against sixteen launches backward
+        c, hs, hrn, ss = (t.contiguous() for t in torch.split(box_pred, [3, 12, 12, 3, 9], 1)[:4])
+        return (c, hs, hrn, hrn * (np.pi / NUM_HEADING_BIN), ss, srn, srn * mean[None])
+
+    @staticmethod
+    def backward(ctx, gc, ghs, ghrn, ghr, gss, gsrn, gsr):
+        (mean,) = ctx.saved_tensors
+        B, dtype, dev = ctx.meta
+
+        def z(n):
+            return torch.zeros((B, n), dtype=dtype, device=dev)
+        if ghr is not None:
+            ghrn = ghr * (np.pi / NUM_HEADING_BIN) if ghrn is None else ghrn + ghr * (np.pi / NUM_HEADING_BIN)
+        if gsr is not None:
+            gsrn = gsr * mean[None] if gsrn is None else gsrn + gsr * mean[None]
+        parts = [gc if gc is not None else z(3), ghs if ghs is not None else z(12), ghrn if ghrn is not None else z(12),
+                 gss if gss is not None else z(3), gsrn.reshape(B, 9) if gsrn is not None else z(9)]
+        return torch.cat(parts, 1), None
+
+
 def _parse(box_pred):
+    mean = _mean_size(box_pred.device, box_pred.dtype)
+    if box_pred.requires_grad:
+        return _ParseBoxPred.apply(box_pred, mean)
     B = box_pred.shape[0]
     hrn = box_pred[:, 15:27]
     srn = box_pred[:, 30:39].contiguous().view(B, 3, 3)
-    mean = _mean_size(box_pred.device, box_pred.dtype)
     return (box_pred[:, 0:3], box_pred[:, 3:15], hrn, hrn * (np.pi / NUM_HEADING_BIN),
             box_pred[:, 27:30], srn, srn * mean[None])
 

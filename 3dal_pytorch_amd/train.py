@@ -655,8 +655,9 @@ class _InsSeg(torch.autograd.Function):
         bn5 = _BN((M, W5c.shape[0]), gamma5, beta5, *(stats[4] if stats is not None else (None, None)), sums=sums)
         if N % 32 == 0:
             g, arg = _linear_pool(zs[3], bns[3].act, W5c, b5c, bn5, N)
-            rows = arg.long() + torch.arange(B, device=arg.device)[:, None] * N
-            zarg = torch.einsum("bck,ck->bc", a4c[rows.reshape(-1)].view(B, W5c.shape[0], -1), W5c) + b5c    # pre-BN value there
+            zarg = torch.empty_like(g)                                  # the pre-BN value at each pooled point: one small kernel
+            _hip.check(_hip.lib().dal3_tr_pool_zarg(_hip.ptr(arg), _hip.ptr(a4c), a4c.stride(0), _hip.ptr(W5c), W5c.stride(0),
+                                                    _hip.ptr(b5c), B, W5c.shape[0], W5c.shape[1], N, _hip.ptr(zarg), _hip.stream()))
         else:
             z5 = _linear(zs[3], W5c, W5c.shape[1], W5c.shape[1], W5c.shape[0], act=bns[3].act, bias=b5c)
             g, arg = _segmax(z5, bn5, N)
@@ -730,8 +731,7 @@ class _InsSeg(torch.autograd.Function):
         dWa = _wgrad(dz, zs[1], 512, 64, bns[1].act)
         if dgb is None:
             dgb = _segsum(dz, N, g.shape[0])
-        dW1 = torch.cat([dWa, dgb.t() @ g], 1)
-        grads[20] = dW1.reshape(shapes[20])
+        dW1g = dgb.t() @ g
         grads[21] = zero[21]
         grads[22], grads[23] = dgam, dbet
         dg = dgb @ Wd1[:, 64:]                                          # (B,1024)
@@ -758,6 +758,7 @@ class _InsSeg(torch.autograd.Function):
                              accumulate=True, packed=pk["t2"])
             elif k > 0:                                                 # (with the sums of the layer below: conv3's and conv1's)
                 da, co = bns[k - 1].dgrad_with_sums(zs[k - 1], dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], pk[f"t{k}"])
+        grads[20] = torch.cat([dWa, dW1g], 1).reshape(shapes[20])
         return (None, None, None, *grads)
 
 

@@ -430,6 +430,11 @@ int dal3_tr_pool_coef(const float* dg, const float* g, const float* zarg, const 
  *                         dal3_tr_pool_coef — the operands of the dense part of da = a G + v;
  *   dal3_tr_pool_dw       backward: dW (C, K) fp32 = A m1^T + diag(Bc) (W S + b m1^T) + dWs, S = sum a a^T (K x K fp32)
  *                         given directly (centred = 0) or as Sc + m1 m1^T / M (centred != 0); dWs (C, K): the sparse term. */
+/* zarg (B,C) = the pooled layer's pre-BatchNorm value at each pooled point: W[c] . a[b*N + arg[b][c]] + bias[c], from the
+ * layer's input activation a (B*N, K) — what dal3_tr_pool_coef takes, when the fused forward (dal3_tr_linear_pool) has not
+ * written the layer's output. fp32, a fixed order of additions. */
+int dal3_tr_pool_zarg(const int32_t* arg, const float* a, int64_t lda, const float* W, int64_t ldw, const float* bias, int B, int C,
+                      int K, int N, float* zarg, dal3_stream stream);
 int dal3_tr_pool_moments(const float* W, int64_t ldw, const float* b, const double* m1, const float* Sc, int64_t M, int C, int K,
                          double* sums, dal3_stream stream);
 size_t dal3_tr_pool_gv_workspace_bytes(int K);
