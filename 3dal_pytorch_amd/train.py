@@ -132,10 +132,11 @@ def _prepack(specs, dev):
     them (c_in / c_out swapped for a transposed weight). Returns one packed tensor per spec, None where the call reads
     no packed image. The weights must not change between this and the calls (a step's forward and backward: they do not)."""
     lib = _hip.lib()
-    specs = [sp if len(sp) == 9 else (*sp, False) for sp in specs]      # 9th element: a dgrad whose caller supplies the operand's amax
+    # 9th element: a dgrad whose caller supplies the operand's amax (True), or "fp32": never the f16x3 image for this call
+    specs = [sp if len(sp) == 9 else (*sp, False) for sp in specs]
     lay = [lib.dal3_tr_linear_pack_layout(M, ci, seg, co, int(acc), int(has_act)) for _, ci, co, _, M, seg, acc, has_act, _d in specs]
     if ARITH == "f16x3":                                    # forward calls (and marked dgrads) that qualify take the f16x3 image instead
-        lay = [(lib.dal3_tr_linear_x3_layout(M, ci, seg, co, int(acc), int(has_act)) if (not tr or dg) else 0) or l
+        lay = [(lib.dal3_tr_linear_x3_layout(M, ci, seg, co, int(acc), int(has_act)) if ((not tr or dg) and dg != "fp32") else 0) or l
                for l, (_, ci, co, tr, M, seg, acc, has_act, dg) in zip(lay, specs)]
     size = [int(lib.dal3_tr_linear_workspace_bytes(ci, co)) if l else 0 for l, (_, ci, co, *_r) in zip(lay, specs)]
     size = [(n + 255) // 256 * 256 for n in size]
@@ -628,8 +629,12 @@ class _InsSeg(torch.autograd.Function):
         # the f16x3 image when the arithmetic says so and the shape qualifies — dconv3's and dconv2's do)
         tr = lambda k, acc=False, dg=False: (W2s[k], W2s[k].shape[0], W2s[k].shape[1], True, Mp, 0, acc, False, dg)   # noqa: E731
         order = ["f0", "f1", "f2", "f3", "fd1", "f6", "f7", "f8", "fd5", "td5", "t8", "t7", "t6", "td1", "t3", "t2", "t1"]
-        specs = [fw(0), fw(1), fw(2), fw(3), (Wd1, 64, 512, False, Mp, N, False, True), fw(6), fw(7), fw(8),
-                 (W5, 128, 32, False, Mp, 0, False, False), (W5, 32, 128, True, Mp, 0, False, False), tr(8, dg=True), tr(7, dg=True),
+        # Two calls stay on the fp32 kernels in an f16x3 step too, because the fp32 kernel takes the reduction that follows in
+        # its epilogue and the f16x3 kernel does not: dconv1's forward (64 -> 512, HBM-bound either way: 0.185 ms with its
+        # statistics against 0.145 + 0.15 of a separate pass over the 537 MB output) and dconv3's dgrad (128 -> 256: 0.19
+        # with dconv2's BatchNorm-backward sums against 0.11 + 0.13)
+        specs = [fw(0), fw(1), fw(2), fw(3), (Wd1, 64, 512, False, Mp, N, False, True, "fp32"), fw(6), fw(7), fw(8),
+                 (W5, 128, 32, False, Mp, 0, False, False), (W5, 32, 128, True, Mp, 0, False, False), tr(8, dg=True), tr(7, dg="fp32"),
                  tr(6, dg=True),
                  (Wd1, 512, 64, True, Mp, 0, False, False), tr(3), tr(2, True), tr(1)]
         pk = dict(zip(order, _prepack(specs, pts.device)))
