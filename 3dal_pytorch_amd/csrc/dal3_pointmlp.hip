@@ -39,6 +39,9 @@ extern "C" int dal3_debug_set_stamps(void* p) {
 // ------------------------------------------------------------------------------------------------
 // Every kernel reads its MFMA weights as ONE fragment stream in consumption order (see InsSegW /
 // PointHeadW) through one prefetch ring that never restarts between layers.
+#ifndef DAL3_ENC_LDS_MAX
+#define DAL3_ENC_LDS_MAX 1              // 0: every wave's per-tile maxima straight to global memory (A/B builds)
+#endif
 template <int T>
 __global__ __launch_bounds__(64 * DAL3_WG_WAVES) void ins_seg_encode_kernel(InsSegW w, BCN pts, int c_in, int n_pts,
                                                              int tiles_per_item, float* __restrict__ g) {
@@ -48,21 +51,38 @@ __global__ __launch_bounds__(64 * DAL3_WG_WAVES) void ins_seg_encode_kernel(InsS
     const int64_t b = blockIdx.x / tiles_per_item;
     const int n0 = ((blockIdx.x % tiles_per_item) * DAL3_WG_WAVES + wave) * (32 * T);
     __shared__ float s_b5[1024];                       // conv5's folded bias, read by the max epilogue
-    for (int i = threadIdx.x; i < 1024; i += 64 * DAL3_WG_WAVES) s_b5[i] = w.b5[i];
+    // The workgroup's maxima meet in LDS first (round 4): every wave used to send its 1024 per-channel maxima to the
+    // crop's row of g with global atomics — 4 KiB of atomic traffic per 64 points, 268 MB per 4096 x 1024 launch for a
+    // 16.8 MB result (16 x). The bit patterns are >= 0 after the ReLU, so the table starts at 0 and an
+    // integer max is the float max; one global atomicMax per channel and WORKGROUP follows (none where the value is 0:
+    // the caller zero-fills g).
+    __shared__ int s_max[DAL3_ENC_LDS_MAX ? 1024 : 1];
+    for (int i = threadIdx.x; i < 1024; i += 64 * DAL3_WG_WAVES) {
+        s_b5[i] = w.b5[i];
+        if (DAL3_ENC_LDS_MAX) s_max[i] = 0;
+    }
     __syncthreads();
-    if (n0 >= n_pts) return;
-
-    WRing<DAL3_PF> ring;
-    ring.init(w.enc_stream, lane);                     // conv2 | conv3 | conv4 | conv5
-    f32x16 bias = tile_from_channels(w.b2, h);
-    float in[T][2];
-    load_points<2, T>(pts, b, n0, n_pts, c_in, in, lane);
-    f32x16 x1[T][2], x2[T][2], x3[T][2], x4[T][4];
-    first_layer<2, 2, T>(w.w1, w.b1, in, x1, lane);
-    mlp_layer_ring<2, 2, T>(ring, w.b2, w.b3, bias, x1, x2, lane);
-    mlp_layer_ring<2, 2, T>(ring, w.b3, w.b4, bias, x2, x3, lane);
-    mlp_layer_ring<2, 4, T>(ring, w.b4, w.b4, bias, x3, x4, lane);
-    conv_max_layer<4, T>(ring, s_b5, x4, g + b * 1024, 32, lane);
+    if (n0 < n_pts) {                                  // (no early return: every wave meets the barrier below)
+        WRing<DAL3_PF> ring;
+        ring.init(w.enc_stream, lane);                 // conv2 | conv3 | conv4 | conv5
+        f32x16 bias = tile_from_channels(w.b2, h);
+        float in[T][2];
+        load_points<2, T>(pts, b, n0, n_pts, c_in, in, lane);
+        f32x16 x1[T][2], x2[T][2], x3[T][2], x4[T][4];
+        first_layer<2, 2, T>(w.w1, w.b1, in, x1, lane);
+        mlp_layer_ring<2, 2, T>(ring, w.b2, w.b3, bias, x1, x2, lane);
+        mlp_layer_ring<2, 2, T>(ring, w.b3, w.b4, bias, x2, x3, lane);
+        mlp_layer_ring<2, 4, T>(ring, w.b4, w.b4, bias, x3, x4, lane);
+        conv_max_layer<4, T>(ring, s_b5, x4, DAL3_ENC_LDS_MAX ? reinterpret_cast<float*>(s_max) : g + b * 1024, 32, lane);
+    }
+    if (DAL3_ENC_LDS_MAX) {
+        __syncthreads();
+        int* gi = reinterpret_cast<int*>(g + b * 1024);
+        for (int c = threadIdx.x; c < 1024; c += 64 * DAL3_WG_WAVES) {
+            const int v = s_max[c];
+            if (v > 0) atomicMax(gi + c, v);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -98,9 +98,11 @@ def main():
         # over five steps moved by 20 % between two runs of the same binary
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.iters + 1)]
         marks[0].record()
+        t_host = time.perf_counter()
         for i in range(args.iters):
             loss = step()
             marks[i + 1].record()
+        host_ms = (time.perf_counter() - t_host) / args.iters * 1e3      # the host's time to ISSUE a step (no sync inside)
         torch.cuda.synchronize()
         per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.iters))
         ms = per[len(per) // 2]
@@ -128,7 +130,7 @@ def main():
             torch.cuda.synchronize()
             g_ms = round((time.perf_counter() - t0) / args.iters * 1e3, 2)
             model, opt = gm, gopt
-        out[backend] = {"ms": round(ms, 2), "graph_ms": g_ms, "crops_per_s": round(B / ms * 1e3, 1), "tflops_per_point_stacks": round(flop / ms / 1e9, 1),
+        out[backend] = {"ms": round(ms, 2), "host_issue_ms": round(host_ms, 2), "graph_ms": g_ms, "crops_per_s": round(B / ms * 1e3, 1), "tflops_per_point_stacks": round(flop / ms / 1e9, 1),
                         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "loss": round(float(loss), 4),
                         "adam": args.adam}
         del model, opt
