@@ -635,8 +635,9 @@ def accuracy_vs_fp32_path(model, inputs, prec):
     (1e-6 from the reference's PyTorch-CPU forward, tests/test_gpu_parity.py) is the yardstick. Three runs of the whole
     path: fp32; `prec` free-running (its own mask, its own draws); `prec` with the fp32 run's mask forced
     (mask_override: the device sampler, keyed on the item and the count, then draws the very same points), which
-    isolates the box estimator's error from the discrete effect of a flipped point. Box error per parameter group:
-    centre (m, absolute), size (relative to the largest size), yaw (rad, absolute)."""
+    isolates the box estimator's error from the discrete effect of a flipped point. Box error per parameter group —
+    centre (m, absolute), size (relative to the largest size), yaw (rad, absolute) — on the crops whose decoded classes
+    agree, with their count (box_err)."""
     keep = model.precision
     with torch.no_grad():
         model.precision = "fp32"
@@ -649,21 +650,68 @@ def accuracy_vs_fp32_path(model, inputs, prec):
     B = ref["mask"].shape[0]
     same = (ref["mask"] == got["mask"]).all(1)
     flipped = int((ref["mask"] != got["mask"]).sum())
-
-    def box_err(a, b):
-        d = (a.double() - b.double()).abs()
-        return {"centre_m_max_abs": round(d[:, :3].max().item(), 6),
-                "size_max_rel": round((d[:, 3:6].max() / b[:, 3:6].abs().max()).item(), 6),
-                "yaw_rad_max_abs": round(d[:, 6].max().item(), 6),
-                "centre_m_median_abs": round(d[:, :3].max(1).values.median().item(), 6)}
     bp = "bp1" if "bp1" in ref else "bp"
+
+    def classes(o):
+        return o[bp][:, 3:15].argmax(1), o[bp][:, 27:30].argmax(1)
+
+    def box_err(o):
+        """boxes of run `o` against the fp32 run's: on the crops whose heading AND size classes agree (the decoded box is
+        continuous in the 39 parameters there), and how many do — a flipped class is a different bin centre / mean size,
+        i.e. a discrete event like a flipped mask bit, counted, not averaged"""
+        (h0, s0), (h1, s1) = classes(ref), classes(o)
+        same = (h0 == h1) & (s0 == s1)
+        a, b = o["boxes7"][same].double(), ref["boxes7"][same].double()
+        d = (a - b).abs()
+        return {"crops_with_the_same_heading_and_size_class": int(same.sum()), "crops": int(same.numel()),
+                "on_those": {"centre_m_max_abs": round(d[:, :3].max().item(), 6),
+                             "centre_m_median_abs": round(d[:, :3].max(1).values.median().item(), 6),
+                             "size_max_rel": round((d[:, 3:6].max() / b[:, 3:6].abs().max()).item(), 6),
+                             "yaw_rad_max_abs": round(d[:, 6].max().item(), 6)}}
     return {"logits_max_rel": round(((ref["logits"] - got["logits"]).abs().max() / ref["logits"].abs().max()).item(), 6),
             "mask_bits_flipped": flipped, "mask_bits": int(ref["mask"].numel()),
             "mask_agreement": round(1.0 - flipped / ref["mask"].numel(), 6),
             "crops_with_identical_mask": int(same.sum()), "crops": B,
             "box_params_max_rel_fp32_mask_forced": round(((ref[bp] - forced[bp]).abs().max() / ref[bp].abs().max()).item(), 6),
-            "boxes7_fp32_mask_forced": box_err(forced["boxes7"], ref["boxes7"]),
-            "boxes7_free_running": box_err(got["boxes7"], ref["boxes7"])}
+            "boxes7_fp32_mask_forced": box_err(forced), "boxes7_free_running": box_err(got)}
+
+
+def next_rows():
+    """SURVEY.md 8(f)'s rows either side of the heads, measured in THIS run: N1 crop preparation from the
+    resident StaticTrackStore, N2 crop extraction from full sweeps, N3 write-back of the refined boxes with the segment
+    flattened once (post.WritebackPlan). Per row: stream time of the device part (HIP events), the algorithmic bytes it
+    moves, GB/s and the fraction of the 8 TB/s HBM roof, and the whole call with its host part. The measuring code is
+    tools/bench_prep_post.py and tools/bench_crops.py (`measure()`); none of these rows is bandwidth-bound at a
+    segment's size — they are launch- and gather-bound, which is what the fractions say."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    out = {}
+    try:
+        pp = importlib.import_module("bench_prep_post").measure(1024)
+        n1, st = pp["N1_device_batch_of_64"], pp["prepare_static_batch[device, StaticTrackStore, batches of 64]"]
+        out["N1"] = {"what": "prepare_static_batch: 64 tracks -> (64,3,4096) crops, from the resident StaticTrackStore",
+                     "kernel_ms": n1["stream_ms_per_call"], "algorithmic_bytes": n1["algorithmic_bytes"], "gb_per_s": n1["gb_per_s"],
+                     "frac_of_hbm_8TBps": n1["frac_of_8TBps"], "whole_call_ms": st["ms_per_batch_of_64"],
+                     "one_time_store_build_ms_1024_tracks": st["store_build_ms"], "note": n1["note"]}
+        wb = pp["writeback_static[WritebackPlan]"]
+        out["N3"] = {"what": f"writeback of {wb['pairs']} (track, frame) pairs into {wb['detections']} detections of a 198-frame segment",
+                     "kernel_ms": wb["stream_ms_per_launch"], "algorithmic_bytes": wb["algorithmic_bytes"], "gb_per_s": wb["gb_per_s"],
+                     "frac_of_hbm_8TBps": wb["frac_of_8TBps"], "whole_call_ms": wb["apply_call_ms"],
+                     "one_time_plan_build_ms": wb["plan_build_ms"], "one_shot_call_ms": pp["writeback_static"]["call_ms"],
+                     "note": wb["note"]}
+    except Exception as e:                                  # (a row that cannot run must not take the headline with it)
+        out["N1_N3_error"] = repr(e)
+    try:
+        for order in ("range_image", "shuffled"):
+            c = importlib.import_module("bench_crops").measure(order=order)
+            out["N2" if order == "range_image" else "N2_shuffled_points"] = {
+                "what": "extract_crops: " + c["workload"], "kernel_ms": c["device_ms"],
+                "algorithmic_bytes": c["roofline"]["algorithmic_bytes"], "gb_per_s": c["roofline"]["achieved"],
+                "frac_of_hbm_8TBps": c["roofline"]["frac"], "whole_call_ms": c["call_ms_with_host_setup"],
+                "point_box_tests_per_s_e9": c["point_box_tests_per_s"],
+                "note": "VALU-bound (six plane tests per candidate pair behind a sphere cull), not HBM-bound"}
+    except Exception as e:
+        out["N2_error"] = repr(e)
+    return out
 
 
 def other_config(name, dev, steps):
@@ -993,6 +1041,7 @@ def main():
             torch.cuda.empty_cache()
             # BASELINE.json's other configurations and the reference's other two model classes in its own arithmetic,
             # driver-timed in the same run (the metric is "static+dynamic heads")
+            rec["next_rows"] = next_rows()
             rec["configs"] = {"C2": "this line's `value`"}
             for name, st in (("C3", 10), ("C5", 10), ("TwoBoxEst", 5), ("TwoBoxEst_f16x3", 5), ("Dynamic_fp32", 5),
                                  ("Dynamic_f16x3", 5), ("C4", 3), ("C4_f16x3", 3)):

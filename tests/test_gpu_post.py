@@ -34,3 +34,25 @@ def test_writeback_raises_when_a_box_is_missing():
     dets[tok] = dets[tok] + np.float32(5.0)                 # move every detection of that frame away
     with pytest.raises(AssertionError, match="not in det_annos"):
         post.writeback_static(tracks, poses, has_gt, np.zeros((3, 7)), dets)
+
+
+def test_a_writeback_plan_applied_twice_equals_two_one_shot_calls():
+    """round 4: the segment's pairs / poses / detections flattened and uploaded once (post.WritebackPlan); applying it
+    to two different sets of refined boxes gives exactly what two one-shot calls give (the detection array is restored
+    from its pristine copy in between), and the wrong number of boxes is refused"""
+    tracks, poses, dets, has_gt = synth.scene(34, n_frames=24, n_tracks=9)
+    g = golden("post_writeback")
+    plan = post.WritebackPlan(tracks, poses, has_gt, dets, static=True)
+    for final in (g["final_static"], g["final_static"][::-1].copy() if len(g["final_static"]) == plan.n_final else g["final_static"]):
+        try:
+            want, wm = post.writeback_static(tracks, poses, has_gt, final, dets)
+        except AssertionError:
+            with pytest.raises(AssertionError, match="not in det_annos"):
+                plan.apply(final)
+            continue
+        got, gm = plan.apply(final)
+        assert np.array_equal(gm, wm)
+        for t in dets:
+            assert np.array_equal(got[t], want[t]), t
+    with pytest.raises(ValueError):
+        plan.apply(np.zeros((plan.n_final + 1, 7)))

@@ -33,7 +33,16 @@ def main():
                     help="point order inside a sweep: synth.sweep's random order (worst case for the cull: every 64-point "
                          "round touches every detection's neighbourhood) or beam-major / azimuth-minor like a lidar "
                          "range image (what real sweeps look like)")
-    args = ap.parse_args()
+    print(json.dumps(measure(ap.parse_args())))
+
+
+def measure(args=None, **kw):
+    """-> dict (what main() prints). args: a namespace with frames / points / boxes / distinct / order, or keyword overrides
+    of the defaults (bench.py's `next_rows`)"""
+    if args is None:
+        args = argparse.Namespace(frames=192, points=180000, boxes=60, distinct=8, order="shuffled")
+    for k, v in kw.items():
+        setattr(args, k, v)
     base = [list(synth.sweep(46, f"b{f}", n_points=args.points, n_boxes=args.boxes)) for f in range(args.distinct)]
     if args.order == "range_image":
         for b in base:
@@ -92,7 +101,7 @@ def main():
     t1 = time.perf_counter()
     datasets.points_in_rbbox(base[0][0], boxes7)
     t_cpu = time.perf_counter() - t1
-    print(json.dumps({"workload": f"{F} frames x {args.points} pts x {args.boxes} detections, {args.order} point order",
+    return ({"workload": f"{F} frames x {args.points} pts x {args.boxes} detections, {args.order} point order",
                       "members": members,
                       "device_ms": round(ms, 3), "frames_per_s_device": round(F / (ms * 1e-3), 1),
                       "point_box_tests_per_s": round(n_total * args.boxes / (ms * 1e-3) / 1e9, 1),
@@ -101,7 +110,7 @@ def main():
                                    "algorithmic_bytes": nbytes},
                       "call_ms_with_host_setup": round(t_call * 1e3, 1),
                       "frames_per_s_call": round(F / t_call, 1),
-                      "host_numpy_membership_frames_per_s": round(1.0 / t_cpu, 2)}))
+                      "host_numpy_membership_frames_per_s": round(1.0 / t_cpu, 2)})
 
 
 if __name__ == "__main__":

@@ -22,11 +22,21 @@ prep = importlib.import_module("3dal_pytorch_amd.prep")
 post = importlib.import_module("3dal_pytorch_amd.post")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--tracks", type=int, default=1024)
-    args = ap.parse_args()
-    B = args.tracks
+def _events_ms(fn, iters=10, warmup=2):
+    for _ in range(warmup):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def measure(B=1024):
+    """-> dict (what main() prints): crop preparation (N1) and write-back (N3) at batch size; bench.py's `next_rows` reads
+    the StaticTrackStore / WritebackPlan entries"""
     base = [synth.track(80, t, n_frames=8 + t % 5) for t in range(64)]
     tracks = [base[i % 64] for i in range(B)]
     poses = [synth.pose_veh_to_global(80, tr["token"][int(np.argmax(tr["score"]))]) for tr in tracks]
@@ -66,6 +76,13 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out["prepare_dynamic_batch[device]"] = {"items": len(items), "call_ms": round(dt * 1e3, 1), "items_per_s": round(len(items) / dt, 1)}
+    # N1 on the device alone: one batch of 64 crops x 4096 points from the resident store (HIP events over 10 calls).
+    # Algorithmic bytes per crop: 4096 drawn points read as float64 xyz (24 B, a gather) and written as fp32 xyz (12 B).
+    ms = _events_ms(lambda: prep.prepare_static_batch(store, poses[:64], n_points=4096, sampler="device", first=0))
+    nbytes = 64 * 4096 * 36
+    out["N1_device_batch_of_64"] = {"stream_ms_per_call": round(ms, 4), "algorithmic_bytes": nbytes,
+                                    "gb_per_s": round(nbytes / ms / 1e6, 1), "frac_of_8TBps": round(nbytes / ms / 1e6 / 8000.0, 4),
+                                    "note": "call-bound: four small launches per batch; the rows of a crop are gathered from a ragged store"}
     tr_l, poses_s, dets_s, has_gt = synth.scene(81, n_frames=198, n_tracks=64)
     final = torch.randn((len(tr_l), 7), dtype=torch.float64, device="cuda")
     post.writeback_static(tr_l, poses_s, has_gt, final, dets_s)
@@ -76,8 +93,32 @@ def main():
     dt = time.perf_counter() - t0
     pairs = sum(len(t["token"]) for t in tr_l)
     out["writeback_static"] = {"frames": 198, "tracks": len(tr_l), "pairs": pairs, "call_ms": round(dt * 1e3, 1)}
-    print(json.dumps(out))
+    # the same with the segment flattened once (post.WritebackPlan): build, then the call that follows the heads
+    t0 = time.perf_counter()
+    plan = post.WritebackPlan(tr_l, poses_s, has_gt, dets_s, static=True)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    plan.apply(final)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan.apply(final)
+    torch.cuda.synchronize()
+    t_apply = time.perf_counter() - t0
+    ms = _events_ms(lambda: plan.launch(final))
+    n_det = plan.n_det
+    # algorithmic bytes: per (track, frame) pair its pose products (2 x 128 B) + box (56 B) + the frame's detection centres
+    # scanned (12 B each, ~n_det / frames per pair) + one 28-B row rewritten; the detection array copied once (2 x 28 B a row)
+    nbytes = pairs * (256 + 56 + 28 + 12 * (n_det // 198)) + n_det * 56
+    out["writeback_static[WritebackPlan]"] = {"pairs": pairs, "detections": n_det, "plan_build_ms": round(t_build * 1e3, 2),
+                                              "apply_call_ms": round(t_apply * 1e3, 3), "stream_ms_per_launch": round(ms, 4),
+                                              "algorithmic_bytes": nbytes, "gb_per_s": round(nbytes / ms / 1e6, 1),
+                                              "frac_of_8TBps": round(nbytes / ms / 1e6 / 8000.0, 5),
+                                              "note": "latency-bound: 6k pairs, two launches"}
+    return out
 
 
-if __name__ == "__main__":
-    main()
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tracks", type=int, default=1024)
+    args = ap.parse_args()
+    print(json.dumps(measure(args.tracks)))
