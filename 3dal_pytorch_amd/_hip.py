@@ -223,8 +223,30 @@ def layer_struct(conv, bn):
     return L
 
 
+F16_MAX = 65504.0
+
+
+def check_f16x3_range(pairs):
+    """DAL3_F16X3 (include/dal3.h): a folded weight beyond fp16's largest finite value cannot be split into two halves.
+    The shared-MLP kernels are built without NaN semantics (a NaN weight is not guaranteed to reach the outputs), so the
+    range is checked HERE, once per packing (one device->host sync per weight change, not per forward), and refused."""
+    with torch.no_grad():
+        worst = None
+        for conv, bn in pairs:
+            w = conv.weight.detach().reshape(conv.weight.shape[0], -1).abs().amax(1)
+            if bn is not None:
+                w = w * (bn.weight.detach() / torch.sqrt(bn.running_var.detach() + 1e-5)).abs()
+            m = w.max()
+            worst = m if worst is None else torch.maximum(worst, m)
+        if worst is not None and not float(worst) < F16_MAX:
+            raise ValueError(f"precision 'f16x3': a folded weight of magnitude {float(worst):.3g} is beyond fp16's range "
+                             f"({F16_MAX:g}); this head cannot run on the f16x3 kernels (use precision 'fp32')")
+
+
 def pack(head_kind, pairs, device, dtype=F32):
     """pairs: [(conv_or_linear, bn_or_None), ...] in forward order -> packed uint8 device tensor."""
+    if dtype == F16X3:
+        check_f16x3_range(pairs)
     arr = (Layer * len(pairs))(*[layer_struct(c, b) for c, b in pairs])
     need = _sz(0)
     check(lib().dal3_pack_weights(head_kind, arr, len(pairs), dtype, None, C.byref(need), None))

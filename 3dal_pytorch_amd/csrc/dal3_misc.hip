@@ -84,7 +84,8 @@ __global__ void pack_weight_x3_kernel(dal3_layer L, int kt_major, int col_off, i
     const int kt = kt_major ? blk / mt_n : blk % kt_n;
     const float v = folded_w(L, 32 * mt + (lane & 31), 32 * kt + 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3), col_off,
                              n_cols);
-    const _Float16 hi = (_Float16)v;
+    // a folded weight beyond fp16's range (dal3.h, DAL3_F16X3) is packed as NaN: the head's outputs are NaN, not silently wrong
+    const _Float16 hi = fabsf(v) < 65504.0f ? (_Float16)v : (_Float16)__builtin_nanf("");
     const _Float16 lo = (_Float16)(v - (float)hi);
     int64_t o = i;
     if (grp_blocks > 0) {

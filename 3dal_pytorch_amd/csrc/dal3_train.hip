@@ -214,7 +214,9 @@ __device__ __forceinline__ void tr_pack_x3_element(const float* __restrict__ W, 
     const int kt = (int)(f % KT), mblk = (int)(f / KT);
     const int row = 32 * (mtb * mblk + t) + (lane & 31), col = 32 * kt + 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
     const float v = transpose_w ? W[(int64_t)col * ldw + row] : W[(int64_t)row * ldw + col];
-    const _Float16 hi = (_Float16)v;
+    // (a weight beyond fp16's range — the f16x3 contract of dal3.h — becomes NaN, not a saturated value: every output of
+    // the layer is then NaN, which a training loop and a test both notice)
+    const _Float16 hi = fabsf(v) < 65504.0f ? (_Float16)v : (_Float16)__builtin_nanf("");
     const _Float16 lo = (_Float16)(v - (float)hi);
     out[i] = __builtin_bit_cast(uint16_t, half ? lo : hi);
 }
@@ -580,14 +582,14 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* _
         if constexpr (RED == 2) bzrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(red.bz) + pt0 * red.ldbz, 0, 0x7fffffff, 0x00020000);
         // RED == 2: the tile of bz under output tile t (the same rows and channels, the transposed tile's own pattern: two
         // whole 128-byte rows per instruction), requested one output tile ahead of its use
-        f32x16 bzt[1][T];
+        f32x16 bzt[2][T];
         auto load_bz = [&](int t) {
             if constexpr (RED == 2) {
 #pragma unroll
                 for (int j = 0; j < T; ++j) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        bzt[0][j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        bzt[t & 1][j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                             bzrs, loff_bz, (uint32_t)(((32 * j + (r & 3) + 8 * (r >> 2)) * (uint32_t)red.ldbz + 32 * (mt0 + t)) * 4u), 0));
                 }
             }
@@ -631,16 +633,23 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* _
                         r1[t] = __builtin_fma(v, v, r1[t]);
                     }
             } else if constexpr (RED == 2) {
+                // the tile's 16 T values per lane are summed in fp32 (two chains per sum), the tile sums join the float64
+                // running sums: per element 7 fp32 operations instead of 5 + two conversions + two float64 operations,
+                // which the matrix pipe had to wait for (256 -> 512: 0.66 -> see profiles/LEDGER_r04.md). These sums
+                // have no variance-type cancellation; a 32-term fp32 partial sum is exact to ~1e-7 of its terms.
+                float p0[2] = {0.0f, 0.0f}, p1[2] = {0.0f, 0.0f};
 #pragma unroll
                 for (int j = 0; j < T; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float zz = bzt[0][j][r];
+                        const float zz = bzt[t & 1][j][r];
                         const float y = zz * bsc[t] + bsh[t];
                         const float dy = y > 0.0f ? acc[j][t][r] : 0.0f;
-                        r0[t] += (double)dy;
-                        r1[t] += (double)dy * ((zz - bmu[t]) * brs[t]);
+                        p0[r & 1] += dy;
+                        p1[r & 1] = __builtin_fmaf(dy, (zz - bmu[t]) * brs[t], p1[r & 1]);
                     }
+                r0[t] += (double)(p0[0] + p0[1]);
+                r1[t] += (double)(p1[0] + p1[1]);
             }
         };
         auto kstep = [&](int kt, auto last_c) {                 // k-tiles kt and kt + 1 (KT is even on this path)
@@ -649,7 +658,12 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* _
             DAL3_SCHED_FENCE();
             if (act) tr_act_lds<T>(xa.X, s_sc, s_sh, kt, h, relu_in);
             if (LAST) load_bz(0);
-            tr_ring_block<T, MTB, 0, SW>(ring, xa.X, acc);
+            if (LAST)
+                tr_ring_block<T, MTB, 0, SW>(ring, xa.X, acc, [&](int i) {
+                    if (i == 2 * MTB && MTB > 1) load_bz(1);       // (half a round later: the two requests do not queue up together)
+                });
+            else
+                tr_ring_block<T, MTB, 0, SW>(ring, xa.X, acc);
             // k-tile kt + 2 of this unit, or — in the last round — the NEXT unit's first k-tile, ahead of the stores
             tr_load_x<T>(xa, LAST ? 0 : kt + 2, a, lda, LAST ? prow_n : prow, h);
             DAL3_SCHED_FENCE();
@@ -659,7 +673,7 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_pers_kernel(const float* _
                     if (i % 4 == 3) {
                         store_tile(i / 4);
                         reduce_tile(i / 4);
-                        if (i / 4 + 1 < MTB) load_bz(i / 4 + 1);
+                        if (i / 4 + 2 < MTB) load_bz(i / 4 + 2);   // two tiles ahead, into the buffer the reduction has just read
                     }
                 });
             else
@@ -2127,18 +2141,20 @@ __global__ __launch_bounds__(256) void tr_box_loss_kernel(BoxLossArgs a, int B) 
         acc[0] += (double)(0.5f * q * q + 2.0f * (dist - q));
 #pragma unroll
         for (int k = 0; k < 3; ++k) a.g_center[b * 3 + k] = dist > 0.0f ? q * d[k] / dist * inv_b : 0.0f;
-        // class labels out of range (an ignore value, a -1): F.nll_loss of the stock criterion raises; here the item's
-        // rows of the gradients are zeroed and every loss term comes back NaN — loud, and no out-of-bounds read
+        // class labels out of range (an ignore value, a -1): F.nll_loss of the stock criterion raises; here every loss term
+        // comes back NaN AND the item's gradient rows are NaN (round 4, ADVICE r3: with zeroed rows a loop that never looks
+        // at the loss kept stepping the optimizer on a batch the reference would have rejected) — nothing is read out of bounds
         const int64_t hc64 = a.hcl[b], sc64 = a.scl[b];
         if (hc64 < 0 || hc64 >= 12 || sc64 < 0 || sc64 >= 3) {
+            const float qn = __builtin_nanf("");
 #pragma unroll
             for (int t = 0; t < 5; ++t) acc[t] = __builtin_nan("");
 #pragma unroll
-            for (int k = 0; k < 12; ++k) a.g_hs[b * 12 + k] = a.g_hrn[b * 12 + k] = 0.0f;
+            for (int k = 0; k < 3; ++k) a.g_center[b * 3 + k] = a.g_ss[b * 3 + k] = qn;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) a.g_ss[b * 3 + k] = 0.0f;
+            for (int k = 0; k < 12; ++k) a.g_hs[b * 12 + k] = a.g_hrn[b * 12 + k] = qn;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) a.g_srn[b * 9 + k] = 0.0f;
+            for (int k = 0; k < 9; ++k) a.g_srn[b * 9 + k] = qn;
             continue;
         }
         // heading class

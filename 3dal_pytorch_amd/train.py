@@ -39,6 +39,17 @@ CAPTURE = None
 # (dal3_train_x3.hip: the same 1e-6 of the output's range, 1.3-2.5 x faster per layer), and the decoder's dgrads that
 # qualify and the decoder's wgrads with them (their dz operand is scaled by a power of two around the products:
 # _BN.backward(amax=)). Set by the drop-ins from model.precision; a backward follows what its forward ran on.
+# Measurement hook (tools/train_roofline.py): when a list, every launch of a per-point kernel family appends what it moves
+# — (family, rows, c_in, c_out, algorithmic FLOP, algorithmic HBM bytes) — in launch order, to be joined with a kernel
+# trace of the same step. None in production.
+CALLS = None
+
+
+def _note(family, M, c_in, c_out, flop=0.0, nbytes=0.0, **extra):
+    if CALLS is not None:
+        CALLS.append(dict(family=family, M=int(M), c_in=int(c_in), c_out=int(c_out), flop=float(flop), bytes=float(nbytes), **extra))
+
+
 ARITH = "fp32"
 _WGRAD_X3 = os.environ.get("DAL3_TRAIN_WGRAD_X3", "1") != "0"      # (A/B switch: 0 keeps wgrad on the fp32 kernel in an f16x3 step)
 
@@ -102,6 +113,8 @@ def _linear(a, W, ldw, c_in, c_out, act=None, bias=None, seg=0, transpose=False,
     z = out if out is not None else torch.empty((M, c_out), dtype=torch.float32, device=a.device)
     sc, sh, relu = (act if act is not None else (None, None, False))
     lib = _hip.lib()
+    _note("linear_x3" if isinstance(packed, _X3Image) else "linear", M, c_in, c_out, 2.0 * M * c_in * c_out,
+          4.0 * M * (c_in + c_out * (2 if accumulate else 1)), transpose=bool(transpose))
     if isinstance(packed, _X3Image):
         # amax: 64 device words whose maximum is the bit pattern of the operand's largest |value| (a dgrad's dz, far below fp16's range: the
         # kernel scales by a power of two around the products); a transposed image is only ever packed for such a caller
@@ -174,6 +187,7 @@ def _colred(z, mode, da=None, dg=None, arg=None, seg=0, bn=None, rows=None):
     M, C = z.shape
     M = rows if rows is not None else M
     lib = _hip.lib()
+    _note("stats" if mode == 0 else "bwd_sums", M, C, C, 0.0, 4.0 * M * C * (1 if mode == 0 else 2))
     need = lib.dal3_tr_colred_workspace_bytes(M, C)
     ws = _ws(need, z.device)
     out = torch.empty(2 * C, dtype=torch.float64, device=z.device)
@@ -192,12 +206,14 @@ def _wgrad(dz, a, c_out, c_in, act=None, amax=None):
     if amax is not None and _WGRAD_X3:
         need = lib.dal3_tr_wgrad_x3_workspace_bytes(M, c_out, c_in)
         if need:
+            _note("wgrad_x3", M, c_in, c_out, 2.0 * M * c_in * c_out, 4.0 * M * (c_in + c_out))
             ws = _ws(need, dz.device)
             dW = torch.empty((c_out, c_in), dtype=torch.float32, device=dz.device)
             sc, sh, relu = (act if act is not None else (None, None, False))
             _hip.check(lib.dal3_tr_wgrad_x3(_hip.ptr(dz), dz.stride(0), _hip.ptr(a), a.stride(0), _hip.ptr(sc), _hip.ptr(sh),
                                             int(relu), _hip.ptr(amax), M, c_out, c_in, _hip.ptr(ws), need, _hip.ptr(dW), _hip.stream()))
             return dW
+    _note("wgrad", M, c_in, c_out, 2.0 * M * c_in * c_out, 4.0 * M * (c_in + c_out))
     need = lib.dal3_tr_wgrad_workspace_bytes(M, c_out, c_in)
     ws = _ws(need, dz.device)
     dW = torch.empty((c_out, c_in), dtype=torch.float32, device=dz.device)
@@ -235,7 +251,14 @@ class _BN:
                                              _hip.ptr(self.scale), _hip.ptr(self.shift), _hip.ptr(ws), need, _hip.stream())
             if rc < 0:
                 _hip.check(rc)
+            Ma = a.shape[0]
+            if rc == 1:                                     # fused: one kernel did both
+                _note("linear+stats", Ma, c_in, C, 2.0 * Ma * c_in * C, 4.0 * Ma * (c_in + C))
+            else:
+                _note("linear", Ma, c_in, C, 2.0 * Ma * c_in * C, 4.0 * Ma * (c_in + C), transpose=False)
+                _note("stats", M, C, C, 0.0, 4.0 * M * C)
         elif sums is None:                                  # reduction + epilogue: two launches
+            _note("stats", M, C, C, 0.0, 4.0 * M * C)
             need = lib.dal3_tr_colred_workspace_bytes(M, C)
             ws = _ws(need, dev)
             _hip.check(lib.dal3_tr_bn_stats(_hip.ptr(z), M, C, z.stride(0), _hip.ptr(self.gamma), _hip.ptr(beta.contiguous()),
@@ -270,6 +293,12 @@ class _BN:
                                            _hip.ptr(co[4]), _hip.ptr(ws), need, _hip.stream())
         if rc < 0:
             _hip.check(rc)
+        Mz = dz_next.shape[0]
+        if rc == 1:
+            _note("linear+bwd_sums", Mz, c_in, C, 2.0 * Mz * c_in * C, 4.0 * Mz * (c_in + 2 * C))
+        else:
+            _note("linear", Mz, c_in, C, 2.0 * Mz * c_in * C, 4.0 * Mz * (c_in + C), transpose=True)
+            _note("bwd_sums", self.M, C, C, 0.0, 8.0 * self.M * C)
         return da, co
 
     def backward(self, z, da=None, dg=None, arg=None, seg=0, sum_seg=0, amax=None, co=None):
@@ -279,7 +308,9 @@ class _BN:
         C = z.shape[1]
         M = self.M                                                          # the real rows; padding rows get dz = 0
         lib = _hip.lib()
+        _note("apply", M, C, C, 0.0, 12.0 * M * C)
         if co is None:
+            _note("bwd_sums", M, C, C, 0.0, 8.0 * M * C if da is not None else 4.0 * M * C)
             co = torch.empty((5, C), dtype=torch.float32, device=z.device)      # dgamma, dbeta, k1, k2, k3
             need = lib.dal3_tr_colred_workspace_bytes(M, C)
             ws = _ws(need, z.device)
@@ -352,6 +383,7 @@ def _linear_pool(a, act, W, b, bn, seg):
     g = torch.empty((n_seg, c_out), dtype=torch.float32, device=a.device)
     arg = torch.empty((n_seg, c_out), dtype=torch.int32, device=a.device)
     sc, sh, relu = act
+    _note("linear_pool", M, c_in, c_out, 2.0 * M * c_in * c_out, 4.0 * M * c_in)
     pool = lib.dal3_tr_linear_pool
     if ARITH == "f16x3" and lib.dal3_tr_linear_pool_x3_ok(M, c_in, seg, c_out):
         pool = lib.dal3_tr_linear_pool_x3
@@ -378,6 +410,7 @@ def _act_dropout(x, act, drop):
     M, C = x.shape
     out = torch.empty((M, C), dtype=torch.float32, device=x.device)
     sc, sh, relu = act if act is not None else (None, None, False)
+    _note("act", M, C, C, 0.0, 8.0 * M * C)
     mult, seed, step, p = None, 0, None, 0.0
     if torch.is_tensor(drop):
         mult = drop

@@ -43,8 +43,10 @@ enum { DAL3_F32 = 0, DAL3_BF16 = 1, DAL3_F16 = 2,
         * fp32 accumulate — fp32 ACCURACY (logits ~1e-6 of their range, like DAL3_F32) from three fp16 MFMAs per fp32 one.
         * An arithmetic dtype of packed weights only (never a storage dtype of dal3_bcn / dal3_maxpool_n_dtype).
         * Range: folded weights and every layer's activations must stay below fp16's largest finite value (65504) in
-        * magnitude — beyond it a half saturates and the crop's outputs are WRONG WITHOUT NOTICE (DAL3_F32 has no such
-        * limit; DAL3_F16 turns NaN there). The margin is three orders of magnitude on this path: the first layer, which sees
+        * magnitude. A folded WEIGHT beyond it is packed as NaN — and a binding should refuse it outright at packing
+        * time (3dal_pytorch_amd/_hip.py check_f16x3_range raises: the shared-MLP kernels are built without NaN semantics,
+        * so a NaN weight is not guaranteed to surface). An ACTIVATION beyond it saturates in the split and the crop's
+        * outputs are WRONG WITHOUT NOTICE (DAL3_F32 has no such limit; DAL3_F16 turns NaN there). The margin is three orders of magnitude on this path: the first layer, which sees
         * the raw coordinates, runs in fp32, and crops scaled 1,000 x (box-frame coordinates of kilometres) still match
         * DAL3_F32 to 1e-6 (tests/test_gpu_x3.py). Values below fp16's normal range lose nothing that fp32 accumulation
         * would keep. */
@@ -455,8 +457,9 @@ int dal3_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int
  * (cross-entropy, 3), size residual (Huber, delta 1, of ||label / mean_size[class] - the label class's normalised
  * residual||) — unweighted; and g_* = the gradient of the matching loss w.r.t. that input (the other entries 0).
  * All inputs contiguous fp32 except the two int64 class labels. A class label outside [0, 12) / [0, 3) (an ignore value
- * such as -1: F.nll_loss of the stock criterion raises on those) makes every entry of `losses` NaN and zeroes that item's
- * gradient rows; nothing is read out of bounds. One launch. */
+ * such as -1: F.nll_loss of the stock criterion raises on those) makes every entry of `losses` NaN and that item's rows
+ * of all five gradients NaN (a step taken on them poisons the parameters: loud whether or not the loss is looked at);
+ * nothing is read out of bounds. One launch. */
 int dal3_tr_box_loss(const float* center, const float* center_label, const float* heading_scores,
                      const float* heading_residuals_normalized, const int64_t* heading_class_label,
                      const float* heading_residuals_label, const float* size_scores,

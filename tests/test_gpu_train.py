@@ -608,6 +608,25 @@ def test_criteria_on_the_gpu_match_the_stock_float64_formulation(tag):
             assert float((res["cuda"][1][k] - g).abs().max()) <= 2e-6 * max(float(g.abs().max()), 1e-6), k
 
 
+def test_an_out_of_range_class_label_poisons_losses_and_gradients():
+    """F.nll_loss of the stock criterion raises on a label outside its classes; dal3_tr_box_loss answers with NaN
+    in every loss term AND in that item's rows of all five gradients (a step taken without looking at the loss then
+    poisons the parameters instead of training on a rejected batch); the other items' rows stay finite"""
+    losses = importlib.import_module("3dal_pytorch_amd.losses")
+    B = 6
+    out_np, labels_np = synth.loss_case(61, batch=B, n_pts=64, two_stage=False)
+    o = {k: torch.from_numpy(v).cuda().requires_grad_(v.dtype == np.float32) for k, v in out_np.items()}
+    lab = [torch.from_numpy(a).cuda() for a in labels_np]
+    lab[2] = lab[2].clone()
+    lab[2][3] = -1                                           # heading class label of item 3: an ignore value
+    ls = losses.FrustumPointNetLossOneBoxEst()(o, *lab)
+    assert all(bool(torch.isnan(ls[k])) for k in ("total_loss", "center_loss", "heading_class_loss", "size_class_loss"))
+    ls["total_loss"].backward()
+    for k in ("center", "heading_scores", "heading_residuals_normalized", "size_scores", "size_residuals_normalized"):
+        g = o[k].grad.reshape(B, -1)
+        assert bool(torch.isnan(g[3]).all()), k
+
+
 @pytest.mark.parametrize("B,C,K,N", [(4, 1024, 128, 4096), (3, 512, 256, 512), (5, 512, 128, 101), (2, 1024, 128, 5120)])
 def test_pooled_layer_sparse_terms_match_stock_index_put_and_gather(B, C, K, N):
     """dal3_tr_pool_sparse against index_put_(accumulate=True) / gather-multiply-sum in float64, with many channels

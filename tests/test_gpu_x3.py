@@ -147,6 +147,24 @@ def test_f16x3_range_margin():
         assert float((a - b).abs().max()) < 1e-5 * float(a.abs().max()), scale
 
 
+def test_f16x3_weight_beyond_the_half_range_is_refused():
+    """a folded weight above fp16's largest finite value cannot be split. The binding checks the folded
+    magnitudes once per packing and raises (the kernels are built without NaN semantics, so a poisoned weight would not
+    reliably reach the outputs); the exact-fp32 path has no such limit and runs"""
+    p, init, _ = synth.static_crops(4, 256, seed=9)
+    sd = dict(recentred_sd("static_one", p[:2], seed=9))
+    w = np.array(sd["ins_seg.conv3.weight"], copy=True)
+    w[5, 7] = 3.0e6                                          # (times the BatchNorm fold: far beyond 65504)
+    sd["ins_seg.conv3.weight"] = w
+    model = build_model("static_one", sd)
+    pts = torch.from_numpy(p).cuda().transpose(2, 1)
+    model.precision = "fp32"
+    assert bool(torch.isfinite(model._run(pts, torch.from_numpy(init).cuda(), None)["logits"]).all())
+    model.precision = "f16x3"
+    with pytest.raises(ValueError, match="beyond fp16's range"):
+        model._run(pts, torch.from_numpy(init).cuda(), None)
+
+
 def test_captured_f16x3_refine_equals_eager():
     """hipGraph capture of refine() on the f16x3 kernels (dynamic LDS sizes set per launch, persistent workgroups): replays
     reproduce the eager path bit for bit, also on new inputs"""

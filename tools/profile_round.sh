@@ -1,10 +1,10 @@
 #!/bin/bash
-# tools/profile_round.sh [TAG] — run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r03'): the bench line plus
+# tools/profile_round.sh [TAG] — run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r04'): the bench line plus
 # the rocprofv3 passes whose summaries tools/prof_summary.py condenses into profiles/. Counters are collected in their
 # own passes (never together with a trace domain), as /opt/skills/guides/MI355X_MICROARCH.md prescribes. The program
 # after `--` is python3 itself (no env / bash -c hop: the profiler's preload has initialised the GPU by then).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
@@ -20,6 +20,14 @@ rocprofv3 $KT -d $O/prof_kt_c5 -o kt -- python3 $R/bench.py --no-extras --config
 rocprofv3 $KT -d $O/prof_kt_train -o kt -- python3 $R/tools/bench_train.py --backends hip --sampler device --iters 10 > $O/bench_train_under_rocprof.json 2>/dev/null
 rocprofv3 $KT -d $O/prof_kt_train_x3 -o kt -- python3 $R/tools/bench_train.py --backends hip_f16x3 --sampler device --iters 10 > /dev/null 2>&1
 python3 $R/tools/bench_train.py --sampler device --backends hip,hip_f16x3,torch > $O/bench_train.json 2>/dev/null
+python3 $R/tools/bench_train.py --sampler device --backends hip,hip_f16x3 --adam fused > $O/bench_train_fused_adam.json 2>/dev/null
+# the training step kernel by kernel against its rooflines (tools/train_roofline.py: record under the trace, then join),
+# and where the step's time goes by kernel family (tools/train_timeline.py)
+for BK in hip hip_f16x3; do
+  rocprofv3 --kernel-trace --output-format csv -d $O/prof_kt_trroof_$BK -o kt -- python3 $R/tools/train_roofline.py --record $O/train_calls_$BK.json --backend $BK > /dev/null 2>&1
+  python3 $R/tools/train_roofline.py --join $O/train_calls_$BK.json $(ls $O/prof_kt_trroof_$BK/*/kt_kernel_trace.csv $O/prof_kt_trroof_$BK/kt_kernel_trace.csv 2>/dev/null | head -1) > $O/train_roofline_$BK.json 2>$O/train_roofline_$BK.err
+done
+python3 $R/tools/train_timeline.py $(ls $O/prof_kt_train/*/kt_kernel_trace.csv $O/prof_kt_train/kt_kernel_trace.csv 2>/dev/null | head -1) --steps 8 > $O/train_timeline.json 2>/dev/null
 python3 $R/tools/bench_train.py --kind dynamic --sampler device --backends hip,hip_f16x3,torch > $O/bench_train_dynamic.json 2>/dev/null
 python3 $R/tools/trx_probe.py > $O/trx_probe.txt 2>/dev/null
 python3 $R/tools/wgx_probe.py >> $O/trx_probe.txt 2>/dev/null
