@@ -282,6 +282,8 @@ class _BN:
         (dal3_tr_linear_bnbwd_sums): returns (da, co) — pass co on to backward(), which then skips its reduction pass"""
         C = z.shape[1]
         lib = _hip.lib()
+        if packed is None or isinstance(packed, _X3Image):                  # no fp32 image for this call: the plain dgrad
+            return _linear(dz_next, W, ldw, c_in, C, transpose=True, packed=packed), None
         da = torch.empty((dz_next.shape[0], C), dtype=torch.float32, device=z.device)
         co = torch.empty((5, C), dtype=torch.float32, device=z.device)      # dgamma, dbeta, k1, k2, k3
         need = lib.dal3_tr_linear_red_workspace_bytes(self.M, C)
@@ -591,8 +593,8 @@ class _PointStack(torch.autograd.Function):
         for k in range(4):
             W, b, gamma, beta = (p.detach() for p in params[4 * k:4 * k + 4])
             W2 = Ws[k]
-            z = _linear(a, W2, W2.shape[1], W2.shape[1], W2.shape[0], act=act, bias=b.contiguous(), packed=pk[k])
-            bn = _BN(z, gamma, beta, *(stats[k] if stats is not None else (None, None)), rows=B * N)
+            z, bn = _linear_bn(a, W2, W2.shape[1], W2.shape[0], act, b.contiguous(), 0, pk[k], gamma, beta,
+                               stats[k] if stats is not None else None, B * N)
             bns.append(bn)
             zs.append(z)
             a, act = z, bn.act
@@ -613,7 +615,7 @@ class _PointStack(torch.autograd.Function):
         (g,) = ctx.saved_tensors
         grads = [None] * 16
         zero = _zero_grads(shapes, [1, 5, 9, 13], a0.device)
-        da = None
+        da = co = None
         for k in (3, 2, 1, 0):
             if k == 3:
                 da, dW, dgam, dbet = _pooled_layer_backward(zs[2], bns[2], Ws[3], biases[3], bns[3], zarg, g, arg,
@@ -622,14 +624,15 @@ class _PointStack(torch.autograd.Function):
                 grads[13] = zero[13]
                 grads[14], grads[15] = dgam, dbet
                 continue
-            dz, dgam, dbet = bns[k].backward(zs[k], da=da)
+            dz, dgam, dbet = bns[k].backward(zs[k], da=da, co=co)
+            co = None
             src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a0, None)
             dW = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
             grads[4 * k] = dW[:, :shapes[4 * k][1]].reshape(shapes[4 * k])
             grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
-            if k > 0:
-                da = _linear(dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], Ws[k].shape[1], transpose=True, packed=pkT[k])
+            if k > 0:                                                   # (with the sums of the layer below where the shape allows)
+                da, co = bns[k - 1].dgrad_with_sums(zs[k - 1], dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], pkT[k])
         return (None, None, *grads)
 
 
