@@ -7,7 +7,7 @@
 #include "../../include/dal3.h"
 #include "dal3_device.h"
 
-// point tiles (of 32 points) per wave; see DESIGN.md "register budget"
+// point tiles (of 32 points) per wave; see profiles/LEDGER_r01_r03.md §4 "register budget"
 #ifndef DAL3_ENC_T
 #define DAL3_ENC_T 2
 #endif

@@ -13,7 +13,7 @@
 // ONE generic block (x3_block) walks the fragment stream with a cursor that is a compile-time constant everywhere; the
 // next k-step's pair is always in registers, a segment is opened a k-step before it is needed, the refill's LDS-DMA
 // instructions go out one per k-step, and the VALU work between layers (bias, ReLU, the (hi, lo) split; the max
-// epilogues) is dealt out under the NEXT block's MFMAs.
+// epilogues) is dealt out under the NEXT block's MFMAs (profiles/LEDGER_r01_r03.md 5.4).
 //
 // The first layer (raw coordinates, K = 3/4/8) stays on the fp32 MFMA, biases and the per-crop dconv1 term are fp32,
 // logits / mask / pooled features and all I/O are fp32, as in the other two families.

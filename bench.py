@@ -258,7 +258,7 @@ def maxpool_roofline(dev, iters, dtype=torch.float32):
     between two device fences with HIP events around that one launch; `back_to_back` from HIP events around `iters`
     launches queued behind each other; `host_clock` from the host's clock around a fenced run of launches. (VERDICT r2:
     rocprofv3's kernel trace reads ~6 % longer per launch than the events do in the same process; three clocks that
-    agree with each other say which side the difference is on — DESIGN.md 5.)"""
+    agree with each other say which side the difference is on — profiles/LEDGER_r01_r03.md 5.)"""
     rows, n = 4096 * 1024, 1024
     es = torch.empty((), dtype=dtype).element_size()        # SURVEY 8(d): bytes = B*C*N*s + B*C*s, s = 4 (fp32) / 2 (bf16, fp16)
     try:
@@ -756,7 +756,7 @@ def apply_config(args):
         args.head, args.precision, args.batch, args.points = "dynamic", "fp32", 1024, 1024
     elif args.config == "C4_f16x3":                        # the mixed segment on the split-fp16 kernels
         args.config, args.precision = "C4", "f16x3"
-    elif args.config == "Dynamic_f16x3":                   # the same, split-fp16 arithmetic (fp32 accuracy: DESIGN.md 5.4)
+    elif args.config == "Dynamic_f16x3":                   # the same, split-fp16 arithmetic (fp32 accuracy: profiles/LEDGER_r01_r03.md 5.4)
         args.head, args.precision, args.batch, args.points = "dynamic", "f16x3", 1024, 1024
     elif args.config == "TwoBoxEst_f16x3":
         args.head, args.precision, args.batch, args.points, args.two_stage = "static", "f16x3", 4096, 1024, True
@@ -999,7 +999,7 @@ def main():
                                         "vs_exact_fp32_path": accuracy_vs_fp32_path(model, inputs, prec),
                                         "kernels": k2}
             # the fp32 formulation on the fp16 MFMA: every operand as an (hi, lo) fp16 pair, three MFMAs per product,
-            # fp32 accumulate. Its distance from the exact-fp32 path is measured here on this very
+            # fp32 accumulate (profiles/LEDGER_r01_r03.md 5.4). Its distance from the exact-fp32 path is measured here on this very
             # input, beside its step; `value` stays the exact-fp32 path's.
             with torch.no_grad():
                 model.precision = args.precision
