@@ -8,7 +8,7 @@ O=gpurun_out
 for f in bench bench_under_rocprof bench_bf16_under_rocprof bench_f16x3_under_rocprof bench_c3_under_rocprof bench_c5_under_rocprof \
          bench_b64_under_rocprof bench_maxpool_under_rocprof bench_maxpool_bf16_under_rocprof bench_latency bench_train \
          bench_train_dynamic bench_train_under_rocprof bench_train_fused_adam bench_rehearsal_2ranks bench_rehearsal_2ranks_c4 \
-         train_timeline; do
+         train_timeline cpu_threads; do
   [ -s $O/$f.json ] && cp $O/$f.json profiles/${TAG}_$f.json
 done
 for f in $O/${TAG}_kernel_stats*.csv $O/${TAG}_train_kernel_stats*.csv $O/${TAG}_pmc*.json $O/traffic.json; do

@@ -56,6 +56,8 @@ for CFG in C3 C5; do
   L=$(echo $CFG | tr A-Z a-z)
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_mfma_$L -o c -- python3 $R/bench.py --no-extras --config $CFG --steps 3 --warmup 1 > /dev/null 2>&1
 done
+# the cpu_baseline leg at several thread counts on this box's host (why bench.py pins it to 32 of the affinity cores)
+python3 $R/bench.py --cpu-sweep 8 16 32 64 128 > $O/cpu_threads.json 2>/dev/null
 python3 $R/tools/prof_summary.py $TAG $O > $O/prof_summary.log 2>&1
 cp $R/profiles/${TAG}_* $R/profiles/traffic.json $O/ 2>/dev/null
 ls $O
