@@ -1026,7 +1026,9 @@ static void tr_linear_ring_launch(const float* a, int64_t M, int c_in, int64_t l
     const int KT = c_in / 32;
     const unsigned pers_grid = 256u * OCC;
     if constexpr (MTB >= 2) {
-        if (tr_linear_pers_ok<T, MTB, OCC>(M, c_in, seg, c_out, accumulate)) {
+        // (the persistent kernel's transposed stores address a unit's 64 rows with 32-bit byte offsets: row strides beyond
+        // 2^22 floats — no tensor of this path comes near — take the one-unit-per-wave kernel)
+        if (tr_linear_pers_ok<T, MTB, OCC>(M, c_in, seg, c_out, accumulate) && ldz < ((int64_t)1 << 22)) {
             const TrRed rd = red ? *red : TrRed{};
             const auto args = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(pers_grid), dim3(256), 0, s, a, M, c_in, lda, scale, shift, relu_in,
