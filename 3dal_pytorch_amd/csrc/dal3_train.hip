@@ -1275,8 +1275,8 @@ __global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict_
     }
 }
 
-// 16 channels x 16 partial-lanes per block: lane l adds the partials l, l+16, l+32, ... (in four interleaved chains),
-// then the 16 lane sums are added in lane order — a fixed association, so the result is reproducible. What follows the sums is
+// TR_FIN_CH channels x TR_FIN_L partial-lanes per block: lane l adds the partials l, l + L, l + 2 L, ... (in four interleaved chains),
+// then the L lane sums are added in lane order — a fixed association, so the result is reproducible. What follows the sums is
 // folded in (EPI): nothing (0: the sums themselves), the forward BatchNorm epilogue (1: batch mean / biased variance ->
 // mu, rstd, the folded affine scale = gamma*rstd, shift = beta - mean*scale, and the running statistics' update with
 // momentum and unbiased variance exactly as torch's BatchNorm1d does it), or the backward one (2: dbeta = sum dy,
@@ -1300,28 +1300,37 @@ struct BnEpi {
     float* k3;
 };
 
+#ifndef TR_FIN_CH
+#define TR_FIN_CH 4
+#endif
+#define TR_FIN_L (256 / TR_FIN_CH)
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 template <int EPI>
 __global__ __launch_bounds__(256) void tr_colred_final_kernel(const double* __restrict__ part, int n_blocks, int C,
                                                               double* __restrict__ out, BnEpi e) {
-    __shared__ double sm[2][16][16];
-    const int cl = threadIdx.x & 15, l = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    // TR_FIN_CH channels x TR_FIN_L partial-lanes per block (round 4: 4 x 64, was 16 x 16 — a 64-channel layer was FOUR
+    // workgroups each walking 1024–2048 partial rows in 16 dependent trips, ~7 us thirty times a step; now 16 workgroups
+    // and 4–8 trips). Lane l adds rows l, l + L, ... in four interleaved chains, the lane sums are added in lane order:
+    // a fixed association.
+    __shared__ double sm[2][TR_FIN_L][TR_FIN_CH];
+    const int cl = threadIdx.x % TR_FIN_CH, l = threadIdx.x / TR_FIN_CH;
+    const int c = blockIdx.x * TR_FIN_CH + cl;
     double s0 = 0.0, s1 = 0.0;
     if (c < C) {
-        // four independent chains (the loop is a chain of dependent L2 round trips otherwise: 16 us for 1024 partials),
-        // combined in a fixed order
         double u0[4] = {0, 0, 0, 0}, u1[4] = {0, 0, 0, 0};
         int b = l;
-        for (; b + 48 < n_blocks; b += 64) {
+        for (; b + 3 * TR_FIN_L < n_blocks; b += 4 * TR_FIN_L) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                u0[k] += part[((int64_t)(b + 16 * k) * C + c) * 2];
-                u1[k] += part[((int64_t)(b + 16 * k) * C + c) * 2 + 1];
+                const f64x2 v = *reinterpret_cast<const f64x2*>(part + ((int64_t)(b + TR_FIN_L * k) * C + c) * 2);
+                u0[k] += v[0];
+                u1[k] += v[1];
             }
         }
-        for (; b < n_blocks; b += 16) {
-            u0[0] += part[((int64_t)b * C + c) * 2];
-            u1[0] += part[((int64_t)b * C + c) * 2 + 1];
+        for (; b < n_blocks; b += TR_FIN_L) {
+            const f64x2 v = *reinterpret_cast<const f64x2*>(part + ((int64_t)b * C + c) * 2);
+            u0[0] += v[0];
+            u1[0] += v[1];
         }
         s0 = (u0[0] + u0[1]) + (u0[2] + u0[3]);
         s1 = (u1[0] + u1[1]) + (u1[2] + u1[3]);
@@ -1331,7 +1340,7 @@ __global__ __launch_bounds__(256) void tr_colred_final_kernel(const double* __re
     __syncthreads();
     if (l == 0 && c < C) {
         double t0 = 0.0, t1 = 0.0;
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < TR_FIN_L; ++i) {
             t0 += sm[0][i][cl];
             t1 += sm[1][i][cl];
         }
@@ -1384,7 +1393,7 @@ hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int m
                             const float* mu, const float* rstd, double* part, double* out, hipStream_t s) {
     const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
     colred_partials(z, M, C, ldz, mode, DaSrc{da, ldda, dg, arg, seg}, scale, shift, mu, rstd, part, s);
-    hipLaunchKernelGGL(tr_colred_final_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, s, part, nb, C, out, BnEpi{});
+    hipLaunchKernelGGL(tr_colred_final_kernel<0>, dim3((C + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, nb, C, out, BnEpi{});
     return hipGetLastError();
 }
 
@@ -1397,7 +1406,7 @@ hipError_t launch_tr_bn_stats(const float* z, int64_t M, int C, int64_t ldz, con
     BnEpi e{};
     e.M = M, e.gamma = gamma, e.beta = beta, e.running_mean = running_mean, e.running_var = running_var;
     e.momentum = momentum, e.eps = eps, e.mu = mu, e.rstd = rstd, e.scale = scale, e.shift = shift;
-    hipLaunchKernelGGL(tr_colred_final_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, s, part, nb, C, nullptr, e);
+    hipLaunchKernelGGL(tr_colred_final_kernel<1>, dim3((C + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, nb, C, nullptr, e);
     return hipGetLastError();
 }
 
@@ -1410,7 +1419,7 @@ hipError_t launch_tr_bnbwd_sums(const float* z, int64_t M, int C, int64_t ldz, c
     colred_partials(z, M, C, ldz, 1, DaSrc{da, ldda, dg, arg, seg}, scale, shift, mu, rstd, part, s);
     BnEpi e{};
     e.M = M, e.gamma = gamma, e.rstd = const_cast<float*>(rstd), e.dgamma = dgamma, e.dbeta = dbeta, e.k1 = k1, e.k2 = k2, e.k3 = k3;
-    hipLaunchKernelGGL(tr_colred_final_kernel<2>, dim3((C + 15) / 16), dim3(256), 0, s, part, nb, C, nullptr, e);
+    hipLaunchKernelGGL(tr_colred_final_kernel<2>, dim3((C + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, nb, C, nullptr, e);
     return hipGetLastError();
 }
 
@@ -1437,7 +1446,7 @@ hipError_t launch_tr_linear_bn_stats(const float* a, int64_t M, int c_in, int64_
     BnEpi ep{};
     ep.M = rows, ep.gamma = gamma, ep.beta = beta, ep.running_mean = running_mean, ep.running_var = running_var;
     ep.momentum = momentum, ep.eps = eps, ep.mu = mu, ep.rstd = rstd, ep.scale = bn_scale, ep.shift = bn_shift;
-    hipLaunchKernelGGL(tr_colred_final_kernel<1>, dim3((c_out + 15) / 16), dim3(256), 0, s, part, n_part, c_out, nullptr, ep);
+    hipLaunchKernelGGL(tr_colred_final_kernel<1>, dim3((c_out + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, n_part, c_out, nullptr, ep);
     return hipGetLastError();
 }
 
@@ -1461,7 +1470,7 @@ hipError_t launch_tr_linear_bnbwd_sums(const float* a, int64_t M, int c_in, int6
     if (e != hipSuccess) return e;
     BnEpi ep{};
     ep.M = rows, ep.gamma = gamma, ep.rstd = const_cast<float*>(brstd), ep.dgamma = dgamma, ep.dbeta = dbeta, ep.k1 = k1, ep.k2 = k2, ep.k3 = k3;
-    hipLaunchKernelGGL(tr_colred_final_kernel<2>, dim3((c_out + 15) / 16), dim3(256), 0, s, part, n_part, c_out, nullptr, ep);
+    hipLaunchKernelGGL(tr_colred_final_kernel<2>, dim3((c_out + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, n_part, c_out, nullptr, ep);
     return hipGetLastError();
 }
 
