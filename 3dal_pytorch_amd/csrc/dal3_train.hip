@@ -1809,28 +1809,38 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
     }
 }
 
-// 64 elements x 4 slice-lanes per block; lane l adds slices l, l+4, ... in order, then the 4 lane sums in lane order
-__global__ __launch_bounds__(256) void tr_wgrad_final_kernel(const float* __restrict__ part, int n_slices, int64_t n,
-                                                             float* __restrict__ dW) {
-    __shared__ float sm[4][64];
+// 64 elements x WGF_L slice-lanes per block; lane l adds slices l, l + L, ... (four interleaved chains), then the L lane
+// sums are added in lane order: a fixed association. (Round 4: 16 lanes, was 4 — the 64-channel layers have 1024 slices,
+// which four lanes walked in 64 dependent trips: 20 us, seventeen times a step.)
+#ifndef WGF_L
+#define WGF_L 16
+#endif
+__global__ __launch_bounds__(64 * WGF_L) void tr_wgrad_final_kernel(const float* __restrict__ part, int n_slices, int64_t n,
+                                                                   float* __restrict__ dW) {
+    __shared__ float sm[WGF_L][64];
     const int el = threadIdx.x & 63, l = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + el;
     float s = 0.0f;
     if (i < n) {
         float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;       // four independent chains: the loop is load-latency bound
         int k = l;
-        for (; k + 12 < n_slices; k += 16) {
+        for (; k + 3 * WGF_L < n_slices; k += 4 * WGF_L) {
             u0 += part[(int64_t)k * n + i];
-            u1 += part[(int64_t)(k + 4) * n + i];
-            u2 += part[(int64_t)(k + 8) * n + i];
-            u3 += part[(int64_t)(k + 12) * n + i];
+            u1 += part[(int64_t)(k + WGF_L) * n + i];
+            u2 += part[(int64_t)(k + 2 * WGF_L) * n + i];
+            u3 += part[(int64_t)(k + 3 * WGF_L) * n + i];
         }
-        for (; k < n_slices; k += 4) u0 += part[(int64_t)k * n + i];
+        for (; k < n_slices; k += WGF_L) u0 += part[(int64_t)k * n + i];
         s = (u0 + u1) + (u2 + u3);
     }
     sm[l][el] = s;
     __syncthreads();
-    if (l == 0 && i < n) dW[i] = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
+    if (l == 0 && i < n) {
+        float t = sm[0][el];
+#pragma unroll
+        for (int j = 1; j < WGF_L; ++j) t += sm[j][el];
+        dW[i] = t;
+    }
 }
 
 // slice length: enough (tile block, slice) units to occupy the chip (~1024 waves: with 2048 the partial sums of the
@@ -1866,7 +1876,7 @@ size_t tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in) {
 }
 
 hipError_t launch_tr_wgrad_final(const float* part, int n_slices, int64_t n, float* dW, hipStream_t s) {
-    hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, n_slices, n, dW);
+    hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * WGF_L), 0, s, part, n_slices, n, dW);
     return hipGetLastError();
 }
 
@@ -1889,7 +1899,7 @@ hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_
         hipLaunchKernelGGL((tr_wgrad_kernel<WG_MT, WG_KT, 2>), grid, dim3(256), 0, s, dz, lddz, a, lda, scale, shift, relu_in,
                            M, c_out, c_in, part, n_mb, n_kb, pts);
     const int64_t n = (int64_t)c_out * c_in;
-    hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, (int)n_slices, n, dW);
+    hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * WGF_L), 0, s, part, (int)n_slices, n, dW);
     return hipGetLastError();
 }
 
