@@ -2456,22 +2456,24 @@ hipError_t launch_tr_pool_sparse(const int32_t* arg, const float* kd, const floa
 //   dbeta = sum_b D, dgamma = sum_b D * xhat, k1 = gamma * rstd, k2 = dbeta / M, k3 = dgamma / M,
 //   A = -k1 k2 + k1 k3 rstd mu, Bc = -k1 k3 rstd, kd[b][c] = k1 * D[b][c]            (float64 except kd)
 // — two dozen stock launches on (C,) and (B, C) tensors otherwise. coef: (4, C) float64 = dbeta | dgamma | A | Bc.
-// 64 channels x 4 item lanes per workgroup: lane l adds items l, l + 4, ... in order, the four lane sums are added in
+// PC_CH channels x PC_L item lanes per workgroup: lane l adds items l, l + L, ... in order, the lane sums are added in
 // lane order (deterministic; one thread per channel walking all B items was 74 us of dependent loads for B = 64).
+#define PC_CH 16                         // channels per workgroup (round 4: 16 x 16 item lanes, was 64 x 4 — sixteen workgroups
+#define PC_L 16                          // walking 16 items each in dependent trips: 24 us for a few hundred KB)
 __global__ __launch_bounds__(256) void tr_pool_coef_kernel(const float* __restrict__ dg, const float* __restrict__ g,
                                                            const float* __restrict__ zarg, const float* __restrict__ mu,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            int B, int C, int64_t M, double* __restrict__ coef,
                                                            float* __restrict__ kd) {
-    __shared__ double sm[2][4][64];
-    const int el = threadIdx.x & 63, l = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + el;
+    __shared__ double sm[2][PC_L][PC_CH];
+    const int el = threadIdx.x % PC_CH, l = threadIdx.x / PC_CH;
+    const int c = blockIdx.x * PC_CH + el;
     const bool live = c < C;
     const double m = live ? (double)mu[c] : 0.0, rs = live ? (double)rstd[c] : 0.0;
     double dbeta = 0.0, dgamma = 0.0;
     if (live) {
 #pragma unroll 4
-        for (int b = l; b < B; b += 4) {
+        for (int b = l; b < B; b += PC_L) {                 // lane l: items l, l + L, ... in order
             const int64_t i = (int64_t)b * C + c;
             const double D = g[i] > 0.0f ? (double)dg[i] : 0.0;
             dbeta += D;
@@ -2482,8 +2484,12 @@ __global__ __launch_bounds__(256) void tr_pool_coef_kernel(const float* __restri
     sm[1][l][el] = dgamma;
     __syncthreads();
     if (!live) return;
-    dbeta = ((sm[0][0][el] + sm[0][1][el]) + sm[0][2][el]) + sm[0][3][el];
-    dgamma = ((sm[1][0][el] + sm[1][1][el]) + sm[1][2][el]) + sm[1][3][el];
+    dbeta = dgamma = 0.0;
+#pragma unroll
+    for (int j = 0; j < PC_L; ++j) {                        // the lane sums in lane order: a fixed association
+        dbeta += sm[0][j][el];
+        dgamma += sm[1][j][el];
+    }
     const double k1 = (double)gamma[c] * rs, k2 = dbeta / (double)M, k3 = dgamma / (double)M;
     if (l == 0) {
         coef[c] = dbeta;
@@ -2492,7 +2498,7 @@ __global__ __launch_bounds__(256) void tr_pool_coef_kernel(const float* __restri
         coef[3 * C + c] = -k1 * k3 * rs;
     }
 #pragma unroll 4
-    for (int b = l; b < B; b += 4) {
+    for (int b = l; b < B; b += PC_L) {
         const int64_t i = (int64_t)b * C + c;
         kd[i] = (float)(k1 * (g[i] > 0.0f ? (double)dg[i] : 0.0));
     }
@@ -2500,7 +2506,7 @@ __global__ __launch_bounds__(256) void tr_pool_coef_kernel(const float* __restri
 
 hipError_t launch_tr_pool_coef(const float* dg, const float* g, const float* zarg, const float* mu, const float* rstd,
                                const float* gamma, int B, int C, int64_t M, double* coef, float* kd, hipStream_t s) {
-    hipLaunchKernelGGL(tr_pool_coef_kernel, dim3((C + 63) / 64), dim3(256), 0, s, dg, g, zarg, mu, rstd, gamma, B, C, M, coef,
+    hipLaunchKernelGGL(tr_pool_coef_kernel, dim3((C + PC_CH - 1) / PC_CH), dim3(256), 0, s, dg, g, zarg, mu, rstd, gamma, B, C, M, coef,
                        kd);
     return hipGetLastError();
 }
