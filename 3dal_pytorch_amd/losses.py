@@ -117,18 +117,32 @@ def _box_terms(center, heading_scores, heading_residuals_normalized, size_scores
     return center_loss, heading_class_loss, heading_res_loss, size_class_loss, size_res_loss
 
 
+_WEIGHTS = {}
+
+
+def _weighted(terms, w_box):
+    """the five box terms of an estimate (centre, heading class, heading residual, size class, size residual) with the
+    criterion's weights on them — w_box * (10, 1, 20, 1, 20) — as ONE (5,) tensor: a stack and a multiplication instead of
+    nine scalar kernels forward and as many backward (the weight vector is built once per value of w_box: an upload
+    inside a step would also break hipGraph capture)"""
+    t = torch.stack(list(terms))
+    key = (float(w_box), t.device, t.dtype)
+    w = _WEIGHTS.get(key)
+    if w is None:
+        w = _WEIGHTS[key] = torch.tensor([10.0, 1.0, 20.0, 1.0, 20.0], dtype=t.dtype, device=t.device) * float(w_box)
+    return t * w
+
+
 class _OneBoxLoss(nn.Module):
     def forward(self, output, mask_label, center_label, heading_class_label, heading_residuals_label, size_class_label,
                 size_residuals_label, w_box=1.0):
         mask_loss = _mask_loss(output["logits"], mask_label)
-        c, hc, hr, sc, sr = _box_terms(output["center"], output["heading_scores"], output["heading_residuals_normalized"],
-                                       output["size_scores"], output["size_residuals_normalized"], center_label,
-                                       heading_class_label, heading_residuals_label, size_class_label,
-                                       size_residuals_label)
-        total = mask_loss + w_box * (c * 10 + hc + sc + hr * 20 + sr * 20)
-        return {"total_loss": total, "mask_loss": mask_loss, "center_loss": w_box * c * 10,
-                "heading_class_loss": w_box * hc, "size_class_loss": w_box * sc,
-                "heading_residuals_normalized_loss": w_box * hr * 20, "size_residuals_normalized_loss": w_box * sr * 20}
+        w = _weighted(_box_terms(output["center"], output["heading_scores"], output["heading_residuals_normalized"],
+                                 output["size_scores"], output["size_residuals_normalized"], center_label,
+                                 heading_class_label, heading_residuals_label, size_class_label, size_residuals_label), w_box)
+        total = mask_loss + w.sum()
+        return {"total_loss": total, "mask_loss": mask_loss, "center_loss": w[0], "heading_class_loss": w[1],
+                "size_class_loss": w[3], "heading_residuals_normalized_loss": w[2], "size_residuals_normalized_loss": w[4]}
 
 
 class FrustumPointNetLossOneBoxEst(_OneBoxLoss):
@@ -153,11 +167,10 @@ class FrustumPointNetLossTwoBoxEst(nn.Module):
                          output["size_scores_two"], output["size_residuals_normalized_two"], center_label,
                          output["heading_class_label_two"], output["heading_residuals_label_two"], size_class_label,
                          size_residuals_label)
-        total = mask_loss + w_box * sum(c * 10 + hc + sc + hr * 20 + sr * 20 for c, hc, hr, sc, sr in (one, two))
+        w1, w2 = _weighted(one, w_box), _weighted(two, w_box)
+        total = mask_loss + (w1 + w2).sum()
         out = {"total_loss": total, "mask_loss": mask_loss}
-        for tag, (c, hc, hr, sc, sr) in (("one", one), ("two", two)):
-            out.update({f"center_loss_{tag}": w_box * c * 10, f"heading_class_loss_{tag}": w_box * hc,
-                        f"size_class_loss_{tag}": w_box * sc,
-                        f"heading_residuals_normalized_loss_{tag}": w_box * hr * 20,
-                        f"size_residuals_normalized_loss_{tag}": w_box * sr * 20})
+        for tag, w in (("one", w1), ("two", w2)):
+            out.update({f"center_loss_{tag}": w[0], f"heading_class_loss_{tag}": w[1], f"size_class_loss_{tag}": w[3],
+                        f"heading_residuals_normalized_loss_{tag}": w[2], f"size_residuals_normalized_loss_{tag}": w[4]})
         return out
