@@ -1082,6 +1082,13 @@ extern "C" int dal3_tr_pool_moments(const float* W, int64_t ldw, const float* b,
     return 0;
 }
 
+extern "C" int dal3_tr_gather_at(const float* z, int64_t ldz, const int32_t* arg, int64_t seg, int n_seg, int C, float* out,
+                                 dal3_stream stream) {
+    if (!z || !arg || !out || seg <= 0 || n_seg <= 0 || C <= 0 || ldz < C) return fail(DAL3_EINVAL, "tr_gather_at: bad argument");
+    HIP_TRY(launch_tr_gather_at(z, ldz, arg, seg, n_seg, C, out, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_tr_pool_zarg(const int32_t* arg, const float* a, int64_t lda, const float* W, int64_t ldw, const float* bias,
                                  int B, int C, int K, int N, float* zarg, dal3_stream stream) {
     if (!arg || !a || !W || !bias || !zarg || B <= 0 || C <= 0 || N <= 0 || K <= 0 || K % 4 || lda < K || ldw < K || lda % 4 || ldw % 4 ||
@@ -1304,6 +1311,48 @@ extern "C" int dal3_tr_act_dropout(const float* x, int64_t M, int C, int64_t ldx
         return fail(DAL3_EINVAL, "tr_act_dropout: bad argument (C and the row strides multiples of 4, 0 <= p <= 1)");
     HIP_TRY(launch_tr_act_dropout(x, M, C, ldx, scale, shift, relu, mult, ldm, seed, step, p_drop, out, ldo,
                                   static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+static bool head2_common_ok(int64_t M, int C, const float* mult, int64_t ldm, float p_drop) {
+    return M > 0 && C == 128 && (!mult || (ldm >= C && !(ldm & 3) && !(reinterpret_cast<uintptr_t>(mult) & 15))) &&
+           p_drop >= 0.0f && p_drop <= 1.0f;
+}
+
+extern "C" int dal3_tr_head2_forward(const float* z, int64_t M, int C, int64_t ldz, const float* scale, const float* shift, int relu,
+                                     const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop,
+                                     const float* W, int64_t ldw, const float* bias, float* logits, dal3_stream stream) {
+    if (!z || !W || !bias || !logits || !head2_common_ok(M, C, mult, ldm, p_drop) || ldz < C || (ldz & 3) || ldw < C || (ldw & 3) ||
+        (scale && !shift) || (reinterpret_cast<uintptr_t>(z) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) ||
+        (reinterpret_cast<uintptr_t>(logits) & 7))
+        return fail(DAL3_EINVAL, "tr_head2_forward: bad argument (C == 128, row strides multiples of 4, 16-byte aligned z / W / mult)");
+    HIP_TRY(launch_tr_head2_forward(z, M, ldz, scale, shift, relu, mult, ldm, seed, step, p_drop, W, ldw, bias, logits,
+                                    static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_head2_dgrad(const float* dlogits, int64_t M, int C, const float* mult, int64_t ldm, uint64_t seed,
+                                   const int64_t* step, float p_drop, const float* W, int64_t ldw, float* da, int64_t ldda,
+                                   dal3_stream stream) {
+    if (!dlogits || !W || !da || !head2_common_ok(M, C, mult, ldm, p_drop) || ldw < C || (ldw & 3) || ldda < C || (ldda & 3) ||
+        (reinterpret_cast<uintptr_t>(dlogits) & 7) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(da) & 15))
+        return fail(DAL3_EINVAL, "tr_head2_dgrad: bad argument (C == 128, row strides multiples of 4, aligned pointers)");
+    HIP_TRY(launch_tr_head2_dgrad(dlogits, M, mult, ldm, seed, step, p_drop, W, ldw, da, ldda, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" size_t dal3_tr_head2_wgrad_workspace_bytes(int64_t M) { return M > 0 ? tr_head2_wgrad_workspace_bytes(M) : 0; }
+
+extern "C" int dal3_tr_head2_wgrad(const float* dlogits, const float* z, int64_t M, int C, int64_t ldz, const float* scale,
+                                   const float* shift, int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step,
+                                   float p_drop, void* workspace, size_t workspace_bytes, double* sums, dal3_stream stream) {
+    if (!dlogits || !z || !sums || !head2_common_ok(M, C, mult, ldm, p_drop) || ldz < C || (ldz & 3) || (scale && !shift) ||
+        (reinterpret_cast<uintptr_t>(z) & 15) || (reinterpret_cast<uintptr_t>(dlogits) & 7))
+        return fail(DAL3_EINVAL, "tr_head2_wgrad: bad argument (C == 128, row strides multiples of 4, aligned pointers)");
+    if (!workspace || workspace_bytes < tr_head2_wgrad_workspace_bytes(M))
+        return fail(DAL3_EWORKSPACE, "tr_head2_wgrad: workspace smaller than dal3_tr_head2_wgrad_workspace_bytes()");
+    HIP_TRY(launch_tr_head2_wgrad(dlogits, z, M, ldz, scale, shift, relu, mult, ldm, seed, step, p_drop,
+                                  static_cast<double*>(workspace), sums, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

@@ -300,6 +300,17 @@ hipError_t launch_tr_pool_gv(const double* coef, const float* W, int64_t ldw, co
                              double* ws, hipStream_t s);
 hipError_t launch_tr_pool_dw(const double* coef, const float* W, int64_t ldw, const float* b, const float* S, const double* m1,
                              int64_t M, int centred, const float* dWs, int C, int K, float* dW, hipStream_t s);
+// the 128 -> 2 logits layer with its Dropout as VALU kernels (dal3_train.hip)
+hipError_t launch_tr_head2_forward(const float* z, int64_t M, int64_t ldz, const float* scale, const float* shift, int relu,
+                                   const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, const float* W,
+                                   int64_t ldw, const float* bias, float* logits, hipStream_t s);
+hipError_t launch_tr_head2_dgrad(const float* dl, int64_t M, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step,
+                                 float p_drop, const float* W, int64_t ldw, float* da, int64_t ldda, hipStream_t s);
+size_t tr_head2_wgrad_workspace_bytes(int64_t M);
+hipError_t launch_tr_head2_wgrad(const float* dl, const float* z, int64_t M, int64_t ldz, const float* scale, const float* shift,
+                                 int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop,
+                                 double* ws, double* sums, hipStream_t s);
+hipError_t launch_tr_gather_at(const float* z, int64_t ldz, const int32_t* arg, int64_t seg, int n_seg, int C, float* out, hipStream_t s);
 hipError_t launch_tr_pool_zarg(const int32_t* arg, const float* a, int64_t lda, const float* W, int64_t ldw, const float* bias, int B,
                                int C, int K, int N, float* zarg, hipStream_t s);
 hipError_t launch_tr_pool_sparse(const int32_t* arg, const float* kd, const float* W, int64_t ldw, const float* a, int64_t lda,

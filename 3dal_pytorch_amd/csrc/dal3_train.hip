@@ -1961,6 +1961,208 @@ hipError_t launch_tr_act_dropout(const float* x, int64_t M, int C, int64_t ldx, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------- the 128 -> 2 logits layer
+// dconv5 is Dropout(relu(dbn4(z4))) -> Conv1d(128, 2) (static_model.py:292-294). Through the MFMA kernels it was the
+// activation + Dropout pass writing a4 (134 MB), a 128 -> 32 linear on a weight padded from 2 to 32 rows, and backward a
+// zero-padded (M, 32) gradient, a 32 -> 128 dgrad, the Dropout pass over its output and a 32 x 128 wgrad: 0.30 ms of a
+// 7.1 ms step for 512 multiply-adds per point. Three VALU kernels instead (round 4), a4 never materialised — the
+// multiplier is re-created from its key wherever it is needed, exactly as tr_act_dropout_kernel draws it:
+//   forward  logits[p][j] = b[j] + sum_c W[j][c] * m[p][c] * act(z[p][c])
+//   dgrad    da[p][c]     = m[p][c] * (dl[p][0] W[0][c] + dl[p][1] W[1][c])          (gradient w.r.t. act(z), Dropout undone)
+//   wgrad    dW[j][c]     = sum_p dl[p][j] * m[p][c] * act(z[p][c]),  db[j] = sum_p dl[p][j]   (float64 partials per 256 rows,
+//            added in row-block order by tr_colred_final_kernel<0>: the column-reduction machinery, MODE 2)
+// 32 lanes x 4 channels per point: C == 128.
+struct DropKey {
+    const float* mult;                   // explicit multiplier (M x C, row stride ldm) or NULL
+    int64_t ldm;
+    uint64_t key;                        // seed + step * const (resolved on the device: step lives there)
+    uint32_t thresh;
+    float keep_scale;
+};
+__device__ __forceinline__ f32x4 drop_mult4(const DropKey& d, int64_t p, int c, int C) {
+    if (d.mult) return *reinterpret_cast<const f32x4*>(d.mult + p * d.ldm + c);
+    f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = tr_hash32(d.key, (uint64_t)(p * C + c + e)) >= d.thresh ? d.keep_scale : 0.0f;
+    return m;
+}
+__device__ __forceinline__ f32x4 act4(const f32x4 v, const f32x4 sc, const f32x4 sh, bool affine, int relu) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = affine ? __builtin_fmaf(v[e], sc[e], sh[e]) : v[e];
+        o[e] = relu ? fmaxf(x, 0.0f) : x;
+    }
+    return o;
+}
+__global__ __launch_bounds__(256) void tr_head2_fwd_kernel(const float* __restrict__ z, int64_t M, int64_t ldz,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                           DropKey d, uint64_t seed, const int64_t* __restrict__ step,
+                                                           const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
+                                                           float* __restrict__ logits) {
+    constexpr int C = 128;
+    const int l = threadIdx.x & 31, c = 4 * l;
+    d.key = seed + (step ? (uint64_t)(*step) * 0xD1B54A32D192ED03ull : 0ull);
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(W + c), w1 = *reinterpret_cast<const f32x4*>(W + ldw + c);
+    f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+    if (scale) {
+        sc = *reinterpret_cast<const f32x4*>(scale + c);
+        sh = *reinterpret_cast<const f32x4*>(shift + c);
+    }
+    const float b0 = bias[0], b1 = bias[1];
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    for (int64_t p0 = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); p0 < M; p0 += 4 * stride) {
+        f32x4 v[4];                                         // four points' loads in flight per lane group
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(z + min(p0 + u * stride, M - 1) * ldz + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = p0 + u * stride;
+            if (p >= M) break;                              // (uniform over the 32 lanes of a point)
+            const f32x4 a = act4(v[u], sc, sh, scale != nullptr, relu), m = drop_mult4(d, p, c, C);
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = a[e] * m[e];
+                s0 = __builtin_fmaf(x, w0[e], s0);
+                s1 = __builtin_fmaf(x, w1[e], s1);
+            }
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) {             // a fixed tree over the point's 32 lanes
+                s0 += __shfl_xor(s0, o, 64);
+                s1 += __shfl_xor(s1, o, 64);
+            }
+            if (l == 0) {
+                f32x2 o2 = {s0 + b0, s1 + b1};
+                *reinterpret_cast<f32x2*>(logits + p * 2) = o2;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void tr_head2_dgrad_kernel(const float* __restrict__ dl, int64_t M, DropKey d, uint64_t seed,
+                                                             const int64_t* __restrict__ step, const float* __restrict__ W,
+                                                             int64_t ldw, float* __restrict__ da, int64_t ldda) {
+    constexpr int C = 128;
+    const int l = threadIdx.x & 31, c = 4 * l;
+    d.key = seed + (step ? (uint64_t)(*step) * 0xD1B54A32D192ED03ull : 0ull);
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(W + c), w1 = *reinterpret_cast<const f32x4*>(W + ldw + c);
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    for (int64_t p = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); p < M; p += stride) {
+        const f32x2 g = *reinterpret_cast<const f32x2*>(dl + p * 2);
+        const f32x4 m = drop_mult4(d, p, c, C);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = m[e] * __builtin_fmaf(g[0], w0[e], g[1] * w1[e]);
+        *reinterpret_cast<f32x4*>(da + p * ldda + c) = o;
+    }
+}
+// wgrad: per block 256 rows x 128 channels (+ the two bias sums in channel slots 128, 129): thread = (4 channels, 8 row
+// lanes), float64 partial sums, one partial row per block — the layout tr_colred_final_kernel<0> adds up (C = 130 columns)
+#define H2_COLS 130
+__global__ __launch_bounds__(256) void tr_head2_wgrad_kernel(const float* __restrict__ dl, const float* __restrict__ z, int64_t M,
+                                                             int64_t ldz, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int relu, DropKey d, uint64_t seed,
+                                                             const int64_t* __restrict__ step, double* __restrict__ part) {
+    constexpr int C = 128;
+    __shared__ double sm[2][8][H2_COLS];
+    const int l = threadIdx.x & 31, rl = threadIdx.x >> 5, c = 4 * l;
+    d.key = seed + (step ? (uint64_t)(*step) * 0xD1B54A32D192ED03ull : 0ull);
+    f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+    if (scale) {
+        sc = *reinterpret_cast<const f32x4*>(scale + c);
+        sh = *reinterpret_cast<const f32x4*>(shift + c);
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * TR_RED_ROWS, r1 = min(M, r0 + TR_RED_ROWS);
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, t0 = 0.0, t1 = 0.0;
+    for (int64_t p0 = r0 + rl; p0 < r1; p0 += 8 * 4) {
+        f32x4 v[4];
+        f32x2 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = min(p0 + 8 * u, M - 1);
+            v[u] = *reinterpret_cast<const f32x4*>(z + p * ldz + c);
+            g[u] = *reinterpret_cast<const f32x2*>(dl + p * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = p0 + 8 * u;
+            if (p >= r1) break;
+            const f32x4 a = act4(v[u], sc, sh, scale != nullptr, relu), m = drop_mult4(d, p, c, C);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double x = (double)(a[e] * m[e]);
+                s0[e] += x * (double)g[u][0];
+                s1[e] += x * (double)g[u][1];
+            }
+            if (l == 0) {
+                t0 += (double)g[u][0];
+                t1 += (double)g[u][1];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sm[0][rl][c + e] = s0[e];
+        sm[1][rl][c + e] = s1[e];
+    }
+    if (l == 0) {
+        sm[0][rl][128] = t0;                                // db[0]: column 128 of "sum 0", db[1]: column 129
+        sm[0][rl][129] = t1;
+        sm[1][rl][128] = 0.0;
+        sm[1][rl][129] = 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < H2_COLS) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int i = 0; i < 8; ++i) {
+            a0 += sm[0][i][threadIdx.x];
+            a1 += sm[1][i][threadIdx.x];
+        }
+        const int64_t o = ((int64_t)blockIdx.x * H2_COLS + threadIdx.x) * 2;
+        part[o] = a0;
+        part[o + 1] = a1;
+    }
+}
+static DropKey drop_key(const float* mult, int64_t ldm, float p_drop) {
+    const double t = (double)p_drop * 4294967296.0;
+    DropKey d{};
+    d.mult = mult, d.ldm = ldm;
+    d.thresh = p_drop <= 0.0f ? 0u : (t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t);
+    d.keep_scale = p_drop < 1.0f ? 1.0f / (1.0f - p_drop) : 0.0f;
+    return d;
+}
+static unsigned head2_grid(int64_t M) {
+    const int64_t want = (M + 7) / 8;
+    return (unsigned)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+}
+hipError_t launch_tr_head2_forward(const float* z, int64_t M, int64_t ldz, const float* scale, const float* shift, int relu,
+                                   const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, const float* W,
+                                   int64_t ldw, const float* bias, float* logits, hipStream_t s) {
+    hipLaunchKernelGGL(tr_head2_fwd_kernel, dim3(head2_grid((M + 3) / 4)), dim3(256), 0, s, z, M, ldz, scale, shift, relu,
+                       drop_key(mult, ldm, p_drop), seed, step, W, ldw, bias, logits);
+    return hipGetLastError();
+}
+hipError_t launch_tr_head2_dgrad(const float* dl, int64_t M, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step,
+                                 float p_drop, const float* W, int64_t ldw, float* da, int64_t ldda, hipStream_t s) {
+    hipLaunchKernelGGL(tr_head2_dgrad_kernel, dim3(head2_grid(M)), dim3(256), 0, s, dl, M, drop_key(mult, ldm, p_drop), seed, step, W,
+                       ldw, da, ldda);
+    return hipGetLastError();
+}
+size_t tr_head2_wgrad_workspace_bytes(int64_t M) {
+    return (size_t)((M + TR_RED_ROWS - 1) / TR_RED_ROWS) * H2_COLS * 2 * sizeof(double);
+}
+// sums (2 * H2_COLS float64): [0, 128) = dW[0][.], 128 / 129 = db[0] / db[1], [130, 258) = dW[1][.] (258, 259 unused)
+hipError_t launch_tr_head2_wgrad(const float* dl, const float* z, int64_t M, int64_t ldz, const float* scale, const float* shift,
+                                 int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop,
+                                 double* ws, double* sums, hipStream_t s) {
+    const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
+    hipLaunchKernelGGL(tr_head2_wgrad_kernel, dim3(nb), dim3(256), 0, s, dl, z, M, ldz, scale, shift, relu, drop_key(mult, ldm, p_drop),
+                       seed, step, ws);
+    hipLaunchKernelGGL(tr_colred_final_kernel<0>, dim3((H2_COLS + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, ws, nb, H2_COLS, sums,
+                       BnEpi{});
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------- max over points
 // g[s][c] = max_p act(z[p][c]) over the `seg` points of segment s, with the index of the FIRST maximum for the
 // backward pass. Block = 64 channels x 4 row-lanes over one of SEG_CHUNKS chunks of the segment; candidates meet
@@ -2446,6 +2648,22 @@ __global__ __launch_bounds__(256) void tr_pool_zarg_kernel(const int32_t* __rest
     acc += __shfl_xor(acc, 1, 64);
     if (l == 0 && i < n) zarg[i] = acc + bias[c];
 }
+// out[s][c] = z[(s*seg + arg[s][c])][c]: the pre-BN value at each pooled point when the layer's output IS materialised
+// (the point heads' unfused conv4 + max): one launch instead of the seven of a stock fancy-indexing expression
+__global__ __launch_bounds__(256) void tr_gather_at_kernel(const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ arg,
+                                                           int64_t seg, int64_t n, int C, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t s = i / C;
+    const int c = (int)(i - s * C);
+    out[i] = z[(s * seg + arg[i]) * ldz + c];
+}
+hipError_t launch_tr_gather_at(const float* z, int64_t ldz, const int32_t* arg, int64_t seg, int n_seg, int C, float* out, hipStream_t s) {
+    const int64_t n = (int64_t)n_seg * C;
+    hipLaunchKernelGGL(tr_gather_at_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, ldz, arg, seg, n, C, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_tr_pool_zarg(const int32_t* arg, const float* a, int64_t lda, const float* W, int64_t ldw, const float* bias, int B,
                                int C, int K, int N, float* zarg, hipStream_t s) {
     const int64_t n = (int64_t)B * C;

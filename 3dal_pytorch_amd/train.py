@@ -424,11 +424,56 @@ def _act_dropout(x, act, drop):
     return out
 
 
+def _drop_args(drop):
+    """drop (None | multiplier tensor | (seed, step tensor, p)) -> (mult, ldm, seed, step, p) as the C ABI takes them"""
+    if torch.is_tensor(drop):
+        return drop, drop.stride(0), 0, None, 0.0
+    if drop is not None:
+        seed, step, p = drop
+        return None, 0, seed, step, float(p)
+    return None, 0, 0, None, 0.0
+
+
+def _head2_forward(z, act, drop, W, b, M):
+    """logits (M, 2) = dconv5(Dropout(act(z))) without the post-Dropout activation in memory (dal3_tr_head2_forward)"""
+    sc, sh, relu = act
+    mult, ldm, seed, step, p = _drop_args(drop)
+    out = torch.empty((M, 2), dtype=torch.float32, device=z.device)
+    _note("head2", M, 128, 2, 0.0, 4.0 * M * 130)
+    _hip.check(_hip.lib().dal3_tr_head2_forward(_hip.ptr(z), M, z.shape[1], z.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu),
+                                                _hip.ptr(mult), ldm, seed, _hip.ptr(step), p, _hip.ptr(W), W.stride(0), _hip.ptr(b),
+                                                _hip.ptr(out), _hip.stream()))
+    return out
+
+
+def _head2_backward(dl, z, act, drop, W, M):
+    """(da (rows of z, 128) = gradient w.r.t. act(z), dW (2, 128), db (2,)) of the same layer: dal3_tr_head2_dgrad / _wgrad"""
+    lib = _hip.lib()
+    sc, sh, relu = act
+    mult, ldm, seed, step, p = _drop_args(drop)
+    C = z.shape[1]
+    da = torch.empty((z.shape[0], C), dtype=torch.float32, device=z.device)
+    _note("head2", M, 2, 128, 0.0, 4.0 * M * 130)
+    _hip.check(lib.dal3_tr_head2_dgrad(_hip.ptr(dl), M, C, _hip.ptr(mult), ldm, seed, _hip.ptr(step), p, _hip.ptr(W), W.stride(0),
+                                       _hip.ptr(da), da.stride(0), _hip.stream()))
+    if z.shape[0] > M:
+        da[M:].zero_()
+    need = lib.dal3_tr_head2_wgrad_workspace_bytes(M)
+    ws = _ws(need, z.device)
+    sums = torch.empty(260, dtype=torch.float64, device=z.device)
+    _note("head2", M, 128, 2, 0.0, 4.0 * M * 130)
+    _hip.check(lib.dal3_tr_head2_wgrad(_hip.ptr(dl), _hip.ptr(z), M, C, z.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu), _hip.ptr(mult),
+                                       ldm, seed, _hip.ptr(step), p, _hip.ptr(ws), need, _hip.ptr(sums), _hip.stream()))
+    f = sums.float()
+    return da, torch.stack([f[:128], f[130:258]]), f[128:130]
+
+
 def _gather_at(z, arg, seg):
     """z[item*seg + arg[item,c], c] -> (items, C): the pre-BN value at each pooled point"""
     n_seg, C = arg.shape
-    rows = arg.long() + torch.arange(n_seg, device=z.device)[:, None] * seg
-    return z[rows, torch.arange(C, device=z.device)[None, :]]
+    out = torch.empty((n_seg, C), dtype=torch.float32, device=z.device)
+    _hip.check(_hip.lib().dal3_tr_gather_at(_hip.ptr(z), z.stride(0), _hip.ptr(arg), seg, n_seg, C, _hip.ptr(out), _hip.stream()))
+    return out
 
 
 def _segsum(x, seg, n_seg):
@@ -658,8 +703,13 @@ class _InsSeg(torch.autograd.Function):
             W2 = P[4 * k].reshape(P[4 * k].shape[0], -1)
             W2s[k] = _pad_cols(W2, 32) if k == 0 else W2.contiguous()
         Wd1 = P[20].reshape(P[20].shape[0], -1).contiguous()            # dconv1 (512, 1088): columns 0..63 per point
-        W5 = torch.zeros((32, 128), dtype=torch.float32, device=pts.device)
-        W5[:2] = P[36].reshape(2, 128)                                  # dconv5, rows padded to a tile
+        # dconv5 (128 -> 2) with its Dropout: three VALU kernels (dal3_tr_head2_*) when dconv4 has the reference's 128 channels;
+        # otherwise through the MFMA kernels on a weight padded from 2 to 32 rows
+        head2 = P[32].shape[0] == 128 and P[36].shape[0] == 2
+        W5 = P[36].reshape(2, -1).contiguous()
+        if not head2:
+            W5 = torch.zeros((32, 128), dtype=torch.float32, device=pts.device)
+            W5[:2] = P[36].reshape(2, 128)                              # rows padded to a tile
         fw = lambda k: (W2s[k], W2s[k].shape[1], W2s[k].shape[0], False, Mp, 0, False, k > 0)      # noqa: E731
         # (dg: the decoder's dgrads get their operand's amax from the BatchNorm backward in front of them, so they may take
         # the f16x3 image when the arithmetic says so and the shape qualifies — dconv3's and dconv2's do)
@@ -673,6 +723,9 @@ class _InsSeg(torch.autograd.Function):
                  (W5, 128, 32, False, Mp, 0, False, False), (W5, 32, 128, True, Mp, 0, False, False), tr(8, dg=True), tr(7, dg="fp32"),
                  tr(6, dg=True),
                  (Wd1, 512, 64, True, Mp, 0, False, False), tr(3), tr(2, True), tr(1)]
+        if head2:                                                       # (no packed images for dconv5)
+            specs = [sp for sp, name in zip(specs, order) if name not in ("fd5", "td5")]
+            order = [name for name in order if name not in ("fd5", "td5")]
         pk = dict(zip(order, _prepack(specs, pts.device)))
         pk["arith"] = ARITH                                             # (the backward runs outside the forward's context)
         a, act = a0, None
@@ -724,17 +777,23 @@ class _InsSeg(torch.autograd.Function):
             bns.append(bn)
             zs.append(z)
             a, act = z, bn.act
-        if torch.is_tensor(drop) and drop.shape[0] < zs[8].shape[0]:     # a supplied multiplier: pad its rows too
-            drop = torch.cat([drop, drop.new_zeros((zs[8].shape[0] - drop.shape[0], drop.shape[1]))])
-        a4 = _act_dropout(zs[8], bns[8].act, drop)                      # Dropout sits between dbn4's ReLU and dconv5
-        b5 = torch.zeros(32, dtype=torch.float32, device=pts.device)
-        b5[:2] = P[37]
-        zl = _linear(a4, W5, 128, 128, 32, bias=b5, packed=pk["fd5"])
+        if torch.is_tensor(drop):
+            drop = drop.contiguous()
+        if head2:                                                       # Dropout sits between dbn4's ReLU and dconv5
+            a4 = None
+            logits = _head2_forward(zs[8], bns[8].act, drop, W5, P[37].contiguous(), M).reshape(B, N, 2)
+        else:
+            if torch.is_tensor(drop) and drop.shape[0] < zs[8].shape[0]:     # a supplied multiplier: pad its rows too
+                drop = torch.cat([drop, drop.new_zeros((zs[8].shape[0] - drop.shape[0], drop.shape[1]))])
+            a4 = _act_dropout(zs[8], bns[8].act, drop)
+            b5 = torch.zeros(32, dtype=torch.float32, device=pts.device)
+            b5[:2] = P[37]
+            logits = _linear(a4, W5, 128, 128, 32, bias=b5, packed=pk["fd5"])[:M, :2].reshape(B, N, 2).contiguous()
         ctx.saved = (a0, Ws, bns, zs, g, arg, a4, drop, W5, N, [tuple(p.shape) for p in params], zarg, P[17].contiguous(),
                      (a4c, S4, m14), pk)
         if CAPTURE is not None:
             CAPTURE["ins_seg"] = {"zs": list(zs), "bns": list(bns), "g": g, "arg": arg, "M": M, "N": N, "B": B}
-        return zl[:M, :2].reshape(B, N, 2).contiguous()
+        return logits
 
     @staticmethod
     def backward(ctx, dlogits):
@@ -744,13 +803,17 @@ class _InsSeg(torch.autograd.Function):
         dev = a0.device
         grads = [None] * 38
         zero = _zero_grads(shapes, [4 * k + 1 for k in range(9)], dev)
-        dzl = torch.zeros((Mp, 32), dtype=torch.float32, device=dev)
-        dzl[:M, :2] = dlogits.reshape(M, 2)
-        grads[36] = _wgrad(dzl, a4, 32, 128)[:2].reshape(shapes[36])
-        grads[37] = dzl[:, :2].sum(0)
-        da = _linear(dzl, W5, 128, 32, 128, transpose=True, packed=pk["td5"])
-        if drop is not None:
-            da = _act_dropout(da, None, drop)                           # the same multiplier, re-created from its key
+        if a4 is None:                                                  # dconv5 + Dropout on the head2 kernels
+            da, dW5, db5 = _head2_backward(dlogits.reshape(M, 2).contiguous(), zs[8], bns[8].act, drop, W5, M)
+            grads[36], grads[37] = dW5.reshape(shapes[36]), db5
+        else:
+            dzl = torch.zeros((Mp, 32), dtype=torch.float32, device=dev)
+            dzl[:M, :2] = dlogits.reshape(M, 2)
+            grads[36] = _wgrad(dzl, a4, 32, 128)[:2].reshape(shapes[36])
+            grads[37] = dzl[:, :2].sum(0)
+            da = _linear(dzl, W5, 128, 32, 128, transpose=True, packed=pk["td5"])
+            if drop is not None:
+                da = _act_dropout(da, None, drop)                       # the same multiplier, re-created from its key
         amaxes = torch.zeros(3 * 64, dtype=torch.int32, device=dlogits.device)
         co = None
         for k in (8, 7, 6):                                             # dconv4..2

@@ -435,6 +435,9 @@ int dal3_tr_pool_coef(const float* dg, const float* g, const float* zarg, const 
 /* zarg (B,C) = the pooled layer's pre-BatchNorm value at each pooled point: W[c] . a[b*N + arg[b][c]] + bias[c], from the
  * layer's input activation a (B*N, K) — what dal3_tr_pool_coef takes, when the fused forward (dal3_tr_linear_pool) has not
  * written the layer's output. fp32, a fixed order of additions. */
+/* out (n_seg, C) = z[s*seg + arg[s][c]][c]: the same values gathered from a MATERIALISED layer output (dal3_tr_segmax's arg) */
+int dal3_tr_gather_at(const float* z, int64_t ldz, const int32_t* arg, int64_t seg, int n_seg, int C, float* out,
+                      dal3_stream stream);
 int dal3_tr_pool_zarg(const int32_t* arg, const float* a, int64_t lda, const float* W, int64_t ldw, const float* bias, int B, int C,
                       int K, int N, float* zarg, dal3_stream stream);
 int dal3_tr_pool_moments(const float* W, int64_t ldw, const float* b, const double* m1, const float* Sc, int64_t M, int C, int K,
@@ -522,6 +525,24 @@ int dal3_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float*
  * same multiplier without storing it; step (device int64, may be NULL = 0) lets a hipGraph replay draw afresh.
  * Replaces: self.dropout = nn.Dropout(p=0.5) applied to relu(dbn4(dconv4(x))) (static_model.py:268,292-293) and its
  * backward. */
+/* The 128 -> 2 logits layer with the Dropout in front of it (static_model.py:292-294: dconv5(dropout(relu(dbn4(z))))) as three
+ * VALU kernels; the post-Dropout activation is never materialised, the multiplier m is re-created from its key exactly as
+ * dal3_tr_act_dropout draws it (same mult / seed / step / p_drop arguments). C must be 128.
+ *   dal3_tr_head2_forward  logits[p][j] = bias[j] + sum_c W[j][c] * m[p][c] * act(z[p][c])       (W: 2 rows of C, row stride ldw)
+ *   dal3_tr_head2_dgrad    da[p][c] = m[p][c] * (dlogits[p][0] W[0][c] + dlogits[p][1] W[1][c])  (d / d act(z): Dropout undone)
+ *   dal3_tr_head2_wgrad    sums (260 float64): [0,128) = dW[0][.], [128] = db[0], [129] = db[1], [130,258) = dW[1][.]
+ *                          with dW[j][c] = sum_p dlogits[p][j] * m[p][c] * act(z[p][c]), db[j] = sum_p dlogits[p][j];
+ *                          float64 partial sums per 256 rows added in a fixed order.
+ *                          workspace: dal3_tr_head2_wgrad_workspace_bytes(M). */
+int dal3_tr_head2_forward(const float* z, int64_t M, int C, int64_t ldz, const float* scale, const float* shift, int relu,
+                          const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, const float* W,
+                          int64_t ldw, const float* bias, float* logits, dal3_stream stream);
+int dal3_tr_head2_dgrad(const float* dlogits, int64_t M, int C, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step,
+                        float p_drop, const float* W, int64_t ldw, float* da, int64_t ldda, dal3_stream stream);
+size_t dal3_tr_head2_wgrad_workspace_bytes(int64_t M);
+int dal3_tr_head2_wgrad(const float* dlogits, const float* z, int64_t M, int C, int64_t ldz, const float* scale, const float* shift,
+                        int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, void* workspace,
+                        size_t workspace_bytes, double* sums, dal3_stream stream);
 int dal3_tr_act_dropout(const float* x, int64_t M, int C, int64_t ldx, const float* scale, const float* shift, int relu,
                         const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, float* out,
                         int64_t ldo, dal3_stream stream);

@@ -134,3 +134,46 @@ def test_dgrad_with_fused_bn_backward_sums_equals_dgrad_then_sums(M, K, C, rows,
     dz_f, dgam_f, dbet_f = bn.backward(bz, da=da2, co=co2)
     dz_u, dgam_u, dbet_u = bn.backward(bz, da=da_ref)
     assert torch.equal(da2, da_ref) and _close(dz_f, dz_u) and _close(dgam_f, dgam_u) and _close(dbet_f, dbet_u)
+
+
+@pytest.mark.parametrize("M,Mp", [(64 * 4096, 64 * 4096), (5 * 77, 416), (3, 32)])
+def test_logits_layer_with_dropout_as_valu_kernels(M, Mp):
+    """dal3_tr_head2_* (round 4): dconv5(Dropout(relu(bn(z)))) forward, its input gradient and its parameter gradients
+    without the post-Dropout activation in memory — against the stock float64 composition on an explicit multiplier, and
+    with the multiplier re-created from a (seed, step) key: bit-identical to the run on the multiplier dal3_tr_act_dropout
+    draws from the same key."""
+    lib = hip.lib()
+    gen = torch.Generator(device="cuda").manual_seed(M)
+    z = torch.randn((Mp, 128), device="cuda", generator=gen)
+    sc = torch.rand(128, device="cuda", generator=gen) + 0.5
+    sh = torch.randn(128, device="cuda", generator=gen) * 0.3
+    W = torch.randn((2, 128), device="cuda", generator=gen) * 0.2
+    b = torch.randn(2, device="cuda", generator=gen)
+    dl = torch.randn((M, 2), device="cuda", generator=gen) * 1e-3
+    step = torch.tensor([3], dtype=torch.int64, device="cuda")
+    key = (123456789, step, 0.5)
+    # the multiplier that key stands for: act_dropout of ones
+    ones = torch.ones((M, 128), device="cuda")
+    mult = train._act_dropout(ones, None, key)
+    assert 0.4 < float((mult == 0).float().mean()) < 0.6 and float(mult.max()) == 2.0
+    a64 = (torch.relu(z[:M].double() * sc.double() + sh.double()) * mult.double())
+    want_logits = a64 @ W.double().t() + b.double()
+    want_da = (dl.double() @ W.double()) * mult.double()
+    want_dW = dl.double().t() @ a64
+    want_db = dl.double().sum(0)
+    res = {}
+    for tag, drop in (("mask", mult), ("key", key)):
+        logits = train._head2_forward(z, (sc, sh, True), drop, W, b, M)
+        da, dW, db = train._head2_backward(dl, z, (sc, sh, True), drop, W, M)
+        torch.cuda.synchronize()
+        res[tag] = (logits, da, dW, db)
+        assert _close(logits, want_logits, 2e-6)
+        assert _close(da[:M], want_da, 2e-6) and (Mp == M or float(da[M:].abs().max()) == 0.0)
+        assert _close(dW, want_dW, 2e-6) and _close(db, want_db, 2e-6)
+    for x, y in zip(res["mask"], res["key"]):
+        assert torch.equal(x, y)
+    # no Dropout at all (p = 0): the plain layer
+    logits = train._head2_forward(z, (sc, sh, True), None, W, b, M)
+    assert _close(logits, torch.relu(z[:M].double() * sc.double() + sh.double()) @ W.double().t() + b.double(), 2e-6)
+    assert lib.dal3_tr_head2_forward(hip.ptr(z), M, 64, 128, None, None, 0, None, 0, 0, None, 0.0, hip.ptr(W), 128, hip.ptr(b),
+                                     hip.ptr(logits), hip.stream()) == hip.EINVAL          # C must be 128
