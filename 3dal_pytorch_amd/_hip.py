@@ -108,6 +108,8 @@ SIGNATURES = {
     "dal3_tr_pool_coef": (_i, [vp, vp, vp, vp, vp, vp, _i, _i, _i64, vp, vp, vp]),
     "dal3_tr_head2_forward": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _u64, vp, C.c_float, vp, _i64, vp, vp, vp]),
     "dal3_tr_head2_dgrad": (_i, [vp, _i64, _i, vp, _i64, _u64, vp, C.c_float, vp, _i64, vp, _i64, vp]),
+    "dal3_tr_head2_dgrad_bnbwd": (_i, [vp, _i64, _i, vp, _i64, _u64, vp, C.c_float, vp, _i64, vp, _i64, vp, _i64, vp, vp, vp, vp, vp,
+                                       vp, vp, vp, vp, vp, vp, _sz, vp]),
     "dal3_tr_head2_wgrad_workspace_bytes": (_sz, [_i64]),
     "dal3_tr_head2_wgrad": (_i, [vp, vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _u64, vp, C.c_float, vp, _sz, vp, vp]),
     "dal3_tr_gather_at": (_i, [vp, _i64, vp, _i64, _i, _i, vp, vp]),

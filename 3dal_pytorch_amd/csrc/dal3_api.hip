@@ -1341,6 +1341,24 @@ extern "C" int dal3_tr_head2_dgrad(const float* dlogits, int64_t M, int C, const
     return 0;
 }
 
+extern "C" int dal3_tr_head2_dgrad_bnbwd(const float* dlogits, int64_t M, int C, const float* mult, int64_t ldm, uint64_t seed,
+                                         const int64_t* step, float p_drop, const float* W, int64_t ldw, float* da, int64_t ldda,
+                                         const float* bz, int64_t ldbz, const float* bscale, const float* bshift, const float* bmu,
+                                         const float* brstd, const float* gamma, float* dgamma, float* dbeta, float* k1, float* k2,
+                                         float* k3, void* workspace, size_t workspace_bytes, dal3_stream stream) {
+    if (!dlogits || !W || !da || !bz || !bscale || !bshift || !bmu || !brstd || !gamma || !dgamma || !dbeta || !k1 || !k2 || !k3 ||
+        !head2_common_ok(M, C, mult, ldm, p_drop) || ldw < C || (ldw & 3) || ldda < C || (ldda & 3) || ldbz < C || (ldbz & 3) ||
+        (reinterpret_cast<uintptr_t>(dlogits) & 7) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(da) & 15) ||
+        (reinterpret_cast<uintptr_t>(bz) & 15))
+        return fail(DAL3_EINVAL, "tr_head2_dgrad_bnbwd: bad argument (C == 128, row strides multiples of 4, aligned pointers)");
+    if (!workspace || workspace_bytes < tr_colred_workspace_bytes(M, C))
+        return fail(DAL3_EWORKSPACE, "tr_head2_dgrad_bnbwd: workspace smaller than dal3_tr_colred_workspace_bytes(M, 128)");
+    HIP_TRY(launch_tr_head2_dgrad_bnbwd(dlogits, M, mult, ldm, seed, step, p_drop, W, ldw, da, ldda, bz, ldbz, bscale, bshift, bmu, brstd,
+                                        gamma, dgamma, dbeta, k1, k2, k3, static_cast<double*>(workspace),
+                                        static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" size_t dal3_tr_head2_wgrad_workspace_bytes(int64_t M) { return M > 0 ? tr_head2_wgrad_workspace_bytes(M) : 0; }
 
 extern "C" int dal3_tr_head2_wgrad(const float* dlogits, const float* z, int64_t M, int C, int64_t ldz, const float* scale,

@@ -306,6 +306,11 @@ hipError_t launch_tr_head2_forward(const float* z, int64_t M, int64_t ldz, const
                                    int64_t ldw, const float* bias, float* logits, hipStream_t s);
 hipError_t launch_tr_head2_dgrad(const float* dl, int64_t M, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step,
                                  float p_drop, const float* W, int64_t ldw, float* da, int64_t ldda, hipStream_t s);
+hipError_t launch_tr_head2_dgrad_bnbwd(const float* dl, int64_t M, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step,
+                                       float p_drop, const float* W, int64_t ldw, float* da, int64_t ldda, const float* bz,
+                                       int64_t ldbz, const float* bscale, const float* bshift, const float* bmu, const float* brstd,
+                                       const float* gamma, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, double* part,
+                                       hipStream_t s);
 size_t tr_head2_wgrad_workspace_bytes(int64_t M);
 hipError_t launch_tr_head2_wgrad(const float* dl, const float* z, int64_t M, int64_t ldz, const float* scale, const float* shift,
                                  int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop,

@@ -1940,7 +1940,7 @@ __global__ __launch_bounds__(256) void tr_act_dropout_kernel(const float* __rest
             const f32x4 mv = *reinterpret_cast<const f32x4*>(mult + p * ldm + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= mv[e];
-        } else {
+        } else if (thresh != 0u) {                          // (p_drop == 0: every element kept at scale 1, no draw to make)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = tr_hash32(key, (uint64_t)(p * C + c + e)) >= thresh ? v[e] * keep_scale : 0.0f;
         }
@@ -1981,6 +1981,7 @@ struct DropKey {
 };
 __device__ __forceinline__ f32x4 drop_mult4(const DropKey& d, int64_t p, int c, int C) {
     if (d.mult) return *reinterpret_cast<const f32x4*>(d.mult + p * d.ldm + c);
+    if (d.thresh == 0u) return f32x4{d.keep_scale, d.keep_scale, d.keep_scale, d.keep_scale};      // p_drop == 0: no draw
     f32x4 m;
 #pragma unroll
     for (int e = 0; e < 4; ++e) m[e] = tr_hash32(d.key, (uint64_t)(p * C + c + e)) >= d.thresh ? d.keep_scale : 0.0f;
@@ -2054,6 +2055,69 @@ __global__ __launch_bounds__(256) void tr_head2_dgrad_kernel(const float* __rest
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = m[e] * __builtin_fmaf(g[0], w0[e], g[1] * w1[e]);
         *reinterpret_cast<f32x4*>(da + p * ldda + c) = o;
+    }
+}
+// dgrad TOGETHER with the BatchNorm-backward sums of the layer below (dbn4): the thread that forms da[p][c] also reads that
+// layer's pre-BN value, gates it and accumulates sum dy, sum dy * xhat for its four channels (float64, as tr_colred_kernel
+// mode 1; one partial row per 256-row block, added by tr_colred_final_kernel<2> with the coefficient epilogue) — the
+// separate sums pass (a read of da and z: 60 us) becomes one more read of z inside this HBM-bound kernel.
+__global__ __launch_bounds__(256) void tr_head2_dgrad_sums_kernel(const float* __restrict__ dl, int64_t M, DropKey d, uint64_t seed,
+                                                                  const int64_t* __restrict__ step, const float* __restrict__ W,
+                                                                  int64_t ldw, float* __restrict__ da, int64_t ldda,
+                                                                  const float* __restrict__ bz, int64_t ldbz,
+                                                                  const float* __restrict__ bscale, const float* __restrict__ bshift,
+                                                                  const float* __restrict__ bmu, const float* __restrict__ brstd,
+                                                                  double* __restrict__ part) {
+    constexpr int C = 128;
+    __shared__ double sm[2][8][C];
+    const int l = threadIdx.x & 31, rl = threadIdx.x >> 5, c = 4 * l;
+    d.key = seed + (step ? (uint64_t)(*step) * 0xD1B54A32D192ED03ull : 0ull);
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(W + c), w1 = *reinterpret_cast<const f32x4*>(W + ldw + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(bscale + c), sh = *reinterpret_cast<const f32x4*>(bshift + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(bmu + c), rs = *reinterpret_cast<const f32x4*>(brstd + c);
+    const int64_t r0 = (int64_t)blockIdx.x * TR_RED_ROWS, r1 = min(M, r0 + TR_RED_ROWS);
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    for (int64_t p0 = r0 + rl; p0 < r1; p0 += 8 * 4) {
+        f32x4 v[4];
+        f32x2 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = min(p0 + 8 * u, M - 1);
+            v[u] = *reinterpret_cast<const f32x4*>(bz + p * ldbz + c);
+            g[u] = *reinterpret_cast<const f32x2*>(dl + p * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = p0 + 8 * u;
+            if (p >= r1) break;
+            const f32x4 m = drop_mult4(d, p, c, C);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = m[e] * __builtin_fmaf(g[u][0], w0[e], g[u][1] * w1[e]);
+                const float y = v[u][e] * sc[e] + sh[e];
+                const float dy = y > 0.0f ? o[e] : 0.0f;
+                s0[e] += dy;
+                s1[e] += (double)dy * ((v[u][e] - mu[e]) * rs[e]);
+            }
+            *reinterpret_cast<f32x4*>(da + p * ldda + c) = o;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sm[0][rl][c + e] = s0[e];
+        sm[1][rl][c + e] = s1[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int i = 0; i < 8; ++i) {
+            a0 += sm[0][i][threadIdx.x];
+            a1 += sm[1][i][threadIdx.x];
+        }
+        const int64_t o = ((int64_t)blockIdx.x * C + threadIdx.x) * 2;
+        part[o] = a0;
+        part[o + 1] = a1;
     }
 }
 // wgrad: per block 256 rows x 128 channels (+ the two bias sums in channel slots 128, 129): thread = (4 channels, 8 row
@@ -2146,6 +2210,20 @@ hipError_t launch_tr_head2_dgrad(const float* dl, int64_t M, const float* mult, 
                                  float p_drop, const float* W, int64_t ldw, float* da, int64_t ldda, hipStream_t s) {
     hipLaunchKernelGGL(tr_head2_dgrad_kernel, dim3(head2_grid(M)), dim3(256), 0, s, dl, M, drop_key(mult, ldm, p_drop), seed, step, W,
                        ldw, da, ldda);
+    return hipGetLastError();
+}
+// workspace: tr_colred_workspace_bytes(M, 128)
+hipError_t launch_tr_head2_dgrad_bnbwd(const float* dl, int64_t M, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step,
+                                       float p_drop, const float* W, int64_t ldw, float* da, int64_t ldda, const float* bz,
+                                       int64_t ldbz, const float* bscale, const float* bshift, const float* bmu, const float* brstd,
+                                       const float* gamma, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, double* part,
+                                       hipStream_t s) {
+    const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
+    hipLaunchKernelGGL(tr_head2_dgrad_sums_kernel, dim3(nb), dim3(256), 0, s, dl, M, drop_key(mult, ldm, p_drop), seed, step, W, ldw, da,
+                       ldda, bz, ldbz, bscale, bshift, bmu, brstd, part);
+    BnEpi e{};
+    e.M = M, e.gamma = gamma, e.rstd = const_cast<float*>(brstd), e.dgamma = dgamma, e.dbeta = dbeta, e.k1 = k1, e.k2 = k2, e.k3 = k3;
+    hipLaunchKernelGGL(tr_colred_final_kernel<2>, dim3((128 + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, nb, 128, nullptr, e);
     return hipGetLastError();
 }
 size_t tr_head2_wgrad_workspace_bytes(int64_t M) {

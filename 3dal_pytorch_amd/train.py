@@ -446,16 +446,30 @@ def _head2_forward(z, act, drop, W, b, M):
     return out
 
 
-def _head2_backward(dl, z, act, drop, W, M):
-    """(da (rows of z, 128) = gradient w.r.t. act(z), dW (2, 128), db (2,)) of the same layer: dal3_tr_head2_dgrad / _wgrad"""
+def _head2_backward(dl, z, act, drop, W, M, bn=None):
+    """(da (rows of z, 128) = gradient w.r.t. act(z), dW (2, 128), db (2,)[, co]) of the same layer: dal3_tr_head2_dgrad /
+    _wgrad. bn: the _BN of z — then the dgrad kernel also takes that layer's BatchNorm-backward sums (co, for
+    _BN.backward(co=)) and a fourth value is returned"""
     lib = _hip.lib()
     sc, sh, relu = act
     mult, ldm, seed, step, p = _drop_args(drop)
     C = z.shape[1]
     da = torch.empty((z.shape[0], C), dtype=torch.float32, device=z.device)
-    _note("head2", M, 2, 128, 0.0, 4.0 * M * 130)
-    _hip.check(lib.dal3_tr_head2_dgrad(_hip.ptr(dl), M, C, _hip.ptr(mult), ldm, seed, _hip.ptr(step), p, _hip.ptr(W), W.stride(0),
-                                       _hip.ptr(da), da.stride(0), _hip.stream()))
+    co = None
+    if bn is not None and bn.M == M:
+        co = torch.empty((5, C), dtype=torch.float32, device=z.device)
+        need = lib.dal3_tr_colred_workspace_bytes(M, C)
+        ws = _ws(need, z.device)
+        _note("head2", M, 2, 128, 0.0, 4.0 * M * 258)
+        _hip.check(lib.dal3_tr_head2_dgrad_bnbwd(_hip.ptr(dl), M, C, _hip.ptr(mult), ldm, seed, _hip.ptr(step), p, _hip.ptr(W),
+                                                 W.stride(0), _hip.ptr(da), da.stride(0), _hip.ptr(z), z.stride(0), _hip.ptr(bn.scale),
+                                                 _hip.ptr(bn.shift), _hip.ptr(bn.mu), _hip.ptr(bn.rstd), _hip.ptr(bn.gamma),
+                                                 _hip.ptr(co[0]), _hip.ptr(co[1]), _hip.ptr(co[2]), _hip.ptr(co[3]), _hip.ptr(co[4]),
+                                                 _hip.ptr(ws), need, _hip.stream()))
+    else:
+        _note("head2", M, 2, 128, 0.0, 4.0 * M * 130)
+        _hip.check(lib.dal3_tr_head2_dgrad(_hip.ptr(dl), M, C, _hip.ptr(mult), ldm, seed, _hip.ptr(step), p, _hip.ptr(W), W.stride(0),
+                                           _hip.ptr(da), da.stride(0), _hip.stream()))
     if z.shape[0] > M:
         da[M:].zero_()
     need = lib.dal3_tr_head2_wgrad_workspace_bytes(M)
@@ -465,6 +479,8 @@ def _head2_backward(dl, z, act, drop, W, M):
     _hip.check(lib.dal3_tr_head2_wgrad(_hip.ptr(dl), _hip.ptr(z), M, C, z.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu), _hip.ptr(mult),
                                        ldm, seed, _hip.ptr(step), p, _hip.ptr(ws), need, _hip.ptr(sums), _hip.stream()))
     f = sums.float()
+    if bn is not None:
+        return da, torch.stack([f[:128], f[130:258]]), f[128:130], co
     return da, torch.stack([f[:128], f[130:258]]), f[128:130]
 
 
@@ -803,8 +819,9 @@ class _InsSeg(torch.autograd.Function):
         dev = a0.device
         grads = [None] * 38
         zero = _zero_grads(shapes, [4 * k + 1 for k in range(9)], dev)
-        if a4 is None:                                                  # dconv5 + Dropout on the head2 kernels
-            da, dW5, db5 = _head2_backward(dlogits.reshape(M, 2).contiguous(), zs[8], bns[8].act, drop, W5, M)
+        co = None
+        if a4 is None:                                                  # dconv5 + Dropout on the head2 kernels, dbn4's sums with them
+            da, dW5, db5, co = _head2_backward(dlogits.reshape(M, 2).contiguous(), zs[8], bns[8].act, drop, W5, M, bn=bns[8])
             grads[36], grads[37] = dW5.reshape(shapes[36]), db5
         else:
             dzl = torch.zeros((Mp, 32), dtype=torch.float32, device=dev)
@@ -815,7 +832,6 @@ class _InsSeg(torch.autograd.Function):
             if drop is not None:
                 da = _act_dropout(da, None, drop)                       # the same multiplier, re-created from its key
         amaxes = torch.zeros(3 * 64, dtype=torch.int32, device=dlogits.device)
-        co = None
         for k in (8, 7, 6):                                             # dconv4..2
             # f16x3 step: dz's largest |value| comes with it (64 words), for the wgrad and — where its image is the f16x3
             # one — the dgrad of this layer

@@ -539,6 +539,14 @@ int dal3_tr_head2_forward(const float* z, int64_t M, int C, int64_t ldz, const f
                           int64_t ldw, const float* bias, float* logits, dal3_stream stream);
 int dal3_tr_head2_dgrad(const float* dlogits, int64_t M, int C, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step,
                         float p_drop, const float* W, int64_t ldw, float* da, int64_t ldda, dal3_stream stream);
+/* dal3_tr_head2_dgrad together with dal3_tr_bnbwd_sums of the layer below (z = bz, da = the gradient just formed; the layer
+ * whose relu(bn(bz)) feeds the Dropout): one kernel forms da, gates it and takes the two sums; workspace:
+ * dal3_tr_colred_workspace_bytes(M, 128). Same results as the two calls up to the order of the float64 additions. */
+int dal3_tr_head2_dgrad_bnbwd(const float* dlogits, int64_t M, int C, const float* mult, int64_t ldm, uint64_t seed,
+                              const int64_t* step, float p_drop, const float* W, int64_t ldw, float* da, int64_t ldda,
+                              const float* bz, int64_t ldbz, const float* bscale, const float* bshift, const float* bmu,
+                              const float* brstd, const float* gamma, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
+                              void* workspace, size_t workspace_bytes, dal3_stream stream);
 size_t dal3_tr_head2_wgrad_workspace_bytes(int64_t M);
 int dal3_tr_head2_wgrad(const float* dlogits, const float* z, int64_t M, int C, int64_t ldz, const float* scale, const float* shift,
                         int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, void* workspace,

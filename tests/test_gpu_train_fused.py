@@ -172,6 +172,15 @@ def test_logits_layer_with_dropout_as_valu_kernels(M, Mp):
         assert _close(dW, want_dW, 2e-6) and _close(db, want_db, 2e-6)
     for x, y in zip(res["mask"], res["key"]):
         assert torch.equal(x, y)
+    # the dgrad that also takes the BatchNorm-backward sums of the layer below: the same da bits, the same dz / dgamma / dbeta
+    gamma = torch.rand(128, device="cuda", generator=gen) + 0.5
+    bn = train._BN(z, gamma, sh, None, None, rows=M)
+    da_f, dW_f, db_f, co = train._head2_backward(dl, z, bn.act, key, W, M, bn=bn)
+    da_u, dW_u, db_u = train._head2_backward(dl, z, bn.act, key, W, M)
+    assert co is not None and torch.equal(da_f, da_u) and torch.equal(dW_f, dW_u)
+    dz_f, dgam_f, dbet_f = bn.backward(z, da=da_f, co=co)
+    dz_u, dgam_u, dbet_u = bn.backward(z, da=da_u)
+    assert _close(dz_f[:M], dz_u[:M]) and _close(dgam_f, dgam_u) and _close(dbet_f, dbet_u)
     # no Dropout at all (p = 0): the plain layer
     logits = train._head2_forward(z, (sc, sh, True), None, W, b, M)
     assert _close(logits, torch.relu(z[:M].double() * sc.double() + sh.double()) @ W.double().t() + b.double(), 2e-6)
