@@ -104,6 +104,7 @@ SIGNATURES = {
     "dal3_tr_linear_x3": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _i, vp, _i64, vp, vp, vp]),
     "dal3_tr_bnbwd_apply_amax": (_i, [vp, _i64, _i, _i64, vp, _i64, vp, vp, _i64, vp, vp, vp, vp, vp, vp, vp, vp, _i64, vp, vp]),
     "dal3_tr_colred_workspace_bytes": (_sz, [_i64, _i]),
+    "dal3_tr_act_colsum": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, vp, _sz, vp, vp]),
     "dal3_tr_colred": (_i, [vp, _i64, _i, _i64, _i, vp, _i64, vp, vp, _i64, vp, vp, vp, vp, vp, _sz, vp, vp]),
     "dal3_tr_pool_coef": (_i, [vp, vp, vp, vp, vp, vp, _i, _i, _i64, vp, vp, vp]),
     "dal3_tr_head2_forward": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _u64, vp, C.c_float, vp, _i64, vp, vp, vp]),

@@ -1049,6 +1049,17 @@ extern "C" size_t dal3_tr_colred_workspace_bytes(int64_t M, int C) {
     return (M > 0 && C > 0) ? tr_colred_workspace_bytes(M, C) : 0;
 }
 
+extern "C" int dal3_tr_act_colsum(const float* x, int64_t M, int C, int64_t ldx, const float* scale, const float* shift, int relu,
+                                  float* out, int64_t ldo, void* workspace, size_t workspace_bytes, double* sums, dal3_stream stream) {
+    if (!x || !out || !sums || M <= 0 || C <= 0 || (C & 3) || ldx < C || (ldx & 3) || ldo < C || (ldo & 3) || (scale && !shift))
+        return fail(DAL3_EINVAL, "tr_act_colsum: bad argument (C and the row strides multiples of 4)");
+    if (!workspace || workspace_bytes < tr_colred_workspace_bytes(M, C))
+        return fail(DAL3_EWORKSPACE, "tr_act_colsum: workspace smaller than dal3_tr_colred_workspace_bytes()");
+    HIP_TRY(launch_tr_act_colsum(x, M, C, ldx, scale, shift, relu, out, ldo, static_cast<double*>(workspace), sums,
+                                 static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                               const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                               const float* mu, const float* rstd, void* workspace, size_t workspace_bytes, double* out,

@@ -288,6 +288,8 @@ hipError_t launch_tr_linear_x3(const float* a, int64_t M, int c_in, int64_t lda,
                                const uint16_t* wpk, int layout, const float* bias, int64_t seg, int c_out, float* z, int64_t ldz,
                                hipStream_t s, const uint32_t* in_amax = nullptr);
 size_t tr_colred_workspace_bytes(int64_t M, int C);
+hipError_t launch_tr_act_colsum(const float* x, int64_t M, int C, int64_t ldx, const float* scale, const float* shift, int relu,
+                                float* out, int64_t ldo, double* part, double* sums, hipStream_t s);
 hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                             const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                             const float* mu, const float* rstd, double* part, double* out, hipStream_t s);

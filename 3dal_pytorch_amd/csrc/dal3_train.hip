@@ -1195,7 +1195,8 @@ template <int MODE, bool DENSE>
 __global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict__ z, int64_t M, int C, int64_t ldz,
                                                         DaSrc src, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ mu,
-                                                        const float* __restrict__ rstd, double* __restrict__ part) {
+                                                        const float* __restrict__ rstd, double* __restrict__ part,
+                                                        float* __restrict__ act_out = nullptr, int64_t ldo = 0, int relu = 0) {
     // block: 16 groups of 4 channels (float4 loads: a 256-B row segment per 16 lanes) x 16 row-lanes;
     // rows [blockIdx.y*TR_RED_ROWS, +TR_RED_ROWS); C % 4 == 0 (channels are padded to 32)
     __shared__ double sm[2][16][64];
@@ -1211,6 +1212,13 @@ __global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict_
             sh = *reinterpret_cast<const f32x4*>(shift + c);
             mean = *reinterpret_cast<const f32x4*>(mu + c);
             rs = *reinterpret_cast<const f32x4*>(rstd + c);
+        }
+        if (mode == 2) {                                   // (mode 2: y = act(z) written to act_out, s0 = sum y, s1 = sum y^2)
+            sc = f32x4{1, 1, 1, 1};
+            if (scale) {
+                sc = *reinterpret_cast<const f32x4*>(scale + c);
+                sh = *reinterpret_cast<const f32x4*>(shift + c);
+            }
         }
         const int64_t r1 = min(M, r0 + TR_RED_ROWS);
         // eight rows per trip, their loads issued together (a trip is one HBM round trip: with one row per trip the
@@ -1241,6 +1249,16 @@ __global__ __launch_bounds__(256) void tr_colred_kernel(const float* __restrict_
                         s0[e] += v[e];
                         s1[e] += (double)v[e] * v[e];
                     }
+                } else if (mode == 2) {
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = __builtin_fmaf(v[e], sc[e], sh[e]);
+                        y[e] = relu ? fmaxf(t, 0.0f) : t;
+                        s0[e] += y[e];
+                        s1[e] += (double)y[e] * y[e];
+                    }
+                    *reinterpret_cast<f32x4*>(act_out + (p0 + 16 * u) * ldo + c) = y;
                 } else {
                     const f32x4 d = d4[u];
 #pragma unroll
@@ -1394,6 +1412,18 @@ hipError_t launch_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int m
     const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
     colred_partials(z, M, C, ldz, mode, DaSrc{da, ldda, dg, arg, seg}, scale, shift, mu, rstd, part, s);
     hipLaunchKernelGGL(tr_colred_final_kernel<0>, dim3((C + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, nb, C, out, BnEpi{});
+    return hipGetLastError();
+}
+
+// out = act(x) AND the float64 column sums of out (sums[0..C) = sum, [C..2C) = sum of squares) in one pass: what the pooled
+// layer's moment route needs of its input activation (train.py _moments_through) — was an activation pass + a reduction pass
+hipError_t launch_tr_act_colsum(const float* x, int64_t M, int C, int64_t ldx, const float* scale, const float* shift, int relu,
+                                float* out, int64_t ldo, double* part, double* sums, hipStream_t s) {
+    const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
+    const dim3 grid((C + 63) / 64, nb);
+    hipLaunchKernelGGL((tr_colred_kernel<2, true>), grid, dim3(256), 0, s, x, M, C, ldx, DaSrc{nullptr, 0, nullptr, nullptr, 0}, scale,
+                       shift, nullptr, nullptr, part, out, ldo, relu);
+    hipLaunchKernelGGL(tr_colred_final_kernel<0>, dim3((C + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, nb, C, sums, BnEpi{});
     return hipGetLastError();
 }
 

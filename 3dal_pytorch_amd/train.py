@@ -536,10 +536,19 @@ def _moments_through(z_prev, bn_prev, W, b):
     sum a for the backward shortcut (S = sum a a^T = Sc + m1 m1^T / M)."""
     K = z_prev.shape[1]
     M = bn_prev.M                                                          # real rows (z_prev is padded to 32s)
-    a = _act_dropout(z_prev, bn_prev.act, None)                            # relu(bn(z_prev)) in one pass
+    # a = relu(bn(z_prev)) and its float64 column sums (fixed order) in ONE pass over the rows (dal3_tr_act_colsum)
+    lib = _hip.lib()
+    a = torch.empty((z_prev.shape[0], K), dtype=torch.float32, device=z_prev.device)
+    sums_a = torch.empty(2 * K, dtype=torch.float64, device=z_prev.device)
+    need = lib.dal3_tr_colred_workspace_bytes(M, K)
+    ws = _ws(need, z_prev.device)
+    sc, sh, relu = bn_prev.act
+    _note("act", M, K, K, 0.0, 8.0 * M * K)
+    _hip.check(lib.dal3_tr_act_colsum(_hip.ptr(z_prev), M, K, z_prev.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu), _hip.ptr(a),
+                                      a.stride(0), _hip.ptr(ws), need, _hip.ptr(sums_a), _hip.stream()))
     if a.shape[0] > M:
         a[M:].zero_()
-    m1 = _colred(a, 0, rows=M)[:K]                                          # float64 column sums, fixed order
+    m1 = sums_a[:K]
     mean_a = m1 / M
     ac = a - mean_a.float()
     if a.shape[0] > M:

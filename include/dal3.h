@@ -407,6 +407,10 @@ int dal3_tr_linear_pool_x3(const float* a, int64_t M, int c_in, int64_t lda, con
                            int64_t seg, int c_out, float* g, int32_t* arg, void* workspace, size_t workspace_bytes,
                            dal3_stream stream);
 size_t dal3_tr_colred_workspace_bytes(int64_t M, int C);
+/* out = act(x) (as dal3_tr_act_dropout without a multiplier) AND sums (2 C float64) = [sum out | sum out^2] over the M rows,
+ * one pass; workspace: dal3_tr_colred_workspace_bytes(M, C). */
+int dal3_tr_act_colsum(const float* x, int64_t M, int C, int64_t ldx, const float* scale, const float* shift, int relu,
+                       float* out, int64_t ldo, void* workspace, size_t workspace_bytes, double* sums, dal3_stream stream);
 int dal3_tr_colred(const float* z, int64_t M, int C, int64_t ldz, int mode, const float* da, int64_t ldda,
                    const float* dg, const int32_t* arg, int64_t seg, const float* scale, const float* shift,
                    const float* mu, const float* rstd, void* workspace, size_t workspace_bytes, double* out,
