@@ -113,6 +113,10 @@ SIGNATURES = {
                                        vp, vp, vp, vp, vp, vp, _sz, vp]),
     "dal3_tr_head2_wgrad_workspace_bytes": (_sz, [_i64]),
     "dal3_tr_head2_wgrad": (_i, [vp, vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _u64, vp, C.c_float, vp, _sz, vp, vp]),
+    "dal3_tr_conv1_workspace_bytes": (_sz, [_i64, _i]),
+    "dal3_tr_conv1_bn_stats": (_i, [vp, _i64, _i64, _i, _i64, vp, _i64, vp, _i, vp, _i64, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp,
+                                    vp, vp, vp, _sz, vp]),
+    "dal3_tr_conv1_wgrad": (_i, [vp, _i64, vp, _i64, _i, _i64, _i, vp, _sz, vp, vp]),
     "dal3_tr_gather_at": (_i, [vp, _i64, vp, _i64, _i, _i, vp, vp]),
     "dal3_tr_pool_zarg": (_i, [vp, vp, _i64, vp, _i64, vp, _i, _i, _i, _i, vp, vp]),
     "dal3_tr_pool_moments": (_i, [vp, _i64, vp, vp, vp, _i64, _i, _i, vp, vp]),

@@ -1093,6 +1093,36 @@ extern "C" int dal3_tr_pool_moments(const float* W, int64_t ldw, const float* b,
     return 0;
 }
 
+static bool conv1_shape_ok(int c_in, int c_out) { return c_in >= 1 && c_in <= 8 && (c_out == 64 || c_out == 128); }
+
+extern "C" size_t dal3_tr_conv1_workspace_bytes(int64_t Mp, int c_out) { return Mp > 0 && c_out > 0 ? tr_conv1_workspace_bytes(Mp, c_out) : 0; }
+
+extern "C" int dal3_tr_conv1_bn_stats(const float* x, int64_t M, int64_t Mp, int c_in, int64_t ldx, const float* W, int64_t ldw,
+                                      const float* bias, int c_out, float* z, int64_t ldz, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
+                                      float* scale, float* shift, void* workspace, size_t workspace_bytes, dal3_stream stream) {
+    if (!x || !W || !bias || !z || !gamma || !beta || !mu || !rstd || !scale || !shift || M < 2 || Mp < M || !conv1_shape_ok(c_in, c_out) ||
+        ldx < c_in || ldw < c_in || ldz < c_out || (ldz & 3) || (!running_mean != !running_var) ||
+        (reinterpret_cast<uintptr_t>(z) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15))
+        return fail(DAL3_EINVAL, "tr_conv1_bn_stats: bad argument (c_in <= 8, c_out 64 or 128, 16-byte aligned z / bias, M >= 2)");
+    if (!workspace || workspace_bytes < tr_conv1_workspace_bytes(Mp, c_out))
+        return fail(DAL3_EWORKSPACE, "tr_conv1_bn_stats: workspace smaller than dal3_tr_conv1_workspace_bytes()");
+    HIP_TRY(launch_tr_conv1_bn_stats(x, M, Mp, c_in, ldx, W, ldw, bias, c_out, z, ldz, gamma, beta, running_mean, running_var, momentum,
+                                     eps, mu, rstd, scale, shift, static_cast<double*>(workspace), static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x, int64_t M, int c_in, int64_t ldx, int c_out,
+                                   void* workspace, size_t workspace_bytes, double* sums, dal3_stream stream) {
+    if (!dz || !x || !sums || M <= 0 || !conv1_shape_ok(c_in, c_out) || ldx < c_in || lddz < c_out || (lddz & 3) ||
+        (reinterpret_cast<uintptr_t>(dz) & 15))
+        return fail(DAL3_EINVAL, "tr_conv1_wgrad: bad argument (c_in <= 8, c_out 64 or 128, 16-byte aligned dz)");
+    if (!workspace || workspace_bytes < tr_conv1_workspace_bytes(M, c_out))
+        return fail(DAL3_EWORKSPACE, "tr_conv1_wgrad: workspace smaller than dal3_tr_conv1_workspace_bytes()");
+    HIP_TRY(launch_tr_conv1_wgrad(dz, lddz, x, M, c_in, ldx, c_out, static_cast<double*>(workspace), sums, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_tr_gather_at(const float* z, int64_t ldz, const int32_t* arg, int64_t seg, int n_seg, int C, float* out,
                                  dal3_stream stream) {
     if (!z || !arg || !out || seg <= 0 || n_seg <= 0 || C <= 0 || ldz < C) return fail(DAL3_EINVAL, "tr_gather_at: bad argument");

@@ -2271,6 +2271,143 @@ hipError_t launch_tr_head2_wgrad(const float* dl, const float* z, int64_t M, int
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------- the first layer (c_in <= 8)
+// conv1 of every stack takes 3, 4 or 8 input channels. Through the MFMA kernels that was a (M, 32) zero-padded copy of the
+// points, a K = 32 linear whose weight is 90 % zeros, a statistics pass, and backward a 32 x 64 wgrad over the padded copy.
+// Two VALU kernels instead (round 4):
+//   forward  z[p][c] = b[c] + sum_k W[c][k] x[p][k] for the Mp rows of z (rows >= M see x = 0), with sum z, sum z^2 over the
+//            M real rows taken in the same pass (float64 partials per 256 rows -> tr_colred_final_kernel<1>: the BatchNorm
+//            epilogue of dal3_tr_bn_stats);
+//   wgrad    dW[c][k] = sum_{p < M} dz[p][c] x[p][k]  (float64 partials per 256 rows, pairs of (c, k) entries as the two
+//            sums of a "column": tr_colred_final_kernel<0> over c_out * KIN / 2 columns).
+// Thread = 4 consecutive output channels (CO4 = c_out / 4 lanes per row) x 256 / CO4 row lanes; c_out = 64 or 128.
+template <int KIN, int CO4>
+__global__ __launch_bounds__(256) void tr_conv1_fwd_kernel(const float* __restrict__ x, int64_t M, int64_t Mp, int c_in, int64_t ldx,
+                                                           const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
+                                                           float* __restrict__ z, int64_t ldz, double* __restrict__ part) {
+    constexpr int C = 4 * CO4, RL = 256 / CO4;
+    __shared__ double sm[2][RL][C];
+    const int l = threadIdx.x % CO4, rl = threadIdx.x / CO4, c = 4 * l;
+    float w[4][KIN];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) w[e][k] = k < c_in ? W[(int64_t)(c + e) * ldw + k] : 0.0f;
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c);
+    const int64_t r0 = (int64_t)blockIdx.x * TR_RED_ROWS, r1 = min(Mp, r0 + TR_RED_ROWS);
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    for (int64_t p = r0 + rl; p < r1; p += RL) {
+        float xv[KIN];
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) xv[k] = (k < c_in && p < M) ? x[p * ldx + k] : 0.0f;
+        f32x4 o = b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < KIN; ++k) o[e] = __builtin_fmaf(w[e][k], xv[k], o[e]);
+        *reinterpret_cast<f32x4*>(z + p * ldz + c) = o;
+        if (p < M) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s0[e] += o[e];
+                s1[e] += (double)o[e] * o[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sm[0][rl][c + e] = s0[e];
+        sm[1][rl][c + e] = s1[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int i = 0; i < RL; ++i) {
+            a0 += sm[0][i][threadIdx.x];
+            a1 += sm[1][i][threadIdx.x];
+        }
+        const int64_t o = ((int64_t)blockIdx.x * C + threadIdx.x) * 2;
+        part[o] = a0;
+        part[o + 1] = a1;
+    }
+}
+template <int KIN, int CO4>
+__global__ __launch_bounds__(256) void tr_conv1_wgrad_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ x,
+                                                             int64_t M, int c_in, int64_t ldx, double* __restrict__ part) {
+    constexpr int C = 4 * CO4, RL = 256 / CO4;
+    extern __shared__ double c1_sm[];                       // [RL][C * KIN]
+    const int l = threadIdx.x % CO4, rl = threadIdx.x / CO4, c = 4 * l;
+    const int64_t r0 = (int64_t)blockIdx.x * TR_RED_ROWS, r1 = min(M, r0 + TR_RED_ROWS);
+    double acc[4][KIN];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) acc[e][k] = 0.0;
+    for (int64_t p = r0 + rl; p < r1; p += RL) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dz + p * lddz + c);
+        float xv[KIN];
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) xv[k] = k < c_in ? x[p * ldx + k] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < KIN; ++k) acc[e][k] += (double)g[e] * (double)xv[k];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) c1_sm[(int64_t)rl * (C * KIN) + (c + e) * KIN + k] = acc[e][k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * KIN; i += 256) {      // entry i = (channel, k): the row lanes in order
+        double t = 0.0;
+        for (int r = 0; r < RL; ++r) t += c1_sm[(int64_t)r * (C * KIN) + i];
+        part[(int64_t)blockIdx.x * (C * KIN) + i] = t;       // = part[(blk * C' + i / 2) * 2 + i % 2], C' = C * KIN / 2
+    }
+}
+static bool tr_conv1_ok(int c_in, int c_out) { return c_in >= 1 && c_in <= 8 && (c_out == 64 || c_out == 128); }
+size_t tr_conv1_workspace_bytes(int64_t Mp, int c_out) {     // forward: pairs per channel; wgrad: c_out * 8 entries per block
+    return (size_t)((Mp + TR_RED_ROWS - 1) / TR_RED_ROWS) * c_out * 8 * sizeof(double);
+}
+hipError_t launch_tr_conv1_bn_stats(const float* x, int64_t M, int64_t Mp, int c_in, int64_t ldx, const float* W, int64_t ldw,
+                                    const float* bias, int c_out, float* z, int64_t ldz, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
+                                    float* scale, float* shift, double* part, hipStream_t s) {
+    const int nb = (int)((Mp + TR_RED_ROWS - 1) / TR_RED_ROWS);
+    const auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, x, M, Mp, c_in, ldx, W, ldw, bias, z, ldz, part);
+    };
+    if (c_in <= 4) {
+        if (c_out == 64) go(tr_conv1_fwd_kernel<4, 16>); else go(tr_conv1_fwd_kernel<4, 32>);
+    } else {
+        if (c_out == 64) go(tr_conv1_fwd_kernel<8, 16>); else go(tr_conv1_fwd_kernel<8, 32>);
+    }
+    BnEpi e{};
+    e.M = M, e.gamma = gamma, e.beta = beta, e.running_mean = running_mean, e.running_var = running_var;
+    e.momentum = momentum, e.eps = eps, e.mu = mu, e.rstd = rstd, e.scale = scale, e.shift = shift;
+    // (blocks of padding rows only write zero partials: harmless in the sums)
+    hipLaunchKernelGGL(tr_colred_final_kernel<1>, dim3((c_out + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, nb, c_out, nullptr, e);
+    return hipGetLastError();
+}
+// sums: 2 * C' float64 with C' = c_out * KIN / 2 (KIN = 4 for c_in <= 4, else 8): dW[c][k] = sums[(i % 2) * C' + i / 2], i = c * KIN + k
+hipError_t launch_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x, int64_t M, int c_in, int64_t ldx, int c_out, double* part,
+                                 double* sums, hipStream_t s) {
+    const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
+    const int kin = c_in <= 4 ? 4 : 8, co4 = c_out / 4;
+    const size_t lds = (size_t)(256 / co4) * c_out * kin * sizeof(double);
+    const auto go = [&](auto kern) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, s, dz, lddz, x, M, c_in, ldx, part);
+    };
+    if (kin == 4) {
+        if (c_out == 64) go(tr_conv1_wgrad_kernel<4, 16>); else go(tr_conv1_wgrad_kernel<4, 32>);
+    } else {
+        if (c_out == 64) go(tr_conv1_wgrad_kernel<8, 16>); else go(tr_conv1_wgrad_kernel<8, 32>);
+    }
+    const int Cp = c_out * kin / 2;
+    hipLaunchKernelGGL(tr_colred_final_kernel<0>, dim3((Cp + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, nb, Cp, sums, BnEpi{});
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------- max over points
 // g[s][c] = max_p act(z[p][c]) over the `seg` points of segment s, with the index of the FIRST maximum for the
 // backward pass. Block = 64 channels x 4 row-lanes over one of SEG_CHUNKS chunks of the segment; candidates meet

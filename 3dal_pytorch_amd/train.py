@@ -514,6 +514,57 @@ def _points_major(pts, c_pad=32):
     return a0
 
 
+class _Rows:
+    """the input points as (M, C) rows for the first-layer kernels (dal3_tr_conv1_*): the caller's own storage when it is
+    point-major fp32, no (pad32(M), 32) zero-padded copy; .shape / .device as that padded buffer had them"""
+
+    def __init__(self, pts):
+        B, C, N = pts.shape
+        x = pts.transpose(2, 1).reshape(B * N, C)
+        self.x = x if (x.is_contiguous() and x.dtype == torch.float32) else x.contiguous().float()
+        self.M, self.C = B * N, C
+        self.shape = (_pad32(B * N), C)
+        self.device = pts.device
+
+
+def _conv1_ok(c_in, c_out):
+    return 1 <= c_in <= 8 and c_out in (64, 128)
+
+
+def _conv1_bn(rows, W, b, gamma, beta, stats):
+    """z (pad32(M), c_out) = x W^T + b (padding rows: b) and its _BN over the M real rows, one pass (dal3_tr_conv1_bn_stats)"""
+    lib = _hip.lib()
+    M, Mp, c_in, c_out = rows.M, rows.shape[0], rows.C, W.shape[0]
+    z = torch.empty((Mp, c_out), dtype=torch.float32, device=rows.device)
+    bn = _BN.__new__(_BN)
+    st = torch.empty((4, c_out), dtype=torch.float32, device=rows.device)
+    bn.mu, bn.rstd, bn.scale, bn.shift = st[0], st[1], st[2], st[3]
+    bn.gamma, bn.M = gamma.contiguous(), M
+    rm, rv = stats if stats is not None else (None, None)
+    need = lib.dal3_tr_conv1_workspace_bytes(Mp, c_out)
+    ws = _ws(need, rows.device)
+    _note("conv1", M, c_in, c_out, 2.0 * M * c_in * c_out, 4.0 * M * (c_in + c_out))
+    _hip.check(lib.dal3_tr_conv1_bn_stats(_hip.ptr(rows.x), M, Mp, c_in, rows.x.stride(0), _hip.ptr(W), W.stride(0), _hip.ptr(b), c_out,
+                                          _hip.ptr(z), z.stride(0), _hip.ptr(bn.gamma), _hip.ptr(beta.contiguous()), _hip.ptr(rm),
+                                          _hip.ptr(rv), _MOM, _EPS, _hip.ptr(bn.mu), _hip.ptr(bn.rstd), _hip.ptr(bn.scale),
+                                          _hip.ptr(bn.shift), _hip.ptr(ws), need, _hip.stream()))
+    return z, bn
+
+
+def _conv1_wgrad(dz, rows, c_out):
+    """dW (c_out, c_in) = dz^T x over the M real rows (dal3_tr_conv1_wgrad)"""
+    lib = _hip.lib()
+    kin = 4 if rows.C <= 4 else 8
+    Cp = c_out * kin // 2
+    need = lib.dal3_tr_conv1_workspace_bytes(rows.M, c_out)
+    ws = _ws(need, rows.device)
+    sums = torch.empty(2 * Cp, dtype=torch.float64, device=rows.device)
+    _note("conv1", rows.M, rows.C, c_out, 2.0 * rows.M * rows.C * c_out, 4.0 * rows.M * (rows.C + c_out))
+    _hip.check(lib.dal3_tr_conv1_wgrad(_hip.ptr(dz), dz.stride(0), _hip.ptr(rows.x), rows.M, rows.C, rows.x.stride(0), c_out,
+                                       _hip.ptr(ws), need, _hip.ptr(sums), _hip.stream()))
+    return sums.view(2, Cp).t().reshape(c_out, kin)[:, :rows.C].float()          # entry i = c * kin + k sits at [i % 2][i // 2]
+
+
 def supported(pts):
     """CUDA tensors of any (B, N): the kernels tile the flattened point axis in 32s, the host pads the row buffers to
     a multiple of 32 and keeps the padding out of every sum (statistics over the real rows, dz = 0 on the rest)"""
@@ -648,23 +699,29 @@ class _PointStack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, stats, *params):
         _check(pts, "pts")
-        B, _, N = pts.shape
-        a0 = a = _points_major(pts.detach())
+        B, C_in, N = pts.shape
+        fast1 = _conv1_ok(C_in, params[0].shape[0])           # conv1 on the first-layer kernels: no padded copy of the points
+        a0 = a = _Rows(pts.detach()) if fast1 else _points_major(pts.detach())
         Ws, bns, zs = [], [], []
         act = None
         for k in range(4):
             W2 = params[4 * k].detach().reshape(params[4 * k].shape[0], -1)
-            Ws.append(_pad_cols(W2, 32) if k == 0 else W2.contiguous())
+            Ws.append(_pad_cols(W2, 32) if (k == 0 and not fast1) else W2.contiguous())
         Mp = a0.shape[0]
         # one packing launch for the stack: conv1..4 forward and the dgrads of conv2, conv3 (the pooled layer's goes through
         # its algebraic shortcut) — the weights are the same when the backward runs
-        pk = _prepack([(Ws[k], Ws[k].shape[1], Ws[k].shape[0], False, Mp, 0, False, k > 0) for k in range(4)] +
+        pk = _prepack([(Ws[k], Ws[k].shape[1], Ws[k].shape[0], False, Mp, 0, False, k > 0) for k in range(1 if fast1 else 0, 4)] +
                       [(Ws[k], Ws[k].shape[0], Ws[k].shape[1], True, Mp, 0, False, False) for k in (1, 2)], a0.device)
+        if fast1:
+            pk = [None] + pk
         for k in range(4):
             W, b, gamma, beta = (p.detach() for p in params[4 * k:4 * k + 4])
             W2 = Ws[k]
-            z, bn = _linear_bn(a, W2, W2.shape[1], W2.shape[0], act, b.contiguous(), 0, pk[k], gamma, beta,
-                               stats[k] if stats is not None else None, B * N)
+            if k == 0 and fast1:
+                z, bn = _conv1_bn(a0, W2, b.contiguous(), gamma, beta, stats[0] if stats is not None else None)
+            else:
+                z, bn = _linear_bn(a, W2, W2.shape[1], W2.shape[0], act, b.contiguous(), 0, pk[k], gamma, beta,
+                                   stats[k] if stats is not None else None, B * N)
             bns.append(bn)
             zs.append(z)
             a, act = z, bn.act
@@ -697,7 +754,7 @@ class _PointStack(torch.autograd.Function):
             dz, dgam, dbet = bns[k].backward(zs[k], da=da, co=co)
             co = None
             src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a0, None)
-            dW = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
+            dW = _conv1_wgrad(dz, src, Ws[k].shape[0]) if isinstance(src, _Rows) else _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
             grads[4 * k] = dW[:, :shapes[4 * k][1]].reshape(shapes[4 * k])
             grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
@@ -717,7 +774,8 @@ class _InsSeg(torch.autograd.Function):
         B, C_in, N = pts.shape
         M = B * N
         P = [p.detach() for p in params]
-        a0 = _points_major(pts.detach())
+        fast1 = _conv1_ok(C_in, P[0].shape[0])                          # conv1 on the first-layer kernels (dal3_tr_conv1_*)
+        a0 = _Rows(pts.detach()) if fast1 else _points_major(pts.detach())
         Mp = a0.shape[0]
         Ws, bns, zs = [], [], []
         # every layer's weight as the linear kernels take it, and ONE launch that puts them all into fragment order — the
@@ -726,7 +784,7 @@ class _InsSeg(torch.autograd.Function):
         W2s = {}
         for k in (0, 1, 2, 3, 6, 7, 8):
             W2 = P[4 * k].reshape(P[4 * k].shape[0], -1)
-            W2s[k] = _pad_cols(W2, 32) if k == 0 else W2.contiguous()
+            W2s[k] = _pad_cols(W2, 32) if (k == 0 and not fast1) else W2.contiguous()
         Wd1 = P[20].reshape(P[20].shape[0], -1).contiguous()            # dconv1 (512, 1088): columns 0..63 per point
         # dconv5 (128 -> 2) with its Dropout: three VALU kernels (dal3_tr_head2_*) when dconv4 has the reference's 128 channels;
         # otherwise through the MFMA kernels on a weight padded from 2 to 32 rows
@@ -748,17 +806,20 @@ class _InsSeg(torch.autograd.Function):
                  (W5, 128, 32, False, Mp, 0, False, False), (W5, 32, 128, True, Mp, 0, False, False), tr(8, dg=True), tr(7, dg="fp32"),
                  tr(6, dg=True),
                  (Wd1, 512, 64, True, Mp, 0, False, False), tr(3), tr(2, True), tr(1)]
-        if head2:                                                       # (no packed images for dconv5)
-            specs = [sp for sp, name in zip(specs, order) if name not in ("fd5", "td5")]
-            order = [name for name in order if name not in ("fd5", "td5")]
+        skip = (("fd5", "td5") if head2 else ()) + (("f0",) if fast1 else ())      # (calls that read no packed image)
+        specs = [sp for sp, name in zip(specs, order) if name not in skip]
+        order = [name for name in order if name not in skip]
         pk = dict(zip(order, _prepack(specs, pts.device)))
         pk["arith"] = ARITH                                             # (the backward runs outside the forward's context)
         a, act = a0, None
         for k in range(4):                                              # conv1..4
             W, b, gamma, beta = P[4 * k:4 * k + 4]
             W2 = W2s[k]
-            z, bn = _linear_bn(a, W2, W2.shape[1], W2.shape[0], act, b.contiguous(), 0, pk[f"f{k}"], gamma, beta,
-                               stats[k] if stats is not None else None, M)
+            if k == 0 and fast1:
+                z, bn = _conv1_bn(a0, W2, b.contiguous(), gamma, beta, stats[0] if stats is not None else None)
+            else:
+                z, bn = _linear_bn(a, W2, W2.shape[1], W2.shape[0], act, b.contiguous(), 0, pk[f"f{k}"], gamma, beta,
+                                   stats[k] if stats is not None else None, M)
             Ws.append(W2)
             bns.append(bn)
             zs.append(z)
@@ -878,7 +939,7 @@ class _InsSeg(torch.autograd.Function):
             dz, dgam, dbet = bns[k].backward(zs[k], da=da, co=co)
             co = None
             src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a0, None)
-            dW = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
+            dW = _conv1_wgrad(dz, src, Ws[k].shape[0]) if isinstance(src, _Rows) else _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
             grads[4 * k] = dW[:, :shapes[4 * k][1]].reshape(shapes[4 * k])
             grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet

@@ -439,6 +439,20 @@ int dal3_tr_pool_coef(const float* dg, const float* g, const float* zarg, const 
 /* zarg (B,C) = the pooled layer's pre-BatchNorm value at each pooled point: W[c] . a[b*N + arg[b][c]] + bias[c], from the
  * layer's input activation a (B*N, K) — what dal3_tr_pool_coef takes, when the fused forward (dal3_tr_linear_pool) has not
  * written the layer's output. fp32, a fixed order of additions. */
+/* The FIRST layer of a stack (conv1: 3, 4 or 8 input channels -> 64 or 128) as VALU kernels, on the points as they are
+ * (x: M rows of c_in floats, row stride ldx — no zero-padded copy):
+ *   dal3_tr_conv1_bn_stats  z[p][c] = bias[c] + sum_k W[c][k] x[p][k] for the Mp >= M rows of z (rows >= M get x = 0), and
+ *                           dal3_tr_bn_stats over the M real rows in the same pass;
+ *   dal3_tr_conv1_wgrad     sums (2 C' float64, C' = c_out * KIN / 2, KIN = 4 for c_in <= 4 else 8):
+ *                           dW[c][k] = sum_{p < M} dz[p][c] x[p][k] = sums[(i % 2) * C' + i / 2] with i = c * KIN + k.
+ * workspace: dal3_tr_conv1_workspace_bytes(rows, c_out). Float64 partial sums per 256 rows, added in a fixed order. */
+size_t dal3_tr_conv1_workspace_bytes(int64_t Mp, int c_out);
+int dal3_tr_conv1_bn_stats(const float* x, int64_t M, int64_t Mp, int c_in, int64_t ldx, const float* W, int64_t ldw,
+                           const float* bias, int c_out, float* z, int64_t ldz, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
+                           float* scale, float* shift, void* workspace, size_t workspace_bytes, dal3_stream stream);
+int dal3_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x, int64_t M, int c_in, int64_t ldx, int c_out, void* workspace,
+                        size_t workspace_bytes, double* sums, dal3_stream stream);
 /* out (n_seg, C) = z[s*seg + arg[s][c]][c]: the same values gathered from a MATERIALISED layer output (dal3_tr_segmax's arg) */
 int dal3_tr_gather_at(const float* z, int64_t ldz, const int32_t* arg, int64_t seg, int n_seg, int C, float* out,
                       dal3_stream stream);

@@ -186,3 +186,33 @@ def test_logits_layer_with_dropout_as_valu_kernels(M, Mp):
     assert _close(logits, torch.relu(z[:M].double() * sc.double() + sh.double()) @ W.double().t() + b.double(), 2e-6)
     assert lib.dal3_tr_head2_forward(hip.ptr(z), M, 64, 128, None, None, 0, None, 0, 0, None, 0.0, hip.ptr(W), 128, hip.ptr(b),
                                      hip.ptr(logits), hip.stream()) == hip.EINVAL          # C must be 128
+
+
+@pytest.mark.parametrize("B,N,c_in,c_out", [(64, 4096, 3, 64), (5, 77, 4, 64), (3, 101, 8, 64), (64, 512, 3, 128), (1, 2, 3, 64)])
+def test_first_layer_as_valu_kernels(B, N, c_in, c_out):
+    """dal3_tr_conv1_bn_stats / dal3_tr_conv1_wgrad (round 4): conv1 of a stack (3, 4 or 8 input channels) on the points as
+    they are — output, batch statistics, running statistics and the weight gradient against float64; padding rows of z
+    hold the bias and stay out of the statistics"""
+    gen = torch.Generator(device="cuda").manual_seed(B * N + c_in)
+    pts = torch.randn((B, N, c_in), device="cuda", generator=gen).transpose(2, 1)      # (B, C, N) view of point-major storage
+    W = torch.randn((c_out, c_in), device="cuda", generator=gen)
+    b = torch.randn(c_out, device="cuda", generator=gen)
+    gamma = torch.rand(c_out, device="cuda", generator=gen) + 0.5
+    beta = torch.randn(c_out, device="cuda", generator=gen) * 0.3
+    rm, rv = torch.zeros(c_out, device="cuda"), torch.ones(c_out, device="cuda")
+    rows = train._Rows(pts)
+    M, Mp = B * N, rows.shape[0]
+    assert rows.x.data_ptr() == pts.data_ptr()                                          # no copy of point-major points
+    z, bn = train._conv1_bn(rows, W, b, gamma, beta, (rm, rv))
+    x64 = pts.transpose(2, 1).reshape(M, c_in).double()
+    z64 = x64 @ W.double().t() + b.double()
+    assert z.shape == (Mp, c_out) and _close(z[:M], z64, 2e-6)
+    if Mp > M:
+        assert torch.equal(z[M:], b.expand(Mp - M, c_out))
+    mean, var = z64.mean(0), z64.var(0, unbiased=False)
+    assert _close(bn.mu, mean, 2e-6) and _close(bn.rstd, 1.0 / torch.sqrt(var + 1e-5), 2e-6)
+    assert _close(bn.scale, gamma.double() / torch.sqrt(var + 1e-5), 2e-6)
+    assert _close(rm, 0.1 * mean, 2e-6) and _close(rv, 0.9 + 0.1 * z64.var(0, unbiased=True), 2e-6)
+    dz = torch.randn((Mp, c_out), device="cuda", generator=gen) * 1e-3
+    dW = train._conv1_wgrad(dz, rows, c_out)
+    assert dW.shape == (c_out, c_in) and _close(dW, dz[:M].double().t() @ x64, 2e-6)
