@@ -26,7 +26,8 @@ FAMILY_OF_KERNEL = [("linear_pool", r"tr_linear_pool|tr_linear_x3_kernel<(true|f
                     ("linear+bwd_sums", r"tr_linear_pers_kernel<\d, \d, \d, \d, 2>"), ("linear_x3", r"tr_linear_x3"),
                     ("linear", r"tr_linear_(pers|ring)_kernel|tr_linear_kernel"), ("wgrad_x3", r"tr_wgrad_x3"),
                     ("wgrad", r"tr_wgrad_kernel"), ("stats", r"tr_colred_kernel<0"), ("bwd_sums", r"tr_colred_kernel<1"),
-                    ("apply", r"tr_bnbwd_apply"), ("act", r"tr_act_dropout")]
+                    ("apply", r"tr_bnbwd_apply"), ("act", r"tr_act_dropout|tr_colred_kernel<2"),
+                    ("head2", r"tr_head2_(fwd|dgrad|dgrad_sums|wgrad)_kernel"), ("conv1", r"tr_conv1_(fwd|wgrad)_kernel")]
 
 
 def family(name):
