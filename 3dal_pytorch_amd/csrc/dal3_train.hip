@@ -957,6 +957,180 @@ __global__ __launch_bounds__(256, OCC) void tr_linear_pool_pers_kernel(const flo
     }
 }
 
+// The 128-channel case (ins_seg's conv5, 128 -> 1024) with the wave's activations RESIDENT: the kernel above loads and
+// activates a unit's 64 x 128 inputs once per block of 128 output channels, eight times per point at c_out = 1024 (by
+// ablation at 64 x 4096 points: input loads 48 us, activation 71 us, epilogue 95 us of 627; the MFMAs alone 459). Here a
+// wave takes 64 points, loads and activates them ONCE (128 registers), and sweeps all output tiles over them, the
+// weights arriving in tile-major order (tr_pack_kernel with mtb = 1) through the same cyclic ring: one turn of the
+// stream per group of points.
+//  * Two accumulator sets alternate, and the epilogue of the tile just finished — BN, ReLU, running (max, index) over its
+//    16 registers — is dealt out one register per weight fragment under the MFMAs of the tile being computed.
+//  * A wave's groups are CONSECUTIVE (gpw of them, all in one segment when seg % (64 gpw) == 0), and its candidates meet
+//    in a private LDS row per output channel (ds_max_u64, counted by lgkmcnt); the packed global atomicMax — which sits
+//    in the same in-order vmcnt queue as the weight ring's loads — is taken once per wave and segment, not per tile.
+//  * The next group's 64 x 128 inputs are requested under the second tile of the current one (two loads per fragment),
+//    so the switch costs the activation's VALU only (by ablation the simultaneous reload of all waves was ~40 us).
+// Same FMA chains per output element, same candidate order: g and arg are bit-identical to the kernels above.
+// Host-side conditions: c_in == 128, M % 64 == 0, seg % 64 == 0, c_out % 64 == 0, c_out <= TR_POOL_RES_MAX_COUT.
+#define TR_POOL_RES_MAX_COUT 1024
+__global__ __launch_bounds__(256, 1) void tr_linear_pool_res_kernel(const float* __restrict__ a, int64_t M, int64_t lda,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int relu_in,
+                                                                  const f32x4* __restrict__ wpk, const float* __restrict__ bias,
+                                                                  const float* __restrict__ out_scale,
+                                                                  const float* __restrict__ out_shift, int64_t seg, int c_out,
+                                                                  unsigned long long* __restrict__ packed, uint32_t n_groups,
+                                                                  uint32_t gpw) {
+    __shared__ float s_sc[128], s_sh[128];
+    __shared__ float s_b[TR_POOL_RES_MAX_COUT], s_osc[TR_POOL_RES_MAX_COUT], s_osh[TR_POOL_RES_MAX_COUT];
+    __shared__ unsigned long long s_key[4][TR_POOL_RES_MAX_COUT];
+    const bool act = scale != nullptr;
+    for (int i = threadIdx.x; i < 128; i += 256) {
+        s_sc[i] = act ? scale[i] : 1.0f;
+        s_sh[i] = act ? shift[i] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < c_out; i += 256) {
+        s_b[i] = bias ? bias[i] : 0.0f;
+        s_osc[i] = out_scale[i];
+        s_osh[i] = out_shift[i];
+    }
+    for (int i = threadIdx.x; i < 4 * TR_POOL_RES_MAX_COUT; i += 256) (&s_key[0][0])[i] = 0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned long long* key = s_key[wv];
+    uint32_t group = (blockIdx.x * 4u + wv) * gpw;
+    if (group >= n_groups) return;
+    const uint32_t group_end = min(group + gpw, n_groups);
+    WRingCyc ring;
+    ring.init(wpk, (uint32_t)c_out * 128u * 4u, lane);
+    const int n_tiles = c_out / 32;
+    auto flush = [&](int64_t s_idx) {                           // this wave's candidates of segment s_idx -> packed, row cleared
+        for (int c = lane; c < c_out; c += 64) {
+            const unsigned long long k = key[c];
+            if (k) atomicMax(packed + s_idx * c_out + c, k);
+            key[c] = 0ull;
+        }
+    };
+    TrX<2> x[4], xn[4];
+    {
+        const int64_t prow[2] = {(int64_t)group * 64 + m, (int64_t)group * 64 + 32 + m};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) tr_load_x(xn[kt], kt, a, lda, prow, h);
+    }
+    int64_t cur_seg = (int64_t)((uint32_t)((int64_t)group * 64) / (uint32_t)seg);
+    for (; group < group_end; ++group) {
+        const int64_t pt0 = (int64_t)group * 64;
+        const int64_t s_idx = (int64_t)((uint32_t)pt0 / (uint32_t)seg);
+        if (s_idx != cur_seg) {
+            flush(cur_seg);
+            cur_seg = s_idx;
+        }
+        const uint32_t in_seg0 = (uint32_t)(pt0 - s_idx * seg);
+        // the group's inputs arrived under the previous group's second tile: activation, and the registers change roles
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            x[kt] = xn[kt];
+            if (act) tr_act_lds(x[kt].X, s_sc, s_sh, kt, h, relu_in);
+        }
+        const bool more = group + 1 < group_end;
+        const int64_t pn = more ? pt0 + 64 : pt0;
+        const int64_t prow_n[2] = {pn + m, pn + 32 + m};
+        f32x16 accA[2], accB[2];
+        float bv[2] = {0.0f, 0.0f};
+        int bi[2] = {4 * h, 4 * h};                             // (this lane's first point: what a tile of zeros returns)
+        // per-lane constants of the tiles, read from LDS half a tile ahead: bias of the NEXT tile, BN affine of THIS one
+        // (needed when it is the pending one)
+        float b_nx = s_b[m], osc_nx = 0.0f, osh_nx = 0.0f, posc = 0.0f, posh = 0.0f;
+        // one register (both point tiles) of the pending tile's epilogue. The empty asm pins each step where it is written:
+        // left alone hipcc sinks one point tile's whole chain (16 x fma, max, cmp, 2 cndmask with their VCC wait states)
+        // behind the tile's last MFMA, ~1,000 cycles per tile with the matrix pipe idle
+        auto epi_step = [&](const f32x16 (&P)[2], int r) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // (the ReLU is taken once, on the running maximum, in epi_finish: max and ReLU commute, and the first index
+                // attaining a positive maximum is the same before and after it; a maximum <= 0 means every value is 0
+                // after the ReLU, whose first maximum is index 0 — the initial bi, kept because bv starts at 0)
+                const float y = __builtin_fmaf(P[j][r], posc, posh);
+                const bool up = y > bv[j];
+                bv[j] = up ? y : bv[j];
+                bi[j] = up ? (r & 3) + 8 * (r >> 2) + 4 * h : bi[j];
+            }
+            asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bi[0]), "+v"(bi[1]));
+        };
+        // the pending tile's candidates leave: as packed keys (value bits, ~index: the larger key is the larger value, at
+        // equal values the earlier point) the two point tiles and the two lane halves meet by plain 64-bit maxima; the
+        // halves are exchanged by v_permlane32_swap (no LDS round trip), the lower half's lanes write
+        auto epi_finish = [&](int ptile) {
+            uint32_t kh = 0, kl = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t vh = __float_as_uint(bv[j]), vl = 0xffffffffu - (in_seg0 + 32u * j + (uint32_t)bi[j]);
+                const bool up = j == 0 || vh > kh || (vh == kh && vl > kl);
+                kh = up ? vh : kh;
+                kl = up ? vl : kl;
+                bv[j] = 0.0f;
+                bi[j] = 4 * h;
+            }
+            const uint32_t oh = __builtin_amdgcn_permlane32_swap(kh, kh, false, false)[1];
+            const uint32_t ol = __builtin_amdgcn_permlane32_swap(kl, kl, false, false)[1];
+            const unsigned long long k0 = ((unsigned long long)kh << 32) | kl, k1 = ((unsigned long long)oh << 32) | ol;
+            if (h == 0) atomicMax(key + 32 * ptile + m, k0 > k1 ? k0 : k1);
+        };
+        // tile `t` into Cc while the epilogue of tile t - 1 (in P) runs; pending: there is one; pf: request the next group
+        auto tile = [&](f32x16 (&Cc)[2], const f32x16 (&P)[2], int t, auto pending_c, auto pf_c) {
+            constexpr bool pending = decltype(pending_c)::value, pf = decltype(pf_c)::value;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Cc[j][r] = b_nx;
+            posc = osc_nx;
+            posh = osh_nx;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {                      // fragment (kt, q) = (i / 4, i % 4)
+                const f32x4 w = ring.slot[i % DAL3_PF];
+                ring.slot[i % DAL3_PF] = ring.fetch();
+                if (pf) {                                       // two of the next group's 32 16-byte pieces per fragment
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int id = 2 * i + u, kt = id >> 3, j = (id >> 2) & 1, q = id & 3;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(a + prow_n[j] * lda + 32 * kt + 4 * h + 8 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xn[kt].X[j][4 * q + e] = v[e];
+                    }
+                }
+                if (i == 8) {
+                    b_nx = s_b[(32 * (t + 1) + m) & (TR_POOL_RES_MAX_COUT - 1)];
+                    osc_nx = s_osc[32 * t + m];
+                    osh_nx = s_osh[32 * t + m];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Cc[j] = mfma32(x[i / 4].X[j][4 * (i % 4) + e], w[e], Cc[j]);
+                }
+                if (pending) {
+                    epi_step(P, i);
+                    if (i == 15) epi_finish(t - 1);
+                }
+                DAL3_SCHED_FENCE();
+            }
+        };
+        tile(accA, accB, 0, std::false_type{}, std::false_type{});
+        tile(accB, accA, 1, std::true_type{}, std::true_type{});
+        for (int t = 2; t < n_tiles; t += 2) {
+            tile(accA, accB, t, std::true_type{}, std::false_type{});
+            tile(accB, accA, t + 1, std::true_type{}, std::false_type{});
+        }
+        posc = osc_nx;
+        posh = osh_nx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) epi_step(accB, r);
+        epi_finish(n_tiles - 1);
+    }
+    flush(cur_seg);
+}
+
 hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t lda, const float* scale, const float* shift,
                                  int relu_in, const float* W, int64_t ldw, const float* bias, const float* out_scale,
                                  const float* out_shift, int64_t seg, int c_out, float* g, int32_t* arg, float* ws,
@@ -966,6 +1140,19 @@ hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t ld
     const int64_t n = (int64_t)c_out * c_in, n_seg = M / seg;
     hipError_t e = launch_fill_words(packed, (size_t)n_seg * c_out * 2, 0u, s);
     if (e != hipSuccess) return e;
+#ifndef TR_POOL_RES
+#define TR_POOL_RES 1                   // 0: the 128-channel case through the per-block kernels too (A/B builds)
+#endif
+    if (TR_POOL_RES && c_in == 128 && M % 64 == 0 && seg % 64 == 0 && c_out % 64 == 0 && c_out <= TR_POOL_RES_MAX_COUT &&
+        M / 64 >= 1024 && M / 64 < (int64_t)1 << 31) {
+        const uint32_t n_groups = (uint32_t)(M / 64), gpw = (n_groups + 1023u) / 1024u;
+        hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, 0, c_out, c_in, 1, ws);
+        hipLaunchKernelGGL(tr_linear_pool_res_kernel, dim3((n_groups + 4u * gpw - 1u) / (4u * gpw)), dim3(256), 0, s, a, M, lda, scale, shift,
+                           relu_in, reinterpret_cast<const f32x4*>(ws), bias, out_scale, out_shift, seg, c_out, packed, n_groups, gpw);
+        const int64_t total = n_seg * c_out;
+        hipLaunchKernelGGL(tr_segmax_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, packed, total, g, arg);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, 0, c_out, c_in, TR_MTB, ws);
 #ifndef TR_POOL_OCC
 #define TR_POOL_OCC 1                   // (at 2 the persistent kernel spills 120-170 registers)

@@ -427,7 +427,11 @@ def test_persistent_linear_kernels_match_float64_and_the_one_unit_kernels_bitwis
 
 
 @pytest.mark.parametrize("B,N,c_in,c_out", [(4, 256, 128, 1024), (3, 96, 64, 128), (2, 4096, 128, 1024),
-                                            (16, 4096, 128, 1024), (32, 2048, 64, 256)])
+                                            (16, 4096, 128, 1024), (32, 2048, 64, 256),
+                                            # the kernel with resident activations (c_in 128, >= 1024 groups of 64 points):
+                                            # two and four groups per wave, waves that cross a segment, few channels
+                                            (20, 3840, 128, 1024), (400, 192, 128, 256), (64, 4096, 128, 1024),
+                                            (18, 4096, 128, 128)])
 def test_fused_linear_pool_equals_linear_then_segmax_bitwise(B, N, c_in, c_out):
     """dal3_tr_linear_pool (conv -> BN -> ReLU -> max over each crop's points without writing the layer's output) must
     give the bits of dal3_tr_linear + dal3_tr_segmax: same g, same arg-max (first maximum), ties included"""
