@@ -1755,55 +1755,59 @@ __global__ __launch_bounds__(256) void tr_bnbwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ shift, const float* __restrict__ mu,
                                                              const float* __restrict__ rstd, const float* __restrict__ k1,
                                                              const float* __restrict__ k2, const float* __restrict__ k3,
-                                                             float* __restrict__ dz, int64_t lddz,
+                                                             float* __restrict__ dz, int64_t lddz, int cgs,
                                                              double* __restrict__ seg_part = nullptr,
                                                              uint32_t* __restrict__ amax = nullptr) {
-    // block: 16 groups of 4 channels x 16 rows; grid (C/64, M/128): a thread walks 8 rows, all their loads issued before
-    // the first is used (rows past the end are clamped for the loads and skipped for the stores)
+    // block: 2^cgs groups of 4 channels x (256 >> cgs) rows, 128 rows in all; grid (C / (4 << cgs), M/128); cgs: tr_apply_cgs
+    // (512-channel rows: a wave's 16-byte loads are 1 KiB of ONE row instead of 256-byte pieces of four rows, +4 %; the pass
+    // runs at 5.3-5.6 TB/s either way — two streams in, one out). A thread walks its rows in batches of 8, all of a
+    // batch's loads issued before the first is used (rows past the end are clamped for the loads and skipped for the stores).
     constexpr int U = 8;
-    const int c = (blockIdx.x * 16 + (threadIdx.x & 15)) * 4;
+    const int gl = threadIdx.x & ((1 << cgs) - 1), rl = threadIdx.x >> cgs, RP = 256 >> cgs;
+    const int c = ((blockIdx.x << cgs) + gl) * 4;
     if (c >= C) return;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
     const f32x4 mean = *reinterpret_cast<const f32x4*>(mu + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
     const f32x4 a1 = *reinterpret_cast<const f32x4*>(k1 + c), a2 = *reinterpret_cast<const f32x4*>(k2 + c);
     const f32x4 a3 = *reinterpret_cast<const f32x4*>(k3 + c);
-    const int64_t p0 = (int64_t)blockIdx.y * (16 * U) + (threadIdx.x >> 4);
-    f32x4 v[U], d[U];
     double ssum[4] = {0.0, 0.0, 0.0, 0.0};                 // (SEGSUM; the host asks for it only when C % 64 == 0: no early return)
     uint32_t mx = 0;                                        // (amax: the bit pattern of the largest |dz| this thread wrote)
+    for (int64_t pb = (int64_t)blockIdx.y * 128 + rl; pb < (int64_t)blockIdx.y * 128 + 128; pb += RP * U) {
+        f32x4 v[U], d[U];
 #pragma unroll
-    for (int i = 0; i < U; ++i) {
-        const int64_t p = min(p0 + 16 * i, M - 1);
-        v[i] = *reinterpret_cast<const f32x4*>(z + p * ldz + c);
-        if (DENSE) {
-            d[i] = *reinterpret_cast<const f32x4*>(src.da + p * src.ldda + c);
-        } else {
+        for (int i = 0; i < U; ++i) {
+            const int64_t p = min(pb + RP * i, M - 1);
+            v[i] = *reinterpret_cast<const f32x4*>(z + p * ldz + c);
+            if (DENSE) {
+                d[i] = *reinterpret_cast<const f32x4*>(src.da + p * src.ldda + c);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) d[i][e] = src.at(p, c + e, C);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < U; ++i) {
-        const int64_t p = p0 + 16 * i;
-        if (p >= M) break;
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float y = v[i][e] * sc[e] + sh[e];
-            const float dy = y > 0.0f ? d[i][e] : 0.0f;
-            o[e] = a1[e] * (dy - a2[e] - (v[i][e] - mean[e]) * rs[e] * a3[e]);
-        }
-        *reinterpret_cast<f32x4*>(dz + p * lddz + c) = o;
-        if (amax) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t b = __float_as_uint(o[e]) & 0x7fffffffu;
-                mx = b > mx ? b : mx;
+                for (int e = 0; e < 4; ++e) d[i][e] = src.at(p, c + e, C);
             }
         }
-        if (SEGSUM) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ssum[e] += (double)o[e];
+        for (int i = 0; i < U; ++i) {
+            const int64_t p = pb + RP * i;
+            if (p >= M) break;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = v[i][e] * sc[e] + sh[e];
+                const float dy = y > 0.0f ? d[i][e] : 0.0f;
+                o[e] = a1[e] * (dy - a2[e] - (v[i][e] - mean[e]) * rs[e] * a3[e]);
+            }
+            *reinterpret_cast<f32x4*>(dz + p * lddz + c) = o;
+            if (amax) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t b = __float_as_uint(o[e]) & 0x7fffffffu;
+                    mx = b > mx ? b : mx;
+                }
+            }
+            if (SEGSUM) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ssum[e] += (double)o[e];
+            }
         }
     }
     if (amax) {                                             // (C % 64 == 0: whole waves; one atomic per wave)
@@ -1815,21 +1819,29 @@ __global__ __launch_bounds__(256) void tr_bnbwd_apply_kernel(const float* __rest
         // 64 words, a wave's by its index: 32,768 waves on ONE word are ~370 us of serialised atomics (88 per us), on 64 a few
         if ((threadIdx.x & 63) == 0) atomicMax(amax + ((blockIdx.y * 4u + (threadIdx.x >> 6)) & 63u), mx);
     }
-    if (SEGSUM) {
-        __shared__ double sm[16][64];
-        const int gl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    if (SEGSUM) {                                           // a thread's rows in order (above), then the block's row lanes in order
+        __shared__ double sm[1024];                         // [row lane][channel of the block]: RP x (4 << cgs) = 1024
+        const int W = 4 << cgs;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sm[rl][gl * 4 + e] = ssum[e];
+        for (int e = 0; e < 4; ++e) sm[rl * W + gl * 4 + e] = ssum[e];
         __syncthreads();
-        if (threadIdx.x < 64) {
-            const int cc = blockIdx.x * 64 + threadIdx.x;
+        for (int cb = threadIdx.x; cb < W; cb += 256) {
+            const int cc = blockIdx.x * W + cb;
             if (cc < C) {
                 double t = 0.0;
-                for (int i = 0; i < 16; ++i) t += sm[i][threadIdx.x];
+                for (int i = 0; i < RP; ++i) t += sm[i * W + cb];
                 seg_part[(int64_t)blockIdx.y * C + cc] = t;
             }
         }
     }
+}
+
+// threads per row (log2) of tr_bnbwd_apply_kernel: 512-channel strips where the rows are that long, else 64-channel strips
+static int tr_apply_cgs(int C) {
+#ifdef TR_APPLY_CGS
+    return TR_APPLY_CGS;
+#endif
+    return C % 512 == 0 ? 7 : 4;        // (A/B at 262,144 rows: 512 channels 299 -> 287 us; 256 equal; 128 slower by 4 us as whole rows)
 }
 
 // out[s][c] = sum of the n_blk block partials of segment s, in block order (fp32 out)
@@ -1849,13 +1861,14 @@ hipError_t launch_tr_bnbwd_apply(const float* z, int64_t M, int C, int64_t ldz, 
                                  const float* mu, const float* rstd, const float* k1, const float* k2, const float* k3,
                                  float* dz, int64_t lddz, hipStream_t s, uint32_t* amax) {
     DaSrc src{da, ldda, dg, arg, seg};
-    const dim3 grid((C + 63) / 64, (unsigned)((M + 127) / 128));
+    const int cgs = tr_apply_cgs(C), W = 4 << cgs;
+    const dim3 grid((C + W - 1) / W, (unsigned)((M + 127) / 128));
     if (da)
         hipLaunchKernelGGL((tr_bnbwd_apply_kernel<true>), grid, dim3(256), 0, s, z, M, C, ldz, src, scale, shift, mu, rstd, k1,
-                           k2, k3, dz, lddz, nullptr, amax);
+                           k2, k3, dz, lddz, cgs, nullptr, amax);
     else
         hipLaunchKernelGGL((tr_bnbwd_apply_kernel<false>), grid, dim3(256), 0, s, z, M, C, ldz, src, scale, shift, mu, rstd, k1,
-                           k2, k3, dz, lddz, nullptr, amax);
+                           k2, k3, dz, lddz, cgs, nullptr, amax);
     return hipGetLastError();
 }
 
@@ -1866,9 +1879,10 @@ hipError_t launch_tr_bnbwd_apply_segsum(const float* z, int64_t M, int C, int64_
                                         const float* k1, const float* k2, const float* k3, float* dz, int64_t lddz,
                                         int64_t sum_seg, float* seg_sums, double* ws, hipStream_t s) {
     DaSrc src{da, ldda, nullptr, nullptr, 0};
-    const dim3 grid((C + 63) / 64, (unsigned)((M + 127) / 128));
+    const int cgs = tr_apply_cgs(C), W = 4 << cgs;
+    const dim3 grid((C + W - 1) / W, (unsigned)((M + 127) / 128));
     hipLaunchKernelGGL((tr_bnbwd_apply_kernel<true, true>), grid, dim3(256), 0, s, z, M, C, ldz, src, scale, shift, mu, rstd, k1, k2,
-                       k3, dz, lddz, ws);
+                       k3, dz, lddz, cgs, ws);
     const int64_t n = (M / sum_seg) * C;
     hipLaunchKernelGGL(tr_blocksum_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, (int)(sum_seg / 128), C, n,
                        seg_sums);
