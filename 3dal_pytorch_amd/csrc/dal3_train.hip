@@ -1910,7 +1910,11 @@ struct WgBlock {
 // a conditional load (`t < n_mt ? p[..] : 0`) is a BRANCH per load to hipcc, 50-120 of them per 16-point block, and
 // with them every load, its address arithmetic and the activation sat in one blob between two bursts of MFMAs (the big
 // layers ran at 58 % of peak for it).
-template <int MT, int KT>
+// FULL: every tile of the block is real (c_out % (32 MT) == 0 and c_in % (32 KT) == 0: all the big layers) — the tile
+// offsets are then compile-time constants and travel in the load's immediate field: ONE 64-bit address per k-step and
+// operand instead of one per load (round 4: 144 of the 246 vector instructions of the <4, 4, 2> loop body were
+// v_lshl_add_u64, beside 128 MFMAs that share the SIMD's FMA lanes with them: tools/isa_mix.py, tools/pmc_train.sh).
+template <bool FULL, int MT, int KT>
 __device__ __forceinline__ void wg_load(WgBlock<MT, KT>& bk, const float* __restrict__ pa, int64_t lddz,
                                         const float* __restrict__ pb, int64_t lda, const int (&oa)[MT], const int (&ob)[KT]) {
 #pragma unroll
@@ -1918,9 +1922,9 @@ __device__ __forceinline__ void wg_load(WgBlock<MT, KT>& bk, const float* __rest
         const float* ra = pa + 2 * s * lddz;
         const float* rb = pb + 2 * s * lda;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) bk.av[s][t] = ra[oa[t]];
+        for (int t = 0; t < MT; ++t) bk.av[s][t] = ra[FULL ? 32 * t : oa[t]];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) bk.bv[s][k] = rb[ob[k]];                        // raw; activation at use
+        for (int k = 0; k < KT; ++k) bk.bv[s][k] = rb[FULL ? 32 * k : ob[k]];        // raw; activation at use
     }
 }
 
@@ -1948,7 +1952,7 @@ __device__ __forceinline__ void wg_compute(WgBlock<MT, KT>& bk, f32x16 (&acc)[MT
 // one is consumed. The big layers run <4, 2, 2> (128 accumulator registers, 96 of operands); layers with at most 64
 // output channels would leave most of that idle and are bound by the latency of their loads instead (one 16-point block
 // in flight per wave: 93 us for 134 MB), so they run <2, 2, 4>: three blocks in flight in the same registers (55 us).
-template <int MT, int KT, int NB>
+template <int MT, int KT, int NB, bool FULL = false>
 __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ a,
                                                        int64_t lda, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int relu_in, int64_t M, int c_out,
@@ -1991,16 +1995,16 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
         // ping-pong with running pointers (n_blk is even: M and the slices are multiples of 32 points)
         const float* pa = pa0;
         const float* pb = pb0;
-        wg_load(ring[0], pa, lddz, pb, lda, oa, ob);
+        wg_load<FULL>(ring[0], pa, lddz, pb, lda, oa, ob);
         for (int64_t i = 0; i < n_blk; i += 2) {
-            wg_load(ring[1], pa + sa, lddz, pb + sb, lda, oa, ob);
+            wg_load<FULL>(ring[1], pa + sa, lddz, pb + sb, lda, oa, ob);
             DAL3_SCHED_FENCE();
             wg_compute(ring[0], acc, sc, sh, act, relu_in);
             DAL3_SCHED_FENCE();
             const bool more = i + 2 < n_blk;
             pa = more ? pa + 2 * sa : pa0;
             pb = more ? pb + 2 * sb : pb0;
-            wg_load(ring[0], pa, lddz, pb, lda, oa, ob);
+            wg_load<FULL>(ring[0], pa, lddz, pb, lda, oa, ob);
             DAL3_SCHED_FENCE();
             wg_compute(ring[1], acc, sc, sh, act, relu_in);
             DAL3_SCHED_FENCE();
@@ -2011,14 +2015,14 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
 #pragma unroll
         for (int b = 0; b < NB - 1; ++b) {
             const int64_t i = b < n_blk ? b : 0;
-            wg_load(ring[b], pa0 + i * sa, lddz, pb0 + i * sb, lda, oa, ob);
+            wg_load<FULL>(ring[b], pa0 + i * sa, lddz, pb0 + i * sb, lda, oa, ob);
         }
         for (int64_t i0 = 0; i0 < n_blk; i0 += NB) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int64_t nx = i0 + u + NB - 1;
                 const int64_t j = nx < n_blk ? nx : 0;
-                wg_load(ring[(u + NB - 1) % NB], pa0 + j * sa, lddz, pb0 + j * sb, lda, oa, ob);
+                wg_load<FULL>(ring[(u + NB - 1) % NB], pa0 + j * sa, lddz, pb0 + j * sb, lda, oa, ob);
                 DAL3_SCHED_FENCE();
                 if (i0 + u < n_blk) wg_compute(ring[u], acc, sc, sh, act, relu_in);
                 DAL3_SCHED_FENCE();
@@ -2120,15 +2124,21 @@ hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_
     const int64_t n_slices = (M + pts - 1) / pts;
     const int64_t units = n_slices * n_mb * n_kb;
     const dim3 grid((unsigned)((units + 3) / 4));
+#ifndef WG_FULL
+#define WG_FULL 1                       // 0: the clamped-offset loads for every layer (A/B builds)
+#endif
+    const auto go = [&](auto plain, auto full, int mt, int kt) {
+        if (WG_FULL && c_out % (32 * mt) == 0 && c_in % (32 * kt) == 0)
+            hipLaunchKernelGGL(full, grid, dim3(256), 0, s, dz, lddz, a, lda, scale, shift, relu_in, M, c_out, c_in, part, n_mb, n_kb, pts);
+        else
+            hipLaunchKernelGGL(plain, grid, dim3(256), 0, s, dz, lddz, a, lda, scale, shift, relu_in, M, c_out, c_in, part, n_mb, n_kb, pts);
+    };
     if (wgrad_small(c_out))
-        hipLaunchKernelGGL((tr_wgrad_kernel<2, WG_KT, 4>), grid, dim3(256), 0, s, dz, lddz, a, lda, scale, shift, relu_in, M,
-                           c_out, c_in, part, n_mb, n_kb, pts);
+        go(tr_wgrad_kernel<2, WG_KT, 4>, tr_wgrad_kernel<2, WG_KT, 4, true>, 2, WG_KT);
     else if (wgrad_kt(c_out, c_in) == 4)
-        hipLaunchKernelGGL((tr_wgrad_kernel<WG_MT, 4, 2>), grid, dim3(256), 0, s, dz, lddz, a, lda, scale, shift, relu_in,
-                           M, c_out, c_in, part, n_mb, n_kb, pts);
+        go(tr_wgrad_kernel<WG_MT, 4, 2>, tr_wgrad_kernel<WG_MT, 4, 2, true>, WG_MT, 4);
     else
-        hipLaunchKernelGGL((tr_wgrad_kernel<WG_MT, WG_KT, 2>), grid, dim3(256), 0, s, dz, lddz, a, lda, scale, shift, relu_in,
-                           M, c_out, c_in, part, n_mb, n_kb, pts);
+        go(tr_wgrad_kernel<WG_MT, WG_KT, 2>, tr_wgrad_kernel<WG_MT, WG_KT, 2, true>, WG_MT, WG_KT);
     const int64_t n = (int64_t)c_out * c_in;
     hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * WGF_L), 0, s, part, (int)n_slices, n, dW);
     return hipGetLastError();
@@ -2595,15 +2605,18 @@ hipError_t launch_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x, 
     const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
     const int kin = c_in <= 4 ? 4 : 8, co4 = c_out / 4;
     const size_t lds = (size_t)(256 / co4) * c_out * kin * sizeof(double);
-    const auto go = [&](auto kern) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const auto go = [&](auto kern) -> hipError_t {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, s, dz, lddz, x, M, c_in, ldx, part);
+        return hipSuccess;
     };
-    if (kin == 4) {
-        if (c_out == 64) go(tr_conv1_wgrad_kernel<4, 16>); else go(tr_conv1_wgrad_kernel<4, 32>);
-    } else {
-        if (c_out == 64) go(tr_conv1_wgrad_kernel<8, 16>); else go(tr_conv1_wgrad_kernel<8, 32>);
-    }
+    hipError_t e;
+    if (kin == 4)
+        e = c_out == 64 ? go(tr_conv1_wgrad_kernel<4, 16>) : go(tr_conv1_wgrad_kernel<4, 32>);
+    else
+        e = c_out == 64 ? go(tr_conv1_wgrad_kernel<8, 16>) : go(tr_conv1_wgrad_kernel<8, 32>);
+    if (e != hipSuccess) return e;
     const int Cp = c_out * kin / 2;
     hipLaunchKernelGGL(tr_colred_final_kernel<0>, dim3((Cp + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, nb, Cp, sums, BnEpi{});
     return hipGetLastError();
