@@ -137,6 +137,10 @@ SIGNATURES = {
                                 vp]),
     "dal3_tr_bn_finalize": (_i, [vp, _i, _i64, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp]),
     "dal3_tr_bnbwd_coef": (_i, [vp, _i, _i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dal3_tr_fc_max_rows": (_i, []),
+    "dal3_tr_fc_forward": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _i, vp, _i, vp, _i64, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp]),
+    "dal3_tr_fc_backward_w": (_i, [vp, _i64, _i64, _i, vp, _i64, vp, vp, vp, vp, vp, vp, vp, vp, _i, _i64, vp, vp, _i, vp, _i64, vp, _i64,
+                                   vp, vp]),
     "dal3_tr_bnbwd_apply": (_i, [vp, _i64, _i, _i64, vp, _i64, vp, vp, _i64, vp, vp, vp, vp, vp, vp, vp, vp, _i64, vp]),
     "dal3_tr_bnbwd_apply_segsum_workspace_bytes": (_sz, [_i64, _i]),
     "dal3_tr_bnbwd_apply_segsum": (_i, [vp, _i64, _i, _i64, vp, _i64, vp, vp, vp, vp, vp, vp, vp, vp, _i64, _i64, vp, vp, _sz, vp]),

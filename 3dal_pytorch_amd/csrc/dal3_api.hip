@@ -1123,6 +1123,40 @@ extern "C" int dal3_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x
     return 0;
 }
 
+extern "C" int dal3_tr_fc_max_rows(void) { return tr_fc_max_rows(); }
+
+extern "C" int dal3_tr_fc_forward(const float* a, int64_t B, int c_in, int64_t lda, const float* in_scale, const float* in_shift,
+                                  int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int c_out, float* z,
+                                  int64_t ldz, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  float momentum, float eps, float* mu, float* rstd, float* scale, float* shift, dal3_stream stream) {
+    if (!a || !W || !z || B < 1 || B > tr_fc_max_rows() || c_in <= 0 || c_out <= 0 || lda < c_in || ldz < c_out ||
+        ldw < (transpose_w ? c_out : c_in) || (in_scale && (!in_shift || c_in > tr_fc_max_act_cin())) || (!running_mean != !running_var))
+        return fail(DAL3_EINVAL, "tr_fc_forward: bad argument (1 <= B <= dal3_tr_fc_max_rows(); strides at least the row lengths; "
+                                 "c_in <= 2048 under an input activation)");
+    if (gamma && (!beta || !mu || !rstd || !scale || !shift || B < 2))
+        return fail(DAL3_EINVAL, "tr_fc_forward: a BatchNorm needs beta, the four outputs and at least two rows");
+    HIP_TRY(launch_tr_fc_forward(a, (int)B, c_in, lda, in_scale, in_shift, relu_in, W, ldw, transpose_w, bias, c_out, z, ldz, gamma, beta,
+                                 gamma ? running_mean : nullptr, gamma ? running_var : nullptr, momentum, eps, mu, rstd, scale, shift,
+                                 static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_fc_backward_w(const float* da, int64_t ldda, int64_t B, int c_out, const float* z, int64_t ldz, const float* scale,
+                                     const float* shift, const float* mu, const float* rstd, const float* gamma, float* dgamma,
+                                     float* dbeta, const float* a_prev, int c_in, int64_t lda, const float* in_scale,
+                                     const float* in_shift, int relu_in, float* dz, int64_t lddz, float* dW, int64_t lddw, float* db,
+                                     dal3_stream stream) {
+    if (!da || B < 1 || B > tr_fc_max_rows() || c_out <= 0 || ldda < c_out || (dz && lddz < c_out) ||
+        (in_scale && (!in_shift || c_in > tr_fc_max_act_cin())) ||
+        (dW && (!a_prev || c_in <= 0 || lda < c_in || lddw < c_in)))
+        return fail(DAL3_EINVAL, "tr_fc_backward_w: bad argument (1 <= B <= dal3_tr_fc_max_rows(); strides at least the row lengths)");
+    if (scale && (!z || ldz < c_out || !shift || !mu || !rstd || !gamma || !dgamma || !dbeta))
+        return fail(DAL3_EINVAL, "tr_fc_backward_w: a BatchNorm needs z, shift, mu, rstd, gamma and the two gradient outputs");
+    HIP_TRY(launch_tr_fc_backward_w(da, ldda, (int)B, c_out, z, ldz, scale, shift, mu, rstd, gamma, dgamma, dbeta, a_prev, c_in, lda,
+                                    in_scale, in_shift, relu_in, dz, lddz, dW, lddw, db, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_tr_gather_at(const float* z, int64_t ldz, const int32_t* arg, int64_t seg, int n_seg, int C, float* out,
                                  dal3_stream stream) {
     if (!z || !arg || !out || seg <= 0 || n_seg <= 0 || C <= 0 || ldz < C) return fail(DAL3_EINVAL, "tr_gather_at: bad argument");

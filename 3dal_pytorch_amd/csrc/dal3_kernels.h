@@ -318,6 +318,18 @@ hipError_t launch_tr_head2_wgrad(const float* dl, const float* z, int64_t M, int
                                  int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop,
                                  double* ws, double* sums, hipStream_t s);
 // the first layer of a stack (c_in <= 8) as VALU kernels (dal3_train.hip)
+// dal3_train_fc.hip
+int tr_fc_max_rows();
+int tr_fc_max_act_cin();
+hipError_t launch_tr_fc_forward(const float* a, int B, int c_in, int64_t lda, const float* in_scale, const float* in_shift, int relu_in,
+                                const float* W, int64_t ldw, int transpose_w, const float* bias, int c_out, float* z, int64_t ldz,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                float eps, float* mu, float* rstd, float* scale, float* shift, hipStream_t s);
+hipError_t launch_tr_fc_backward_w(const float* da, int64_t ldda, int B, int c_out, const float* z, int64_t ldz, const float* scale,
+                                   const float* shift, const float* mu, const float* rstd, const float* gamma, float* dgamma,
+                                   float* dbeta, const float* a_prev, int c_in, int64_t lda, const float* in_scale,
+                                   const float* in_shift, int relu_in, float* dz, int64_t lddz, float* dW, int64_t lddw, float* db,
+                                   hipStream_t s);
 size_t tr_conv1_workspace_bytes(int64_t Mp, int c_out);
 hipError_t launch_tr_conv1_bn_stats(const float* x, int64_t M, int64_t Mp, int c_in, int64_t ldx, const float* W, int64_t ldw,
                                     const float* bias, int c_out, float* z, int64_t ldz, const float* gamma, const float* beta,

@@ -952,6 +952,9 @@ class _InsSeg(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+FC_ROWS_KERNELS = True          # False: every FC tail through the per-point kernels (_FcTail; tests, A/B)
+
+
 class _FcTail(torch.autograd.Function):
     """The per-item tail of a head in train mode — Linear -> BatchNorm1d (batch statistics over the B items) -> ReLU,
     n_bn times, then an optional last Linear without BN (fc3) — on the same training kernels as the per-point stacks,
@@ -1029,6 +1032,108 @@ class _FcTail(torch.autograd.Function):
         return (da[:B], None, None, *grads)
 
 
+class _BNc:
+    """the BatchNorm constants of one FC layer as dal3_tr_fc_forward left them (what _BN holds, without its launches)"""
+
+    def __init__(self, st, gamma, M):
+        self.mu, self.rstd, self.scale, self.shift = st[0], st[1], st[2], st[3]
+        self.gamma, self.M = gamma, M
+
+    @property
+    def act(self):
+        return (self.scale, self.shift, True)
+
+
+def _fc_forward(a, act, W, bias, c_out, bn=None, transpose=False):
+    """z (B, c_out) = act(a) Wop^T + bias on dal3_tr_fc_forward; bn = (gamma, beta, running_mean, running_var): the layer's
+    batch statistics in the same launch -> (z, _BNc)"""
+    B, dev = a.shape[0], a.device
+    sc, sh, relu = act if act is not None else (None, None, False)
+    z = torch.empty((B, c_out), dtype=torch.float32, device=dev)
+    c_in = W.shape[0] if transpose else W.shape[1]
+    gamma = beta = rm = rv = None
+    st = [None] * 4
+    if bn is not None:
+        gamma, beta, rm, rv = bn
+        st = torch.empty((4, c_out), dtype=torch.float32, device=dev)
+    _hip.check(_hip.lib().dal3_tr_fc_forward(_hip.ptr(a), B, c_in, a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu), _hip.ptr(W),
+                                             W.stride(0), int(transpose), _hip.ptr(bias), c_out, _hip.ptr(z), z.stride(0),
+                                             _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(rm), _hip.ptr(rv), _MOM, _EPS, _hip.ptr(st[0]),
+                                             _hip.ptr(st[1]), _hip.ptr(st[2]), _hip.ptr(st[3]), _hip.stream()))
+    return (z, _BNc(st, gamma, B)) if bn is not None else z
+
+
+def _fc_backward_w(da, z, bn, src, act_in, W_shape):
+    """of one FC layer: (dz, dW, db, dgamma, dbeta) from the gradient w.r.t. its output (relu(bn(z)), or — bn None — z itself,
+    and dz is da) on dal3_tr_fc_backward_w"""
+    B, C = da.shape
+    dev = da.device
+    c_in = src.shape[1]
+    sc, sh, relu = act_in if act_in is not None else (None, None, False)
+    dW = torch.empty((C, c_in), dtype=torch.float32, device=dev)
+    db = torch.empty(C, dtype=torch.float32, device=dev)
+    dz = dgb = None
+    args = [None] * 7
+    if bn is not None:
+        dz = torch.empty((B, C), dtype=torch.float32, device=dev)
+        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        args = [bn.scale, bn.shift, bn.mu, bn.rstd, bn.gamma, dgb[0], dgb[1]]
+    _hip.check(_hip.lib().dal3_tr_fc_backward_w(_hip.ptr(da), da.stride(0), B, C, _hip.ptr(z), z.stride(0) if z is not None else 0,
+                                                *[_hip.ptr(t) for t in args], _hip.ptr(src), c_in, src.stride(0), _hip.ptr(sc),
+                                                _hip.ptr(sh), int(relu), _hip.ptr(dz), dz.stride(0) if dz is not None else 0,
+                                                _hip.ptr(dW), dW.stride(0), _hip.ptr(db), _hip.stream()))
+    return (dz if bn is not None else da), dW.reshape(W_shape), db, (dgb[0] if bn is not None else None), (dgb[1] if bn is not None else None)
+
+
+class _FcTailRows(torch.autograd.Function):
+    """_FcTail for 2 <= B <= dal3_tr_fc_max_rows() items on the rows-are-items kernels (csrc/dal3_train_fc.hip): one launch per
+    layer forward (product, bias, batch statistics, running statistics), two backward (BatchNorm backward + weight gradient;
+    input gradient) — no padding, no packed weight images. The same arguments, the same results."""
+
+    @staticmethod
+    def forward(ctx, x, stats, n_bn, *params):
+        P = [p.detach() for p in params]
+        a_in = x.detach()
+        a_in = a_in if (a_in.is_contiguous() and a_in.dtype == torch.float32) else a_in.contiguous().float()
+        a, act, bns, zs, Ws = a_in, None, [], [], []
+        for k in range(n_bn):
+            W, b, gamma, beta = (t.contiguous() for t in P[4 * k:4 * k + 4])
+            W2 = W.reshape(W.shape[0], -1)
+            rm, rv = stats[k] if stats is not None else (None, None)
+            z, bn = _fc_forward(a, act, W2, b, W2.shape[0], bn=(gamma, beta, rm, rv))
+            Ws.append(W2)
+            bns.append(bn)
+            zs.append(z)
+            a, act = z, bn.act
+        last = None
+        if len(P) > 4 * n_bn:
+            W, b = P[4 * n_bn].contiguous(), P[4 * n_bn + 1].contiguous()
+            last = W.reshape(W.shape[0], -1)
+            out = _fc_forward(a, act, last, b, last.shape[0])
+        else:
+            out = _act_dropout(a, act, None)                       # relu(bn(z)) of the last BatchNorm layer
+        ctx.saved = (a_in, Ws, bns, zs, last, n_bn, [tuple(p.shape) for p in params])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a_in, Ws, bns, zs, last, n_bn, shapes = _take_saved(ctx)
+        grads = [None] * len(shapes)
+        da = dout if (dout.is_contiguous() and dout.dtype == torch.float32) else dout.contiguous().float()
+        if last is not None:
+            src, act = (zs[-1], bns[-1].act) if n_bn else (a_in, None)
+            _, grads[4 * n_bn], grads[4 * n_bn + 1], _, _ = _fc_backward_w(da, None, None, src, act, shapes[4 * n_bn])
+            da = _fc_forward(da, None, last, None, last.shape[1], transpose=True)
+        for k in range(n_bn - 1, -1, -1):
+            src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a_in, None)
+            dz, grads[4 * k], grads[4 * k + 1], grads[4 * k + 2], grads[4 * k + 3] = _fc_backward_w(da, zs[k], bns[k], src, act, shapes[4 * k])
+            if k > 0 or ctx.needs_input_grad[0]:
+                da = _fc_forward(dz, None, Ws[k], None, Ws[k].shape[1], transpose=True)
+            else:
+                da = None
+        return (da, None, None, *grads)
+
+
 def fc_tail_supported(x):
     return x.is_cuda and x.dim() == 2 and x.shape[1] % 32 == 0
 
@@ -1048,6 +1153,8 @@ def fc_tail_train_forward(head, x):
     if any(bn is None for _, bn, _, _ in fcs[:-1]):
         raise RuntimeError("fc tail: only the last layer may come without a BatchNorm")
     stats = _bn_stats(head, bn_names)
+    if FC_ROWS_KERNELS and 2 <= x.shape[0] <= _hip.lib().dal3_tr_fc_max_rows():
+        return _FcTailRows.apply(x, stats, len(bn_names), *params)
     return _FcTail.apply(x, stats, len(bn_names), *params)
 
 

@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dal3_stream;               /* hipStream_t */
 
-#define DAL3_VERSION 130                 /* 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums */
+#define DAL3_VERSION 131                 /* 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums; .1: dal3_tr_fc_* */
 
 enum {
     DAL3_OK = 0,
@@ -453,6 +453,26 @@ int dal3_tr_conv1_bn_stats(const float* x, int64_t M, int64_t Mp, int c_in, int6
                            float* scale, float* shift, void* workspace, size_t workspace_bytes, dal3_stream stream);
 int dal3_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x, int64_t M, int c_in, int64_t ldx, int c_out, void* workspace,
                         size_t workspace_bytes, double* sums, dal3_stream stream);
+/* The per-item FC tails in train mode (static_model.py:336-338, dynamic_model.py:247-248, :284-285, :306-311;
+ * `_PointHead.tail` with self.training): Linear -> BatchNorm1d over the B ITEMS -> ReLU with rows = items,
+ * 2 <= B <= dal3_tr_fc_max_rows(). One launch per layer forward, two backward; no padding, no packed weight image; every
+ * sum in index order (float64 for the batch statistics and the BatchNorm-backward sums).
+ *   dal3_tr_fc_forward     z (B, c_out) = act(a) Wop^T + bias, act = (in_scale, in_shift, relu_in) of the layer below (NULL:
+ *                          identity), Wop = W (c_out, c_in) or, transpose_w, W^T of a (c_in, c_out) matrix (the dgrad:
+ *                          da_prev = dz W); with gamma != NULL also dal3_tr_bn_stats of z over its B rows (mu, rstd,
+ *                          scale, shift, the running statistics when given) in the same launch
+ *   dal3_tr_fc_backward_w  of the layer whose pre-BN output is z: from da (gradient w.r.t. relu(bn(z)); with scale == NULL
+ *                          the layer has no BatchNorm and da IS dz) -> dz (B, c_out; may be NULL), dgamma, dbeta, db
+ *                          (zeros in front of a BatchNorm), dW (c_out, c_in) = dz^T act(a_prev) (may be NULL) */
+int dal3_tr_fc_max_rows(void);
+int dal3_tr_fc_forward(const float* a, int64_t B, int c_in, int64_t lda, const float* in_scale, const float* in_shift, int relu_in,
+                       const float* W, int64_t ldw, int transpose_w, const float* bias, int c_out, float* z, int64_t ldz,
+                       const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                       float* mu, float* rstd, float* scale, float* shift, dal3_stream stream);
+int dal3_tr_fc_backward_w(const float* da, int64_t ldda, int64_t B, int c_out, const float* z, int64_t ldz, const float* scale,
+                          const float* shift, const float* mu, const float* rstd, const float* gamma, float* dgamma, float* dbeta,
+                          const float* a_prev, int c_in, int64_t lda, const float* in_scale, const float* in_shift, int relu_in,
+                          float* dz, int64_t lddz, float* dW, int64_t lddw, float* db, dal3_stream stream);
 /* out (n_seg, C) = z[s*seg + arg[s][c]][c]: the same values gathered from a MATERIALISED layer output (dal3_tr_segmax's arg) */
 int dal3_tr_gather_at(const float* z, int64_t ldz, const int32_t* arg, int64_t seg, int n_seg, int C, float* out,
                       dal3_stream stream);

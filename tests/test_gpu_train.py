@@ -495,11 +495,13 @@ def test_dropout_kernel_statistics_key_and_backward():
 
 @pytest.mark.parametrize("kind,head_name,c_in,B", [("static_one", "box_est", 512, 64), ("dynamic", "point_emb", 512, 64),
                                                    ("dynamic", "box_emb", 512, 64), ("dynamic", "box_est", 384, 64),
-                                                   ("static_one", "box_est", 512, 40), ("dynamic", "box_est", 384, 7)])
+                                                   ("static_one", "box_est", 512, 40), ("dynamic", "box_est", 384, 7),
+                                                   ("static_one", "box_est", 512, 5), ("dynamic", "point_emb", 512, 256),
+                                                   ("static_one", "box_est", 512, 300), ("dynamic", "box_est", 384, 289)])
 def test_fc_tail_on_hip_kernels_matches_float64_autograd(kind, head_name, c_in, B):
     """the per-item Linear -> BatchNorm1d -> ReLU tails (rows = items) on the training kernels: output, input
-    gradient, every parameter gradient and the running statistics against float64 autograd of `_PointHead.tail`
-    (B = 40 and 7: batches that are not a multiple of 32 — padded rows, statistics over the real ones)"""
+    gradient, every parameter gradient and the running statistics against float64 autograd of `_PointHead.tail`.
+    Up to dal3_tr_fc_max_rows() = 256 items: the rows-are-items kernels (csrc/dal3_train_fc.hip); more: the per-point kernels (B = 300, 289: no multiple of 32 — padded rows, statistics over the real ones)"""
     model = build_model(kind, synth.state_dict(kind, seed=27)).train()
     head = getattr(model, head_name)
     ref = copy.deepcopy(head).double()

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 mkdir -p variants/obj_$1
 CC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function"
 NONAN=-fno-honor-nans          # the shared-MLP kernels only, as in the Makefile
-for f in dal3_api dal3_misc dal3_prep dal3_crops dal3_train; do
+for f in dal3_api dal3_misc dal3_prep dal3_crops dal3_train dal3_train_fc; do
   $CC $2 -c 3dal_pytorch_amd/csrc/$f.hip -o variants/obj_$1/$f.o &
 done
 $CC $2 -mllvm -pragma-unroll-threshold=1000000 -c 3dal_pytorch_amd/csrc/dal3_train_x3.hip -o variants/obj_$1/dal3_train_x3.o &
