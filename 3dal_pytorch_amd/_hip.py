@@ -33,6 +33,11 @@ class PackItem(C.Structure):
                 ("mtb", C.c_int32), ("out", vp)]
 
 
+class WgradPart(C.Structure):
+    """dal3_tr_wgrad_part"""
+    _fields_ = [("part", vp), ("n_slices", C.c_int64), ("n", C.c_int64), ("dW", vp)]
+
+
 class BCN(C.Structure):
     _fields_ = [("data", vp), ("stride_b", C.c_int64), ("stride_c", C.c_int64), ("stride_n", C.c_int64),
                 ("dtype", C.c_int32), ("flags", C.c_int32)]
@@ -146,6 +151,7 @@ SIGNATURES = {
     "dal3_tr_bnbwd_apply_segsum": (_i, [vp, _i64, _i, _i64, vp, _i64, vp, vp, vp, vp, vp, vp, vp, vp, _i64, _i64, vp, vp, _sz, vp]),
     "dal3_tr_wgrad_workspace_bytes": (_sz, [_i64, _i, _i]),
     "dal3_tr_wgrad": (_i, [vp, _i64, vp, _i64, vp, vp, _i, _i64, _i, _i, vp, _sz, vp, vp]),
+    "dal3_tr_wgrad_final_many": (_i, [C.POINTER(WgradPart), _i, vp]),
     "dal3_tr_wgrad_x3_workspace_bytes": (_sz, [_i64, _i, _i]),
     "dal3_tr_wgrad_x3": (_i, [vp, _i64, vp, _i64, vp, vp, _i, vp, _i64, _i, _i, vp, _sz, vp, vp]),
     "dal3_tr_segmax": (_i, [vp, _i64, _i64, _i, vp, vp, vp, vp, _i64, vp, _sz, vp]),

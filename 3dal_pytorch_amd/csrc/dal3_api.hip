@@ -1336,12 +1336,21 @@ extern "C" size_t dal3_tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in) 
 extern "C" int dal3_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale,
                              const float* shift, int relu_in, int64_t M, int c_out, int c_in, void* workspace,
                              size_t workspace_bytes, float* dW, dal3_stream stream) {
-    if (!dz || !a || !dW || !mult32(M) || !mult32(c_out) || !mult32(c_in) || lddz < c_out || lda < c_in || (scale && !shift))
+    if (!dz || !a || !mult32(M) || !mult32(c_out) || !mult32(c_in) || lddz < c_out || lda < c_in || (scale && !shift))
         return fail(DAL3_EINVAL, "tr_wgrad: bad argument (M, c_in, c_out multiples of 32)");
     if (!workspace || workspace_bytes < tr_wgrad_workspace_bytes(M, c_out, c_in))
         return fail(DAL3_EWORKSPACE, "tr_wgrad: workspace smaller than dal3_tr_wgrad_workspace_bytes()");
     HIP_TRY(launch_tr_wgrad(dz, lddz, a, lda, scale, shift, relu_in, M, c_out, c_in, static_cast<float*>(workspace), dW,
                             static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_tr_wgrad_final_many(const dal3_tr_wgrad_part* items, int n, dal3_stream stream) {
+    if (!items || n <= 0 || n > 24) return fail(DAL3_EINVAL, "tr_wgrad_final_many: 1 .. 24 items");
+    for (int i = 0; i < n; ++i)
+        if (!items[i].part || !items[i].dW || items[i].n <= 0 || items[i].n_slices <= 0 || items[i].n_slices > 0x7fffffff)
+            return fail(DAL3_EINVAL, "tr_wgrad_final_many: bad item %d", i);
+    HIP_TRY(launch_tr_wgrad_final_many(items, n, static_cast<hipStream_t>(stream)));
     return 0;
 }
 
@@ -1352,7 +1361,7 @@ extern "C" size_t dal3_tr_wgrad_x3_workspace_bytes(int64_t M, int c_out, int c_i
 extern "C" int dal3_tr_wgrad_x3(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale,
                                 const float* shift, int relu_in, const uint32_t* dz_amax, int64_t M, int c_out, int c_in,
                                 void* workspace, size_t workspace_bytes, float* dW, dal3_stream stream) {
-    if (!dz || !a || !dW || !mult32(M) || !mult32(c_out) || !mult32(c_in) || lddz < c_out || lda < c_in || (scale && !shift) ||
+    if (!dz || !a || !mult32(M) || !mult32(c_out) || !mult32(c_in) || lddz < c_out || lda < c_in || (scale && !shift) ||
         (lddz & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(dz) & 15) || (reinterpret_cast<uintptr_t>(a) & 15) ||
         (scale && ((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15)) ||
         (reinterpret_cast<uintptr_t>(dz_amax) & 3))

@@ -318,6 +318,7 @@ hipError_t launch_tr_head2_wgrad(const float* dl, const float* z, int64_t M, int
                                  int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop,
                                  double* ws, double* sums, hipStream_t s);
 // the first layer of a stack (c_in <= 8) as VALU kernels (dal3_train.hip)
+hipError_t launch_tr_wgrad_final_many(const dal3_tr_wgrad_part* items, int n, hipStream_t s);
 // dal3_train_fc.hip
 int tr_fc_max_rows();
 int tr_fc_max_act_cin();

@@ -2050,11 +2050,10 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
 #ifndef WGF_L
 #define WGF_L 16
 #endif
-__global__ __launch_bounds__(64 * WGF_L) void tr_wgrad_final_kernel(const float* __restrict__ part, int n_slices, int64_t n,
-                                                                   float* __restrict__ dW) {
-    __shared__ float sm[WGF_L][64];
+__device__ __forceinline__ void wgrad_final_block(const float* __restrict__ part, int n_slices, int64_t n, float* __restrict__ dW,
+                                                  uint32_t block, float (*sm)[64]) {
     const int el = threadIdx.x & 63, l = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + el;
+    const int64_t i = (int64_t)block * 64 + el;
     float s = 0.0f;
     if (i < n) {
         float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;       // four independent chains: the loop is load-latency bound
@@ -2076,6 +2075,11 @@ __global__ __launch_bounds__(64 * WGF_L) void tr_wgrad_final_kernel(const float*
         for (int j = 1; j < WGF_L; ++j) t += sm[j][el];
         dW[i] = t;
     }
+}
+__global__ __launch_bounds__(64 * WGF_L) void tr_wgrad_final_kernel(const float* __restrict__ part, int n_slices, int64_t n,
+                                                                   float* __restrict__ dW) {
+    __shared__ float sm[WGF_L][64];
+    wgrad_final_block(part, n_slices, n, dW, blockIdx.x, sm);
 }
 
 // slice length: enough (tile block, slice) units to occupy the chip (~1024 waves: with 2048 the partial sums of the
@@ -2110,6 +2114,41 @@ size_t tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in) {
     return (size_t)((M + pts - 1) / pts) * c_out * c_in * sizeof(float);
 }
 
+// The second stages of SEVERAL weight gradients in one launch (round 4: a backward pass issued one 5-us second stage behind
+// each of its 10–14 wgrad kernels; nothing reads a dW before the optimizer, so they can all wait for the end of the
+// backward function). Same kernel body and association as tr_wgrad_final_kernel; the table travels in the kernel arguments.
+#define TR_FINAL_MAX 24
+struct TrFinalItem {
+    const float* part;
+    float* dW;
+    int64_t n;
+    int32_t n_slices;
+    uint32_t first_block;                                   // of 64 elements; blocks [first_block, next item's) belong to it
+};
+struct TrFinalMany {
+    TrFinalItem it[TR_FINAL_MAX];
+    int n;
+};
+__global__ __launch_bounds__(64 * WGF_L) void tr_wgrad_final_many_kernel(TrFinalMany p) {
+    __shared__ float sm[WGF_L][64];
+    int k = 0;
+    for (int i = 1; i < p.n; ++i) k = blockIdx.x >= p.it[i].first_block ? i : k;      // (first_block is ascending)
+    const TrFinalItem& t = p.it[k];
+    wgrad_final_block(t.part, t.n_slices, t.n, t.dW, blockIdx.x - t.first_block, sm);
+}
+hipError_t launch_tr_wgrad_final_many(const dal3_tr_wgrad_part* items, int n, hipStream_t s) {
+    if (n <= 0 || n > TR_FINAL_MAX) return hipErrorInvalidValue;
+    TrFinalMany p;
+    p.n = n;
+    uint32_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        p.it[i] = TrFinalItem{items[i].part, items[i].dW, items[i].n, (int32_t)items[i].n_slices, blocks};
+        blocks += (uint32_t)((items[i].n + 63) / 64);
+    }
+    hipLaunchKernelGGL(tr_wgrad_final_many_kernel, dim3(blocks), dim3(64 * WGF_L), 0, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_tr_wgrad_final(const float* part, int n_slices, int64_t n, float* dW, hipStream_t s) {
     hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * WGF_L), 0, s, part, n_slices, n, dW);
     return hipGetLastError();
@@ -2139,6 +2178,7 @@ hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_
         go(tr_wgrad_kernel<WG_MT, 4, 2>, tr_wgrad_kernel<WG_MT, 4, 2, true>, WG_MT, 4);
     else
         go(tr_wgrad_kernel<WG_MT, WG_KT, 2>, tr_wgrad_kernel<WG_MT, WG_KT, 2, true>, WG_MT, WG_KT);
+    if (!dW) return hipGetLastError();                          // the caller adds the slices later (dal3_tr_wgrad_final_many)
     const int64_t n = (int64_t)c_out * c_in;
     hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * WGF_L), 0, s, part, (int)n_slices, n, dW);
     return hipGetLastError();

@@ -671,6 +671,6 @@ hipError_t launch_tr_wgrad_x3(const float* dz, int64_t lddz, const float* a, int
         case 4: e = go(tr_wgrad_x3_kernel<4, 2, 4, 1>, lds); break;
         default: return hipErrorInvalidValue;
     }
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || !dW) return e;                       // (dW NULL: the caller adds the slices later)
     return launch_tr_wgrad_final(part, n_slices, (int64_t)c_out * c_in, dW, s);
 }

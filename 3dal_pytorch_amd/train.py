@@ -198,28 +198,66 @@ def _colred(z, mode, da=None, dg=None, arg=None, seg=0, bn=None, rows=None):
     return out
 
 
-def _wgrad(dz, a, c_out, c_in, act=None, amax=None):
+_DEFERRED = None        # inside deferred_wgrad_finals(): the (partial sums, slices, elements, dW) of the weight gradients so far
+
+
+class deferred_wgrad_finals:
+    """`with deferred_wgrad_finals() as d:` — every _wgrad inside leaves its per-slice partial sums in a buffer of its own and
+    returns a dW that is filled when the block ends (or at d.flush(), which must precede any stock op that reads one of
+    them): ONE second-stage launch for up to 24 weight gradients instead of one behind each (dal3_tr_wgrad_final_many)."""
+
+    def __enter__(self):
+        global _DEFERRED
+        self.outer, _DEFERRED = _DEFERRED, []
+        return self
+
+    def flush(self):
+        items = _DEFERRED
+        while items:
+            chunk, items[:] = items[:24], items[24:]
+            arr = (_hip.WgradPart * len(chunk))(*[_hip.WgradPart(_hip.ptr(p), ns, n, _hip.ptr(dW)) for p, ns, n, dW in chunk])
+            _hip.check(_hip.lib().dal3_tr_wgrad_final_many(arr, len(chunk), _hip.stream()))
+
+    def __exit__(self, exc_type, exc, tb):
+        global _DEFERRED
+        try:
+            if exc_type is None:
+                self.flush()
+        finally:
+            _DEFERRED = self.outer
+        return False
+
+
+def _wgrad(dz, a, c_out, c_in, act=None, amax=None, later=False):
     """dW (c_out, c_in) = dz^T act(a). amax (64 device words holding the bits of max |dz|, _BN.backward(amax=)): the caller's
-    step runs on the f16x3 arithmetic — the layer takes dal3_tr_wgrad_x3 when its shape qualifies"""
+    step runs on the f16x3 arithmetic — the layer takes dal3_tr_wgrad_x3 when its shape qualifies. later: inside
+    deferred_wgrad_finals() the returned dW is filled when that block ends (the caller only passes it on, as a view)"""
     M = dz.shape[0]
     lib = _hip.lib()
     if amax is not None and _WGRAD_X3:
         need = lib.dal3_tr_wgrad_x3_workspace_bytes(M, c_out, c_in)
         if need:
             _note("wgrad_x3", M, c_in, c_out, 2.0 * M * c_in * c_out, 4.0 * M * (c_in + c_out))
-            ws = _ws(need, dz.device)
+            defer = later and _DEFERRED is not None
+            ws = torch.empty(need, dtype=torch.uint8, device=dz.device) if defer else _ws(need, dz.device)
             dW = torch.empty((c_out, c_in), dtype=torch.float32, device=dz.device)
             sc, sh, relu = (act if act is not None else (None, None, False))
             _hip.check(lib.dal3_tr_wgrad_x3(_hip.ptr(dz), dz.stride(0), _hip.ptr(a), a.stride(0), _hip.ptr(sc), _hip.ptr(sh),
-                                            int(relu), _hip.ptr(amax), M, c_out, c_in, _hip.ptr(ws), need, _hip.ptr(dW), _hip.stream()))
+                                            int(relu), _hip.ptr(amax), M, c_out, c_in, _hip.ptr(ws), need,
+                                            None if defer else _hip.ptr(dW), _hip.stream()))
+            if defer:
+                _DEFERRED.append((ws, need // (4 * c_out * c_in), c_out * c_in, dW))
             return dW
     _note("wgrad", M, c_in, c_out, 2.0 * M * c_in * c_out, 4.0 * M * (c_in + c_out))
     need = lib.dal3_tr_wgrad_workspace_bytes(M, c_out, c_in)
-    ws = _ws(need, dz.device)
+    defer = later and _DEFERRED is not None
+    ws = torch.empty(need, dtype=torch.uint8, device=dz.device) if defer else _ws(need, dz.device)
     dW = torch.empty((c_out, c_in), dtype=torch.float32, device=dz.device)
     sc, sh, relu = (act if act is not None else (None, None, False))
     _hip.check(lib.dal3_tr_wgrad(_hip.ptr(dz), dz.stride(0), _hip.ptr(a), a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu),
-                                 M, c_out, c_in, _hip.ptr(ws), need, _hip.ptr(dW), _hip.stream()))
+                                 M, c_out, c_in, _hip.ptr(ws), need, None if defer else _hip.ptr(dW), _hip.stream()))
+    if defer:
+        _DEFERRED.append((ws, need // (4 * c_out * c_in), c_out * c_in, dW))
     return dW
 
 
@@ -738,6 +776,11 @@ class _PointStack(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dg):
+        with deferred_wgrad_finals():                                       # (the weight gradients' second stages: one launch)
+            return _PointStack._backward(ctx, dg)
+
+    @staticmethod
+    def _backward(ctx, dg):
         a0, Ws, bns, zs, arg, N, shapes, zarg, biases, pkT = _take_saved(ctx)
         (g,) = ctx.saved_tensors
         grads = [None] * 16
@@ -754,7 +797,10 @@ class _PointStack(torch.autograd.Function):
             dz, dgam, dbet = bns[k].backward(zs[k], da=da, co=co)
             co = None
             src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a0, None)
-            dW = _conv1_wgrad(dz, src, Ws[k].shape[0]) if isinstance(src, _Rows) else _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
+            if isinstance(src, _Rows):
+                dW = _conv1_wgrad(dz, src, Ws[k].shape[0])
+            else:                                                       # (deferred only where grads[] takes dW as a view of itself)
+                dW = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act, later=shapes[4 * k][1] == Ws[k].shape[1])
             grads[4 * k] = dW[:, :shapes[4 * k][1]].reshape(shapes[4 * k])
             grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
@@ -883,6 +929,11 @@ class _InsSeg(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
+        with deferred_wgrad_finals() as later:                              # (the weight gradients' second stages: one launch)
+            return _InsSeg._backward(ctx, dlogits, later)
+
+    @staticmethod
+    def _backward(ctx, dlogits, later):
         a0, Ws, bns, zs, g, arg, a4, drop, W5, N, shapes, zarg, b_conv5, conv5_cache, pk = _take_saved(ctx)
         Mp = a0.shape[0]
         M = dlogits.shape[0] * dlogits.shape[1]
@@ -907,7 +958,7 @@ class _InsSeg(torch.autograd.Function):
             # one — the dgrad of this layer
             amax = amaxes[64 * (8 - k):64 * (9 - k)] if pk.get("arith") == "f16x3" and zs[k].shape[1] % 64 == 0 else None
             dz, dgam, dbet = bns[k].backward(zs[k], da=da, amax=amax, co=co)
-            grads[4 * k] = _wgrad(dz, zs[k - 1], Ws[k].shape[0], Ws[k].shape[1], bns[k - 1].act, amax=amax).reshape(shapes[4 * k])
+            grads[4 * k] = _wgrad(dz, zs[k - 1], Ws[k].shape[0], Ws[k].shape[1], bns[k - 1].act, amax=amax, later=True).reshape(shapes[4 * k])
             grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
             if isinstance(pk[f"t{k}"], _X3Image):
@@ -918,7 +969,7 @@ class _InsSeg(torch.autograd.Function):
         # dconv1: per-point part against out2, per-crop part against g
         dz, dgam, dbet, dgb = bns[5].backward(zs[5], da=da, sum_seg=N, co=co)   # dgb (B,512): dz summed over each crop's points
         Wd1 = Ws[5]
-        dWa = _wgrad(dz, zs[1], 512, 64, bns[1].act)
+        dWa = _wgrad(dz, zs[1], 512, 64, bns[1].act, later=True)
         if dgb is None:
             dgb = _segsum(dz, N, g.shape[0])
         dW1g = dgb.t() @ g
@@ -939,7 +990,10 @@ class _InsSeg(torch.autograd.Function):
             dz, dgam, dbet = bns[k].backward(zs[k], da=da, co=co)
             co = None
             src, act = (zs[k - 1], bns[k - 1].act) if k > 0 else (a0, None)
-            dW = _conv1_wgrad(dz, src, Ws[k].shape[0]) if isinstance(src, _Rows) else _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act)
+            if isinstance(src, _Rows):
+                dW = _conv1_wgrad(dz, src, Ws[k].shape[0])
+            else:                                                       # (deferred only where grads[] takes dW as a view of itself)
+                dW = _wgrad(dz, src, Ws[k].shape[0], Ws[k].shape[1], act, later=shapes[4 * k][1] == Ws[k].shape[1])
             grads[4 * k] = dW[:, :shapes[4 * k][1]].reshape(shapes[4 * k])
             grads[4 * k + 1] = zero[4 * k + 1]
             grads[4 * k + 2], grads[4 * k + 3] = dgam, dbet
@@ -948,6 +1002,7 @@ class _InsSeg(torch.autograd.Function):
                              accumulate=True, packed=pk["t2"])
             elif k > 0:                                                 # (with the sums of the layer below: conv3's and conv1's)
                 da, co = bns[k - 1].dgrad_with_sums(zs[k - 1], dz, Ws[k], Ws[k].shape[1], Ws[k].shape[0], pk[f"t{k}"])
+        later.flush()                                                   # (dWa is read now)
         grads[20] = torch.cat([dWa, dW1g], 1).reshape(shapes[20])
         return (None, None, None, *grads)
 

@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dal3_stream;               /* hipStream_t */
 
-#define DAL3_VERSION 131                 /* 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums; .1: dal3_tr_fc_* */
+#define DAL3_VERSION 131                 /* 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums; .1: dal3_tr_fc_*, dal3_tr_wgrad_final_many */
 
 enum {
     DAL3_OK = 0,
@@ -553,6 +553,16 @@ size_t dal3_tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in);
 int dal3_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_t lda, const float* scale, const float* shift,
                   int relu_in, int64_t M, int c_out, int c_in, void* workspace, size_t workspace_bytes, float* dW,
                   dal3_stream stream);
+/* dW == NULL in dal3_tr_wgrad / dal3_tr_wgrad_x3: only the per-slice partial sums are left in `workspace`
+ * (dal3_tr_wgrad*_workspace_bytes / (4 c_out c_in) slices of c_out * c_in floats, which the caller keeps), and
+ * dal3_tr_wgrad_final_many adds the slices of up to 24 such calls in ONE launch — the same fixed-order sums as the
+ * per-call second stage (nothing reads a weight gradient before the backward pass ends). */
+typedef struct dal3_tr_wgrad_part {
+    const float* part;                                   /* the call's workspace */
+    int64_t n_slices, n;                                 /* n = c_out * c_in */
+    float* dW;
+} dal3_tr_wgrad_part;
+int dal3_tr_wgrad_final_many(const dal3_tr_wgrad_part* items, int n, dal3_stream stream);
 int dal3_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float* scale, const float* shift, float* g,
                    int32_t* arg, int64_t n_seg, void* workspace /* n_seg*C*8 bytes, 8-byte aligned */,
                    size_t workspace_bytes, dal3_stream stream);
