@@ -1113,13 +1113,13 @@ extern "C" int dal3_tr_conv1_bn_stats(const float* x, int64_t M, int64_t Mp, int
 }
 
 extern "C" int dal3_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x, int64_t M, int c_in, int64_t ldx, int c_out,
-                                   void* workspace, size_t workspace_bytes, double* sums, dal3_stream stream) {
-    if (!dz || !x || !sums || M <= 0 || !conv1_shape_ok(c_in, c_out) || ldx < c_in || lddz < c_out || (lddz & 3) ||
+                                   void* workspace, size_t workspace_bytes, float* dW, dal3_stream stream) {
+    if (!dz || !x || !dW || M <= 0 || !conv1_shape_ok(c_in, c_out) || ldx < c_in || lddz < c_out || (lddz & 3) ||
         (reinterpret_cast<uintptr_t>(dz) & 15))
         return fail(DAL3_EINVAL, "tr_conv1_wgrad: bad argument (c_in <= 8, c_out 64 or 128, 16-byte aligned dz)");
     if (!workspace || workspace_bytes < tr_conv1_workspace_bytes(M, c_out))
         return fail(DAL3_EWORKSPACE, "tr_conv1_wgrad: workspace smaller than dal3_tr_conv1_workspace_bytes()");
-    HIP_TRY(launch_tr_conv1_wgrad(dz, lddz, x, M, c_in, ldx, c_out, static_cast<double*>(workspace), sums, static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_tr_conv1_wgrad(dz, lddz, x, M, c_in, ldx, c_out, static_cast<double*>(workspace), dW, static_cast<hipStream_t>(stream)));
     return 0;
 }
 
@@ -1447,14 +1447,14 @@ extern "C" size_t dal3_tr_head2_wgrad_workspace_bytes(int64_t M) { return M > 0 
 
 extern "C" int dal3_tr_head2_wgrad(const float* dlogits, const float* z, int64_t M, int C, int64_t ldz, const float* scale,
                                    const float* shift, int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step,
-                                   float p_drop, void* workspace, size_t workspace_bytes, double* sums, dal3_stream stream) {
-    if (!dlogits || !z || !sums || !head2_common_ok(M, C, mult, ldm, p_drop) || ldz < C || (ldz & 3) || (scale && !shift) ||
+                                   float p_drop, void* workspace, size_t workspace_bytes, float* dWb, dal3_stream stream) {
+    if (!dlogits || !z || !dWb || !head2_common_ok(M, C, mult, ldm, p_drop) || ldz < C || (ldz & 3) || (scale && !shift) ||
         (reinterpret_cast<uintptr_t>(z) & 15) || (reinterpret_cast<uintptr_t>(dlogits) & 7))
         return fail(DAL3_EINVAL, "tr_head2_wgrad: bad argument (C == 128, row strides multiples of 4, aligned pointers)");
     if (!workspace || workspace_bytes < tr_head2_wgrad_workspace_bytes(M))
         return fail(DAL3_EWORKSPACE, "tr_head2_wgrad: workspace smaller than dal3_tr_head2_wgrad_workspace_bytes()");
     HIP_TRY(launch_tr_head2_wgrad(dlogits, z, M, ldz, scale, shift, relu, mult, ldm, seed, step, p_drop,
-                                  static_cast<double*>(workspace), sums, static_cast<hipStream_t>(stream)));
+                                  static_cast<double*>(workspace), dWb, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

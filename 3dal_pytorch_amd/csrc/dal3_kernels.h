@@ -316,7 +316,7 @@ hipError_t launch_tr_head2_dgrad_bnbwd(const float* dl, int64_t M, const float* 
 size_t tr_head2_wgrad_workspace_bytes(int64_t M);
 hipError_t launch_tr_head2_wgrad(const float* dl, const float* z, int64_t M, int64_t ldz, const float* scale, const float* shift,
                                  int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop,
-                                 double* ws, double* sums, hipStream_t s);
+                                 double* ws, float* dWb, hipStream_t s);
 // the first layer of a stack (c_in <= 8) as VALU kernels (dal3_train.hip)
 hipError_t launch_tr_wgrad_final_many(const dal3_tr_wgrad_part* items, int n, hipStream_t s);
 // dal3_train_fc.hip
@@ -337,7 +337,7 @@ hipError_t launch_tr_conv1_bn_stats(const float* x, int64_t M, int64_t Mp, int c
                                     float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
                                     float* scale, float* shift, double* part, hipStream_t s);
 hipError_t launch_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x, int64_t M, int c_in, int64_t ldx, int c_out, double* part,
-                                 double* sums, hipStream_t s);
+                                 float* dW, hipStream_t s);
 hipError_t launch_tr_gather_at(const float* z, int64_t ldz, const int32_t* arg, int64_t seg, int n_seg, int C, float* out, hipStream_t s);
 hipError_t launch_tr_pool_zarg(const int32_t* arg, const float* a, int64_t lda, const float* W, int64_t ldw, const float* bias, int B,
                                int C, int K, int N, float* zarg, hipStream_t s);

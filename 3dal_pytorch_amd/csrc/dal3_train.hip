@@ -1552,6 +1552,23 @@ __global__ __launch_bounds__(256) void tr_colred_final_kernel(const double* __re
         if (EPI == 0) {
             out[c] = t0;
             out[C + c] = t1;
+        } else if (EPI == 3) {
+            // float32 results in the caller's layout (e.mu), e.M the layout code — round 4: the float64 sums of the narrow
+            // layers' weight gradients were converted, transposed and sliced by three stock launches per layer
+            float* o = e.mu;
+            const int mode = (int)(e.M & 0xff), kin = (int)((e.M >> 8) & 0xff), cuse = (int)(e.M >> 16);
+            if (mode == 1) {                                // conv1: column c holds entries i = 2c, 2c + 1 of dW[ch][k], i = ch * kin + k
+                const int i0 = 2 * c, i1 = 2 * c + 1;
+                if (i0 % kin < cuse) o[(i0 / kin) * cuse + i0 % kin] = (float)t0;
+                if (i1 % kin < cuse) o[(i1 / kin) * cuse + i1 % kin] = (float)t1;
+            } else {                                        // head2: dW[0][c], dW[1][c] for c < 128, then db[0], db[1]
+                if (c < 128) {
+                    o[c] = (float)t0;
+                    o[128 + c] = (float)t1;
+                } else {
+                    o[256 + (c - 128)] = (float)t0;
+                }
+            }
         } else if (EPI == 1) {
             const double mean = t0 / (double)e.M;
             double var = t1 / (double)e.M - mean * mean;
@@ -2513,12 +2530,14 @@ size_t tr_head2_wgrad_workspace_bytes(int64_t M) {
 // sums (2 * H2_COLS float64): [0, 128) = dW[0][.], 128 / 129 = db[0] / db[1], [130, 258) = dW[1][.] (258, 259 unused)
 hipError_t launch_tr_head2_wgrad(const float* dl, const float* z, int64_t M, int64_t ldz, const float* scale, const float* shift,
                                  int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop,
-                                 double* ws, double* sums, hipStream_t s) {
+                                 double* ws, float* dWb, hipStream_t s) {
     const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
     hipLaunchKernelGGL(tr_head2_wgrad_kernel, dim3(nb), dim3(256), 0, s, dl, z, M, ldz, scale, shift, relu, drop_key(mult, ldm, p_drop),
                        seed, step, ws);
-    hipLaunchKernelGGL(tr_colred_final_kernel<0>, dim3((H2_COLS + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, ws, nb, H2_COLS, sums,
-                       BnEpi{});
+    BnEpi e{};
+    e.M = 2;                                                // layout code: head2
+    e.mu = dWb;
+    hipLaunchKernelGGL(tr_colred_final_kernel<3>, dim3((H2_COLS + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, ws, nb, H2_COLS, nullptr, e);
     return hipGetLastError();
 }
 
@@ -2639,9 +2658,9 @@ hipError_t launch_tr_conv1_bn_stats(const float* x, int64_t M, int64_t Mp, int c
     hipLaunchKernelGGL(tr_colred_final_kernel<1>, dim3((c_out + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, nb, c_out, nullptr, e);
     return hipGetLastError();
 }
-// sums: 2 * C' float64 with C' = c_out * KIN / 2 (KIN = 4 for c_in <= 4, else 8): dW[c][k] = sums[(i % 2) * C' + i / 2], i = c * KIN + k
+// dW (c_out, c_in) float32, from 2 * C' float64 column sums with C' = c_out * KIN / 2 (KIN = 4 for c_in <= 4, else 8): entry i = c * KIN + k is sum (i % 2) of column i / 2
 hipError_t launch_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x, int64_t M, int c_in, int64_t ldx, int c_out, double* part,
-                                 double* sums, hipStream_t s) {
+                                 float* dW, hipStream_t s) {
     const int nb = (int)((M + TR_RED_ROWS - 1) / TR_RED_ROWS);
     const int kin = c_in <= 4 ? 4 : 8, co4 = c_out / 4;
     const size_t lds = (size_t)(256 / co4) * c_out * kin * sizeof(double);
@@ -2658,7 +2677,10 @@ hipError_t launch_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x, 
         e = c_out == 64 ? go(tr_conv1_wgrad_kernel<8, 16>) : go(tr_conv1_wgrad_kernel<8, 32>);
     if (e != hipSuccess) return e;
     const int Cp = c_out * kin / 2;
-    hipLaunchKernelGGL(tr_colred_final_kernel<0>, dim3((Cp + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, nb, Cp, sums, BnEpi{});
+    BnEpi ep{};
+    ep.M = 1 | ((int64_t)kin << 8) | ((int64_t)c_in << 16);  // layout code: conv1, kin columns computed per channel, c_in kept
+    ep.mu = dW;
+    hipLaunchKernelGGL(tr_colred_final_kernel<3>, dim3((Cp + TR_FIN_CH - 1) / TR_FIN_CH), dim3(256), 0, s, part, nb, Cp, nullptr, ep);
     return hipGetLastError();
 }
 

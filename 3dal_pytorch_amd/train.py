@@ -512,14 +512,13 @@ def _head2_backward(dl, z, act, drop, W, M, bn=None):
         da[M:].zero_()
     need = lib.dal3_tr_head2_wgrad_workspace_bytes(M)
     ws = _ws(need, z.device)
-    sums = torch.empty(260, dtype=torch.float64, device=z.device)
+    f = torch.empty(258, dtype=torch.float32, device=z.device)                 # dW (2, 128), then db (2): views of one buffer
     _note("head2", M, 128, 2, 0.0, 4.0 * M * 130)
     _hip.check(lib.dal3_tr_head2_wgrad(_hip.ptr(dl), _hip.ptr(z), M, C, z.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu), _hip.ptr(mult),
-                                       ldm, seed, _hip.ptr(step), p, _hip.ptr(ws), need, _hip.ptr(sums), _hip.stream()))
-    f = sums.float()
+                                       ldm, seed, _hip.ptr(step), p, _hip.ptr(ws), need, _hip.ptr(f), _hip.stream()))
     if bn is not None:
-        return da, torch.stack([f[:128], f[130:258]]), f[128:130], co
-    return da, torch.stack([f[:128], f[130:258]]), f[128:130]
+        return da, f[:256].view(2, 128), f[256:258], co
+    return da, f[:256].view(2, 128), f[256:258]
 
 
 def _gather_at(z, arg, seg):
@@ -592,15 +591,13 @@ def _conv1_bn(rows, W, b, gamma, beta, stats):
 def _conv1_wgrad(dz, rows, c_out):
     """dW (c_out, c_in) = dz^T x over the M real rows (dal3_tr_conv1_wgrad)"""
     lib = _hip.lib()
-    kin = 4 if rows.C <= 4 else 8
-    Cp = c_out * kin // 2
     need = lib.dal3_tr_conv1_workspace_bytes(rows.M, c_out)
     ws = _ws(need, rows.device)
-    sums = torch.empty(2 * Cp, dtype=torch.float64, device=rows.device)
+    dW = torch.empty((c_out, rows.C), dtype=torch.float32, device=rows.device)
     _note("conv1", rows.M, rows.C, c_out, 2.0 * rows.M * rows.C * c_out, 4.0 * rows.M * (rows.C + c_out))
     _hip.check(lib.dal3_tr_conv1_wgrad(_hip.ptr(dz), dz.stride(0), _hip.ptr(rows.x), rows.M, rows.C, rows.x.stride(0), c_out,
-                                       _hip.ptr(ws), need, _hip.ptr(sums), _hip.stream()))
-    return sums.view(2, Cp).t().reshape(c_out, kin)[:, :rows.C].float()          # entry i = c * kin + k sits at [i % 2][i // 2]
+                                       _hip.ptr(ws), need, _hip.ptr(dW), _hip.stream()))
+    return dW
 
 
 def supported(pts):
@@ -728,7 +725,8 @@ def _pooled_layer_backward(z_prev, bn_prev, W, b, bn, zarg, g, arg, dg, N, cache
     else:
         S64 = S.double() + (m1[:, None] * m1[None, :] / M if centred else 0.0)
         dW = (A[:, None] * m1[None] + Bc[:, None] * (W64 @ S64 + b64[:, None] * m1[None]) + dWs.double()).float()
-    return da, dW, dgamma.float(), dbeta.float()
+    dgb = coef[:2].float()                                                  # (dbeta, dgamma) in one conversion
+    return da, dW, dgb[1], dgb[0]
 
 
 class _PointStack(torch.autograd.Function):

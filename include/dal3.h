@@ -443,8 +443,7 @@ int dal3_tr_pool_coef(const float* dg, const float* g, const float* zarg, const 
  * (x: M rows of c_in floats, row stride ldx — no zero-padded copy):
  *   dal3_tr_conv1_bn_stats  z[p][c] = bias[c] + sum_k W[c][k] x[p][k] for the Mp >= M rows of z (rows >= M get x = 0), and
  *                           dal3_tr_bn_stats over the M real rows in the same pass;
- *   dal3_tr_conv1_wgrad     sums (2 C' float64, C' = c_out * KIN / 2, KIN = 4 for c_in <= 4 else 8):
- *                           dW[c][k] = sum_{p < M} dz[p][c] x[p][k] = sums[(i % 2) * C' + i / 2] with i = c * KIN + k.
+ *   dal3_tr_conv1_wgrad     dW (c_out, c_in) float32, row-major: dW[c][k] = sum_{p < M} dz[p][c] x[p][k].
  * workspace: dal3_tr_conv1_workspace_bytes(rows, c_out). Float64 partial sums per 256 rows, added in a fixed order. */
 size_t dal3_tr_conv1_workspace_bytes(int64_t Mp, int c_out);
 int dal3_tr_conv1_bn_stats(const float* x, int64_t M, int64_t Mp, int c_in, int64_t ldx, const float* W, int64_t ldw,
@@ -452,7 +451,7 @@ int dal3_tr_conv1_bn_stats(const float* x, int64_t M, int64_t Mp, int c_in, int6
                            float* running_mean, float* running_var, float momentum, float eps, float* mu, float* rstd,
                            float* scale, float* shift, void* workspace, size_t workspace_bytes, dal3_stream stream);
 int dal3_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x, int64_t M, int c_in, int64_t ldx, int c_out, void* workspace,
-                        size_t workspace_bytes, double* sums, dal3_stream stream);
+                        size_t workspace_bytes, float* dW, dal3_stream stream);
 /* The per-item FC tails in train mode (static_model.py:336-338, dynamic_model.py:247-248, :284-285, :306-311;
  * `_PointHead.tail` with self.training): Linear -> BatchNorm1d over the B ITEMS -> ReLU with rows = items,
  * 2 <= B <= dal3_tr_fc_max_rows(). One launch per layer forward, two backward; no padding, no packed weight image; every
@@ -578,9 +577,9 @@ int dal3_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float*
  * dal3_tr_act_dropout draws it (same mult / seed / step / p_drop arguments). C must be 128.
  *   dal3_tr_head2_forward  logits[p][j] = bias[j] + sum_c W[j][c] * m[p][c] * act(z[p][c])       (W: 2 rows of C, row stride ldw)
  *   dal3_tr_head2_dgrad    da[p][c] = m[p][c] * (dlogits[p][0] W[0][c] + dlogits[p][1] W[1][c])  (d / d act(z): Dropout undone)
- *   dal3_tr_head2_wgrad    sums (260 float64): [0,128) = dW[0][.], [128] = db[0], [129] = db[1], [130,258) = dW[1][.]
+ *   dal3_tr_head2_wgrad    dWb (258 floats): dW (2, 128) row-major, then db[0], db[1]
  *                          with dW[j][c] = sum_p dlogits[p][j] * m[p][c] * act(z[p][c]), db[j] = sum_p dlogits[p][j];
- *                          float64 partial sums per 256 rows added in a fixed order.
+ *                          float64 partial sums per 256 rows added in a fixed order, rounded to float32 at the end.
  *                          workspace: dal3_tr_head2_wgrad_workspace_bytes(M). */
 int dal3_tr_head2_forward(const float* z, int64_t M, int C, int64_t ldz, const float* scale, const float* shift, int relu,
                           const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, const float* W,
@@ -598,7 +597,7 @@ int dal3_tr_head2_dgrad_bnbwd(const float* dlogits, int64_t M, int C, const floa
 size_t dal3_tr_head2_wgrad_workspace_bytes(int64_t M);
 int dal3_tr_head2_wgrad(const float* dlogits, const float* z, int64_t M, int C, int64_t ldz, const float* scale, const float* shift,
                         int relu, const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, void* workspace,
-                        size_t workspace_bytes, double* sums, dal3_stream stream);
+                        size_t workspace_bytes, float* dWb, dal3_stream stream);
 int dal3_tr_act_dropout(const float* x, int64_t M, int C, int64_t ldx, const float* scale, const float* shift, int relu,
                         const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, float* out,
                         int64_t ldo, dal3_stream stream);
