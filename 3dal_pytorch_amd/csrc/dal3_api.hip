@@ -1123,6 +1123,28 @@ extern "C" int dal3_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x
     return 0;
 }
 
+extern "C" int dal3_parse_box_pred(const float* box_pred, int64_t ldb, int64_t B, float* center, float* heading_scores,
+                                   float* heading_residuals_normalized, float* heading_residuals, float* size_scores,
+                                   float* size_residuals_normalized, float* size_residuals, dal3_stream stream) {
+    if (!box_pred || !center || !heading_scores || !heading_residuals_normalized || !heading_residuals || !size_scores ||
+        !size_residuals_normalized || !size_residuals || B <= 0 || B > (1 << 24) || ldb < 39)
+        return fail(DAL3_EINVAL, "parse_box_pred: bad argument (seven outputs, ldb >= 39)");
+    HIP_TRY(launch_parse_box_pred(box_pred, ldb, (int)B, center, heading_scores, heading_residuals_normalized, heading_residuals,
+                                  size_scores, size_residuals_normalized, size_residuals, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_parse_box_pred_backward(const float* g_center, const float* g_heading_scores,
+                                            const float* g_heading_residuals_normalized, const float* g_heading_residuals,
+                                            const float* g_size_scores, const float* g_size_residuals_normalized,
+                                            const float* g_size_residuals, int64_t B, float* g_box_pred, dal3_stream stream) {
+    if (!g_box_pred || B <= 0 || B > (1 << 24)) return fail(DAL3_EINVAL, "parse_box_pred_backward: bad argument");
+    HIP_TRY(launch_parse_box_pred_backward(g_center, g_heading_scores, g_heading_residuals_normalized, g_heading_residuals, g_size_scores,
+                                           g_size_residuals_normalized, g_size_residuals, (int)B, g_box_pred,
+                                           static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int dal3_tr_fc_max_rows(void) { return tr_fc_max_rows(); }
 
 extern "C" int dal3_tr_fc_forward(const float* a, int64_t B, int c_in, int64_t lda, const float* in_scale, const float* in_shift,

@@ -319,6 +319,10 @@ hipError_t launch_tr_head2_wgrad(const float* dl, const float* z, int64_t M, int
                                  double* ws, float* dWb, hipStream_t s);
 // the first layer of a stack (c_in <= 8) as VALU kernels (dal3_train.hip)
 hipError_t launch_tr_wgrad_final_many(const dal3_tr_wgrad_part* items, int n, hipStream_t s);
+hipError_t launch_parse_box_pred(const float* bp, int64_t ldb, int B, float* c, float* hs, float* hrn, float* hr, float* ss, float* srn,
+                                 float* sr, hipStream_t s);
+hipError_t launch_parse_box_pred_backward(const float* gc, const float* ghs, const float* ghrn, const float* ghr, const float* gss,
+                                          const float* gsrn, const float* gsr, int B, float* g, hipStream_t s);
 // dal3_train_fc.hip
 int tr_fc_max_rows();
 int tr_fc_max_act_cin();

@@ -844,3 +844,66 @@ hipError_t launch_recenter(const float* obj_pts, int B, int M, const float* init
                        init_box7, box_one7, bbox_gt7, obj_pts_two, hcl, hrl);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------- parse_output_to_tensors
+// tools/static_model.py:64-92 (dynamic_model.py: the same slices): the (B, 39) output of a box estimator cut into centre (3),
+// heading scores (12), normalised heading residuals (12), size scores (3), normalised size residuals (3 x 3), plus the two
+// scaled copies heading_residuals = hrn * (pi / 12) and size_residuals = srn * MEAN_SIZE — seven tensors from one launch
+// (train mode, where they have to be tensors of their own: five strided copies and two multiplications before), and their
+// gradients put back side by side by one launch (a concatenation, two multiplications and two additions before).
+__global__ void parse_box_pred_kernel(const float* __restrict__ bp, int64_t ldb, int B, float* __restrict__ c, float* __restrict__ hs,
+                                      float* __restrict__ hrn, float* __restrict__ hr, float* __restrict__ ss,
+                                      float* __restrict__ srn, float* __restrict__ sr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 39) return;
+    const int b = i / 39, k = i % 39;
+    const float v = bp[(int64_t)b * ldb + k];
+    if (k < 3) {
+        c[b * 3 + k] = v;
+    } else if (k < 15) {
+        hs[b * 12 + k - 3] = v;
+    } else if (k < 27) {
+        hrn[b * 12 + k - 15] = v;
+        hr[b * 12 + k - 15] = v * (float)(3.14159265358979323846 / 12.0);
+    } else if (k < 30) {
+        ss[b * 3 + k - 27] = v;
+    } else {
+        srn[b * 9 + k - 30] = v;
+        sr[b * 9 + k - 30] = v * c_mean_size[k - 30];
+    }
+}
+// any of the seven gradients may be NULL (= zeros)
+__global__ void parse_box_pred_bwd_kernel(const float* __restrict__ gc, const float* __restrict__ ghs, const float* __restrict__ ghrn,
+                                          const float* __restrict__ ghr, const float* __restrict__ gss,
+                                          const float* __restrict__ gsrn, const float* __restrict__ gsr, int B,
+                                          float* __restrict__ g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 39) return;
+    const int b = i / 39, k = i % 39;
+    float v = 0.0f;
+    if (k < 3) {
+        v = gc ? gc[b * 3 + k] : 0.0f;
+    } else if (k < 15) {
+        v = ghs ? ghs[b * 12 + k - 3] : 0.0f;
+    } else if (k < 27) {
+        const float t = ghr ? __fmul_rn(ghr[b * 12 + k - 15], (float)(3.14159265358979323846 / 12.0)) : 0.0f;
+        v = ghrn ? (ghr ? __fadd_rn(ghrn[b * 12 + k - 15], t) : ghrn[b * 12 + k - 15]) : t;
+    } else if (k < 30) {
+        v = gss ? gss[b * 3 + k - 27] : 0.0f;
+    } else {
+        const float t = gsr ? __fmul_rn(gsr[b * 9 + k - 30], c_mean_size[k - 30]) : 0.0f;
+        v = gsrn ? (gsr ? __fadd_rn(gsrn[b * 9 + k - 30], t) : gsrn[b * 9 + k - 30]) : t;
+    }
+    g[i] = v;
+}
+hipError_t launch_parse_box_pred(const float* bp, int64_t ldb, int B, float* c, float* hs, float* hrn, float* hr, float* ss, float* srn,
+                                 float* sr, hipStream_t s) {
+    hipLaunchKernelGGL(parse_box_pred_kernel, dim3((unsigned)((B * 39 + 255) / 256)), dim3(256), 0, s, bp, ldb, B, c, hs, hrn, hr, ss, srn, sr);
+    return hipGetLastError();
+}
+hipError_t launch_parse_box_pred_backward(const float* gc, const float* ghs, const float* ghrn, const float* ghr, const float* gss,
+                                          const float* gsrn, const float* gsr, int B, float* g, hipStream_t s) {
+    hipLaunchKernelGGL(parse_box_pred_bwd_kernel, dim3((unsigned)((B * 39 + 255) / 256)), dim3(256), 0, s, gc, ghs, ghrn, ghr, gss, gsrn, gsr,
+                       B, g);
+    return hipGetLastError();
+}

@@ -258,20 +258,34 @@ class _ParseBoxPred(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, box_pred, mean):
-        B = box_pred.shape[0]
-        srn = box_pred[:, 30:39].contiguous().view(B, 3, 3)
+        B, dev = box_pred.shape[0], box_pred.device
+        ctx.meta = (B, box_pred.dtype, dev)
+        if box_pred.is_cuda and box_pred.dtype == torch.float32 and box_pred.stride(1) == 1:
+            # one launch (dal3_parse_box_pred) for the seven tensors. Copies, not views: an output of a custom Function that
+            # is a VIEW of its input makes autograd rebase the view on the Function's node (and aborted the process in a
+            # later backward on this build)
+            outs = [torch.empty(s_, dtype=torch.float32, device=dev)
+                    for s_ in ((B, 3), (B, 12), (B, 12), (B, 12), (B, 3), (B, 3, 3), (B, 3, 3))]
+            _hip.check(_hip.lib().dal3_parse_box_pred(_hip.ptr(box_pred), box_pred.stride(0), B, *[_hip.ptr(t) for t in outs],
+                                                      _hip.stream()))
+            ctx.hip = True
+            return tuple(outs)
+        ctx.hip = False
         ctx.save_for_backward(mean)
-        ctx.meta = (B, box_pred.dtype, box_pred.device)
-        # copies, not views: an output of a custom Function that is a VIEW of its input makes autograd rebase the view on
-        # the Function's node (and aborted the process in a later backward on this build); four small copies forward
-        # against sixteen launches backward
+        srn = box_pred[:, 30:39].contiguous().view(B, 3, 3)
         c, hs, hrn, ss = (t.contiguous() for t in torch.split(box_pred, [3, 12, 12, 3, 9], 1)[:4])
         return (c, hs, hrn, hrn * (np.pi / NUM_HEADING_BIN), ss, srn, srn * mean[None])
 
     @staticmethod
     def backward(ctx, gc, ghs, ghrn, ghr, gss, gsrn, gsr):
-        (mean,) = ctx.saved_tensors
         B, dtype, dev = ctx.meta
+        if ctx.hip:
+            gs = [None if t is None else (t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float())
+                  for t in (gc, ghs, ghrn, ghr, gss, gsrn, gsr)]
+            g = torch.empty((B, 39), dtype=torch.float32, device=dev)
+            _hip.check(_hip.lib().dal3_parse_box_pred_backward(*[_hip.ptr(t) for t in gs], B, _hip.ptr(g), _hip.stream()))
+            return g, None
+        (mean,) = ctx.saved_tensors
 
         def z(n):
             return torch.zeros((B, n), dtype=dtype, device=dev)

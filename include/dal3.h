@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dal3_stream;               /* hipStream_t */
 
-#define DAL3_VERSION 131                 /* 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums; .1: dal3_tr_fc_*, dal3_tr_wgrad_final_many */
+#define DAL3_VERSION 131                 /* 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums; .1: dal3_tr_fc_*, dal3_tr_wgrad_final_many, dal3_parse_box_pred* */
 
 enum {
     DAL3_OK = 0,
@@ -452,6 +452,18 @@ int dal3_tr_conv1_bn_stats(const float* x, int64_t M, int64_t Mp, int c_in, int6
                            float* scale, float* shift, void* workspace, size_t workspace_bytes, dal3_stream stream);
 int dal3_tr_conv1_wgrad(const float* dz, int64_t lddz, const float* x, int64_t M, int c_in, int64_t ldx, int c_out, void* workspace,
                         size_t workspace_bytes, float* dW, dal3_stream stream);
+/* parse_output_to_tensors (tools/static_model.py:64-92) in train mode, where its seven results must be tensors of their own:
+ * the (B, 39) box_pred -> center (B,3), heading_scores (B,12), heading_residuals_normalized (B,12), heading_residuals =
+ * normalized * (pi / 12), size_scores (B,3), size_residuals_normalized (B,3,3), size_residuals = normalized * MEAN_SIZE, all
+ * contiguous, in one launch; _backward puts their gradients (any of them NULL = zeros) back side by side as the (B, 39)
+ * gradient of box_pred: scaled gradients multiplied, then added to the normalized ones, as autograd would. */
+int dal3_parse_box_pred(const float* box_pred, int64_t ldb, int64_t B, float* center, float* heading_scores,
+                        float* heading_residuals_normalized, float* heading_residuals, float* size_scores,
+                        float* size_residuals_normalized, float* size_residuals, dal3_stream stream);
+int dal3_parse_box_pred_backward(const float* g_center, const float* g_heading_scores, const float* g_heading_residuals_normalized,
+                                 const float* g_heading_residuals, const float* g_size_scores,
+                                 const float* g_size_residuals_normalized, const float* g_size_residuals, int64_t B,
+                                 float* g_box_pred, dal3_stream stream);
 /* The per-item FC tails in train mode (static_model.py:336-338, dynamic_model.py:247-248, :284-285, :306-311;
  * `_PointHead.tail` with self.training): Linear -> BatchNorm1d over the B ITEMS -> ReLU with rows = items,
  * 2 <= B <= dal3_tr_fc_max_rows(). One launch per layer forward, two backward; no padding, no packed weight image; every

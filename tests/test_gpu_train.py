@@ -799,3 +799,26 @@ def test_a_training_step_leaves_no_buffers_behind_without_the_garbage_collector(
     finally:
         gc.enable()
 
+
+
+@pytest.mark.parametrize("B,some_missing", [(64, False), (5, True), (300, False)])
+def test_parse_output_to_tensors_in_one_launch_equals_the_slices(B, some_missing):
+    """static_model._parse in train mode (dal3_parse_box_pred / _backward, tools/static_model.py:64-92): the seven tensors
+    bit for bit what slicing and scaling box_pred gives, contiguous; the gradient of box_pred bit for bit autograd's, also
+    when some of the seven take no part in the loss (NULL gradients)"""
+    sm = importlib.import_module("3dal_pytorch_amd.static_model")
+    gen = torch.Generator(device="cuda").manual_seed(B)
+    bp = torch.randn((B, 39), device="cuda", generator=gen)
+    x = bp.clone().requires_grad_(True)
+    y = bp.clone().requires_grad_(True)
+    got = sm._parse(x)
+    mean = sm._mean_size(bp.device)
+    srn = y[:, 30:39].reshape(B, 3, 3)
+    want = (y[:, 0:3], y[:, 3:15], y[:, 15:27], y[:, 15:27] * (np.pi / sm.NUM_HEADING_BIN), y[:, 27:30], srn, srn * mean[None])
+    w = [torch.randn(t.shape, device="cuda", generator=gen) for t in want]
+    use = [0, 3, 6] if some_missing else range(7)
+    for i in range(7):
+        assert got[i].is_contiguous() and torch.equal(got[i].detach(), want[i].detach()), i
+    sum((got[i] * w[i]).sum() for i in use).backward()
+    sum((want[i] * w[i]).sum() for i in use).backward()
+    assert torch.equal(x.grad, y.grad)
