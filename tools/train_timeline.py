@@ -12,11 +12,11 @@ from collections import defaultdict
 
 FAMILIES = [("gemm: linear", r"tr_linear_(pers|ring|x3)|tr_linear_kernel"), ("gemm: pooled conv5", r"tr_linear_pool"),
             ("gemm: wgrad", r"tr_wgrad_(kernel|x3)"), ("wgrad second stage", r"tr_wgrad_final"),
-            ("narrow layers (conv1, dconv5) on VALU", r"tr_head2_|tr_conv1_"),
+            ("narrow layers (conv1, dconv5) on VALU", r"tr_head2_|tr_conv1_"), ("fc tails (rows = items)", r"tr_fc_"),
             ("bn: forward statistics", r"tr_colred_kernel<0|tr_stats"), ("bn: backward sums", r"tr_colred_kernel<1"),
             ("bn: reduction second stages", r"tr_colred_final|tr_blocksum_final|tr_segsum_final"),
             ("bn: backward apply", r"tr_bnbwd_apply"), ("dropout / activation", r"tr_act|tr_colred_kernel<2"),
-            ("pooled layer glue", r"tr_pool_|tr_segmax"), ("criterion", r"tr_seg_ce|tr_box_loss"),
+            ("pooled layer glue", r"tr_pool_|tr_segmax"), ("criterion, parse_output_to_tensors", r"tr_seg_ce|tr_box_loss|parse_box_pred"),
             ("packing", r"tr_pack"), ("sampler", r"compact_sample|mask_"),
             ("torch: optimizer", r"multi_tensor_apply|fused_adam|FusedAdam"), ("torch: fill", r"FillFunctor"),
             ("torch: copy", r"direct_copy|copyBuffer"), ("torch: other", r"at::native|Cijk_|rocblas")]
