@@ -18,6 +18,7 @@ torch autograd over the stock-torch composite (`PointNetInstanceSeg.forward`, `_
 tests/test_host_cpu.py ties to the oracle.
 """
 import os
+import threading
 
 import torch
 
@@ -198,33 +199,36 @@ def _colred(z, mode, da=None, dg=None, arg=None, seg=0, bn=None, rows=None):
     return out
 
 
-_DEFERRED = None        # inside deferred_wgrad_finals(): the (partial sums, slices, elements, dW) of the weight gradients so far
+_TLS = threading.local()    # .deferred: inside deferred_wgrad_finals(), the (partial sums, slices, elements, dW) of the weight
+#                             gradients so far — per thread (autograd runs a device's backward functions on its own thread)
+
+
+def _deferred():
+    return getattr(_TLS, "deferred", None)
 
 
 class deferred_wgrad_finals:
-    """`with deferred_wgrad_finals() as d:` — every _wgrad inside leaves its per-slice partial sums in a buffer of its own and
-    returns a dW that is filled when the block ends (or at d.flush(), which must precede any stock op that reads one of
-    them): ONE second-stage launch for up to 24 weight gradients instead of one behind each (dal3_tr_wgrad_final_many)."""
+    """`with deferred_wgrad_finals() as d:` — every _wgrad(later=True) inside leaves its per-slice partial sums in a buffer of its
+    own and returns a dW that is filled when the block ends (or at d.flush(), which must precede any stock op that reads one
+    of them): ONE second-stage launch for up to 24 weight gradients instead of one behind each (dal3_tr_wgrad_final_many)."""
 
     def __enter__(self):
-        global _DEFERRED
-        self.outer, _DEFERRED = _DEFERRED, []
+        self.outer, _TLS.deferred = _deferred(), []
         return self
 
     def flush(self):
-        items = _DEFERRED
+        items = _deferred()
         while items:
             chunk, items[:] = items[:24], items[24:]
             arr = (_hip.WgradPart * len(chunk))(*[_hip.WgradPart(_hip.ptr(p), ns, n, _hip.ptr(dW)) for p, ns, n, dW in chunk])
             _hip.check(_hip.lib().dal3_tr_wgrad_final_many(arr, len(chunk), _hip.stream()))
 
     def __exit__(self, exc_type, exc, tb):
-        global _DEFERRED
         try:
             if exc_type is None:
                 self.flush()
         finally:
-            _DEFERRED = self.outer
+            _TLS.deferred = self.outer
         return False
 
 
@@ -238,7 +242,7 @@ def _wgrad(dz, a, c_out, c_in, act=None, amax=None, later=False):
         need = lib.dal3_tr_wgrad_x3_workspace_bytes(M, c_out, c_in)
         if need:
             _note("wgrad_x3", M, c_in, c_out, 2.0 * M * c_in * c_out, 4.0 * M * (c_in + c_out))
-            defer = later and _DEFERRED is not None
+            defer = later and _deferred() is not None
             ws = torch.empty(need, dtype=torch.uint8, device=dz.device) if defer else _ws(need, dz.device)
             dW = torch.empty((c_out, c_in), dtype=torch.float32, device=dz.device)
             sc, sh, relu = (act if act is not None else (None, None, False))
@@ -246,18 +250,18 @@ def _wgrad(dz, a, c_out, c_in, act=None, amax=None, later=False):
                                             int(relu), _hip.ptr(amax), M, c_out, c_in, _hip.ptr(ws), need,
                                             None if defer else _hip.ptr(dW), _hip.stream()))
             if defer:
-                _DEFERRED.append((ws, need // (4 * c_out * c_in), c_out * c_in, dW))
+                _deferred().append((ws, need // (4 * c_out * c_in), c_out * c_in, dW))
             return dW
     _note("wgrad", M, c_in, c_out, 2.0 * M * c_in * c_out, 4.0 * M * (c_in + c_out))
     need = lib.dal3_tr_wgrad_workspace_bytes(M, c_out, c_in)
-    defer = later and _DEFERRED is not None
+    defer = later and _deferred() is not None
     ws = torch.empty(need, dtype=torch.uint8, device=dz.device) if defer else _ws(need, dz.device)
     dW = torch.empty((c_out, c_in), dtype=torch.float32, device=dz.device)
     sc, sh, relu = (act if act is not None else (None, None, False))
     _hip.check(lib.dal3_tr_wgrad(_hip.ptr(dz), dz.stride(0), _hip.ptr(a), a.stride(0), _hip.ptr(sc), _hip.ptr(sh), int(relu),
                                  M, c_out, c_in, _hip.ptr(ws), need, None if defer else _hip.ptr(dW), _hip.stream()))
     if defer:
-        _DEFERRED.append((ws, need // (4 * c_out * c_in), c_out * c_in, dW))
+        _deferred().append((ws, need // (4 * c_out * c_in), c_out * c_in, dW))
     return dW
 
 
