@@ -1144,7 +1144,7 @@ hipError_t launch_tr_linear_pool(const float* a, int64_t M, int c_in, int64_t ld
 #define TR_POOL_RES 1                   // 0: the 128-channel case through the per-block kernels too (A/B builds)
 #endif
     if (TR_POOL_RES && c_in == 128 && M % 64 == 0 && seg % 64 == 0 && c_out % 64 == 0 && c_out <= TR_POOL_RES_MAX_COUT &&
-        M / 64 >= 1024 && M / 64 < (int64_t)1 << 31) {
+        M / 64 >= 1024 && M < (int64_t)1 << 31) {            // (point indices are taken as 32-bit values inside)
         const uint32_t n_groups = (uint32_t)(M / 64), gpw = (n_groups + 1023u) / 1024u;
         hipLaunchKernelGGL(tr_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, 0, c_out, c_in, 1, ws);
         hipLaunchKernelGGL(tr_linear_pool_res_kernel, dim3((n_groups + 4u * gpw - 1u) / (4u * gpw)), dim3(256), 0, s, a, M, lda, scale, shift,
