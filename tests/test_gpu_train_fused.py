@@ -216,3 +216,31 @@ def test_first_layer_as_valu_kernels(B, N, c_in, c_out):
     dz = torch.randn((Mp, c_out), device="cuda", generator=gen) * 1e-3
     dW = train._conv1_wgrad(dz, rows, c_out)
     assert dW.shape == (c_out, c_in) and _close(dW, dz[:M].double().t() @ x64, 2e-6)
+
+
+def test_deferred_second_stages_of_the_weight_gradients_give_the_same_bits():
+    """train.deferred_wgrad_finals (dal3_tr_wgrad_final_many, round 4): the weight gradients of a backward function leave
+    their per-slice partial sums behind and ONE launch adds them — the bits of the per-call second stage, for the fp32 and
+    the f16x3 kernels, more items than one launch takes (24), and a dW is untouched until the flush"""
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    M = 16 * 4096
+    shapes = [(64, 64), (128, 64), (256, 128), (512, 256), (64, 512)] * 6          # 30 items: two launches
+    dzs = [torch.randn((M, co), device="cuda", generator=gen) * 1e-3 for co, _ in shapes[:5]]
+    acts = [torch.randn((M, ci), device="cuda", generator=gen) for _, ci in shapes[:5]]
+    sc = [torch.rand(ci, device="cuda", generator=gen) + 0.5 for _, ci in shapes[:5]]
+    sh = [torch.randn(ci, device="cuda", generator=gen) * 0.1 for _, ci in shapes[:5]]
+    want = [train._wgrad(dzs[i % 5], acts[i % 5], co, ci, (sc[i % 5], sh[i % 5], True)) for i, (co, ci) in enumerate(shapes)]
+    with train.deferred_wgrad_finals() as later:
+        got = [train._wgrad(dzs[i % 5], acts[i % 5], co, ci, (sc[i % 5], sh[i % 5], True), later=True) for i, (co, ci) in enumerate(shapes)]
+        now = train._wgrad(dzs[0], acts[0], 64, 64, (sc[0], sh[0], True))       # (not marked: complete when it returns)
+        assert torch.equal(now, want[0])
+        later.flush()
+        assert all(torch.equal(g, w) for g, w in zip(got, want))
+    # the f16x3 wgrad takes the same route (amax: the bits of max |dz| in 64 words)
+    amax = torch.zeros(64, dtype=torch.int32, device="cuda")
+    amax[0] = int(dzs[3].abs().max().view(torch.int32))
+    w3 = train._wgrad(dzs[3], acts[3], 512, 256, (sc[3], sh[3], True), amax=amax)
+    with train.deferred_wgrad_finals():
+        g3 = train._wgrad(dzs[3], acts[3], 512, 256, (sc[3], sh[3], True), amax=amax, later=True)
+    assert torch.equal(g3, w3)
+    assert train._deferred() is None
