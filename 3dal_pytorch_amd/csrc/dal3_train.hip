@@ -1969,19 +1969,30 @@ __device__ __forceinline__ void wg_compute(WgBlock<MT, KT>& bk, f32x16 (&acc)[MT
 // one is consumed. The big layers run <4, 2, 2> (128 accumulator registers, 96 of operands); layers with at most 64
 // output channels would leave most of that idle and are bound by the latency of their loads instead (one 16-point block
 // in flight per wave: 93 us for 134 MB), so they run <2, 2, 4>: three blocks in flight in the same registers (55 us).
-template <int MT, int KT, int NB, bool FULL = false>
+#ifndef WG_COMBINE
+#define WG_COMBINE 1                    // 0: one partial sum per wave for every layer (A/B builds)
+#endif
+// COMB: the four waves of a workgroup take four consecutive slices of ONE tile block and add their tiles through LDS before
+// anything is written (see below). Not for the 4 x 4-tile variant: its waves then stop sharing operand rows in L1 and its
+// 256 accumulator registers spill around the exchange (A/B, both orders: 512 x 256 +2–3 %, the small layers −5…−10 %).
+template <int MT, int KT, int NB, bool FULL = false, bool COMB = false>
 __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ a,
                                                        int64_t lda, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int relu_in, int64_t M, int c_out,
                                                        int c_in, float* __restrict__ part, int n_mb, int n_kb,
                                                        int64_t slice_pts) {
     const int lane = threadIdx.x & 63, h = lane >> 5, m = lane & 31;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int blk = (int)(unit % (n_mb * n_kb));
-    const int64_t slice = unit / (n_mb * n_kb);
-    const int64_t p_begin = slice * slice_pts;
-    if (p_begin >= M) return;
-    const int64_t p_end = min(M, p_begin + slice_pts);         // M % 32 == 0, slice_pts % 64 == 0: whole 16-point blocks
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // COMB: a quarter of the partial sums in memory (round 4: 235 MB of slices written and read back per step —
+    // `tools/pmc_train_traffic.sh` — beside 4 GB of operands). A tail wave computes nothing and joins the reduction with zeros.
+    const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+    const int blk = COMB ? (int)(blockIdx.x % (unsigned)(n_mb * n_kb)) : (int)(unit % (n_mb * n_kb));
+    const int64_t slice_out = COMB ? blockIdx.x / (unsigned)(n_mb * n_kb) : unit / (n_mb * n_kb);
+    const int64_t slice = COMB ? slice_out * 4 + wave : slice_out;
+    const bool idle = slice * slice_pts >= M;
+    if (!COMB && idle) return;
+    const int64_t p_begin = idle ? 0 : slice * slice_pts;
+    const int64_t p_end = idle ? 0 : min(M, p_begin + slice_pts);  // M % 32 == 0, slice_pts % 64 == 0: whole 16-point blocks
     const int mt0 = (blk / n_kb) * MT, kt0 = (blk % n_kb) * KT;
     const int n_mt = min(MT, c_out / 32 - mt0), n_kt = min(KT, c_in / 32 - kt0);
     int oa[MT], ob[KT];                                        // tile offsets, clamped to the last real tile (see wg_load)
@@ -2046,8 +2057,35 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
             }
         }
     }
+    if constexpr (COMB) {
+        // waves 1..3 hand their tiles to wave 0, four tiles at a time (48 KiB of LDS), added in wave order: a fixed association
+        __shared__ float comb[3][4][16][64];
+        constexpr int NT = MT * KT;
+#pragma unroll
+        for (int g0 = 0; g0 < NT; g0 += 4) {
+            if (wave > 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (g0 + u < NT) comb[wave - 1][u][r][lane] = acc[(g0 + u) / KT][(g0 + u) % KT][r];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (g0 + u < NT) acc[(g0 + u) / KT][(g0 + u) % KT][r] += comb[w][u][r][lane];
+            }
+            __syncthreads();
+        }
+        if (wave != 0) return;
+    }
     // D tile: row (co) = tile_chan(r, h), col (ci) = lane & 31
-    float* out = part + slice * (int64_t)c_out * c_in;
+    float* out = part + slice_out * (int64_t)c_out * c_in;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         if (t >= n_mt) break;
@@ -2126,9 +2164,15 @@ static int64_t wgrad_slice_pts(int64_t M, int c_out, int c_in) {
     return pts < WG_MIN_SLICE ? WG_MIN_SLICE : pts;
 }
 
+// partial sums in memory: one per workgroup (its four waves' slices added through LDS: tr_wgrad_kernel COMB) or one per wave
+static bool wgrad_comb(int c_out, int c_in) { return WG_COMBINE && (wgrad_small(c_out) || wgrad_kt(c_out, c_in) != 4); }
+static int64_t wgrad_out_slices(int64_t M, int64_t pts, bool comb) {
+    const int64_t n = (M + pts - 1) / pts;
+    return comb ? (n + 3) / 4 : n;
+}
 size_t tr_wgrad_workspace_bytes(int64_t M, int c_out, int c_in) {
     const int64_t pts = wgrad_slice_pts(M, c_out, c_in);
-    return (size_t)((M + pts - 1) / pts) * c_out * c_in * sizeof(float);
+    return (size_t)wgrad_out_slices(M, pts, wgrad_comb(c_out, c_in)) * c_out * c_in * sizeof(float);
 }
 
 // The second stages of SEVERAL weight gradients in one launch (round 4: a backward pass issued one 5-us second stage behind
@@ -2177,9 +2221,9 @@ hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_
     int n_mb, n_kb;
     wgrad_blocks(c_out, c_in, &n_mb, &n_kb);
     const int64_t pts = wgrad_slice_pts(M, c_out, c_in);
-    const int64_t n_slices = (M + pts - 1) / pts;
-    const int64_t units = n_slices * n_mb * n_kb;
-    const dim3 grid((unsigned)((units + 3) / 4));
+    const bool comb = wgrad_comb(c_out, c_in);
+    const int64_t n_slices = wgrad_out_slices(M, pts, comb);    // as they reach memory
+    const dim3 grid(comb ? (unsigned)(n_slices * n_mb * n_kb) : (unsigned)((n_slices * n_mb * n_kb + 3) / 4));
 #ifndef WG_FULL
 #define WG_FULL 1                       // 0: the clamped-offset loads for every layer (A/B builds)
 #endif
@@ -2189,12 +2233,15 @@ hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_
         else
             hipLaunchKernelGGL(plain, grid, dim3(256), 0, s, dz, lddz, a, lda, scale, shift, relu_in, M, c_out, c_in, part, n_mb, n_kb, pts);
     };
-    if (wgrad_small(c_out))
-        go(tr_wgrad_kernel<2, WG_KT, 4>, tr_wgrad_kernel<2, WG_KT, 4, true>, 2, WG_KT);
-    else if (wgrad_kt(c_out, c_in) == 4)
+    if (wgrad_small(c_out)) {
+        if (comb) go(tr_wgrad_kernel<2, WG_KT, 4, false, true>, tr_wgrad_kernel<2, WG_KT, 4, true, true>, 2, WG_KT);
+        else go(tr_wgrad_kernel<2, WG_KT, 4>, tr_wgrad_kernel<2, WG_KT, 4, true>, 2, WG_KT);
+    } else if (wgrad_kt(c_out, c_in) == 4) {
         go(tr_wgrad_kernel<WG_MT, 4, 2>, tr_wgrad_kernel<WG_MT, 4, 2, true>, WG_MT, 4);
-    else
-        go(tr_wgrad_kernel<WG_MT, WG_KT, 2>, tr_wgrad_kernel<WG_MT, WG_KT, 2, true>, WG_MT, WG_KT);
+    } else {
+        if (comb) go(tr_wgrad_kernel<WG_MT, WG_KT, 2, false, true>, tr_wgrad_kernel<WG_MT, WG_KT, 2, true, true>, WG_MT, WG_KT);
+        else go(tr_wgrad_kernel<WG_MT, WG_KT, 2>, tr_wgrad_kernel<WG_MT, WG_KT, 2, true>, WG_MT, WG_KT);
+    }
     if (!dW) return hipGetLastError();                          // the caller adds the slices later (dal3_tr_wgrad_final_many)
     const int64_t n = (int64_t)c_out * c_in;
     hipLaunchKernelGGL(tr_wgrad_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * WGF_L), 0, s, part, (int)n_slices, n, dW);
