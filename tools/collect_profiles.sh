@@ -18,6 +18,7 @@ done
 [ -s $O/train_roofline_hip_f16x3.json ] && cp $O/train_roofline_hip_f16x3.json profiles/${TAG}_train_roofline_f16x3.json
 [ -s $O/train_pmc.txt ] && cp $O/train_pmc.txt profiles/${TAG}_train_pmc.txt
 [ -s $O/pool_pmc.txt ] && cp $O/pool_pmc.txt profiles/${TAG}_pool_pmc.txt
+[ -s $O/train_traffic.txt ] && cp $O/train_traffic.txt profiles/${TAG}_train_traffic.txt
 [ -s $O/trx_probe.txt ] && cp $O/trx_probe.txt profiles/${TAG}_trx_probe.txt
 [ -s $O/pmc_x3.txt ] && cp $O/pmc_x3.txt profiles/${TAG}_pmc_f16x3_detail.txt
 ls profiles | grep "^${TAG}_" | wc -l

@@ -32,6 +32,7 @@ python3 $R/tools/train_timeline.py $(ls $O/prof_kt_train_x3/*/kt_kernel_trace.cs
 # instruction mix and matrix-pipe busy share of the training step's MFMA kernels (two --pmc passes of their own), and of the pooled layer alone
 bash $R/tools/pmc_train.sh hip > $O/train_pmc.txt 2>/dev/null
 bash $R/tools/pmc_pool.sh > $O/pool_pmc.txt 2>/dev/null
+bash $R/tools/pmc_train_traffic.sh hip > $O/train_traffic.txt 2>/dev/null
 python3 $R/tools/bench_train.py --kind dynamic --sampler device --backends hip,hip_f16x3,torch > $O/bench_train_dynamic.json 2>/dev/null
 python3 $R/tools/trx_probe.py > $O/trx_probe.txt 2>/dev/null
 python3 $R/tools/wgx_probe.py >> $O/trx_probe.txt 2>/dev/null
