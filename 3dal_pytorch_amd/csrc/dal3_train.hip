@@ -2254,11 +2254,22 @@ hipError_t launch_tr_wgrad(const float* dz, int64_t lddz, const float* a, int64_
 // same key instead of reading a stored (M x C) mask (128 MB at 64 x 4096 points for ins_seg's Dropout), and `step`
 // is read from DEVICE memory so that a step captured into a hipGraph draws afresh on every replay (the host bumps
 // that scalar with an ordinary captured op). 16 bytes per lane, rows of C floats (C a multiple of 4).
-__device__ __forceinline__ uint32_t tr_hash32(uint64_t key, uint64_t idx) {
-    uint64_t z = key + idx * 0x9E3779B97F4A7C15ull;                     // splitmix64 finaliser
+// One draw per FOUR consecutive elements (a lane's 16 bytes): the splitmix64 finaliser of (key, index of the quad), its 64 bits
+// cut into four 16-bit fields, element e kept when field e >= thresh (thresh = p_drop * 65536: the keep probability is exact
+// to 2^-16; p = 0.5 exactly). Round 4: one 64-bit hash per ELEMENT — ~28 vector instructions each — made the three kernels of
+// the logits layer compute-bound at 3.1–4.7 TB/s (`profiles/r04_train_traffic.txt`); every kernel that re-creates the multiplier
+// calls this one function.
+__device__ __forceinline__ uint64_t tr_hash_quad(uint64_t key, uint64_t quad) {
+    uint64_t z = key + quad * 0x9E3779B97F4A7C15ull;                    // splitmix64 finaliser
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return (uint32_t)((z ^ (z >> 31)) >> 32);
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ bool tr_keep(uint64_t h, int e, uint32_t thresh) { return (uint32_t)((h >> (16 * e)) & 0xffffu) >= thresh; }
+static uint32_t tr_drop_thresh(float p_drop) {                          // 0 (keep everything, no draw) .. 65536 (keep nothing)
+    if (p_drop <= 0.0f) return 0u;
+    const double t = (double)p_drop * 65536.0 + 0.5;
+    return t >= 65536.0 ? 65536u : (uint32_t)t;
 }
 __global__ __launch_bounds__(256) void tr_act_dropout_kernel(const float* __restrict__ x, int64_t M, int C, int64_t ldx,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
@@ -2286,8 +2297,9 @@ __global__ __launch_bounds__(256) void tr_act_dropout_kernel(const float* __rest
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= mv[e];
         } else if (thresh != 0u) {                          // (p_drop == 0: every element kept at scale 1, no draw to make)
+            const uint64_t hq = tr_hash_quad(key, (uint64_t)(p * C + c) >> 2);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = tr_hash32(key, (uint64_t)(p * C + c + e)) >= thresh ? v[e] * keep_scale : 0.0f;
+            for (int e = 0; e < 4; ++e) v[e] = tr_keep(hq, e, thresh) ? v[e] * keep_scale : 0.0f;
         }
         *reinterpret_cast<f32x4*>(out + p * ldo + c) = v;
     }
@@ -2298,8 +2310,7 @@ hipError_t launch_tr_act_dropout(const float* x, int64_t M, int C, int64_t ldx, 
     const int64_t n = M * (C / 4);
     const int64_t want = (n + 255) / 256;
     const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
-    const double t = (double)p_drop * 4294967296.0;
-    const uint32_t thresh = p_drop <= 0.0f ? 0u : (t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t);
+    const uint32_t thresh = tr_drop_thresh(p_drop);
     const float keep_scale = p_drop < 1.0f ? 1.0f / (1.0f - p_drop) : 0.0f;
     hipLaunchKernelGGL(tr_act_dropout_kernel, dim3(grid), dim3(256), 0, s, x, M, C, ldx, scale, shift, relu, mult, ldm, seed, step,
                        thresh, keep_scale, out, ldo);
@@ -2328,8 +2339,9 @@ __device__ __forceinline__ f32x4 drop_mult4(const DropKey& d, int64_t p, int c, 
     if (d.mult) return *reinterpret_cast<const f32x4*>(d.mult + p * d.ldm + c);
     if (d.thresh == 0u) return f32x4{d.keep_scale, d.keep_scale, d.keep_scale, d.keep_scale};      // p_drop == 0: no draw
     f32x4 m;
+    const uint64_t hq = tr_hash_quad(d.key, (uint64_t)(p * C + c) >> 2);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) m[e] = tr_hash32(d.key, (uint64_t)(p * C + c + e)) >= d.thresh ? d.keep_scale : 0.0f;
+    for (int e = 0; e < 4; ++e) m[e] = tr_keep(hq, e, d.thresh) ? d.keep_scale : 0.0f;
     return m;
 }
 __device__ __forceinline__ f32x4 act4(const f32x4 v, const f32x4 sc, const f32x4 sh, bool affine, int relu) {
@@ -2533,10 +2545,9 @@ __global__ __launch_bounds__(256) void tr_head2_wgrad_kernel(const float* __rest
     }
 }
 static DropKey drop_key(const float* mult, int64_t ldm, float p_drop) {
-    const double t = (double)p_drop * 4294967296.0;
     DropKey d{};
     d.mult = mult, d.ldm = ldm;
-    d.thresh = p_drop <= 0.0f ? 0u : (t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t);
+    d.thresh = tr_drop_thresh(p_drop);
     d.keep_scale = p_drop < 1.0f ? 1.0f / (1.0f - p_drop) : 0.0f;
     return d;
 }
