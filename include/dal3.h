@@ -580,8 +580,8 @@ int dal3_tr_segmax(const float* z, int64_t ldz, int64_t seg, int C, const float*
 /* dal3_tr_act_dropout: out = act(x) * m, one pass. act as in dal3_tr_linear (scale == NULL: identity; relu applied after the
  * affine when relu != 0). m = mult[p][c] (row stride ldm) when mult != NULL — a caller-supplied multiplier, e.g. the
  * reference's own draw in a parity test — else m = keep / (1 - p_drop) with keep ~ Bernoulli(1 - p_drop) drawn by a
- * counter-based generator keyed on (seed, *step, p * C + c): forward and backward pass the same (seed, step) and get the
- * same multiplier without storing it; step (device int64, may be NULL = 0) lets a hipGraph replay draw afresh.
+ * counter-based generator keyed on (seed, *step, element index; one draw per four consecutive elements, the keep
+ * probability exact to 2^-16): forward and backward pass the same (seed, step) and get the same multiplier without storing it; step (device int64, may be NULL = 0) lets a hipGraph replay draw afresh.
  * Replaces: self.dropout = nn.Dropout(p=0.5) applied to relu(dbn4(dconv4(x))) (static_model.py:268,292-293) and its
  * backward. */
 /* The 128 -> 2 logits layer with the Dropout in front of it (static_model.py:292-294: dconv5(dropout(relu(dbn4(z))))) as three
