@@ -51,7 +51,7 @@ def _rehearsal(extra_args, timeout=900):
                          text=True, env=env, timeout=timeout)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, out.stdout[-2000:]
+    assert len(lines) == 1 and len(lines[0].encode()) <= 4096, out.stdout[-2000:]
     return json.loads(lines[0])
 
 
@@ -62,11 +62,11 @@ def test_two_rank_rehearsal_on_one_gpu_static_line_proves_its_gather():
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["rccl"]["backend"] == "gloo" and rec["rccl"]["world_size"] == 2 and rec["rccl"]["ranks_counted"] == 2
     assert rec["rccl"]["ranks_share_gpus"] is True
-    assert len(rec["ms_per_step_per_rank"]) == 2 and rec["ms_per_step_rank_max"] >= rec["ms_per_step_rank_min"] > 0
+    assert len(rec["ms_per_step_per_rank"]) == 2 and min(rec["ms_per_step_per_rank"]) > 0
     assert rec["gather_equals_single_rank"] is True, rec["gather_self_check"]
     (c,) = rec["gather_self_check"]["checks"]
     assert (c["head"], c["peer"], c["first_item"], c["rows"]) == ("static", 1, 512, 64)
-    # rank 0's per-kernel table and roofline are part of the line at every world size
+    # rank 0's roofline is part of the (<= 4 KB) line at every world size
     assert rec["roofline"]["kernel"].startswith("ins_seg_decode") and 0 < rec["roofline"]["frac"] < 1
     assert rec["config"]["items_per_gpu"] == 512
 

@@ -21,6 +21,37 @@ def _env(**extra):
     return env
 
 
+def _strict(line):
+    """the driver's view of the one stdout line: bounded, strictly parseable (no NaN / Infinity), contract keys present"""
+    bench = importlib.import_module("bench")
+    assert len(line.encode()) <= bench.LINE_CAP == 4096, len(line)
+
+    def no_constants(c):
+        raise AssertionError(f"non-strict JSON constant {c} in the bench line")
+    rec = json.loads(line, parse_constant=no_constants)
+    missing = [k for k in bench.REQUIRED if k not in rec]
+    assert not missing, missing
+    return rec
+
+
+def test_compact_line_drops_optional_keys_until_it_fits_and_refuses_nan():
+    """the line can never again outgrow the driver's parser. A record with the contract's keys and
+    oversized optional ones comes out <= 4 KB with every required key kept; NaN is an error, not 'NaN' in the line"""
+    bench = importlib.import_module("bench")
+    rec = {k: 1 for k in bench.REQUIRED}
+    rec["config"] = {"workload": "w" * 300}
+    rec["roofline"] = {"kernel": "k", "bound": "mfma", "achieved": 138.3, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.879, "traffic": None}
+    rec["cpu_baseline"] = {"value": 80.0, "unit": "object-crops/s", "cores": 32, "kind": "port", "sample": "s" * 300}
+    rec["gather_self_check"] = {"checks": [{"head": "static", "peer": i, "equal": True, "pad": "x" * 200} for i in range(40)]}
+    rec["ms_per_step_per_rank"] = [25.123] * 8
+    rec["rccl"] = {"backend": "nccl", "world_size": 8, "ranks_counted": 8}
+    out = _strict(bench.compact_line(rec))
+    assert out["dropped_for_size"] == ["gather_self_check"] and out["rccl"]["ranks_counted"] == 8
+    import pytest
+    with pytest.raises(ValueError):
+        bench.compact_line(dict(rec, value=float("nan")))
+
+
 def test_bench_without_enough_gpus_fails_cleanly():
     """no GPU here: a plain `bench.py --gpus 2` says what it needs and exits non-zero without starting anything"""
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
@@ -55,7 +86,7 @@ def test_eight_ranks_c2_weak_and_c4_ragged_on_gloo():
         assert out.returncode == 0, out.stderr[-3000:]
         lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
         assert len(lines) == 1, out.stdout
-        rec = json.loads(lines[0])
+        rec = _strict(lines[0])
         assert rec["n_gpus"] == 8 and rec["gathered_ok"] is True
         assert rec["rccl"] == {"backend": "gloo", "world_size": 8, "ranks_counted": 8}
         assert rec["scaling"] == ("strong" if config == "C4" else "weak")
@@ -85,7 +116,7 @@ def test_bench_self_launches_two_ranks_and_relays_one_line():
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout
-    rec = json.loads(lines[0])
+    rec = _strict(lines[0])
     assert rec["n_gpus"] == 2 and rec["plumbing_only"] and rec["gathered_ok"]
     assert rec["rccl"] == {"backend": "gloo", "world_size": 2, "ranks_counted": 2}
     # what a real N > 1 line carries: every rank's own step time, and rank 0's recomputation of rank 1's first rows
