@@ -161,15 +161,13 @@ def test_static_c5_full_size_lowprec(prec):
     == whole bit for bit; single-group launches == the persistent launch; logits invariant under a permutation of
     a crop's points."""
     B, N = 2048, 4096
-    base, init_np, gt_np = synth.static_crops(128, N, seed=32)
-    pts_np = np.tile(base, (16, 1, 1))
-    pts_np[128:] += synth.normal(32, "jit", (1, 1, 3), 0.0, 0.01).astype(np.float32)
-    sd = recentred_sd("static_one", base[:4], 32)
+    pts_np, init_np, gt_np = synth.static_crops(B, N, seed=32)                  # 2048 DISTINCT crops (not tilings)
+    assert len({pts_np[i, :2].tobytes() for i in range(B)}) == B
+    sd = recentred_sd("static_one", pts_np[:4], 32)
     # every ninth crop is shrunk so that only a few dozen of its points are segmented (the head then skips whole
     # tiles of copies; factor found with the oracle: 0.85 leaves 10..170 points of these crops), some to none at all
     pts_np[::9] *= np.float32(0.85)
     pts_np[4::27] *= np.float32(0.02)
-    init_np, gt_np = np.tile(init_np, (16, 1)), np.tile(gt_np, (16, 1))
     model = build_model("static_one", sd)
     model.precision = prec
     pts, init, gt = (torch.from_numpy(a).cuda() for a in (pts_np, init_np, gt_np))
@@ -187,6 +185,103 @@ def test_static_c5_full_size_lowprec(prec):
     perm = torch.from_numpy(np.argsort(synth.uniform(32, "perm", (N,)))).cuda()
     permuted = model._run(pts[:32][:, perm].transpose(2, 1), init[:32], gt[:32])
     assert torch.equal(permuted["logits"], full["logits"][:32][:, perm])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The two 16-bit BASELINE configurations at THEIR OWN SIZE against the oracle. The reference is fp32
+# only, so the bars are tests/test_gpu_lowprec.py's BARS (each the measured worst case of the small-size cases with at
+# most 2x headroom), applied here to a stratified sample of the full-size launch, plus a bar on the fraction of mask
+# bits that differ from the exact-fp32 path's over the WHOLE batch. Inputs are stored in bf16 as BASELINE.json says
+# ("bf16 storage"); the oracle is given the stored values, so both sides compute on identical inputs. The box
+# estimators are teacher-forced on the exact-fp32 path's mask (`mask_override`: the device sampler, keyed on the item
+# and the count, then draws the same points, which the oracle is handed through `forced`).
+from test_gpu_lowprec import BARS                       # noqa: E402  (the one table of 16-bit bars)
+
+FULL_MEASURED = []
+
+
+def _bar16(key, prec, value, where):
+    value = float(value)
+    FULL_MEASURED.append({"bar": key, "prec": prec, "value": value, "limit": BARS[key][prec], "where": where})
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(FULL_MEASURED, open(os.path.join(out, "lowprec_fullsize_measured.json"), "w"), indent=1)
+    assert value < BARS[key][prec], (key, prec, value, BARS[key][prec], where)
+
+
+def test_dynamic_c3_full_size_bf16_vs_oracle_on_a_stratified_sample():
+    """BASELINE.json configs[2] as bench.py --config C3 runs it: DynamicModel, 1024 items x 5120 points + 101 boxes,
+    bf16 storage and bf16 MFMA arithmetic, one launch; 32 stratified rows against the oracle."""
+    B, prec = 1024, "bf16"
+    p, bx, i8, _ = synth.dynamic_items(B, seed=44)
+    sd = recentred_sd("dynamic", p[:2], 44)
+    model = build_model("dynamic", sd)
+    dp = torch.from_numpy(p).cuda().to(torch.bfloat16).transpose(2, 1)
+    db = torch.from_numpy(bx).cuda().to(torch.bfloat16).transpose(2, 1)
+    di = torch.from_numpy(i8).cuda()
+    ref = model._run(dp, db, init_box8=di)                                    # the exact-fp32 arithmetic on the stored inputs
+    model.precision = prec
+    free = model._run(dp, db, init_box8=di)
+    _bar16("mask_flip", prec, (free["mask"] != ref["mask"]).float().mean().item(), "C3 full size, all 1024 x 5120 bits vs fp32 path")
+    forced = model._run(dp, db, init_box8=di, mask_override=ref["mask"])
+    assert torch.equal(forced["obj_idx"], ref["obj_idx"]) and torch.equal(forced["counts"], ref["counts"])
+    rows = _stratified_rows(B, 32, 8)
+    sel = torch.from_numpy(rows).cuda()
+    got = {k: forced[k][sel].cpu().numpy() for k in ("counts", "obj_idx", "embedding", "bp", "boxes7")}
+    p_t, b_t = dp[sel].float().cpu(), db[sel].float().cpu()                    # the stored (bf16) values, as the oracle's fp32 input
+    want = R.dynamic_forward(R.as_torch_sd(sd), p_t, b_t, forced=(torch.from_numpy(got["obj_idx"].astype(np.int64)), got["counts"]))
+    wl = want["logits"].numpy()
+    _bar16("logits", prec, rel_err(free["logits"][sel].cpu().numpy(), wl), "C3 full size, 32 rows vs oracle")
+    margin = wl[:, :, 1] - wl[:, :, 0]
+    sure = np.abs(margin) > 2 * BARS["logits"][prec] * np.abs(wl).max()
+    assert sure.mean() > 0.5 and np.array_equal(free["mask"][sel].cpu().numpy().astype(bool)[sure], (margin > 0)[sure])
+    _bar16("box", prec, rel_err(got["embedding"], torch.cat([want["_point_e"], want["_box_e"]], 1).numpy()), "C3 full size embedding vs oracle")
+    want_bp = np.concatenate([want["center"].numpy(), want["heading_scores"].numpy(), want["heading_residuals_normalized"].numpy(),
+                              want["size_scores"].numpy(), want["size_residuals_normalized"].numpy().reshape(len(rows), 9)], 1)
+    _bar16("box_tail", prec, rel_err(got["bp"], want_bp), "C3 full size bp vs oracle")
+    same = (got["bp"][:, 3:15].argmax(1) == want_bp[:, 3:15].argmax(1)) & (got["bp"][:, 27:30].argmax(1) == want_bp[:, 27:30].argmax(1))
+    assert same.mean() > 0.7                                                  # (a near-tie class may flip: a different bin centre)
+    wb7 = R.decode_dynamic(want, torch.from_numpy(i8[rows]))
+    _bar16("box_tail", prec, np.abs(got["boxes7"][same] - wb7[same]).max() / np.abs(wb7).max(), "C3 full size boxes7 vs oracle")
+
+
+def test_static_c5_full_size_fp16_vs_oracle_on_a_stratified_sample():
+    """BASELINE.json configs[4] per-GPU size as bench.py --config C5 runs it: StaticModelOneBoxEst, 2048 DISTINCT crops
+    x 4096 points, bf16 storage, fp16 MFMA shared MLP, one launch; 48 stratified rows against the oracle."""
+    B, N, prec = 2048, 4096, "fp16"
+    pts_np, init_np, gt_np = synth.static_crops(B, N, seed=45)
+    assert len({pts_np[i, :2].tobytes() for i in range(B)}) == B               # distinct crops, not tilings
+    sd = recentred_sd("static_one", pts_np[:4], 45)
+    pts_np[::9] *= np.float32(0.85)                                            # some crops with few segmented points
+    model = build_model("static_one", sd)
+    pts = torch.from_numpy(pts_np).cuda().to(torch.bfloat16).transpose(2, 1)
+    init, gt = torch.from_numpy(init_np).cuda(), torch.from_numpy(gt_np).cuda()
+    ref = model._run(pts, init, gt)
+    model.precision = prec
+    free = model._run(pts, init, gt)
+    _bar16("mask_flip", prec, (free["mask"] != ref["mask"]).float().mean().item(), "C5 full size, all 2048 x 4096 bits vs fp32 path")
+    forced = model._run(pts, init, gt, mask_override=ref["mask"])
+    assert torch.equal(forced["obj_idx"], ref["obj_idx"])
+    rows = _stratified_rows(B, 48, 12)
+    sel = torch.from_numpy(rows).cuda()
+    got = {k: forced[k][sel].cpu().numpy() for k in ("counts", "obj_idx", "bp1", "boxes7")}
+    assert (got["counts"] < 512).any() and (got["counts"] >= 512).any()
+    p_t, i_t = pts[sel].float().cpu(), torch.from_numpy(init_np[rows])
+    want = R.static_one_forward(R.as_torch_sd(sd), p_t, i_t, forced=(torch.from_numpy(got["obj_idx"].astype(np.int64)), got["counts"]))
+    wl = want["logits"].numpy()
+    _bar16("logits", prec, rel_err(free["logits"][sel].cpu().numpy(), wl), "C5 full size, 48 rows vs oracle")
+    margin = wl[:, :, 1] - wl[:, :, 0]
+    sure = np.abs(margin) > 2 * BARS["logits"][prec] * np.abs(wl).max()
+    assert sure.mean() > 0.5 and np.array_equal(free["mask"][sel].cpu().numpy().astype(bool)[sure], (margin > 0)[sure])
+    wbp = np.concatenate([want["center_boxnet"].numpy(), want["heading_scores"].numpy(), want["heading_residuals_normalized"].numpy(),
+                          want["size_scores"].numpy(), want["size_residuals_normalized"].numpy().reshape(len(rows), 9)], 1)
+    _bar16("box", prec, rel_err(got["bp1"], wbp), "C5 full size bp1 vs oracle")
+    same = (got["bp1"][:, 3:15].argmax(1) == wbp[:, 3:15].argmax(1)) & (got["bp1"][:, 27:30].argmax(1) == wbp[:, 27:30].argmax(1))
+    assert same.mean() > 0.7
+    wb7 = R.decode_static(want, i_t, False)
+    _bar16("box_tail", prec, np.abs(got["boxes7"][same] - wb7[same]).max() / np.abs(wb7).max(), "C5 full size boxes7 vs oracle")
 
 
 def test_fused_max_equals_standalone_maxpool():
