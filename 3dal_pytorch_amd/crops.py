@@ -68,6 +68,97 @@ class RaggedRows:
         return np.split(host, cuts) if len(self) else []
 
 
+class CropPlan:
+    """Everything about a segment's crop extraction that does not depend on the sweeps' points, prepared and uploaded
+    ONCE (round 5; as post.WritebackPlan and prep.StaticTrackStore do for their steps): the detections in Waymo
+    convention, their face equations and cull balls (the O(#boxes) NumPy arithmetic the reference does per detection,
+    geom.py), the poses, the frame offsets, the workspace and the output order. `run(points)` then is three kernel
+    launches on the current stream — count, starts (dal3_crop_starts: the prefix sums stay on the device), fill — with
+    no host work and no synchronisation in between: the detections of a segment are known before its sweeps are
+    touched, so the plan is built off the critical path.
+
+        plan = CropPlan(n_pts, detections, veh_to_global, order=track_major)     # once per segment
+        out, offsets = plan.run(flat_points)                                      # enqueue only
+        total = plan.total()                                                      # (first host sync, when needed)
+
+    n_pts: points per frame; order: optional permutation of the K_total detections (numbered frame by frame) giving
+    their order in the output — e.g. track-major, so that a track's rows are contiguous and prep.py's kernels can read
+    them in place; capacity: rows of the output buffer (default: sized by the first run, which then synchronises once;
+    rows past the capacity are dropped by the kernel and `total()` tells)."""
+
+    def __init__(self, n_pts, detections, veh_to_global, device="cuda", order=None, capacity=None, return_index=False):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("extract_crops runs on the GPU only (lib3dal_hip.so has no CPU fallback)")
+        F = len(n_pts)
+        if not (F == len(detections) == len(veh_to_global)) or F == 0:
+            raise ValueError("extract_crops: need the same non-zero number of sweeps, detection sets and poses")
+        self.dev, self.F = dev, F
+        self.boxes = [waymo_boxes(np.asarray(d, dtype=np.float32).reshape(-1, np.asarray(d).shape[-1])) for d in detections]
+        self.poses = [np.reshape(np.asarray(p, dtype=np.float64), [4, 4]) for p in veh_to_global]
+        all_boxes = np.concatenate(self.boxes) if self.boxes else np.zeros((0, 7), np.float32)
+        self.n_pts = [int(n) for n in n_pts]
+        self.n_box = [int(b.shape[0]) for b in self.boxes]
+        self.K, self.max_pts = sum(self.n_box), max(self.n_pts)
+        K = self.K
+        self.d_poff = torch.from_numpy(np.concatenate([[0], np.cumsum(self.n_pts)]).astype(np.int64)).to(dev)
+        self.d_boff = torch.from_numpy(np.concatenate([[0], np.cumsum(self.n_box)]).astype(np.int64)).to(dev)
+        self.d_planes = geom.planes_to_device(geom.box_planes(all_boxes), dev)       # per-box arithmetic: one call for every frame
+        self.d_sph = torch.from_numpy(geom.cull_spheres(all_boxes)).to(dev)
+        self.d_pose = torch.from_numpy(np.stack(self.poses).reshape(F, 16)).to(dev)
+        self.d_order = None
+        if order is not None:
+            order = np.asarray(order, np.int64)
+            if order.shape != (K,) or not np.array_equal(np.sort(order), np.arange(K)):
+                raise ValueError("CropPlan: order must be a permutation of the detections")
+            self.d_order = torch.from_numpy(order).to(dev)
+        lib = _hip.lib()
+        self.ws = torch.empty(max(int(lib.dal3_crop_workspace_bytes(K, self.max_pts)), 4), dtype=torch.uint8, device=dev)
+        self.counts = torch.zeros(max(K, 1), dtype=torch.int64, device=dev)
+        self.start = torch.zeros(K + 1, dtype=torch.int64, device=dev)           # by detection; [K] = total
+        self.offsets = torch.zeros(K + 1, dtype=torch.int64, device=dev)         # by output position
+        self.capacity = int(capacity) if capacity else 0
+        self.out = torch.empty((self.capacity, 3), dtype=torch.float64, device=dev) if self.capacity else None
+        self.idx = None
+        self.return_index = return_index
+
+    def count(self, d_pts):
+        lib = _hip.lib()
+        _hip.check(lib.dal3_crop_count(_hip.ptr(d_pts), _hip.ptr(self.d_poff), _hip.ptr(self.d_planes), _hip.ptr(self.d_sph),
+                                       _hip.ptr(self.d_boff), self.F, self.K, self.max_pts, _hip.ptr(self.counts),
+                                       _hip.ptr(self.ws), self.ws.numel(), _hip.stream()))
+        _hip.check(lib.dal3_crop_starts(_hip.ptr(self.counts), _hip.ptr(self.d_order), self.K, _hip.ptr(self.start),
+                                        _hip.ptr(self.offsets), _hip.stream()))
+
+    def fill(self, d_pts):
+        if self.return_index and (self.idx is None or self.idx.numel() < self.capacity):
+            self.idx = torch.empty(max(self.capacity, 1), dtype=torch.int32, device=self.dev)
+        _hip.check(_hip.lib().dal3_crop_fill(_hip.ptr(d_pts), _hip.ptr(self.d_poff), _hip.ptr(self.d_planes), _hip.ptr(self.d_sph),
+                                             _hip.ptr(self.d_boff), self.F, self.K, self.max_pts, _hip.ptr(self.d_pose),
+                                             _hip.ptr(self.counts), _hip.ptr(self.start), _hip.ptr(self.out),
+                                             _hip.ptr(self.idx) if self.return_index else None, self.capacity,
+                                             _hip.ptr(self.ws), self.ws.numel(), _hip.stream()))
+
+    def total(self):
+        """members over all detections of the last run (a host synchronisation)"""
+        return int(self.start[self.K].item())
+
+    def run(self, d_pts):
+        """d_pts: the segment's sweeps as ONE (sum P_f, 3) float32 CUDA tensor, frame after frame. Enqueues count,
+        starts and fill; returns (out (capacity,3) float64 global-frame rows, offsets (K+1) int64 by output position),
+        both device tensors that the NEXT run overwrites. Without a capacity (first run) the total is read back once
+        to size the buffer (+12 % headroom for later runs of the same plan)."""
+        if d_pts.dtype != torch.float32 or d_pts.dim() != 2 or d_pts.shape[1] != 3 or not d_pts.is_contiguous() \
+                or d_pts.shape[0] != sum(self.n_pts):
+            raise ValueError("CropPlan.run: points must be the contiguous (sum of n_pts, 3) float32 tensor of the segment")
+        self.count(d_pts)
+        if not self.capacity:
+            self.capacity = max(int(self.total() * 1.125) + 64, 64)
+            self.out = torch.empty((self.capacity, 3), dtype=torch.float64, device=self.dev)
+        self.fill(d_pts)
+        return self.out, self.offsets
+
+
 def extract_crops(sweeps, detections, veh_to_global, device="cuda", return_index=False):
     """sweeps: list of (P_f,3) float32 arrays or CUDA tensors; detections: list of (K_f,7|9) float32 detector
     boxes; veh_to_global: list of flat-16 poses. Returns a list (one entry per frame) of dicts
@@ -78,39 +169,16 @@ def extract_crops(sweeps, detections, veh_to_global, device="cuda", return_index
       'index'       (return_index) likewise K_f CUDA int32 tensors: which sweep points they are
     """
     dev = torch.device(device)
-    if dev.type != "cuda":
-        raise RuntimeError("extract_crops runs on the GPU only (lib3dal_hip.so has no CPU fallback)")
-    F = len(sweeps)
-    if not (F == len(detections) == len(veh_to_global)) or F == 0:
-        raise ValueError("extract_crops: need the same non-zero number of sweeps, detection sets and poses")
-    boxes = [waymo_boxes(np.asarray(d, dtype=np.float32).reshape(-1, np.asarray(d).shape[-1])) for d in detections]
-    poses = [np.reshape(np.asarray(p, dtype=np.float64), [4, 4]) for p in veh_to_global]
-    all_boxes = np.concatenate(boxes) if boxes else np.zeros((0, 7), np.float32)
-    planes = geom.box_planes(all_boxes)                            # per-box arithmetic: one call for every frame
     n_pts = [int(s.shape[0]) for s in sweeps]
-    n_box = [int(b.shape[0]) for b in boxes]
-    K, max_pts = sum(n_box), max(n_pts)
+    plan = CropPlan(n_pts, detections, veh_to_global, dev, return_index=return_index)
     d_pts = torch.cat([(s if torch.is_tensor(s) else torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32))).to(dev)
                        .to(torch.float32).reshape(-1, 3) for s in sweeps]).contiguous()
-    d_poff = torch.from_numpy(np.concatenate([[0], np.cumsum(n_pts)]).astype(np.int64)).to(dev)
-    d_boff = torch.from_numpy(np.concatenate([[0], np.cumsum(n_box)]).astype(np.int64)).to(dev)
-    d_planes = geom.planes_to_device(planes, dev)
-    d_sph = torch.from_numpy(geom.cull_spheres(all_boxes)).to(dev)
-    d_pose = torch.from_numpy(np.stack(poses).reshape(F, 16)).to(dev)
-    lib = _hip.lib()
-    ws = torch.empty(max(int(lib.dal3_crop_workspace_bytes(K, max_pts)), 4), dtype=torch.uint8, device=dev)
-    counts = torch.zeros(max(K, 1), dtype=torch.int64, device=dev)
-    _hip.check(lib.dal3_crop_count(_hip.ptr(d_pts), _hip.ptr(d_poff), _hip.ptr(d_planes), _hip.ptr(d_sph), _hip.ptr(d_boff), F, K, max_pts,
-                                   _hip.ptr(counts), _hip.ptr(ws), ws.numel(), _hip.stream()))
-    start = torch.zeros(K + 1, dtype=torch.int64, device=dev)
-    start[1:] = torch.cumsum(counts[:K], 0)
-    h_start = start.cpu().numpy()                                   # the one host sync: sizes of the ragged outputs
-    total = int(h_start[-1])
-    out = torch.empty((max(total, 1), 3), dtype=torch.float64, device=dev)
-    idx = torch.empty(max(total, 1), dtype=torch.int32, device=dev) if return_index else None
-    _hip.check(lib.dal3_crop_fill(_hip.ptr(d_pts), _hip.ptr(d_poff), _hip.ptr(d_planes), _hip.ptr(d_sph), _hip.ptr(d_boff), F,
-                                  K, max_pts, _hip.ptr(d_pose), _hip.ptr(counts), _hip.ptr(start), _hip.ptr(out),
-                                  _hip.ptr(idx), _hip.ptr(ws), ws.numel(), _hip.stream()))
+    plan.count(d_pts)
+    h_start = plan.start.cpu().numpy()                              # the one host sync: sizes of the ragged outputs
+    plan.capacity = max(int(h_start[-1]), 1)
+    plan.out = torch.empty((plan.capacity, 3), dtype=torch.float64, device=dev)
+    plan.fill(d_pts)
+    out, idx, boxes, poses, n_box, F = plan.out, plan.idx, plan.boxes, plan.poses, plan.n_box, plan.F
     frames, k = [], 0
     for f in range(F):
         rec = {"boxes_lidar": boxes[f], "bbox": transform_box(boxes[f], poses[f]),

@@ -892,16 +892,24 @@ extern "C" int dal3_crop_count(const float* points, const int64_t* point_offsets
 extern "C" int dal3_crop_fill(const float* points, const int64_t* point_offsets, const double* planes,
                               const float* spheres, const int64_t* box_offsets, int F, int64_t K_total,
                               int64_t max_points_per_frame, const double* pose, const int64_t* counts,
-                              const int64_t* box_start, double* out_points, int32_t* out_index, const void* workspace,
-                              size_t workspace_bytes, dal3_stream stream) {
+                              const int64_t* box_start, double* out_points, int32_t* out_index, int64_t out_capacity,
+                              const void* workspace, size_t workspace_bytes, dal3_stream stream) {
     if (int e = crop_args_ok(points, point_offsets, planes, spheres, box_offsets, F, K_total, max_points_per_frame,
                              workspace, workspace_bytes))
         return e;
-    if (K_total > 0 && (!pose || !counts || !box_start || !out_points))
-        return fail(DAL3_EINVAL, "crop_fill: null pose / counts / box_start / out");
+    if (K_total > 0 && (!pose || !counts || !box_start || !out_points || out_capacity < 0))
+        return fail(DAL3_EINVAL, "crop_fill: null pose / counts / box_start / out, or a negative out_capacity");
     HIP_TRY(launch_crop_fill(points, point_offsets, planes, spheres, box_offsets, F, K_total, max_points_per_frame, pose,
-                             counts, box_start, static_cast<const int32_t*>(workspace), out_points, out_index,
+                             counts, box_start, static_cast<const int32_t*>(workspace), out_points, out_index, out_capacity,
                              static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_crop_starts(const int64_t* counts, const int64_t* order, int64_t K_total, int64_t* box_start,
+                                int64_t* out_offsets, dal3_stream stream) {
+    if (K_total < 0 || !box_start || (K_total > 0 && !counts))
+        return fail(DAL3_EINVAL, "crop_starts: null counts / box_start or K_total < 0");
+    HIP_TRY(launch_crop_starts(counts, order, K_total, box_start, out_offsets, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

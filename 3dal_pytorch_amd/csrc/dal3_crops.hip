@@ -2,7 +2,7 @@
 // _create_pd_detection (det3d/datasets/waymo/waymo_common.py:166-171) — for every tracked detection of a frame, the
 // sweep's points inside its rotated box, moved to the global frame with the frame's veh_to_global — for many frames
 // in one pass. HBM-bound integer/compare work: every sweep point is read once per pass (12 B), tested against the
-// frame's boxes whose face equations sit in scalar registers, and only the members are written.
+// candidate boxes of its own grid cell (see CROP_GRID below), and only the members are written.
 //
 // Ordered output without a sort: a wavefront owns a chunk of CROP_CHUNK consecutive points of one frame.
 //   pass 1 (count):  cc[box][chunk] = members of the chunk                       (ballot + popcount)
@@ -16,20 +16,44 @@
 #define CROP_CHUNK 1024                  // points per wavefront: 16 rounds of 64
 #define CROP_ROUNDS (CROP_CHUNK / 64)
 #define CROP_WAVES 4
+// The cull in front of the exact test (round 5; rounds 2-4 tested every 64-point round against every detection's
+// ball: 10 VALU per point and box, 1.3e12 point-box tests/s, and three times slower on a shuffled sweep than on a
+// range-image-ordered one, where most rounds miss most balls). Now: a workgroup (four chunks of ONE frame) rasterises
+// the frame's detections — 64 at a time, one bit each — into a CROP_GRID x CROP_GRID grid of 64-bit masks over the
+// vehicle frame's x/y plane in LDS (cell CROP_CELL m; the detection's ball, as handed in `spheres`, projected and
+// rounded outwards; coordinates beyond +-CROP_GRID*CROP_CELL/2 clamp to the border cells, which is monotonic, so a
+// point inside a ball always lands in a marked cell). A point then looks up ITS cell: the set bits are its candidate
+// detections (none for most points, one or two near an object), and only those get the exact face test, per lane,
+// with the face equations read from LDS. Whatever the order of the sweep, a point costs one lookup plus its own
+// candidates. Non-finite coordinates are candidates of every detection (the reference's NaN behaviour: dal3_geom.h),
+// non-finite balls cover the whole grid.
+#define CROP_GRID 64
+#define CROP_CELL 2.5f
+#define CROP_BATCH 64                    // detections per grid pass (one mask bit each)
 
 __device__ __forceinline__ int lanes_below(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
+// monotonic non-decreasing in v (float add, multiply by a positive constant, clamp, truncation of a non-negative
+// value); NaN -> 0 (callers never rely on it: non-finite points bypass the grid, non-finite balls span it)
+__device__ __forceinline__ int crop_cell(float v) {
+    float t = (v + 0.5f * CROP_GRID * CROP_CELL) * (1.0f / CROP_CELL);
+    t = fminf(fmaxf(t, 0.0f), (float)(CROP_GRID - 1));
+    return (int)t;
+}
+__device__ __forceinline__ bool finite_f32(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
 
-// Conservative cull before the exact test: a sphere around the detection (centre = box centre, radius = half
-// diagonal + a margin far above fp32 rounding of the face equations). One subtract-square-add chain per point and
-// box instead of six plane evaluations; a round of 64 points goes on to the exact test only when some lane is a
-// candidate. Non-finite distances (NaN / inf coordinates) are always candidates, so the exact test alone decides
-// membership, as in the reference. d2 >= 0, so its bit pattern orders like the value.
-__device__ __forceinline__ bool sphere_candidate(float x, float y, float z, float cx, float cy, float cz, uint32_t r2_bits) {
-    const float dx = x - cx, dy = y - cy, dz = z - cz;
-    const uint32_t b = __float_as_uint(dx * dx + dy * dy + dz * dz) & 0x7fffffffu;
-    return b <= r2_bits || b >= 0x7f800000u;
+// inside_box_f32 (dal3_geom.h) with the six face equations already converted to float (the same conversion, done once
+// per workgroup when they are staged in LDS)
+__device__ __forceinline__ bool inside_box_lds(const float* pl, float x, float y, float z) {
+    bool in = true;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const float sgn = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, pl[f * 4 + 0]), __fmul_rn(y, pl[f * 4 + 1])),
+                                              __fmul_rn(z, pl[f * 4 + 2])), pl[f * 4 + 3]);
+        in = in && !ge_zero(sgn);
+    }
+    return in;
 }
 
 template <bool FILL>
@@ -37,12 +61,16 @@ __global__ __launch_bounds__(64 * CROP_WAVES) void crop_pass_kernel(
     const float* __restrict__ points, const int64_t* __restrict__ point_offsets, const double* __restrict__ planes,
     const float* __restrict__ spheres, const int64_t* __restrict__ box_offsets, int max_chunks, int32_t* __restrict__ cc,
     const int64_t* __restrict__ counts, const double* __restrict__ pose_all, const int64_t* __restrict__ box_start,
-    double* __restrict__ out_points, int32_t* __restrict__ out_index) {
+    double* __restrict__ out_points, int32_t* __restrict__ out_index, int64_t out_capacity) {
+    __shared__ unsigned long long s_grid[CROP_GRID * CROP_GRID];         // 32 KiB
+    __shared__ float s_pl[CROP_BATCH * DAL3_PLANE_DOUBLES];               // 6 KiB
+    __shared__ int s_cnt[CROP_WAVES][CROP_BATCH];                         // count pass: a wave's members per detection
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int chunk = blockIdx.x * CROP_WAVES + (threadIdx.x >> 6);
     const int64_t p0 = point_offsets[frame], n_pts = point_offsets[frame + 1] - p0;
-    if ((int64_t)chunk * CROP_CHUNK >= n_pts) return;
+    if ((int64_t)blockIdx.x * CROP_WAVES * CROP_CHUNK >= n_pts) return;  // the whole workgroup is past the sweep's end
+    const bool active = (int64_t)chunk * CROP_CHUNK < n_pts;             // (a wave past it still joins the barriers)
     const bool last_chunk = (int64_t)(chunk + 1) * CROP_CHUNK >= n_pts;
     const int64_t k0 = box_offsets[frame], k1 = box_offsets[frame + 1];
     float x[CROP_ROUNDS], y[CROP_ROUNDS], z[CROP_ROUNDS];
@@ -50,7 +78,7 @@ __global__ __launch_bounds__(64 * CROP_WAVES) void crop_pass_kernel(
 #pragma unroll
     for (int r = 0; r < CROP_ROUNDS; ++r) {
         const int64_t i = (int64_t)chunk * CROP_CHUNK + r * 64 + lane;
-        const bool ok = i < n_pts;
+        const bool ok = active && i < n_pts;
         const float* p = points + (p0 + (ok ? i : 0)) * 3;
         x[r] = p[0];
         y[r] = p[1];
@@ -58,39 +86,94 @@ __global__ __launch_bounds__(64 * CROP_WAVES) void crop_pass_kernel(
         valid |= (uint32_t)ok << r;
     }
     const double* pose = FILL ? pose_all + (int64_t)frame * 16 : nullptr;
-    for (int64_t k = k0; k < k1; ++k) {
-        const double* pl = planes + k * DAL3_PLANE_DOUBLES;              // uniform address: scalar loads
-        int64_t base = 0;
-        if (FILL) {                                                      // nothing of this detection in this chunk: skip
-            const int32_t excl = cc[k * max_chunks + chunk];
-            const int64_t next = last_chunk ? counts[k] : (int64_t)cc[k * max_chunks + chunk + 1];
-            if (next == excl) continue;
-            base = box_start[k] + excl;
+    for (int64_t kb = k0; kb < k1; kb += CROP_BATCH) {
+        const int nb = (int)(k1 - kb < CROP_BATCH ? k1 - kb : CROP_BATCH);
+        if (kb > k0) __syncthreads();                                    // everyone is done with the previous batch's grid
+        for (int i = threadIdx.x; i < CROP_GRID * CROP_GRID; i += 64 * CROP_WAVES) s_grid[i] = 0ull;
+        for (int i = threadIdx.x; i < nb * DAL3_PLANE_DOUBLES; i += 64 * CROP_WAVES)
+            s_pl[i] = (float)planes[kb * DAL3_PLANE_DOUBLES + i];
+        __syncthreads();
+        if ((int)threadIdx.x < nb) {                                     // one thread rasterises one detection's ball
+            const float* sp = spheres + (kb + threadIdx.x) * 4;
+            // radius rounded UP (sqrt's last bit, then a relative 1e-6 on top: the ball itself carries a margin of
+            // 1 mm + 1e-3 r, geom.cull_spheres); r2 = +inf (no cull) -> the whole grid
+            const float rad = sqrtf(sp[3]) * 1.000001f;
+            const int cx0 = crop_cell(sp[0] - rad), cx1 = crop_cell(sp[0] + rad);
+            const int cy0 = crop_cell(sp[1] - rad), cy1 = crop_cell(sp[1] + rad);
+            const bool all = !finite_f32(rad) || !finite_f32(sp[0]) || !finite_f32(sp[1]);
+            const unsigned long long bit = 1ull << threadIdx.x;
+            for (int cy = all ? 0 : cy0; cy <= (all ? CROP_GRID - 1 : cy1); ++cy)
+                for (int cx = all ? 0 : cx0; cx <= (all ? CROP_GRID - 1 : cx1); ++cx)
+                    atomicOr(&s_grid[cy * CROP_GRID + cx], bit);
         }
-        const float cx = spheres[k * 4 + 0], cy = spheres[k * 4 + 1], cz = spheres[k * 4 + 2];
-        const uint32_t r2 = __float_as_uint(spheres[k * 4 + 3]);
-        int cnt = 0;
+        __syncthreads();
+        if (!active) continue;
+        // lane j carries detection kb + j's running state: its member count in this chunk (count pass) / the output
+        // row of its next member (fill pass)
+        int64_t state = 0;
+        if (FILL) {
+            bool any = false;
+            if (lane < nb) {
+                const int64_t k = kb + lane;
+                const int32_t excl = cc[k * max_chunks + chunk];
+                const int64_t next = last_chunk ? counts[k] : (int64_t)cc[k * max_chunks + chunk + 1];
+                any = next != excl;
+                state = box_start[k] + excl;
+            }
+            if (__ballot(any) == 0) continue;                            // nothing of this batch in this chunk
+        }
+        const unsigned long long all_bits = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
+        if (!FILL) s_cnt[threadIdx.x >> 6][lane] = 0;                    // (wave-private row: LDS operations of a wave are in order)
 #pragma unroll
         for (int r = 0; r < CROP_ROUNDS; ++r) {
-            const bool cand = ((valid >> r) & 1u) && sphere_candidate(x[r], y[r], z[r], cx, cy, cz, r2);
-            if (__ballot(cand) == 0) continue;                           // wave-uniform
-            const bool in = cand && inside_box_f32(pl, x[r], y[r], z[r]);
-            const uint64_t m = __ballot(in);
-            if (FILL) {
-                if (in) {
-                    const int64_t o = base + lanes_below(m);
-                    const double px = x[r], py = y[r], pz = z[r];        // concatenate([lidars_o, ones]) is float64
-                    out_points[o * 3 + 0] = pose[0] * px + pose[1] * py + pose[2] * pz + pose[3];
-                    out_points[o * 3 + 1] = pose[4] * px + pose[5] * py + pose[6] * pz + pose[7];
-                    out_points[o * 3 + 2] = pose[8] * px + pose[9] * py + pose[10] * pz + pose[11];
-                    if (out_index) out_index[o] = (int32_t)((int64_t)chunk * CROP_CHUNK + r * 64 + lane);
+            const float px = x[r], py = y[r], pz = z[r];
+            unsigned long long cand = 0ull;
+            if ((valid >> r) & 1u)
+                cand = (finite_f32(px) && finite_f32(py) && finite_f32(pz)) ? s_grid[crop_cell(py) * CROP_GRID + crop_cell(px)]
+                                                                           : all_bits;
+            unsigned long long in = 0ull;
+            while (cand) {                                               // per lane: its own candidates only
+                const int j = __builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                if (inside_box_lds(s_pl + j * DAL3_PLANE_DOUBLES, px, py, pz)) in |= 1ull << j;
+            }
+            if (!FILL) {
+                // counting needs no order: every member adds one to its detection's counter, per lane (with the ordered
+                // loop below a shuffled sweep — half a dozen detections with a member in every round — paid an iteration
+                // per detection and round in BOTH passes)
+                while (in) {
+                    atomicAdd(&s_cnt[threadIdx.x >> 6][__builtin_ctzll(in)], 1);
+                    in &= in - 1ull;
                 }
-                base += __popcll(m);
-            } else {
-                cnt += __popcll(m);
+                continue;
+            }
+            // ordered compaction, detection by detection, over the detections that HAVE a member in this round
+            for (;;) {
+                const uint64_t has = __ballot(in != 0ull);
+                if (has == 0) break;
+                const int src = __builtin_ctzll(has);
+                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)in, src);
+                const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(in >> 32), src);
+                const int j = lo ? __builtin_ctz(lo) : 32 + __builtin_ctz(hi);      // wave-uniform
+                const bool mine = (in >> j) & 1ull;
+                const uint64_t m = __ballot(mine);
+                if (FILL) {
+                    const int64_t base = ((int64_t)__builtin_amdgcn_readlane((uint32_t)((uint64_t)state >> 32), j) << 32) |
+                                         (int64_t)__builtin_amdgcn_readlane((uint32_t)(uint64_t)state, j);
+                    const int64_t o = base + lanes_below(m);
+                    if (mine && o < out_capacity) {      // (a caller that sized `out` from an estimate: rows past it are dropped)
+                        const double dx = px, dy = py, dz = pz;          // concatenate([lidars_o, ones]) is float64
+                        out_points[o * 3 + 0] = pose[0] * dx + pose[1] * dy + pose[2] * dz + pose[3];
+                        out_points[o * 3 + 1] = pose[4] * dx + pose[5] * dy + pose[6] * dz + pose[7];
+                        out_points[o * 3 + 2] = pose[8] * dx + pose[9] * dy + pose[10] * dz + pose[11];
+                        if (out_index) out_index[o] = (int32_t)((int64_t)chunk * CROP_CHUNK + r * 64 + lane);
+                    }
+                }
+                if (lane == j) state += __popcll(m);
+                in &= ~(1ull << j);
             }
         }
-        if (!FILL && lane == 0) cc[k * max_chunks + chunk] = cnt;
+        if (!FILL && lane < nb) cc[(kb + lane) * max_chunks + chunk] = s_cnt[threadIdx.x >> 6][lane];
     }
 }
 
@@ -136,7 +219,7 @@ hipError_t launch_crop_count(const float* points, const int64_t* point_offsets, 
     if (F > 0 && max_chunks > 0 && K_total > 0)
         hipLaunchKernelGGL(crop_pass_kernel<false>, dim3((max_chunks + CROP_WAVES - 1) / CROP_WAVES, F), dim3(64 * CROP_WAVES),
                            0, s, points, point_offsets, planes, spheres, box_offsets, max_chunks, cc, (const int64_t*)nullptr,
-                           (const double*)nullptr, (const int64_t*)nullptr, (double*)nullptr, (int32_t*)nullptr);
+                           (const double*)nullptr, (const int64_t*)nullptr, (double*)nullptr, (int32_t*)nullptr, (int64_t)0);
     if (K_total > 0)
         hipLaunchKernelGGL(crop_scan_kernel, dim3((unsigned)((K_total + 3) / 4)), dim3(256), 0, s, point_offsets, box_offsets,
                            F, max_chunks > 0 ? max_chunks : 1, cc, counts);
@@ -147,12 +230,60 @@ hipError_t launch_crop_fill(const float* points, const int64_t* point_offsets, c
                             const float* spheres, const int64_t* box_offsets, int F, int64_t K_total,
                             int64_t max_points_per_frame, const double* pose, const int64_t* counts,
                             const int64_t* box_start, const int32_t* cc, double* out_points, int32_t* out_index,
-                            hipStream_t s) {
+                            int64_t out_capacity, hipStream_t s) {
     const int max_chunks = (int)((max_points_per_frame + CROP_CHUNK - 1) / CROP_CHUNK);
     if (F > 0 && max_chunks > 0 && K_total > 0)
         hipLaunchKernelGGL(crop_pass_kernel<true>, dim3((max_chunks + CROP_WAVES - 1) / CROP_WAVES, F), dim3(64 * CROP_WAVES),
                            0, s, points, point_offsets, planes, spheres, box_offsets, max_chunks, const_cast<int32_t*>(cc),
-                           counts, pose, box_start, out_points, out_index);
+                           counts, pose, box_start, out_points, out_index, out_capacity);
+    return hipGetLastError();
+}
+
+
+// box_start / out_offsets from counts, on the device (round 5: the chained run has no host round trip between count and
+// fill). The detections are laid out in the caller's ORDER (order[i] = the detection at output position i; NULL = as
+// numbered): out_offsets[i] = rows in front of position i (K+1 entries, the last = the total), box_start[order[i]] =
+// out_offsets[i], box_start[K] = the total. One workgroup: K is a segment's detections (~1e4), a few microseconds.
+__global__ __launch_bounds__(1024) void crop_starts_kernel(const int64_t* __restrict__ counts, const int64_t* __restrict__ order,
+                                                           int64_t K, int64_t* __restrict__ box_start,
+                                                           int64_t* __restrict__ out_offsets) {
+    __shared__ int64_t s_wave[16];
+    __shared__ int64_t s_run;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < K; i0 += 1024) {
+        const int64_t i = i0 + threadIdx.x;
+        const int64_t k = i < K ? (order ? order[i] : i) : 0;
+        const int64_t v = i < K ? counts[k] : 0;
+        int64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int64_t before = s_run;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        const int64_t excl = before + incl - v;
+        if (i < K) {
+            box_start[k] = excl;
+            if (out_offsets) out_offsets[i] = excl;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_run = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        box_start[K] = s_run;
+        if (out_offsets) out_offsets[K] = s_run;
+    }
+}
+
+hipError_t launch_crop_starts(const int64_t* counts, const int64_t* order, int64_t K, int64_t* box_start, int64_t* out_offsets,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(crop_starts_kernel, dim3(1), dim3(1024), 0, s, counts, order, K, box_start, out_offsets);
     return hipGetLastError();
 }
 

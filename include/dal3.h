@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dal3_stream;               /* hipStream_t */
 
-#define DAL3_VERSION 131                 /* 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums; .1: dal3_tr_fc_*, dal3_tr_wgrad_final_many, dal3_parse_box_pred* */
+#define DAL3_VERSION 140                 /* 0.1.4: dal3_crop_starts, dal3_crop_fill takes out_capacity; 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums; .1: dal3_tr_fc_*, dal3_tr_wgrad_final_many, dal3_parse_box_pred* */
 
 enum {
     DAL3_OK = 0,
@@ -295,10 +295,15 @@ int dal3_points_in_boxes(const void* points, int points_f64, int64_t P, int64_t 
  * (already in Waymo convention), box_offsets (F+1); max_points_per_frame bounds the launch. spheres (K_total,4)
  * f32 [cx,cy,cz,r^2]: a ball that CONTAINS the detection with a margin well above fp32 rounding (the library
  * culls with it before the exact test; it never decides membership; r^2 = +inf disables the cull).
- * dal3_crop_count -> counts (K_total) i64 = points inside each detection. The caller forms box_start (K_total+1)
- * = exclusive prefix of counts and allocates out_points (box_start[K_total],3) f64, then
+ * dal3_crop_count -> counts (K_total) i64 = points inside each detection. box_start (K_total+1) = where each
+ * detection's rows begin in out_points, [K_total] = the total: formed by the caller (exclusive prefix of counts) or, on
+ * the device, by dal3_crop_starts -> box_start and (optional) out_offsets (K_total+1) for the detections laid out in
+ * `order` (order[i] = the detection at output position i, e.g. track-major; NULL = as numbered): out_offsets[i] = rows
+ * in front of position i, box_start[order[i]] = out_offsets[i]. out_points is (>= out_capacity, 3) f64; then
  * dal3_crop_fill -> out_points = veh_to_global (pose (F,16) f64 row-major) applied to the members, per detection
  * in sweep order (what `pose @ [lidars[indices]; 1]` yields); out_index (optional, i32) = index within the sweep.
+ * Rows at or past out_capacity are not written (a caller that sized out_points from an estimate compares
+ * box_start[K_total] with it afterwards; one that sized it from the total passes that total).
  * workspace: dal3_crop_workspace_bytes(K_total, max_points_per_frame); it carries state from count to fill. */
 size_t dal3_crop_workspace_bytes(int64_t K_total, int64_t max_points_per_frame);
 int dal3_crop_count(const float* points, const int64_t* point_offsets, const double* planes, const float* spheres,
@@ -307,7 +312,9 @@ int dal3_crop_count(const float* points, const int64_t* point_offsets, const dou
 int dal3_crop_fill(const float* points, const int64_t* point_offsets, const double* planes, const float* spheres,
                    const int64_t* box_offsets, int F, int64_t K_total, int64_t max_points_per_frame, const double* pose,
                    const int64_t* counts, const int64_t* box_start, double* out_points, int32_t* out_index,
-                   const void* workspace, size_t workspace_bytes, dal3_stream stream);
+                   int64_t out_capacity, const void* workspace, size_t workspace_bytes, dal3_stream stream);
+int dal3_crop_starts(const int64_t* counts, const int64_t* order, int64_t K_total, int64_t* box_start,
+                     int64_t* out_offsets, dal3_stream stream);
 
 /* ---- training-mode building blocks of the shared-MLP stacks (first slice) --------------
  * What loss.backward() drives through Conv1d(k=1) + BatchNorm1d (batch statistics) + ReLU + max over points

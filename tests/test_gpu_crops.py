@@ -144,3 +144,62 @@ def test_crop_extraction_without_any_detection():
     frames = crops.extract_crops([pts, pts[:100]], [box9[:0], box9[:0]], [pose, pose], return_index=True)
     assert len(frames) == 2 and all(len(f["point"]) == 0 and len(f["index"]) == 0 and list(f["point"]) == [] and
                                     f["point"].numpy_list() == [] and f["bbox"].shape == (0, 7) for f in frames)
+
+
+def test_crop_extraction_more_than_64_detections_in_a_frame_vs_oracle():
+    """the cull rasterises 64 detections at a time (one mask bit each): a frame with 150 goes through three grid
+    passes; and a frame whose detections sit far outside the grid's +-80 m (clamped to its border cells)"""
+    pts, box9, _, _, pose = synth.sweep(48, "many", n_points=60000, n_boxes=150)
+    far_pts, far_box, _, _, far_pose = synth.sweep(48, "far", n_points=9000, n_boxes=6)
+    far_pts = far_pts + np.float32([300.0, -250.0, 0.0])
+    far_box = far_box.copy()
+    far_box[:, :2] += np.float32([300.0, -250.0])
+    frames = crops.extract_crops([pts, far_pts], [box9, far_box], [pose, far_pose], return_index=True)
+    for (p, b, ps), rec in zip(((pts, box9, pose), (far_pts, far_box, far_pose)), frames):
+        inside = G.points_in_rbbox(p, rec["boxes_lidar"])
+        assert inside.sum() > 500
+        _, _, pts_g = G.extract_crops(p, b, ps)
+        for k, idx in enumerate(rec["index"]):
+            assert np.array_equal(idx.cpu().numpy(), np.nonzero(inside[:, k])[0]), k
+            if pts_g[k].size:
+                assert np.abs(rec["point"][k].cpu().numpy() - pts_g[k]).max() < 1e-9
+
+
+def test_crop_plan_track_major_order_capacity_and_reuse():
+    """crops.CropPlan: the planned run (count, device-side starts, fill; no host step in between) with the detections
+    laid out TRACK-major (detection k of every frame = object k): equal, row for row, to the per-detection results of
+    extract_crops; offsets by output position; a second run of the same plan gives the same bits; with a capacity below
+    the total the rows in front of it are intact, nothing is written past it and total() reports the real size."""
+    F, K = 4, 9
+    sweeps, dets, poses = [], [], []
+    for f in range(F):
+        pts, box9, _, _, pose = synth.sweep(49, f"pl{f}", n_points=15000 + 700 * f, n_boxes=K)
+        sweeps.append(pts)
+        dets.append(box9)
+        poses.append(pose)
+    frames = crops.extract_crops(sweeps, dets, poses)
+    want = [[frames[f]["point"][k].cpu().numpy() for f in range(F)] for k in range(K)]      # [object][frame]
+    order = np.array([f * K + k for k in range(K) for f in range(F)])                       # output position -> detection
+    d_pts = torch.from_numpy(np.concatenate(sweeps)).cuda()
+    plan = crops.CropPlan([s.shape[0] for s in sweeps], dets, poses, order=order)
+    out, offsets = plan.run(d_pts)
+    total = plan.total()
+    off = offsets.cpu().numpy()
+    flat = np.concatenate([want[k][f] for k in range(K) for f in range(F)])
+    assert total == flat.shape[0] == off[-1] and plan.capacity >= total
+    assert np.array_equal(np.diff(off), [want[k][f].shape[0] for k in range(K) for f in range(F)])
+    assert np.array_equal(out[:total].cpu().numpy(), flat)
+    start = plan.start.cpu().numpy()
+    assert all(start[order[i]] == off[i] for i in range(F * K))
+    first = out[:total].clone()
+    out2, _ = plan.run(d_pts)
+    assert out2.data_ptr() == out.data_ptr() and torch.equal(out2[:total], first)
+    cap = total // 2
+    small = crops.CropPlan([s.shape[0] for s in sweeps], dets, poses, order=order, capacity=cap)
+    guard = torch.full((cap + 64, 3), -7.0, dtype=torch.float64, device="cuda")
+    small.out = guard[:cap]                                                               # rows [cap, cap+64) must stay -7
+    o, _ = small.run(d_pts)
+    assert small.total() == total > cap
+    assert np.array_equal(o.cpu().numpy(), flat[:cap]) and bool((guard[cap:] == -7.0).all())
+    with pytest.raises(ValueError):
+        crops.CropPlan([s.shape[0] for s in sweeps], dets, poses, order=order[:-1])

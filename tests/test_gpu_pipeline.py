@@ -81,3 +81,63 @@ def test_extract_prepare_refine_write_back():
             yaw_g = new[t][k, 6] + np.arctan2(m[1, 0], m[0, 0])
             want_yaw = refined[k, 6] + np.arctan2(m_best[1, 0], m_best[0, 0])
             assert abs(np.angle(np.exp(1j * (yaw_g - want_yaw)))) < 1e-4
+
+
+def test_segment_plan_chain_equals_the_step_by_step_run():
+    """segment.SegmentPlan: the same segment, chained on the device — crops laid out track-major, the prep kernels
+    reading the tracks' rows in place, heads, write-back, nothing downloaded in between — gives, bit for bit, the
+    detection rows the step-by-step run (each step handing NumPy track dictionaries to the next, as the reference's
+    files do) gives: static tracks through the static head, dynamic tracks (one item per track-frame) through the
+    dynamic head. A second run of the plan reuses its buffers and repeats the bits; a plan with too small a crop
+    capacity says so."""
+    segment = importlib.import_module("3dal_pytorch_amd.segment")
+    poses, sweeps, dets, gbox = _segment(n_frames=7, n_obj=6, seed=71)
+    F, K = len(poses), gbox.shape[0]
+    tokens = [f"frame{f:04d}" for f in range(F)]
+    kinds = ["static", "dynamic", "static", "dynamic", "static", "static"]
+    scores = [[0.5 + 0.05 * ((f + k) % F) for f in range(F)] for k in range(K)]
+    static = build_model("static_one", synth.state_dict("static_one"))
+    dynamic = build_model("dynamic", synth.state_dict("dynamic"))
+    # ---- step by step
+    frames = crops.extract_crops(sweeps, dets, poses)
+    tracks = [{"bbox": [frames[f]["bbox"][k] for f in range(F)], "point": [frames[f]["point"][k].cpu().numpy() for f in range(F)],
+               "score": scores[k], "token": tokens, "match": [f"gt{k}"] * F, "type": [1] * F} for k in range(K)]
+    v2g = {tokens[f]: poses[f] for f in range(F)}
+    det_rows = {tokens[f]: frames[f]["boxes_lidar"].copy() for f in range(F)}
+    s_tr = [tracks[k] for k in range(K) if kinds[k] == "static"]
+    best = [int(np.argmax(t["score"])) for t in s_tr]
+    pts, init = prep.prepare_static_batch(s_tr, [poses[b] for b in best], n_points=1024, sampler="device")
+    want_s, _ = post.writeback_static(s_tr, v2g, {(i, t): True for i in range(len(s_tr)) for t in tokens},
+                                      static.refine(pts, init), det_rows)
+    d_tr = [tracks[k] for k in range(K) if kinds[k] == "dynamic"]
+    items = [(i, f) for i in range(len(d_tr)) for f in range(F)]
+    dp, db, di = prep.prepare_dynamic_batch(d_tr, items, [poses[f] for _, f in items], n_per_frame=256, sampler="device")
+    want_d, _ = post.writeback_dynamic(d_tr, v2g, {(i, t): True for i in range(len(d_tr)) for t in tokens},
+                                       dynamic.refine(dp, db, di), det_rows)
+    # ---- chained
+    plan = segment.SegmentPlan([s.shape[0] for s in sweeps], dets, poses,
+                               [{"kind": kinds[k], "dets": [(f, k) for f in range(F)], "score": scores[k]} for k in range(K)],
+                               static, dynamic, n_static_points=1024, n_per_frame=256, dynamic_batch=5)   # (ragged batches: 5,5,4)
+    d_pts = torch.from_numpy(np.concatenate(sweeps)).cuda()
+    plan.run(d_pts)
+    assert not plan.overflowed()
+    got_s, got_d = plan.detections("static"), plan.detections("dynamic")
+    moved = 0
+    for t in tokens:
+        assert np.array_equal(got_s[t], want_s[t]), t
+        assert np.array_equal(got_d[t], want_d[t]), t
+        moved += int((got_s[t] != det_rows[t]).any(1).sum()) + int((got_d[t] != det_rows[t]).any(1).sum())
+    assert moved == K * F                                                             # every tracked detection was rewritten
+    res = plan.run(d_pts)
+    torch.cuda.synchronize()
+    assert bool((res["static"][1].cpu().numpy().reshape(4, F) >= 0).all())
+    again = plan.detections("static")
+    assert all(np.array_equal(again[t], got_s[t]) for t in tokens)
+    small = segment.SegmentPlan([s.shape[0] for s in sweeps], dets, poses,
+                                [{"kind": "static", "dets": [(f, 0) for f in range(F)], "score": scores[0]}], static, None,
+                                n_static_points=1024, capacity=100)
+    small.run(d_pts)
+    assert small.overflowed()
+    small.grow()
+    small.run(d_pts)
+    assert not small.overflowed() and np.array_equal(small.detections("static")[tokens[0]][0], got_s[tokens[0]][0])

@@ -55,41 +55,36 @@ def measure(args=None, **kw):
     poses = [base[f % args.distinct][4] for f in range(args.frames)]
     crops.extract_crops(sweeps[:2], dets[:2], poses[:2])                       # warm-up
     torch.cuda.synchronize()
+    # (1) the reference-shaped call: a list of sweeps in, per-frame dicts of ragged rows out (concatenation of the
+    # sweeps, the plan's host arithmetic and uploads, one host sync for the sizes)
     t0 = time.perf_counter()
     frames = crops.extract_crops(sweeps, dets, poses, return_index=True)
     torch.cuda.synchronize()
     t_call = time.perf_counter() - t0
     members = int(sum(fr["point"].counts().sum() for fr in frames))
-
-    # device part alone, through the C ABI
+    # (2) the planned call (crops.CropPlan): the segment's sweeps already ONE resident tensor, the plan built once;
+    # run() = count + starts + fill on the stream, no host work in between; wall time of run() + one synchronise
     F, K = args.frames, args.frames * args.boxes
-    lib = hip.lib()
     d_pts = torch.cat(sweeps)
     n_pts = [int(s.shape[0]) for s in sweeps]
-    d_poff = torch.tensor(np.concatenate([[0], np.cumsum(n_pts)]), dtype=torch.int64, device="cuda")
-    d_boff = torch.arange(0, K + 1, args.boxes, dtype=torch.int64, device="cuda")
-    planes = geom.planes_to_device(np.concatenate([geom.box_planes(crops.waymo_boxes(d)) for d in dets]), "cuda")
-    sph = torch.from_numpy(np.ascontiguousarray(np.concatenate([geom.cull_spheres(crops.waymo_boxes(d)) for d in dets]))).cuda()
-    d_pose = torch.from_numpy(np.stack(poses)).cuda()
-    ws = torch.empty(int(lib.dal3_crop_workspace_bytes(K, max(n_pts))), dtype=torch.uint8, device="cuda")
-    counts = torch.zeros(K, dtype=torch.int64, device="cuda")
-    start = torch.zeros(K + 1, dtype=torch.int64, device="cuda")
-    out = torch.empty((members, 3), dtype=torch.float64, device="cuda")
-    idx = torch.empty(members, dtype=torch.int32, device="cuda")
-
-    def device_part():
-        hip.check(lib.dal3_crop_count(hip.ptr(d_pts), hip.ptr(d_poff), hip.ptr(planes), hip.ptr(sph), hip.ptr(d_boff), F, K, max(n_pts),
-                                      hip.ptr(counts), hip.ptr(ws), ws.numel(), hip.stream()))
-        start[1:] = torch.cumsum(counts, 0)
-        hip.check(lib.dal3_crop_fill(hip.ptr(d_pts), hip.ptr(d_poff), hip.ptr(planes), hip.ptr(sph), hip.ptr(d_boff), F, K,
-                                     max(n_pts), hip.ptr(d_pose), hip.ptr(counts), hip.ptr(start), hip.ptr(out), hip.ptr(idx),
-                                     hip.ptr(ws), ws.numel(), hip.stream()))
-    for _ in range(2):
-        device_part()
+    t0 = time.perf_counter()
+    plan = crops.CropPlan(n_pts, dets, poses, return_index=True)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter() - t0
+    plan.run(d_pts)                                                             # sizes the output (one sync), warm-up
+    assert plan.total() == members
+    torch.cuda.synchronize()
+    walls = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        plan.run(d_pts)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+    t_run = sorted(walls)[len(walls) // 2]
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(10):
-        device_part()
+        plan.run(d_pts)
     b.record()
     b.synchronize()
     ms = a.elapsed_time(b) / 10
@@ -108,6 +103,8 @@ def measure(args=None, **kw):
                       "roofline": {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0,
                                    "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 4),
                                    "algorithmic_bytes": nbytes},
+                      "planned_call_ms": round(t_run * 1e3, 3), "planned_call_over_kernels": round(t_run * 1e3 / ms, 2),
+                      "plan_build_ms": round(t_plan * 1e3, 1),
                       "call_ms_with_host_setup": round(t_call * 1e3, 1),
                       "frames_per_s_call": round(F / t_call, 1),
                       "host_numpy_membership_frames_per_s": round(1.0 / t_cpu, 2)})
