@@ -155,34 +155,49 @@ class CapturedTrainStep:
 
         cap = CapturedTrainStep(model, optimizer, step_fn, *example_inputs)
         loss = cap(*batch)            # copies the batch into the captured buffers, replays, returns the loss tensor
+
+    optimizer_in_graph=False (round 5): forward, criterion and backward are the graph; `optimizer.step()` runs eagerly
+    behind every replay, with the optimizer exactly as the train drivers build it (static_train.py:220, no
+    `capturable=True`). Why: a capturable Adam keeps its step counters on the device and computes the two bias
+    corrections with `_foreach_pow(scalar, [0-dim step tensors])`, which has no multi-tensor path — 120 single-element
+    kernels per step (one per parameter and beta) plus 8 more multi-tensor launches than the plain optimizer; inside a
+    replay every kernel node costs at least ~4.5 us of stream time, so the captured step was SLOWER than the eager one
+    (6.93 vs 6.55 ms; profiles/r05_train_graph.json: 324 vs 185 dispatches, 0.75 ms of them those kernels). With the
+    optimizer outside, the replay is the eager step's kernels without its launch gaps and the host issues one replay
+    and the optimizer's ~14 launches per step instead of ~185.
     """
 
-    def __init__(self, model, optimizer, step_fn, *example_inputs, warmup=3):
+    def __init__(self, model, optimizer, step_fn, *example_inputs, warmup=3, optimizer_in_graph=True):
         if not model.training:
             raise RuntimeError("capture the train-mode path: call model.train() first")
         if getattr(model, "sampler", "device") != "device":
             raise RuntimeError("graph capture needs sampler='device' (the NumPy sampler synchronises with the host)")
         self.inputs = [None if t is None else torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
                        .copy_(t) for t in example_inputs]
+        self.optimizer, self.optimizer_in_graph = optimizer, optimizer_in_graph
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                                  # also sizes every scratch buffer
                 optimizer.zero_grad(set_to_none=True)
                 step_fn(*self.inputs).backward()
-                optimizer.step()
+                if optimizer_in_graph:
+                    optimizer.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.loss = step_fn(*self.inputs)
-            self.loss.backward()
-            optimizer.step()
+            self.loss.backward()                                     # (gradients: the graph's own buffers, rewritten by every replay)
+            if optimizer_in_graph:
+                optimizer.step()
 
     def __call__(self, *inputs):
         for dst, src in zip(self.inputs, inputs):
             if dst is not None:
                 dst.copy_(src)
         self.graph.replay()
+        if not self.optimizer_in_graph:
+            self.optimizer.step()
         return self.loss

@@ -96,9 +96,11 @@ def test_capture_refuses_the_numpy_sampler_and_train_mode():
         graph.CapturedRefine(model, p.transpose(2, 1), i, g)
 
 
-def test_captured_train_step_matches_eager_steps():
-    """forward + criterion + backward + Adam as one hipGraph: warm-up step + one replay leave the parameters where two
-    eager steps leave them (Dropout off: its draw differs between the two runs' RNG positions)"""
+@pytest.mark.parametrize("inside", [True, False])
+def test_captured_train_step_matches_eager_steps(inside):
+    """forward + criterion + backward + Adam as one hipGraph (inside), or forward + criterion + backward as the graph
+    with the plain Adam stepping eagerly behind each replay (round 5): warm-up step + replays leave the parameters where
+    the same number of eager steps leave them (Dropout off: its draw differs between the two runs' RNG positions)"""
     losses = importlib.import_module("3dal_pytorch_amd.losses")
     B, N = 8, 1024
     p, i, g = (torch.from_numpy(a).cuda() for a in synth.static_crops(B, N, seed=6))
@@ -112,13 +114,18 @@ def test_captured_train_step_matches_eager_steps():
     for mode in ("graph", "eager"):
         model = build_model("static_one", synth.state_dict("static_one", seed=6)).train()
         model.ins_seg.dropout.p = 0.0
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, **({"capturable": True} if inside else {}))
 
         def step(p_, i_, g_, model=model):
             return crit(model(p_, i_, g_), *labels)["total_loss"]
-        if mode == "graph":
+        if mode == "graph" and inside:
             cap = graph.CapturedTrainStep(model, opt, step, pts, i, g, warmup=1)      # one real step; capturing runs nothing
             last = cap(pts, i, g)                                                     # the second step
+        elif mode == "graph":
+            # the warm-up runs forward + backward only (no optimizer step): two replays = two steps
+            cap = graph.CapturedTrainStep(model, opt, step, pts, i, g, warmup=1, optimizer_in_graph=False)
+            cap(pts, i, g)
+            last = cap(pts, i, g)
         else:
             for _ in range(2):
                 opt.zero_grad(set_to_none=True)

@@ -26,8 +26,14 @@ def main():
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--backends", default="hip,torch")
-    ap.add_argument("--adam", default="default", choices=["default", "fused"],
-                    help="default: torch.optim.Adam as static_train.py:220 builds it; fused: the same with fused=True")
+    ap.add_argument("--adam", default="default", choices=["default", "fused", "capturable"],
+                    help="default: torch.optim.Adam as static_train.py:220 builds it; fused: the same with fused=True; capturable: "
+                         "with capturable=True (what a hipGraph capture needs: its step counter lives on the device)")
+    ap.add_argument("--graph-optimizer", default="inside", choices=["inside", "outside"],
+                    help="inside: Adam(capturable=True) captured with the step; outside: forward + backward captured, the plain Adam "
+                         "stepping eagerly behind every replay (graph.CapturedTrainStep optimizer_in_graph=False)")
+    ap.add_argument("--graph-only", action="store_true",
+                    help="with --graph: skip the eager timed loop (a kernel trace of this run then holds the replays only)")
     ap.add_argument("--graph", action="store_true", help="also time the step captured into a hipGraph (device sampler)")
     ap.add_argument("--kind", default="static_one", choices=["static_one", "dynamic"],
                     help="static_train.py's StaticModelOneBoxEst (64 x 4096) or dynamic_train.py's DynamicModel (5 x 1024 points "
@@ -81,7 +87,7 @@ def main():
         # --adam default: what static_train.py:220 constructs (torch picks its multi-tensor "foreach" path: ~12 launches
         # per step over the 150 tensors); fused: torch.optim.Adam(..., fused=True), ONE multi-tensor launch — the same
         # update, the setting this path is measured and supported with when the optimizer's launches matter
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, **({"fused": True} if args.adam == "fused" else {}))
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, **({"fused": True} if args.adam == "fused" else {"capturable": True} if args.adam == "capturable" else {}))
 
         def step():
             o = model(pts, init, gt)
@@ -96,15 +102,16 @@ def main():
         torch.cuda.synchronize()
         # median of per-step times (HIP events around each step): a fresh box's first seconds run slower, and a mean
         # over five steps moved by 20 % between two runs of the same binary
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.iters + 1)]
+        n_eager = 1 if (args.graph and args.graph_only) else args.iters
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_eager + 1)]
         marks[0].record()
         t_host = time.perf_counter()
-        for i in range(args.iters):
+        for i in range(n_eager):
             loss = step()
             marks[i + 1].record()
-        host_ms = (time.perf_counter() - t_host) / args.iters * 1e3      # the host's time to ISSUE a step (no sync inside)
+        host_ms = (time.perf_counter() - t_host) / n_eager * 1e3         # the host's time to ISSUE a step (no sync inside)
         torch.cuda.synchronize()
-        per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.iters))
+        per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_eager))
         ms = per[len(per) // 2]
         g_ms = None
         if args.graph and args.sampler == "device":
@@ -118,21 +125,31 @@ def main():
             gm.train_backend, gm.sampler = ("hip" if backend == "hip_f16x3" else backend), "device"
             if backend == "hip_f16x3":
                 gm.precision = "f16x3"
-            gopt = torch.optim.Adam(gm.parameters(), lr=1e-3, weight_decay=1e-4, capturable=True)
+            inside = args.graph_optimizer == "inside"
+            gopt = torch.optim.Adam(gm.parameters(), lr=1e-3, weight_decay=1e-4, **({"capturable": True} if inside else {}))
             cap = graph.CapturedTrainStep(gm, gopt, lambda p_, i_, g_: crit(gm(p_, i_, g_), *labels)["total_loss"],
-                                          pts, init, gt)
+                                          pts, init, gt, optimizer_in_graph=inside)
             for _ in range(2):
                 cap(pts, init, gt)
             torch.cuda.synchronize()
+            gm_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.iters + 1)]
             t0 = time.perf_counter()
-            for _ in range(args.iters):
+            gm_marks[0].record()
+            for i in range(args.iters):
                 cap(pts, init, gt)
+                gm_marks[i + 1].record()
+            g_issue = (time.perf_counter() - t0) / args.iters * 1e3
             torch.cuda.synchronize()
             g_ms = round((time.perf_counter() - t0) / args.iters * 1e3, 2)
+            g_per = sorted(gm_marks[i].elapsed_time(gm_marks[i + 1]) for i in range(args.iters))
+            g_extra = {"graph_ms_median_of_events": round(g_per[len(g_per) // 2], 2), "graph_host_issue_ms": round(g_issue, 3),
+                       "graph_optimizer": args.graph_optimizer}
             model, opt = gm, gopt
         out[backend] = {"ms": round(ms, 2), "host_issue_ms": round(host_ms, 2), "graph_ms": g_ms, "crops_per_s": round(B / ms * 1e3, 1), "tflops_per_point_stacks": round(flop / ms / 1e9, 1),
                         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "loss": round(float(loss), 4),
                         "adam": args.adam}
+        if g_ms is not None:
+            out[backend].update(g_extra)
         del model, opt
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
