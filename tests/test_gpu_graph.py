@@ -127,6 +127,8 @@ def test_captured_train_step_matches_eager_steps(inside):
             cap(pts, i, g)
             last = cap(pts, i, g)
         else:
+            if not inside:                                                            # what the capture's warm-up ran: one forward +
+                step(pts, i, g).backward()                                            # backward without a step (it advances the draw counters)
             for _ in range(2):
                 opt.zero_grad(set_to_none=True)
                 last = step(pts, i, g)
