@@ -285,6 +285,16 @@ __global__ __launch_bounds__(64 * DAL3_WG_WAVES) void point_head_kernel(PointHea
 // already and a group of copies is a uniform 1-us skip there — so they keep walking (item, group) pairs.)
 //   ctl[0] = n_live, ctl[1] = cursor (zero), list[i] = {item, tile, n_eff, 0}: written by nonfinite_rows_kernel
 //   (dal3_misc.hip), the launch that zero-fills `feat` in front of this kernel anyway
+// Round 5: a wave takes RUNS of consecutive entries (the list is item-major, so a run is mostly one item's tiles) and
+// keeps the item's 512 channel maxima in a private LDS row across the run; the global atomicMax is issued once per
+// channel when the run leaves the item, not once per channel and TILE (rocprofv3 WRITE_SIZE: 108 MB per launch for an
+// 8.4-MB result at 4096 x 512 object points, profiles/r04_pmc.json). Runs are HEAD_RUN entries long while plenty of
+// work is left and shrink towards single entries at the end of the list (a run is the unit of the dynamic schedule:
+// long runs at the end would leave waves idle for up to a run's time; guided self-scheduling: half of an even share of
+// what is left). max is order-independent: bit-identical results.
+#ifndef HEAD_RUN
+#define HEAD_RUN 6
+#endif
 template <int KS, int C1, int C2, int C3>
 __global__ __launch_bounds__(64) void point_head_pers_kernel(PointHeadW w, BCN x, int c_in, float* __restrict__ feat,
                                                              uint32_t* __restrict__ ctl, const u32x4* __restrict__ list) {
@@ -292,10 +302,16 @@ __global__ __launch_bounds__(64) void point_head_pers_kernel(PointHeadW w, BCN x
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
     __shared__ float s_b4[512];                        // conv4's folded bias, read by the max epilogue
-    for (int i = threadIdx.x; i < 512; i += 64) s_b4[i] = w.b4[i];
+    __shared__ int s_run[512];                         // the current item's channel maxima (bit patterns, >= 0)
+    for (int i = threadIdx.x; i < 512; i += 64) {
+        s_b4[i] = w.b4[i];
+        s_run[i] = 0;
+    }
     __syncthreads();
     const uint32_t n_live = ctl[0];
-    uint32_t cur = blockIdx.x;                         // the first entry is the block's own, the others come from the cursor
+    // the schedule's cursor counts ENTRIES; the first gridDim.x * HEAD_RUN entries are dealt out by block index
+    const uint32_t first_free = gridDim.x * HEAD_RUN;
+    uint32_t cur = blockIdx.x * HEAD_RUN, run_end = cur + HEAD_RUN;     // this wave's run: entries [cur, run_end)
     if (cur >= n_live) return;
 
     constexpr uint32_t STREAM_BYTES =
@@ -306,27 +322,53 @@ __global__ __launch_bounds__(64) void point_head_pers_kernel(PointHeadW w, BCN x
     u32x4 e = list[cur];
     float in[T][KS];
     load_points<KS, T>(x, (int64_t)e[0], (int)e[1] * 32, (int)e[2], c_in, in, lane);
+    auto flush = [&](int64_t b) {                      // the finished item's maxima -> feat (nothing where the value is 0)
+        int* gi = reinterpret_cast<int*>(feat + b * 512);
+#pragma unroll
+        for (int c = lane; c < 512; c += 64) {
+            const int v = s_run[c];
+            if (v > 0) atomicMax(gi + c, v);
+            s_run[c] = 0;
+        }
+    };
     for (;;) {
         const int64_t b = (int64_t)e[0];
-        // the next entry: one returning atomic per tile, issued a whole layer before its result is looked at (by then
-        // it is older than everything the ring has in flight, so the wait for it costs the ring nothing)
-        uint32_t nxt = 0;
-        if (lane == 0) nxt = atomicAdd(&ctl[1], 1u);
+        // the run's last entry asks for the next run: one returning atomic, issued a whole layer before its result is
+        // looked at (by then it is older than everything the ring has in flight, so the wait for it costs the ring
+        // nothing). Its length: HEAD_RUN while more than 8 runs per wave are left behind the cursor, else 1.
+        const bool last_of_run = cur + 1 >= run_end || cur + 1 >= n_live;
+        uint32_t nxt = 0, take = 1;
+        if (last_of_run) {
+            const uint32_t left = n_live > run_end ? n_live - run_end : 0u;           // (behind this wave's own run: a proxy for the cursor)
+            take = left / (2u * gridDim.x);                                           // guided: half of an even share of what is left
+            take = take < 1u ? 1u : (take > HEAD_RUN ? HEAD_RUN : take);
+            if (lane == 0) nxt = atomicAdd(&ctl[1], take);
+        }
         f32x16 x3[T][C3 / 32];
         float in_n[T][KS];
+        uint32_t ncur, nend;
         {
             f32x16 x1[T][C1 / 32], x2[T][C2 / 32];
             first_layer<KS, C1 / 32, T>(w.w1, w.b1, in, x1, lane);
             mlp_layer_ring<C1 / 32, C2 / 32, T>(ring, w.b2, w.b3, bias, x1, x2, lane);
-            nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt) + gridDim.x;
-            const uint32_t nclamp = nxt < n_live ? nxt : cur;          // (past the end: re-read this tile's entry, unused)
+            if (last_of_run) {
+                ncur = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt) + first_free;
+                nend = ncur + take;
+            } else {
+                ncur = cur + 1;
+                nend = run_end;
+            }
+            const uint32_t nclamp = ncur < n_live ? ncur : cur;        // (past the end: re-read this tile's entry, unused)
             e = list[nclamp];
             mlp_layer_ring<C2 / 32, C3 / 32, T>(ring, w.b3, w.b2, bias, x2, x3, lane);   // leaves bias = conv2's tile 0
             load_points<KS, T>(x, (int64_t)e[0], (int)e[1] * 32, (int)e[2], c_in, in_n, lane);
         }
-        conv_max_layer<C3 / 32, T>(ring, s_b4, x3, feat + b * 512, 16, lane);
-        if (nxt >= n_live) break;
-        cur = nxt;
+        conv_max_layer<C3 / 32, T>(ring, s_b4, x3, reinterpret_cast<float*>(s_run), 16, lane);
+        const bool more = ncur < n_live;
+        if (!more || (int64_t)e[0] != b) flush(b);     // (the wave's own LDS operations are in order: no barrier)
+        if (!more) break;
+        cur = ncur;
+        run_end = nend;
 #pragma unroll
         for (int k = 0; k < KS; ++k) in[0][k] = in_n[0][k];
     }
@@ -449,9 +491,9 @@ hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in
     if (pers) {
         uint32_t* ctl = static_cast<uint32_t*>(worklist);
         u32x4* list = reinterpret_cast<u32x4*>(static_cast<char*>(worklist) + 256);
-        const int64_t tiles = (int64_t)B * tpi;
+        const int64_t runs = ((int64_t)B * tpi + HEAD_RUN - 1) / HEAD_RUN;   // (an upper bound: the list holds the live tiles only)
         const int64_t slots = head_slots();
-        const dim3 grid((unsigned)(tiles < slots ? tiles : slots)), block(64);
+        const dim3 grid((unsigned)(runs < slots ? runs : slots)), block(64);
         switch (head_kind) {
             case 1:
                 hipLaunchKernelGGL((point_head_pers_kernel<2, 128, 128, 256>), grid, block, 0, s, w, x, c_in, feat, ctl, list);
