@@ -146,6 +146,7 @@ SIGNATURES = {
     "dal3_parse_box_pred": (_i, [vp, _i64, _i64, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dal3_parse_box_pred_backward": (_i, [vp, vp, vp, vp, vp, vp, vp, _i64, vp, vp]),
     "dal3_tr_fc_max_rows": (_i, []),
+    "dal3_tr_fc_max_act_cin": (_i, []),
     "dal3_tr_fc_forward": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _i, vp, _i, vp, _i64, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp]),
     "dal3_tr_fc_backward_w": (_i, [vp, _i64, _i64, _i, vp, _i64, vp, vp, vp, vp, vp, vp, vp, vp, _i, _i64, vp, vp, _i, vp, _i64, vp, _i64,
                                    vp, vp]),

@@ -1154,6 +1154,7 @@ extern "C" int dal3_parse_box_pred_backward(const float* g_center, const float* 
 }
 
 extern "C" int dal3_tr_fc_max_rows(void) { return tr_fc_max_rows(); }
+extern "C" int dal3_tr_fc_max_act_cin(void) { return tr_fc_max_act_cin(); }
 
 extern "C" int dal3_tr_fc_forward(const float* a, int64_t B, int c_in, int64_t lda, const float* in_scale, const float* in_shift,
                                   int relu_in, const float* W, int64_t ldw, int transpose_w, const float* bias, int c_out, float* z,

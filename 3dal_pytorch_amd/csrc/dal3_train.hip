@@ -468,9 +468,11 @@ struct WRingCyc {
 //   RED == 2  the output is da, the gradient w.r.t. relu(bn(bz)) of the layer whose pre-BN output is `bz`:
 //             dy = da * [bz*bscale + bshift > 0];  sum dy, sum dy * (bz - bmu)*brstd    (mode 1: dbeta, dgamma)
 // The tile is computed transposed (tr_ring_block SWAP): a lane owns ONE output channel of each tile and sixteen points of
-// it, so the sums run over registers; a wave's units all lie in one channel block, so the running sums (float64, like
-// the separate pass) stay in registers for the wave's whole life and are written once: part[wave of the block][c][2],
-// added in wave order by tr_colred_final_kernel. Fixed unit -> wave map, fixed order of additions: deterministic.
+// it, so the sums run over registers; a wave's units all lie in one channel block, so the running sums (float64) stay
+// in registers for the wave's whole life and are written once: part[wave of the block][c][2], added in wave order by
+// tr_colred_final_kernel. Fixed unit -> wave map, fixed order of additions: deterministic. NOT the separate pass's
+// arithmetic in one respect: RED == 2 adds a tile's 16 T terms in fp32 before they join the float64 sums (see there;
+// dal3.h states the bound), RED == 1 converts every term to float64 first like the separate pass.
 struct TrRed {
     double* part;
     const float* bz;                     // RED == 2

@@ -1210,7 +1210,10 @@ def fc_tail_train_forward(head, x):
     if any(bn is None for _, bn, _, _ in fcs[:-1]):
         raise RuntimeError("fc tail: only the last layer may come without a BatchNorm")
     stats = _bn_stats(head, bn_names)
-    if FC_ROWS_KERNELS and 2 <= x.shape[0] <= _hip.lib().dal3_tr_fc_max_rows():
+    # the rows-are-items kernels hold a hidden layer's input-activation constants in LDS: layers behind the first must
+    # have c_in <= dal3_tr_fc_max_act_cin() (the reference's tails: 512 / 256); a wider tail takes the per-point kernels
+    narrow = all(ci <= _hip.lib().dal3_tr_fc_max_act_cin() for _, _, ci, _ in fcs[1:])
+    if FC_ROWS_KERNELS and narrow and 2 <= x.shape[0] <= _hip.lib().dal3_tr_fc_max_rows():
         return _FcTailRows.apply(x, stats, len(bn_names), *params)
     return _FcTail.apply(x, stats, len(bn_names), *params)
 

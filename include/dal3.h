@@ -109,7 +109,9 @@ typedef struct {
     const float* data;
     int64_t stride_b, stride_c, stride_n;
     int32_t dtype;
-    int32_t flags;                       /* 0, or DAL3_BCN_* dispatch hints for the call this view is the input of */
+    int32_t flags;                       /* MUST be 0 or a mask of DAL3_BCN_* (was `reserved` before 0.1.3: a caller that never
+                                          * zeroed it now gets DAL3_EINVAL for unknown bits, or a different — bit-identical
+                                          * — kernel family for bits 1 / 2; zero-initialise the struct) */
 } dal3_bcn;
 
 /* Per-call dispatch hints (dal3_bcn.flags; dal3_static_args / dal3_dynamic_args take them from args.pts.flags for every
@@ -369,7 +371,12 @@ int dal3_tr_linear_prepacked(const float* a, int64_t M, int c_in, int64_t lda, c
  *                                da = dz W) + dal3_tr_bnbwd_sums(z = bz, da = its output): the sums of the BatchNorm/ReLU
  *                                backward of the layer whose post-activation gradient the dgrad has just produced
  *                                (bz, bscale .. brstd, gamma: that layer's pre-BN output and BatchNorm).
- * Same results as the two-call sequences up to the order of the float64 additions (deterministic either way). Fused
+ * Same results as the two-call sequences up to summation order, deterministic either way. bn_stats: float64 running
+ * sums per lane, a reordering of the separate pass's float64 additions (1e-6 of each vector's largest entry, the bar of
+ * tests/test_gpu_train_fused.py). bnbwd_sums (RED 2): a tile's 32-64 terms of dy and dy*xhat are first added in FP32
+ * (one fp32 partial per tile and channel), then joined to the float64 running sums — so dgamma / dbeta carry fp32
+ * partial-sum rounding, bounded by 64 * 2^-24 = 3.8e-6 relative to sum(|terms|) per tile (the tests hold them to 1e-5 of
+ * the vector's largest entry against float64 sums), not merely a reordering of float64 additions. Fused
  * when the shape takes the persistent linear kernel and rows == M (padding rows must stay out of the sums); otherwise
  * the library runs the two steps itself. Return: 1 fused, 0 ran as two steps, < 0 error.
  * workspace: dal3_tr_linear_red_workspace_bytes(rows, c_out). */
@@ -483,6 +490,7 @@ int dal3_parse_box_pred_backward(const float* g_center, const float* g_heading_s
  *                          the layer has no BatchNorm and da IS dz) -> dz (B, c_out; may be NULL), dgamma, dbeta, db
  *                          (zeros in front of a BatchNorm), dW (c_out, c_in) = dz^T act(a_prev) (may be NULL) */
 int dal3_tr_fc_max_rows(void);
+int dal3_tr_fc_max_act_cin(void);       /* most input channels of a layer whose input carries an activation (hidden layers of a tail) */
 int dal3_tr_fc_forward(const float* a, int64_t B, int c_in, int64_t lda, const float* in_scale, const float* in_shift, int relu_in,
                        const float* W, int64_t ldw, int transpose_w, const float* bias, int c_out, float* z, int64_t ldz,
                        const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,

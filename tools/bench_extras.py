@@ -248,6 +248,7 @@ def main():
     ap.add_argument("--only", default=",".join(LEGS), help="comma-separated legs: " + ", ".join(LEGS))
     ap.add_argument("--configs", default=",".join(n for n, _ in OTHER), help="which of the `configs` leg's workloads")
     ap.add_argument("--maxpool-iters", type=int, default=5)
+    ap.add_argument("--maxpool-storage", default="fp32,bf16", help="row storage(s) of the maxpool leg (profiling runs take one)")
     a = ap.parse_args()
     legs = set(a.only.split(","))
     dev = torch.device("cuda", 0)
@@ -281,8 +282,9 @@ def main():
     leg("headline", headline)
     leg("lowprec", lambda: lowprec_leg(wl, dev, a.steps))
     leg("f16x3", lambda: f16x3_leg(wl, dev, a.steps))
-    leg("maxpool", lambda: {"fp32": maxpool_roofline(dev, iters=a.maxpool_iters),
-                            "bf16": maxpool_roofline(dev, iters=a.maxpool_iters, dtype=torch.bfloat16)})
+    leg("maxpool", lambda: {st: maxpool_roofline(dev, iters=a.maxpool_iters, dtype={"fp32": torch.float32, "bf16": torch.bfloat16,
+                                                                                       "fp16": torch.float16}[st])
+                            for st in a.maxpool_storage.split(",")})
     leg("torch_gpu", lambda: torch_gpu_baseline(wl.model, wl.inputs))
     del wl
     torch.cuda.empty_cache()

@@ -5,12 +5,13 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmc_pool
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
+. $R/tools/_pmc_lib.sh
 P="python3 $R/tools/pool_probe.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o c -- $P > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/p1 -o c -- $P > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $O/p2 -o c -- $P > /dev/null 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/p4 -o c -- $P > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM --output-format csv -d $O/p5 -o c -- $P > /dev/null 2>&1
+pmc_pass $O/p1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -- $P
+pmc_pass $O/p2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -- $P
+pmc_pass $O/p4 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE -- $P
+pmc_pass $O/p5 SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM -- $P
 grep -h "tr_linear_pool\|tr_pack\|unpack\|fill" $O/kt/c_kernel_stats.csv | cut -c1-160
 python3 - <<PY
 import csv, glob
@@ -25,3 +26,4 @@ for k in sorted(acc):
     v = acc[k][1:] or acc[k]
     print(f"{k:36s} {sum(v) / len(v):16.0f}")
 PY
+exit $PROF_RC

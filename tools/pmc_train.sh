@@ -6,9 +6,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmc_train
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
+. $R/tools/_pmc_lib.sh
 P="python3 $R/tools/bench_train.py --backends ${1:-hip} --sampler device --iters 3"
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_WAIT_ANY --output-format csv -d $O/p1 -o c -- $P > /dev/null 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/p2 -o c -- $P > /dev/null 2>&1
+pmc_pass $O/p1 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_WAIT_ANY -- $P
+pmc_pass $O/p2 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -- $P
 python3 - <<PY
 import csv, glob, re
 from collections import defaultdict
@@ -34,3 +35,4 @@ print(f"{'kernel':84s} {'us':>7s} {'valu/mfma':>9s} {'salu/mfma':>9s} {'mfma bus
 for _, k, us, vm, sm, busy, ghz, n in sorted(rows, reverse=True):
     print(f"{k[:84]:84s} {us:7.1f} {vm:9.2f} {sm:9.2f} {busy:9.3f} {ghz:5.2f} {n:3d}")
 PY
+exit $PROF_RC

@@ -7,9 +7,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmc_train_traffic
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
+. $R/tools/_pmc_lib.sh
 P="python3 $R/tools/bench_train.py --backends ${1:-hip} --sampler device --iters 3"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p1 -o c -- $P > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p2 -o c -- $P > /dev/null 2>&1
+pmc_pass $O/p1 FETCH_SIZE -- $P
+pmc_pass $O/p2 WRITE_SIZE -- $P
 python3 - <<PY
 import csv, glob, re
 from collections import defaultdict
@@ -33,3 +34,4 @@ print(f"{'kernel (grid)':84s} {'us':>7s} {'read MB':>8s} {'write MB':>8s} {'TB/s
 for _, k, us, rd, wr, tbs, n in sorted(rows, reverse=True):
     print(f"{k[:84]:84s} {us:7.1f} {rd:8.1f} {wr:8.1f} {tbs:5.2f} {n:3d}")
 PY
+exit $PROF_RC

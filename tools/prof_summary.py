@@ -19,7 +19,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(root, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 OURS = ("ins_seg_", "point_head_", "maxpool_rows", "fc_kernel", "fc39_decode", "compact_sample", "decode_boxes",
-        "segment_counts", "recenter_kernel", "pack_", "generic_layer", "tr_", "fill_words", "lat_kernel", "nonfinite_rows")
+        "segment_counts", "recenter_kernel", "pack_", "generic_layer", "tr_", "fill_words", "lat_kernel", "nonfinite_rows",
+        "crop_", "item_prep", "writeback")
 
 
 def short(name):
@@ -28,7 +29,7 @@ def short(name):
 
 for sub, sfx in (("prof_kt", ""), ("prof_kt_bf16", "_bf16"), ("prof_kt_f16x3", "_f16x3"), ("prof_kt_c3", "_c3"), ("prof_kt_c5", "_c5"),
                  ("prof_kt_maxpool", "_maxpool"), ("prof_kt_maxpool_bf16", "_maxpool_bf16"), ("prof_kt_b64", "_b64"),
-                 ("prof_kt_train", "_train"), ("prof_kt_train_x3", "_train_x3")):
+                 ("prof_kt_train", "_train"), ("prof_kt_train_x3", "_train_x3"), ("prof_kt_pipeline", "_pipeline")):
     stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
     if not stats:
         continue
