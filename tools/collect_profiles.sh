@@ -13,7 +13,7 @@ for f in bench bench_extras bench_under_rocprof bench_bf16_under_rocprof bench_f
   [ -s $O/$f.json ] && cp $O/$f.json profiles/${TAG}_$f.json
 done
 [ -s $O/bench_full_headline.json ] && cp $O/bench_full_headline.json profiles/${TAG}_bench_full.json
-for f in $O/${TAG}_kernel_stats*.csv $O/${TAG}_train_kernel_stats*.csv $O/${TAG}_pmc*.json $O/${TAG}_pmc_c3.txt $O/traffic.json; do
+for f in $O/${TAG}_kernel_stats*.csv $O/${TAG}_train_kernel_stats*.csv $O/${TAG}_pmc*.json $O/${TAG}_pmc_c3.txt $O/${TAG}_pmc_crops.txt $O/traffic.json; do
   [ -s $f ] && cp $f profiles/
 done
 [ -s $O/train_roofline_hip.json ] && cp $O/train_roofline_hip.json profiles/${TAG}_train_roofline.json

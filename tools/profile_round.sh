@@ -66,6 +66,14 @@ bash $R/tools/pmc_train_traffic.sh hip > $O/train_traffic.txt 2>/dev/null || PRO
 # ---- the rows either side of the path: each alone, and chained on the device
 python3 $R/tools/bench_crops.py --order range_image > $O/crops_range_image.json 2>/dev/null
 python3 $R/tools/bench_crops.py --order shuffled > $O/crops_shuffled.json 2>/dev/null
+# (what bounds the crop kernels: vector-ALU activity, waits and HBM bytes per launch, counter passes of their own)
+C="python3 $R/tools/bench_crops.py --order range_image --frames 192"
+pmc_pass $O/pmc_crops/p1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -- $C
+pmc_pass $O/pmc_crops/p2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD -- $C
+pmc_pass $O/pmc_crops/p3 SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -- $C
+pmc_pass $O/pmc_crops/p4 FETCH_SIZE -- $C
+pmc_pass $O/pmc_crops/p5 WRITE_SIZE -- $C
+python3 $R/tools/pmc_lp.py $O/pmc_crops --match crop_ --json $O/${TAG}_pmc_crops.json > $O/${TAG}_pmc_crops.txt 2>&1
 python3 $R/tools/bench_pipeline.py > $O/pipeline_fp32.json 2>/dev/null
 python3 $R/tools/bench_pipeline.py --precision bf16 > $O/pipeline_bf16.json 2>/dev/null
 trace_pass $O/prof_kt_pipeline -- python3 $R/tools/bench_pipeline.py --precision bf16 --iters 3
