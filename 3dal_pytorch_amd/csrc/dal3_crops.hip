@@ -13,9 +13,13 @@
 #include "dal3_geom.h"
 #include "dal3_kernels.h"
 
+#ifndef CROP_CHUNK
 #define CROP_CHUNK 1024                  // points per wavefront: 16 rounds of 64
+#endif
 #define CROP_ROUNDS (CROP_CHUNK / 64)
-#define CROP_WAVES 4
+#ifndef CROP_WAVES
+#define CROP_WAVES 8                     // chunks (waves) per workgroup: they share the frame's grid
+#endif
 // The cull in front of the exact test (round 5; rounds 2-4 tested every 64-point round against every detection's
 // ball: 10 VALU per point and box, 1.3e12 point-box tests/s, and three times slower on a shuffled sweep than on a
 // range-image-ordered one, where most rounds miss most balls). Now: a workgroup (four chunks of ONE frame) rasterises
@@ -73,18 +77,22 @@ __global__ __launch_bounds__(64 * CROP_WAVES) void crop_pass_kernel(
     const bool active = (int64_t)chunk * CROP_CHUNK < n_pts;             // (a wave past it still joins the barriers)
     const bool last_chunk = (int64_t)(chunk + 1) * CROP_CHUNK >= n_pts;
     const int64_t k0 = box_offsets[frame], k1 = box_offsets[frame + 1];
-    float x[CROP_ROUNDS], y[CROP_ROUNDS], z[CROP_ROUNDS];
-    uint32_t valid = 0;
-#pragma unroll
-    for (int r = 0; r < CROP_ROUNDS; ++r) {
-        const int64_t i = (int64_t)chunk * CROP_CHUNK + r * 64 + lane;
+    // The chunk's points are NOT held in registers across the rounds (round 5, first version: 48 registers of coordinates,
+    // a fully unrolled 16-round body, 227 VGPRs in the fill pass = two waves per SIMD, and counters that said the kernel
+    // WAITS: SQ_WAIT_ANY 0.53 of the wave cycles, the vector ALUs active in 0.10 of the SIMD cycles — profiles/
+    // r05_pmc_crops.txt). A rolled loop loads round r + 1 while round r is worked on; at ~48 registers eight waves share a
+    // SIMD and hide each other's LDS and memory latency.
+    const float* pbase = points + p0 * 3;
+    const int64_t i0 = (int64_t)chunk * CROP_CHUNK + lane;
+    auto load_round = [&](int r, float& px, float& py, float& pz) -> bool {
+        const int64_t i = i0 + r * 64;
         const bool ok = active && i < n_pts;
-        const float* p = points + (p0 + (ok ? i : 0)) * 3;
-        x[r] = p[0];
-        y[r] = p[1];
-        z[r] = p[2];
-        valid |= (uint32_t)ok << r;
-    }
+        const float* p = pbase + (ok ? i : 0) * 3;
+        px = p[0];
+        py = p[1];
+        pz = p[2];
+        return ok;
+    };
     const double* pose = FILL ? pose_all + (int64_t)frame * 16 : nullptr;
     for (int64_t kb = k0; kb < k1; kb += CROP_BATCH) {
         const int nb = (int)(k1 - kb < CROP_BATCH ? k1 - kb : CROP_BATCH);
@@ -124,11 +132,18 @@ __global__ __launch_bounds__(64 * CROP_WAVES) void crop_pass_kernel(
         }
         const unsigned long long all_bits = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
         if (!FILL) s_cnt[threadIdx.x >> 6][lane] = 0;                    // (wave-private row: LDS operations of a wave are in order)
-#pragma unroll
+        float nx, ny, nz;
+        bool nok = load_round(0, nx, ny, nz);
+#ifndef CROP_UNROLL
+#define CROP_UNROLL 4
+#endif
+#pragma unroll CROP_UNROLL
         for (int r = 0; r < CROP_ROUNDS; ++r) {
-            const float px = x[r], py = y[r], pz = z[r];
+            const float px = nx, py = ny, pz = nz;
+            const bool ok = nok;
+            if (r + 1 < CROP_ROUNDS) nok = load_round(r + 1, nx, ny, nz);
             unsigned long long cand = 0ull;
-            if ((valid >> r) & 1u)
+            if (ok)
                 cand = (finite_f32(px) && finite_f32(py) && finite_f32(pz)) ? s_grid[crop_cell(py) * CROP_GRID + crop_cell(px)]
                                                                            : all_bits;
             unsigned long long in = 0ull;
