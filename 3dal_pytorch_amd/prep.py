@@ -90,7 +90,10 @@ class StaticTrackStore:
     order, static_eval.py:256-267 through the DataLoader). What the reference does per ITEM instead: stack the
     track's frames, `np.argmax` the scores, invert the pose, move the box (static_model.py:530-544)."""
 
-    def __init__(self, tracks, device="cuda"):
+    def __init__(self, tracks, device="cuda", veh_to_global=None):
+        """veh_to_global (optional): the flat-16 pose of every track's best-score frame. With it the per-track inverse
+        poses and vehicle-frame boxes are computed and uploaded HERE, once, and `prepare_static_batch(store, B, first=k)`
+        is a single kernel launch with no host arithmetic and no upload (round 5)."""
         dev = torch.device(device)
         frames, counts = [], []
         for tr in tracks:
@@ -110,6 +113,13 @@ class StaticTrackStore:
         self.pts = _upload(flat, dev)
         self.d_offsets = torch.from_numpy(self.offsets).to(dev)
         self.device = dev
+        self.d_pose = self.d_box = None
+        if veh_to_global is not None:
+            if len(veh_to_global) != len(tracks):
+                raise ValueError("StaticTrackStore: one best-frame pose per track")
+            pose = np.linalg.inv(np.reshape(np.asarray(veh_to_global, np.float64), [len(tracks), 4, 4]))
+            self.d_pose = _dev(pose.reshape(len(tracks), 16), dev, np.float64)
+            self.d_box = _dev(_transform_boxes(self.best_box, pose), dev, np.float64)
 
     def __len__(self):
         return len(self.tracks)
@@ -119,7 +129,8 @@ def prepare_static_batch(tracks, veh_to_global, n_points=4096, sampler="numpy", 
                          device="cuda", gt_boxes=None, first=0):
     """tracks: list of track dicts, or a StaticTrackStore (then tracks [first, first + len(veh_to_global)) of it are
     prepared and nothing is uploaded); veh_to_global: list of flat-16 poses of each track's BEST-score frame
-    (annos['veh_to_global'], static_model.py:538). Returns (pts (B,3,N) fp32 view of point-major storage,
+    (annos['veh_to_global'], static_model.py:538) — or, for a store built WITH its poses, just the batch size (int):
+    the call is then one kernel launch (device sampler, no labels). Returns (pts (B,3,N) fp32 view of point-major storage,
     init_box (B,7) fp32) — exactly what static_eval.py:265-266 feeds forward().
     gt_boxes: optional list of the matched annotation's float32 (9,) `box` of that frame (static_model.py:550-553);
     then a third value is returned, the labels of static_model.py:548-566 as a dict of device tensors:
@@ -128,10 +139,21 @@ def prepare_static_batch(tracks, veh_to_global, n_points=4096, sampler="numpy", 
     store = tracks if isinstance(tracks, StaticTrackStore) else StaticTrackStore(tracks, device)
     if not isinstance(tracks, StaticTrackStore):
         first = 0
-    B = len(veh_to_global)
+    resident = isinstance(veh_to_global, (int, np.integer))
+    B = int(veh_to_global) if resident else len(veh_to_global)
     if first < 0 or first + B > len(store):
         raise ValueError(f"prepare_static_batch: tracks [{first}, {first + B}) are not in the store of {len(store)}")
     dev = store.device
+    if resident:
+        if store.d_pose is None or sampler != "device" or gt_boxes is not None:
+            raise ValueError("prepare_static_batch(store, B): the store must hold its poses (StaticTrackStore(..., veh_to_global=)), "
+                             "sampler='device', no labels")
+        out = torch.empty((B, n_points, 3), dtype=torch.float32, device=dev)
+        init = torch.empty((B, 7), dtype=torch.float32, device=dev)
+        _hip.check(_hip.lib().dal3_static_crop_prep(_hip.ptr(store.pts), _hip.ptr(store.d_offsets[first:first + B + 1]), None,
+                                                    _hip.ptr(store.d_pose[first:first + B]), _hip.ptr(store.d_box[first:first + B]),
+                                                    B, n_points, seed, item_offset, _hip.ptr(out), _hip.ptr(init), _hip.stream()))
+        return out.transpose(2, 1), init
     pose = np.linalg.inv(np.reshape(np.asarray(veh_to_global, np.float64), [B, 4, 4]))          # one batched inverse
     boxes = _transform_boxes(store.best_box[first:first + B], pose)
     choice = None

@@ -194,3 +194,13 @@ def test_static_track_store_batches_equal_the_one_shot_call():
     assert torch.equal(a_p, b_p) and torch.equal(a_i, b_i)
     with pytest.raises(ValueError):
         prep.prepare_static_batch(store, poses[:4], first=8)
+    # round 5: a store that holds its tracks' best-frame poses: a batch is `prepare_static_batch(store, B, first=k)` —
+    # one launch, no host arithmetic or upload — and gives the same bits
+    store_p = prep.StaticTrackStore(tracks, veh_to_global=poses)
+    parts = [prep.prepare_static_batch(store_p, min(4, 10 - k), n_points=512, sampler="device", seed=9, first=k, item_offset=k)
+             for k in range(0, 10, 4)]
+    assert torch.equal(torch.cat([p for p, _ in parts]), whole_p) and torch.equal(torch.cat([i for _, i in parts]), whole_i)
+    with pytest.raises(ValueError):
+        prep.prepare_static_batch(store, 4, first=0)                                # a store without poses
+    with pytest.raises(ValueError):
+        prep.prepare_static_batch(store_p, 4, first=0, sampler="numpy")

@@ -132,7 +132,8 @@ def next_rows():
         n1, st = pp["N1_device_batch_of_64"], pp["prepare_static_batch[device, StaticTrackStore, batches of 64]"]
         out["N1"] = {"what": "prepare_static_batch: 64 tracks -> (64,3,4096) crops, from the resident StaticTrackStore",
                      "kernel_ms": n1["stream_ms_per_call"], "algorithmic_bytes": n1["algorithmic_bytes"], "gb_per_s": n1["gb_per_s"],
-                     "frac_of_hbm_8TBps": n1["frac_of_8TBps"], "whole_call_ms": st["ms_per_batch_of_64"],
+                     "frac_of_hbm_8TBps": n1["frac_of_8TBps"], "whole_call_ms": n1["whole_call_ms"],
+                     "stream_ms_with_per_batch_uploads": n1["stream_ms_with_per_batch_uploads"],
                      "one_time_store_build_ms_1024_tracks": st["store_build_ms"], "note": n1["note"]}
         wb = pp["writeback_static[WritebackPlan]"]
         out["N3"] = {"what": f"writeback of {wb['pairs']} (track, frame) pairs into {wb['detections']} detections of a 198-frame segment",
@@ -150,7 +151,9 @@ def next_rows():
                 "algorithmic_bytes": c["roofline"]["algorithmic_bytes"], "gb_per_s": c["roofline"]["achieved"],
                 "frac_of_hbm_8TBps": c["roofline"]["frac"], "whole_call_ms": c["call_ms_with_host_setup"],
                 "point_box_tests_per_s_e9": c["point_box_tests_per_s"],
-                "note": "VALU-bound (six plane tests per candidate pair behind a sphere cull), not HBM-bound"}
+                "planned_call_ms": c["planned_call_ms"],
+                "note": "latency-bound, not HBM- or VALU-bound (profiles/r05_pmc_crops.txt): a grid lookup and a point's own "
+                        "candidates' face tests, eight waves per SIMD hiding each other's LDS / memory latency"}
     except Exception as e:
         out["N2_error"] = repr(e)
     return out
