@@ -421,10 +421,40 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     load4(gq[0], 0);                                       // since the main loop's last barrier — read in front of the a2
     DAL3_SCHED_FENCE();                                    // pack, not behind it with the matrix pipe waiting
     ActTile<DT> xd[T][8], y3[T][4];
+#ifndef DAL3_LP_A2_UNDER
+#define DAL3_LP_A2_UNDER 0
+#endif
+    // one register pair of dconv2's output chunk mt -> its 16-bit place in dconv3's input
+    auto pack_a2_pair = [&](int mt, int p) {
+        const int tj = p >> 3, ts = (p >> 2) & 1, ti = p & 3;
+        int4_t w = __builtin_bit_cast(int4_t, xd[tj][mt].k[ts]);
+        w[ti] = pack_relu_pair<DT>(a2[tj][mt][8 * ts + 2 * ti], a2[tj][mt][8 * ts + 2 * ti + 1]);
+        xd[tj][mt].k[ts] = __builtin_bit_cast(frag_t, w);
+    };
+    if (DAL3_LP_A2_UNDER) {
+        // round 5 experiment: only the first two chunks are packed with the matrix pipe idle (they also free 64 AGPRs for
+        // dconv3's first accumulators); chunks 2..7 are packed under dconv3 tile 0's MFMAs, four pairs per gap, each a
+        // whole chunk (four gaps) ahead of its first use
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
+        for (int j = 0; j < T; ++j) {
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) xd[j][mt] = pack_relu<DT>(a2[j][mt]);
+            for (int mt = 0; mt < 8; ++mt) {
+                const int4_t z = {0, 0, 0, 0};
+                xd[j][mt].k[0] = __builtin_bit_cast(frag_t, z);
+                xd[j][mt].k[1] = __builtin_bit_cast(frag_t, z);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) pack_a2_pair(mt, pp);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) xd[j][mt] = pack_relu<DT>(a2[j][mt]);
+        }
     }
     const int lnB = fresh_lane(), hB = lnB >> 5;         // for the rest of the group (see fresh_lane)
     LP_STAMP(3);
@@ -452,7 +482,17 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     // dconv3 | dconv4 | dconv5 as ONE chain of blocks: every block reads the first four fragments of the next one under
     // its own MFMAs (lp_block F_NEXT / CARRY_IN), the chain's first four were read in front of the a2 pack above.
     bias_tile(accA, s_db3);
-    lp_block<DT, 8, T, SEG, false, true, 16>(ring, 0, xd, accA, gq);                     // dconv3 tile 0
+    if (DAL3_LP_A2_UNDER) {
+        lp_block<DT, 8, T, SEG, false, true, 16>(ring, 0, xd, accA, gq, [&](int n) {      // dconv3 tile 0 | pack a2 chunks 2..7
+            const int c = 2 + n / 4;
+            if (c < 8) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pack_a2_pair(c, (n & 3) * 4 + q);
+            }
+        });
+    } else {
+        lp_block<DT, 8, T, SEG, false, true, 16>(ring, 0, xd, accA, gq);                 // dconv3 tile 0
+    }
     LP_SUB(0);
     bias_tile(accB, s_db3 + 32);
     lp_block<DT, 8, T, SEG, true, true, 0>(ring, 16, xd, accB, gq, [&](int n) {          // tile 1 | pack tile 0

@@ -83,6 +83,6 @@ DAL3_BENCH_SHARE_GPU=1 DAL3_BENCH_BACKEND=gloo $B --gpus 2 --steps 10 --warmup 3
 DAL3_BENCH_SHARE_GPU=1 DAL3_BENCH_BACKEND=gloo $B --gpus 2 --config C4 --steps 2 --warmup 1 --no-extras > $O/bench_rehearsal_2ranks_c4.json 2>/dev/null
 $B --cpu-sweep 8 16 32 64 128 > $O/cpu_threads.json 2>/dev/null
 python3 $R/tools/prof_summary.py $TAG $O > $O/prof_summary.log 2>&1
-cp $R/profiles/${TAG}_* $R/profiles/traffic.json $O/ 2>/dev/null
+cp -n $R/profiles/${TAG}_* $R/profiles/traffic.json $O/ 2>/dev/null   # (-n: never over what this run wrote into $O itself)
 echo "profile_round: PROF_RC=$PROF_RC" | tee $O/profile_round.status
 exit $PROF_RC
