@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     DAL3_SCHED_FENCE();                                    // pack, not behind it with the matrix pipe waiting
     ActTile<DT> xd[T][8], y3[T][4];
 #ifndef DAL3_LP_A2_UNDER
-#define DAL3_LP_A2_UNDER 0
+#define DAL3_LP_A2_UNDER 1
 #endif
     // one register pair of dconv2's output chunk mt -> its 16-bit place in dconv3's input
     auto pack_a2_pair = [&](int mt, int p) {
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         xd[tj][mt].k[ts] = __builtin_bit_cast(frag_t, w);
     };
     if (DAL3_LP_A2_UNDER) {
-        // round 5 experiment: only the first two chunks are packed with the matrix pipe idle (they also free 64 AGPRs for
+        // round 5 (0.6 % at both shapes, bitwise-equal: tools/ab_kernels.py): only the first two chunks are packed with the matrix pipe idle (they also free 64 AGPRs for
         // dconv3's first accumulators); chunks 2..7 are packed under dconv3 tile 0's MFMAs, four pairs per gap, each a
         // whole chunk (four gaps) ahead of its first use
 #pragma unroll
