@@ -31,7 +31,9 @@
 // with the face equations read from LDS. Whatever the order of the sweep, a point costs one lookup plus its own
 // candidates. Non-finite coordinates are candidates of every detection (the reference's NaN behaviour: dal3_geom.h),
 // non-finite balls cover the whole grid.
-#define CROP_GRID 64
+#ifndef CROP_GRID
+#define CROP_GRID 60                     // 60 x 2.5 m = +-75 m (the lidar's range); 64 put the fill pass's LDS 2 KiB over a quarter of a CU's
+#endif
 #define CROP_CELL 2.5f
 #define CROP_BATCH 64                    // detections per grid pass (one mask bit each)
 
@@ -68,7 +70,9 @@ __global__ __launch_bounds__(64 * CROP_WAVES) void crop_pass_kernel(
     double* __restrict__ out_points, int32_t* __restrict__ out_index, int64_t out_capacity) {
     __shared__ unsigned long long s_grid[CROP_GRID * CROP_GRID];         // 32 KiB
     __shared__ float s_pl[CROP_BATCH * DAL3_PLANE_DOUBLES];               // 6 KiB
-    __shared__ int s_cnt[CROP_WAVES][CROP_BATCH];                         // count pass: a wave's members per detection
+    __shared__ int s_cnt[FILL ? 1 : CROP_WAVES][FILL ? 1 : CROP_BATCH];   // count pass: a wave's members per detection
+    __shared__ unsigned long long s_row[FILL ? CROP_WAVES : 1][FILL ? CROP_BATCH : 1];   // fill pass: a detection's next output row, per wave
+    __shared__ uint32_t s_seen[FILL ? CROP_WAVES : 1][2];                 // fill pass: detections met in the current round
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int chunk = blockIdx.x * CROP_WAVES + (threadIdx.x >> 6);
@@ -116,9 +120,9 @@ __global__ __launch_bounds__(64 * CROP_WAVES) void crop_pass_kernel(
         }
         __syncthreads();
         if (!active) continue;
-        // lane j carries detection kb + j's running state: its member count in this chunk (count pass) / the output
-        // row of its next member (fill pass)
-        int64_t state = 0;
+        // the running state per detection is wave-private LDS (a wave's LDS operations execute in order): its member
+        // count in this chunk (count pass, s_cnt) / the output row of its next member (fill pass, s_row)
+        const int w = threadIdx.x >> 6;
         if (FILL) {
             bool any = false;
             if (lane < nb) {
@@ -126,12 +130,12 @@ __global__ __launch_bounds__(64 * CROP_WAVES) void crop_pass_kernel(
                 const int32_t excl = cc[k * max_chunks + chunk];
                 const int64_t next = last_chunk ? counts[k] : (int64_t)cc[k * max_chunks + chunk + 1];
                 any = next != excl;
-                state = box_start[k] + excl;
+                if constexpr (FILL) s_row[w][lane] = (unsigned long long)(box_start[k] + excl);
             }
             if (__ballot(any) == 0) continue;                            // nothing of this batch in this chunk
         }
         const unsigned long long all_bits = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
-        if (!FILL) s_cnt[threadIdx.x >> 6][lane] = 0;                    // (wave-private row: LDS operations of a wave are in order)
+        if constexpr (!FILL) s_cnt[w][lane] = 0;
         float nx, ny, nz;
         bool nok = load_round(0, nx, ny, nz);
 #ifndef CROP_UNROLL
@@ -156,13 +160,51 @@ __global__ __launch_bounds__(64 * CROP_WAVES) void crop_pass_kernel(
                 // counting needs no order: every member adds one to its detection's counter, per lane (with the ordered
                 // loop below a shuffled sweep — half a dozen detections with a member in every round — paid an iteration
                 // per detection and round in BOTH passes)
-                while (in) {
-                    atomicAdd(&s_cnt[threadIdx.x >> 6][__builtin_ctzll(in)], 1);
-                    in &= in - 1ull;
+                if constexpr (!FILL) {
+                    while (in) {
+                        atomicAdd(&s_cnt[w][__builtin_ctzll(in)], 1);
+                        in &= in - 1ull;
+                    }
                 }
                 continue;
             }
-            // ordered compaction, detection by detection, over the detections that HAVE a member in this round
+            if constexpr (FILL) {
+            if (__ballot(in != 0ull) == 0) continue;
+            auto emit = [&](int64_t o) {                                 // this lane's point -> output row o
+                if (o < out_capacity) {                  // (a caller that sized `out` from an estimate: rows past it are dropped)
+                    const double dx = px, dy = py, dz = pz;              // concatenate([lidars_o, ones]) is float64
+                    out_points[o * 3 + 0] = pose[0] * dx + pose[1] * dy + pose[2] * dz + pose[3];
+                    out_points[o * 3 + 1] = pose[4] * dx + pose[5] * dy + pose[6] * dz + pose[7];
+                    out_points[o * 3 + 2] = pose[8] * dx + pose[9] * dy + pose[10] * dz + pose[11];
+                    if (out_index) out_index[o] = (int32_t)((int64_t)chunk * CROP_CHUNK + r * 64 + lane);
+                }
+            };
+            // Does any detection have TWO members in this round? (A shuffled sweep: half a dozen detections with one member
+            // each in every round, and the ordered loop below paid an iteration of two ballots and four readlanes for each;
+            // a range-image sweep: runs of one detection's points.) Every member sets its detection's bit in a per-wave
+            // word and looks at what was there.
+            // (first the cheap case of a run: every member lane holds the SAME set of detections — then the ordered loop
+            // below is one iteration per detection of that set, and the LDS round trip of the check is not worth taking)
+            const uint64_t has0 = __ballot(in != 0ull);
+            const int src0 = __builtin_ctzll(has0);
+            const unsigned long long v0 = ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(in >> 32), src0) << 32) |
+                                          (unsigned long long)__builtin_amdgcn_readlane((uint32_t)in, src0);
+            bool dup = true;
+            if (__ballot(in != 0ull && in != v0) != 0) {
+                if (lane < 2) s_seen[w][lane] = 0u;
+                dup = false;
+                for (unsigned long long t = in; t; t &= t - 1ull) {
+                    const int j = __builtin_ctzll(t);
+                    dup |= (atomicOr(&s_seen[w][j >> 5], 1u << (j & 31)) >> (j & 31)) & 1u;
+                }
+            }
+            if (__ballot(dup) == 0) {
+                // no: the one member of a detection takes the detection's running row and bumps it — no order to keep
+                // inside the round, and the rounds follow each other in program order
+                for (unsigned long long t = in; t; t &= t - 1ull) emit((int64_t)atomicAdd(&s_row[w][__builtin_ctzll(t)], 1ull));
+                continue;
+            }
+            // yes: ordered compaction, detection by detection, over the detections that have a member in this round
             for (;;) {
                 const uint64_t has = __ballot(in != 0ull);
                 if (has == 0) break;
@@ -172,23 +214,16 @@ __global__ __launch_bounds__(64 * CROP_WAVES) void crop_pass_kernel(
                 const int j = lo ? __builtin_ctz(lo) : 32 + __builtin_ctz(hi);      // wave-uniform
                 const bool mine = (in >> j) & 1ull;
                 const uint64_t m = __ballot(mine);
-                if (FILL) {
-                    const int64_t base = ((int64_t)__builtin_amdgcn_readlane((uint32_t)((uint64_t)state >> 32), j) << 32) |
-                                         (int64_t)__builtin_amdgcn_readlane((uint32_t)(uint64_t)state, j);
-                    const int64_t o = base + lanes_below(m);
-                    if (mine && o < out_capacity) {      // (a caller that sized `out` from an estimate: rows past it are dropped)
-                        const double dx = px, dy = py, dz = pz;          // concatenate([lidars_o, ones]) is float64
-                        out_points[o * 3 + 0] = pose[0] * dx + pose[1] * dy + pose[2] * dz + pose[3];
-                        out_points[o * 3 + 1] = pose[4] * dx + pose[5] * dy + pose[6] * dz + pose[7];
-                        out_points[o * 3 + 2] = pose[8] * dx + pose[9] * dy + pose[10] * dz + pose[11];
-                        if (out_index) out_index[o] = (int32_t)((int64_t)chunk * CROP_CHUNK + r * 64 + lane);
-                    }
-                }
-                if (lane == j) state += __popcll(m);
+                const int64_t base = (int64_t)s_row[w][j];               // (one address: a broadcast read)
+                if (mine) emit(base + lanes_below(m));
+                if (lane == src) s_row[w][j] = (unsigned long long)(base + __popcll(m));
                 in &= ~(1ull << j);
             }
+            }   // FILL
         }
-        if (!FILL && lane < nb) cc[(kb + lane) * max_chunks + chunk] = s_cnt[threadIdx.x >> 6][lane];
+        if constexpr (!FILL) {
+            if (lane < nb) cc[(kb + lane) * max_chunks + chunk] = s_cnt[w][lane];
+        }
     }
 }
 

@@ -88,6 +88,16 @@ def measure(args=None, **kw):
     b.record()
     b.synchronize()
     ms = a.elapsed_time(b) / 10
+
+    def ev(fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) / 10
+    ms_count, ms_fill = ev(lambda: plan.count(d_pts)), ev(lambda: plan.fill(d_pts))
     n_total = sum(n_pts)
     nbytes = 2 * 12 * n_total + 28 * members
     # the package's host NumPy membership test (datasets.points_in_rbbox, vectorised over the frame's boxes) on one frame
@@ -98,7 +108,7 @@ def measure(args=None, **kw):
     t_cpu = time.perf_counter() - t1
     return ({"workload": f"{F} frames x {args.points} pts x {args.boxes} detections, {args.order} point order",
                       "members": members,
-                      "device_ms": round(ms, 3), "frames_per_s_device": round(F / (ms * 1e-3), 1),
+                      "device_ms": round(ms, 3), "count_and_starts_ms": round(ms_count, 3), "fill_ms": round(ms_fill, 3), "frames_per_s_device": round(F / (ms * 1e-3), 1),
                       "point_box_tests_per_s": round(n_total * args.boxes / (ms * 1e-3) / 1e9, 1),
                       "roofline": {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0,
                                    "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 4),
