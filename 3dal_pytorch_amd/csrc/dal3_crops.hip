@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64 * CROP_WAVES) void crop_pass_kernel(
     const float* __restrict__ spheres, const int64_t* __restrict__ box_offsets, int max_chunks, int32_t* __restrict__ cc,
     const int64_t* __restrict__ counts, const double* __restrict__ pose_all, const int64_t* __restrict__ box_start,
     double* __restrict__ out_points, int32_t* __restrict__ out_index, int64_t out_capacity) {
-    __shared__ unsigned long long s_grid[CROP_GRID * CROP_GRID];         // 32 KiB
+    __shared__ unsigned long long s_grid[CROP_GRID * CROP_GRID];         // 28.8 KiB
     __shared__ float s_pl[CROP_BATCH * DAL3_PLANE_DOUBLES];               // 6 KiB
     __shared__ int s_cnt[FILL ? 1 : CROP_WAVES][FILL ? 1 : CROP_BATCH];   // count pass: a wave's members per detection
     __shared__ unsigned long long s_row[FILL ? CROP_WAVES : 1][FILL ? CROP_BATCH : 1];   // fill pass: a detection's next output row, per wave
@@ -293,7 +293,8 @@ hipError_t launch_crop_fill(const float* points, const int64_t* point_offsets, c
 // box_start / out_offsets from counts, on the device (round 5: the chained run has no host round trip between count and
 // fill). The detections are laid out in the caller's ORDER (order[i] = the detection at output position i; NULL = as
 // numbered): out_offsets[i] = rows in front of position i (K+1 entries, the last = the total), box_start[order[i]] =
-// out_offsets[i], box_start[K] = the total. One workgroup: K is a segment's detections (~1e4), a few microseconds.
+// out_offsets[i], box_start[K] = the total. One workgroup: K is a segment's detections (~1e4), two trips.
+#define STARTS_PER 8                     // positions per thread and trip: a segment's ~1e4 detections are two trips of the workgroup
 __global__ __launch_bounds__(1024) void crop_starts_kernel(const int64_t* __restrict__ counts, const int64_t* __restrict__ order,
                                                            int64_t K, int64_t* __restrict__ box_start,
                                                            int64_t* __restrict__ out_offsets) {
@@ -302,11 +303,16 @@ __global__ __launch_bounds__(1024) void crop_starts_kernel(const int64_t* __rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_run = 0;
     __syncthreads();
-    for (int64_t i0 = 0; i0 < K; i0 += 1024) {
-        const int64_t i = i0 + threadIdx.x;
-        const int64_t k = i < K ? (order ? order[i] : i) : 0;
-        const int64_t v = i < K ? counts[k] : 0;
-        int64_t incl = v;
+    for (int64_t i0 = 0; i0 < K; i0 += 1024 * STARTS_PER) {
+        const int64_t i = i0 + (int64_t)threadIdx.x * STARTS_PER;        // this thread's STARTS_PER consecutive positions
+        int64_t k[STARTS_PER], v[STARTS_PER], mine = 0;
+#pragma unroll
+        for (int q = 0; q < STARTS_PER; ++q) {
+            k[q] = i + q < K ? (order ? order[i + q] : i + q) : 0;
+            v[q] = i + q < K ? counts[k[q]] : 0;
+            mine += v[q];
+        }
+        int64_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int64_t up = __shfl_up(incl, d);
@@ -316,10 +322,14 @@ __global__ __launch_bounds__(1024) void crop_starts_kernel(const int64_t* __rest
         __syncthreads();
         int64_t before = s_run;
         for (int w = 0; w < wave; ++w) before += s_wave[w];
-        const int64_t excl = before + incl - v;
-        if (i < K) {
-            box_start[k] = excl;
-            if (out_offsets) out_offsets[i] = excl;
+        int64_t excl = before + incl - mine;
+#pragma unroll
+        for (int q = 0; q < STARTS_PER; ++q) {
+            if (i + q < K) {
+                box_start[k[q]] = excl;
+                if (out_offsets) out_offsets[i + q] = excl;
+            }
+            excl += v[q];
         }
         __syncthreads();
         if (threadIdx.x == 1023) s_run = before + incl;
