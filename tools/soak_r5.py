@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Round 5's two kernels with new cross-lane / LDS protocols, launched many times on the same inputs, every output
+compared bit for bit with the first launch (a race or a missing wait shows up as a rare mismatch):
+  point_head_pers_kernel  (runs of worklist entries, an item's maxima kept in LDS across a run)   through model.refine
+  crop_pass_kernel        (LDS grid, unordered counting, the fill pass's duplicate check + LDS row counters)  through CropPlan
+    python tools/soak_r5.py [--launches 300]"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+synth = importlib.import_module("3dal_pytorch_amd.synth")
+sm = importlib.import_module("3dal_pytorch_amd.static_model")
+crops = importlib.import_module("3dal_pytorch_amd.crops")
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--launches", type=int, default=300)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+bad = 0
+model = sm.StaticModelOneBoxEst()
+model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict("static_one").items()})
+model = model.to(dev).eval()
+for B, N in ((4096, 1024), (300, 700), (64, 4096)):
+    p, i, g = synth.static_crops(min(B, 256), N, seed=5)
+    reps = (B + p.shape[0] - 1) // p.shape[0]
+    p = np.tile(p, (reps, 1, 1))[:B]
+    p[::7] *= np.float32(0.85)                            # crops with few segmented points (short worklist runs)
+    pts = torch.from_numpy(p).to(dev).transpose(2, 1)
+    init = torch.from_numpy(np.tile(i, (reps, 1))[:B]).to(dev)
+    first = model._run(pts, init, None)
+    ref = {k: first[k].clone() for k in ("bp1", "boxes7", "counts")}
+    n = max(a.launches // (8 if B == 4096 else 1), 20)
+    miss = 0
+    for _ in range(n):
+        o = model._run(pts, init, None)
+        miss += sum(0 if torch.equal(o[k], v) else 1 for k, v in ref.items())
+    print(f"point heads {B}x{N}: {n} launches, {miss} mismatching outputs")
+    bad += miss
+for order in ("shuffled", "range_image"):
+    sweeps, dets, poses = [], [], []
+    for f in range(6):
+        pts, box9, _, _, pose = synth.sweep(51, f"soak{f}", n_points=60000 + 3000 * f, n_boxes=40 + 20 * f)
+        if order == "range_image":
+            r = np.linalg.norm(pts[:, :2], axis=1)
+            beam = np.clip(((np.arctan2(pts[:, 2] - 2.0, r) + 0.35) / 0.4 * 64).astype(np.int64), 0, 63)
+            pts = np.ascontiguousarray(pts[np.lexsort((np.arctan2(pts[:, 1], pts[:, 0]), beam))])
+        sweeps.append(pts)
+        dets.append(box9)
+        poses.append(pose)
+    d_pts = torch.from_numpy(np.concatenate(sweeps)).to(dev)
+    plan = crops.CropPlan([s.shape[0] for s in sweeps], dets, poses, return_index=True)
+    plan.run(d_pts)
+    total = plan.total()
+    ref = (plan.out[:total].clone(), plan.idx[:total].clone(), plan.offsets.clone())
+    miss = 0
+    for _ in range(a.launches):
+        plan.run(d_pts)
+        miss += 0 if (torch.equal(plan.out[:total], ref[0]) and torch.equal(plan.idx[:total], ref[1]) and torch.equal(plan.offsets, ref[2])) else 1
+    print(f"crops {order}: {a.launches} launches of 6 frames (40..140 detections), {total} rows, {miss} mismatching")
+    bad += miss
+print("total mismatches", bad)
+sys.exit(1 if bad else 0)
