@@ -17,12 +17,19 @@ done ONCE per segment in `SegmentPlan.__init__` (before the sweeps are touched: 
 `run()` only enqueues kernels and returns device tensors. The one size that depends on the points — the number of rows
 the crops hold — is bounded by a capacity (first run: read back once; later runs: checked after the fact, `overflowed()`).
 
+Several GPUs: under an initialised process group `run()` shards the HEADS' items — static tracks and
+dynamic track-frames, contiguous index ranges per rank, the device sampler keyed on the global item index — and closes
+each head with ONE all-gather of the refined (n,7) boxes (dist.all_gather_boxes, RCCL); crop extraction (0.7 ms for a
+segment) and the write-back run replicated on every rank, so every rank ends with the same detection arrays, bit for
+bit the single-rank ones (tests/test_gpu_pipeline.py: two ranks sharing the test box's GPU over gloo).
+
 The reference's file formats (pickles of SURVEY.md 8(g)) stay with eval.py; this module is the device-resident core.
 """
 import numpy as np
 import torch
 
 from . import _hip, arch, crops, post, prep
+from . import dist as sharding
 
 
 class SegmentPlan:
@@ -114,7 +121,7 @@ class SegmentPlan:
             self.d_final = torch.empty((self.D, 7), dtype=torch.float32, device=dev)
         self.dev, self.tokens = dev, tokens
 
-    def run(self, d_pts, marks=None):
+    def run(self, d_pts, marks=None, group=None, shard=True):
         """Enqueue the whole chain on the current stream. d_pts: the segment's sweeps, one (sum P_f, 3) float32 CUDA
         tensor. Returns {"static": (det rows (n_det,7) fp32, match (P,) i32), "dynamic": (...)} — device tensors, valid
         once the stream has run; nothing here waits for the GPU (except the very first run of a plan without a
@@ -125,14 +132,25 @@ class SegmentPlan:
         out, offsets = self.crop.run(d_pts)
         mark("crops")
         res = {}
+        rank, world = 0, 1
+        if shard and torch.distributed.is_available() and torch.distributed.is_initialized():       # (shard=False: this rank does it all)
+            rank, world = torch.distributed.get_rank(group), torch.distributed.get_world_size(group)
         if self.S:
             s_off = offsets.index_select(0, self.d_s_pos)                          # (S+1) row offsets of the static tracks
-            _hip.check(lib.dal3_static_crop_prep(_hip.ptr(out), _hip.ptr(s_off), None, _hip.ptr(self.d_s_pose), _hip.ptr(self.d_s_box),
-                                                 self.S, self.n_static_points, self.seed, 0, _hip.ptr(self.s_pts),
-                                                 _hip.ptr(self.s_init), st()))
-            mark("static_prep")
-            self.static_model.item_offset = 0
-            boxes = self.static_model.refine(self.s_pts.transpose(2, 1), self.s_init)
+            lo, hi = sharding.shard_range(self.S, rank, world)
+            n = hi - lo
+            if n > 0:
+                _hip.check(lib.dal3_static_crop_prep(_hip.ptr(out), _hip.ptr(s_off[lo:hi + 1]), None, _hip.ptr(self.d_s_pose[lo:hi]),
+                                                     _hip.ptr(self.d_s_box[lo:hi]), n, self.n_static_points, self.seed, lo,
+                                                     _hip.ptr(self.s_pts), _hip.ptr(self.s_init), st()))
+                mark("static_prep")
+                self.static_model.item_offset = lo
+                boxes = self.static_model.refine(self.s_pts[:n].transpose(2, 1), self.s_init[:n])
+                self.static_model.item_offset = 0
+            else:
+                boxes = torch.zeros((0, 7), dtype=torch.float32, device=self.dev)
+            if world > 1:
+                boxes = sharding.all_gather_boxes(boxes, self.S, group)
             mark("static_heads")
             self.wb_static.launch(boxes)
             mark("static_writeback")
@@ -140,17 +158,20 @@ class SegmentPlan:
         if self.D:
             f_off = offsets[self.d_pos0:self.d_pos0 + self.D + 1]                  # a view: the dynamic frames' row offsets
             Bd = self.d_pts.shape[0]
-            for lo in range(0, self.D, Bd):
-                n = min(Bd, self.D - lo)
+            lo, hi = sharding.shard_range(self.D, rank, world)
+            for b0 in range(lo, hi, Bd):
+                n = min(Bd, hi - b0)
                 _hip.check(lib.dal3_dynamic_item_prep(_hip.ptr(out), _hip.ptr(f_off), _hip.ptr(self.d_dbox), _hip.ptr(self.d_tfirst),
-                                                      _hip.ptr(self.d_it[lo:lo + n]), _hip.ptr(self.d_if[lo:lo + n]), None,
-                                                      _hip.ptr(self.d_ipose[lo:lo + n]), n, self.n_per_frame, 2, 50, self.seed, lo,
+                                                      _hip.ptr(self.d_it[b0:b0 + n]), _hip.ptr(self.d_if[b0:b0 + n]), None,
+                                                      _hip.ptr(self.d_ipose[b0:b0 + n]), n, self.n_per_frame, 2, 50, self.seed, b0,
                                                       _hip.ptr(self.d_pts), _hip.ptr(self.d_box), _hip.ptr(self.d_init), st()))
-                self.dynamic_model.item_offset = lo
-                self.d_final[lo:lo + n] = self.dynamic_model.refine(self.d_pts[:n].transpose(2, 1), self.d_box[:n].transpose(2, 1),
+                self.dynamic_model.item_offset = b0
+                self.d_final[b0:b0 + n] = self.dynamic_model.refine(self.d_pts[:n].transpose(2, 1), self.d_box[:n].transpose(2, 1),
                                                                      self.d_init[:n])
+            self.dynamic_model.item_offset = 0
+            final = self.d_final if world == 1 else sharding.all_gather_boxes(self.d_final[lo:hi], self.D, group)
             mark("dynamic_prep_heads")
-            self.wb_dynamic.launch(self.d_final)
+            self.wb_dynamic.launch(final)
             mark("dynamic_writeback")
             res["dynamic"] = (self.wb_dynamic.d_det, self.wb_dynamic.match)
         return res

@@ -141,3 +141,18 @@ def test_segment_plan_chain_equals_the_step_by_step_run():
     small.grow()
     small.run(d_pts)
     assert not small.overflowed() and np.array_equal(small.detections("static")[tokens[0]][0], got_s[tokens[0]][0])
+
+
+def test_segment_chain_sharded_over_two_ranks_equals_one_rank():
+    """SURVEY.md 8(e) for the chain: two ranks (sharing this box's one GPU, the boxes all-gathered over gloo through host
+    memory — RCCL cannot connect ranks on one device) shard the static tracks (4 -> 2 + 2) and the dynamic track-frames
+    (21 -> 11 + 10), gather the refined boxes once per head and write back; each rank compares its detections with its
+    own single-rank run of the same plan, bit for bit (tools/segment_ranks_check.py)."""
+    import os
+    launch = importlib.import_module("3dal_pytorch_amd.launch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DAL3_BENCH_SHARE_GPU="1", DAL3_BENCH_BACKEND="gloo")
+    rc, out = launch.spawn_ranks(os.path.join(root, "tools", "segment_ranks_check.py"), [], 2, share_gpu=True, env=env, timeout=600)
+    assert rc == 0, out[-2000:]
+    assert "segment rank 0/2: sharded == alone True" in out and "segment rank 1/2: sharded == alone True" in out, out[-2000:]
