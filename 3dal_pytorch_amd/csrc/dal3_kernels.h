@@ -415,7 +415,7 @@ hipError_t launch_ins_seg_decode_lat(const InsSegW& w, BCN pts, int c_in, int B,
                                      uint8_t* mask, hipStream_t s);
 hipError_t launch_point_head_lat(int head_kind, const PointHeadW& w, BCN x, int c_in, int B, int M, float* feat,
                                  const int32_t* distinct, hipStream_t s);
-bool lat_use(int64_t tiles, int flags);    // the dispatch rule (dal3_pointmlp.hip)
+bool lat_use(int64_t tiles, int flags, int64_t max_tiles);    // the dispatch rule (dal3_pointmlp.hip)
 hipError_t launch_tr_act_dropout(const float* x, int64_t M, int C, int64_t ldx, const float* scale, const float* shift, int relu,
                                  const float* mult, int64_t ldm, uint64_t seed, const int64_t* step, float p_drop, float* out,
                                  int64_t ldo, hipStream_t s);

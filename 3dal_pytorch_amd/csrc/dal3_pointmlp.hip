@@ -309,9 +309,14 @@ __global__ __launch_bounds__(64) void point_head_pers_kernel(PointHeadW w, BCN x
     }
     __syncthreads();
     const uint32_t n_live = ctl[0];
-    // the schedule's cursor counts ENTRIES; the first gridDim.x * HEAD_RUN entries are dealt out by block index
-    const uint32_t first_free = gridDim.x * HEAD_RUN;
-    uint32_t cur = blockIdx.x * HEAD_RUN, run_end = cur + HEAD_RUN;     // this wave's run: entries [cur, run_end)
+    // the schedule's cursor counts ENTRIES; the first gridDim.x * run0 entries are dealt out by block index. The first
+    // run follows the same guided rule as every later one (round 6): half of an even share of the list, at most
+    // HEAD_RUN, at least 1 — so a job of about one tile per wave (the reference's eval batch: 64 crops x 512 object
+    // points = 1024 tiles) gives every wave ONE tile instead of six to a sixth of the chip (0.48 ms -> 0.1 ms there).
+    uint32_t run0 = n_live / (2u * gridDim.x);
+    run0 = run0 < 1u ? 1u : (run0 > HEAD_RUN ? HEAD_RUN : run0);
+    const uint32_t first_free = gridDim.x * run0;
+    uint32_t cur = blockIdx.x * run0, run_end = cur + run0;             // this wave's run: entries [cur, run_end)
     if (cur >= n_live) return;
 
     constexpr uint32_t STREAM_BYTES =
@@ -436,11 +441,22 @@ static inline int tiles_per_item(int n_pts, int T) {
 // at most DAL3_LAT_MAX_TILES tiles (512 = two rounds of workgroups on the 256 CUs), the throughput kernels above that.
 // Both give the same bits. A pure function of the job and of the caller's flags (dal3.h: DAL3_BCN_NO_SMALL_JOB_KERNELS):
 // no environment variable, no process-wide switch.
-static constexpr int64_t DAL3_LAT_MAX_TILES = 512;
-bool lat_use(int64_t tiles, int flags) { return !(flags & DAL3_BCN_NO_SMALL_JOB_KERNELS) && tiles <= DAL3_LAT_MAX_TILES; }
+#ifndef DAL3_LAT_MAX_TILES
+#define DAL3_LAT_MAX_TILES 512
+#endif
+#ifndef DAL3_LAT_MAX_TILES_ENC
+#define DAL3_LAT_MAX_TILES_ENC DAL3_LAT_MAX_TILES
+#endif
+#ifndef DAL3_LAT_MAX_TILES_DEC
+#define DAL3_LAT_MAX_TILES_DEC DAL3_LAT_MAX_TILES
+#endif
+#ifndef DAL3_LAT_MAX_TILES_HEAD
+#define DAL3_LAT_MAX_TILES_HEAD DAL3_LAT_MAX_TILES
+#endif
+bool lat_use(int64_t tiles, int flags, int64_t max_tiles) { return !(flags & DAL3_BCN_NO_SMALL_JOB_KERNELS) && tiles <= max_tiles; }
 
 hipError_t launch_ins_seg_encode(const InsSegW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s) {
-    if (lat_use((int64_t)B * ((N + 31) / 32), pts.flags)) return launch_ins_seg_encode_lat(w, pts, c_in, B, N, g, s);
+    if (lat_use((int64_t)B * ((N + 31) / 32), pts.flags, DAL3_LAT_MAX_TILES_ENC)) return launch_ins_seg_encode_lat(w, pts, c_in, B, N, g, s);
     constexpr int T = DAL3_ENC_T;
     // A wave runs its T tiles through the whole encoder one after the other (~150 us per tile at 2.4 GHz). When the
     // job cannot fill the chip's 1024 SIMDs anyway (small eval batches), one tile per wave halves that serial
@@ -457,7 +473,7 @@ hipError_t launch_ins_seg_encode(const InsSegW& w, BCN pts, int c_in, int B, int
 
 hipError_t launch_ins_seg_decode(const InsSegW& w, BCN pts, int c_in, int B, int N, const float* gbias,
                                  float* logits, uint8_t* mask, hipStream_t s) {
-    if (lat_use((int64_t)B * ((N + 31) / 32), pts.flags)) return launch_ins_seg_decode_lat(w, pts, c_in, B, N, gbias, logits, mask, s);
+    if (lat_use((int64_t)B * ((N + 31) / 32), pts.flags, DAL3_LAT_MAX_TILES_DEC)) return launch_ins_seg_decode_lat(w, pts, c_in, B, N, gbias, logits, mask, s);
     constexpr int T = DAL3_DEC_T;
     const int tpi = tiles_per_item(N, T);
     hipLaunchKernelGGL(ins_seg_decode_kernel<T>, dim3((unsigned)((int64_t)B * tpi)), dim3(64 * DAL3_WG_WAVES), 0, s, w, pts, c_in, N, tpi,
@@ -482,7 +498,7 @@ hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in
                              const int32_t* distinct, hipStream_t s, void* worklist, size_t worklist_bytes) {
     constexpr int T = DAL3_HEAD_T;
     const int tpi = (M + 32 * T - 1) / (32 * T);       // one-wave workgroups
-    const bool lat = lat_use((int64_t)B * ((M + 31) / 32), x.flags);
+    const bool lat = lat_use((int64_t)B * ((M + 31) / 32), x.flags, DAL3_LAT_MAX_TILES_HEAD);
     const bool pers = !lat && worklist && worklist_bytes >= point_head_worklist_bytes(B, M) && !(x.flags & DAL3_BCN_NO_WORKLIST) && T == 1;
     // feat = 0 (NaN rows for items with a non-finite input, dal3.h) and, for the persistent kernel, the worklist
     hipError_t e0 = launch_nonfinite_rows(x, B, M, c_in, feat, 512, s, distinct, pers ? worklist : nullptr);
@@ -491,9 +507,9 @@ hipError_t launch_point_head(int head_kind, const PointHeadW& w, BCN x, int c_in
     if (pers) {
         uint32_t* ctl = static_cast<uint32_t*>(worklist);
         u32x4* list = reinterpret_cast<u32x4*>(static_cast<char*>(worklist) + 256);
-        const int64_t runs = ((int64_t)B * tpi + HEAD_RUN - 1) / HEAD_RUN;   // (an upper bound: the list holds the live tiles only)
+        const int64_t tiles = (int64_t)B * tpi;            // (an upper bound: the list holds the live tiles only; a wave beyond it exits)
         const int64_t slots = head_slots();
-        const dim3 grid((unsigned)(runs < slots ? runs : slots)), block(64);
+        const dim3 grid((unsigned)(tiles < slots ? tiles : slots)), block(64);
         switch (head_kind) {
             case 1:
                 hipLaunchKernelGGL((point_head_pers_kernel<2, 128, 128, 256>), grid, block, 0, s, w, x, c_in, feat, ctl, list);

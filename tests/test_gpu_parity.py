@@ -474,7 +474,12 @@ def test_whole_static_forward_on_tiny_crops_vs_oracle(n):
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("kind,head,c,B,M", [("static_one", "box_est", 3, 300, 512), ("dynamic", "point_emb", 4, 70, 2560),
-                                             ("dynamic", "box_emb", 8, 200, 101)])
+                                             ("dynamic", "box_emb", 8, 200, 101),
+                                             # round 6, the mid-size route (guided FIRST run): about one tile per wave (the
+                                             # reference's eval batch, static_eval.py:299), fewer tiles than the chip holds
+                                             # waves, and a list a few times the grid (first runs of 1, the rest by cursor)
+                                             ("static_one", "box_est", 3, 64, 512), ("static_one", "box_est", 3, 40, 512),
+                                             ("static_one", "box_est", 3, 150, 512), ("dynamic", "point_emb", 4, 64, 2560)])
 def test_point_head_on_the_live_tile_worklist_equals_the_per_tile_launch_bitwise(kind, head, c, B, M, prec):
     """round 3: large jobs run the point heads as persistent waves over the compacted list of tiles that hold distinct
     points (dal3_point_head_pool with a workspace) instead of one workgroup per (item, tile) (without one). Same
