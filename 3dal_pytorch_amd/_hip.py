@@ -101,6 +101,7 @@ SIGNATURES = {
     "dal3_crop_count": (_i, [vp, vp, vp, vp, vp, _i, _i64, _i64, vp, vp, _sz, vp]),
     "dal3_crop_fill": (_i, [vp, vp, vp, vp, vp, _i, _i64, _i64, vp, vp, vp, vp, vp, _i64, vp, _sz, vp]),
     "dal3_crop_starts": (_i, [vp, vp, _i64, vp, vp, vp]),
+    "dal3_crop_starts_capped": (_i, [vp, vp, _i64, vp, vp, _i64, vp]),
     "dal3_tr_linear": (_i, [vp, _i64, _i, _i64, vp, vp, _i, vp, _i64, _i, vp, _i64, _i, vp, _i64, _i, vp, _sz, vp]),
     "dal3_tr_linear_workspace_bytes": (_sz, [_i, _i]),
     "dal3_tr_linear_pack_layout": (_i, [_i64, _i, _i64, _i, _i, _i]),

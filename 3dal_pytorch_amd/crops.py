@@ -84,7 +84,7 @@ class CropPlan:
     n_pts: points per frame; order: optional permutation of the K_total detections (numbered frame by frame) giving
     their order in the output — e.g. track-major, so that a track's rows are contiguous and prep.py's kernels can read
     them in place; capacity: rows of the output buffer (default: sized by the first run, which then synchronises once;
-    rows past the capacity are dropped by the kernel and `total()` tells)."""
+    rows past the capacity are dropped by the kernel, the returned offsets are capped at it, and `total()` tells)."""
 
     def __init__(self, n_pts, detections, veh_to_global, device="cuda", order=None, capacity=None, return_index=False):
         dev = torch.device(device)
@@ -127,8 +127,15 @@ class CropPlan:
         _hip.check(lib.dal3_crop_count(_hip.ptr(d_pts), _hip.ptr(self.d_poff), _hip.ptr(self.d_planes), _hip.ptr(self.d_sph),
                                        _hip.ptr(self.d_boff), self.F, self.K, self.max_pts, _hip.ptr(self.counts),
                                        _hip.ptr(self.ws), self.ws.numel(), _hip.stream()))
-        _hip.check(lib.dal3_crop_starts(_hip.ptr(self.counts), _hip.ptr(self.d_order), self.K, _hip.ptr(self.start),
-                                        _hip.ptr(self.offsets), _hip.stream()))
+        # with a buffer of fixed capacity the offsets handed on to the consumers are capped at it (the fill drops the rows
+        # past it): an overflowing run yields short or empty crops for the last detections, never a read past the buffer
+        # (ADVICE r5); self.start keeps the true prefix sums — total() / SegmentPlan.overflowed() tell
+        if self.capacity:
+            _hip.check(lib.dal3_crop_starts_capped(_hip.ptr(self.counts), _hip.ptr(self.d_order), self.K, _hip.ptr(self.start),
+                                                   _hip.ptr(self.offsets), self.capacity, _hip.stream()))
+        else:
+            _hip.check(lib.dal3_crop_starts(_hip.ptr(self.counts), _hip.ptr(self.d_order), self.K, _hip.ptr(self.start),
+                                            _hip.ptr(self.offsets), _hip.stream()))
 
     def fill(self, d_pts):
         if self.return_index and (self.idx is None or self.idx.numel() < self.capacity):

@@ -499,6 +499,21 @@ static int check_bcn(const dal3_bcn& t, const char* what) {
     return 0;
 }
 
+// Upper bounds of a batch (dal3.h: DAL3_MAX_ITEMS, DAL3_MAX_POINTS_PER_ITEM, DAL3_MAX_TILES). The kernels index an item's
+// points and the per-item outputs with 32-bit ints and launch one workgroup (or worklist entry) per 32-point tile of an
+// item: a job beyond these would get a truncated grid or a wrapped offset, so it is refused here, before
+// any workspace is carved or anything is launched.
+static int check_extent(int64_t B, int64_t N, const char* what) {
+    if (B <= 0 || N <= 0) return fail(DAL3_EINVAL, "%s: B and N must be positive (B=%lld N=%lld)", what, (long long)B, (long long)N);
+    if (B > DAL3_MAX_ITEMS) return fail(DAL3_EINVAL, "%s: B=%lld items exceed DAL3_MAX_ITEMS (%d)", what, (long long)B, DAL3_MAX_ITEMS);
+    if (N > DAL3_MAX_POINTS_PER_ITEM)
+        return fail(DAL3_EINVAL, "%s: N=%lld points per item exceed DAL3_MAX_POINTS_PER_ITEM (%d)", what, (long long)N, DAL3_MAX_POINTS_PER_ITEM);
+    if (B * ((N + 31) / 32) > (int64_t)DAL3_MAX_TILES)
+        return fail(DAL3_EINVAL, "%s: B=%lld x N=%lld is %lld 32-point tiles, more than DAL3_MAX_TILES (%d): split the batch", what,
+                    (long long)B, (long long)N, (long long)(B * ((N + 31) / 32)), DAL3_MAX_TILES);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------- ins_seg
 struct InsSegWs { float* g; float* gb; };
 static InsSegWs carve_ins_seg(Carver& c, int B) {
@@ -523,7 +538,7 @@ static int ins_seg_run(const void* packed, int dtype, int c_in, const dal3_bcn& 
                        uint8_t* mask, float* global_feat_out, const InsSegWs& ws, hipStream_t s) {
     TRY(check_dtype(dtype));
     if (!packed || !logits || !mask) return fail(DAL3_EINVAL, "ins_seg: null pointer");
-    if (B <= 0 || N <= 0) return fail(DAL3_EINVAL, "ins_seg: B and N must be positive (B=%d N=%d)", B, N);
+    TRY(check_extent(B, N, "ins_seg"));
     if (c_in != 3 && c_in != 4) return fail(DAL3_EINVAL, "ins_seg: c_in must be 3 or 4");
     TRY(check_bcn(pts, "pts"));
     const BCN x = to_bcn(pts);
@@ -554,7 +569,7 @@ extern "C" int dal3_ins_seg_forward(const void* packed, int dtype, int c_in, dal
                                     uint8_t* mask, float* global_feat_out, void* workspace, size_t workspace_bytes,
                                     dal3_stream stream) {
     if (!workspace) return fail(DAL3_EINVAL, "ins_seg: workspace is NULL");
-    if (B <= 0 || N <= 0) return fail(DAL3_EINVAL, "ins_seg: B and N must be positive (B=%d N=%d)", B, N);
+    TRY(check_extent(B, N, "ins_seg"));
     Carver c(workspace, workspace_bytes);
     const InsSegWs ws = carve_ins_seg(c, B);
     if (!c.ok) return fail(DAL3_EWORKSPACE, "ins_seg: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
@@ -564,8 +579,8 @@ extern "C" int dal3_ins_seg_forward(const void* packed, int dtype, int c_in, dal
 extern "C" int dal3_ins_seg_encode(const void* packed, int dtype, int c_in, dal3_bcn pts, int B, int N,
                                    float* global_feat, dal3_stream stream) {
     TRY(check_dtype(dtype));
-    if (!packed || !global_feat || B <= 0 || N <= 0 || (c_in != 3 && c_in != 4))
-        return fail(DAL3_EINVAL, "ins_seg_encode: bad argument");
+    if (!packed || !global_feat || (c_in != 3 && c_in != 4)) return fail(DAL3_EINVAL, "ins_seg_encode: bad argument");
+    TRY(check_extent(B, N, "ins_seg_encode"));
     TRY(check_bcn(pts, "pts"));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == DAL3_F32)
@@ -581,7 +596,8 @@ extern "C" int dal3_ins_seg_encode(const void* packed, int dtype, int c_in, dal3
 extern "C" int dal3_ins_seg_global_bias(const void* packed, int dtype, const float* global_feat, int B, float* gbias,
                                         dal3_stream stream) {
     TRY(check_dtype(dtype));
-    if (!packed || !global_feat || !gbias || B <= 0) return fail(DAL3_EINVAL, "ins_seg_global_bias: bad argument");
+    if (!packed || !global_feat || !gbias) return fail(DAL3_EINVAL, "ins_seg_global_bias: bad argument");
+    TRY(check_extent(B, 1, "ins_seg_global_bias"));
     const float* dw1g = dtype == DAL3_F32 ? ins_seg_view(static_cast<const float*>(packed), 3).dw1g
                         : dtype == DAL3_F16X3 ? ins_seg_x3_view(packed).dw1g : ins_seg_lp_view(packed).dw1g;
     const float* db1 = dtype == DAL3_F32 ? ins_seg_view(static_cast<const float*>(packed), 3).db1
@@ -593,8 +609,8 @@ extern "C" int dal3_ins_seg_global_bias(const void* packed, int dtype, const flo
 extern "C" int dal3_ins_seg_decode(const void* packed, int dtype, int c_in, dal3_bcn pts, int B, int N,
                                    const float* gbias, float* logits, uint8_t* mask, dal3_stream stream) {
     TRY(check_dtype(dtype));
-    if (!packed || !gbias || !logits || !mask || B <= 0 || N <= 0 || (c_in != 3 && c_in != 4))
-        return fail(DAL3_EINVAL, "ins_seg_decode: bad argument");
+    if (!packed || !gbias || !logits || !mask || (c_in != 3 && c_in != 4)) return fail(DAL3_EINVAL, "ins_seg_decode: bad argument");
+    TRY(check_extent(B, N, "ins_seg_decode"));
     TRY(check_bcn(pts, "pts"));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == DAL3_F32)
@@ -615,7 +631,8 @@ extern "C" size_t dal3_gather_workspace_bytes(int B, int N) {
 }
 
 extern "C" int dal3_segment_counts(const uint8_t* mask, int B, int N, int32_t* counts, dal3_stream stream) {
-    if (!mask || !counts || B <= 0 || N <= 0) return fail(DAL3_EINVAL, "segment_counts: bad argument");
+    if (!mask || !counts) return fail(DAL3_EINVAL, "segment_counts: bad argument");
+    TRY(check_extent(B, N, "segment_counts"));
     HIP_TRY(launch_segment_counts(mask, B, N, counts, static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -624,7 +641,9 @@ static int gather_run(const uint8_t* mask, const dal3_bcn& pts, int B, int N, in
                       const int32_t* choice, uint64_t seed, int64_t item_offset, int32_t* counts, int32_t* obj_idx,
                       float* obj_pts, int32_t* pos, hipStream_t s, const int64_t* step = nullptr) {
     if (!mask || !counts || !obj_idx || !obj_pts) return fail(DAL3_EINVAL, "gather: null pointer");
-    if (B <= 0 || N <= 0 || M <= 0 || C <= 0 || C > 8) return fail(DAL3_EINVAL, "gather: bad shape");
+    if (M <= 0 || C <= 0 || C > 8) return fail(DAL3_EINVAL, "gather: bad shape");
+    TRY(check_extent(B, N, "gather"));
+    TRY(check_extent(B, M, "gather (object points)"));
     if (sampler == DAL3_SAMPLER_CHOICE && !choice) return fail(DAL3_EINVAL, "gather: DAL3_SAMPLER_CHOICE needs choice");
     if (sampler != DAL3_SAMPLER_CHOICE && sampler != DAL3_SAMPLER_DEVICE) return fail(DAL3_EINVAL, "gather: bad sampler");
     TRY(check_bcn(pts, "pts"));
@@ -638,6 +657,7 @@ extern "C" int dal3_mask_compact_sample(const uint8_t* mask, dal3_bcn pts, int B
                                         int32_t* obj_idx, float* obj_pts, void* workspace, size_t workspace_bytes,
                                         dal3_stream stream) {
     if (!workspace) return fail(DAL3_EINVAL, "gather: workspace is NULL");
+    TRY(check_extent(B, N, "gather"));
     Carver c(workspace, workspace_bytes);
     int32_t* pos = c.take<int32_t>((size_t)B * N);
     if (!c.ok) return fail(DAL3_EWORKSPACE, "gather: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
@@ -649,6 +669,7 @@ extern "C" int dal3_mask_compact_sample_step(const uint8_t* mask, dal3_bcn pts, 
                                              const int64_t* step, int64_t item_offset, int32_t* counts, int32_t* obj_idx,
                                              float* obj_pts, void* workspace, size_t workspace_bytes, dal3_stream stream) {
     if (!workspace) return fail(DAL3_EINVAL, "gather: workspace is NULL");
+    TRY(check_extent(B, N, "gather"));
     Carver c(workspace, workspace_bytes);
     int32_t* pos = c.take<int32_t>((size_t)B * N);
     if (!c.ok) return fail(DAL3_EWORKSPACE, "gather: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
@@ -706,7 +727,7 @@ static int point_head_run(int head_kind, const void* packed, int dtype, const da
     if (head_kind != DAL3_HEAD_STATIC_BOX_EST && head_kind != DAL3_HEAD_POINT_EMB && head_kind != DAL3_HEAD_BOX_EMB)
         return fail(DAL3_EINVAL, "point_head: head_kind %d is not a point head", head_kind);
     if (!packed || !out) return fail(DAL3_EINVAL, "point_head: null pointer");
-    if (B <= 0 || M <= 0) return fail(DAL3_EINVAL, "point_head: B and M must be positive");
+    TRY(check_extent(B, M, "point_head"));
     TRY(check_bcn(x, "x"));
     int c_in, ks, c[4], n_fc, fi[3], fo[3];
     point_head_dims(head_kind, &c_in, &ks, c, &n_fc, fi, fo);
@@ -729,6 +750,7 @@ extern "C" int dal3_point_head_forward(int head_kind, const void* packed, int dt
                                        int64_t out_stride, void* workspace, size_t workspace_bytes,
                                        dal3_stream stream) {
     if (!workspace) return fail(DAL3_EINVAL, "point_head: workspace is NULL");
+    TRY(check_extent(B, M, "point_head"));
     Carver c(workspace, workspace_bytes);
     const HeadWs ws = carve_head(c, B);
     if (!c.ok) return fail(DAL3_EWORKSPACE, "point_head: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
@@ -748,7 +770,7 @@ extern "C" int dal3_point_head_pool(int head_kind, const void* packed, int dtype
         return fail(DAL3_EINVAL, "point_head_pool: head_kind %d is not a point head", head_kind);
     if (!packed || !feat) return fail(DAL3_EINVAL, "point_head_pool: null pointer");
     if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) return fail(DAL3_EINVAL, "point_head_pool: workspace must be 16-byte aligned");
-    if (B <= 0 || M <= 0) return fail(DAL3_EINVAL, "point_head_pool: B and M must be positive");
+    TRY(check_extent(B, M, "point_head_pool"));
     TRY(check_bcn(x, "x"));
     hipStream_t s = static_cast<hipStream_t>(stream);
     int c_in, ks, c[4], n_fc, fi[3], fo[3];
@@ -769,7 +791,8 @@ extern "C" int dal3_point_head_pool(int head_kind, const void* packed, int dtype
 
 extern "C" int dal3_dynamic_box_est_forward(const void* packed, const float* embedding, int B, float* box_pred,
                                             void* workspace, size_t workspace_bytes, dal3_stream stream) {
-    if (!packed || !embedding || !box_pred || !workspace || B <= 0) return fail(DAL3_EINVAL, "dynamic_box_est: bad argument");
+    if (!packed || !embedding || !box_pred || !workspace) return fail(DAL3_EINVAL, "dynamic_box_est: bad argument");
+    TRY(check_extent(B, 1, "dynamic_box_est"));
     Carver c(workspace, workspace_bytes);
     const HeadWs ws = carve_head(c, B);
     if (!c.ok) return fail(DAL3_EWORKSPACE, "dynamic_box_est: workspace needs %zu bytes, got %zu", c.off, workspace_bytes);
@@ -909,7 +932,15 @@ extern "C" int dal3_crop_starts(const int64_t* counts, const int64_t* order, int
                                 int64_t* out_offsets, dal3_stream stream) {
     if (K_total < 0 || !box_start || (K_total > 0 && !counts))
         return fail(DAL3_EINVAL, "crop_starts: null counts / box_start or K_total < 0");
-    HIP_TRY(launch_crop_starts(counts, order, K_total, box_start, out_offsets, static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_crop_starts(counts, order, K_total, box_start, out_offsets, -1, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+extern "C" int dal3_crop_starts_capped(const int64_t* counts, const int64_t* order, int64_t K_total, int64_t* box_start,
+                                       int64_t* out_offsets, int64_t out_capacity, dal3_stream stream) {
+    if (K_total < 0 || !box_start || (K_total > 0 && !counts) || out_capacity < 0)
+        return fail(DAL3_EINVAL, "crop_starts_capped: null counts / box_start, K_total < 0 or out_capacity < 0");
+    HIP_TRY(launch_crop_starts(counts, order, K_total, box_start, out_offsets, out_capacity, static_cast<hipStream_t>(stream)));
     return 0;
 }
 
@@ -1566,7 +1597,8 @@ extern "C" size_t dal3_shared_mlp_layer_workspace_bytes(int c_in, int c_out) {
 
 extern "C" int dal3_shared_mlp_layer(const dal3_layer* layer, int relu, dal3_bcn x, int B, int N, float* y,
                                      void* workspace, size_t workspace_bytes, dal3_stream stream) {
-    if (!layer || !y || !workspace || B <= 0 || N <= 0) return fail(DAL3_EINVAL, "shared_mlp_layer: bad argument");
+    if (!layer || !y || !workspace) return fail(DAL3_EINVAL, "shared_mlp_layer: bad argument");
+    TRY(check_extent(B, N, "shared_mlp_layer"));
     TRY(check_bcn(x, "x"));
     if (x.dtype != DAL3_F32) return fail(DAL3_EINVAL, "shared_mlp_layer: the layer-wise test entry takes fp32 input only");
     const dal3_layer& L = *layer;
@@ -1609,7 +1641,7 @@ extern "C" size_t dal3_static_workspace_bytes(int B, int N, int two_stage) {
 
 extern "C" int dal3_static_forward(const dal3_static_args* a, int phases, dal3_stream stream) {
     if (!a) return fail(DAL3_EINVAL, "static_forward: args is NULL");
-    if (a->B <= 0 || a->N <= 0) return fail(DAL3_EINVAL, "static_forward: B and N must be positive");
+    TRY(check_extent(a->B, a->N, "static_forward"));
     if (!a->workspace) return fail(DAL3_EINVAL, "static_forward: workspace is NULL");
     if (!(phases & DAL3_PHASE_ALL)) return fail(DAL3_EINVAL, "static_forward: no phase selected");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1678,7 +1710,8 @@ extern "C" size_t dal3_dynamic_workspace_bytes(int B, int N, int) {
 
 extern "C" int dal3_dynamic_forward(const dal3_dynamic_args* a, int phases, dal3_stream stream) {
     if (!a) return fail(DAL3_EINVAL, "dynamic_forward: args is NULL");
-    if (a->B <= 0 || a->N <= 0 || a->n_box <= 0) return fail(DAL3_EINVAL, "dynamic_forward: B, N, n_box must be positive");
+    TRY(check_extent(a->B, a->N, "dynamic_forward"));
+    TRY(check_extent(a->B, a->n_box, "dynamic_forward (n_box)"));
     if (!a->workspace) return fail(DAL3_EINVAL, "dynamic_forward: workspace is NULL");
     if (!(phases & DAL3_PHASE_ALL)) return fail(DAL3_EINVAL, "dynamic_forward: no phase selected");
     hipStream_t s = static_cast<hipStream_t>(stream);

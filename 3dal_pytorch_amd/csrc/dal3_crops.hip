@@ -293,11 +293,13 @@ hipError_t launch_crop_fill(const float* points, const int64_t* point_offsets, c
 // box_start / out_offsets from counts, on the device (round 5: the chained run has no host round trip between count and
 // fill). The detections are laid out in the caller's ORDER (order[i] = the detection at output position i; NULL = as
 // numbered): out_offsets[i] = rows in front of position i (K+1 entries, the last = the total), box_start[order[i]] =
-// out_offsets[i], box_start[K] = the total. One workgroup: K is a segment's detections (~1e4), two trips.
+// out_offsets[i], box_start[K] = the total. cap >= 0 (dal3_crop_starts_capped): out_offsets — what CONSUMERS of the filled
+// buffer index it with — never point past the buffer's `cap` rows (the fill drops those rows); box_start keeps the true
+// prefix sums (the fill needs them, and box_start[K] is how the caller learns of the overflow). One workgroup: K is a segment's detections (~1e4), two trips.
 #define STARTS_PER 8                     // positions per thread and trip: a segment's ~1e4 detections are two trips of the workgroup
 __global__ __launch_bounds__(1024) void crop_starts_kernel(const int64_t* __restrict__ counts, const int64_t* __restrict__ order,
                                                            int64_t K, int64_t* __restrict__ box_start,
-                                                           int64_t* __restrict__ out_offsets) {
+                                                           int64_t* __restrict__ out_offsets, int64_t cap) {
     __shared__ int64_t s_wave[16];
     __shared__ int64_t s_run;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(1024) void crop_starts_kernel(const int64_t* __rest
         for (int q = 0; q < STARTS_PER; ++q) {
             if (i + q < K) {
                 box_start[k[q]] = excl;
-                if (out_offsets) out_offsets[i + q] = excl;
+                if (out_offsets) out_offsets[i + q] = cap >= 0 && excl > cap ? cap : excl;
             }
             excl += v[q];
         }
@@ -337,13 +339,13 @@ __global__ __launch_bounds__(1024) void crop_starts_kernel(const int64_t* __rest
     }
     if (threadIdx.x == 0) {
         box_start[K] = s_run;
-        if (out_offsets) out_offsets[K] = s_run;
+        if (out_offsets) out_offsets[K] = cap >= 0 && s_run > cap ? cap : s_run;
     }
 }
 
 hipError_t launch_crop_starts(const int64_t* counts, const int64_t* order, int64_t K, int64_t* box_start, int64_t* out_offsets,
-                              hipStream_t s) {
-    hipLaunchKernelGGL(crop_starts_kernel, dim3(1), dim3(1024), 0, s, counts, order, K, box_start, out_offsets);
+                              int64_t out_capacity, hipStream_t s) {
+    hipLaunchKernelGGL(crop_starts_kernel, dim3(1), dim3(1024), 0, s, counts, order, K, box_start, out_offsets, out_capacity);
     return hipGetLastError();
 }
 

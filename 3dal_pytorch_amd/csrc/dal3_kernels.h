@@ -231,7 +231,7 @@ hipError_t launch_crop_fill(const float* points, const int64_t* point_offsets, c
                             const int64_t* box_start, const int32_t* cc, double* out_points, int32_t* out_index,
                             int64_t out_capacity, hipStream_t s);
 hipError_t launch_crop_starts(const int64_t* counts, const int64_t* order, int64_t K, int64_t* box_start, int64_t* out_offsets,
-                              hipStream_t s);
+                              int64_t out_capacity, hipStream_t s);
 hipError_t launch_points_in_boxes(const void* points, int points_f64, int64_t P, int64_t stride, const double* planes,
                                   int K, int f32_math, uint8_t* inside, hipStream_t s);
 hipError_t launch_writeback(const double* final_boxes, const int32_t* final_idx, const double* pose_best,

@@ -425,6 +425,7 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
 #define DAL3_LP_A2_UNDER 1
 #endif
     // one register pair of dconv2's output chunk mt -> its 16-bit place in dconv3's input
+    static_assert(!DAL3_LP_A2_UNDER || T == 2, "pack_a2_pair's p -> (tile, half, word) map and the gap schedule below (16 MFMAs per chunk pair) are written for T == 2");
     auto pack_a2_pair = [&](int mt, int p) {
         const int tj = p >> 3, ts = (p >> 2) & 1, ti = p & 3;
         int4_t w = __builtin_bit_cast(int4_t, xd[tj][mt].k[ts]);

@@ -139,6 +139,64 @@ def world_census(device, group=None):
             "ranks_counted": int(round(float(one.item())))}
 
 
+RCCL_VIA = None          # compiled lazily (module import stays cheap)
+
+
+def parse_rccl_debug(texts):
+    """`texts`: the contents of the ranks' RCCL debug files. Returns what they say about the communicator:
+    `via` = how many channel connections each transport carries ("P2P/IPC", "P2P/direct pointer", "SHM/direct/direct",
+    "NET/Socket/0" ...: the words RCCL prints after "via" in its `Channel 00/0 : 0[0] -> 1[1] via P2P/IPC` lines),
+    `pairs` = the distinct (from, to) rank pairs among them, `nranks` = the communicator sizes its "Init COMPLETE" /
+    "nranks N" lines report, `xgmi_lines` = lines that mention XGMI (RCCL's topology dump names the link type), and
+    (the files are asked for by launch.rccl_debug_to() before torch is imported.)
+    `p2p_only` = every connection is a P2P one (on an MI355X node: xGMI; what SURVEY.md 8(e) asks of the one
+    all-gather). A pure function of the text: tests/test_dist_gloo.py feeds it a recorded sample."""
+    import re
+    global RCCL_VIA
+    if RCCL_VIA is None:
+        RCCL_VIA = (re.compile(r"(\d+)\[[0-9a-fA-F]+\]\s*->\s*(\d+)\[[0-9a-fA-F]+\].*?\bvia\s+(\S+(?: pointer)?)"),
+                    re.compile(r"\bnranks\s+(\d+)"))
+    via, pairs, nranks, xgmi, lines = {}, set(), set(), 0, 0
+    for text in texts:
+        for ln in text.splitlines():
+            lines += 1
+            if "XGMI" in ln.upper():
+                xgmi += 1
+            m = RCCL_VIA[0].search(ln)
+            if m:
+                via[m.group(3)] = via.get(m.group(3), 0) + 1
+                pairs.add((int(m.group(1)), int(m.group(2))))
+            m = RCCL_VIA[1].search(ln)
+            if m:
+                nranks.add(int(m.group(1)))
+    return {"files": len(texts), "lines": lines, "via": dict(sorted(via.items())), "pairs": len(pairs),
+            "nranks": sorted(nranks), "xgmi_lines": xgmi,
+            "p2p_only": bool(via) and all(k.startswith("P2P") for k in via)}
+
+
+def peer_access_row(device):
+    """this rank's view of HIP peer access: one 0/1 per visible device (1 on the diagonal). Host-side queries only."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return []
+    n = torch.cuda.device_count()
+    me = dev.index if dev.index is not None else torch.cuda.current_device()
+    return [1 if p == me or torch.cuda.can_device_access_peer(me, p) else 0 for p in range(n)]
+
+
+def gather_rows(row, width, device, group=None):
+    """one fixed-width row of small ints per rank -> every rank's rows (world x width), on every rank"""
+    row = (list(row) + [-1] * width)[:width]
+    if not (dist.is_available() and dist.is_initialized()):
+        return [row]
+    world = dist.get_world_size(group)
+    dev = "cpu" if host_staged(device, group) else device
+    mine = torch.tensor(row, dtype=torch.int32, device=dev)
+    out = torch.empty(world * width, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return [[int(v) for v in r] for r in out.cpu().view(world, width)]
+
+
 def replicate_(tensor, src=0, group=None):
     """Weights are REPLICATED: overwrite `tensor` on every rank with rank `src`'s values (a start-up broadcast, not
     part of the data path). No-op without a process group."""

@@ -175,6 +175,15 @@ class CapturedTrainStep:
         self.inputs = [None if t is None else torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
                        .copy_(t) for t in example_inputs]
         self.optimizer, self.optimizer_in_graph = optimizer, optimizer_in_graph
+        # optimizer outside the graph: the warm-up runs forward + backward with NO optimizer step, so it must leave no
+        # trace an eager run would not have — the BatchNorm running statistics / num_batches_tracked and the
+        # device-resident draw counters (train.draw_step) it advances are put back afterwards. With the optimizer inside,
+        # the warm-up iterations are real training steps on the example batch and everything moves together.
+        keep = None
+        if not optimizer_in_graph:
+            mods = list(model.modules())
+            keep = ([(b, b.detach().clone()) for b in model.buffers()],
+                    [(m.__dict__["_draw_step"], m.__dict__["_draw_step"].clone()) for m in mods if "_draw_step" in m.__dict__], mods)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -183,6 +192,13 @@ class CapturedTrainStep:
                 step_fn(*self.inputs).backward()
                 if optimizer_in_graph:
                     optimizer.step()
+            if keep is not None:
+                with torch.no_grad():
+                    for t, was in keep[0] + keep[1]:
+                        t.copy_(was)
+                    for m in keep[2]:                                # counters the warm-up itself created: back to their start
+                        if "_draw_step" in m.__dict__ and not any(m.__dict__["_draw_step"] is t for t, _ in keep[1]):
+                            m.__dict__["_draw_step"].zero_()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()

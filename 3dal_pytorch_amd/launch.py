@@ -22,6 +22,21 @@ import sys
 import threading
 
 
+def rccl_debug_to(directory):
+    """Ask RCCL for its INIT / P2P log, one file per process under `directory`, so that a multi-GPU run can PROVE which
+    transport carried the all-gather (xGMI peer-to-peer vs host shared memory vs sockets; dist.parse_rccl_debug reads
+    the files). RCCL takes the variables when its library is LOADED, i.e. with `import torch`: call this before that
+    import (measured on the pool: set between the import and init_process_group, no file is written). This module
+    imports torch nowhere at its top for that reason. The level is raised to INFO unless the caller asked for more
+    (TRACE); a caller's NCCL_DEBUG_SUBSYS is kept; the file pattern is this function's. Returns the file pattern."""
+    os.makedirs(directory, exist_ok=True)
+    if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):
+        os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,P2P,GRAPH")
+    os.environ["NCCL_DEBUG_FILE"] = os.path.join(directory, "rccl.%h.%p.log")
+    return os.environ["NCCL_DEBUG_FILE"]
+
+
 def under_launcher():
     """True when this process is a rank started by torch.distributed.run / torchrun."""
     return "RANK" in os.environ and "WORLD_SIZE" in os.environ

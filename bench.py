@@ -35,22 +35,36 @@ import time
 # the variable itself; setdefault keeps a caller's value. It must be set before the HSA runtime loads.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import numpy as np                                           # noqa: E402
-import torch                                                 # noqa: E402
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+launch = importlib.import_module("3dal_pytorch_amd.launch")     # (imports no torch)
+
+
+def rccl_debug_dir():
+    return os.path.join(ROOT, "gpurun_out", "rccl_debug_" + os.environ.get("MASTER_PORT", "29533"))
+
+
+# A rank of an RCCL job (not the self-launching parent, not a gloo rehearsal): RCCL's own INIT / P2P log goes to one
+# file per rank, parsed into the line's `rccl.transport` after the run. RCCL reads the variables when `import torch`
+# loads it, so this happens here, before that import.
+RCCL_RANK = ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("DAL3_FORCE_DIST") == "1")
+             and os.environ.get("DAL3_BENCH_BACKEND", "nccl") == "nccl" and "--plumbing-only" not in sys.argv)
+if RCCL_RANK:
+    launch.rccl_debug_to(rccl_debug_dir())
+
+import numpy as np                                           # noqa: E402
+import torch                                                 # noqa: E402
+
 from bench_workloads import (Part, Workload, apply_config, build_workload, workload_shards,      # noqa: E402,F401
-                             make_static, make_dynamic)
+                             make_static, make_dynamic, static_inputs, dynamic_inputs)
 from bench_kernels import MFMA_PEAK_TFLOPS, DNAME, events_ms, kernel_table, roofline_of      # noqa: E402
 dal3_dist = importlib.import_module("3dal_pytorch_amd.dist")
-launch = importlib.import_module("3dal_pytorch_amd.launch")
 
 LINE_CAP = 4096            # bytes of the one stdout line; r04's 21.7 KB line was not parsed by the driver
 REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
-OPTIONAL = ("gather_self_check", "ms_per_step_per_rank", "rccl", "ms_per_step_max", "ms_per_step_min", "ms_per_step_median")
+OPTIONAL = ("gather_self_check", "ms_per_step_per_rank", "ms_per_step_max", "ms_per_step_min", "ms_per_step_median", "rccl", "strong")
 METRIC = "object-crops/sec through static+dynamic refinement heads"
 
 
@@ -81,14 +95,8 @@ def time_steps(wl, dev, steps, warmup, use_dist, overlap=True):
             torch.distributed.barrier()
         torch.cuda.synchronize()
     last = [None] * len(wl.parts)
-    pipe = getattr(wl, "pipe", None)
 
     def step(final=False):
-        if pipe is not None:                                # consecutive steps on alternating streams (one head, no ranks)
-            pipe.submit(*wl.inputs)
-            for got in pipe.collect(keep=0 if final else len(pipe.streams) - 1):
-                last[0] = got
-            return
         for i, (fn, _, _) in enumerate(wl.parts):
             wl.gatherers[i].submit(fn())
             got = wl.gatherers[i].collect(keep=1 if (overlap and not final) else 0)
@@ -171,6 +179,64 @@ def gather_latency(wl, dev, iters=50):
         local = torch.zeros((n_local, 7), device=dev)
         outs.append(events_ms(lambda: dal3_dist.all_gather_boxes(local, n_total), iters, warmup=5))
     return [round(t * 1e3, 1) for t in outs]
+
+
+def strong_shards(args, world):
+    """the STRONG-scaling split of the configured single-head workload: ONE batch of the N = 1 size —
+    C2: 4096 crops — in contiguous ranges, rank r gets [r * ceil(B / W), ...). Returns (head, items, rank -> (first, count))."""
+    static = args.head == "static"
+    n_total = args.batch or (4096 if static else 1024)
+    return ("static" if static else "dynamic", n_total,
+            lambda r: (lambda lo, hi: (lo, hi - lo))(*dal3_dist.shard_range(n_total, r, world)))
+
+
+def strong_leg(args, dev, rank, world, use_dist):
+    """The same step with the batch of the N = 1 run SPLIT over the ranks instead of repeated on each (VERDICT r5 #2:
+    `value` above is weak scaling and says nothing about per-rank launch overhead or the gather; this record does).
+    Same fences, same K, the max over ranks; `vs_n1` stays null: the N = 1 figure is another run's line (the driver
+    divides the lines it collected itself)."""
+    name, n_total, span = strong_shards(args, world)
+    lo, n = span(rank)
+    prec, static = args.precision, args.head == "static"
+    if static:
+        model, inputs, _ = make_static(max(n, 1), args.points, dev, lo, prec, two=getattr(args, "two_stage", False))
+        inputs_for = lambda first, count: static_inputs(first, count, args.points, dev, prec)      # noqa: E731
+    else:
+        model, inputs = make_dynamic(max(n, 1), dev, lo, prec, args.points)
+        inputs_for = lambda first, count: dynamic_inputs(first, count, args.points, dev, prec)     # noqa: E731
+    wl = Workload()
+    wl.parts = [Part(name, model, inputs, n, n_total, span, inputs_for)]
+    wl.n_total = n_total
+    dt, per_step, _ = time_steps(wl, dev, args.steps, args.warmup, use_dist, overlap=not args.serial_gather)
+    check = gather_self_check(wl, dev, rank, world)
+    return {"scaling": "strong", "items": n_total, "items_per_rank": [span(r)[1] for r in range(world)],
+            "value": round(n_total * args.steps / dt, 1), "unit": "object-crops/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step_per_rank": [round(t / args.steps * 1e3, 3) for t in wl.rank_seconds],
+            "gather_equals_single_rank": check["equal"] if check and rank == 0 else None, "vs_n1": None}
+
+
+def transport_report(dev, backend, debug_dir):
+    """which wires the collective used: every rank's HIP peer-access row (gathered; call before the group is destroyed)
+    and what RCCL's own INIT / P2P log says (parsed by rank 0 after the run). On gloo: the rows only."""
+    rows = dal3_dist.gather_rows(dal3_dist.peer_access_row(dev), 16, dev)
+    n_dev = torch.cuda.device_count() if dev.type == "cuda" else 0
+    return {"backend": backend, "peer_access": ["".join(str(v) if v >= 0 else "" for v in r[:n_dev]) for r in rows],
+            "debug_dir": os.path.relpath(debug_dir, ROOT) if debug_dir else None}
+
+
+def transport_from_logs(tr):
+    """rank 0, after destroy_process_group: the ranks' RCCL debug files -> `via` counts etc. (dist.parse_rccl_debug)"""
+    d = tr.get("debug_dir")
+    if not d:
+        return tr
+    texts = []
+    try:
+        for f in sorted(os.listdir(os.path.join(ROOT, d))):
+            with open(os.path.join(ROOT, d, f), errors="replace") as fh:
+                texts.append(fh.read())
+    except OSError:
+        pass
+    return dict(tr, **dal3_dist.parse_rccl_debug(texts))
 
 
 def cpu_baseline(host, budget_s=20.0, threads=None):
@@ -256,6 +322,19 @@ def plumbing_only(args, rank, world):
         ok = ok and bool(torch.equal(dal3_dist.all_gather_boxes(p.run(), p.n_total), want))
     check = gather_self_check(wl, cpu, rank, world, rows=5)
     census = dal3_dist.world_census(cpu)
+    strong = None
+    if scaling == "weak":                                   # the split the GPU run's `strong` record uses, gathered once
+        name, n_strong, sspan = strong_shards(args, world)
+        lo, cnt = sspan(rank)
+        sstub = _Stub(7000.0)
+        dal3_dist.replicate_(sstub.bias)
+        g = dal3_dist.all_gather_boxes(sstub.refine(*idx(lo, cnt)), n_strong)
+        want = torch.arange(n_strong, dtype=torch.float32)[:, None] * 10 + torch.arange(7, dtype=torch.float32)[None] + 1.0 + 7000.0
+        s_ok = g.shape == (n_strong, 7) and bool(torch.equal(g, want))
+        ok = ok and s_ok
+        strong = {"scaling": "strong", "items": n_strong, "items_per_rank": [sspan(r)[1] for r in range(world)], "value": None,
+                  "unit": "object-crops/s", "ms_per_step": None, "gathered_ok": s_ok, "vs_n1": None}
+    census["transport"] = transport_report(cpu, backend, None)
     if os.environ.get("DAL3_BENCH_FAIL_RANK") == str(rank):          # the launcher's failure path, for its test
         sys.exit(3)
     if os.environ.get("DAL3_BENCH_HANG_RANK") == str(rank):          # a rank that never comes back, for the launcher's timeout
@@ -269,7 +348,7 @@ def plumbing_only(args, rank, world):
                             "config": {"workload": args.config or "stub", "heads": [
                                 {"head": p.name, "items": p.n_total, "items_per_rank": [p.shard(r)[1] for r in range(world)]}
                                 for p in wl.parts]},
-                            "roofline": None, "cpu_baseline": None, "rccl": census, "ms_per_step_per_rank": rank_ms,
+                            "roofline": None, "cpu_baseline": None, "rccl": census, "strong": strong, "ms_per_step_per_rank": rank_ms,
                             "gather_equals_single_rank": check["equal"] if check else None, "gather_self_check": check}),
               flush=True)
     sys.exit(0 if ok else 4)
@@ -349,6 +428,7 @@ def main():
         # "nccl" = RCCL over xGMI, the product transport. DAL3_BENCH_BACKEND=gloo: the rehearsal transport (boxes staged
         # through pinned host memory) for boxes where RCCL cannot connect the ranks, e.g. two ranks on ONE GPU.
         backend = os.environ.get("DAL3_BENCH_BACKEND", "nccl")
+        debug_dir = rccl_debug_dir() if RCCL_RANK else None   # RCCL's own account of the transport, one file per rank
         torch.distributed.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
 
     wl = build_workload(args, dev, rank, world)
@@ -374,7 +454,10 @@ def main():
         rec["gather_self_check"] = check
         rec["rccl"] = dict(census, allgather_us=gather_latency(wl, dev), ranks_share_gpus=share_gpu,
                            message_bytes_per_rank=[((n_total + world - 1) // world) * 28 for _, _, n_total in wl.parts],
-                           rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()))
+                           rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()),
+                           transport=transport_report(dev, backend, debug_dir))
+        # ONE batch of the N = 1 size split over the ranks (C4 is that already)
+        rec["strong"] = None if mixed else strong_leg(args, dev, rank, world, use_dist)
     if rank == 0 and not args.no_extras and not mixed:
         # the dominant kernel, live: every kernel of the step through its own entry, HIP events on the launch stream
         kr, mean_count = kernel_table(wl.model, wl.inputs, wl.static, wl.B, wl.N, iters=max(3, min(args.steps, 10)))
@@ -388,6 +471,8 @@ def main():
         torch.distributed.destroy_process_group()
     sys.stdout.flush()
     C.CDLL(None).fflush(None)                                   # whatever C stdio still holds goes to stderr too
+    if rank == 0 and use_dist:                              # (after destroy_process_group: every rank's log is complete)
+        rec["rccl"]["transport"] = transport_from_logs(rec["rccl"]["transport"])
     if rank == 0:
         os.write(real_stdout, (compact_line(rec) + "\n").encode())
         write_full(dict(rec, **full))

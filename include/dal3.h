@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dal3_stream;               /* hipStream_t */
 
-#define DAL3_VERSION 140                 /* 0.1.4: dal3_crop_starts, dal3_crop_fill takes out_capacity; 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums; .1: dal3_tr_fc_*, dal3_tr_wgrad_final_many, dal3_parse_box_pred* */
+#define DAL3_VERSION 150                 /* 0.1.5: dal3_crop_starts_capped; upper bounds on B, N (DAL3_MAX_*); 0.1.4: dal3_crop_starts, dal3_crop_fill takes out_capacity; 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums; .1: dal3_tr_fc_*, dal3_tr_wgrad_final_many, dal3_parse_box_pred* */
 
 enum {
     DAL3_OK = 0,
@@ -34,10 +34,21 @@ enum {
     DAL3_EHIP = -3                       /* a HIP runtime call failed (message has hipGetErrorString) */
 };
 
+/* Upper bounds of ONE call's batch, checked by every entry that takes (B, N) or (B, M) before anything is carved or
+ * launched: a call beyond them returns DAL3_EINVAL ("split the batch"). The kernels index an item's points and the
+ * per-item outputs with 32-bit ints and launch one workgroup (or worklist entry) per 32-point tile of an item, so a
+ * larger job would get a truncated grid or a wrapped offset instead of an error. None of them is reachable with buffers
+ * that fit the 288 GB of an MI355X except through a wrong argument: 2^31 tiles of fp32 xyz points alone are 824 GB. */
+#define DAL3_MAX_ITEMS 16777216            /* B  <= 2^24 items (crops / track-frames) per call */
+#define DAL3_MAX_POINTS_PER_ITEM 16777216  /* N, M, n_box <= 2^24 points per item */
+#define DAL3_MAX_TILES 2147483647          /* B * ceil(N / 32) <= 2^31 - 1 (the launch grid) */
+
 /* arithmetic dtype of the shared-MLP kernels of a packed head. DAL3_F32: exact-fp32 MFMA (the reference's
  * precision). DAL3_BF16 / DAL3_F16: weights and inter-layer activations rounded to 16 bits, fp32 accumulate,
- * v_mfma_f32_32x32x16_{bf16,f16} (BASELINE.json configs C3 / C5); first layer, FC heads, dconv5, mask and all
- * I/O stay fp32. The same dtype must be given to dal3_pack_weights and to the forward calls. */
+ * v_mfma_f32_32x32x16_{bf16,f16} (BASELINE.json configs C3 / C5); dconv5 (128 -> 2) runs as one more 16-bit
+ * out-tile of the decode stack; first layer, the per-crop term of dconv1, FC heads, mask and all I/O stay fp32.
+ * tests/emu16.py is the reference model of this arithmetic: the kernels' error against the fp32 oracle equals the
+ * model's to a few per cent (rms), and the tests hold them to 1.5 x (max) / 1.15 x (rms) of it. The same dtype must be given to dal3_pack_weights and to the forward calls. */
 enum { DAL3_F32 = 0, DAL3_BF16 = 1, DAL3_F16 = 2,
        /* fp16 MFMAs on (hi, lo) SPLIT operands: x = x_hi + x_lo, w = w_hi + w_lo in fp16, w x ~ w_hi x_hi + w_hi x_lo + w_lo x_hi,
         * fp32 accumulate — fp32 ACCURACY (logits ~1e-6 of their range, like DAL3_F32) from three fp16 MFMAs per fp32 one.
@@ -317,6 +328,13 @@ int dal3_crop_fill(const float* points, const int64_t* point_offsets, const doub
                    int64_t out_capacity, const void* workspace, size_t workspace_bytes, dal3_stream stream);
 int dal3_crop_starts(const int64_t* counts, const int64_t* order, int64_t K_total, int64_t* box_start,
                      int64_t* out_offsets, dal3_stream stream);
+/* The same with out_offsets CAPPED at out_capacity (>= 0), for a caller that fills a buffer sized from an estimate and
+ * hands (out_points, out_offsets) on to consumers that index out_points by them (dal3_static_crop_prep,
+ * dal3_dynamic_item_prep): rows the fill dropped are then rows no offset points at — a detection past the capacity
+ * reads as shorter or empty, never past the buffer. box_start is NOT capped: dal3_crop_fill needs the true starts, and
+ * box_start[K_total] > out_capacity is how the caller learns that the buffer was too small. */
+int dal3_crop_starts_capped(const int64_t* counts, const int64_t* order, int64_t K_total, int64_t* box_start,
+                            int64_t* out_offsets, int64_t out_capacity, dal3_stream stream);
 
 /* ---- training-mode building blocks of the shared-MLP stacks (first slice) --------------
  * What loss.backward() drives through Conv1d(k=1) + BatchNorm1d (batch statistics) + ReLU + max over points

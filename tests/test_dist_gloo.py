@@ -250,3 +250,24 @@ def test_eval_drivers_shard_and_gather(tmp_path, head):
     assert len(np.unique(results[1][:, 6])) == n                   # the stand-in encodes the global item index
     for world in (2, 3):
         assert np.array_equal(results[world], results[1]), world
+
+
+def test_rccl_debug_log_parser_counts_transports_pairs_and_ranks():
+    """dist.parse_rccl_debug on recorded RCCL INFO lines (the format of `Channel .. : a[dev] -> b[dev] via <transport>`
+    and `... nranks N ... Init COMPLETE`): what bench.py's `rccl.transport` is built from on a multi-GPU node"""
+    dal3_dist = importlib.import_module("3dal_pytorch_amd.dist")
+    xgmi = "\n".join([
+        "node:101:201 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC",
+        "node:101:201 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC",
+        "node:101:201 [0] NCCL INFO Channel 00/0 : 0[c1000] -> 7[e5000] via P2P/direct pointer",
+        "node:101:201 [0] NCCL INFO comm 0x55 rank 0 nranks 8 cudaDev 0 busId c1000 commId 0x1 - Init COMPLETE",
+        "node:101:201 [0] NCCL INFO  GPU/C1000 (0) --XGMI--> GPU/E5000",
+    ])
+    got = dal3_dist.parse_rccl_debug([xgmi, "node:102:202 [1] NCCL INFO Channel 00/0 : 1[1] -> 2[2] via P2P/IPC\n"])
+    assert got["files"] == 2 and got["via"] == {"P2P/IPC": 3, "P2P/direct pointer": 1} and got["pairs"] == 3
+    assert got["nranks"] == [8] and got["xgmi_lines"] == 1 and got["p2p_only"] is True
+    shm = dal3_dist.parse_rccl_debug(["n:1:1 [0] NCCL INFO Channel 00 : 0[0] -> 1[1] via SHM/direct/direct\n"])
+    assert shm["via"] == {"SHM/direct/direct": 1} and shm["p2p_only"] is False
+    assert dal3_dist.parse_rccl_debug([]) == {"files": 0, "lines": 0, "via": {}, "pairs": 0, "nranks": [], "xgmi_lines": 0,
+                                              "p2p_only": False}
+    assert dal3_dist.peer_access_row("cpu") == [] and dal3_dist.gather_rows([1, 0], 4, "cpu") == [[1, 0, -1, -1]]

@@ -195,6 +195,7 @@ def test_static_c5_full_size_lowprec(prec):
 # ("bf16 storage"); the oracle is given the stored values, so both sides compute on identical inputs. The box
 # estimators are teacher-forced on the exact-fp32 path's mask (`mask_override`: the device sampler, keyed on the item
 # and the count, then draws the same points, which the oracle is handed through `forced`).
+import emu16                                            # noqa: E402  (the model of 16-bit arithmetic)
 from test_gpu_lowprec import BARS                       # noqa: E402  (the one table of 16-bit bars)
 
 FULL_MEASURED = []
@@ -209,6 +210,21 @@ def _bar16(key, prec, value, where):
     os.makedirs(out, exist_ok=True)
     json.dump(FULL_MEASURED, open(os.path.join(out, "lowprec_fullsize_measured.json"), "w"), indent=1)
     assert value < BARS[key][prec], (key, prec, value, BARS[key][prec], where)
+
+
+def _model16(key, prec, hip_err, model_err, where, n_bits=0):
+    """the HIP path's error on these rows <= emu16.MODEL_SLACK x the error of the arithmetic itself (tests/emu16.py) on
+    the SAME rows (+ four bits for mask-flip fractions)"""
+    hip_err, model_err = float(hip_err), float(model_err)
+    limit = (emu16.RMS_SLACK if key.endswith("_rms") else emu16.MODEL_SLACK) * model_err + (4.0 / n_bits if n_bits else 0.0)
+    FULL_MEASURED.append({"bar": key + "_vs_model", "prec": prec, "value": hip_err, "model": model_err, "limit": limit,
+                          "ratio": hip_err / model_err if model_err else None, "where": where})
+    assert hip_err <= limit, (key, prec, "HIP", hip_err, "model of the arithmetic", model_err, where)
+
+
+def _flips(a, b):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    return float(((a[..., 0] < a[..., 1]) != (b[..., 0] < b[..., 1])).float().mean())
 
 
 def test_dynamic_c3_full_size_bf16_vs_oracle_on_a_stratified_sample():
@@ -234,13 +250,22 @@ def test_dynamic_c3_full_size_bf16_vs_oracle_on_a_stratified_sample():
     want = R.dynamic_forward(R.as_torch_sd(sd), p_t, b_t, forced=(torch.from_numpy(got["obj_idx"].astype(np.int64)), got["counts"]))
     wl = want["logits"].numpy()
     _bar16("logits", prec, rel_err(free["logits"][sel].cpu().numpy(), wl), "C3 full size, 32 rows vs oracle")
+    tsd = R.as_torch_sd(sd)
+    emu_lg = emu16.ins_seg(tsd, p_t, prec).numpy()                             # the same 32 rows in modelled bf16 arithmetic
+    _model16("logits", prec, rel_err(free["logits"][sel].cpu().numpy(), wl), rel_err(emu_lg, wl), "C3 full size, 32 rows")
+    _model16("logits_rms", prec, emu16.rms(free["logits"][sel].cpu(), wl), emu16.rms(emu_lg, wl), "C3 full size, 32 rows")
+    _model16("mask_flip", prec, _flips(free["logits"][sel].cpu(), wl), _flips(emu_lg, wl), "C3 full size, 32 rows", n_bits=32 * 5120)
     margin = wl[:, :, 1] - wl[:, :, 0]
     sure = np.abs(margin) > 2 * BARS["logits"][prec] * np.abs(wl).max()
     assert sure.mean() > 0.5 and np.array_equal(free["mask"][sel].cpu().numpy().astype(bool)[sure], (margin > 0)[sure])
     _bar16("box", prec, rel_err(got["embedding"], torch.cat([want["_point_e"], want["_box_e"]], 1).numpy()), "C3 full size embedding vs oracle")
+    emu_emb = torch.cat([emu16.embedding(tsd, want["_object_pts"].float(), "point_emb", prec), emu16.embedding(tsd, b_t, "box_emb", prec)], 1)
+    want_emb = torch.cat([want["_point_e"], want["_box_e"]], 1).numpy()
+    _model16("box", prec, rel_err(got["embedding"], want_emb), rel_err(emu_emb.numpy(), want_emb), "C3 full size embedding, 32 rows")
     want_bp = np.concatenate([want["center"].numpy(), want["heading_scores"].numpy(), want["heading_residuals_normalized"].numpy(),
                               want["size_scores"].numpy(), want["size_residuals_normalized"].numpy().reshape(len(rows), 9)], 1)
     _bar16("box_tail", prec, rel_err(got["bp"], want_bp), "C3 full size bp vs oracle")
+    _model16("box_tail", prec, rel_err(got["bp"], want_bp), rel_err(R.dynamic_box_est(tsd, emu_emb).numpy(), want_bp), "C3 full size bp, 32 rows")
     same = (got["bp"][:, 3:15].argmax(1) == want_bp[:, 3:15].argmax(1)) & (got["bp"][:, 27:30].argmax(1) == want_bp[:, 27:30].argmax(1))
     assert same.mean() > 0.7                                                  # (a near-tie class may flip: a different bin centre)
     wb7 = R.decode_dynamic(want, torch.from_numpy(i8[rows]))
@@ -272,12 +297,19 @@ def test_static_c5_full_size_fp16_vs_oracle_on_a_stratified_sample():
     want = R.static_one_forward(R.as_torch_sd(sd), p_t, i_t, forced=(torch.from_numpy(got["obj_idx"].astype(np.int64)), got["counts"]))
     wl = want["logits"].numpy()
     _bar16("logits", prec, rel_err(free["logits"][sel].cpu().numpy(), wl), "C5 full size, 48 rows vs oracle")
+    tsd = R.as_torch_sd(sd)
+    emu_lg = emu16.ins_seg(tsd, p_t, prec).numpy()                             # the same 48 rows in modelled fp16 arithmetic
+    _model16("logits", prec, rel_err(free["logits"][sel].cpu().numpy(), wl), rel_err(emu_lg, wl), "C5 full size, 48 rows")
+    _model16("logits_rms", prec, emu16.rms(free["logits"][sel].cpu(), wl), emu16.rms(emu_lg, wl), "C5 full size, 48 rows")
+    _model16("mask_flip", prec, _flips(free["logits"][sel].cpu(), wl), _flips(emu_lg, wl), "C5 full size, 48 rows", n_bits=48 * 4096)
     margin = wl[:, :, 1] - wl[:, :, 0]
     sure = np.abs(margin) > 2 * BARS["logits"][prec] * np.abs(wl).max()
     assert sure.mean() > 0.5 and np.array_equal(free["mask"][sel].cpu().numpy().astype(bool)[sure], (margin > 0)[sure])
     wbp = np.concatenate([want["center_boxnet"].numpy(), want["heading_scores"].numpy(), want["heading_residuals_normalized"].numpy(),
                           want["size_scores"].numpy(), want["size_residuals_normalized"].numpy().reshape(len(rows), 9)], 1)
     _bar16("box", prec, rel_err(got["bp1"], wbp), "C5 full size bp1 vs oracle")
+    _model16("box", prec, rel_err(got["bp1"], wbp), rel_err(emu16.static_box_est(tsd, want["_object_pts"].float(), prec).numpy(), wbp),
+             "C5 full size bp1, 48 rows")
     same = (got["bp1"][:, 3:15].argmax(1) == wbp[:, 3:15].argmax(1)) & (got["bp1"][:, 27:30].argmax(1) == wbp[:, 27:30].argmax(1))
     assert same.mean() > 0.7
     wb7 = R.decode_static(want, i_t, False)

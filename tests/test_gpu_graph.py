@@ -122,23 +122,25 @@ def test_captured_train_step_matches_eager_steps(inside):
             cap = graph.CapturedTrainStep(model, opt, step, pts, i, g, warmup=1)      # one real step; capturing runs nothing
             last = cap(pts, i, g)                                                     # the second step
         elif mode == "graph":
-            # the warm-up runs forward + backward only (no optimizer step): two replays = two steps
-            cap = graph.CapturedTrainStep(model, opt, step, pts, i, g, warmup=1, optimizer_in_graph=False)
+            # the warm-up (default: 3 iterations) runs forward + backward only, no optimizer step, and leaves no trace:
+            # BN running statistics and the draw counters are put back — two replays = two eager steps
+            cap = graph.CapturedTrainStep(model, opt, step, pts, i, g, optimizer_in_graph=False)
             cap(pts, i, g)
             last = cap(pts, i, g)
         else:
-            if not inside:                                                            # what the capture's warm-up ran: one forward +
-                step(pts, i, g).backward()                                            # backward without a step (it advances the draw counters)
             for _ in range(2):
                 opt.zero_grad(set_to_none=True)
                 last = step(pts, i, g)
                 last.backward()
                 opt.step()
         torch.cuda.synchronize()
-        runs[mode] = (float(last.detach()), {k: v.detach().clone() for k, v in model.named_parameters()})
+        runs[mode] = (float(last.detach()), {k: v.detach().clone() for k, v in model.named_parameters()},
+                      {k: v.detach().clone() for k, v in model.named_buffers()})
     assert abs(runs["graph"][0] - runs["eager"][0]) <= 1e-5 * abs(runs["eager"][0])
     for k, v in runs["eager"][1].items():
         assert torch.allclose(runs["graph"][1][k], v, rtol=1e-5, atol=1e-6), k
+    for k, v in runs["eager"][2].items():                                             # BN running statistics, num_batches_tracked
+        assert torch.allclose(runs["graph"][2][k].double(), v.double(), rtol=1e-5, atol=1e-6), k
 
 
 def test_a_captured_training_draw_advances_on_every_replay():

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+import emu16
 from _common import build_model, positions_from_indices, recentred_sd, rel_err, synth
 from oracle import ref_heads as R
 
@@ -25,6 +26,30 @@ BARS = {                                             # measured worst (bf16 / fp
 }
 TOL_LOGITS = BARS["logits"]                          # (the margin band for "only near-ties may flip")
 MEASURED = []
+# Round 6: next to each absolute bar, a bar that does NOT come from the product — tests/emu16.py computes
+# the same rows with the oracle's layers in 16-bit MFMA arithmetic (operands rounded per layer, fp32 accumulate, the
+# fp32 parts in fp32) and the HIP path may lose at most emu16.MODEL_SLACK (1.5) x what that model loses. Mask bits: the
+# same factor plus four bits (a handful of near-ties decides either way).
+
+
+def _model_bar(key, prec, hip_err, model_err, where, n_bits=0, distance=None):
+    hip_err, model_err = float(hip_err), float(model_err)
+    slack = emu16.RMS_SLACK if key.endswith("_rms") else emu16.MODEL_SLACK      # an rms over >= 1e4 values is a stable statistic
+    limit = slack * model_err + (4.0 / n_bits if n_bits else 0.0)
+    MEASURED.append({"bar": key + "_vs_model", "prec": prec, "value": hip_err, "model": model_err, "limit": limit,
+                     "ratio": hip_err / model_err if model_err else None, "where": where,
+                     "hip_to_model_distance": None if distance is None else float(distance)})
+    assert hip_err <= limit, (key, prec, "HIP", hip_err, "model of the arithmetic", model_err, where)
+    if distance is not None and key == "box":
+        # the point heads (three 16-bit layers, a max, fp32 FC tail) are short enough for the model to predict the HIP
+        # VALUES, not just the size of their error: measured 0.03 of the error (the rest is summation order)
+        assert distance <= 0.15 * model_err, (key, prec, "HIP to model", distance, "model error", model_err, where)
+
+
+def _flips(logits_a, logits_b):
+    """fraction of points whose mask bit (strict '<', static_model.py:59) differs between two sets of logits"""
+    a, b = torch.as_tensor(logits_a), torch.as_tensor(logits_b)
+    return float(((a[..., 0] < a[..., 1]) != (b[..., 0] < b[..., 1])).float().mean())
 
 
 def _bar(key, prec, value, where):
@@ -68,6 +93,11 @@ def test_ins_seg_lowprec_vs_fp32_oracle(prec, n):
     model.precision = prec
     out = model(pts, init, gt)
     _bar("logits", prec, rel_err(out["logits"].cpu().numpy(), want), f"ins_seg vs oracle n={n}")
+    emu = emu16.ins_seg(R.as_torch_sd(sd), torch.from_numpy(pts_np).transpose(2, 1), prec).numpy()
+    _model_bar("logits", prec, rel_err(out["logits"].cpu().numpy(), want), rel_err(emu, want), f"ins_seg n={n}",
+               distance=rel_err(out["logits"].cpu().numpy(), emu))
+    _model_bar("logits_rms", prec, emu16.rms(out["logits"].cpu(), want), emu16.rms(emu, want), f"ins_seg n={n}")
+    _model_bar("mask_flip", prec, _flips(out["logits"].cpu(), want), _flips(emu, want), f"ins_seg n={n}", n_bits=8 * n)
     margin = want[:, :, 1] - want[:, :, 0]
     sure = np.abs(margin) > 2 * TOL_LOGITS[prec] * np.abs(want).max()
     assert np.array_equal(out["mask"].cpu().numpy()[sure], (margin > 0)[sure])   # only near-ties may flip
@@ -80,10 +110,22 @@ def test_static_two_lowprec_vs_fp32_path(prec):
     model.precision = prec
     o = model._run(pts, init, gt)
     _bar("mask_flip", prec, (o["mask"] != ref["mask"]).float().mean().item(), "static_two 64x1024 vs fp32 path")
+    tsd, pts_t = R.as_torch_sd(sd), torch.from_numpy(pts_np).transpose(2, 1)
+    want_lg = R.ins_seg(tsd, pts_t)
+    _model_bar("mask_flip", prec, (o["mask"] != ref["mask"]).float().mean().item(), _flips(emu16.ins_seg(tsd, pts_t, prec), want_lg),
+               "static_two 64x1024", n_bits=64 * 1024)
     # teacher-force the fp32 segmentation (the device sampler then draws the same points)
     t = model._run(pts, init, gt, mask_override=ref["mask"])
     assert torch.equal(t["obj_idx"], ref["obj_idx"])
     _bar("box", prec, rel_err(t["bp1"].cpu().numpy(), ref["bp1"].cpu().numpy()), "static_two bp1, fp32 mask forced")
+    # the same object points through the oracle's estimator and through the model of its 16-bit arithmetic
+    obj = R.take_object_pts(pts_t, ref["obj_idx"].cpu().long(), ref["counts"].cpu().numpy())
+    shift = np.zeros((64, 39), np.float32)
+    shift[:, :3] = init.cpu().numpy()[:, :3]                # (the two-stage model adds init_box to bp1's centre in place, static_model.py:174)
+    want_bp1 = R.static_box_est(tsd, obj, "box_est_one").numpy() + shift
+    assert rel_err(ref["bp1"].cpu().numpy(), want_bp1) < 1e-4                         # (the fp32 path IS the oracle, to 1e-4)
+    _model_bar("box", prec, rel_err(t["bp1"].cpu().numpy(), want_bp1),
+               rel_err(emu16.static_box_est(tsd, obj, prec, "box_est_one").numpy() + shift, want_bp1), "static_two bp1, fp32 mask forced")
     # stage two re-centres on the DECODED stage-one box: a flipped heading/size argmax is a different problem,
     # so compare the crops whose stage-one classes agree (nearly all of them)
     b1, r1 = t["bp1"].cpu().numpy(), ref["bp1"].cpu().numpy()
@@ -138,6 +180,12 @@ def test_dynamic_lowprec_vs_oracle_teacher_forced(prec):
     free = model._run(dp, dbx, init_box8=di8)
     wl = want["logits"].numpy()
     _bar("logits", prec, rel_err(free["logits"].cpu().numpy(), wl), "dynamic vs oracle")
+    tsd = R.as_torch_sd(sd)
+    emu_lg = emu16.ins_seg(tsd, p_t, prec).numpy()
+    _model_bar("logits", prec, rel_err(free["logits"].cpu().numpy(), wl), rel_err(emu_lg, wl), "dynamic 4x5120",
+               distance=rel_err(free["logits"].cpu().numpy(), emu_lg))
+    _model_bar("logits_rms", prec, emu16.rms(free["logits"].cpu(), wl), emu16.rms(emu_lg, wl), "dynamic 4x5120")
+    _model_bar("mask_flip", prec, _flips(free["logits"].cpu(), wl), _flips(emu_lg, wl), "dynamic 4x5120", n_bits=B * 5120)
     margin = wl[:, :, 1] - wl[:, :, 0]
     sure = np.abs(margin) > 2 * TOL_LOGITS[prec] * np.abs(wl).max()
     assert np.array_equal(free["mask"].cpu().numpy()[sure], (margin > 0)[sure])          # only near-ties may flip
@@ -147,11 +195,17 @@ def test_dynamic_lowprec_vs_oracle_teacher_forced(prec):
     emb = o["embedding"].cpu().numpy()
     _bar("box", prec, rel_err(emb[:, :256], want["_point_e"].numpy()), "dynamic point_e vs oracle")
     _bar("box", prec, rel_err(emb[:, 256:], want["_box_e"].numpy()), "dynamic box_e vs oracle")
+    emu_pe = emu16.embedding(tsd, want["_object_pts"].float(), "point_emb", prec)
+    emu_be = emu16.embedding(tsd, b_t, "box_emb", prec)
+    _model_bar("box", prec, rel_err(emb[:, :256], want["_point_e"].numpy()), rel_err(emu_pe.numpy(), want["_point_e"].numpy()), "dynamic point_e",
+               distance=rel_err(emb[:, :256], emu_pe.numpy()))
+    _model_bar("box", prec, rel_err(emb[:, 256:], want["_box_e"].numpy()), rel_err(emu_be.numpy(), want["_box_e"].numpy()), "dynamic box_e")
     bp = o["bp"].cpu().numpy()
     wbp = np.concatenate([want["center"].numpy(), want["heading_scores"].numpy(),
                           want["heading_residuals_normalized"].numpy(), want["size_scores"].numpy(),
                           want["size_residuals_normalized"].numpy().reshape(B, 9)], 1)
     _bar("box_tail", prec, rel_err(bp, wbp), "dynamic bp vs oracle")
+    _model_bar("box_tail", prec, rel_err(bp, wbp), rel_err(R.dynamic_box_est(tsd, torch.cat([emu_pe, emu_be], 1)).numpy(), wbp), "dynamic bp")
     # decoded boxes wherever the 16-bit argmaxes agree with the oracle's (a near-tie class may flip)
     same = (bp[:, 3:15].argmax(1) == wbp[:, 3:15].argmax(1)) & (bp[:, 27:30].argmax(1) == wbp[:, 27:30].argmax(1))
     assert same.any()
@@ -174,6 +228,11 @@ def test_c5_static_n4096_lowprec_vs_oracle(prec):
     model.precision = prec
     free = model._run(pts, init, gt)
     _bar("logits", prec, rel_err(free["logits"].cpu().numpy(), wl), "C5 shape vs oracle")
+    emu_lg = emu16.ins_seg(tsd, pts_t, prec).numpy()
+    _model_bar("logits", prec, rel_err(free["logits"].cpu().numpy(), wl), rel_err(emu_lg, wl), "C5 shape 8x4096",
+               distance=rel_err(free["logits"].cpu().numpy(), emu_lg))
+    _model_bar("logits_rms", prec, emu16.rms(free["logits"].cpu(), wl), emu16.rms(emu_lg, wl), "C5 shape 8x4096")
+    _model_bar("mask_flip", prec, _flips(free["logits"].cpu(), wl), _flips(emu_lg, wl), "C5 shape 8x4096", n_bits=B * N)
     margin = wl[:, :, 1] - wl[:, :, 0]
     sure = np.abs(margin) > 2 * TOL_LOGITS[prec] * np.abs(wl).max()
     assert np.array_equal(free["mask"].cpu().numpy()[sure], (margin > 0)[sure])
@@ -186,6 +245,8 @@ def test_c5_static_n4096_lowprec_vs_oracle(prec):
                           want["heading_residuals_normalized"].numpy(), want["size_scores"].numpy(),
                           want["size_residuals_normalized"].numpy().reshape(B, 9)], 1)
     _bar("box", prec, rel_err(o["bp1"].cpu().numpy(), wbp), "C5 shape bp1 vs oracle")
+    _model_bar("box", prec, rel_err(o["bp1"].cpu().numpy(), wbp),
+               rel_err(emu16.static_box_est(tsd, want["_object_pts"].float(), prec).numpy(), wbp), "C5 shape bp1")
 
 
 def test_lowprec_api_errors():

@@ -138,6 +138,13 @@ def test_segment_plan_chain_equals_the_step_by_step_run():
                                 n_static_points=1024, capacity=100)
     small.run(d_pts)
     assert small.overflowed()
+    # the overflowing run must not hand the consumers offsets past its 100-row buffer — they are capped at
+    # the capacity (the true prefix sums stay in `start`, which is how overflowed() knows), monotone, and what fits
+    # in front of the cap is untouched
+    off, start = small.crop.offsets.cpu().numpy(), small.crop.start.cpu().numpy()
+    order = small.crop.d_order.cpu().numpy()
+    assert off.max() == 100 and start[-1] > 100 and (np.diff(off) >= 0).all()
+    assert np.array_equal(off[:-1], np.minimum(start[order], 100)) and off[-1] == 100
     small.grow()
     small.run(d_pts)
     assert not small.overflowed() and np.array_equal(small.detections("static")[tokens[0]][0], got_s[tokens[0]][0])

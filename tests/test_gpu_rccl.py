@@ -69,6 +69,35 @@ def test_two_rank_rehearsal_on_one_gpu_static_line_proves_its_gather():
     # rank 0's roofline is part of the (<= 4 KB) line at every world size
     assert rec["roofline"]["kernel"].startswith("ins_seg_decode") and 0 < rec["roofline"]["frac"] < 1
     assert rec["config"]["items_per_gpu"] == 512
+    # round 6: next to the weak-scaling value, the same 512-crop batch SPLIT over the two ranks (256 each, real kernels),
+    # gathered, and rank 0's recomputation of rank 1's first rows bit-equal
+    st = rec["strong"]
+    assert (st["scaling"], st["items"], st["items_per_rank"]) == ("strong", 512, [256, 256])
+    assert st["value"] > 0 and st["ms_per_step"] > 0 and st["gather_equals_single_rank"] is True and st["vs_n1"] is None
+    assert len(st["ms_per_step_per_rank"]) == 2
+    tr = rec["rccl"]["transport"]
+    assert tr["backend"] == "gloo" and tr["peer_access"] == ["1", "1"]          # one device, each rank sees itself
+
+
+def test_one_rank_rccl_bench_line_carries_the_transport_report():
+    """`bench.py --gpus 1` with the RCCL path forced (DAL3_FORCE_DIST=1): the line's `rccl.transport` is filled from
+    RCCL's own INIT log (one file per rank under gpurun_out/rccl_debug_<port>/) — with one rank there is no peer
+    connection to report, but the communicator's size, the parsed file and the peer-access row are there; on a
+    multi-GPU node the same code reports `via` (P2P/IPC = xGMI) for every channel."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR")}
+    env.update(DAL3_FORCE_DIST="1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--batch", "256", "--no-extras"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0].encode()) <= 4096
+    rec = json.loads(lines[0])
+    tr = rec["rccl"]["transport"]
+    assert rec["rccl"]["backend"] == "nccl" and tr["backend"] == "nccl" and tr["peer_access"] == ["1"]
+    assert tr["files"] >= 1 and tr["lines"] > 0 and 1 in tr["nranks"], tr
+    assert tr["via"] == {} and tr["p2p_only"] is False                          # (no peer with one rank)
+    assert rec["strong"]["items_per_rank"] == [256] and rec["strong"]["value"] > 0
 
 
 def test_two_rank_rehearsal_on_one_gpu_mixed_segment_checks_both_heads():

@@ -49,6 +49,46 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.dal3_static_workspace_bytes(8, 1024, 0) > 8 * 1024 * 4
 
 
+def test_batches_beyond_the_32_bit_grid_and_offset_limits_are_refused_without_a_gpu():
+    """B * ceil(N / 32) >= 2^31 used to become a truncated `(unsigned)` grid. Every entry that takes
+    (B, N) / (B, M) now returns DAL3_EINVAL before anything is carved or launched (so this runs without a GPU; the
+    pointers below are never dereferenced): too many tiles, too many items, too many points per item — and the
+    largest job inside the limits still gets past this check (it then fails on its NULL workspace / null pointer)."""
+    lib = hip.lib()
+    header = open(os.path.join(ROOT, "include", "dal3.h")).read()
+    lim = {k: int(v) for k, v in re.findall(r"#define\s+(DAL3_MAX_[A-Z_]+)\s+(\d+)", header)}
+    assert lim == {"DAL3_MAX_ITEMS": 1 << 24, "DAL3_MAX_POINTS_PER_ITEM": 1 << 24, "DAL3_MAX_TILES": (1 << 31) - 1}
+    fake = ctypes.c_void_p(0x1000)                       # non-NULL, never read: every call returns before a launch
+    x = hip.BCN(fake, 1, 1, 1, hip.F32, 0)
+    big_B, big_N = 1 << 24, 1 << 13                      # 2^24 items x 2^13 points = 2^32 tiles of 32 points
+    calls = {
+        "ins_seg_forward": lambda B, N: lib.dal3_ins_seg_forward(fake, hip.F32, 3, x, B, N, fake, fake, None, fake, 1 << 40, None),
+        "ins_seg_encode": lambda B, N: lib.dal3_ins_seg_encode(fake, hip.F32, 3, x, B, N, fake, None),
+        "ins_seg_decode": lambda B, N: lib.dal3_ins_seg_decode(fake, hip.F32, 3, x, B, N, fake, fake, fake, None),
+        "segment_counts": lambda B, N: lib.dal3_segment_counts(fake, B, N, fake, None),
+        "mask_compact_sample": lambda B, N: lib.dal3_mask_compact_sample(fake, x, B, N, 3, 512, hip.SAMPLER_DEVICE, None, 0, 0, fake,
+                                                                         fake, fake, fake, 1 << 40, None),
+        "point_head_forward": lambda B, N: lib.dal3_point_head_forward(hip.HEAD_STATIC_BOX_EST, fake, hip.F32, x, B, N, fake, 39, fake,
+                                                                       1 << 40, None),
+        "point_head_pool": lambda B, N: lib.dal3_point_head_pool(hip.HEAD_STATIC_BOX_EST, fake, hip.F32, x, B, N, None, fake, None, 0, None),
+    }
+    for name, call in calls.items():
+        for B, N, word in ((big_B, big_N, b"DAL3_MAX_TILES"), (big_B + 1, 32, b"DAL3_MAX_ITEMS"), (2, (1 << 24) + 1, b"DAL3_MAX_POINTS_PER_ITEM"),
+                           (0, 32, b"positive"), (4, -1, b"positive")):
+            assert call(B, N) == hip.EINVAL, (name, B, N)
+            assert word in lib.dal3_last_error(), (name, B, N, lib.dal3_last_error())
+    sa = hip.StaticArgs()
+    sa.B, sa.N, sa.workspace = big_B, big_N, fake
+    assert lib.dal3_static_forward(ctypes.byref(sa), hip.PHASE_ALL, None) == hip.EINVAL and b"DAL3_MAX_TILES" in lib.dal3_last_error()
+    da = hip.DynamicArgs()
+    da.B, da.N, da.n_box, da.workspace = 4, 5120, (1 << 24) + 1, fake
+    assert lib.dal3_dynamic_forward(ctypes.byref(da), hip.PHASE_ALL, None) == hip.EINVAL and b"n_box" in lib.dal3_last_error()
+    # inside the limits the check lets the call through to the next one: the workspace is too small (no launch either)
+    assert lib.dal3_ins_seg_forward(fake, hip.F32, 3, x, 1 << 16, 1 << 13, fake, fake, None, fake, 16, None) == hip.EWORKSPACE
+    # dal3_crop_starts_capped: a negative capacity is an argument error
+    assert lib.dal3_crop_starts_capped(fake, None, 4, fake, fake, -1, None) == hip.EINVAL
+
+
 @pytest.mark.parametrize("kind,ctor", [
     ("static_one", lambda: static_model.StaticModelOneBoxEst(3, 3)),
     ("static_two", lambda: static_model.StaticModelTwoBoxEst(3, 3)),

@@ -88,8 +88,18 @@ def test_eight_ranks_c2_weak_and_c4_ragged_on_gloo():
         assert len(lines) == 1, out.stdout
         rec = _strict(lines[0])
         assert rec["n_gpus"] == 8 and rec["gathered_ok"] is True
-        assert rec["rccl"] == {"backend": "gloo", "world_size": 8, "ranks_counted": 8}
+        assert {k: rec["rccl"][k] for k in ("backend", "world_size", "ranks_counted")} == {"backend": "gloo", "world_size": 8, "ranks_counted": 8}
+        # round 6: which wires carried the gather (here: gloo, no HIP devices -> eight empty peer-access rows, no RCCL log)
+        assert rec["rccl"]["transport"] == {"backend": "gloo", "peer_access": [""] * 8, "debug_dir": None}
         assert rec["scaling"] == ("strong" if config == "C4" else "weak")
+        # ... and the STRONG record next to C2's weak `value`: ONE 4096-crop batch in contiguous ranges of 512;
+        # C4 is strong scaling already
+        if config == "C2":
+            st = rec["strong"]
+            assert (st["scaling"], st["items"], st["items_per_rank"]) == ("strong", 4096, [512] * 8)
+            assert st["gathered_ok"] is True and st["vs_n1"] is None and st["unit"] == "object-crops/s"
+        else:
+            assert rec["strong"] is None
         heads = [(h["head"], h["items"], h["items_per_rank"]) for h in rec["config"]["heads"]]
         assert heads == want_heads, heads
         assert len(rec["ms_per_step_per_rank"]) == 8
@@ -118,12 +128,35 @@ def test_bench_self_launches_two_ranks_and_relays_one_line():
     assert len(lines) == 1, out.stdout
     rec = _strict(lines[0])
     assert rec["n_gpus"] == 2 and rec["plumbing_only"] and rec["gathered_ok"]
-    assert rec["rccl"] == {"backend": "gloo", "world_size": 2, "ranks_counted": 2}
+    assert {k: rec["rccl"][k] for k in ("backend", "world_size", "ranks_counted")} == {"backend": "gloo", "world_size": 2, "ranks_counted": 2}
+    assert rec["rccl"]["transport"]["backend"] == "gloo" and rec["strong"] is None       # (the 37-item stub is split already)
     # what a real N > 1 line carries: every rank's own step time, and rank 0's recomputation of rank 1's first rows
     # (its inputs regenerated from their global indices, the replicated weight) equal to what the gather delivered
     assert len(rec["ms_per_step_per_rank"]) == 2
     assert rec["gather_equals_single_rank"] is True
     assert rec["gather_self_check"]["checks"] == [{"head": "stub", "peer": 1, "first_item": 19, "rows": 5, "equal": True}]
+
+
+def test_two_ranks_c2_carry_the_strong_record_and_a_ragged_split():
+    """the N > 1 line holds, next to the weak-scaling `value`, the same batch SPLIT over the ranks. World 2
+    with C2's 4096 crops (2048 each) and, through --batch 37, a ragged split (19 + 18)."""
+    for extra, want in ((["--config", "C2"], (4096, [2048, 2048])), (["--head", "static", "--batch", "37", "--config", "C2"], None)):
+        out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--plumbing-only"] + extra, capture_output=True, text=True,
+                             env=_env(), timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        rec = _strict([ln for ln in out.stdout.splitlines() if ln.strip()][0])
+        st = rec["strong"]
+        assert st["scaling"] == "strong" and st["gathered_ok"] is True and st["value"] is None
+        if want:
+            assert (st["items"], st["items_per_rank"]) == want
+    bench = importlib.import_module("bench")
+
+    class A:
+        head, batch = "dynamic", 37
+    name, n, span = bench.strong_shards(A, 2)
+    assert (name, n, span(0), span(1)) == ("dynamic", 37, (0, 19), (19, 18))
+    A.batch = 0
+    assert bench.strong_shards(A, 8)[1] == 1024 and bench.strong_shards(A, 8)[2](7) == (896, 128)
 
 
 def test_a_failing_rank_fails_the_launcher():
