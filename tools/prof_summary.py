@@ -28,7 +28,7 @@ def short(name):
 
 
 for sub, sfx in (("prof_kt", ""), ("prof_kt_bf16", "_bf16"), ("prof_kt_f16x3", "_f16x3"), ("prof_kt_c3", "_c3"), ("prof_kt_c5", "_c5"),
-                 ("prof_kt_maxpool", "_maxpool"), ("prof_kt_maxpool_bf16", "_maxpool_bf16"), ("prof_kt_b64", "_b64"),
+                 ("prof_kt_maxpool", "_maxpool"), ("prof_kt_maxpool_bf16", "_maxpool_bf16"), ("prof_kt_b64", "_b64"), ("prof_kt_b64n1024", "_b64n1024"), ("prof_kt_b512", "_b512"),
                  ("prof_kt_train", "_train"), ("prof_kt_train_x3", "_train_x3"), ("prof_kt_pipeline", "_pipeline")):
     stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
     if not stats:

@@ -6,7 +6,7 @@
 # tools/_pmc_lib.sh: output directory cleared first, exit code and CSV checked, a failed pass named on stdout and in the
 # script's exit code — tools/collect_profiles.sh refuses a run whose log holds such a line.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
@@ -24,6 +24,8 @@ trace_pass $O/prof_kt_f16x3 -- $B --no-extras --precision f16x3 --steps 10 --war
 trace_pass $O/prof_kt_c3 -- $B --no-extras --config C3 --steps 10 --warmup 2;           cp $O/prof_kt_c3.out $O/bench_c3_under_rocprof.json
 trace_pass $O/prof_kt_c5 -- $B --no-extras --config C5 --steps 10 --warmup 2;           cp $O/prof_kt_c5.out $O/bench_c5_under_rocprof.json
 trace_pass $O/prof_kt_b64 -- $B --no-extras --batch 64 --points 4096 --steps 20 --warmup 3; cp $O/prof_kt_b64.out $O/bench_b64_under_rocprof.json
+trace_pass $O/prof_kt_b64n1024 -- $B --no-extras --batch 64 --points 1024 --steps 20 --warmup 3; cp $O/prof_kt_b64n1024.out $O/bench_b64n1024_under_rocprof.json
+trace_pass $O/prof_kt_b512 -- $B --no-extras --batch 512 --points 1024 --steps 20 --warmup 3; cp $O/prof_kt_b512.out $O/bench_b512_under_rocprof.json
 trace_pass $O/prof_kt_maxpool -- $X --only maxpool --maxpool-storage fp32 --maxpool-iters 10 --out $O/bench_maxpool_under_rocprof.json
 trace_pass $O/prof_kt_maxpool_bf16 -- $X --only maxpool --maxpool-storage bf16 --maxpool-iters 10 --out $O/bench_maxpool_bf16_under_rocprof.json
 # ---- HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and MFMA-busy + clock per precision at C2's shape
@@ -78,6 +80,10 @@ python3 $R/tools/bench_pipeline.py > $O/pipeline_fp32.json 2>/dev/null
 python3 $R/tools/bench_pipeline.py --precision bf16 > $O/pipeline_bf16.json 2>/dev/null
 trace_pass $O/prof_kt_pipeline -- python3 $R/tools/bench_pipeline.py --precision bf16 --iters 3
 python3 $R/tools/bench_latency.py > $O/bench_latency.json 2>/dev/null
+# ---- the mid-size regime (round 6): every strong-scaling share and the reference's eval batch as a fraction of the
+# large-batch rate; where the decode kernel's HBM-side reads come from (old vs XCD-contiguous block map), when the A/B build exists
+python3 $R/tools/bench_shares.py --out $O/share_efficiency.json 2> $O/share_efficiency.log
+[ -f $R/variants/decnoxcd.so ] && { bash $R/tools/pmc_decode_traffic.sh gpurun_out/pmc_dec 3dal_pytorch_amd/lib3dal_hip.so variants/decnoxcd.so > /dev/null 2>&1 || PROF_RC=1; }
 # ---- the N > 1 path rehearsed on this box's one GPU (two ranks on device 0, boxes gathered over gloo)
 DAL3_BENCH_SHARE_GPU=1 DAL3_BENCH_BACKEND=gloo $B --gpus 2 --steps 10 --warmup 3 > $O/bench_rehearsal_2ranks.json 2>/dev/null
 DAL3_BENCH_SHARE_GPU=1 DAL3_BENCH_BACKEND=gloo $B --gpus 2 --config C4 --steps 2 --warmup 1 --no-extras > $O/bench_rehearsal_2ranks_c4.json 2>/dev/null
