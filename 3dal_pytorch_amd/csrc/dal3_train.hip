@@ -1835,8 +1835,19 @@ __global__ __launch_bounds__(256) void tr_bnbwd_apply_kernel(const float* __rest
             const uint32_t other = (uint32_t)__shfl_xor((int)mx, off);
             mx = other > mx ? other : mx;
         }
-        // 64 words, a wave's by its index: 32,768 waves on ONE word are ~370 us of serialised atomics (88 per us), on 64 a few
-        if ((threadIdx.x & 63) == 0) atomicMax(amax + ((blockIdx.y * 4u + (threadIdx.x >> 6)) & 63u), mx);
+        // 64 words, a workgroup's by its index: 32,768 waves on ONE word are ~370 us of serialised atomics (88 per us).
+        // Round 6: the four waves of the workgroup meet in LDS first and ONE atomic leaves per workgroup — the 64 words are
+        // four 64-byte lines, and atomics on one line serialise at the memory side whatever the word: with an atomic per
+        // wave this pass took 183 / 97 us at 256 / 128 channels x 262,144 rows against 139 / 66 us without the maximum
+        // (profiles/r06_train_roofline_f16x3.json). (C % (4 << cgs) == 0 for every caller that asks for the maximum: no
+        // thread has left at the top, the barrier is safe.)
+        __shared__ uint32_t s_mx[4];
+        if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t a = s_mx[0] > s_mx[1] ? s_mx[0] : s_mx[1], b = s_mx[2] > s_mx[3] ? s_mx[2] : s_mx[3];
+            atomicMax(amax + ((blockIdx.y + 17u * blockIdx.x) & 63u), a > b ? a : b);
+        }
     }
     if (SEGSUM) {                                           // a thread's rows in order (above), then the block's row lanes in order
         __shared__ double sm[1024];                         // [row lane][channel of the block]: RP x (4 << cgs) = 1024

@@ -42,7 +42,17 @@ launch = importlib.import_module("3dal_pytorch_amd.launch")     # (imports no to
 
 
 def rccl_debug_dir():
-    return os.path.join(ROOT, "gpurun_out", "rccl_debug_" + os.environ.get("MASTER_PORT", "29533"))
+    """where the ranks' RCCL logs go: gpurun_out/ under the repo, or the system's temporary directory when the repo
+    cannot be written (every rank of a node makes the same choice: same file system, same user)"""
+    name = "rccl_debug_" + os.environ.get("MASTER_PORT", "29533")
+    for base in (os.path.join(ROOT, "gpurun_out"), os.path.join(os.environ.get("TMPDIR", "/tmp"), "dal3_bench")):
+        try:
+            os.makedirs(os.path.join(base, name), exist_ok=True)
+            if os.access(os.path.join(base, name), os.W_OK):
+                return os.path.join(base, name)
+        except OSError:
+            continue
+    return None
 
 
 # A rank of an RCCL job (not the self-launching parent, not a gloo rehearsal): RCCL's own INIT / P2P log goes to one
@@ -50,8 +60,10 @@ def rccl_debug_dir():
 # loads it, so this happens here, before that import.
 RCCL_RANK = ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("DAL3_FORCE_DIST") == "1")
              and os.environ.get("DAL3_BENCH_BACKEND", "nccl") == "nccl" and "--plumbing-only" not in sys.argv)
-if RCCL_RANK:
-    launch.rccl_debug_to(rccl_debug_dir())
+T_START = time.time()
+RCCL_DEBUG_DIR = rccl_debug_dir() if RCCL_RANK else None
+if RCCL_DEBUG_DIR:
+    launch.rccl_debug_to(RCCL_DEBUG_DIR)
 
 import numpy as np                                           # noqa: E402
 import torch                                                 # noqa: E402
@@ -221,7 +233,7 @@ def transport_report(dev, backend, debug_dir):
     rows = dal3_dist.gather_rows(dal3_dist.peer_access_row(dev), 16, dev)
     n_dev = torch.cuda.device_count() if dev.type == "cuda" else 0
     return {"backend": backend, "peer_access": ["".join(str(v) if v >= 0 else "" for v in r[:n_dev]) for r in rows],
-            "debug_dir": os.path.relpath(debug_dir, ROOT) if debug_dir else None}
+            "debug_dir": (os.path.relpath(debug_dir, ROOT) if debug_dir.startswith(ROOT) else debug_dir) if debug_dir else None}
 
 
 def transport_from_logs(tr):
@@ -231,8 +243,11 @@ def transport_from_logs(tr):
         return tr
     texts = []
     try:
-        for f in sorted(os.listdir(os.path.join(ROOT, d))):
-            with open(os.path.join(ROOT, d, f), errors="replace") as fh:
+        for f in sorted(os.listdir(os.path.join(ROOT, d))):                 # (os.path.join keeps an absolute d as it is)
+            path = os.path.join(ROOT, d, f)
+            if os.path.getmtime(path) < T_START - 5.0:                      # an earlier job's log under the same port
+                continue
+            with open(path, errors="replace") as fh:
                 texts.append(fh.read())
     except OSError:
         pass
@@ -428,7 +443,7 @@ def main():
         # "nccl" = RCCL over xGMI, the product transport. DAL3_BENCH_BACKEND=gloo: the rehearsal transport (boxes staged
         # through pinned host memory) for boxes where RCCL cannot connect the ranks, e.g. two ranks on ONE GPU.
         backend = os.environ.get("DAL3_BENCH_BACKEND", "nccl")
-        debug_dir = rccl_debug_dir() if RCCL_RANK else None   # RCCL's own account of the transport, one file per rank
+        debug_dir = RCCL_DEBUG_DIR                          # RCCL's own account of the transport, one file per rank
         torch.distributed.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
 
     wl = build_workload(args, dev, rank, world)

@@ -23,6 +23,7 @@ losses = importlib.import_module("3dal_pytorch_amd.losses")
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--lib", default=None, help="another build of the library (variants/NAME.so): A/B runs of the step on one box")
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--backends", default="hip,torch")
@@ -41,6 +42,9 @@ def main():
     ap.add_argument("--sampler", default="numpy", choices=["numpy", "device"],
                     help="object-point sampling in the train-mode forward: the reference's host loop or the GPU kernel")
     args = ap.parse_args()
+    if args.lib:
+        hip_mod = importlib.import_module("3dal_pytorch_amd._hip")
+        hip_mod.LIB_PATH = os.path.abspath(args.lib)        # before the first hip.lib()
     B, N = args.batch, args.points
     dev = torch.device("cuda", 0)
     dynamic = args.kind == "dynamic"
