@@ -18,6 +18,11 @@ pytestmark = pytest.mark.gpu
 
 CASES = [("static_one", 1, 1024), ("static_one", 3, 700), ("static_two", 2, 33), ("static_one", 16, 1024),
          ("dynamic", 2, 0), ("static_one", 5, 4096)]
+# round 6: the throughput decode kernel gives XCD x (workgroup ids = x mod 8) a contiguous range of logical blocks
+# (csrc/dal3_pointmlp.hip). N = 600 is five 128-point workgroups per crop, so B = 17 .. 24 makes grids of 85 .. 120 blocks:
+# every residue of G mod 8 (5, 2, 7, 4, 1, 6, 3, 0) — the ragged split of the map — against the latency family, which has
+# no such map. (323 .. 456 tiles of 32 points: the default dispatch takes the latency kernels, the flag the throughput ones.)
+CASES += [("static_one", B, 600) for B in range(17, 25)]
 
 
 def _run(kind, B, N):
