@@ -25,7 +25,7 @@ bad = 0
 model = sm.StaticModelOneBoxEst()
 model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.state_dict("static_one").items()})
 model = model.to(dev).eval()
-for B, N in ((4096, 1024), (300, 700), (64, 4096)):
+for B, N in ((4096, 1024), (300, 700), (64, 4096), (256, 1024), (150, 1024), (40, 1024)):       # (round 6: the mid-size schedules)
     p, i, g = synth.static_crops(min(B, 256), N, seed=5)
     reps = (B + p.shape[0] - 1) // p.shape[0]
     p = np.tile(p, (reps, 1, 1))[:B]

@@ -61,6 +61,25 @@ def main():
         nb = sum(0 if torch.equal(run(), first) else 1 for _ in range(n))
         bad += nb
         print(f"wgrad {M}: {co} x {ci}: {n} launches, {nb} mismatching", flush=True)
+    # round 6: the BatchNorm-backward apply pass that also takes max |dz| — the four waves of a workgroup meet in LDS behind a
+    # barrier and ONE integer atomicMax leaves per workgroup: dz and the maximum bit for bit, every launch
+    for M, C in ((262144, 256), (262144, 128), (65536 + 96, 512), (8192, 64)):
+        z = torch.randn((M, C), device="cuda", generator=g)
+        bn = train._BN(z, torch.rand(C, device="cuda", generator=g) + 0.5, torch.randn(C, device="cuda", generator=g), None, None, rows=M)
+        da = torch.randn((M, C), device="cuda", generator=g) * 1e-6
+
+        def run():
+            words = torch.zeros(64, dtype=torch.int32, device="cuda")
+            dz = bn.backward(z, da=da, amax=words)[0]
+            return dz, words
+        dz0, w0 = run()
+        assert int(w0.max()) == int(dz0.abs().max().view(torch.int32))
+        nb = 0
+        for _ in range(n):
+            dz1, w1 = run()
+            nb += 0 if (torch.equal(dz1, dz0) and torch.equal(w1, w0)) else 1
+        bad += nb
+        print(f"apply+amax {M} x {C}: {n} launches, {nb} mismatching", flush=True)
     print("total mismatches", bad)
     sys.exit(1 if bad else 0)
 
