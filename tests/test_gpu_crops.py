@@ -203,3 +203,40 @@ def test_crop_plan_track_major_order_capacity_and_reuse():
     assert np.array_equal(o.cpu().numpy(), flat[:cap]) and bool((guard[cap:] == -7.0).all())
     with pytest.raises(ValueError):
         crops.CropPlan([s.shape[0] for s in sweeps], dets, poses, order=order[:-1])
+
+
+@pytest.mark.parametrize("K", [1, 7, 1000, 8192 + 5, 20000])
+def test_crop_starts_on_the_device_equal_numpy_prefix_sums_plain_and_capped(K):
+    """dal3_crop_starts / dal3_crop_starts_capped (round 6) against NumPy: box_start[order[i]] = rows in front of output
+    position i and box_start[K] = the total, always the TRUE prefix sums; out_offsets the same by position — and, for
+    the capped entry, min(., capacity) for capacities of 0, inside the range, exactly the total and beyond it (the
+    consumers of a buffer of `capacity` rows must never be pointed past it). One to three trips of the one workgroup
+    (8192 positions per trip), with and without an output order."""
+    lib = hip.lib()
+    rng = np.random.default_rng(K)
+    counts = rng.integers(0, 400, size=K).astype(np.int64)
+    counts[rng.integers(0, K, size=max(K // 10, 1))] = 0
+    total = int(counts.sum())
+    d_counts = torch.from_numpy(counts).cuda()
+    for order in (None, rng.permutation(K).astype(np.int64)):
+        d_order = None if order is None else torch.from_numpy(order).cuda()
+        by_pos = counts if order is None else counts[order]
+        want_off = np.concatenate([[0], np.cumsum(by_pos)])
+        want_start = np.empty(K + 1, np.int64)
+        want_start[np.arange(K) if order is None else order] = want_off[:-1]
+        want_start[K] = total
+        start = torch.full((K + 1,), -7, dtype=torch.int64, device="cuda")
+        off = torch.full((K + 1,), -7, dtype=torch.int64, device="cuda")
+        hip.check(lib.dal3_crop_starts(hip.ptr(d_counts), hip.ptr(d_order), K, hip.ptr(start), hip.ptr(off), hip.stream()))
+        assert np.array_equal(start.cpu().numpy(), want_start) and np.array_equal(off.cpu().numpy(), want_off)
+        for cap in (0, total // 3, max(total - 1, 0), total, total + 100):
+            start.fill_(-7)
+            off.fill_(-7)
+            hip.check(lib.dal3_crop_starts_capped(hip.ptr(d_counts), hip.ptr(d_order), K, hip.ptr(start), hip.ptr(off), cap,
+                                                  hip.stream()))
+            assert np.array_equal(start.cpu().numpy(), want_start), cap                     # never capped
+            assert np.array_equal(off.cpu().numpy(), np.minimum(want_off, cap)), cap
+        # out_offsets is optional
+        start.fill_(-7)
+        hip.check(lib.dal3_crop_starts_capped(hip.ptr(d_counts), hip.ptr(d_order), K, hip.ptr(start), None, 5, hip.stream()))
+        assert np.array_equal(start.cpu().numpy(), want_start)
