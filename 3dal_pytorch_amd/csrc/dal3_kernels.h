@@ -409,6 +409,17 @@ hipError_t launch_tr_linear_pool_x3(const float* a, int64_t M, int c_in, int64_t
                                     int relu_in, const float* W, int64_t ldw, const float* bias, const float* out_scale,
                                     const float* out_shift, int64_t seg, int c_out, float* g, int32_t* arg, float* ws,
                                     unsigned long long* packed, hipStream_t s);
+// A persistent kernel's workgroup w walks the groups w, w + G, w + 2G, ... Workgroup ids are dealt round-robin over the 8
+// XCDs (an L2 each), so consecutive groups — the groups of ONE crop, which share the crop's 2-KiB dconv1 term — land on
+// different XCDs and each L2 fetches the term for itself. With this virtual id XCD x (ids = x mod 8) owns the
+// contiguous virtual blocks [x G/8, (x+1) G/8): a crop's groups of one round share an L2 (round 6; a bijection on [0, G),
+// so every group is still walked exactly once; G not a multiple of 8: the plain id).
+#if defined(__HIPCC__)
+__device__ __forceinline__ int xcd_contiguous_block() {
+    const unsigned g = gridDim.x, b = blockIdx.x;
+    return (g & 7u) ? (int)b : (int)((b & 7u) * (g >> 3) + (b >> 3));
+}
+#endif
 // small jobs: one 16-wave workgroup per 32-point tile, activations through LDS (dal3_latency.hip); bit-identical results
 hipError_t launch_ins_seg_encode_lat(const InsSegW& w, BCN pts, int c_in, int B, int N, float* g, hipStream_t s);
 hipError_t launch_ins_seg_decode_lat(const InsSegW& w, BCN pts, int c_in, int B, int N, const float* gbias, float* logits,

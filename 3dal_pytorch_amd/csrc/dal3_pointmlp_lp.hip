@@ -202,7 +202,11 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
         gb_nx[0] = gbias[bb * 512 + wave * 64 + l];
         gb_nx[1] = gbias[bb * 512 + 256 + wave * 64 + l];
     };
-    prefetch(blockIdx.x);
+#ifndef DAL3_LP_DEC_XCD
+#define DAL3_LP_DEC_XCD 1
+#endif
+    const int vblk = DAL3_LP_DEC_XCD ? xcd_contiguous_block() : (int)blockIdx.x;    // (dal3_kernels.h: a crop's groups on one L2)
+    prefetch(vblk);
     // The crop's dconv1 term goes to LDS one group ahead: here for the first group, in front of dconv4 for the others
     // (nobody reads the old one after the main loop; dconv4's barrier, here acquire(), publishes the new one).
     // (the compiler's wait for gb_nx is an `s_waitcnt vmcnt(0)`: it does not know of the ring's LDS-DMA, which it
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256) void ins_seg_decode_lp_kernel(InsSegLpW w, BCN
     publish_gb();
     ring.acquire();                                        // segment 0 of the first group (publishes s_bias ... too)
 
-  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+  for (int grp = vblk; grp < n_groups; grp += gridDim.x) {
     const int64_t b = grp / tiles_per_item;
     const int n0 = ((grp % tiles_per_item) * LP_WAVES + wave) * (32 * T);
     LP_STAMP(0);

@@ -307,8 +307,9 @@ __global__ __launch_bounds__(256) void ins_seg_decode_x3_kernel(InsSegX3W w, BCN
         gb_nx[0] = gbias[bb * 512 + threadIdx.x];
         gb_nx[1] = gbias[bb * 512 + 256 + threadIdx.x];
     };
-    prefetch(blockIdx.x);
-    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int vblk = xcd_contiguous_block();               // (dal3_kernels.h: a crop's groups on one L2)
+    prefetch(vblk);
+    for (int grp = vblk; grp < n_groups; grp += gridDim.x) {
         st.pin(st.START, 0);
         const int64_t b = grp / tiles_per_item;
         const int n0 = ((grp % tiles_per_item) * X3_WAVES + wave) * (32 * T);
