@@ -126,7 +126,11 @@ class SegmentPlan:
         tensor. Returns {"static": (det rows (n_det,7) fp32, match (P,) i32), "dynamic": (...)} — device tensors, valid
         once the stream has run; nothing here waits for the GPU (except the very first run of a plan without a
         capacity, which reads the crops' size back once). marks: optional callable(name) invoked between the stages
-        (the bench records an event there)."""
+        (the bench records an event there).
+        A run whose crops outgrew the buffer (`overflowed()`, one host read AFTER the run) is not a result: the last
+        detections' crops were cut short or empty (their offsets are capped at the capacity, so nothing is read past
+        the buffer — dal3_crop_starts_capped), their tracks' boxes and the rows written back for them are wrong;
+        `grow()` and run again before using any of it."""
         lib, st = _hip.lib(), _hip.stream
         mark = marks or (lambda name: None)
         out, offsets = self.crop.run(d_pts)
