@@ -115,7 +115,7 @@ def main():
     if "dynamic" in only:
         for prec in ("fp32", "bf16"):
             shapes = {}
-            for B in (1024, 256, 64):
+            for B in (1024, 256, 128, 64):            # (128 = C3's share at 8 ranks)
                 model, inputs = W.make_dynamic(B, dev, 0, prec)
                 shapes[f"{B}x5120"] = measure(model, inputs, False, B, 5120, arch.dynamic_flop(5120), args.iters if B <= 256 else 8)
                 del model, inputs
