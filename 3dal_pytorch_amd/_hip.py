@@ -223,7 +223,7 @@ def require_gpu(t, what):
 
 
 STORAGE = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
-BCN_NO_SMALL_JOB_KERNELS, BCN_NO_WORKLIST = 1, 2
+BCN_NO_SMALL_JOB_KERNELS, BCN_NO_WORKLIST, BCN_NO_LDS_SAMPLER = 1, 2, 4
 # dal3_bcn.flags of every view bcn() builds (include/dal3.h, DAL3_BCN_*). 0 in normal use; A/B measurements and the
 # tests that pin "both kernel families give the same bits" set it around a call (binding-side, the library has no switch).
 DISPATCH_FLAGS = 0

@@ -495,7 +495,7 @@ static int check_bcn(const dal3_bcn& t, const char* what) {
     if (t.dtype != DAL3_F32 && t.dtype != DAL3_BF16 && t.dtype != DAL3_F16)
         return fail(DAL3_EINVAL, "%s: storage dtype %d is none of DAL3_F32 / DAL3_BF16 / DAL3_F16", what, t.dtype);
     if (t.dtype != DAL3_F32 && (reinterpret_cast<uintptr_t>(t.data) & 1)) return fail(DAL3_EINVAL, "%s: 16-bit data must be 2-byte aligned", what);
-    if (t.flags & ~(DAL3_BCN_NO_SMALL_JOB_KERNELS | DAL3_BCN_NO_WORKLIST)) return fail(DAL3_EINVAL, "%s: unknown bits in flags (%d)", what, t.flags);
+    if (t.flags & ~(DAL3_BCN_NO_SMALL_JOB_KERNELS | DAL3_BCN_NO_WORKLIST | DAL3_BCN_NO_LDS_SAMPLER)) return fail(DAL3_EINVAL, "%s: unknown bits in flags (%d)", what, t.flags);
     return 0;
 }
 

@@ -555,6 +555,143 @@ __global__ __launch_bounds__(256) void compact_sample_kernel(const uint8_t* __re
     }
 }
 
+// The same, for items whose positions and hash keys fit the LDS (N <= CS_LDS_MAX_N: every BASELINE shape — 1024, 4096,
+// 5 x 1024 points). Round 6: at small batches the kernel above is a chain of ~150 barriers per item (a block scan per
+// 256 mask bytes, six passes that each recompute the 64-bit hash of every segmented point, a two-scan output pass per
+// 256 candidates, positions bounced through global memory): 34-42 us for 64-128 dynamic items, 7-9 % of a 16-bit step.
+// Here a thread owns a CONTIGUOUS piece of the mask (its flags in one register), ONE block scan orders the positions
+// into LDS, the keys are hashed once into LDS, the radix select reads them there, and the output pass is one more
+// block scan over contiguous pieces of the candidates. Same definition, same order of obj_idx: bit-identical outputs
+// (tests/test_gpu_parity.py runs both kernels on the same masks: DAL3_BCN_NO_LDS_SAMPLER in the view's flags selects
+// the kernel above).
+#define CS_LDS_MAX_N 7936
+
+// exclusive prefix of v over the 256 threads (thread order) and the block total; lds_wave: 4 ints
+__device__ __forceinline__ int block_scan_int(int v, int* total, int* lds_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int cum = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(cum, off);
+        if (lane >= off) cum += up;
+    }
+    __syncthreads();                                        // lds_wave reuse
+    if (lane == 63) lds_wave[wave] = cum;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) {
+        const int c = lds_wave[wv];
+        base += wv < wave ? c : 0;
+        tot += c;
+    }
+    *total = tot;
+    return base + cum - v;
+}
+
+__global__ __launch_bounds__(256) void compact_sample_lds_kernel(const uint8_t* __restrict__ mask, BCN pts, int N, int C, int M,
+                                                                 int sampler, const int32_t* __restrict__ choice, uint64_t seed,
+                                                                 int64_t item_offset, const int64_t* __restrict__ step,
+                                                                 int32_t* __restrict__ counts, int32_t* __restrict__ obj_idx,
+                                                                 float* __restrict__ obj_pts) {
+    extern __shared__ int cs_smem[];                        // pos[N] | key[N]
+    int* s_pos = cs_smem;
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(cs_smem + N);
+    __shared__ int lds_wave[8];
+    __shared__ int lds_hist[256];
+    if (step) seed += (uint64_t)(*step) * 0xD6E8FEB86659FD93ull;
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    int32_t* idx_b = obj_idx + b * M;
+    // 1. ordered compaction: thread t owns the mask bytes [t * chunk, (t + 1) * chunk), chunk <= 31
+    const int chunk = (N + 255) / 256;
+    const int i0 = tid * chunk;
+    uint32_t bits = 0;
+    {
+        const uint8_t* mb = mask + b * N;
+        for (int j = 0; j < chunk; ++j) {
+            const int i = i0 + j;
+            bits |= (i < N && mb[i]) ? (1u << j) : 0u;
+        }
+    }
+    int count;
+    int p = block_scan_int(__popc(bits), &count, lds_wave);
+    for (uint32_t m = bits; m; m &= m - 1) s_pos[p++] = i0 + (__ffs((int)m) - 1);
+    if (tid == 0) counts[b] = count;
+    __syncthreads();                                        // s_pos complete
+
+    if (count == 0) {
+        for (int k = tid; k < M; k += 256) idx_b[k] = 0;
+        for (int k = tid; k < M * C; k += 256) obj_pts[b * M * C + k] = 0.0f;
+        return;
+    }
+    if (sampler == DAL3_SAMPLER_CHOICE) {
+        for (int k = tid; k < M; k += 256) {
+            int c = choice[b * M + k];
+            c = c < 0 ? 0 : (c >= count ? count - 1 : c);
+            idx_b[k] = s_pos[c];
+        }
+    } else if (count < M) {
+        for (int k = tid; k < M; k += 256) idx_b[k] = s_pos[k % count];
+    } else {
+        const uint64_t item = (uint64_t)(item_offset + b);
+        for (int i = tid; i < count; i += 256) s_key[i] = hash_key(seed, item, (uint32_t)i);
+        // thr = the M-th smallest key: four radix rounds of one byte each over the keys that match the prefix so far
+        uint32_t prefix = 0;
+        int remaining = M;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            __syncthreads();                                // s_key complete (first round) / lds_hist, lds_wave reuse
+            lds_hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < count; i += 256) {
+                const uint32_t key = s_key[i];
+                if (shift == 24 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&lds_hist[(key >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            const int h = lds_hist[tid];
+            int tot;
+            const int before = block_scan_int(h, &tot, lds_wave);
+            if (before < remaining && before + h >= remaining) {   // exactly one thread
+                lds_wave[4] = tid;
+                lds_wave[5] = before;
+            }
+            __syncthreads();
+            prefix |= (uint32_t)lds_wave[4] << shift;
+            remaining -= lds_wave[5];
+        }
+        const uint32_t thr = prefix;
+        // output: the keys below thr in index order, then the first (M - n_less) ties in index order. Thread t owns the
+        // candidates [t * cc, (t + 1) * cc); one scan carries both counts (count <= 7936 < 2^16)
+        const int cc = (count + 255) / 256;
+        const int j0 = tid * cc, j1 = min(count, j0 + cc);
+        int nl = 0, nt = 0;
+        for (int i = j0; i < j1; ++i) {
+            const uint32_t key = s_key[i];
+            nl += key < thr ? 1 : 0;
+            nt += key == thr ? 1 : 0;
+        }
+        int tot;
+        const int pre = block_scan_int(nl | (nt << 16), &tot, lds_wave);
+        int pl = pre & 0xffff, pt = pre >> 16;
+        const int n_less = tot & 0xffff, need = M - n_less;
+        for (int i = j0; i < j1; ++i) {
+            const uint32_t key = s_key[i];
+            if (key < thr) idx_b[pl++] = s_pos[i];
+            else if (key == thr) {
+                if (pt < need) idx_b[n_less + pt] = s_pos[i];
+                ++pt;
+            }
+        }
+    }
+    __syncthreads();
+    __threadfence_block();
+    for (int k = tid; k < M; k += 256) {
+        const int n = idx_b[k];
+        const int64_t o = b * pts.sb + (int64_t)n * pts.sn;
+        for (int c = 0; c < C; ++c) obj_pts[(b * M + k) * C + c] = bcn_value(pts, o + c * pts.sc);   // (16-bit points: widened here)
+    }
+}
+
 // Zero-fill as a KERNEL, not hipMemsetAsync: on ROCm 7.0 a memset node of a captured hipGraph does not keep its
 // fill value reliably — after other work on the process (a larger eager launch, a big allocation) replays of the graph
 // filled the max-pool accumulators with an arbitrary 32-bit pattern instead of 0 (tools/dbg_graph.py: about half of
@@ -651,6 +788,14 @@ hipError_t launch_segment_counts(const uint8_t* mask, int B, int N, int32_t* cou
 hipError_t launch_compact_sample(const uint8_t* mask, BCN pts, int B, int N, int C, int M, int sampler,
                                  const int32_t* choice, uint64_t seed, int64_t item_offset, int32_t* counts,
                                  int32_t* pos, int32_t* obj_idx, float* obj_pts, hipStream_t s, const int64_t* step) {
+#ifndef DAL3_CS_LDS
+#define DAL3_CS_LDS 1
+#endif
+    if (DAL3_CS_LDS && N <= CS_LDS_MAX_N && !(pts.flags & DAL3_BCN_NO_LDS_SAMPLER)) {                 // positions + keys in LDS (8 N bytes <= 62 KiB: no attribute needed)
+        hipLaunchKernelGGL(compact_sample_lds_kernel, dim3(B), dim3(256), (size_t)N * 8, s, mask, pts, N, C, M, sampler, choice,
+                           seed, item_offset, step, counts, obj_idx, obj_pts);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(compact_sample_kernel, dim3(B), dim3(256), 0, s, mask, pts, N, C, M, sampler, choice, seed,
                        item_offset, step, counts, pos, obj_idx, obj_pts);
     return hipGetLastError();

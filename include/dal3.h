@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dal3_stream;               /* hipStream_t */
 
-#define DAL3_VERSION 150                 /* 0.1.5: dal3_crop_starts_capped; upper bounds on B, N (DAL3_MAX_*); 0.1.4: dal3_crop_starts, dal3_crop_fill takes out_capacity; 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums; .1: dal3_tr_fc_*, dal3_tr_wgrad_final_many, dal3_parse_box_pred* */
+#define DAL3_VERSION 150                 /* 0.1.5: dal3_crop_starts_capped; upper bounds on B, N (DAL3_MAX_*); DAL3_BCN_NO_LDS_SAMPLER; 0.1.4: dal3_crop_starts, dal3_crop_fill takes out_capacity; 0.1.3: dal3_bcn.flags (DAL3_BCN_*); dal3_tr_linear_bn_stats / dal3_tr_linear_bnbwd_sums; .1: dal3_tr_fc_*, dal3_tr_wgrad_final_many, dal3_parse_box_pred* */
 
 enum {
     DAL3_OK = 0,
@@ -122,7 +122,7 @@ typedef struct {
     int32_t dtype;
     int32_t flags;                       /* MUST be 0 or a mask of DAL3_BCN_* (was `reserved` before 0.1.3: a caller that never
                                           * zeroed it now gets DAL3_EINVAL for unknown bits, or a different — bit-identical
-                                          * — kernel family for bits 1 / 2; zero-initialise the struct) */
+                                          * — kernel family for bits 1 / 2 / 4; zero-initialise the struct) */
 } dal3_bcn;
 
 /* Per-call dispatch hints (dal3_bcn.flags; dal3_static_args / dal3_dynamic_args take them from args.pts.flags for every
@@ -130,8 +130,10 @@ typedef struct {
  * reads no environment variable and keeps no process-wide switch. Results are bit-identical either way; the bits exist
  * for A/B measurements and for the tests that pin that identity (tests/test_gpu_latency.py, test_gpu_parity.py).
  *   DAL3_BCN_NO_SMALL_JOB_KERNELS  never the small-job ("latency") family (jobs of <= 512 tiles of 32 points)
- *   DAL3_BCN_NO_WORKLIST           point heads: one workgroup per (item, tile) instead of the live-tile worklist */
-enum { DAL3_BCN_NO_SMALL_JOB_KERNELS = 1, DAL3_BCN_NO_WORKLIST = 2 };
+ *   DAL3_BCN_NO_WORKLIST           point heads: one workgroup per (item, tile) instead of the live-tile worklist
+ *   DAL3_BCN_NO_LDS_SAMPLER        mask compaction + sampling: positions through global memory, keys recomputed per
+ *                                  pass (what items of more than 7936 points always take) instead of both in LDS */
+enum { DAL3_BCN_NO_SMALL_JOB_KERNELS = 1, DAL3_BCN_NO_WORKLIST = 2, DAL3_BCN_NO_LDS_SAMPLER = 4 };
 
 /* ---- PointNetInstanceSeg.forward (static_model.py:271-296, dynamic_model.py:187-212) plus
  * the mask of point_cloud_masking (static_model.py:59). logits (B,N,2) fp32, mask (B,N) u8.

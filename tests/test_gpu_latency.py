@@ -61,7 +61,7 @@ def test_latency_family_equals_throughput_family_bitwise():
 def test_unknown_dispatch_flag_bits_are_rejected():
     p, _, _ = synth.static_crops(1, 64, seed=1)
     v = hip.bcn(torch.from_numpy(p).cuda().transpose(2, 1))
-    v.flags = 4
+    v.flags = 8
     g = torch.zeros((1, 1024), device="cuda")
     assert hip.lib().dal3_ins_seg_encode(hip.ptr(g), hip.F32, 3, v, 1, 64, hip.ptr(g), hip.stream()) == hip.EINVAL
     assert b"flags" in hip.lib().dal3_last_error()

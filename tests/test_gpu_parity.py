@@ -227,6 +227,45 @@ def test_gather_device_sampler_is_uniform():
     assert abs(freq.mean() - 0.5) < 1e-9 and freq.std() < 0.04 and freq.min() > 0.35 and freq.max() < 0.65
 
 
+@pytest.mark.parametrize("N,M,C", [(1024, 512, 3), (4096, 512, 3), (5120, 2560, 4), (700, 512, 3), (33, 512, 3), (7936, 512, 3),
+                                   (7937, 512, 3), (300, 101, 8)])
+def test_the_lds_sampler_equals_the_global_memory_sampler_bitwise(N, M, C):
+    """round 6: items of up to 7936 points are compacted and sampled with their positions and hash keys in LDS (one block
+    scan over contiguous pieces instead of one per 256 mask bytes, keys hashed once); DAL3_BCN_NO_LDS_SAMPLER selects the
+    original kernel. Same definition, same order: counts, indices and gathered points must agree bit for bit — masks of
+    every density incl. empty, a single point, count == M - 1 / M / M + 1 and all points; the device sampler with two seeds
+    and an item offset, and the CHOICE sampler; N = 7937 takes the original kernel either way (the dispatch edge)."""
+    rng = np.random.default_rng(N * 31 + M)
+    B = 24
+    dens = rng.random(B)
+    mask = rng.random((B, N)) < dens[:, None]
+    mask[0] = False
+    mask[1] = False
+    mask[1, N // 2] = True
+    mask[2] = True
+    for row, k in ((3, M - 1), (4, M), (5, M + 1)):
+        mask[row] = False
+        if 0 < k <= N:
+            mask[row, rng.permutation(N)[:k]] = True
+    pts_np = rng.standard_normal((B, N, C)).astype(np.float32)
+    pts = dev(pts_np).transpose(2, 1)
+    choice = rng.integers(-3, N + 5, size=(B, M))
+    for sampler, kw in ((hip.SAMPLER_DEVICE, dict(seed=42)), (hip.SAMPLER_DEVICE, dict(seed=10922081, item_offset=1000)),
+                        (hip.SAMPLER_CHOICE, dict(choice=choice))):
+        got = _gather(mask, pts, M, sampler, **kw)
+        hip.DISPATCH_FLAGS = hip.BCN_NO_LDS_SAMPLER
+        try:
+            want = _gather(mask, pts, M, sampler, **kw)
+        finally:
+            hip.DISPATCH_FLAGS = 0
+        for a, b, name in zip(got, want, ("counts", "obj_idx", "obj_pts")):
+            assert np.array_equal(a, b), (name, sampler, N)
+        assert np.array_equal(got[0], mask.sum(1))
+        assert (got[1] >= 0).all() and (got[1] < N).all()
+        live = got[0] > 0
+        assert np.array_equal(got[2][live], np.stack([pts_np[r][got[1][r]] for r in np.nonzero(live)[0]]))
+
+
 # ------------------------------------------------------------------------------- full models
 ONE_KEYS = ["logits", "center_boxnet", "heading_scores", "heading_residuals_normalized",
             "heading_residuals", "size_scores", "size_residuals_normalized", "size_residuals", "center"]
