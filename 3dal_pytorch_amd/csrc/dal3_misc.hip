@@ -589,14 +589,16 @@ __device__ __forceinline__ int block_scan_int(int v, int* total, int* lds_wave) 
     return base + cum - v;
 }
 
+template <int CT>                                           // CT: channels per point at compile time (3, 4, 8), 0 = any
 __global__ __launch_bounds__(256) void compact_sample_lds_kernel(const uint8_t* __restrict__ mask, BCN pts, int N, int C, int M,
                                                                  int sampler, const int32_t* __restrict__ choice, uint64_t seed,
                                                                  int64_t item_offset, const int64_t* __restrict__ step,
                                                                  int32_t* __restrict__ counts, int32_t* __restrict__ obj_idx,
                                                                  float* __restrict__ obj_pts) {
-    extern __shared__ int cs_smem[];                        // pos[N] | key[N]
+    extern __shared__ int cs_smem[];                        // pos[N] | key[N] | idx[M]
     int* s_pos = cs_smem;
     uint32_t* s_key = reinterpret_cast<uint32_t*>(cs_smem + N);
+    int* s_idx = cs_smem + 2 * N;                           // the chosen indices stay here for the gather (no global round trip)
     __shared__ int lds_wave[8];
     __shared__ int lds_hist[256];
     if (step) seed += (uint64_t)(*step) * 0xD6E8FEB86659FD93ull;
@@ -629,10 +631,10 @@ __global__ __launch_bounds__(256) void compact_sample_lds_kernel(const uint8_t* 
         for (int k = tid; k < M; k += 256) {
             int c = choice[b * M + k];
             c = c < 0 ? 0 : (c >= count ? count - 1 : c);
-            idx_b[k] = s_pos[c];
+            s_idx[k] = s_pos[c];
         }
     } else if (count < M) {
-        for (int k = tid; k < M; k += 256) idx_b[k] = s_pos[k % count];
+        for (int k = tid; k < M; k += 256) s_idx[k] = s_pos[k % count];
     } else {
         const uint64_t item = (uint64_t)(item_offset + b);
         for (int i = tid; i < count; i += 256) s_key[i] = hash_key(seed, item, (uint32_t)i);
@@ -676,19 +678,51 @@ __global__ __launch_bounds__(256) void compact_sample_lds_kernel(const uint8_t* 
         const int n_less = tot & 0xffff, need = M - n_less;
         for (int i = j0; i < j1; ++i) {
             const uint32_t key = s_key[i];
-            if (key < thr) idx_b[pl++] = s_pos[i];
+            if (key < thr) s_idx[pl++] = s_pos[i];
             else if (key == thr) {
-                if (pt < need) idx_b[n_less + pt] = s_pos[i];
+                if (pt < need) s_idx[n_less + pt] = s_pos[i];
                 ++pt;
             }
         }
     }
-    __syncthreads();
-    __threadfence_block();
-    for (int k = tid; k < M; k += 256) {
-        const int n = idx_b[k];
-        const int64_t o = b * pts.sb + (int64_t)n * pts.sn;
-        for (int c = 0; c < C; ++c) obj_pts[(b * M + k) * C + c] = bcn_value(pts, o + c * pts.sc);   // (16-bit points: widened here)
+    __syncthreads();                                        // s_idx complete
+    // gather, four points per thread in flight (a dependent index -> point chain each: one at a time this loop was most of
+    // the kernel at M = 2560)
+    constexpr int U = 4;
+    const int Cn = CT ? CT : C;
+    for (int k0 = tid; k0 < M; k0 += 256 * U) {
+        int n[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 256 * u;
+            n[u] = s_idx[k < M ? k : 0];               // (past the end: a valid index, its point is loaded and dropped)
+            if (k < M) idx_b[k] = n[u];
+        }
+        if (CT) {
+            float v[U][CT ? CT : 1];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t o = b * pts.sb + (int64_t)n[u] * pts.sn;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) v[u][c] = bcn_value(pts, o + c * pts.sc);   // (16-bit points: widened here)
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 256 * u;
+                if (k < M) {
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) obj_pts[(b * M + k) * CT + c] = v[u][c];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 256 * u;
+                if (k >= M) continue;
+                const int64_t o = b * pts.sb + (int64_t)n[u] * pts.sn;
+                for (int c = 0; c < Cn; ++c) obj_pts[(b * M + k) * Cn + c] = bcn_value(pts, o + c * pts.sc);
+            }
+        }
     }
 }
 
@@ -791,9 +825,15 @@ hipError_t launch_compact_sample(const uint8_t* mask, BCN pts, int B, int N, int
 #ifndef DAL3_CS_LDS
 #define DAL3_CS_LDS 1
 #endif
-    if (DAL3_CS_LDS && N <= CS_LDS_MAX_N && !(pts.flags & DAL3_BCN_NO_LDS_SAMPLER)) {                 // positions + keys in LDS (8 N bytes <= 62 KiB: no attribute needed)
-        hipLaunchKernelGGL(compact_sample_lds_kernel, dim3(B), dim3(256), (size_t)N * 8, s, mask, pts, N, C, M, sampler, choice,
-                           seed, item_offset, step, counts, obj_idx, obj_pts);
+    const size_t lds = (size_t)N * 8 + (size_t)M * 4;      // positions + keys + chosen indices (<= 62 KiB: no attribute needed)
+    if (DAL3_CS_LDS && N <= CS_LDS_MAX_N && lds <= 62 * 1024 && !(pts.flags & DAL3_BCN_NO_LDS_SAMPLER)) {
+#define CS_GO(CT) hipLaunchKernelGGL(compact_sample_lds_kernel<CT>, dim3(B), dim3(256), lds, s, mask, pts, N, C, M, sampler, choice, \
+                                     seed, item_offset, step, counts, obj_idx, obj_pts)
+        if (C == 3) CS_GO(3);
+        else if (C == 4) CS_GO(4);
+        else if (C == 8) CS_GO(8);
+        else CS_GO(0);
+#undef CS_GO
         return hipGetLastError();
     }
     hipLaunchKernelGGL(compact_sample_kernel, dim3(B), dim3(256), 0, s, mask, pts, N, C, M, sampler, choice, seed,
