@@ -787,7 +787,37 @@ __global__ __launch_bounds__(256) void nonfinite_rows_kernel(BCN x, int n_pts, i
     bool bad = false;
     const int total = n_pts * c_in;
     if (x.sc == 1 && x.sn == c_in) {                        // point-major storage: the item is one contiguous run
-        for (int i = threadIdx.x; i < total; i += 256) bad |= bits_nonfinite(bcn_value(x, base + i));
+        // round 6: 16 bytes per thread and trip where the run allows (an exponent of all ones on the raw bits: NaN or
+        // +-Inf in fp32 / bf16 / fp16 alike), four trips' loads in flight; one element per trip made this fill 12-26 us
+        // for a 5120-point item — 80 dependent-free but un-unrolled scalar loads per thread
+        const int es = x.dtype == 0 ? 4 : 2;               // bytes per stored element
+        const char* p0 = reinterpret_cast<const char*>(x.data) + base * es;
+        const int bytes = total * es;
+        int done = 0;
+        if ((reinterpret_cast<uintptr_t>(p0) & 15) == 0) {
+            const uint4* v4 = reinterpret_cast<const uint4*>(p0);
+            const int n16 = bytes >> 4;
+            const uint32_t m32 = x.dtype == 0 ? 0x7F800000u : (x.dtype == 1 ? 0x7F807F80u : 0x7C007C00u);
+            auto word_bad = [&](uint32_t w) {
+                if (x.dtype == 0) return (w & m32) == m32;
+                const uint32_t lo = m32 & 0xffffu, a = w & m32;
+                return (a & 0xffffu) == lo || (a >> 16) == lo;
+            };
+            int i = threadIdx.x;
+            for (; i + 768 < n16; i += 1024) {
+                uint4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = v4[i + 256 * u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bad |= word_bad(q[u].x) | word_bad(q[u].y) | word_bad(q[u].z) | word_bad(q[u].w);
+            }
+            for (; i < n16; i += 256) {
+                const uint4 q = v4[i];
+                bad |= word_bad(q.x) | word_bad(q.y) | word_bad(q.z) | word_bad(q.w);
+            }
+            done = (n16 << 4) / es;
+        }
+        for (int i = done + threadIdx.x; i < total; i += 256) bad |= bits_nonfinite(bcn_value(x, base + i));
     } else {
         for (int i = threadIdx.x; i < total; i += 256) {
             const int n = i / c_in, c = i - n * c_in;
