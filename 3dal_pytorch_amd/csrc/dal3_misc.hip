@@ -366,7 +366,7 @@ hipError_t launch_maxpool_n(const void* x, int dtype, int64_t rows, int64_t n, v
     // little per wave to hide its butterfly and store behind), as many workgroups as that takes: with the grid capped
     // at 16 workgroups per CU (waves walking 256 rows each) the fp32 kernel read 6.5 TB/s, uncapped 7.1 (one box,
     // (4096, 1024, 1024) fp32) — a wave's next row starts behind its butterfly and store, a fresh wave's loads do not.
-    // (Two fp32 rows per wave: 6.9 in the same process; plain instead of non-temporal loads: 6.5. tools/ab_maxpool.py)
+    // (Two fp32 rows per wave: 6.9 in the same process; plain instead of non-temporal loads: 6.5; a one-off A/B script of round 3, since deleted)
     const int per16 = dtype == DAL3_F32 ? 4 : 8;
     const bool vec = (n % per16 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const int R = dtype == DAL3_F32 ? 1 : 2;
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void compact_sample_lds_kernel(const uint8_t* 
 
 // Zero-fill as a KERNEL, not hipMemsetAsync: on ROCm 7.0 a memset node of a captured hipGraph does not keep its
 // fill value reliably — after other work on the process (a larger eager launch, a big allocation) replays of the graph
-// filled the max-pool accumulators with an arbitrary 32-bit pattern instead of 0 (tools/dbg_graph.py: about half of
+// filled the max-pool accumulators with an arbitrary 32-bit pattern instead of 0 (a one-off reproducer of round 2, since deleted: about half of
 // the processes, persistent until the graph is recorded again; torch-only graphs and eager calls were never affected).
 // A kernel node carries its arguments by value. n_words 32-bit words, 16-byte aligned pointers take the wide path.
 __global__ __launch_bounds__(256) void fill_words_kernel(uint32_t* __restrict__ p, size_t n_words, uint32_t value) {

@@ -2,7 +2,7 @@
 torch autograd over the stock-torch composite of the same modules, evaluated in FLOAT64 (the composite is what the
 train drivers ran before; tests/test_host_cpu.py ties it to the oracle). Tolerance: 1e-4 of each tensor's largest
 entry, for outputs, running statistics and every parameter gradient. For scale: the same composite in fp32
-through stock PyTorch-ROCm ops is 2e-4 .. 1e-3 away from the float64 gradients (tools/dbg_train.py); the HIP path
+through stock PyTorch-ROCm ops is 2e-4 .. 1e-3 away from the float64 gradients (a one-off script of round 2, since deleted); the HIP path
 (exact-fp32 MFMA, float64 batch statistics) is ~1e-5 away."""
 import copy
 import importlib
@@ -349,7 +349,7 @@ def test_whole_train_step_hip_backend_vs_torch_backend(kind, B):
     if not torch.equal(out["hip"][3], out["torch"][3]):
         # a logit pair within fp32 rounding of a tie flipped the segmentation of a point: the object points then
         # differ and the runs are no longer comparable term by term (dynamic B=32, and B=3 where the STOCK fp32 run is
-        # the one that leaves the float64 mask: one point with a logit gap of 8e-5, tools/dbg_mask_flip.py)
+        # the one that leaves the float64 mask: one point with a logit gap of 8e-5; found with a one-off script, since deleted)
         assert float((out["hip"][3] != out["torch"][3]).float().mean()) < (1e-4 if B >= 32 else 5e-4)
         assert abs(out["hip"][0] - out["torch"][0]) <= 2e-2 * abs(out["torch"][0])
         return
